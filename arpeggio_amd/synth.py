@@ -1,0 +1,318 @@
+"""Deterministic synthetic PackedComplex generators (BASELINE.json configs 2-5).
+
+The reference ships no input files or fixtures, so every workload
+here is generated from a counter-based splitmix64 stream: the same (seed, index)
+gives the same value on every machine, independent of NumPy's RNG.
+
+Nothing here is on the hot path; it only manufactures what
+``InteractionComplex.initialize()`` (interactions.py:288-327) would leave behind.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .core import config
+from .core.packed import PackedComplex
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed: int, idx) -> np.ndarray:
+    """splitmix64 of (seed + (idx+1) * golden gamma); idx is an integer array."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def u01(seed: int, stream: int, idx) -> np.ndarray:
+    """Uniform [0,1) with 24 random bits (exactly representable in float32)."""
+    s = (seed * 0x1000003 + stream * 0x632BE5AB) & 0xFFFFFFFFFFFFFFFF
+    return (splitmix64(s, idx) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def _unit_vectors(seed, stream, idx):
+    """Uniform unit vectors (float64) from two uniforms."""
+    z = 2.0 * u01(seed, stream, idx) - 1.0
+    phi = 2.0 * np.pi * u01(seed, stream + 1, idx)
+    r = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+    return np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
+
+
+def _rotation_matrices(seed, stream, idx):
+    """Random rotations: columns (e1, e2, e3) orthonormal, float64 [K,3,3]."""
+    e3 = _unit_vectors(seed, stream, idx)
+    t = _unit_vectors(seed, stream + 2, idx)
+    e1 = np.cross(e3, t)
+    nrm = np.linalg.norm(e1, axis=1, keepdims=True)
+    bad = nrm[:, 0] < 1e-6
+    if np.any(bad):
+        e1[bad] = np.cross(e3[bad], np.array([1.0, 0.0, 0.0]))
+        nrm = np.linalg.norm(e1, axis=1, keepdims=True)
+    e1 /= nrm
+    e2 = np.cross(e3, e1)
+    return np.stack([e1, e2, e3], axis=2)
+
+
+# element table: (symbol, cdf weight, vdw, cov) — radii are OpenBabel-style element
+# table values (synthetic constants here; the real ones come from I:1501,1509)
+_ELEMENTS = [
+    ('C', 0.62, 1.70, 0.76),
+    ('N', 0.17, 1.55, 0.71),
+    ('O', 0.19, 1.52, 0.66),
+    ('S', 0.01, 1.80, 1.05),
+    ('CL', 0.005, 1.75, 1.02),
+    ('ZN', 0.005, 1.39, 1.22),
+]
+_EL_C, _EL_N, _EL_O, _EL_S, _EL_CL, _EL_ZN = range(6)
+
+T = config.ATOM_TYPE_BIT
+
+
+def _close_pairs(xyz32, radius):
+    """All pairs (i<j) with float64 distance < radius; sorted, deterministic."""
+    from scipy.spatial import cKDTree
+    if xyz32.shape[0] < 2:
+        return np.zeros((0, 2), np.int64)
+    tree = cKDTree(xyz32.astype(np.float64))
+    pairs = tree.query_pairs(radius, output_type='ndarray')
+    if pairs.size == 0:
+        return np.zeros((0, 2), np.int64)
+    pairs = np.sort(pairs, axis=1)
+    order = np.lexsort((pairs[:, 1], pairs[:, 0]))
+    return pairs[order].astype(np.int64)
+
+
+def make_synthetic(n_uniform: int, seed: int = 3, density: float = 0.05, box=None,
+                   origin=(0.0, 0.0, 0.0), n_rings: int = 0, n_amides: int = 0,
+                   water_frac: float = 0.05, bond_radius: float = 1.7,
+                   atoms_per_residue: int = 8, residues_per_chain: int = 300,
+                   id: str = 'synthetic') -> PackedComplex:
+    """Uniform random atoms (+ optional hexagonal rings and amide groups) in a box.
+
+    box: (Lx, Ly, Lz) in Angstrom; default = cube with n_total / density volume.
+    Config 3 = make_synthetic(100_000 - ring/amide atoms, seed=3, ...) with L=126.
+    """
+    n_ring_atoms, n_amide_atoms = 6 * n_rings, 4 * n_amides
+    n = n_uniform + n_ring_atoms + n_amide_atoms
+    if box is None:
+        L = (max(n, 1) / density) ** (1.0 / 3.0)
+        box = (L, L, L)
+    box = np.asarray(box, dtype=np.float64)
+    origin = np.asarray(origin, dtype=np.float64)
+    idx = np.arange(n_uniform, dtype=np.uint64)
+
+    # ---------------- uniform atoms ----------------
+    xyz_u = np.stack([u01(seed, 10 + a, idx) * box[a] + origin[a] for a in range(3)], axis=1).astype(np.float32)
+    is_water = u01(seed, 20, idx) < water_frac
+    ue = u01(seed, 21, idx)
+    cdf = np.cumsum([e[1] for e in _ELEMENTS])
+    cdf[-1] = 1.0 + 1e-9
+    elem_u = np.searchsorted(cdf, ue, side='right').astype(np.int64)
+    elem_u[is_water] = _EL_O
+
+    def p(stream):
+        return u01(seed, stream, idx)
+
+    tm = np.zeros(n_uniform, np.uint32)
+    o, nn, c, s_, cl = (elem_u == _EL_O), (elem_u == _EL_N), (elem_u == _EL_C), (elem_u == _EL_S), (elem_u == _EL_CL)
+    acc = (o & (p(30) < 0.9)) | (nn & (p(30) < 0.2)) | (s_ & (p(30) < 0.3))
+    don = (o & (p(31) < 0.3)) | (nn & (p(31) < 0.7))
+    tm[acc] |= T['hbond acceptor'] | T['weak hbond acceptor']
+    tm[acc & (p(32) < 0.9)] |= T['xbond acceptor']
+    tm[don] |= T['hbond donor']
+    tm[o & (p(33) < 0.5)] |= T['carbonyl oxygen']
+    tm[o & (p(34) < 0.1)] |= T['neg ionisable']
+    tm[nn & (p(34) < 0.1)] |= T['pos ionisable']
+    wdon = c & (p(35) < 0.6)
+    tm[wdon] |= T['weak hbond donor']
+    tm[(c & (p(36) < 0.4)) | (s_ & (p(36) < 0.5)) | (cl & (p(36) < 0.5))] |= T['hydrophobe']
+    tm[c & (p(37) < 0.15)] |= T['aromatic']
+    tm[c & (p(38) < 0.2)] |= T['carbonyl carbon']
+    tm[cl] |= T['weak hbond acceptor']
+    # waters are donors and acceptors (interactions.py:1953-1956)
+    tm[is_water] = T['hbond acceptor'] | T['hbond donor']
+
+    # residues of the uniform block: runs of `atoms_per_residue` non-water atoms, then waters
+    prot = ~is_water
+    ordinal = np.cumsum(prot) - 1
+    n_prot_res = int((int(prot.sum()) + atoms_per_residue - 1) // atoms_per_residue)
+    res_u = np.where(prot, ordinal // atoms_per_residue, n_prot_res + np.cumsum(is_water) - 1).astype(np.int64)
+    n_wat = int(is_water.sum())
+    nres_u = n_prot_res + n_wat
+
+    # ---------------- rings: regular hexagons, radius 1.39 ----------------
+    ridx = np.arange(n_rings, dtype=np.uint64)
+    rc = np.stack([u01(seed, 50 + a, ridx) * box[a] + origin[a] for a in range(3)], axis=1)
+    rrot = _rotation_matrices(seed, 53, ridx)
+    ang = np.arange(6) * (np.pi / 3.0)
+    hexa = 1.39 * (np.cos(ang)[None, :, None] * rrot[:, None, :, 0] + np.sin(ang)[None, :, None] * rrot[:, None, :, 1])
+    xyz_r = (rc[:, None, :] + hexa).reshape(-1, 3).astype(np.float32)
+
+    # ---------------- amides: N, C, O, CA planar ----------------
+    aidx = np.arange(n_amides, dtype=np.uint64)
+    ac = np.stack([u01(seed, 60 + a, aidx) * box[a] + origin[a] for a in range(3)], axis=1)
+    arot = _rotation_matrices(seed, 63, aidx)
+    local = np.array([[1.33 * np.cos(np.deg2rad(120.0)), 1.33 * np.sin(np.deg2rad(120.0))],   # N
+                      [0.0, 0.0],                                                                # C
+                      [1.23 * np.cos(np.deg2rad(-120.0)), 1.23 * np.sin(np.deg2rad(-120.0))],  # O
+                      [1.52, 0.0]])                                                              # CA
+    am = local[None, :, 0, None] * arot[:, None, :, 0] + local[None, :, 1, None] * arot[:, None, :, 1]
+    xyz_a = (ac[:, None, :] + am).reshape(-1, 3).astype(np.float32)
+
+    # ---------------- assemble atoms ----------------
+    xyz = np.concatenate([xyz_u, xyz_r, xyz_a], axis=0) if n else np.zeros((0, 3), np.float32)
+    elem = np.concatenate([elem_u, np.full(n_ring_atoms, _EL_C), np.tile([_EL_N, _EL_C, _EL_O, _EL_C], n_amides)]).astype(np.int64)
+    tmask = np.concatenate([
+        tm,
+        np.full(n_ring_atoms, T['aromatic'] | T['hydrophobe'], np.uint32),
+        np.tile(np.array([T['hbond donor'],
+                          T['carbonyl carbon'],
+                          T['hbond acceptor'] | T['weak hbond acceptor'] | T['xbond acceptor'] | T['carbonyl oxygen'],
+                          T['weak hbond donor']], np.uint32), n_amides),
+    ]).astype(np.uint16)
+    water_all = np.concatenate([is_water, np.zeros(n_ring_atoms + n_amide_atoms, bool)])
+    res_id = np.concatenate([res_u,
+                             nres_u + np.repeat(np.arange(n_rings), 6),
+                             nres_u + n_rings + np.repeat(np.arange(n_amides), 4)]).astype(np.int32)
+    nres = nres_u + n_rings + n_amides
+
+    vdw_t = np.array([e[2] for e in _ELEMENTS])
+    cov_t = np.array([e[3] for e in _ELEMENTS])
+    vdw, cov = vdw_t[elem], cov_t[elem]
+
+    flags = np.zeros(n, np.uint16)
+    flags[elem == _EL_ZN] |= config.F_METAL
+    flags[elem == _EL_CL] |= config.F_HALOGEN
+    flags[water_all] |= config.F_WATER
+    flags[elem == _EL_C] |= config.F_ELEM_C
+    flags[elem == _EL_S] |= config.F_ELEM_S
+
+    # residue table: protein-like residues are polypeptide with prev/next inside a chain
+    res_flags = np.zeros(nres, np.uint8)
+    res_prev = np.full(nres, -1, np.int32)
+    res_next = np.full(nres, -1, np.int32)
+    pr = np.arange(n_prot_res)
+    res_flags[:n_prot_res] = config.R_POLYPEPTIDE | config.R_HAS_SEQ
+    has_prev = (pr % residues_per_chain) != 0
+    res_prev[:n_prot_res][has_prev] = pr[has_prev] - 1
+    has_next = ((pr % residues_per_chain) != residues_per_chain - 1) & (pr + 1 < n_prot_res)
+    res_next[:n_prot_res][has_next] = pr[has_next] + 1
+    # 1 % of protein residues are "MET": mark their S atoms' residue flag
+    met = u01(seed, 70, np.arange(n_prot_res, dtype=np.uint64)) < 0.05
+    if n_uniform:
+        is_met_atom = np.zeros(n, bool)
+        is_met_atom[:n_uniform] = prot & met[np.minimum(res_u, max(n_prot_res - 1, 0))] if n_prot_res else False
+        flags[is_met_atom] |= config.F_RES_MET
+
+    # ---------------- bonds ----------------
+    bp = []
+    # ring bonds (aromatic) and amide bonds
+    if n_rings:
+        base = n_uniform + 6 * np.arange(n_rings)[:, None]
+        k = np.arange(6)[None, :]
+        bp.append(np.stack([(base + k).ravel(), (base + (k + 1) % 6).ravel()], axis=1))
+    if n_amides:
+        base = n_uniform + n_ring_atoms + 4 * np.arange(n_amides)
+        for a_, b_ in ((0, 1), (1, 2), (1, 3)):
+            bp.append(np.stack([base + a_, base + b_], axis=1))
+    # proximity bonds between any two atoms closer than bond_radius (inter-residue ones
+    # are what exercises the covalent branch, I:748-757)
+    bp.append(_close_pairs(xyz, bond_radius))
+    bp = np.concatenate(bp, axis=0) if bp else np.zeros((0, 2), np.int64)
+    if bp.size:
+        bp = np.unique(np.sort(bp, axis=1), axis=0)
+    both = np.concatenate([bp, bp[:, ::-1]], axis=0)
+    order = np.lexsort((both[:, 1], both[:, 0]))
+    both = both[order]
+    deg = np.bincount(both[:, 0], minlength=n) if n else np.zeros(0, np.int64)
+    bond_off = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    bond_idx = both[:, 1].astype(np.int32)
+
+    # single-bond heavy neighbour = first bonded atom (utils.py:612-635), -1 if none
+    sb_nbr = np.full(n, -1, np.int32)
+    has = deg > 0
+    sb_nbr[has] = bond_idx[bond_off[:-1][has]]
+    # xbond donors: bonded chlorines only (the reference dereferences None otherwise, U:173)
+    tmask[(elem == _EL_CL) & has] |= T['xbond donor']
+
+    # ---------------- hydrogens: donors / weak donors get 1-3 H at 1.0 A ----------------
+    aall = np.arange(n, dtype=np.uint64)
+    wants_h = (tmask & (T['hbond donor'] | T['weak hbond donor'])) != 0
+    nh = np.where(wants_h, 1 + (u01(seed, 80, aall) * 3).astype(np.int64), 0)
+    nh[water_all] = 2
+    h_off = np.concatenate([[0], np.cumsum(nh)]).astype(np.int32)
+    owner = np.repeat(np.arange(n), nh)
+    slot = np.arange(int(nh.sum())) - np.repeat(h_off[:-1], nh)
+    hdir = _unit_vectors(seed, 81, owner.astype(np.uint64) * np.uint64(4) + slot.astype(np.uint64))
+    h_xyz = xyz[owner].astype(np.float64) + 1.0 * hdir if owner.size else np.zeros((0, 3))
+
+    # ---------------- ring / amide geometry ----------------
+    if n_rings:
+        rp = xyz_r.astype(np.float64).reshape(n_rings, 6, 3)
+        ring_center = rp.mean(axis=1)
+        v = rp - ring_center[:, None, :]
+        nrm = np.cross(v, np.roll(v, -1, axis=1)).sum(axis=1)
+        ring_normal = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    else:
+        ring_center = np.zeros((0, 3)); ring_normal = np.zeros((0, 3))
+    ring_res = (nres_u + np.arange(n_rings)).astype(np.int32)
+    ring_atoms = [np.arange(n_uniform + 6 * r, n_uniform + 6 * r + 6, dtype=np.int32) for r in range(n_rings)]
+    if n_amides:
+        ap = xyz_a.reshape(n_amides, 4, 3)
+        amide_center = ((ap[:, 1, :] + ap[:, 0, :]) / np.float32(2.0)).astype(np.float32)   # mean(C, N), float32
+        nv = np.cross((ap[:, 2, :] - ap[:, 1, :]).astype(np.float64), (ap[:, 0, :] - ap[:, 1, :]).astype(np.float64))
+        amide_normal = (nv / np.linalg.norm(nv, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        amide_center = np.zeros((0, 3), np.float32); amide_normal = np.zeros((0, 3), np.float32)
+    amide_res = (nres_u + n_rings + np.arange(n_amides)).astype(np.int32)
+    amide_atoms = (n_uniform + n_ring_atoms + 4 * np.arange(n_amides)[:, None] + np.arange(4)[None, :]).astype(np.int32)
+
+    # ---------------- labels ----------------
+    sym = [e[0] for e in _ELEMENTS]
+    element = [sym[e] for e in elem.tolist()]
+    atom_name = ([f'{sym[e][0]}{i % 97}' for i, e in enumerate(elem_u.tolist())]
+                 + [f'C{k + 1}' for _ in range(n_rings) for k in range(6)]
+                 + ['N', 'C', 'O', 'CA'] * n_amides)
+    res_name = (['MET' if m else 'ALA' for m in met.tolist()] + ['HOH'] * n_wat + ['BNZ'] * n_rings + ['AMD'] * n_amides)
+    res_chain = ([chr(ord('A') + (r // residues_per_chain) % 26) for r in range(n_prot_res)]
+                 + ['W'] * n_wat + ['R'] * n_rings + ['G'] * n_amides)
+    res_seq = np.concatenate([pr % residues_per_chain + 1, np.arange(n_wat) + 1, np.arange(n_rings) + 1,
+                              np.arange(n_amides) + 1]).astype(np.int32)
+    comp = {'ALA': 'P', 'MET': 'P', 'HOH': 'W', 'BNZ': 'B', 'AMD': 'B'}
+
+    return PackedComplex(
+        xyz=xyz, vdw=vdw, cov=cov, type_mask=tmask, flags=flags, res_id=res_id,
+        res_flags=res_flags, res_prev=res_prev, res_next=res_next,
+        bond_off=bond_off, bond_idx=bond_idx, h_off=h_off, h_xyz=h_xyz, sb_nbr=sb_nbr,
+        ring_center=ring_center, ring_normal=ring_normal, ring_res=ring_res, ring_atoms=ring_atoms,
+        amide_center=amide_center, amide_normal=amide_normal, amide_res=amide_res, amide_atoms=amide_atoms,
+        atom_name=atom_name, element=element, serial=np.arange(1, n + 1, dtype=np.int32),
+        res_name=res_name, res_seq=res_seq, res_icode=[' '] * nres, res_chain=res_chain,
+        component_types=comp, id=id)
+
+
+def config3(n: int = 100_000, seed: int = 3) -> PackedComplex:
+    """BASELINE.json configs[2]: 100k random-coordinate atoms, rho = 0.05 / A^3 (L = 126 A)."""
+    n_rings, n_amides = n // 100, n // 50
+    L = (n / 0.05) ** (1.0 / 3.0)
+    return make_synthetic(n - 6 * n_rings - 4 * n_amides, seed=seed, box=(L, L, L), n_rings=n_rings,
+                          n_amides=n_amides, id=f'synthetic_{n}')
+
+
+def config5(n_rings: int = 10_000, n_amides: int = 10_000, seed: int = 5, L: float = 100.0) -> PackedComplex:
+    """BASELINE.json configs[4]: 10k aromatic rings (+10k amide groups) in a 100 A cube."""
+    return make_synthetic(0, seed=seed, box=(L, L, L), n_rings=n_rings, n_amides=n_amides, id='rings_10k')
+
+
+def slab_config(n_per_slab: int, n_slabs: int, seed: int = 4) -> PackedComplex:
+    """BASELINE.json configs[3] family: n_slabs * n_per_slab atoms, box elongated along x
+    so that each slab is the config-3 cube (weak scaling)."""
+    n = n_per_slab * n_slabs
+    L = (n_per_slab / 0.05) ** (1.0 / 3.0)
+    n_rings, n_amides = n // 100, n // 50
+    return make_synthetic(n - 6 * n_rings - 4 * n_amides, seed=seed, box=(L * n_slabs, L, L), n_rings=n_rings,
+                          n_amides=n_amides, id=f'slab_{n_slabs}x{n_per_slab}')

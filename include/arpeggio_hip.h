@@ -1,0 +1,237 @@
+/*
+ * arpeggio_hip.h — C ABI of the MI355X-native contact-detection hot path.
+ *
+ * This is the drop-in boundary for arpeggio's `InteractionComplex.run_arpeggio`
+ * (reference: arpeggio/core/interactions.py:329-347).  The reference is pure
+ * Python with no FFI of its own, so every entry point below names the reference
+ * function it replaces (file:line, relative to the reference tree; `I:` =
+ * arpeggio/core/interactions.py, `U:` = arpeggio/core/utils.py, `C:` =
+ * arpeggio/core/config.py).  INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - All host buffers are caller-allocated; the library never keeps a host
+ *     pointer after a call returns.  Device memory is owned by the context.
+ *   - One HIP stream per context; calls are blocking unless named *_launch.
+ *   - Return value: ARP_OK or a negative ARP_E_* code; arp_last_error() gives
+ *     the message.  ARP_E_CAPACITY stores the required element count in *count
+ *     so the caller can re-call with a larger buffer.
+ *   - Atom indices in every output are indices into the arrays given to
+ *     arp_set_atoms (the "packed atom order").  bgn = lower packed index
+ *     (canonical orientation; the reference's own orientation is a hash/KD-tree
+ *     artefact).
+ */
+#ifndef ARPEGGIO_HIP_H
+#define ARPEGGIO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes -------------------------------------------------------- */
+#define ARP_OK            0
+#define ARP_E_ARG        -1   /* bad argument / call order */
+#define ARP_E_HIP        -2   /* HIP runtime error */
+#define ARP_E_CAPACITY   -3   /* output buffer too small; *count = required */
+#define ARP_E_XBOND_NBR  -4   /* U:173 dereferenced None: xbond donor without a
+                                 single-bond heavy neighbour (reference raises
+                                 AttributeError) */
+#define ARP_E_NOMEM      -5
+
+/* ---- atom type mask: bit = position in this list (keys of C:53-145) ------ */
+#define ARP_T_HBOND_ACCEPTOR       (1u << 0)
+#define ARP_T_HBOND_DONOR          (1u << 1)
+#define ARP_T_XBOND_ACCEPTOR       (1u << 2)
+#define ARP_T_XBOND_DONOR          (1u << 3)
+#define ARP_T_WEAK_HBOND_ACCEPTOR  (1u << 4)
+#define ARP_T_WEAK_HBOND_DONOR     (1u << 5)
+#define ARP_T_POS_IONISABLE        (1u << 6)
+#define ARP_T_NEG_IONISABLE        (1u << 7)
+#define ARP_T_HYDROPHOBE           (1u << 8)
+#define ARP_T_CARBONYL_OXYGEN      (1u << 9)
+#define ARP_T_CARBONYL_CARBON      (1u << 10)
+#define ARP_T_AROMATIC             (1u << 11)
+
+/* ---- per-atom flags (u16) ------------------------------------------------ */
+#define ARP_F_METAL     (1u << 0)   /* I:1990  element in C:27-31            */
+#define ARP_F_HALOGEN   (1u << 1)   /* I:1991  element in C:33               */
+#define ARP_F_WATER     (1u << 2)   /* get_full_id()[3][0] == 'W' (I:678)    */
+#define ARP_F_HYDROGEN  (1u << 3)   /* element.strip() == 'H' (I:712, I:964) */
+#define ARP_F_ELEM_C    (1u << 4)   /* element == 'C' (I:1009)               */
+#define ARP_F_ELEM_S    (1u << 5)   /* element == 'S' (I:1023)               */
+#define ARP_F_RES_MET   (1u << 6)   /* parent resname == 'MET' (I:1023)      */
+
+/* ---- per-residue flags (u8) ---------------------------------------------- */
+#define ARP_R_POLYPEPTIDE (1u << 0) /* residue.is_polypeptide (I:1671,1860)  */
+#define ARP_R_HAS_SEQ     (1u << 1) /* hasattr(prev_residue/next_residue) (I:736) */
+
+/* ---- atom-atom SIFt bits (order of the name list at I:178-180) ----------- */
+#define ARP_S_CLASH         (1u << 0)
+#define ARP_S_COVALENT      (1u << 1)
+#define ARP_S_VDW_CLASH     (1u << 2)
+#define ARP_S_VDW           (1u << 3)
+#define ARP_S_PROXIMAL      (1u << 4)
+#define ARP_S_HBOND         (1u << 5)
+#define ARP_S_WEAK_HBOND    (1u << 6)
+#define ARP_S_XBOND         (1u << 7)
+#define ARP_S_IONIC         (1u << 8)
+#define ARP_S_METAL_COMPLEX (1u << 9)
+#define ARP_S_AROMATIC      (1u << 10)
+#define ARP_S_HYDROPHOBIC   (1u << 11)
+#define ARP_S_CARBONYL      (1u << 12)
+#define ARP_S_POLAR         (1u << 13)
+#define ARP_S_WEAK_POLAR    (1u << 14)
+
+/* ---- interacting-entities codes (I:643-691, I:985-997, I:1095-1108) ------ */
+#define ARP_CT_INTRA_NON_SELECTION  0
+#define ARP_CT_INTRA_SELECTION      1
+#define ARP_CT_INTER                2
+#define ARP_CT_SELECTION_WATER      3
+#define ARP_CT_NON_SELECTION_WATER  4
+#define ARP_CT_WATER_WATER          5
+#define ARP_CT_INTRA_BINDING_SITE   6
+
+/* ---- atom-plane interaction bits (I:1007-1024; alphabetical = bit order) -- */
+#define ARP_AP_CARBONPI      (1u << 0)
+#define ARP_AP_CATIONPI      (1u << 1)
+#define ARP_AP_DONORPI       (1u << 2)
+#define ARP_AP_HALOGENPI     (1u << 3)
+#define ARP_AP_METSULPHURPI  (1u << 4)
+
+/* ---- plane-plane classes (I:1127-1148); 9 = '' (NaN angles), 255 = visit skipped */
+#define ARP_PP_FF 0
+#define ARP_PP_OF 1
+#define ARP_PP_EE 2
+#define ARP_PP_FT 3
+#define ARP_PP_OT 4
+#define ARP_PP_ET 5
+#define ARP_PP_FE 6
+#define ARP_PP_OE 7
+#define ARP_PP_EF 8
+#define ARP_PP_NONE 9
+#define ARP_PP_SKIPPED 255
+
+typedef struct arp_ctx arp_ctx;
+
+/* ---- lifetime ------------------------------------------------------------ */
+const char* arp_version(void);
+/* device = HIP device ordinal.  Fails with ARP_E_HIP when no gfx950 device is
+ * usable: there is no CPU fallback in this library. */
+int  arp_create(int device, arp_ctx** out);
+void arp_destroy(arp_ctx* ctx);
+const char* arp_last_error(arp_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* ---- inputs: what InteractionComplex.initialize() (I:288-327) leaves behind */
+/* Atoms = self.s_atoms (I:54-60).  xyz: atom.coord float32 (P:327).
+ * vdw/cov: atom.vdw_radius / atom.cov_radius, Python floats (I:1501,1509).
+ * type_mask: atom.atom_types (I:1959-1983).  flags: ARP_F_*.
+ * res_id: index of atom.get_parent() in the residue table. */
+int arp_set_atoms(arp_ctx* ctx, int64_t n, const float* xyz, const double* vdw,
+                  const double* cov, const uint16_t* type_mask,
+                  const uint16_t* flags, const int32_t* res_id);
+/* Residue table: is_polypeptide / prev_residue / next_residue (I:1671-1693);
+ * prev/next are residue indices, -1 = None. */
+int arp_set_residues(arp_ctx* ctx, int64_t nres, const uint8_t* res_flags,
+                     const int32_t* prev, const int32_t* next);
+/* OpenBabel bond graph as CSR over packed atom indices: the set iterated by
+ * ob.OBAtomAtomIter(ob_atom_bgn) (I:750). */
+int arp_set_bonds(arp_ctx* ctx, const int32_t* bond_off, const int32_t* bond_idx);
+/* atom.h_coords (I:1513-1529): CSR, float64 xyz per hydrogen. */
+int arp_set_hydrogens(arp_ctx* ctx, const int32_t* h_off, const double* h_xyz);
+/* utils.get_single_bond_neighbour (U:612-635) resolved to a packed atom index,
+ * -1 = None. */
+int arp_set_single_bond_neighbours(arp_ctx* ctx, const int32_t* sb_nbr);
+/* biopython_str.rings (I:1697-1733, residue from I:1453-1492; -1 = None). */
+int arp_set_rings(arp_ctx* ctx, int64_t nring, const double* center,
+                  const double* normal, const int32_t* ring_res);
+/* biopython_str.amides (I:1531-1589): float32 centre and normal. */
+int arp_set_amides(arp_ctx* ctx, int64_t namide, const float* center,
+                   const float* normal, const int32_t* amide_res);
+
+/* ---- Bio.PDB.NeighborSearch equivalents (I:707,960,1394,1420,1442) -------- */
+/* NeighborSearch(atoms).search_all(radius): every unordered pair with
+ * float64 d^2 <= radius^2, once, as (i<j).  active = optional u8[n] mask of the
+ * atoms the tree is built on (NULL = all atoms). */
+int arp_search_all(arp_ctx* ctx, double radius, const uint8_t* active,
+                   int64_t cap, int32_t* out_i, int32_t* out_j, int64_t* count);
+
+/* ---- _make_selection (I:1384-1451) --------------------------------------- */
+/* in_selection: u8[n] = utils.selection_parser result (or all ones).
+ * Computes selection_plus (6.0 A expansion over ALL atoms incl. hydrogens,
+ * I:1420-1424), residue sets and ring/amide id sets (I:1416-1417,1434-1437)
+ * and keeps them in the context.  Outputs may be NULL. */
+int arp_make_selection(arp_ctx* ctx, const uint8_t* in_selection, double expand_radius,
+                       uint8_t* out_plus /*n*/, uint8_t* out_ring_sel /*nring*/,
+                       uint8_t* out_ring_plus /*nring*/, uint8_t* out_amide_sel /*namide*/,
+                       uint8_t* out_amide_plus /*namide*/);
+
+/* ---- _calculate_atom_contacts (I:693-936) -------------------------------- */
+/* Enqueue bin + sort + neighbour search + fused per-pair SIFt kernels on the
+ * context stream; results stay in HBM.  Synchronises the stream before
+ * returning and reports the number of emitted contacts.  If the device output
+ * buffer was too small it is regrown and the pass re-run internally. */
+int arp_atom_contacts_launch(arp_ctx* ctx, double cutoff, double vdw_comp,
+                             int include_sequence_adjacent, int64_t* count);
+/* Copy the results of the last launch to the host (any order; callers sort by
+ * (i,j) for the canonical order). */
+int arp_atom_contacts_fetch(arp_ctx* ctx, int64_t cap, int32_t* out_i, int32_t* out_j,
+                            float* out_dist, uint16_t* out_sift, uint8_t* out_ctype,
+                            int64_t* count);
+/* launch + fetch. */
+int arp_atom_contacts(arp_ctx* ctx, double cutoff, double vdw_comp,
+                      int include_sequence_adjacent, int64_t cap, int32_t* out_i,
+                      int32_t* out_j, float* out_dist, uint16_t* out_sift,
+                      uint8_t* out_ctype, int64_t* count);
+
+/* ---- _calculate_ring_contacts (I:938-1206) ------------------------------- */
+/* __calculate_atom_plane_contacts (I:947-1062). mask = ARP_AP_* bits. */
+int arp_atom_plane(arp_ctx* ctx, int64_t cap, int32_t* out_atom, int32_t* out_ring,
+                   double* out_dist, double* out_theta, uint8_t* out_mask,
+                   uint8_t* out_ctype, int64_t* count);
+/* __calculate_plane_plane_contacts (I:1064-1194), one record per unordered ring
+ * pair after the reference's dedupe: type1 = class from the creating visit,
+ * type2 = class appended by the reverse visit or ARP_PP_SKIPPED. */
+int arp_plane_plane(arp_ctx* ctx, int64_t cap, int32_t* out_bgn, int32_t* out_end,
+                    double* out_dist, double* out_dihedral, double* out_theta_bgn,
+                    double* out_theta_end, uint8_t* out_type1, uint8_t* out_type2,
+                    uint8_t* out_ctype, int64_t* count);
+
+/* ---- _calculate_group_contacts (I:1208-1382) ----------------------------- */
+/* __calculate_group_group_contacts (I:1217-1300): ordered amide pairs, float32. */
+int arp_group_group(arp_ctx* ctx, int64_t cap, int32_t* out_bgn, int32_t* out_end,
+                    float* out_dist, float* out_dihedral, float* out_theta,
+                    uint8_t* out_ctype, int64_t* count);
+/* __calculate_group_plane_contacts (I:1302-1382): amide x ring, float64. */
+int arp_group_plane(arp_ctx* ctx, int64_t cap, int32_t* out_amide, int32_t* out_ring,
+                    double* out_dist, double* out_dihedral, double* out_theta,
+                    uint8_t* out_ctype, int64_t* count);
+
+/* ---- multi-GPU slab halo -------------------------------------- */
+/* Marks which atoms this rank owns (u8[n]; NULL = all).  A pair is emitted by
+ * the rank that owns the atom with the lower global id. global_id: i32[n] id
+ * used for the ownership/orientation rule and reported in outputs instead of
+ * the local index (NULL = local index). */
+int arp_set_ownership(arp_ctx* ctx, const uint8_t* is_home, const int32_t* global_id);
+
+/* ---- measurement ---------------------------------------------------------- */
+/* stats[0]=candidate pairs tested by the last atom-contact search,
+ * stats[1]=pairs with d<=cutoff, stats[2]=pairs passing the residue filters
+ * (= emitted contacts), stats[3]=atoms binned, stats[4]=grid cells. */
+int arp_get_stats(arp_ctx* ctx, int64_t stats[8]);
+/* When enabled, every kernel of arp_atom_contacts_launch is bracketed by
+ * hipEvents on the context stream.  ms[k], launches[k] accumulate per kernel
+ * slot: 0 bin, 1 scan, 2 scatter+cellsort, 3 gather, 4 search, 5 sift.
+ * reset != 0 clears the accumulators after reading. */
+int arp_set_profiling(arp_ctx* ctx, int enabled);
+int arp_get_kernel_times(arp_ctx* ctx, double ms[8], int64_t launches[8], int reset);
+/* Address of the context's hipStream_t (as an integer), for callers that
+ * want to order their own work against it. */
+uint64_t arp_stream_handle(arp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARPEGGIO_HIP_H */
