@@ -1,0 +1,266 @@
+"""ctypes binding of include/arpeggio_hip.h (libarpeggio_hip.so).
+
+There is no CPU fallback: if the library is missing or no GPU is usable the calls
+raise NativeLibraryError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .core.exceptions import NativeLibraryError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libarpeggio_hip.so')
+
+ARP_OK, ARP_E_ARG, ARP_E_HIP, ARP_E_CAPACITY, ARP_E_XBOND_NBR, ARP_E_NOMEM = 0, -1, -2, -3, -4, -5
+
+# every symbol declared in include/arpeggio_hip.h
+SYMBOLS = (
+    'arp_version', 'arp_create', 'arp_destroy', 'arp_last_error', 'arp_set_atoms', 'arp_set_residues',
+    'arp_set_bonds', 'arp_set_hydrogens', 'arp_set_single_bond_neighbours', 'arp_set_rings', 'arp_set_amides',
+    'arp_search_all', 'arp_make_selection', 'arp_atom_contacts_launch', 'arp_atom_contacts_fetch',
+    'arp_atom_contacts', 'arp_atom_plane', 'arp_plane_plane', 'arp_group_group', 'arp_group_plane',
+    'arp_set_ownership', 'arp_get_stats', 'arp_set_profiling', 'arp_get_kernel_times', 'arp_stream_handle',
+)
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(f'{LIB_PATH} not found: build it with `python -m arpeggio_amd.build` '
+                                 '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    L.arp_version.restype = C.c_char_p
+    L.arp_last_error.restype = C.c_char_p
+    L.arp_last_error.argtypes = [vp]
+    L.arp_create.argtypes = [i32, C.POINTER(vp)]
+    L.arp_destroy.argtypes = [vp]
+    L.arp_destroy.restype = None
+    L.arp_set_atoms.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.arp_set_residues.argtypes = [vp, i64, vp, vp, vp]
+    L.arp_set_bonds.argtypes = [vp, vp, vp]
+    L.arp_set_hydrogens.argtypes = [vp, vp, vp]
+    L.arp_set_single_bond_neighbours.argtypes = [vp, vp]
+    L.arp_set_rings.argtypes = [vp, i64, vp, vp, vp]
+    L.arp_set_amides.argtypes = [vp, i64, vp, vp, vp]
+    L.arp_search_all.argtypes = [vp, dbl, vp, i64, vp, vp, C.POINTER(i64)]
+    L.arp_make_selection.argtypes = [vp, vp, dbl, vp, vp, vp, vp, vp]
+    L.arp_atom_contacts_launch.argtypes = [vp, dbl, dbl, i32, C.POINTER(i64)]
+    L.arp_atom_contacts_fetch.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.arp_atom_contacts.argtypes = [vp, dbl, dbl, i32, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.arp_atom_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.arp_plane_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.arp_group_group.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.arp_group_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.arp_set_ownership.argtypes = [vp, vp, vp]
+    L.arp_get_stats.argtypes = [vp, vp]
+    L.arp_set_profiling.argtypes = [vp, i32]
+    L.arp_get_kernel_times.argtypes = [vp, vp, vp, i32]
+    L.arp_stream_handle.argtypes = [vp]
+    L.arp_stream_handle.restype = C.c_uint64
+    for s in SYMBOLS:
+        f = getattr(L, s)
+        if s not in ('arp_version', 'arp_last_error', 'arp_destroy', 'arp_stream_handle'):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+KERNEL_SLOTS = ('bin', 'scan', 'scatter_cellsort', 'gather', 'search', 'sift')
+
+
+class Context:
+    """One arp_ctx: one GPU, one HIP stream, device-resident structure."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.arp_create(int(device), C.byref(h))
+        if rc != ARP_OK:
+            msg = self._L.arp_last_error(None).decode()
+            raise NativeLibraryError(f'arp_create(device={device}) failed ({rc}): {msg}')
+        self._h = h
+        self.device = device
+        self.n = self.n_rings = self.n_amides = 0
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.arp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc == ARP_OK:
+            return
+        msg = self._L.arp_last_error(self._h).decode()
+        if rc == ARP_E_XBOND_NBR:
+            # the reference dereferences None here (utils.py:173)
+            raise AttributeError("'NoneType' object has no attribute 'GetId'")
+        if rc == ARP_E_ARG:
+            raise ValueError(f'{what}: {msg}')
+        raise NativeLibraryError(f'{what} failed ({rc}): {msg}')
+
+    # ---- inputs ----
+    def set_complex(self, pc):
+        """Upload a PackedComplex (everything initialize() leaves behind)."""
+        L, h = self._L, self._h
+        self._keep = pc
+        self._check(L.arp_set_atoms(h, pc.n_atoms, _p(pc.xyz), _p(pc.vdw), _p(pc.cov), _p(pc.type_mask), _p(pc.flags),
+                                    _p(pc.res_id)), 'arp_set_atoms')
+        self._check(L.arp_set_residues(h, pc.n_residues, _p(pc.res_flags), _p(pc.res_prev), _p(pc.res_next)), 'arp_set_residues')
+        self._check(L.arp_set_bonds(h, _p(pc.bond_off), _p(pc.bond_idx)), 'arp_set_bonds')
+        self._check(L.arp_set_hydrogens(h, _p(pc.h_off), _p(pc.h_xyz)), 'arp_set_hydrogens')
+        self._check(L.arp_set_single_bond_neighbours(h, _p(pc.sb_nbr)), 'arp_set_single_bond_neighbours')
+        self._check(L.arp_set_rings(h, pc.n_rings, _p(pc.ring_center), _p(pc.ring_normal), _p(pc.ring_res)), 'arp_set_rings')
+        self._check(L.arp_set_amides(h, pc.n_amides, _p(pc.amide_center), _p(pc.amide_normal), _p(pc.amide_res)), 'arp_set_amides')
+        self.n, self.n_rings, self.n_amides = pc.n_atoms, pc.n_rings, pc.n_amides
+
+    def set_ownership(self, is_home=None, global_id=None):
+        home = None if is_home is None else np.ascontiguousarray(is_home, np.uint8)
+        gid = None if global_id is None else np.ascontiguousarray(global_id, np.int32)
+        self._check(self._L.arp_set_ownership(self._h, _p(home), _p(gid)), 'arp_set_ownership')
+
+    # ---- searches ----
+    def search_all(self, radius, active=None):
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        cap = max(16 * self.n, 1024)
+        while True:
+            oi, oj = np.empty(cap, np.int32), np.empty(cap, np.int32)
+            cnt = C.c_int64(0)
+            rc = self._L.arp_search_all(self._h, float(radius), _p(act), cap, _p(oi), _p(oj), C.byref(cnt))
+            if rc == ARP_E_CAPACITY:
+                cap = int(cnt.value)
+                continue
+            self._check(rc, 'arp_search_all')
+            k = int(cnt.value)
+            o = np.lexsort((oj[:k], oi[:k]))
+            return oi[:k][o], oj[:k][o]
+
+    def make_selection(self, in_selection=None, radius=6.0):
+        sel = np.ones(self.n, np.uint8) if in_selection is None else np.ascontiguousarray(in_selection, np.uint8)
+        if sel.shape != (self.n,):
+            raise ValueError('in_selection must have one entry per atom')
+        plus = np.empty(self.n, np.uint8)
+        rs, rp = np.empty(self.n_rings, np.uint8), np.empty(self.n_rings, np.uint8)
+        as_, ap = np.empty(self.n_amides, np.uint8), np.empty(self.n_amides, np.uint8)
+        self._check(self._L.arp_make_selection(self._h, _p(sel), float(radius), _p(plus), _p(rs), _p(rp), _p(as_), _p(ap)),
+                    'arp_make_selection')
+        return dict(plus=plus, ring_sel=rs, ring_plus=rp, amide_sel=as_, amide_plus=ap)
+
+    # ---- atom-atom contacts ----
+    def atom_contacts_launch(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
+        cnt = C.c_int64(0)
+        self._check(self._L.arp_atom_contacts_launch(self._h, float(cutoff), float(vdw_comp), int(bool(include_sequence_adjacent)),
+                                                     C.byref(cnt)), 'arp_atom_contacts_launch')
+        return int(cnt.value)
+
+    def atom_contacts_fetch(self, count, sort=True):
+        cap = max(int(count), 1)
+        oi, oj = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        od, osf, oc = np.empty(cap, np.float32), np.empty(cap, np.uint16), np.empty(cap, np.uint8)
+        cnt = C.c_int64(0)
+        self._check(self._L.arp_atom_contacts_fetch(self._h, cap, _p(oi), _p(oj), _p(od), _p(osf), _p(oc), C.byref(cnt)),
+                    'arp_atom_contacts_fetch')
+        k = int(cnt.value)
+        out = dict(i=oi[:k], j=oj[:k], dist=od[:k], sift=osf[:k], ctype=oc[:k])
+        if sort:
+            o = np.lexsort((out['j'], out['i']))
+            out = {kk: v[o] for kk, v in out.items()}
+        return out
+
+    def atom_contacts(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, sort=True):
+        n = self.atom_contacts_launch(cutoff, vdw_comp, include_sequence_adjacent)
+        out = self.atom_contacts_fetch(n, sort=sort)
+        out['stats'] = self.stats()
+        return out
+
+    # ---- ring / amide contacts ----
+    def _grow(self, call, arrays_factory, what, guess):
+        cap = max(int(guess), 64)
+        while True:
+            arrs = arrays_factory(cap)
+            cnt = C.c_int64(0)
+            rc = call(cap, arrs, cnt)
+            if rc == ARP_E_CAPACITY:
+                cap = int(cnt.value)
+                continue
+            self._check(rc, what)
+            k = int(cnt.value)
+            return [a[:k] for a in arrs]
+
+    def atom_plane(self):
+        def mk(cap):
+            return [np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float64), np.empty(cap, np.float64),
+                    np.empty(cap, np.uint8), np.empty(cap, np.uint8)]
+        a = self._grow(lambda cap, r, cnt: self._L.arp_atom_plane(self._h, cap, *[_p(x) for x in r], C.byref(cnt)), mk,
+                       'arp_atom_plane', 8 * self.n_rings)
+        out = dict(atom=a[0], ring=a[1], dist=a[2], theta=a[3], mask=a[4], ctype=a[5])
+        o = np.lexsort((out['atom'], out['ring']))
+        return {k: v[o] for k, v in out.items()}
+
+    def plane_plane(self):
+        def mk(cap):
+            return [np.empty(cap, np.int32), np.empty(cap, np.int32)] + [np.empty(cap, np.float64) for _ in range(4)] + \
+                   [np.empty(cap, np.uint8) for _ in range(3)]
+        a = self._grow(lambda cap, r, cnt: self._L.arp_plane_plane(self._h, cap, *[_p(x) for x in r], C.byref(cnt)), mk,
+                       'arp_plane_plane', 16 * self.n_rings)
+        out = dict(bgn=a[0], end=a[1], dist=a[2], dihedral=a[3], theta_bgn=a[4], theta_end=a[5], type1=a[6], type2=a[7], ctype=a[8])
+        o = np.lexsort((out['end'], out['bgn']))   # = the reference's creation order (ring-id order)
+        return {k: v[o] for k, v in out.items()}
+
+    def group_group(self):
+        def mk(cap):
+            return [np.empty(cap, np.int32), np.empty(cap, np.int32)] + [np.empty(cap, np.float32) for _ in range(3)] + \
+                   [np.empty(cap, np.uint8)]
+        a = self._grow(lambda cap, r, cnt: self._L.arp_group_group(self._h, cap, *[_p(x) for x in r], C.byref(cnt)), mk,
+                       'arp_group_group', 8 * self.n_amides)
+        out = dict(bgn=a[0], end=a[1], dist=a[2], dihedral=a[3], theta=a[4], ctype=a[5])
+        o = np.lexsort((out['end'], out['bgn']))
+        return {k: v[o] for k, v in out.items()}
+
+    def group_plane(self):
+        def mk(cap):
+            return [np.empty(cap, np.int32), np.empty(cap, np.int32)] + [np.empty(cap, np.float64) for _ in range(3)] + \
+                   [np.empty(cap, np.uint8)]
+        a = self._grow(lambda cap, r, cnt: self._L.arp_group_plane(self._h, cap, *[_p(x) for x in r], C.byref(cnt)), mk,
+                       'arp_group_plane', 8 * self.n_amides)
+        out = dict(amide=a[0], ring=a[1], dist=a[2], dihedral=a[3], theta=a[4], ctype=a[5])
+        o = np.lexsort((out['ring'], out['amide']))
+        return {k: v[o] for k, v in out.items()}
+
+    # ---- measurement ----
+    def stats(self):
+        s = np.zeros(8, np.int64)
+        self._check(self._L.arp_get_stats(self._h, _p(s)), 'arp_get_stats')
+        return dict(candidates=int(s[0]), accepted=int(s[1]), emitted=int(s[2]), binned=int(s[3]), cells=int(s[4]))
+
+    def set_profiling(self, on=True):
+        self._check(self._L.arp_set_profiling(self._h, int(on)), 'arp_set_profiling')
+
+    def kernel_times(self, reset=False):
+        ms, ln = np.zeros(8, np.float64), np.zeros(8, np.int64)
+        self._check(self._L.arp_get_kernel_times(self._h, _p(ms), _p(ln), int(reset)), 'arp_get_kernel_times')
+        return {name: dict(ms=float(ms[k]), launches=int(ln[k])) for k, name in enumerate(KERNEL_SLOTS)}
+
+    def stream_handle(self):
+        return int(self._L.arp_stream_handle(self._h))

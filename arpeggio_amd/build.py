@@ -1,0 +1,47 @@
+"""Build the HIP library in-tree (the .so travels to the GPU box with the snapshot).
+
+    python -m arpeggio_amd.build        # or arpeggio_amd.build.build()
+
+hipcc cross-compiles gfx950 without a GPU.  -ffp-contract=off is part of the numerics
+contract (csrc/arp_numerics.h): the only fused operations are explicit fma() calls.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libarpeggio_hip.so')
+SOURCES = ['arp_api.hip']
+HEADERS = ['arp_numerics.h', 'arp_grid.h', 'arp_pairs.h', 'arp_planes.h']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+         '-Wall', '-Wno-unused-function']
+
+
+def hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, '..', 'include', 'arpeggio_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

@@ -1,0 +1,839 @@
+// arp_api.hip — C ABI (include/arpeggio_hip.h) over the HIP kernels.  gfx950 only.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC
+//        arp_api.hip -o libarpeggio_hip.so
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/arpeggio_hip.h"
+#include "arp_grid.h"
+#include "arp_numerics.h"
+#include "arp_pairs.h"
+#include "arp_planes.h"
+
+namespace {
+
+std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap && p) return hipSuccess;
+        release();
+        size_t c = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void**)&p, c * sizeof(T));
+        if (e == hipSuccess) cap = c;
+        else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Grid {
+    GridDesc d{};
+    DevBuf<int> cell_of, cnt, start, perm, sums;
+    int n_points = 0;   // points offered
+    int n_binned = 0;   // points that passed the filter
+    bool valid = false;
+    double radius = 0;
+    void release() { cell_of.release(); cnt.release(); start.release(); perm.release(); sums.release(); valid = false; }
+};
+
+enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_GATHER = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, NSLOT = 8 };
+
+struct EventPair { int slot; hipEvent_t a, b; };
+
+}  // namespace
+
+struct arp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cu = 256;
+
+    // ---- sizes
+    int64_t n = 0, nres = 0, nring = 0, namide = 0, nh = 0, nbond = 0;
+    // ---- host mirrors needed for later set_* calls / grid boxes
+    std::vector<float> h_xyz;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    double ring_lo[3] = {0, 0, 0}, ring_hi[3] = {0, 0, 0};
+    double am_lo[3] = {0, 0, 0}, am_hi[3] = {0, 0, 0};
+    // ---- raw inputs
+    DevBuf<float4> xyz;          // w unused
+    DevBuf<double2> rad;         // {vdw, cov}
+    DevBuf<uint16_t> tmask, flags;
+    DevBuf<int> res_id, res_prev, res_next;
+    DevBuf<uint8_t> res_flags;
+    DevBuf<int> bond_off, bond_idx, h_off;
+    DevBuf<double> h_xyz_d;
+    DevBuf<float4> sb;           // single-bond neighbour xyz, w = 1 if present
+    DevBuf<int> gid;
+    DevBuf<uint8_t> home, sel, plus, res_sel, res_plus;
+    bool has_res = false, has_bonds = false, has_h = false, has_sb = false, has_gid = false, has_home = false;
+    bool sel_made = false;
+    DevBuf<double> ring_c, ring_n;
+    DevBuf<int> ring_res;
+    DevBuf<uint8_t> ring_sel, ring_plus;
+    DevBuf<float> am_c, am_n;
+    DevBuf<int> am_res;
+    DevBuf<uint8_t> am_sel, am_plus;
+    // ---- derived
+    DevBuf<float4> xyzm, s_xyzm;
+    DevBuf<int4> aux, s_aux;
+    bool records_dirty = true;
+    Grid atom_grid, ring_grid, amide_grid;
+    DevBuf<uint8_t> tmp_u8;
+    // ---- pair list and outputs of the atom-contact pass
+    DevBuf<int2> pairs;
+    DevBuf<int> out_i, out_j;
+    DevBuf<float> out_d;
+    DevBuf<uint16_t> out_s;
+    DevBuf<uint8_t> out_ct;
+    int64_t n_contacts = 0;
+    bool contacts_valid = false;
+    Counters* d_ctr = nullptr;
+    Counters h_ctr{};
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- generic outputs of the plane kernels
+    DevBuf<int> po_a, po_b;
+    DevBuf<double> po_d0, po_d1, po_d2, po_d3;
+    DevBuf<float> po_f0, po_f1, po_f2;
+    DevBuf<uint8_t> po_u0, po_u1, po_u2;
+    // ---- profiling
+    bool profiling = false;
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    double k_ms[NSLOT] = {0};
+    int64_t k_launches[NSLOT] = {0};
+};
+
+namespace {
+
+#define FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+#define HIPCHK(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            return ARP_E_HIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+#define CHK(expr) do { int rc_ = (expr); if (rc_ != ARP_OK) return rc_; } while (0)
+
+template <class T>
+int upload(arp_ctx* c, DevBuf<T>& buf, const T* src, size_t n) {
+    HIPCHK(c, buf.reserve(n ? n : 1));
+    if (n) HIPCHK(c, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ARP_OK;
+}
+template <class T>
+int download(arp_ctx* c, T* dst, const T* src, size_t n) {
+    if (n && dst) HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ARP_OK;
+}
+
+inline int nblocks(int64_t work, int threads, int max_blocks = 2048) {
+    int64_t b = (work + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+struct Prof {  // brackets one launch with events when profiling is on
+    arp_ctx* c;
+    int slot;
+    EventPair* ep = nullptr;
+    Prof(arp_ctx* c_, int slot_) : c(c_), slot(slot_) {
+        if (!c->profiling) return;
+        if (c->ev_used == c->ev_pool.size()) {
+            EventPair e{slot, nullptr, nullptr};
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+            c->ev_pool.push_back(e);
+        }
+        ep = &c->ev_pool[c->ev_used++];
+        ep->slot = slot;
+        (void)hipEventRecord(ep->a, c->stream);
+    }
+    ~Prof() {
+        if (ep) (void)hipEventRecord(ep->b, c->stream);
+    }
+};
+
+void collect_events(arp_ctx* c) {  // call after a stream sync
+    for (size_t k = 0; k < c->ev_used; ++k) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[k].a, c->ev_pool[k].b) == hipSuccess) {
+            c->k_ms[c->ev_pool[k].slot] += ms;
+            c->k_launches[c->ev_pool[k].slot] += 1;
+        }
+    }
+    c->ev_used = 0;
+}
+
+int check_launch(arp_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        c->err = std::string(what) + ": " + hipGetErrorString(e);
+        return ARP_E_HIP;
+    }
+    return ARP_OK;
+}
+
+// Choose grid dimensions: cell edge >= radius (slightly larger so that rounding in the
+// binning can never separate a pair within the radius by two cells), at most 2^26 cells.
+void make_grid_desc(GridDesc& d, const double lo[3], const double hi[3], double radius) {
+    double edge = radius * (1.0 + 1e-6);
+    if (!(edge > 0)) edge = 1.0;
+    for (;;) {
+        double nx = std::floor((hi[0] - lo[0]) / edge) + 1, ny = std::floor((hi[1] - lo[1]) / edge) + 1,
+               nz = std::floor((hi[2] - lo[2]) / edge) + 1;
+        if (nx * ny * nz <= (double)(1 << 26) && nx < 2e9 && ny < 2e9 && nz < 2e9) {
+            d.nx = (int)nx; d.ny = (int)ny; d.nz = (int)nz;
+            break;
+        }
+        edge *= 1.26;
+    }
+    d.ncell = d.nx * d.ny * d.nz;
+    d.ox = lo[0]; d.oy = lo[1]; d.oz = lo[2];
+    d.inv = 1.0 / edge;
+}
+
+// bin + scan + scatter + cell sort.  P = point accessor; filter as in k_bin.
+template <class P, int FILTER>
+int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const double hi[3], double radius,
+               const uint8_t* active, const float4* xyzm, uint32_t req, uint32_t forb) {
+    make_grid_desc(G.d, lo, hi, radius);
+    G.radius = radius;
+    G.n_points = n;
+    const int ncell = G.d.ncell;
+    HIPCHK(c, G.cell_of.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, G.perm.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, G.cnt.reserve((size_t)ncell + 1));
+    HIPCHK(c, G.start.reserve((size_t)ncell + 2));
+    const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
+    HIPCHK(c, G.sums.reserve((size_t)nb_scan + 2));
+    {
+        Prof p(c, SLOT_BIN);
+        HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, ((size_t)ncell + 1) * sizeof(int), c->stream));
+        if (n > 0) {
+            hipLaunchKernelGGL((k_bin<P, FILTER>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, pts, n, G.d, active,
+                               xyzm, req, forb, G.cell_of.p, G.cnt.p);
+            CHK(check_launch(c, "k_bin"));
+        }
+    }
+    {
+        Prof p(c, SLOT_SCAN);
+        hipLaunchKernelGGL(k_scan_local, dim3(nb_scan), dim3(SCAN_THREADS), 0, c->stream, G.cnt.p, ncell, G.start.p, G.sums.p);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, G.sums.p, nb_scan);
+        hipLaunchKernelGGL(k_scan_add, dim3((ncell + 1 + 255) / 256), dim3(256), 0, c->stream, G.start.p, ncell, G.sums.p, nb_scan);
+        CHK(check_launch(c, "k_scan"));
+    }
+    {
+        Prof p(c, SLOT_SCATTER);
+        if (n > 0) {
+            hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, G.cell_of.p, G.start.p, G.cnt.p, G.perm.p);
+            hipLaunchKernelGGL(k_cellsort, dim3(nblocks(ncell, 256)), dim3(256), 0, c->stream, ncell, G.start.p, G.perm.p);
+            CHK(check_launch(c, "k_scatter/k_cellsort"));
+        }
+    }
+    G.valid = true;
+    return ARP_OK;
+}
+
+int ensure_records(arp_ctx* c) {
+    if (!c->records_dirty) return ARP_OK;
+    const int n = (int)c->n;
+    HIPCHK(c, c->xyzm.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->aux.reserve((size_t)std::max(n, 1)));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_build_records, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->xyz.p, c->tmask.p, c->flags.p,
+                           c->res_id.p, c->has_res ? c->res_flags.p : nullptr, c->has_res ? c->res_prev.p : nullptr,
+                           c->has_res ? c->res_next.p : nullptr, c->sel_made ? c->sel.p : nullptr,
+                           c->sel_made ? c->plus.p : nullptr, c->has_home ? c->home.p : nullptr, c->xyzm.p, c->aux.p);
+        CHK(check_launch(c, "k_build_records"));
+    }
+    c->records_dirty = false;
+    c->atom_grid.valid = false;
+    return ARP_OK;
+}
+
+// grid over the atoms selected by (req, forb) meta masks, plus cell-sorted record copies
+int build_atom_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active) {
+    CHK(ensure_records(c));
+    const int n = (int)c->n;
+    PtsF4 pts{c->xyzm.p};
+    if (active) CHK((build_grid<PtsF4, 1>(c, c->atom_grid, pts, n, c->lo, c->hi, radius, active, c->xyzm.p, 0, 0)));
+    else CHK((build_grid<PtsF4, 2>(c, c->atom_grid, pts, n, c->lo, c->hi, radius, nullptr, c->xyzm.p, req, forb)));
+    HIPCHK(c, c->s_xyzm.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_aux.reserve((size_t)std::max(n, 1)));
+    {
+        Prof p(c, SLOT_GATHER);
+        if (n > 0) {
+            hipLaunchKernelGGL(k_gather, dim3(nblocks(n, 256)), dim3(256), 0, c->stream,
+                               c->atom_grid.start.p + c->atom_grid.d.ncell, c->atom_grid.perm.p, c->xyzm.p, c->aux.p,
+                               c->s_xyzm.p, c->s_aux.p);
+            CHK(check_launch(c, "k_gather"));
+        }
+    }
+    c->atom_grid.n_binned = -1;  // known on the device only; fetched with the counters when needed
+    return ARP_OK;
+}
+
+int search_blocks(const GridDesc& d) {
+    int nb = (d.ncell + SEARCH_WAVES * 2 - 1) / (SEARCH_WAVES * 2);
+    nb = std::max(8, std::min(nb, 4096));
+    return (nb + 7) & ~7;
+}
+
+int reset_counters(arp_ctx* c) {
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+    return ARP_OK;
+}
+int read_counters(arp_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync(&c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ARP_OK;
+}
+
+void host_bbox(const float* xyz, int64_t n, int stride, double lo[3], double hi[3]) {
+    for (int k = 0; k < 3; ++k) { lo[k] = 0; hi[k] = 0; }
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double v = xyz[i * stride + k];
+            if (i == 0 || v < lo[k]) lo[k] = v;
+            if (i == 0 || v > hi[k]) hi[k] = v;
+        }
+}
+void host_bbox_d(const double* xyz, int64_t n, double lo[3], double hi[3]) {
+    for (int k = 0; k < 3; ++k) { lo[k] = 0; hi[k] = 0; }
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double v = xyz[i * 3 + k];
+            if (i == 0 || v < lo[k]) lo[k] = v;
+            if (i == 0 || v > hi[k]) hi[k] = v;
+        }
+}
+
+int ensure_ring_grid(arp_ctx* c) {
+    if (c->ring_grid.valid) return ARP_OK;
+    PtsD3 pts{c->ring_c.p};
+    return build_grid<PtsD3, 0>(c, c->ring_grid, pts, (int)c->nring, c->ring_lo, c->ring_hi, 6.0, nullptr, nullptr, 0, 0);
+}
+int ensure_amide_grid(arp_ctx* c) {
+    if (c->amide_grid.valid) return ARP_OK;
+    PtsF3 pts{c->am_c.p};
+    return build_grid<PtsF3, 0>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0, nullptr, nullptr, 0, 0);
+}
+
+// masks for rings/amides default to "everything selected" until arp_make_selection runs
+int ensure_default_selection(arp_ctx* c) {
+    if (c->sel_made) return ARP_OK;
+    std::vector<uint8_t> ones((size_t)std::max<int64_t>(c->n, 1), 1);
+    return arp_make_selection(c, ones.data(), 6.0, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+const char* arp_version(void) { return "arpeggio_hip 0.1.0 (gfx950)"; }
+
+int arp_create(int device, arp_ctx** out) {
+    if (!out) return ARP_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return ARP_E_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "device ordinal out of range";
+        return ARP_E_ARG;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return ARP_E_HIP; }
+    arp_ctx* c = new (std::nothrow) arp_ctx();
+    if (!c) return ARP_E_NOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(Counters));
+    if (e != hipSuccess) {
+        g_create_error = hipGetErrorString(e);
+        delete c;
+        return ARP_E_HIP;
+    }
+    *out = c;
+    return ARP_OK;
+}
+
+void arp_destroy(arp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    c->xyz.release(); c->rad.release(); c->tmask.release(); c->flags.release(); c->res_id.release();
+    c->res_prev.release(); c->res_next.release(); c->res_flags.release(); c->bond_off.release();
+    c->bond_idx.release(); c->h_off.release(); c->h_xyz_d.release(); c->sb.release(); c->gid.release();
+    c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
+    c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
+    c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
+    c->xyzm.release(); c->s_xyzm.release(); c->aux.release(); c->s_aux.release();
+    c->atom_grid.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
+    c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
+    c->po_a.release(); c->po_b.release(); c->po_d0.release(); c->po_d1.release(); c->po_d2.release(); c->po_d3.release();
+    c->po_f0.release(); c->po_f1.release(); c->po_f2.release(); c->po_u0.release(); c->po_u1.release(); c->po_u2.release();
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* arp_last_error(arp_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+// ---- inputs --------------------------------------------------------------------------
+int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, const double* cov, const uint16_t* type_mask,
+                  const uint16_t* flags, const int32_t* res_id) {
+    if (!c) return ARP_E_ARG;
+    if (n < 0 || n > 0x7FFFFFF0LL) FAIL(c, ARP_E_ARG, "arp_set_atoms: n out of range");
+    if (n > 0 && (!xyz || !vdw || !cov || !type_mask || !flags || !res_id)) FAIL(c, ARP_E_ARG, "arp_set_atoms: null input");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->n = n;
+    c->h_xyz.assign(xyz, xyz + 3 * n);
+    host_bbox(xyz, n, 3, c->lo, c->hi);
+    std::vector<float4> x4((size_t)n);
+    std::vector<double2> r2((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        x4[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+        r2[i] = make_double2(vdw[i], cov[i]);
+    }
+    CHK(upload(c, c->xyz, x4.data(), (size_t)n));
+    CHK(upload(c, c->rad, r2.data(), (size_t)n));
+    CHK(upload(c, c->tmask, type_mask, (size_t)n));
+    CHK(upload(c, c->flags, flags, (size_t)n));
+    CHK(upload(c, c->res_id, res_id, (size_t)n));
+    // defaults for the optional per-atom inputs: no bonds, no hydrogens, no neighbours
+    std::vector<int> zeros((size_t)n + 1, 0);
+    CHK(upload(c, c->bond_off, zeros.data(), (size_t)n + 1));
+    CHK(upload(c, c->h_off, zeros.data(), (size_t)n + 1));
+    HIPCHK(c, c->bond_idx.reserve(1));
+    HIPCHK(c, c->h_xyz_d.reserve(3));
+    std::vector<float4> sb0((size_t)n, make_float4(0, 0, 0, 0));
+    CHK(upload(c, c->sb, sb0.data(), (size_t)n));
+    c->has_bonds = c->has_h = c->has_sb = c->has_gid = c->has_home = false;
+    c->sel_made = false;
+    c->records_dirty = true;
+    c->contacts_valid = false;
+    c->atom_grid.valid = false;
+    return ARP_OK;
+}
+
+int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const int32_t* prev, const int32_t* next) {
+    if (!c) return ARP_E_ARG;
+    if (nres < 0 || (nres > 0 && (!res_flags || !prev || !next))) FAIL(c, ARP_E_ARG, "arp_set_residues: bad input");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->nres = nres;
+    CHK(upload(c, c->res_flags, res_flags, (size_t)nres));
+    CHK(upload(c, c->res_prev, prev, (size_t)nres));
+    CHK(upload(c, c->res_next, next, (size_t)nres));
+    c->has_res = true;
+    c->records_dirty = true;
+    c->sel_made = false;
+    c->contacts_valid = false;
+    return ARP_OK;
+}
+
+int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) {
+    if (!c || !bond_off) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t m = bond_off[c->n];
+    if (m < 0 || (m > 0 && !bond_idx)) FAIL(c, ARP_E_ARG, "arp_set_bonds: bad CSR");
+    CHK(upload(c, c->bond_off, bond_off, (size_t)c->n + 1));
+    CHK(upload(c, c->bond_idx, bond_idx, (size_t)m));
+    c->nbond = m;
+    c->has_bonds = true;
+    c->contacts_valid = false;
+    return ARP_OK;
+}
+
+int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
+    if (!c || !h_off) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t m = h_off[c->n];
+    if (m < 0 || (m > 0 && !h_xyz)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: bad CSR");
+    CHK(upload(c, c->h_off, h_off, (size_t)c->n + 1));
+    CHK(upload(c, c->h_xyz_d, h_xyz, (size_t)m * 3));
+    c->nh = m;
+    c->has_h = true;
+    c->contacts_valid = false;
+    return ARP_OK;
+}
+
+int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
+    if (!c || (c->n > 0 && !sb_nbr)) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<float4> sb((size_t)c->n);
+    for (int64_t i = 0; i < c->n; ++i) {
+        int k = sb_nbr[i];
+        if (k < -1 || k >= c->n) FAIL(c, ARP_E_ARG, "arp_set_single_bond_neighbours: index out of range");
+        sb[i] = k < 0 ? make_float4(0, 0, 0, 0)
+                      : make_float4(c->h_xyz[3 * (size_t)k], c->h_xyz[3 * (size_t)k + 1], c->h_xyz[3 * (size_t)k + 2], 1.0f);
+    }
+    CHK(upload(c, c->sb, sb.data(), (size_t)c->n));
+    c->has_sb = true;
+    c->contacts_valid = false;
+    return ARP_OK;
+}
+
+int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double* normal, const int32_t* ring_res) {
+    if (!c) return ARP_E_ARG;
+    if (nring < 0 || (nring > 0 && (!center || !normal || !ring_res))) FAIL(c, ARP_E_ARG, "arp_set_rings: bad input");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->nring = nring;
+    host_bbox_d(center, nring, c->ring_lo, c->ring_hi);
+    CHK(upload(c, c->ring_c, center, (size_t)nring * 3));
+    CHK(upload(c, c->ring_n, normal, (size_t)nring * 3));
+    CHK(upload(c, c->ring_res, ring_res, (size_t)nring));
+    HIPCHK(c, c->ring_sel.reserve((size_t)std::max<int64_t>(nring, 1)));
+    HIPCHK(c, c->ring_plus.reserve((size_t)std::max<int64_t>(nring, 1)));
+    c->ring_grid.valid = false;
+    c->sel_made = false;
+    return ARP_OK;
+}
+
+int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float* normal, const int32_t* amide_res) {
+    if (!c) return ARP_E_ARG;
+    if (namide < 0 || (namide > 0 && (!center || !normal || !amide_res))) FAIL(c, ARP_E_ARG, "arp_set_amides: bad input");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->namide = namide;
+    host_bbox(center, namide, 3, c->am_lo, c->am_hi);
+    CHK(upload(c, c->am_c, center, (size_t)namide * 3));
+    CHK(upload(c, c->am_n, normal, (size_t)namide * 3));
+    CHK(upload(c, c->am_res, amide_res, (size_t)namide));
+    HIPCHK(c, c->am_sel.reserve((size_t)std::max<int64_t>(namide, 1)));
+    HIPCHK(c, c->am_plus.reserve((size_t)std::max<int64_t>(namide, 1)));
+    c->amide_grid.valid = false;
+    c->sel_made = false;
+    return ARP_OK;
+}
+
+int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_id) {
+    if (!c) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (is_home) { CHK(upload(c, c->home, is_home, (size_t)c->n)); c->has_home = true; }
+    else c->has_home = false;
+    if (global_id) {
+        for (int64_t i = 1; i < c->n; ++i)
+            if (global_id[i] <= global_id[i - 1]) FAIL(c, ARP_E_ARG, "arp_set_ownership: global_id must be strictly increasing");
+        CHK(upload(c, c->gid, global_id, (size_t)c->n));
+        c->has_gid = true;
+    } else c->has_gid = false;
+    c->records_dirty = true;
+    c->contacts_valid = false;
+    return ARP_OK;
+}
+
+// ---- NeighborSearch.search_all -----------------------------------------------------------
+int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap, int32_t* out_i, int32_t* out_j, int64_t* count) {
+    if (!c || !count || cap < 0 || !(radius > 0)) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint8_t* d_active = nullptr;
+    if (active) {
+        CHK(upload(c, c->tmp_u8, active, (size_t)c->n));
+        d_active = c->tmp_u8.p;
+    }
+    CHK(build_atom_grid(c, radius, 0, 0, d_active));
+    c->atom_grid.valid = false;  // not the contact grid
+    size_t pcap = (size_t)std::max<int64_t>(cap, 1);
+    HIPCHK(c, c->pairs.reserve(pcap));
+    CHK(reset_counters(c));
+    if (c->n > 0) {
+        hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, c->pairs.p,
+                           (unsigned long long)cap, c->d_ctr, (uint8_t*)nullptr);
+        CHK(check_launch(c, "k_search<PAIRS>"));
+    }
+    CHK(read_counters(c));
+    *count = (int64_t)c->h_ctr.n_pairs;
+    c->contacts_valid = false;
+    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_search_all: output buffer too small");
+    if (*count > 0) {
+        std::vector<int2> tmp((size_t)*count);
+        CHK(download(c, tmp.data(), c->pairs.p, (size_t)*count));
+        for (int64_t k = 0; k < *count; ++k) { out_i[k] = tmp[k].x; out_j[k] = tmp[k].y; }
+    }
+    return ARP_OK;
+}
+
+// ---- _make_selection --------------------------------------------------------------------
+int arp_make_selection(arp_ctx* c, const uint8_t* in_selection, double expand_radius, uint8_t* out_plus, uint8_t* out_ring_sel,
+                       uint8_t* out_ring_plus, uint8_t* out_amide_sel, uint8_t* out_amide_plus) {
+    if (!c || (c->n > 0 && !in_selection) || !(expand_radius > 0)) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = (int)c->n;
+    CHK(upload(c, c->sel, in_selection, (size_t)n));
+    CHK(upload(c, c->plus, in_selection, (size_t)n));  // I:1407 selection_plus starts as the selection
+    c->sel_made = true;
+    c->records_dirty = true;
+    CHK(ensure_records(c));  // meta carries M_SEL; M_PLUS is refreshed below
+    // I:1420-1424: search_all(6.0) over ALL atoms (hydrogens included)
+    CHK(build_atom_grid(c, expand_radius, 0, 0, nullptr));
+    CHK(reset_counters(c));
+    if (c->n > 0) {
+        hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, expand_radius * expand_radius, 1,
+                           (int2*)nullptr, 0ull, c->d_ctr, c->plus.p);
+        CHK(check_launch(c, "k_search<MARK>"));
+    }
+    // I:1413-1437 residue, ring and amide sets
+    const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+    HIPCHK(c, c->res_sel.reserve(nres));
+    HIPCHK(c, c->res_plus.reserve(nres));
+    HIPCHK(c, hipMemsetAsync(c->res_sel.p, 0, nres, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->res_plus.p, 0, nres, c->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
+                           c->res_sel.p, c->res_plus.p);
+    }
+    if (c->nring > 0)
+        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, (int)c->nring, c->ring_res.p,
+                           c->res_sel.p, c->res_plus.p, c->ring_sel.p, c->ring_plus.p);
+    if (c->namide > 0)
+        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, (int)c->namide, c->am_res.p,
+                           c->res_sel.p, c->res_plus.p, c->am_sel.p, c->am_plus.p);
+    CHK(check_launch(c, "selection masks"));
+    c->records_dirty = true;  // M_PLUS changed
+    c->atom_grid.valid = false;
+    c->contacts_valid = false;
+    CHK(download(c, out_plus, c->plus.p, out_plus ? (size_t)n : 0));
+    CHK(download(c, out_ring_sel, c->ring_sel.p, out_ring_sel ? (size_t)c->nring : 0));
+    CHK(download(c, out_ring_plus, c->ring_plus.p, out_ring_plus ? (size_t)c->nring : 0));
+    CHK(download(c, out_amide_sel, c->am_sel.p, out_amide_sel ? (size_t)c->namide : 0));
+    CHK(download(c, out_amide_plus, c->am_plus.p, out_amide_plus ? (size_t)c->namide : 0));
+    return ARP_OK;
+}
+
+// ---- _calculate_atom_contacts -------------------------------------------------------------
+int arp_atom_contacts_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, int64_t* count) {
+    if (!c || !(cutoff > 0)) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_default_selection(c));
+    // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
+    CHK(build_atom_grid(c, cutoff, M_PLUS, M_HYDROGEN, nullptr));
+    const int m = (int)c->n;
+    size_t pcap = c->pairs.cap ? c->pairs.cap : (size_t)m * 16 + 1024;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        HIPCHK(c, c->pairs.reserve(pcap));
+        pcap = c->pairs.cap;
+        CHK(reset_counters(c));
+        if (m > 0) {
+            Prof p(c, SLOT_SEARCH);
+            hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0,
+                               c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
+                               include_sequence_adjacent, c->pairs.p, (unsigned long long)pcap, c->d_ctr, (uint8_t*)nullptr);
+            CHK(check_launch(c, "k_search<CONTACTS>"));
+        }
+        CHK(read_counters(c));
+        if (c->h_ctr.n_pairs <= pcap) break;
+        pcap = (size_t)c->h_ctr.n_pairs;  // regrow and re-run
+        if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_launch: pair buffer could not be sized");
+    }
+    const int64_t np = (int64_t)c->h_ctr.n_pairs;
+    size_t ocap = (size_t)std::max<int64_t>(np, 1);
+    HIPCHK(c, c->out_i.reserve(ocap)); HIPCHK(c, c->out_j.reserve(ocap)); HIPCHK(c, c->out_d.reserve(ocap));
+    HIPCHK(c, c->out_s.reserve(ocap)); HIPCHK(c, c->out_ct.reserve(ocap));
+    if (np > 0) {
+        Prof p(c, SLOT_SIFT);
+        hipLaunchKernelGGL(k_sift, dim3(nblocks(np, 256, 8192)), dim3(256), 0, c->stream, c->pairs.p, (long long)np, c->s_xyzm.p,
+                           c->s_aux.p, c->rad.p, c->bond_off.p, c->bond_idx.p, c->h_off.p, c->h_xyz_d.p, c->sb.p,
+                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p,
+                           c->out_ct.p, &c->d_ctr->err);
+        CHK(check_launch(c, "k_sift"));
+    }
+    CHK(read_counters(c));
+    int binned = 0;
+    CHK(download(c, &binned, c->atom_grid.start.p + c->atom_grid.d.ncell, 1));
+    c->atom_grid.n_binned = binned;
+    collect_events(c);
+    c->n_contacts = np;
+    c->contacts_valid = true;
+    c->stats[0] = (int64_t)c->h_ctr.n_cand;
+    c->stats[1] = (int64_t)c->h_ctr.n_acc;
+    c->stats[2] = np;
+    c->stats[3] = binned;
+    c->stats[4] = c->atom_grid.d.ncell;
+    if (count) *count = np;
+    if (c->h_ctr.err == ARP_E_XBOND_NBR)
+        FAIL(c, ARP_E_XBOND_NBR, "xbond donor without a single-bond heavy neighbour (reference: AttributeError at utils.py:173)");
+    return ARP_OK;
+}
+
+int arp_atom_contacts_fetch(arp_ctx* c, int64_t cap, int32_t* out_i, int32_t* out_j, float* out_dist, uint16_t* out_sift,
+                            uint8_t* out_ctype, int64_t* count) {
+    if (!c || !count) return ARP_E_ARG;
+    if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_atom_contacts_fetch: no launch results");
+    HIPCHK(c, hipSetDevice(c->device));
+    *count = c->n_contacts;
+    if (c->n_contacts > cap) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_fetch: output buffer too small");
+    const size_t k = (size_t)c->n_contacts;
+    CHK(download(c, out_i, c->out_i.p, k)); CHK(download(c, out_j, c->out_j.p, k)); CHK(download(c, out_dist, c->out_d.p, k));
+    CHK(download(c, out_sift, c->out_s.p, k)); CHK(download(c, out_ctype, c->out_ct.p, k));
+    return ARP_OK;
+}
+
+int arp_atom_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, int64_t cap, int32_t* out_i,
+                      int32_t* out_j, float* out_dist, uint16_t* out_sift, uint8_t* out_ctype, int64_t* count) {
+    if (!c || !count) return ARP_E_ARG;
+    CHK(arp_atom_contacts_launch(c, cutoff, vdw_comp, include_sequence_adjacent, count));
+    return arp_atom_contacts_fetch(c, cap, out_i, out_j, out_dist, out_sift, out_ctype, count);
+}
+
+// ---- ring / amide contacts ------------------------------------------------------------------
+int arp_atom_plane(arp_ctx* c, int64_t cap, int32_t* out_atom, int32_t* out_ring, double* out_dist, double* out_theta,
+                   uint8_t* out_mask, uint8_t* out_ctype, int64_t* count) {
+    if (!c || !count || cap < 0) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_default_selection(c));
+    *count = 0;
+    if (c->nring == 0 || c->n == 0) return ARP_OK;
+    CHK(build_atom_grid(c, 6.0, M_PLUS, M_HYDROGEN, nullptr));  // I:960 radius
+    c->atom_grid.valid = false;
+    const size_t k = (size_t)std::max<int64_t>(cap, 1);
+    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_d0.reserve(k)); HIPCHK(c, c->po_d1.reserve(k));
+    HIPCHK(c, c->po_u0.reserve(k)); HIPCHK(c, c->po_u1.reserve(k));
+    CHK(reset_counters(c));
+    hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
+                       c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p,
+                       c->ring_plus.p, c->has_gid ? c->gid.p : nullptr, (long long)cap, c->po_a.p, c->po_b.p, c->po_d0.p,
+                       c->po_d1.p, c->po_u0.p, c->po_u1.p, c->d_ctr);
+    CHK(check_launch(c, "k_atom_plane"));
+    CHK(read_counters(c));
+    *count = (int64_t)c->h_ctr.n_out;
+    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_atom_plane: output buffer too small");
+    const size_t m = (size_t)*count;
+    CHK(download(c, out_atom, c->po_a.p, m)); CHK(download(c, out_ring, c->po_b.p, m)); CHK(download(c, out_dist, c->po_d0.p, m));
+    CHK(download(c, out_theta, c->po_d1.p, m)); CHK(download(c, out_mask, c->po_u0.p, m)); CHK(download(c, out_ctype, c->po_u1.p, m));
+    return ARP_OK;
+}
+
+int arp_plane_plane(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, double* out_dist, double* out_dihedral,
+                    double* out_theta_bgn, double* out_theta_end, uint8_t* out_type1, uint8_t* out_type2, uint8_t* out_ctype,
+                    int64_t* count) {
+    if (!c || !count || cap < 0) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_default_selection(c));
+    *count = 0;
+    if (c->nring == 0) return ARP_OK;
+    CHK(ensure_ring_grid(c));
+    const size_t k = (size_t)std::max<int64_t>(cap, 1);
+    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_d0.reserve(k)); HIPCHK(c, c->po_d1.reserve(k));
+    HIPCHK(c, c->po_d2.reserve(k)); HIPCHK(c, c->po_d3.reserve(k)); HIPCHK(c, c->po_u0.reserve(k)); HIPCHK(c, c->po_u1.reserve(k));
+    HIPCHK(c, c->po_u2.reserve(k));
+    CHK(reset_counters(c));
+    hipLaunchKernelGGL(k_plane_plane, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
+                       c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p, c->ring_plus.p,
+                       (long long)cap, c->po_a.p, c->po_b.p, c->po_d0.p, c->po_d1.p, c->po_d2.p, c->po_d3.p, c->po_u0.p,
+                       c->po_u1.p, c->po_u2.p, c->d_ctr);
+    CHK(check_launch(c, "k_plane_plane"));
+    CHK(read_counters(c));
+    *count = (int64_t)c->h_ctr.n_out;
+    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_plane_plane: output buffer too small");
+    const size_t m = (size_t)*count;
+    CHK(download(c, out_bgn, c->po_a.p, m)); CHK(download(c, out_end, c->po_b.p, m)); CHK(download(c, out_dist, c->po_d0.p, m));
+    CHK(download(c, out_dihedral, c->po_d1.p, m)); CHK(download(c, out_theta_bgn, c->po_d2.p, m));
+    CHK(download(c, out_theta_end, c->po_d3.p, m)); CHK(download(c, out_type1, c->po_u0.p, m));
+    CHK(download(c, out_type2, c->po_u1.p, m)); CHK(download(c, out_ctype, c->po_u2.p, m));
+    return ARP_OK;
+}
+
+int arp_group_group(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, float* out_dist, float* out_dihedral,
+                    float* out_theta, uint8_t* out_ctype, int64_t* count) {
+    if (!c || !count || cap < 0) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_default_selection(c));
+    *count = 0;
+    if (c->namide == 0) return ARP_OK;
+    CHK(ensure_amide_grid(c));
+    const size_t k = (size_t)std::max<int64_t>(cap, 1);
+    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_f0.reserve(k)); HIPCHK(c, c->po_f1.reserve(k));
+    HIPCHK(c, c->po_f2.reserve(k)); HIPCHK(c, c->po_u0.reserve(k));
+    CHK(reset_counters(c));
+    hipLaunchKernelGGL(k_group_group, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->amide_grid.d, c->amide_grid.start.p,
+                       c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, (long long)cap,
+                       c->po_a.p, c->po_b.p, c->po_f0.p, c->po_f1.p, c->po_f2.p, c->po_u0.p, c->d_ctr);
+    CHK(check_launch(c, "k_group_group"));
+    CHK(read_counters(c));
+    *count = (int64_t)c->h_ctr.n_out;
+    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_group_group: output buffer too small");
+    const size_t m = (size_t)*count;
+    CHK(download(c, out_bgn, c->po_a.p, m)); CHK(download(c, out_end, c->po_b.p, m)); CHK(download(c, out_dist, c->po_f0.p, m));
+    CHK(download(c, out_dihedral, c->po_f1.p, m)); CHK(download(c, out_theta, c->po_f2.p, m)); CHK(download(c, out_ctype, c->po_u0.p, m));
+    return ARP_OK;
+}
+
+int arp_group_plane(arp_ctx* c, int64_t cap, int32_t* out_amide, int32_t* out_ring, double* out_dist, double* out_dihedral,
+                    double* out_theta, uint8_t* out_ctype, int64_t* count) {
+    if (!c || !count || cap < 0) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_default_selection(c));
+    *count = 0;
+    if (c->namide == 0 || c->nring == 0) return ARP_OK;
+    CHK(ensure_ring_grid(c));
+    const size_t k = (size_t)std::max<int64_t>(cap, 1);
+    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_d0.reserve(k)); HIPCHK(c, c->po_d1.reserve(k));
+    HIPCHK(c, c->po_d2.reserve(k)); HIPCHK(c, c->po_u0.reserve(k));
+    CHK(reset_counters(c));
+    hipLaunchKernelGGL(k_group_plane, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
+                       c->ring_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, c->ring_c.p,
+                       c->ring_n.p, c->ring_sel.p, c->ring_plus.p, (long long)cap, c->po_a.p, c->po_b.p, c->po_d0.p, c->po_d1.p,
+                       c->po_d2.p, c->po_u0.p, c->d_ctr);
+    CHK(check_launch(c, "k_group_plane"));
+    CHK(read_counters(c));
+    *count = (int64_t)c->h_ctr.n_out;
+    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_group_plane: output buffer too small");
+    const size_t m = (size_t)*count;
+    CHK(download(c, out_amide, c->po_a.p, m)); CHK(download(c, out_ring, c->po_b.p, m)); CHK(download(c, out_dist, c->po_d0.p, m));
+    CHK(download(c, out_dihedral, c->po_d1.p, m)); CHK(download(c, out_theta, c->po_d2.p, m)); CHK(download(c, out_ctype, c->po_u0.p, m));
+    return ARP_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------
+int arp_get_stats(arp_ctx* c, int64_t stats[8]) {
+    if (!c || !stats) return ARP_E_ARG;
+    for (int k = 0; k < 8; ++k) stats[k] = c->stats[k];
+    return ARP_OK;
+}
+
+int arp_set_profiling(arp_ctx* c, int enabled) {
+    if (!c) return ARP_E_ARG;
+    c->profiling = enabled != 0;
+    return ARP_OK;
+}
+
+int arp_get_kernel_times(arp_ctx* c, double ms[8], int64_t launches[8], int reset) {
+    if (!c || !ms || !launches) return ARP_E_ARG;
+    for (int k = 0; k < NSLOT; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
+    if (reset) for (int k = 0; k < NSLOT; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+    return ARP_OK;
+}
+
+uint64_t arp_stream_handle(arp_ctx* c) { return c ? (uint64_t)(uintptr_t)c->stream : 0; }
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// arp_grid.h — uniform spatial-hash grid: binning, counting sort, cell ordering.
+//
+// Stands in for Bio.PDB.NeighborSearch's KD-tree build (interactions.py:1394,1442).
+// Points are binned in float64 with a cell edge >= the search radius, so every pair
+// within the radius lies in a 27-cell stencil.  The sort is a counting sort:
+//   k_bin      cell id per point + histogram (atomicAdd on the cell counter)
+//   k_scan_*   exclusive prefix sum of the histogram (3-phase, LDS block scan)
+//   k_scatter  point -> slot inside its cell (atomicSub on the same counter)
+//   k_cellsort ascending point id inside each cell (deterministic order)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "arp_numerics.h"
+
+struct GridDesc {
+    double ox, oy, oz, inv;
+    int nx, ny, nz, ncell;
+};
+
+struct PtsF4 {  // float4 records (atoms)
+    const float4* p;
+    __device__ __forceinline__ num::d3 get(int i) const {
+        float4 v = p[i];
+        return {(double)v.x, (double)v.y, (double)v.z};
+    }
+};
+struct PtsF3 {  // packed float32[3] (amide centres)
+    const float* p;
+    __device__ __forceinline__ num::d3 get(int i) const {
+        return {(double)p[3 * (size_t)i], (double)p[3 * (size_t)i + 1], (double)p[3 * (size_t)i + 2]};
+    }
+};
+struct PtsD3 {  // packed float64[3] (ring centres)
+    const double* p;
+    __device__ __forceinline__ num::d3 get(int i) const {
+        return {p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2]};
+    }
+};
+
+// Unclamped integer cell coordinate (can be -1 or n for points outside the box).
+__device__ __forceinline__ int cell_coord_raw(double v, double o, double inv, int n) {
+    double t = floor((v - o) * inv);
+    t = fmin(fmax(t, -2.0), (double)n + 1.0);
+    return (int)t;
+}
+__device__ __forceinline__ int cell_coord(double v, double o, double inv, int n) {
+    int c = cell_coord_raw(v, o, inv, n);
+    return min(max(c, 0), n - 1);
+}
+__device__ __forceinline__ int cell_index(const GridDesc& g, num::d3 p) {
+    int cx = cell_coord(p.x, g.ox, g.inv, g.nx);
+    int cy = cell_coord(p.y, g.oy, g.inv, g.ny);
+    int cz = cell_coord(p.z, g.oz, g.inv, g.nz);
+    return (cz * g.ny + cy) * g.nx + cx;
+}
+
+// FILTER: 0 = every point, 1 = active[i] != 0, 2 = (meta & req) == req && !(meta & forb)
+template <class P, int FILTER>
+__global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, const uint8_t* __restrict__ active,
+                                             const float4* __restrict__ xyzm, uint32_t req, uint32_t forb,
+                                             int* __restrict__ cell_of, int* __restrict__ cell_cnt) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        bool on = true;
+        if (FILTER == 1) on = active[i] != 0;
+        if (FILTER == 2) {
+            uint32_t m = __float_as_uint(xyzm[i].w);
+            on = ((m & req) == req) && !(m & forb);
+        }
+        int c = -1;
+        if (on) {
+            c = cell_index(g, pts.get(i));
+            atomicAdd(&cell_cnt[c], 1);
+        }
+        cell_of[i] = c;
+    }
+}
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+// Phase A: exclusive scan inside tiles of SCAN_TILE counters; tile totals to block_sums.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const int* __restrict__ in, int n, int* __restrict__ out,
+                                                              int* __restrict__ block_sums) {
+    __shared__ int sh[SCAN_THREADS];
+    int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        sum += v[k];
+    }
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - sum;  // exclusive prefix of this thread
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+}
+
+// Phase B: one block scans the tile totals in place (exclusive); total -> sums[nb].
+__global__ __launch_bounds__(1024) void k_scan_top(int* __restrict__ sums, int nb) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = (i < nb) ? sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int c = carry;
+        if (i < nb) sums[i] = c + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = carry;
+}
+
+// Phase C: add tile offsets; out[n] = grand total.
+__global__ __launch_bounds__(256) void k_scan_add(int* __restrict__ out, int n, const int* __restrict__ sums, int nb) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += sums[i / SCAN_TILE];
+    if (i == n) out[n] = sums[nb];
+}
+
+__global__ __launch_bounds__(256) void k_scatter(int n, const int* __restrict__ cell_of, const int* __restrict__ start,
+                                                 int* __restrict__ cell_cnt, int* __restrict__ perm) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int c = cell_of[i];
+        if (c >= 0) {
+            int slot = atomicSub(&cell_cnt[c], 1) - 1;
+            perm[start[c] + slot] = i;
+        }
+    }
+}
+
+// ascending point id inside every cell (cells hold a handful of points)
+__global__ __launch_bounds__(256) void k_cellsort(int ncell, const int* __restrict__ start, int* __restrict__ perm) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
+        int s = start[c], e = start[c + 1];
+        for (int a = s + 1; a < e; ++a) {
+            int v = perm[a];
+            int b = a - 1;
+            while (b >= s && perm[b] > v) {
+                perm[b + 1] = perm[b];
+                --b;
+            }
+            perm[b + 1] = v;
+        }
+    }
+}
+
+// sorted (cell-ordered) copies of the atom records: coalesced writes, gathered reads.
+// The number of binned points is read on the device (start[ncell]) so that the host does
+// not have to synchronise between the sort and the search.
+__global__ __launch_bounds__(256) void k_gather(const int* __restrict__ m_ptr, const int* __restrict__ perm,
+                                                const float4* __restrict__ xyzm, const int4* __restrict__ aux,
+                                                float4* __restrict__ s_xyzm, int4* __restrict__ s_aux) {
+    const int m = *m_ptr;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) {
+        int i = perm[p];
+        s_xyzm[p] = xyzm[i];
+        s_aux[p] = aux[i];
+    }
+}

@@ -1,0 +1,405 @@
+// arp_pairs.h — neighbour search over the cell-sorted atoms and the fused per-pair
+// SIFt kernel.
+//
+//   k_search  = NeighborSearch.search_all (interactions.py:707, 1420) + the residue
+//               filters of interactions.py:712-741, wave-ballot compaction.
+//   k_sift    = the body of _calculate_atom_contacts' loop (interactions.py:715-936)
+//               with utils.is_hbond / is_weak_hbond / is_halogen_weak_hbond / is_xbond
+//               (utils.py:73-179) and __get_contact_type (interactions.py:643-691).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/arpeggio_hip.h"
+#include "arp_grid.h"
+#include "arp_numerics.h"
+
+// ---- meta word (float4.w of an atom record) ---------------------------------------
+#define M_TMASK 0xFFFu
+#define M_FLAG_SHIFT 12
+#define M_METAL (1u << 12)
+#define M_HALOGEN (1u << 13)
+#define M_WATER (1u << 14)
+#define M_HYDROGEN (1u << 15)
+#define M_ELEM_C (1u << 16)
+#define M_ELEM_S (1u << 17)
+#define M_RES_MET (1u << 18)
+#define M_SEL (1u << 19)
+#define M_PLUS (1u << 20)
+#define M_RES_POLY (1u << 21)
+#define M_RES_HASSEQ (1u << 22)
+#define M_HOME (1u << 24)
+
+struct Counters {
+    unsigned long long n_pairs;  // pairs enqueued (after residue filters)
+    unsigned long long n_cand;   // distance tests performed
+    unsigned long long n_acc;    // pairs with d^2 <= r^2
+    unsigned long long n_out;    // generic output counter (plane kernels)
+    int err;                     // ARP_E_* raised on the device
+    int pad;
+};
+
+// atom records: xyzm = {x, y, z, meta}; aux = {local id, residue, prev residue, next residue}
+__global__ __launch_bounds__(256) void k_build_records(int n, const float4* __restrict__ xyz, const uint16_t* __restrict__ tmask,
+                                                       const uint16_t* __restrict__ flags, const int* __restrict__ res_id,
+                                                       const uint8_t* __restrict__ res_flags, const int* __restrict__ res_prev,
+                                                       const int* __restrict__ res_next, const uint8_t* __restrict__ sel,
+                                                       const uint8_t* __restrict__ plus, const uint8_t* __restrict__ home,
+                                                       float4* __restrict__ xyzm, int4* __restrict__ aux) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = xyz[i];
+        int r = res_id[i];
+        uint32_t m = (uint32_t)(tmask[i] & M_TMASK) | ((uint32_t)(flags[i] & 0x7F) << M_FLAG_SHIFT);
+        if (sel && sel[i]) m |= M_SEL;
+        if (!plus || plus[i]) m |= M_PLUS;
+        if (!home || home[i]) m |= M_HOME;
+        uint8_t rf = res_flags ? res_flags[r] : 0;
+        if (rf & ARP_R_POLYPEPTIDE) m |= M_RES_POLY;
+        if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
+        v.w = __uint_as_float(m);
+        xyzm[i] = v;
+        aux[i] = make_int4(i, r, res_prev ? res_prev[r] : -1, res_next ? res_next[r] : -1);
+    }
+}
+
+// ---- neighbour search ---------------------------------------------------------------
+#define SEARCH_WAVES 4
+#define QCAP 512
+
+enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
+
+// One wavefront per home cell.  Lanes hold the atoms of a neighbour range in registers
+// (coalesced float4 loads of the cell-sorted records), the home atoms are wave-uniform,
+// so each neighbour record is loaded once per home cell and reused for every home atom.
+// Half stencil: own cell (later entries) + 13 forward cells, expressed as 5 contiguous
+// ranges of the sorted array (cells are x-fastest, so 3 x-neighbours are contiguous).
+// Accepted pairs are compacted with __ballot into a per-wave LDS queue that is flushed
+// to global memory with one atomicAdd per ~QCAP pairs.
+template <int MODE>
+__global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
+                                                               const float4* __restrict__ s_xyzm,
+                                                               const int4* __restrict__ s_aux, double r2,
+                                                               int include_seq_adj, int2* __restrict__ pairs,
+                                                               unsigned long long cap, Counters* __restrict__ ctr,
+                                                               uint8_t* __restrict__ plus) {
+    __shared__ int2 q[SEARCH_WAVES][QCAP];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    // XCD-aware remap: blocks that land on one XCD (b % 8) walk a contiguous run of cells,
+    // so the 26 neighbour cells of a home cell are mostly served by that XCD's L2.
+    const int nb = gridDim.x;
+    const int per = nb >> 3;
+    int vb = blockIdx.x;
+    if (per > 0 && blockIdx.x < per * 8) vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int nwave = nb * SEARCH_WAVES;
+    const int cells_per_wave = (g.ncell + nwave - 1) / nwave;
+    const int c_begin = (vb * SEARCH_WAVES + w) * cells_per_wave;
+    const int c_end = min(c_begin + cells_per_wave, g.ncell);
+
+    int qn = 0;
+    unsigned long long n_cand = 0, n_acc = 0;
+
+    auto flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->n_pairs, (unsigned long long)qn);
+        base = __shfl(base, 0);
+        for (int k = lane; k < qn; k += 64)
+            if (base + k < cap) pairs[base + k] = q[w][k];
+        __builtin_amdgcn_wave_barrier();
+        qn = 0;
+    };
+
+    for (int cell = c_begin; cell < c_end; ++cell) {
+        const int hs = __builtin_amdgcn_readfirstlane(start[cell]);
+        const int he = __builtin_amdgcn_readfirstlane(start[cell + 1]);
+        if (hs == he) continue;
+        const int cz = cell / (g.nx * g.ny);
+        const int rem = cell - cz * g.nx * g.ny;
+        const int cy = rem / g.nx;
+        const int cx = rem - cy * g.nx;
+#pragma unroll 1
+        for (int hb = hs; hb < he; hb += 64) {  // home atoms, 64 at a time, one per lane
+            const int hcount = min(64, he - hb);
+            const bool hvalid = lane < hcount;
+            const float4 hreg = hvalid ? s_xyzm[hb + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            int4 hauxreg = make_int4(0, 0, 0, 0);
+            if (MODE != MODE_PAIRS && hvalid) hauxreg = s_aux[hb + lane];
+            if (MODE == MODE_PAIRS && hvalid) hauxreg.x = s_aux[hb + lane].x;
+#pragma unroll 1
+            for (int r = 0; r < 5; ++r) {
+                // (dy, dz) of the 5 ranges: home pencil, then the 4 forward pencils
+                const int dy = (r == 0) ? 0 : (r == 1) ? 1 : (r - 3);
+                const int dz = (r <= 1) ? 0 : 1;
+                const int y2 = cy + dy, z2 = cz + dz;
+                if (y2 < 0 || y2 >= g.ny || z2 >= g.nz) continue;
+                const int rowbase = (z2 * g.ny + y2) * g.nx;
+                const int xlo = (r == 0) ? cx : max(cx - 1, 0);
+                const int xhi = min(cx + 1, g.nx - 1);
+                const int js = (r == 0) ? hb : __builtin_amdgcn_readfirstlane(start[rowbase + xlo]);
+                const int je = __builtin_amdgcn_readfirstlane(start[rowbase + xhi + 1]);
+#pragma unroll 1
+                for (int jb = js; jb < je; jb += 64) {
+                    const int j = jb + lane;
+                    const bool valid = j < je;
+                    const float4 xj = valid ? s_xyzm[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    int4 aj = make_int4(0, 0, 0, 0);
+                    if (MODE != MODE_PAIRS && valid) aj = s_aux[j];
+                    if (MODE == MODE_PAIRS && valid) aj.x = s_aux[j].x;
+                    const num::d3 pj = {(double)xj.x, (double)xj.y, (double)xj.z};
+                    const uint32_t mj = __float_as_uint(xj.w);
+                    // in range 0 only later entries of the sorted array (j > h) pair up
+                    const int hh_end = (r == 0) ? min(hcount, jb + 64 - hb) : hcount;
+#pragma unroll 1
+                    for (int hh = 0; hh < hh_end; ++hh) {
+                        const int h = hb + hh;
+                        // broadcast the home atom from lane hh (v_readlane, no memory traffic)
+                        const num::d3 ph = {(double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh)),
+                                            (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh)),
+                                            (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.z), hh))};
+                        const bool tested = valid && (r != 0 || j > h);
+                        const bool hit = tested && (num::dist2_kd(ph, pj) <= r2);
+                        n_cand += __popcll(__ballot(tested));
+                        const unsigned long long mhit = __ballot(hit);
+                        if (mhit == 0) continue;
+                        n_acc += __popcll(mhit);
+                        const uint32_t mh = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
+                        const int4 ah = make_int4(__builtin_amdgcn_readlane(hauxreg.x, hh), __builtin_amdgcn_readlane(hauxreg.y, hh),
+                                                  __builtin_amdgcn_readlane(hauxreg.z, hh), __builtin_amdgcn_readlane(hauxreg.w, hh));
+                        if (MODE == MODE_MARK) {
+                            // interactions.py:1420-1424: either atom selected -> both join selection_plus
+                            if (hit && ((mh | mj) & M_SEL)) {
+                                plus[aj.x] = 1;
+                                plus[ah.x] = 1;
+                            }
+                            continue;
+                        }
+                        bool pass = hit;
+                        int pb, pe;
+                        if (MODE == MODE_CONTACTS) {
+                            // canonical orientation: bgn = lower packed index
+                            const bool h_first = ah.x < aj.x;
+                            const int4 ab = h_first ? ah : aj;
+                            const int4 ae = h_first ? aj : ah;
+                            const uint32_t mb = h_first ? mh : mj;
+                            const uint32_t me = h_first ? mj : mh;
+                            pb = h_first ? h : j;
+                            pe = h_first ? j : h;
+                            // interactions.py:729 same residue
+                            if (ab.y == ae.y) pass = false;
+                            // interactions.py:733-741 sequence-adjacent residues (res_end tested twice)
+                            if (!include_seq_adj && (me & M_RES_POLY) && (mb & M_RES_HASSEQ) && (me & M_RES_HASSEQ)) {
+                                if (ab.w == ae.y || ab.z == ae.y || ae.w == ab.y || ae.z == ab.y) pass = false;
+                            }
+                            // multi-GPU ownership: the rank owning the bgn atom emits the pair
+                            if (!(mb & M_HOME)) pass = false;
+                        } else {  // MODE_PAIRS: raw search_all, report packed ids (i < j)
+                            pb = min(ah.x, aj.x);
+                            pe = max(ah.x, aj.x);
+                        }
+                        const unsigned long long mp = __ballot(pass);
+                        if (mp) {
+                            if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
+                            qn += __popcll(mp);
+                            if (qn > QCAP - 64) flush();
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (MODE != MODE_MARK && qn > 0) flush();
+    if (lane == 0) {
+        atomicAdd(&ctr->n_cand, n_cand);
+        atomicAdd(&ctr->n_acc, n_acc);
+    }
+}
+
+// ---- per-pair SIFt --------------------------------------------------------------------
+__device__ __forceinline__ num::f3 xyz_of(float4 v) { return {v.x, v.y, v.z}; }
+
+// utils.is_hbond (utils.py:73-93, angle_min 1.57) / is_weak_hbond (utils.py:96-116, 2.27)
+__device__ __forceinline__ bool hbond_like(num::f3 donor, const double* __restrict__ hx, int h0, int h1, num::f3 acc,
+                                           double acc_vdw, double comp, double angle_min) {
+    const num::d3 d = num::to_d3(donor), a = num::to_d3(acc);
+    const double thr = 1.2 + acc_vdw + comp;  // config.VDW_RADII['H'] + vdw + comp
+    for (int k = h0; k < h1; ++k) {
+        const num::d3 h = {hx[3 * (size_t)k], hx[3 * (size_t)k + 1], hx[3 * (size_t)k + 2]};
+        const double h_dist = num::norm(num::sub(h, a));
+        if (h_dist <= thr) {
+            if (num::get_angle(d, h, a) >= angle_min) return true;
+        }
+    }
+    return false;
+}
+
+// utils.is_halogen_weak_hbond (utils.py:119-155); sbh = single-bond neighbour of the halogen
+__device__ __forceinline__ bool halogen_weak(num::f3 hal, float4 sbh, double hal_vdw, const double* __restrict__ hx,
+                                             int h0, int h1, double comp) {
+    if (sbh.w == 0.0f) return false;  // utils.py:139-141
+    const num::d3 hd = num::to_d3(hal);
+    const num::f3 nbr = {sbh.x, sbh.y, sbh.z};
+    const double thr = 1.2 + hal_vdw + comp;
+    for (int k = h0; k < h1; ++k) {
+        const num::d3 h = {hx[3 * (size_t)k], hx[3 * (size_t)k + 1], hx[3 * (size_t)k + 2]};
+        const double h_dist = num::norm(num::sub(hd, h));
+        if (h_dist <= thr) {
+            const double ang = num::get_angle_mixed(nbr, hal, h);
+            if (0.52 <= ang && ang <= 2.62) return true;
+        }
+    }
+    return false;
+}
+
+// utils.is_xbond (utils.py:158-179); float32 end to end
+__device__ __forceinline__ bool xbond(float4 sbd, num::f3 donor, num::f3 acc, int* err) {
+    if (sbd.w == 0.0f) {  // utils.py:173 would dereference None
+        atomicExch(err, ARP_E_XBOND_NBR);
+        return false;
+    }
+    bool nan_pi;
+    const float theta = num::get_angle(num::f3{sbd.x, sbd.y, sbd.z}, donor, acc, nan_pi);
+    if (nan_pi) return true;  // np.pi >= 2.09
+    return theta >= (float)2.09;
+}
+
+// interactions.py:643-691
+__device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) {
+    int ct = 0;
+    if (!bs && !es) ct = ARP_CT_INTRA_NON_SELECTION;
+    if (bs && es) ct = ARP_CT_INTRA_SELECTION;
+    if ((bs && !es) || (es && !bs)) ct = ARP_CT_INTER;
+    if ((bs && ew) || (es && bw)) ct = ARP_CT_SELECTION_WATER;
+    if ((!bs && ew) || (!es && bw)) ct = ARP_CT_NON_SELECTION_WATER;
+    if (bw && ew) ct = ARP_CT_WATER_WATER;
+    return ct;
+}
+
+// One thread per accepted pair (full 64-lane occupancy for the divergent chemistry).
+__global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, long long npairs,
+                                              const float4* __restrict__ s_xyzm, const int4* __restrict__ s_aux,
+                                              const double2* __restrict__ rad, const int* __restrict__ bond_off,
+                                              const int* __restrict__ bond_idx, const int* __restrict__ h_off,
+                                              const double* __restrict__ h_xyz, const float4* __restrict__ sb,
+                                              const int* __restrict__ gid, double comp, int* __restrict__ out_i,
+                                              int* __restrict__ out_j, float* __restrict__ out_d,
+                                              uint16_t* __restrict__ out_s, uint8_t* __restrict__ out_ct,
+                                              int* __restrict__ err) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npairs;
+         p += (long long)gridDim.x * blockDim.x) {
+        const int2 pr = pairs[p];
+        const float4 vb = s_xyzm[pr.x], ve = s_xyzm[pr.y];
+        const int b = s_aux[pr.x].x, e = s_aux[pr.y].x;
+        const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
+        const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
+        const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
+        const bool bw = mb & M_WATER, ew = me & M_WATER;
+        const int ct = contact_type(mb & M_SEL, me & M_SEL, bw, ew);  // interactions.py:715
+        const double2 rb = rad[b], re = rad[e];                         // {vdw, cov}
+        const double sum_cov = rb.y + re.y, sum_vdw = rb.x + re.x;      // interactions.py:717-718
+        const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
+        uint32_t s = 0;
+        // interactions.py:748-757: end among the bonded neighbours of bgn
+        bool cov = false;
+        for (int k = bond_off[b], k1 = bond_off[b + 1]; k < k1; ++k)
+            if (bond_idx[k] == e) { cov = true; break; }
+        // interactions.py:756-773: float32 distance against Python floats -> float32 compare
+        const double vdw_comp = sum_vdw + comp;
+        const float f_vdw_comp = (float)vdw_comp;
+        if (cov) s |= ARP_S_COVALENT;
+        else if (d < (float)sum_cov) s |= ARP_S_CLASH;
+        else if (d < (float)sum_vdw) s |= ARP_S_VDW_CLASH;
+        else if (d <= f_vdw_comp) s |= ARP_S_VDW;
+        else s |= ARP_S_PROXIMAL;
+        // interactions.py:777-783
+        if (d <= (float)2.8) {
+            if ((tb & ARP_T_HBOND_ACCEPTOR) && (me & M_METAL)) s |= ARP_S_METAL_COMPLEX;
+            else if ((te & ARP_T_HBOND_ACCEPTOR) && (mb & M_METAL)) s |= ARP_S_METAL_COMPLEX;
+        }
+        // interactions.py:786: not clash (covalent pairs do get feature flags) and d <= 4.5
+        if (!(s & ARP_S_CLASH) && d <= (float)4.5) {
+            const int hb0 = h_off[b], hb1 = h_off[b + 1], he0 = h_off[e], he1 = h_off[e + 1];
+            // interactions.py:791-819
+            if (bw && d <= f_vdw_comp) {
+                if (te & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
+            } else if (ew && d <= f_vdw_comp) {
+                if (tb & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
+            } else {
+                if ((tb & ARP_T_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) {
+                    if (hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 1.57)) s |= ARP_S_HBOND;
+                    if (d <= (float)3.5) s |= ARP_S_POLAR;
+                } else if ((te & ARP_T_HBOND_DONOR) && (tb & ARP_T_HBOND_ACCEPTOR)) {
+                    if (hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 1.57)) s |= ARP_S_HBOND;
+                    if (d <= (float)3.5) s |= ARP_S_POLAR;
+                }
+            }
+            // interactions.py:857-886: four independent ifs, each overwrites SIFt[6]
+            bool weak = false;
+            const bool wp = d <= (float)3.5;
+            if ((tb & ARP_T_HBOND_ACCEPTOR) && (te & ARP_T_WEAK_HBOND_DONOR)) {
+                weak = hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 2.27);
+                if (wp) s |= ARP_S_WEAK_POLAR;
+            }
+            if ((tb & ARP_T_WEAK_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) {
+                weak = hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 2.27);
+                if (wp) s |= ARP_S_WEAK_POLAR;
+            }
+            if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) &&
+                (te & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) {
+                weak = halogen_weak(xb, sb[b], rb.x, h_xyz, he0, he1, comp);
+                if (wp) s |= ARP_S_WEAK_POLAR;
+            }
+            if ((te & ARP_T_WEAK_HBOND_ACCEPTOR) && (me & M_HALOGEN) &&
+                (tb & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) {
+                weak = halogen_weak(xe, sb[e], re.x, h_xyz, hb0, hb1, comp);
+                if (wp) s |= ARP_S_WEAK_POLAR;
+            }
+            if (weak) s |= ARP_S_WEAK_HBOND;
+            // interactions.py:889-895
+            if (d <= f_vdw_comp) {
+                if ((tb & ARP_T_XBOND_DONOR) && (te & ARP_T_XBOND_ACCEPTOR)) {
+                    if (xbond(sb[b], xb, xe, err)) s |= ARP_S_XBOND;
+                } else if ((te & ARP_T_XBOND_DONOR) && (tb & ARP_T_XBOND_ACCEPTOR)) {
+                    if (xbond(sb[e], xe, xb, err)) s |= ARP_S_XBOND;
+                }
+            }
+            // interactions.py:898-904
+            if (d <= (float)4.0) {
+                if ((tb & ARP_T_POS_IONISABLE) && (te & ARP_T_NEG_IONISABLE)) s |= ARP_S_IONIC;
+                else if ((tb & ARP_T_NEG_IONISABLE) && (te & ARP_T_POS_IONISABLE)) s |= ARP_S_IONIC;
+            }
+            // interactions.py:907-913
+            if (d <= (float)3.6) {
+                if ((tb & ARP_T_CARBONYL_OXYGEN) && (te & ARP_T_CARBONYL_CARBON)) s |= ARP_S_CARBONYL;
+                else if ((te & ARP_T_CARBONYL_OXYGEN) && (tb & ARP_T_CARBONYL_CARBON)) s |= ARP_S_CARBONYL;
+            }
+            // interactions.py:916-917, 920-921
+            if ((tb & te & ARP_T_AROMATIC) && d <= (float)4.0) s |= ARP_S_AROMATIC;
+            if ((tb & te & ARP_T_HYDROPHOBE) && d <= (float)4.5) s |= ARP_S_HYDROPHOBIC;
+        }
+        out_i[p] = gid ? gid[b] : b;
+        out_j[p] = gid ? gid[e] : e;
+        out_d[p] = d;
+        out_s[p] = (uint16_t)s;
+        out_ct[p] = (uint8_t)ct;
+    }
+}
+
+// residue / ring / amide membership of _make_selection (interactions.py:1413-1437)
+__global__ __launch_bounds__(256) void k_res_mark(int n, const int* __restrict__ res_id, const uint8_t* __restrict__ sel,
+                                                  const uint8_t* __restrict__ plus, uint8_t* __restrict__ res_sel,
+                                                  uint8_t* __restrict__ res_plus) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (sel[i]) res_sel[res_id[i]] = 1;
+        if (plus[i]) res_plus[res_id[i]] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_group_mask(int m, const int* __restrict__ grp_res, const uint8_t* __restrict__ res_sel,
+                                                    const uint8_t* __restrict__ res_plus, uint8_t* __restrict__ g_sel,
+                                                    uint8_t* __restrict__ g_plus) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        int r = grp_res[i];
+        g_sel[i] = (r >= 0 && res_sel[r]) ? 1 : 0;    // a ring whose residue is None never qualifies
+        g_plus[i] = (r >= 0 && res_plus[r]) ? 1 : 0;
+    }
+}
