@@ -24,6 +24,9 @@ SYMBOLS = (
     'arp_search_all', 'arp_make_selection', 'arp_atom_contacts_launch', 'arp_atom_contacts_fetch',
     'arp_atom_contacts', 'arp_atom_plane', 'arp_plane_plane', 'arp_group_group', 'arp_group_plane',
     'arp_set_ownership', 'arp_get_stats', 'arp_set_profiling', 'arp_get_kernel_times', 'arp_stream_handle',
+    'arp_set_selection', 'arp_run_launch', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
+    'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
+    'arp_group_plane_fetch',
 )
 
 _lib = None
@@ -64,6 +67,11 @@ def load():
     L.arp_group_group.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_group_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_set_ownership.argtypes = [vp, vp, vp]
+    L.arp_set_selection.argtypes = [vp, vp]
+    L.arp_run_launch.argtypes = [vp, dbl, dbl, i32, dbl, vp]
+    for nm in ('atom_plane', 'plane_plane', 'group_group', 'group_plane'):
+        getattr(L, f'arp_{nm}_launch').argtypes = [vp, C.POINTER(i64)]
+        getattr(L, f'arp_{nm}_fetch').argtypes = getattr(L, f'arp_{nm}').argtypes
     L.arp_get_stats.argtypes = [vp, vp]
     L.arp_set_profiling.argtypes = [vp, i32]
     L.arp_get_kernel_times.argtypes = [vp, vp, vp, i32]
@@ -81,7 +89,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-KERNEL_SLOTS = ('bin', 'scan', 'scatter_cellsort', 'gather', 'search', 'sift')
+KERNEL_SLOTS = ('bin', 'scan', 'scatter_cellsort', 'gather', 'search', 'sift', 'mark_search', 'planes')
 
 
 class Context:
@@ -156,6 +164,20 @@ class Context:
             o = np.lexsort((oj[:k], oi[:k]))
             return oi[:k][o], oj[:k][o]
 
+    def set_selection(self, in_selection):
+        sel = np.ascontiguousarray(in_selection, np.uint8)
+        if sel.shape != (self.n,):
+            raise ValueError('in_selection must have one entry per atom')
+        self._check(self._L.arp_set_selection(self._h, _p(sel)), 'arp_set_selection')
+
+    def run_launch(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, expand_radius=6.0):
+        """run_arpeggio on the resident structure; results stay in HBM.  Returns the five bag sizes."""
+        counts = np.zeros(5, np.int64)
+        self._check(self._L.arp_run_launch(self._h, float(cutoff), float(vdw_comp), int(bool(include_sequence_adjacent)),
+                                           float(expand_radius), _p(counts)), 'arp_run_launch')
+        return dict(atom_atom=int(counts[0]), plane_plane=int(counts[1]), atom_plane=int(counts[2]),
+                    group_group=int(counts[3]), group_plane=int(counts[4]))
+
     def make_selection(self, in_selection=None, radius=6.0):
         sel = np.ones(self.n, np.uint8) if in_selection is None else np.ascontiguousarray(in_selection, np.uint8)
         if sel.shape != (self.n,):
@@ -195,6 +217,15 @@ class Context:
         return out
 
     # ---- ring / amide contacts ----
+    def fetch_bag(self, name):
+        """Fetch one of the ring/amide bags left in HBM by run_launch (no re-computation)."""
+        fn = getattr(self._L, f'arp_{name}_fetch')
+        mk, keys, order = self._BAGS[name]
+        arrs = self._grow(lambda cap, r, cnt: fn(self._h, cap, *[_p(x) for x in r], C.byref(cnt)), mk, f'arp_{name}_fetch', 64)
+        out = dict(zip(keys, arrs))
+        o = np.lexsort((out[order[1]], out[order[0]]))
+        return {k: v[o] for k, v in out.items()}
+
     def _grow(self, call, arrays_factory, what, guess):
         cap = max(int(guess), 64)
         while True:
@@ -248,11 +279,27 @@ class Context:
         o = np.lexsort((out['ring'], out['amide']))
         return {k: v[o] for k, v in out.items()}
 
+    _BAGS = {
+        'atom_plane': (lambda cap: [np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float64),
+                                    np.empty(cap, np.float64), np.empty(cap, np.uint8), np.empty(cap, np.uint8)],
+                       ('atom', 'ring', 'dist', 'theta', 'mask', 'ctype'), ('ring', 'atom')),
+        'plane_plane': (lambda cap: [np.empty(cap, np.int32), np.empty(cap, np.int32)] + [np.empty(cap, np.float64) for _ in range(4)]
+                        + [np.empty(cap, np.uint8) for _ in range(3)],
+                        ('bgn', 'end', 'dist', 'dihedral', 'theta_bgn', 'theta_end', 'type1', 'type2', 'ctype'), ('bgn', 'end')),
+        'group_group': (lambda cap: [np.empty(cap, np.int32), np.empty(cap, np.int32)] + [np.empty(cap, np.float32) for _ in range(3)]
+                        + [np.empty(cap, np.uint8)],
+                        ('bgn', 'end', 'dist', 'dihedral', 'theta', 'ctype'), ('bgn', 'end')),
+        'group_plane': (lambda cap: [np.empty(cap, np.int32), np.empty(cap, np.int32)] + [np.empty(cap, np.float64) for _ in range(3)]
+                        + [np.empty(cap, np.uint8)],
+                        ('amide', 'ring', 'dist', 'dihedral', 'theta', 'ctype'), ('amide', 'ring')),
+    }
+
     # ---- measurement ----
     def stats(self):
         s = np.zeros(8, np.int64)
         self._check(self._L.arp_get_stats(self._h, _p(s)), 'arp_get_stats')
-        return dict(candidates=int(s[0]), accepted=int(s[1]), emitted=int(s[2]), binned=int(s[3]), cells=int(s[4]))
+        return dict(candidates=int(s[0]), accepted=int(s[1]), emitted=int(s[2]), binned=int(s[3]), cells=int(s[4]),
+                    expand_candidates=int(s[5]), expand_hits=int(s[6]))
 
     def set_profiling(self, on=True):
         self._check(self._L.arp_set_profiling(self._h, int(on)), 'arp_set_profiling')

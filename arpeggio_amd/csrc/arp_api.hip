@@ -52,7 +52,19 @@ struct Grid {
     void release() { cell_of.release(); cnt.release(); start.release(); perm.release(); sums.release(); valid = false; }
 };
 
-enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_GATHER = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, NSLOT = 8 };
+struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
+    DevBuf<int> a, b;
+    DevBuf<double> d0, d1, d2, d3;
+    DevBuf<float> f0, f1, f2;
+    DevBuf<uint8_t> u0, u1, u2;
+    size_t cap = 0;
+    int64_t count = 0;
+    bool valid = false;
+    void release() { a.release(); b.release(); d0.release(); d1.release(); d2.release(); d3.release(); f0.release();
+                     f1.release(); f2.release(); u0.release(); u1.release(); u2.release(); cap = 0; valid = false; }
+};
+
+enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_GATHER = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
 
 struct EventPair { int slot; hipEvent_t a, b; };
 
@@ -104,14 +116,12 @@ struct arp_ctx {
     DevBuf<uint8_t> out_ct;
     int64_t n_contacts = 0;
     bool contacts_valid = false;
-    Counters* d_ctr = nullptr;
-    Counters h_ctr{};
+    u64* d_ctr = nullptr;        // C_COUNT device counters
+    u64 h_ctr[C_COUNT] = {0};
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // ---- generic outputs of the plane kernels
-    DevBuf<int> po_a, po_b;
-    DevBuf<double> po_d0, po_d1, po_d2, po_d3;
-    DevBuf<float> po_f0, po_f1, po_f2;
-    DevBuf<uint8_t> po_u0, po_u1, po_u2;
+    int64_t contact_cells = 0;
+    // ---- device-resident result bags of the ring / amide kernels
+    Bag bag_ap, bag_pp, bag_gg, bag_gp;
     // ---- profiling
     bool profiling = false;
     std::vector<EventPair> ev_pool;
@@ -300,21 +310,21 @@ int search_blocks(const GridDesc& d) {
     return (nb + 7) & ~7;
 }
 
-int reset_counters(arp_ctx* c) {
-    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+int zero_counter(arp_ctx* c, int first, int count) {
+    HIPCHK(c, hipMemsetAsync(c->d_ctr + first, 0, sizeof(u64) * (size_t)count, c->stream));
     return ARP_OK;
 }
-int read_counters(arp_ctx* c) {
-    HIPCHK(c, hipMemcpyAsync(&c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+int read_counters(arp_ctx* c) {  // one D2H copy + the only stream sync of a pass
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(u64) * C_COUNT, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
 
-void host_bbox(const float* xyz, int64_t n, int stride, double lo[3], double hi[3]) {
+void host_bbox(const float* xyz, int64_t n, double lo[3], double hi[3]) {
     for (int k = 0; k < 3; ++k) { lo[k] = 0; hi[k] = 0; }
     for (int64_t i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) {
-            double v = xyz[i * stride + k];
+            double v = xyz[i * 3 + k];
             if (i == 0 || v < lo[k]) lo[k] = v;
             if (i == 0 || v > hi[k]) hi[k] = v;
         }
@@ -340,11 +350,206 @@ int ensure_amide_grid(arp_ctx* c) {
     return build_grid<PtsF3, 0>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0, nullptr, nullptr, 0, 0);
 }
 
-// masks for rings/amides default to "everything selected" until arp_make_selection runs
-int ensure_default_selection(arp_ctx* c) {
+// ---- enqueue-only building blocks (no host synchronisation) -----------------------------------
+
+// _make_selection (I:1384-1451) from the selection mask already in c->sel
+int enqueue_selection(arp_ctx* c, double radius) {
+    const int n = (int)c->n;
+    HIPCHK(c, c->plus.reserve((size_t)std::max(n, 1)));
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->plus.p, c->sel.p, (size_t)n, hipMemcpyDeviceToDevice, c->stream));  // I:1407
+    c->sel_made = true;
+    c->records_dirty = true;
+    // I:1420-1424: search_all(6.0) over ALL atoms (hydrogens included)
+    CHK(build_atom_grid(c, radius, 0, 0, nullptr));
+    CHK(zero_counter(c, C_MARK_CAND, 2));
+    if (n > 0) {
+        Prof p(c, SLOT_MARK);
+        hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, (int2*)nullptr,
+                           0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_MARK_CAND, c->d_ctr + C_MARK_ACC, c->plus.p);
+        CHK(check_launch(c, "k_search<MARK>"));
+    }
+    // I:1413-1437 residue, ring and amide sets
+    const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+    HIPCHK(c, c->res_sel.reserve(nres));
+    HIPCHK(c, c->res_plus.reserve(nres));
+    HIPCHK(c, hipMemsetAsync(c->res_sel.p, 0, nres, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->res_plus.p, 0, nres, c->stream));
+    if (n > 0)
+        hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
+                           c->res_sel.p, c->res_plus.p);
+    if (c->nring > 0)
+        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, (int)c->nring, c->ring_res.p,
+                           c->res_sel.p, c->res_plus.p, c->ring_sel.p, c->ring_plus.p);
+    if (c->namide > 0)
+        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, (int)c->namide, c->am_res.p,
+                           c->res_sel.p, c->res_plus.p, c->am_sel.p, c->am_plus.p);
+    CHK(check_launch(c, "selection masks"));
+    c->records_dirty = true;  // M_PLUS changed
+    c->atom_grid.valid = false;
+    c->contacts_valid = false;
+    c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
+    return ARP_OK;
+}
+
+int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 with no selectors)
     if (c->sel_made) return ARP_OK;
-    std::vector<uint8_t> ones((size_t)std::max<int64_t>(c->n, 1), 1);
-    return arp_make_selection(c, ones.data(), 6.0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const size_t n = (size_t)std::max<int64_t>(c->n, 1);
+    HIPCHK(c, c->sel.reserve(n));
+    HIPCHK(c, hipMemsetAsync(c->sel.p, 1, n, c->stream));
+    return enqueue_selection(c, 6.0);
+}
+
+// _calculate_atom_contacts (I:693-936): bin + sort + search + sift with the current capacities
+int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq_adj) {
+    // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
+    CHK(build_atom_grid(c, cutoff, M_PLUS, M_HYDROGEN, nullptr));
+    c->contact_cells = c->atom_grid.d.ncell;
+    if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 1024));
+    const size_t cap = c->pairs.cap;
+    HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
+    HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
+    CHK(zero_counter(c, C_PAIRS, 3));
+    CHK(zero_counter(c, C_BINNED, 1));
+    CHK(zero_counter(c, C_ERR, 1));
+    HIPCHK(c, hipMemcpyAsync(c->d_ctr + C_BINNED, c->atom_grid.start.p + c->atom_grid.d.ncell, sizeof(int),
+                             hipMemcpyDeviceToDevice, c->stream));
+    if (c->n > 0) {
+        {
+            Prof p(c, SLOT_SEARCH);
+            hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0,
+                               c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
+                               include_seq_adj, c->pairs.p, (u64)cap, c->d_ctr + C_PAIRS, c->d_ctr + C_CAND, c->d_ctr + C_ACC,
+                               (uint8_t*)nullptr);
+            CHK(check_launch(c, "k_search<CONTACTS>"));
+        }
+        {
+            Prof p(c, SLOT_SIFT);
+            hipLaunchKernelGGL(k_sift, dim3(c->num_cu * 8), dim3(256), 0, c->stream, c->pairs.p, c->d_ctr + C_PAIRS, (u64)cap,
+                               c->s_xyzm.p, c->s_aux.p, c->rad.p, c->bond_off.p, c->bond_idx.p, c->h_off.p, c->h_xyz_d.p, c->sb.p,
+                               c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p,
+                               c->out_ct.p, (int*)(c->d_ctr + C_ERR));
+            CHK(check_launch(c, "k_sift"));
+        }
+    }
+    return ARP_OK;
+}
+
+int bag_reserve(arp_ctx* c, Bag& b, size_t cap, bool d, bool f) {
+    HIPCHK(c, b.a.reserve(cap)); HIPCHK(c, b.b.reserve(cap));
+    if (d) { HIPCHK(c, b.d0.reserve(cap)); HIPCHK(c, b.d1.reserve(cap)); HIPCHK(c, b.d2.reserve(cap)); HIPCHK(c, b.d3.reserve(cap)); }
+    if (f) { HIPCHK(c, b.f0.reserve(cap)); HIPCHK(c, b.f1.reserve(cap)); HIPCHK(c, b.f2.reserve(cap)); }
+    HIPCHK(c, b.u0.reserve(cap)); HIPCHK(c, b.u1.reserve(cap)); HIPCHK(c, b.u2.reserve(cap));
+    b.cap = std::min({b.a.cap, b.b.cap, b.u0.cap});
+    return ARP_OK;
+}
+
+int enqueue_atom_plane(arp_ctx* c) {  // I:947-1062
+    Bag& b = c->bag_ap;
+    if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->nring * 8 + 256, true, false));
+    CHK(zero_counter(c, C_AP, 1));
+    if (c->nring == 0 || c->n == 0) return ARP_OK;
+    CHK(build_atom_grid(c, 6.0, M_PLUS, M_HYDROGEN, nullptr));  // I:960 radius
+    c->atom_grid.valid = false;
+    Prof p(c, SLOT_PLANES);
+    hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
+                       c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p,
+                       c->ring_plus.p, c->has_gid ? c->gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p,
+                       b.u1.p, c->d_ctr + C_AP);
+    return check_launch(c, "k_atom_plane");
+}
+
+int enqueue_plane_plane(arp_ctx* c) {  // I:1064-1194
+    Bag& b = c->bag_pp;
+    if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->nring * 16 + 256, true, false));
+    CHK(zero_counter(c, C_PP, 1));
+    if (c->nring == 0) return ARP_OK;
+    CHK(ensure_ring_grid(c));
+    Prof p(c, SLOT_PLANES);
+    hipLaunchKernelGGL(k_plane_plane, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
+                       c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p, c->ring_plus.p,
+                       (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP);
+    return check_launch(c, "k_plane_plane");
+}
+
+int enqueue_group_group(arp_ctx* c) {  // I:1217-1300
+    Bag& b = c->bag_gg;
+    if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->namide * 8 + 256, false, true));
+    CHK(zero_counter(c, C_GG, 1));
+    if (c->namide == 0) return ARP_OK;
+    CHK(ensure_amide_grid(c));
+    Prof p(c, SLOT_PLANES);
+    hipLaunchKernelGGL(k_group_group, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->amide_grid.d, c->amide_grid.start.p,
+                       c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, (long long)b.cap,
+                       b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p, b.u0.p, c->d_ctr + C_GG);
+    return check_launch(c, "k_group_group");
+}
+
+int enqueue_group_plane(arp_ctx* c) {  // I:1302-1382
+    Bag& b = c->bag_gp;
+    if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->namide * 8 + 256, true, false));
+    CHK(zero_counter(c, C_GP, 1));
+    if (c->namide == 0 || c->nring == 0) return ARP_OK;
+    CHK(ensure_ring_grid(c));
+    Prof p(c, SLOT_PLANES);
+    hipLaunchKernelGGL(k_group_plane, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
+                       c->ring_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, c->ring_c.p,
+                       c->ring_n.p, c->ring_sel.p, c->ring_plus.p, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.u0.p,
+                       c->d_ctr + C_GP);
+    return check_launch(c, "k_group_plane");
+}
+
+// After read_counters(): publish contact results; returns true when the pair buffer overflowed.
+bool finish_contacts(arp_ctx* c) {
+    const u64 np = c->h_ctr[C_PAIRS];
+    if (np > c->pairs.cap) return true;
+    c->n_contacts = (int64_t)np;
+    c->contacts_valid = true;
+    c->stats[0] = (int64_t)c->h_ctr[C_CAND];
+    c->stats[1] = (int64_t)c->h_ctr[C_ACC];
+    c->stats[2] = (int64_t)np;
+    c->stats[3] = (int64_t)(uint32_t)c->h_ctr[C_BINNED];
+    c->stats[4] = c->contact_cells;
+    return false;
+}
+bool finish_bag(arp_ctx* c, Bag& b, int slot) {
+    const u64 k = c->h_ctr[slot];
+    if (k > b.cap) return true;
+    b.count = (int64_t)k;
+    b.valid = true;
+    return false;
+}
+int grow_pairs(arp_ctx* c) {
+    const size_t need = (size_t)c->h_ctr[C_PAIRS];
+    c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
+    HIPCHK(c, c->pairs.reserve(need));
+    return ARP_OK;
+}
+int grow_bag(arp_ctx* c, Bag& b, int slot, bool d, bool f) {
+    const size_t need = (size_t)c->h_ctr[slot];
+    b.release();
+    return bag_reserve(c, b, need, d, f);
+}
+int device_error(arp_ctx* c) {
+    if ((int)(uint32_t)c->h_ctr[C_ERR] == ARP_E_XBOND_NBR)
+        FAIL(c, ARP_E_XBOND_NBR, "xbond donor without a single-bond heavy neighbour (reference: AttributeError at utils.py:173)");
+    return ARP_OK;
+}
+
+template <class F>
+int bag_launch(arp_ctx* c, Bag& b, int slot, bool d, bool f, F enqueue, int64_t* count) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_default_selection(c));
+    for (int attempt = 0;; ++attempt) {
+        CHK(enqueue(c));
+        CHK(read_counters(c));
+        collect_events(c);
+        if (!finish_bag(c, b, slot)) break;
+        if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "result bag could not be sized");
+        CHK(grow_bag(c, b, slot, d, f));
+    }
+    if (count) *count = b.count;
+    return ARP_OK;
 }
 
 }  // namespace
@@ -352,7 +557,7 @@ int ensure_default_selection(arp_ctx* c) {
 // =====================================================================================
 extern "C" {
 
-const char* arp_version(void) { return "arpeggio_hip 0.1.0 (gfx950)"; }
+const char* arp_version(void) { return "arpeggio_hip 0.2.0 (gfx950)"; }
 
 int arp_create(int device, arp_ctx** out) {
     if (!out) return ARP_E_ARG;
@@ -375,7 +580,8 @@ int arp_create(int device, arp_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(Counters));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_COUNT);
+    if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(u64) * C_COUNT);
     if (e != hipSuccess) {
         g_create_error = hipGetErrorString(e);
         delete c;
@@ -399,8 +605,7 @@ void arp_destroy(arp_ctx* c) {
     c->xyzm.release(); c->s_xyzm.release(); c->aux.release(); c->s_aux.release();
     c->atom_grid.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
-    c->po_a.release(); c->po_b.release(); c->po_d0.release(); c->po_d1.release(); c->po_d2.release(); c->po_d3.release();
-    c->po_f0.release(); c->po_f1.release(); c->po_f2.release(); c->po_u0.release(); c->po_u1.release(); c->po_u2.release();
+    c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -417,7 +622,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     HIPCHK(c, hipSetDevice(c->device));
     c->n = n;
     c->h_xyz.assign(xyz, xyz + 3 * n);
-    host_bbox(xyz, n, 3, c->lo, c->hi);
+    host_bbox(xyz, n, c->lo, c->hi);
     std::vector<float4> x4((size_t)n);
     std::vector<double2> r2((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
@@ -523,7 +728,7 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
     if (namide < 0 || (namide > 0 && (!center || !normal || !amide_res))) FAIL(c, ARP_E_ARG, "arp_set_amides: bad input");
     HIPCHK(c, hipSetDevice(c->device));
     c->namide = namide;
-    host_bbox(center, namide, 3, c->am_lo, c->am_hi);
+    host_bbox(center, namide, c->am_lo, c->am_hi);
     CHK(upload(c, c->am_c, center, (size_t)namide * 3));
     CHK(upload(c, c->am_n, normal, (size_t)namide * 3));
     CHK(upload(c, c->am_res, amide_res, (size_t)namide));
@@ -550,6 +755,16 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
     return ARP_OK;
 }
 
+int arp_set_selection(arp_ctx* c, const uint8_t* in_selection) {
+    if (!c || (c->n > 0 && !in_selection)) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(upload(c, c->sel, in_selection, (size_t)c->n));
+    c->sel_made = false;  // expansion pending
+    c->records_dirty = true;
+    c->contacts_valid = false;
+    return ARP_OK;
+}
+
 // ---- NeighborSearch.search_all -----------------------------------------------------------
 int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap, int32_t* out_i, int32_t* out_j, int64_t* count) {
     if (!c || !count || cap < 0 || !(radius > 0)) return ARP_E_ARG;
@@ -561,18 +776,18 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     }
     CHK(build_atom_grid(c, radius, 0, 0, d_active));
     c->atom_grid.valid = false;  // not the contact grid
-    size_t pcap = (size_t)std::max<int64_t>(cap, 1);
-    HIPCHK(c, c->pairs.reserve(pcap));
-    CHK(reset_counters(c));
+    c->contacts_valid = false;
+    HIPCHK(c, c->pairs.reserve((size_t)std::max<int64_t>(cap, 1)));
+    CHK(zero_counter(c, C_SEARCH_PAIRS, 3));
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, c->pairs.p,
-                           (unsigned long long)cap, c->d_ctr, (uint8_t*)nullptr);
+                           (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_SCRATCH0, c->d_ctr + C_SCRATCH1, (uint8_t*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));
-    *count = (int64_t)c->h_ctr.n_pairs;
-    c->contacts_valid = false;
+    collect_events(c);
+    *count = (int64_t)c->h_ctr[C_SEARCH_PAIRS];
     if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_search_all: output buffer too small");
     if (*count > 0) {
         std::vector<int2> tmp((size_t)*count);
@@ -585,44 +800,21 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
 // ---- _make_selection --------------------------------------------------------------------
 int arp_make_selection(arp_ctx* c, const uint8_t* in_selection, double expand_radius, uint8_t* out_plus, uint8_t* out_ring_sel,
                        uint8_t* out_ring_plus, uint8_t* out_amide_sel, uint8_t* out_amide_plus) {
-    if (!c || (c->n > 0 && !in_selection) || !(expand_radius > 0)) return ARP_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    const int n = (int)c->n;
-    CHK(upload(c, c->sel, in_selection, (size_t)n));
-    CHK(upload(c, c->plus, in_selection, (size_t)n));  // I:1407 selection_plus starts as the selection
-    c->sel_made = true;
-    c->records_dirty = true;
-    CHK(ensure_records(c));  // meta carries M_SEL; M_PLUS is refreshed below
-    // I:1420-1424: search_all(6.0) over ALL atoms (hydrogens included)
-    CHK(build_atom_grid(c, expand_radius, 0, 0, nullptr));
-    CHK(reset_counters(c));
-    if (c->n > 0) {
-        hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, expand_radius * expand_radius, 1,
-                           (int2*)nullptr, 0ull, c->d_ctr, c->plus.p);
-        CHK(check_launch(c, "k_search<MARK>"));
+    if (!c || !(expand_radius > 0)) return ARP_E_ARG;
+    if (in_selection) CHK(arp_set_selection(c, in_selection));
+    else {
+        HIPCHK(c, hipSetDevice(c->device));
+        if (!c->sel.p || c->sel.cap < (size_t)c->n) {  // nothing uploaded yet: whole structure (I:1395)
+            HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
+            HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
+        }
     }
-    // I:1413-1437 residue, ring and amide sets
-    const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
-    HIPCHK(c, c->res_sel.reserve(nres));
-    HIPCHK(c, c->res_plus.reserve(nres));
-    HIPCHK(c, hipMemsetAsync(c->res_sel.p, 0, nres, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->res_plus.p, 0, nres, c->stream));
-    if (n > 0) {
-        hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
-                           c->res_sel.p, c->res_plus.p);
-    }
-    if (c->nring > 0)
-        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, (int)c->nring, c->ring_res.p,
-                           c->res_sel.p, c->res_plus.p, c->ring_sel.p, c->ring_plus.p);
-    if (c->namide > 0)
-        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, (int)c->namide, c->am_res.p,
-                           c->res_sel.p, c->res_plus.p, c->am_sel.p, c->am_plus.p);
-    CHK(check_launch(c, "selection masks"));
-    c->records_dirty = true;  // M_PLUS changed
-    c->atom_grid.valid = false;
-    c->contacts_valid = false;
-    CHK(download(c, out_plus, c->plus.p, out_plus ? (size_t)n : 0));
+    CHK(enqueue_selection(c, expand_radius));
+    CHK(read_counters(c));
+    collect_events(c);
+    c->stats[5] = (int64_t)c->h_ctr[C_MARK_CAND];
+    c->stats[6] = (int64_t)c->h_ctr[C_MARK_ACC];
+    CHK(download(c, out_plus, c->plus.p, out_plus ? (size_t)c->n : 0));
     CHK(download(c, out_ring_sel, c->ring_sel.p, out_ring_sel ? (size_t)c->nring : 0));
     CHK(download(c, out_ring_plus, c->ring_plus.p, out_ring_plus ? (size_t)c->nring : 0));
     CHK(download(c, out_amide_sel, c->am_sel.p, out_amide_sel ? (size_t)c->namide : 0));
@@ -635,54 +827,16 @@ int arp_atom_contacts_launch(arp_ctx* c, double cutoff, double vdw_comp, int inc
     if (!c || !(cutoff > 0)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     CHK(ensure_default_selection(c));
-    // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
-    CHK(build_atom_grid(c, cutoff, M_PLUS, M_HYDROGEN, nullptr));
-    const int m = (int)c->n;
-    size_t pcap = c->pairs.cap ? c->pairs.cap : (size_t)m * 16 + 1024;
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        HIPCHK(c, c->pairs.reserve(pcap));
-        pcap = c->pairs.cap;
-        CHK(reset_counters(c));
-        if (m > 0) {
-            Prof p(c, SLOT_SEARCH);
-            hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0,
-                               c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_sequence_adjacent, c->pairs.p, (unsigned long long)pcap, c->d_ctr, (uint8_t*)nullptr);
-            CHK(check_launch(c, "k_search<CONTACTS>"));
-        }
+    for (int attempt = 0;; ++attempt) {
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));
         CHK(read_counters(c));
-        if (c->h_ctr.n_pairs <= pcap) break;
-        pcap = (size_t)c->h_ctr.n_pairs;  // regrow and re-run
+        collect_events(c);
+        if (!finish_contacts(c)) break;
         if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_launch: pair buffer could not be sized");
+        CHK(grow_pairs(c));
     }
-    const int64_t np = (int64_t)c->h_ctr.n_pairs;
-    size_t ocap = (size_t)std::max<int64_t>(np, 1);
-    HIPCHK(c, c->out_i.reserve(ocap)); HIPCHK(c, c->out_j.reserve(ocap)); HIPCHK(c, c->out_d.reserve(ocap));
-    HIPCHK(c, c->out_s.reserve(ocap)); HIPCHK(c, c->out_ct.reserve(ocap));
-    if (np > 0) {
-        Prof p(c, SLOT_SIFT);
-        hipLaunchKernelGGL(k_sift, dim3(nblocks(np, 256, 8192)), dim3(256), 0, c->stream, c->pairs.p, (long long)np, c->s_xyzm.p,
-                           c->s_aux.p, c->rad.p, c->bond_off.p, c->bond_idx.p, c->h_off.p, c->h_xyz_d.p, c->sb.p,
-                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p,
-                           c->out_ct.p, &c->d_ctr->err);
-        CHK(check_launch(c, "k_sift"));
-    }
-    CHK(read_counters(c));
-    int binned = 0;
-    CHK(download(c, &binned, c->atom_grid.start.p + c->atom_grid.d.ncell, 1));
-    c->atom_grid.n_binned = binned;
-    collect_events(c);
-    c->n_contacts = np;
-    c->contacts_valid = true;
-    c->stats[0] = (int64_t)c->h_ctr.n_cand;
-    c->stats[1] = (int64_t)c->h_ctr.n_acc;
-    c->stats[2] = np;
-    c->stats[3] = binned;
-    c->stats[4] = c->atom_grid.d.ncell;
-    if (count) *count = np;
-    if (c->h_ctr.err == ARP_E_XBOND_NBR)
-        FAIL(c, ARP_E_XBOND_NBR, "xbond donor without a single-bond heavy neighbour (reference: AttributeError at utils.py:173)");
-    return ARP_OK;
+    if (count) *count = c->n_contacts;
+    return device_error(c);
 }
 
 int arp_atom_contacts_fetch(arp_ctx* c, int64_t cap, int32_t* out_i, int32_t* out_j, float* out_dist, uint16_t* out_sift,
@@ -705,113 +859,129 @@ int arp_atom_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_se
     return arp_atom_contacts_fetch(c, cap, out_i, out_j, out_dist, out_sift, out_ctype, count);
 }
 
-// ---- ring / amide contacts ------------------------------------------------------------------
-int arp_atom_plane(arp_ctx* c, int64_t cap, int32_t* out_atom, int32_t* out_ring, double* out_dist, double* out_theta,
-                   uint8_t* out_mask, uint8_t* out_ctype, int64_t* count) {
-    if (!c || !count || cap < 0) return ARP_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure_default_selection(c));
-    *count = 0;
-    if (c->nring == 0 || c->n == 0) return ARP_OK;
-    CHK(build_atom_grid(c, 6.0, M_PLUS, M_HYDROGEN, nullptr));  // I:960 radius
-    c->atom_grid.valid = false;
-    const size_t k = (size_t)std::max<int64_t>(cap, 1);
-    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_d0.reserve(k)); HIPCHK(c, c->po_d1.reserve(k));
-    HIPCHK(c, c->po_u0.reserve(k)); HIPCHK(c, c->po_u1.reserve(k));
-    CHK(reset_counters(c));
-    hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
-                       c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p,
-                       c->ring_plus.p, c->has_gid ? c->gid.p : nullptr, (long long)cap, c->po_a.p, c->po_b.p, c->po_d0.p,
-                       c->po_d1.p, c->po_u0.p, c->po_u1.p, c->d_ctr);
-    CHK(check_launch(c, "k_atom_plane"));
-    CHK(read_counters(c));
-    *count = (int64_t)c->h_ctr.n_out;
-    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_atom_plane: output buffer too small");
-    const size_t m = (size_t)*count;
-    CHK(download(c, out_atom, c->po_a.p, m)); CHK(download(c, out_ring, c->po_b.p, m)); CHK(download(c, out_dist, c->po_d0.p, m));
-    CHK(download(c, out_theta, c->po_d1.p, m)); CHK(download(c, out_mask, c->po_u0.p, m)); CHK(download(c, out_ctype, c->po_u1.p, m));
+// ---- ring / amide contacts: launch (results stay in HBM) + fetch ----------------------------------
+int arp_atom_plane_launch(arp_ctx* c, int64_t* count) {
+    if (!c) return ARP_E_ARG;
+    return bag_launch(c, c->bag_ap, C_AP, true, false, enqueue_atom_plane, count);
+}
+int arp_plane_plane_launch(arp_ctx* c, int64_t* count) {
+    if (!c) return ARP_E_ARG;
+    return bag_launch(c, c->bag_pp, C_PP, true, false, enqueue_plane_plane, count);
+}
+int arp_group_group_launch(arp_ctx* c, int64_t* count) {
+    if (!c) return ARP_E_ARG;
+    return bag_launch(c, c->bag_gg, C_GG, false, true, enqueue_group_group, count);
+}
+int arp_group_plane_launch(arp_ctx* c, int64_t* count) {
+    if (!c) return ARP_E_ARG;
+    return bag_launch(c, c->bag_gp, C_GP, true, false, enqueue_group_plane, count);
+}
+
+#define FETCH_PROLOGUE(bag, what)                                                                  \
+    if (!c || !count) return ARP_E_ARG;                                                           \
+    if (!(bag).valid) FAIL(c, ARP_E_ARG, what ": no launch results");                             \
+    HIPCHK(c, hipSetDevice(c->device));                                                           \
+    *count = (bag).count;                                                                         \
+    if ((bag).count > cap) FAIL(c, ARP_E_CAPACITY, what ": output buffer too small");             \
+    const size_t m = (size_t)(bag).count;
+
+int arp_atom_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_atom, int32_t* out_ring, double* out_dist, double* out_theta,
+                         uint8_t* out_mask, uint8_t* out_ctype, int64_t* count) {
+    FETCH_PROLOGUE(c->bag_ap, "arp_atom_plane_fetch")
+    Bag& b = c->bag_ap;
+    CHK(download(c, out_atom, b.a.p, m)); CHK(download(c, out_ring, b.b.p, m)); CHK(download(c, out_dist, b.d0.p, m));
+    CHK(download(c, out_theta, b.d1.p, m)); CHK(download(c, out_mask, b.u0.p, m)); CHK(download(c, out_ctype, b.u1.p, m));
+    return ARP_OK;
+}
+int arp_plane_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, double* out_dist, double* out_dihedral,
+                          double* out_theta_bgn, double* out_theta_end, uint8_t* out_type1, uint8_t* out_type2,
+                          uint8_t* out_ctype, int64_t* count) {
+    FETCH_PROLOGUE(c->bag_pp, "arp_plane_plane_fetch")
+    Bag& b = c->bag_pp;
+    CHK(download(c, out_bgn, b.a.p, m)); CHK(download(c, out_end, b.b.p, m)); CHK(download(c, out_dist, b.d0.p, m));
+    CHK(download(c, out_dihedral, b.d1.p, m)); CHK(download(c, out_theta_bgn, b.d2.p, m)); CHK(download(c, out_theta_end, b.d3.p, m));
+    CHK(download(c, out_type1, b.u0.p, m)); CHK(download(c, out_type2, b.u1.p, m)); CHK(download(c, out_ctype, b.u2.p, m));
+    return ARP_OK;
+}
+int arp_group_group_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, float* out_dist, float* out_dihedral,
+                          float* out_theta, uint8_t* out_ctype, int64_t* count) {
+    FETCH_PROLOGUE(c->bag_gg, "arp_group_group_fetch")
+    Bag& b = c->bag_gg;
+    CHK(download(c, out_bgn, b.a.p, m)); CHK(download(c, out_end, b.b.p, m)); CHK(download(c, out_dist, b.f0.p, m));
+    CHK(download(c, out_dihedral, b.f1.p, m)); CHK(download(c, out_theta, b.f2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
+    return ARP_OK;
+}
+int arp_group_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_amide, int32_t* out_ring, double* out_dist, double* out_dihedral,
+                          double* out_theta, uint8_t* out_ctype, int64_t* count) {
+    FETCH_PROLOGUE(c->bag_gp, "arp_group_plane_fetch")
+    Bag& b = c->bag_gp;
+    CHK(download(c, out_amide, b.a.p, m)); CHK(download(c, out_ring, b.b.p, m)); CHK(download(c, out_dist, b.d0.p, m));
+    CHK(download(c, out_dihedral, b.d1.p, m)); CHK(download(c, out_theta, b.d2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
     return ARP_OK;
 }
 
+// launch + fetch.  A too-small caller buffer returns ARP_E_CAPACITY with the required count.
+int arp_atom_plane(arp_ctx* c, int64_t cap, int32_t* out_atom, int32_t* out_ring, double* out_dist, double* out_theta,
+                   uint8_t* out_mask, uint8_t* out_ctype, int64_t* count) {
+    if (!c || !count || cap < 0) return ARP_E_ARG;
+    CHK(arp_atom_plane_launch(c, count));
+    return arp_atom_plane_fetch(c, cap, out_atom, out_ring, out_dist, out_theta, out_mask, out_ctype, count);
+}
 int arp_plane_plane(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, double* out_dist, double* out_dihedral,
                     double* out_theta_bgn, double* out_theta_end, uint8_t* out_type1, uint8_t* out_type2, uint8_t* out_ctype,
                     int64_t* count) {
     if (!c || !count || cap < 0) return ARP_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure_default_selection(c));
-    *count = 0;
-    if (c->nring == 0) return ARP_OK;
-    CHK(ensure_ring_grid(c));
-    const size_t k = (size_t)std::max<int64_t>(cap, 1);
-    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_d0.reserve(k)); HIPCHK(c, c->po_d1.reserve(k));
-    HIPCHK(c, c->po_d2.reserve(k)); HIPCHK(c, c->po_d3.reserve(k)); HIPCHK(c, c->po_u0.reserve(k)); HIPCHK(c, c->po_u1.reserve(k));
-    HIPCHK(c, c->po_u2.reserve(k));
-    CHK(reset_counters(c));
-    hipLaunchKernelGGL(k_plane_plane, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
-                       c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p, c->ring_plus.p,
-                       (long long)cap, c->po_a.p, c->po_b.p, c->po_d0.p, c->po_d1.p, c->po_d2.p, c->po_d3.p, c->po_u0.p,
-                       c->po_u1.p, c->po_u2.p, c->d_ctr);
-    CHK(check_launch(c, "k_plane_plane"));
-    CHK(read_counters(c));
-    *count = (int64_t)c->h_ctr.n_out;
-    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_plane_plane: output buffer too small");
-    const size_t m = (size_t)*count;
-    CHK(download(c, out_bgn, c->po_a.p, m)); CHK(download(c, out_end, c->po_b.p, m)); CHK(download(c, out_dist, c->po_d0.p, m));
-    CHK(download(c, out_dihedral, c->po_d1.p, m)); CHK(download(c, out_theta_bgn, c->po_d2.p, m));
-    CHK(download(c, out_theta_end, c->po_d3.p, m)); CHK(download(c, out_type1, c->po_u0.p, m));
-    CHK(download(c, out_type2, c->po_u1.p, m)); CHK(download(c, out_ctype, c->po_u2.p, m));
-    return ARP_OK;
+    CHK(arp_plane_plane_launch(c, count));
+    return arp_plane_plane_fetch(c, cap, out_bgn, out_end, out_dist, out_dihedral, out_theta_bgn, out_theta_end, out_type1,
+                                 out_type2, out_ctype, count);
 }
-
 int arp_group_group(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, float* out_dist, float* out_dihedral,
                     float* out_theta, uint8_t* out_ctype, int64_t* count) {
     if (!c || !count || cap < 0) return ARP_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure_default_selection(c));
-    *count = 0;
-    if (c->namide == 0) return ARP_OK;
-    CHK(ensure_amide_grid(c));
-    const size_t k = (size_t)std::max<int64_t>(cap, 1);
-    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_f0.reserve(k)); HIPCHK(c, c->po_f1.reserve(k));
-    HIPCHK(c, c->po_f2.reserve(k)); HIPCHK(c, c->po_u0.reserve(k));
-    CHK(reset_counters(c));
-    hipLaunchKernelGGL(k_group_group, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->amide_grid.d, c->amide_grid.start.p,
-                       c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, (long long)cap,
-                       c->po_a.p, c->po_b.p, c->po_f0.p, c->po_f1.p, c->po_f2.p, c->po_u0.p, c->d_ctr);
-    CHK(check_launch(c, "k_group_group"));
-    CHK(read_counters(c));
-    *count = (int64_t)c->h_ctr.n_out;
-    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_group_group: output buffer too small");
-    const size_t m = (size_t)*count;
-    CHK(download(c, out_bgn, c->po_a.p, m)); CHK(download(c, out_end, c->po_b.p, m)); CHK(download(c, out_dist, c->po_f0.p, m));
-    CHK(download(c, out_dihedral, c->po_f1.p, m)); CHK(download(c, out_theta, c->po_f2.p, m)); CHK(download(c, out_ctype, c->po_u0.p, m));
-    return ARP_OK;
+    CHK(arp_group_group_launch(c, count));
+    return arp_group_group_fetch(c, cap, out_bgn, out_end, out_dist, out_dihedral, out_theta, out_ctype, count);
 }
-
 int arp_group_plane(arp_ctx* c, int64_t cap, int32_t* out_amide, int32_t* out_ring, double* out_dist, double* out_dihedral,
                     double* out_theta, uint8_t* out_ctype, int64_t* count) {
     if (!c || !count || cap < 0) return ARP_E_ARG;
+    CHK(arp_group_plane_launch(c, count));
+    return arp_group_plane_fetch(c, cap, out_amide, out_ring, out_dist, out_dihedral, out_theta, out_ctype, count);
+}
+
+// ---- run_arpeggio (I:329-347): every stage enqueued back to back, ONE host synchronisation ---------
+int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius,
+                   int64_t counts[5]) {
+    if (!c || !(cutoff > 0) || !(expand_radius > 0)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure_default_selection(c));
-    *count = 0;
-    if (c->namide == 0 || c->nring == 0) return ARP_OK;
-    CHK(ensure_ring_grid(c));
-    const size_t k = (size_t)std::max<int64_t>(cap, 1);
-    HIPCHK(c, c->po_a.reserve(k)); HIPCHK(c, c->po_b.reserve(k)); HIPCHK(c, c->po_d0.reserve(k)); HIPCHK(c, c->po_d1.reserve(k));
-    HIPCHK(c, c->po_d2.reserve(k)); HIPCHK(c, c->po_u0.reserve(k));
-    CHK(reset_counters(c));
-    hipLaunchKernelGGL(k_group_plane, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
-                       c->ring_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, c->ring_c.p,
-                       c->ring_n.p, c->ring_sel.p, c->ring_plus.p, (long long)cap, c->po_a.p, c->po_b.p, c->po_d0.p, c->po_d1.p,
-                       c->po_d2.p, c->po_u0.p, c->d_ctr);
-    CHK(check_launch(c, "k_group_plane"));
-    CHK(read_counters(c));
-    *count = (int64_t)c->h_ctr.n_out;
-    if (*count > cap) FAIL(c, ARP_E_CAPACITY, "arp_group_plane: output buffer too small");
-    const size_t m = (size_t)*count;
-    CHK(download(c, out_amide, c->po_a.p, m)); CHK(download(c, out_ring, c->po_b.p, m)); CHK(download(c, out_dist, c->po_d0.p, m));
-    CHK(download(c, out_dihedral, c->po_d1.p, m)); CHK(download(c, out_theta, c->po_d2.p, m)); CHK(download(c, out_ctype, c->po_u0.p, m));
-    return ARP_OK;
+    if (!c->sel.p || c->sel.cap < (size_t)std::max<int64_t>(c->n, 1)) {  // no selection uploaded: whole structure
+        HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
+        HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
+    }
+    for (int attempt = 0;; ++attempt) {
+        CHK(enqueue_selection(c, expand_radius));                                   // I:342
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345
+        CHK(enqueue_plane_plane(c));                                                // I:346 (I:944)
+        CHK(enqueue_atom_plane(c));                                                 //       (I:945)
+        CHK(enqueue_group_group(c));                                                // I:347 (I:1214)
+        CHK(enqueue_group_plane(c));                                                //       (I:1215)
+        CHK(read_counters(c));
+        collect_events(c);
+        bool again = false;
+        if (finish_contacts(c)) { CHK(grow_pairs(c)); again = true; }
+        if (finish_bag(c, c->bag_ap, C_AP)) { CHK(grow_bag(c, c->bag_ap, C_AP, true, false)); again = true; }
+        if (finish_bag(c, c->bag_pp, C_PP)) { CHK(grow_bag(c, c->bag_pp, C_PP, true, false)); again = true; }
+        if (finish_bag(c, c->bag_gg, C_GG)) { CHK(grow_bag(c, c->bag_gg, C_GG, false, true)); again = true; }
+        if (finish_bag(c, c->bag_gp, C_GP)) { CHK(grow_bag(c, c->bag_gp, C_GP, true, false)); again = true; }
+        if (!again) break;
+        if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_launch: result buffers could not be sized");
+    }
+    c->stats[5] = (int64_t)c->h_ctr[C_MARK_CAND];
+    c->stats[6] = (int64_t)c->h_ctr[C_MARK_ACC];
+    if (counts) {
+        counts[0] = c->n_contacts; counts[1] = c->bag_pp.count; counts[2] = c->bag_ap.count;
+        counts[3] = c->bag_gg.count; counts[4] = c->bag_gp.count;
+    }
+    return device_error(c);
 }
 
 // ---- measurement -------------------------------------------------------------------------------

@@ -30,14 +30,21 @@
 #define M_RES_HASSEQ (1u << 22)
 #define M_HOME (1u << 24)
 
-struct Counters {
-    unsigned long long n_pairs;  // pairs enqueued (after residue filters)
-    unsigned long long n_cand;   // distance tests performed
-    unsigned long long n_acc;    // pairs with d^2 <= r^2
-    unsigned long long n_out;    // generic output counter (plane kernels)
-    int err;                     // ARP_E_* raised on the device
-    int pad;
+// device counters (one u64 each); kernels receive pointers to the slots they update
+enum {
+    C_PAIRS = 0,      // contact pairs enqueued (after the residue filters)
+    C_CAND = 1,       // distance tests of the contact search
+    C_ACC = 2,        // pairs with d^2 <= cutoff^2
+    C_MARK_CAND = 3,  // distance tests of the selection-expansion search
+    C_MARK_ACC = 4,
+    C_AP = 5, C_PP = 6, C_GG = 7, C_GP = 8,  // records emitted by the ring / amide kernels
+    C_SEARCH_PAIRS = 9,  // arp_search_all
+    C_SCRATCH0 = 10, C_SCRATCH1 = 11,
+    C_BINNED = 12,    // atoms in the contact grid (low 32 bits)
+    C_ERR = 15,       // ARP_E_* raised on the device (low 32 bits)
+    C_COUNT = 16
 };
+typedef unsigned long long u64;
 
 // atom records: xyzm = {x, y, z, meta}; aux = {local id, residue, prev residue, next residue}
 __global__ __launch_bounds__(256) void k_build_records(int n, const float4* __restrict__ xyz, const uint16_t* __restrict__ tmask,
@@ -80,7 +87,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
                                                                int include_seq_adj, int2* __restrict__ pairs,
-                                                               unsigned long long cap, Counters* __restrict__ ctr,
+                                                               unsigned long long cap, u64* __restrict__ ctr_pairs,
+                                                               u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus) {
     __shared__ int2 q[SEARCH_WAVES][QCAP];
     const int lane = threadIdx.x & 63;
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->n_pairs, (unsigned long long)qn);
+        if (lane == 0) base = atomicAdd(ctr_pairs, (unsigned long long)qn);
         base = __shfl(base, 0);
         for (int k = lane; k < qn; k += 64)
             if (base + k < cap) pairs[base + k] = q[w][k];
@@ -210,8 +218,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
     }
     if (MODE != MODE_MARK && qn > 0) flush();
     if (lane == 0) {
-        atomicAdd(&ctr->n_cand, n_cand);
-        atomicAdd(&ctr->n_acc, n_acc);
+        atomicAdd(ctr_cand, n_cand);
+        atomicAdd(ctr_acc, n_acc);
     }
 }
 
@@ -276,7 +284,7 @@ __device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) 
 }
 
 // One thread per accepted pair (full 64-lane occupancy for the divergent chemistry).
-__global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, long long npairs,
+__global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
                                               const float4* __restrict__ s_xyzm, const int4* __restrict__ s_aux,
                                               const double2* __restrict__ rad, const int* __restrict__ bond_off,
                                               const int* __restrict__ bond_idx, const int* __restrict__ h_off,
@@ -285,6 +293,8 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, lo
                                               int* __restrict__ out_j, float* __restrict__ out_d,
                                               uint16_t* __restrict__ out_s, uint8_t* __restrict__ out_ct,
                                               int* __restrict__ err) {
+    // the pair count is read on the device: no host round trip between search and sift
+    const long long npairs = (long long)min(*npairs_ptr, cap);
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npairs;
          p += (long long)gridDim.x * blockDim.x) {
         const int2 pr = pairs[p];

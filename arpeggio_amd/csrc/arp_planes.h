@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
                                                     const int* __restrict__ gid, long long cap, int* __restrict__ out_atom,
                                                     int* __restrict__ out_ring, double* __restrict__ out_dist,
                                                     double* __restrict__ out_theta, uint8_t* __restrict__ out_mask,
-                                                    uint8_t* __restrict__ out_ct, Counters* __restrict__ ctr) {
+                                                    uint8_t* __restrict__ out_ct, u64* __restrict__ n_out) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
                     const unsigned long long me = __ballot(emit);
                     if (me) {
                         unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(&ctr->n_out, (unsigned long long)__popcll(me));
+                        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(me));
                         base = __shfl(base, 0);
                         const long long slot = (long long)(base + __popcll(me & ((1ull << lane) - 1ull)));
                         if (emit && slot < cap) {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_t1, double* __restrict__ out_t2,
                                                      uint8_t* __restrict__ out_y1, uint8_t* __restrict__ out_y2,
-                                                     uint8_t* __restrict__ out_ct, Counters* __restrict__ ctr) {
+                                                     uint8_t* __restrict__ out_ct, u64* __restrict__ n_out) {
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < nring; a += gridDim.x * blockDim.x) {
         if (!ring_plus[a]) continue;  // I:1081
         const num::d3 ca = ld3(ring_c, a), na = ld3(ring_n, a);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
                     const bool skip_ab = intra && y_ab == ARP_PP_EE;  // I:1154
                     const bool skip_ba = intra && y_ba == ARP_PP_EE;
                     if (skip_ab && skip_ba) continue;
-                    const long long slot = (long long)atomicAdd(&ctr->n_out, 1ull);
+                    const long long slot = (long long)atomicAdd(n_out, 1ull);
                     if (slot >= cap) continue;
                     if (!skip_ab) {  // record created by the first visit (a,b); (b,a) may append its class
                         out_bgn[slot] = a; out_end[slot] = b;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __re
                                                      long long cap, int* __restrict__ out_bgn, int* __restrict__ out_end,
                                                      float* __restrict__ out_dist, float* __restrict__ out_dih,
                                                      float* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     Counters* __restrict__ ctr) {
+                                                     u64* __restrict__ n_out) {
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < namide; a += gridDim.x * blockDim.x) {
         if (!am_plus[a]) continue;
         const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __re
                     const float dih = num::fold_deg(acosf(cosd));   // I:1278
                     const float theta = num::group_angle(na, pab);  // I:1279
                     if (dih > 30.0f || theta > 30.0f) continue;     // I:1282
-                    const long long slot = (long long)atomicAdd(&ctr->n_out, 1ull);
+                    const long long slot = (long long)atomicAdd(n_out, 1ull);
                     if (slot >= cap) continue;
                     out_bgn[slot] = a; out_end[slot] = b;
                     out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
                                                      long long cap, int* __restrict__ out_amide, int* __restrict__ out_ring,
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     Counters* __restrict__ ctr) {
+                                                     u64* __restrict__ n_out) {
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < namide; a += gridDim.x * blockDim.x) {
         if (!am_plus[a]) continue;
         const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
                     const double dih = num::fold_deg(acos(cosd));   // I:1359
                     const double theta = num::group_angle(na, par); // I:1360
                     if (dih > 30.0 || theta > 30.0) continue;       // I:1363
-                    const long long slot = (long long)atomicAdd(&ctr->n_out, 1ull);
+                    const long long slot = (long long)atomicAdd(n_out, 1ull);
                     if (slot >= cap) continue;
                     out_amide[slot] = a; out_ring[slot] = r;
                     out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — evaluated atom-pairs/s of the run_arpeggio hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms A]
+
+One "step" = one pass of the whole hot path (InteractionComplex.run_arpeggio,
+interactions.py:329-347: 6 A selection expansion, 5 A neighbour search + fused 15-flag
+SIFt evaluation, ring/amide plane kernels) over the structure resident in HBM; results
+stay in HBM.  Unit of work = one candidate atom pair of the 5 A contact search (SURVEY.md
+§8d).  N > 1: the box is elongated along x (weak scaling, BASELINE configs[3] family),
+sharded into N slabs with a one-cell halo exchanged over RCCL before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (HIP-event time on the context's own stream) and `cpu_baseline` (the C
+oracle timed on one host core on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--atoms', type=int, default=100_000, help='atoms per GPU (configs[2]: 100k; configs[3]: 250k x 8)')
+    ap.add_argument('--cutoff', type=float, default=5.0)
+    ap.add_argument('--vdw-comp', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-atoms', type=int, default=100_000)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(kernel, n_binned, ncell, n_pairs):
+    """Compulsory HBM bytes of one launch (DESIGN.md 'Kernels and rooflines')."""
+    if kernel == 'search':      # read each sorted record once (xyzm 16 B + aux 16 B), the cell table, write the pair list
+        return 32 * n_binned + 4 * (ncell + 1) + 8 * n_pairs
+    if kernel == 'mark_search':  # same reads, writes one byte per marked atom
+        return 32 * n_binned + 4 * (ncell + 1) + n_binned
+    if kernel == 'sift':        # pair list + both records once per atom + radii + CSR offsets + 15-byte output record
+        return 8 * n_pairs + (32 + 16 + 8 + 16) * n_binned + 15 * n_pairs
+    raise KeyError(kernel)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from arpeggio_amd import synth, _capi
+
+    # ---------------- workload ----------------
+    t0 = time.perf_counter()
+    halo_ms = 0.0
+    if world == 1:
+        pc = synth.config3(args.atoms, seed=3)
+        workload = f'synthetic {args.atoms} random-coordinate atoms, rho=0.05/A^3, 5 A cutoff (BASELINE configs[2])'
+        ctx = _capi.Context(local_rank)
+        ctx.set_complex(pc)
+        n_local_home = pc.n_atoms
+    else:
+        from arpeggio_amd import sharding
+        full = synth.slab_config(args.atoms, world, seed=4)
+        workload = (f'synthetic {args.atoms * world} atoms in {world} x-slabs of {args.atoms} '
+                    f'(BASELINE configs[3] family), one-cell halo over RCCL')
+        shard = sharding.make_shard_distributed(full, rank, world, dist, device=torch.device('cuda', local_rank))
+        halo_ms = shard.halo_ms
+        ctx = _capi.Context(local_rank)
+        sharding.upload_shard(ctx, shard)
+        n_local_home = int(shard.is_home.sum())
+        pc = shard.pc
+    gen_s = time.perf_counter() - t0
+
+    def step():
+        return ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        counts = step()
+    ctx.set_profiling(True)
+    ctx.kernel_times(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()          # blocks until the context stream has drained (one sync per step)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ktimes = ctx.kernel_times(reset=True)
+    ctx.set_profiling(False)
+    st = ctx.stats()
+
+    # max over ranks of the elapsed time, sum over ranks of the work
+    cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        w = torch.tensor([cand, acc, emitted, st['expand_candidates']], dtype=torch.float64, device='cuda')
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        cand_all, acc_all, emitted_all, exp_all = (float(x) for x in w.tolist())
+    else:
+        cand_all, acc_all, emitted_all, exp_all = float(cand), float(acc), float(emitted), float(st['expand_candidates'])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = cand_all * args.steps / elapsed
+
+    # ---------------- roofline of the dominant kernel (rank 0) ----------------
+    per_kernel = {k: (v['ms'] / max(v['launches'], 1)) for k, v in ktimes.items() if v['launches']}
+    candidates_for_dominant = {k: per_kernel[k] for k in ('search', 'sift', 'mark_search') if k in per_kernel}
+    dom = max(candidates_for_dominant, key=candidates_for_dominant.get)
+    dom_ms = candidates_for_dominant[dom]
+    n_binned = st['binned'] if dom != 'mark_search' else pc.n_atoms
+    ncell = st['cells']
+    b_alg = algorithmic_bytes(dom, n_binned, ncell, emitted)
+    achieved = b_alg / (dom_ms * 1e-3) / 1e9
+    roofline = {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
+                'algorithmic_bytes_per_launch': int(b_alg), 'avg_launch_ms': round(dom_ms, 5),
+                'note': 'VALU-bound geometry kernel; HBM fraction is small by construction (SURVEY 8d)'}
+
+    # ---------------- CPU baseline: the C oracle on one host core, bounded sample ----------------
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle
+        ns = min(args.cpu_sample_atoms, args.atoms)
+        spc = synth.config3(ns, seed=3) if (world > 1 or ns != args.atoms) else pc
+        oc = oracle.OracleComplex(spc)
+        t0 = time.perf_counter()
+        oc.make_selection(None)
+        r = oc.atom_contacts(args.cutoff, args.vdw_comp, False)
+        oc.plane_plane(); oc.group_group(); oc.group_plane()
+        cpu_s = time.perf_counter() - t0
+        cpu = {'value': round(float(r['stats'][0]) / cpu_s, 1), 'unit': 'candidate atom-pairs/s', 'cores': 1, 'kind': 'port',
+               'sample': f'one full run_arpeggio pass of the C oracle (oracle/ref_c.c, grid search, -O2, 1 thread) on '
+                         f'{ns} synthetic atoms: {cpu_s:.2f} s; atom-plane loop omitted (O(R*N) brute force in the oracle)',
+               'host_cores_available': os.cpu_count()}
+
+    line = {
+        'metric': 'evaluated atom-pairs/s', 'value': round(value, 1), 'unit': 'candidate atom-pairs/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64 distance test / f32+f64 SIFt',
+        'data': 'synthetic',
+        'config': {'workload': workload, 'atoms_per_gpu': args.atoms, 'cutoff_A': args.cutoff, 'vdw_comp': args.vdw_comp,
+                   'parallelism': f'slab{world}' if world > 1 else 'single'},
+        'wall_clock_per_structure_ms': round(ms_per_step, 4),
+        'pairs': {'candidates': cand_all, 'accepted': acc_all, 'contacts_emitted': emitted_all,
+                  'expansion_candidates_6A': exp_all, 'bags': counts},
+        'accepted_pairs_per_s': round(acc_all * args.steps / elapsed, 1),
+        'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()},
+        'kernel_launches_per_step': {k: v['launches'] / args.steps for k, v in ktimes.items() if v['launches']},
+        'halo_exchange_ms': round(halo_ms, 3), 'setup_s': round(gen_s, 2),
+        'roofline': roofline, 'cpu_baseline': cpu,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

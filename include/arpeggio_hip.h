@@ -159,7 +159,8 @@ int arp_search_all(arp_ctx* ctx, double radius, const uint8_t* active,
                    int64_t cap, int32_t* out_i, int32_t* out_j, int64_t* count);
 
 /* ---- _make_selection (I:1384-1451) --------------------------------------- */
-/* in_selection: u8[n] = utils.selection_parser result (or all ones).
+/* in_selection: u8[n] = utils.selection_parser result (NULL = keep the mask already uploaded,
+ * or the whole structure if none was).
  * Computes selection_plus (6.0 A expansion over ALL atoms incl. hydrogens,
  * I:1420-1424), residue sets and ring/amide id sets (I:1416-1417,1434-1437)
  * and keeps them in the context.  Outputs may be NULL. */
@@ -167,6 +168,19 @@ int arp_make_selection(arp_ctx* ctx, const uint8_t* in_selection, double expand_
                        uint8_t* out_plus /*n*/, uint8_t* out_ring_sel /*nring*/,
                        uint8_t* out_ring_plus /*nring*/, uint8_t* out_amide_sel /*namide*/,
                        uint8_t* out_amide_plus /*namide*/);
+
+/* Upload a selection mask without expanding it yet (arp_run_launch expands it). */
+int arp_set_selection(arp_ctx* ctx, const uint8_t* in_selection);
+
+/* ---- run_arpeggio (I:329-347) --------------------------------------------- */
+/* The whole hot path on the resident structure: _make_selection (6.0 A expansion of the
+ * selection uploaded by arp_set_selection / arp_make_selection; whole structure if none),
+ * _calculate_atom_contacts, _calculate_ring_contacts, _calculate_group_contacts.  Every
+ * kernel is enqueued back to back on the context stream with ONE host synchronisation at
+ * the end; results stay in HBM until fetched.  counts = records per bag in the order of
+ * get_contacts (I:183-210): atom-atom, plane-plane, atom-plane, group-group, group-plane. */
+int arp_run_launch(arp_ctx* ctx, double cutoff, double vdw_comp, int include_sequence_adjacent,
+                   double expand_radius, int64_t counts[5]);
 
 /* ---- _calculate_atom_contacts (I:693-936) -------------------------------- */
 /* Enqueue bin + sort + neighbour search + fused per-pair SIFt kernels on the
@@ -199,6 +213,25 @@ int arp_plane_plane(arp_ctx* ctx, int64_t cap, int32_t* out_bgn, int32_t* out_en
                     double* out_theta_end, uint8_t* out_type1, uint8_t* out_type2,
                     uint8_t* out_ctype, int64_t* count);
 
+/* launch-only / fetch-only halves of the four calls in this section and the next */
+int arp_atom_plane_launch(arp_ctx* ctx, int64_t* count);
+int arp_plane_plane_launch(arp_ctx* ctx, int64_t* count);
+int arp_group_group_launch(arp_ctx* ctx, int64_t* count);
+int arp_group_plane_launch(arp_ctx* ctx, int64_t* count);
+int arp_atom_plane_fetch(arp_ctx* ctx, int64_t cap, int32_t* out_atom, int32_t* out_ring,
+                         double* out_dist, double* out_theta, uint8_t* out_mask,
+                         uint8_t* out_ctype, int64_t* count);
+int arp_plane_plane_fetch(arp_ctx* ctx, int64_t cap, int32_t* out_bgn, int32_t* out_end,
+                          double* out_dist, double* out_dihedral, double* out_theta_bgn,
+                          double* out_theta_end, uint8_t* out_type1, uint8_t* out_type2,
+                          uint8_t* out_ctype, int64_t* count);
+int arp_group_group_fetch(arp_ctx* ctx, int64_t cap, int32_t* out_bgn, int32_t* out_end,
+                          float* out_dist, float* out_dihedral, float* out_theta,
+                          uint8_t* out_ctype, int64_t* count);
+int arp_group_plane_fetch(arp_ctx* ctx, int64_t cap, int32_t* out_amide, int32_t* out_ring,
+                          double* out_dist, double* out_dihedral, double* out_theta,
+                          uint8_t* out_ctype, int64_t* count);
+
 /* ---- _calculate_group_contacts (I:1208-1382) ----------------------------- */
 /* __calculate_group_group_contacts (I:1217-1300): ordered amide pairs, float32. */
 int arp_group_group(arp_ctx* ctx, int64_t cap, int32_t* out_bgn, int32_t* out_end,
@@ -219,11 +252,13 @@ int arp_set_ownership(arp_ctx* ctx, const uint8_t* is_home, const int32_t* globa
 /* ---- measurement ---------------------------------------------------------- */
 /* stats[0]=candidate pairs tested by the last atom-contact search,
  * stats[1]=pairs with d<=cutoff, stats[2]=pairs passing the residue filters
- * (= emitted contacts), stats[3]=atoms binned, stats[4]=grid cells. */
+ * (= emitted contacts), stats[3]=atoms binned, stats[4]=grid cells,
+ * stats[5]/[6]=candidates / hits of the last selection-expansion search. */
 int arp_get_stats(arp_ctx* ctx, int64_t stats[8]);
 /* When enabled, every kernel of arp_atom_contacts_launch is bracketed by
  * hipEvents on the context stream.  ms[k], launches[k] accumulate per kernel
- * slot: 0 bin, 1 scan, 2 scatter+cellsort, 3 gather, 4 search, 5 sift.
+ * slot: 0 bin, 1 scan, 2 scatter+cellsort, 3 gather, 4 contact search, 5 sift,
+ * 6 selection-expansion search, 7 ring/amide kernels.
  * reset != 0 clears the accumulators after reading. */
 int arp_set_profiling(arp_ctx* ctx, int enabled);
 int arp_get_kernel_times(arp_ctx* ctx, double ms[8], int64_t launches[8], int reset);

@@ -193,3 +193,32 @@ def test_full_size_config3_properties(ctx):
     oc = oracle.OracleComplex(pc)
     oc.make_selection(None)
     _assert_contacts_equal(got, oc.atom_contacts())
+
+
+def test_run_launch_single_sync_path(ctx):
+    """arp_run_launch (everything enqueued back to back, one sync) == the stage-by-stage calls == oracle."""
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.config3(20000, seed=13)
+    ctx.set_complex(pc)
+    sel = np.zeros(pc.n_atoms, np.uint8)
+    sel[(pc.res_id % 11) == 3] = 1
+    ctx.set_selection(sel)
+    counts = ctx.run_launch(5.0, 0.1, False, 6.0)
+    got = ctx.atom_contacts_fetch(counts['atom_atom'])
+    oc = oracle.OracleComplex(pc)
+    oc.make_selection(sel)
+    exp = oc.atom_contacts()
+    _assert_contacts_equal(got, exp)
+    epp = oc.plane_plane()
+    o = np.lexsort((epp['end'], epp['bgn']))
+    epp = {k: v[o] for k, v in epp.items()}
+    _assert_planes_equal(ctx.fetch_bag('plane_plane'), epp, ('bgn', 'end', 'type1', 'type2', 'ctype', 'dist'), ('dihedral', 'theta_bgn', 'theta_end'))
+    _assert_planes_equal(ctx.fetch_bag('atom_plane'), oc.atom_plane(), ('atom', 'ring', 'mask', 'ctype', 'dist'), ('theta',))
+    _assert_planes_equal(ctx.fetch_bag('group_group'), oc.group_group(), ('bgn', 'end', 'ctype', 'dist'), ('dihedral', 'theta'), tol=2e-4)
+    _assert_planes_equal(ctx.fetch_bag('group_plane'), oc.group_plane(), ('amide', 'ring', 'ctype', 'dist'), ('dihedral', 'theta'))
+    assert counts['plane_plane'] == len(epp['bgn'])
+    # a second run on the same context (buffers already sized) gives the same answer
+    counts2 = ctx.run_launch(5.0, 0.1, False, 6.0)
+    assert counts2 == counts
+    _assert_contacts_equal(ctx.atom_contacts_fetch(counts2['atom_atom']), exp)
