@@ -120,6 +120,7 @@ struct arp_ctx {
     u64 h_ctr[C_COUNT] = {0};
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t contact_cells = 0;
+    bool grid_all_atoms = false;  // atom_grid currently holds every atom (selection-expansion grid)
     // ---- device-resident result bags of the ring / amide kernels
     Bag bag_ap, bag_pp, bag_gg, bag_gp;
     // ---- profiling
@@ -155,6 +156,11 @@ int download(arp_ctx* c, T* dst, const T* src, size_t n) {
     if (n && dst) HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
 }
 
 inline int nblocks(int64_t work, int threads, int max_blocks = 2048) {
@@ -257,7 +263,11 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
         Prof p(c, SLOT_SCATTER);
         if (n > 0) {
             hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, G.cell_of.p, G.start.p, G.cnt.p, G.perm.p);
-            hipLaunchKernelGGL(k_cellsort, dim3(nblocks(ncell, 256)), dim3(256), 0, c->stream, ncell, G.start.p, G.perm.p);
+            // The order inside a cell does not change any result set (pairs are oriented by packed
+            // id and callers sort); ARP_DETERMINISTIC=1 additionally fixes the device-side order.
+            static const int deterministic = env_int("ARP_DETERMINISTIC", 0);
+            if (deterministic)
+                hipLaunchKernelGGL(k_cellsort, dim3(nblocks(ncell, 256)), dim3(256), 0, c->stream, ncell, G.start.p, G.perm.p);
             CHK(check_launch(c, "k_scatter/k_cellsort"));
         }
     }
@@ -284,6 +294,7 @@ int ensure_records(arp_ctx* c) {
 
 // grid over the atoms selected by (req, forb) meta masks, plus cell-sorted record copies
 int build_atom_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active) {
+    c->grid_all_atoms = false;
     CHK(ensure_records(c));
     const int n = (int)c->n;
     PtsF4 pts{c->xyzm.p};
@@ -304,9 +315,11 @@ int build_atom_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, cons
     return ARP_OK;
 }
 
+// Blocks of the neighbour search: ~ARP_SEARCH_CPW cells per wave, a multiple of 8 (one per XCD).
 int search_blocks(const GridDesc& d) {
-    int nb = (d.ncell + SEARCH_WAVES * 2 - 1) / (SEARCH_WAVES * 2);
-    nb = std::max(8, std::min(nb, 4096));
+    static const int cpw = std::max(1, env_int("ARP_SEARCH_CPW", 1));
+    int nb = (d.ncell + SEARCH_WAVES * cpw - 1) / (SEARCH_WAVES * cpw);
+    nb = std::max(8, std::min(nb, 8192));
     return (nb + 7) & ~7;
 }
 
@@ -317,6 +330,12 @@ int zero_counter(arp_ctx* c, int first, int count) {
 int read_counters(arp_ctx* c) {  // one D2H copy + the only stream sync of a pass
     HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(u64) * C_COUNT, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto fold = [&](int first, int into) {
+        u64 t = 0;
+        for (int k = 0; k < STAT_SLOTS; ++k) t += c->h_ctr[first + k];
+        c->h_ctr[into] = t;
+    };
+    fold(C_STAT_CAND, C_CAND); fold(C_STAT_ACC, C_ACC); fold(C_STAT_MCAND, C_MARK_CAND); fold(C_STAT_MACC, C_MARK_ACC);
     return ARP_OK;
 }
 
@@ -361,12 +380,12 @@ int enqueue_selection(arp_ctx* c, double radius) {
     c->records_dirty = true;
     // I:1420-1424: search_all(6.0) over ALL atoms (hydrogens included)
     CHK(build_atom_grid(c, radius, 0, 0, nullptr));
-    CHK(zero_counter(c, C_MARK_CAND, 2));
+    CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
     if (n > 0) {
         Prof p(c, SLOT_MARK);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, (int2*)nullptr,
-                           0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_MARK_CAND, c->d_ctr + C_MARK_ACC, c->plus.p);
+                           0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // I:1413-1437 residue, ring and amide sets
@@ -385,8 +404,8 @@ int enqueue_selection(arp_ctx* c, double radius) {
         hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, (int)c->namide, c->am_res.p,
                            c->res_sel.p, c->res_plus.p, c->am_sel.p, c->am_plus.p);
     CHK(check_launch(c, "selection masks"));
-    c->records_dirty = true;  // M_PLUS changed
-    c->atom_grid.valid = false;
+    c->records_dirty = true;   // M_PLUS changed; the next grid build refreshes the records
+    c->grid_all_atoms = true;  // the 6 A all-atom grid stays usable for the atom-plane kernel (reads plus[] directly)
     c->contacts_valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
     return ARP_OK;
@@ -409,7 +428,8 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     const size_t cap = c->pairs.cap;
     HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
-    CHK(zero_counter(c, C_PAIRS, 3));
+    CHK(zero_counter(c, C_PAIRS, 1));
+    CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
     CHK(zero_counter(c, C_BINNED, 1));
     CHK(zero_counter(c, C_ERR, 1));
     HIPCHK(c, hipMemcpyAsync(c->d_ctr + C_BINNED, c->atom_grid.start.p + c->atom_grid.d.ncell, sizeof(int),
@@ -419,7 +439,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             Prof p(c, SLOT_SEARCH);
             hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->pairs.p, (u64)cap, c->d_ctr + C_PAIRS, c->d_ctr + C_CAND, c->d_ctr + C_ACC,
+                               include_seq_adj, c->pairs.p, (u64)cap, c->d_ctr + C_PAIRS, c->d_ctr + C_STAT_CAND, c->d_ctr + C_STAT_ACC,
                                (uint8_t*)nullptr);
             CHK(check_launch(c, "k_search<CONTACTS>"));
         }
@@ -449,13 +469,17 @@ int enqueue_atom_plane(arp_ctx* c) {  // I:947-1062
     if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->nring * 8 + 256, true, false));
     CHK(zero_counter(c, C_AP, 1));
     if (c->nring == 0 || c->n == 0) return ARP_OK;
-    CHK(build_atom_grid(c, 6.0, M_PLUS, M_HYDROGEN, nullptr));  // I:960 radius
-    c->atom_grid.valid = false;
+    // all-atom 6 A grid: the one the selection expansion has just built, if it is still current
+    if (!(c->atom_grid.valid && c->atom_grid.radius == 6.0 && c->grid_all_atoms)) {
+        CHK(build_atom_grid(c, 6.0, 0, 0, nullptr));  // I:960 radius
+        c->grid_all_atoms = true;
+        c->atom_grid.valid = true;
+    }
     Prof p(c, SLOT_PLANES);
     hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
                        c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p,
-                       c->ring_plus.p, c->has_gid ? c->gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p,
-                       b.u1.p, c->d_ctr + C_AP);
+                       c->ring_plus.p, c->plus.p, c->has_gid ? c->gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p,
+                       b.u0.p, b.u1.p, c->d_ctr + C_AP);
     return check_launch(c, "k_atom_plane");
 }
 
@@ -778,11 +802,12 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     c->atom_grid.valid = false;  // not the contact grid
     c->contacts_valid = false;
     HIPCHK(c, c->pairs.reserve((size_t)std::max<int64_t>(cap, 1)));
-    CHK(zero_counter(c, C_SEARCH_PAIRS, 3));
+    CHK(zero_counter(c, C_SEARCH_PAIRS, 1));
+    CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, c->pairs.p,
-                           (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_SCRATCH0, c->d_ctr + C_SCRATCH1, (uint8_t*)nullptr);
+                           (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, (uint8_t*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));
@@ -959,9 +984,9 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
     }
     for (int attempt = 0;; ++attempt) {
         CHK(enqueue_selection(c, expand_radius));                                   // I:342
+        CHK(enqueue_atom_plane(c));                                                 // I:346 (I:945), reuses the 6 A grid
         CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345
         CHK(enqueue_plane_plane(c));                                                // I:346 (I:944)
-        CHK(enqueue_atom_plane(c));                                                 //       (I:945)
         CHK(enqueue_group_group(c));                                                // I:347 (I:1214)
         CHK(enqueue_group_plane(c));                                                //       (I:1215)
         CHK(read_counters(c));

@@ -42,8 +42,12 @@ enum {
     C_SCRATCH0 = 10, C_SCRATCH1 = 11,
     C_BINNED = 12,    // atoms in the contact grid (low 32 bits)
     C_ERR = 15,       // ARP_E_* raised on the device (low 32 bits)
-    C_COUNT = 16
+    // statistics counters are spread over STAT_SLOTS addresses (hashed by block) so that the
+    // end-of-block atomics of thousands of blocks do not serialise on one L2 line
+    C_STAT_CAND = 16, C_STAT_ACC = 16 + 64, C_STAT_MCAND = 16 + 128, C_STAT_MACC = 16 + 192,
+    C_COUNT = 16 + 256
 };
+#define STAT_SLOTS 64
 typedef unsigned long long u64;
 
 // atom records: xyzm = {x, y, z, meta}; aux = {local id, residue, prev residue, next residue}
@@ -99,10 +103,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
     const int per = nb >> 3;
     int vb = blockIdx.x;
     if (per > 0 && blockIdx.x < per * 8) vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int nwave = nb * SEARCH_WAVES;
-    const int cells_per_wave = (g.ncell + nwave - 1) / nwave;
-    const int c_begin = (vb * SEARCH_WAVES + w) * cells_per_wave;
-    const int c_end = min(c_begin + cells_per_wave, g.ncell);
+    // waves of a block interleave over the block's run of cells (balances empty regions)
+    const int cells_per_block = (g.ncell + nb - 1) / nb;
+    const int c_begin = vb * cells_per_block + w;
+    const int c_end = min((vb + 1) * cells_per_block, g.ncell);
 
     int qn = 0;
     unsigned long long n_cand = 0, n_acc = 0;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         qn = 0;
     };
 
-    for (int cell = c_begin; cell < c_end; ++cell) {
+    for (int cell = c_begin; cell < c_end; cell += SEARCH_WAVES) {
         const int hs = __builtin_amdgcn_readfirstlane(start[cell]);
         const int he = __builtin_amdgcn_readfirstlane(start[cell + 1]);
         if (hs == he) continue;
@@ -216,10 +220,27 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
             }
         }
     }
-    if (MODE != MODE_MARK && qn > 0) flush();
-    if (lane == 0) {
-        atomicAdd(ctr_cand, n_cand);
-        atomicAdd(ctr_acc, n_acc);
+    // End of block: the four per-wave queues leave with ONE atomicAdd (single-address atomics
+    // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
+    __shared__ int s_qn[SEARCH_WAVES];
+    __shared__ u64 s_base, s_cand[SEARCH_WAVES], s_acc[SEARCH_WAVES];
+    if (lane == 0) { s_qn[w] = qn; s_cand[w] = n_cand; s_acc[w] = n_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        u64 tc = 0, ta = 0;
+        for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
+        s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(ctr_pairs, (u64)tot) : 0;
+        const int slot = blockIdx.x & (STAT_SLOTS - 1);
+        atomicAdd(ctr_cand + slot, tc);
+        atomicAdd(ctr_acc + slot, ta);
+    }
+    __syncthreads();
+    if (MODE != MODE_MARK && qn > 0) {
+        u64 base = s_base;
+        for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
+        for (int k = lane; k < qn; k += 64)
+            if (base + k < cap) pairs[base + k] = q[w][k];
     }
 }
 

@@ -41,13 +41,16 @@ __device__ __forceinline__ CellBox cell_box(const GridDesc& g, num::d3 p) {
             cell_coord_raw(p.z, g.oz, g.inv, g.nz)};
 }
 
-// One wavefront per ring; lanes sweep the atoms (selection_plus, no hydrogens) of the
-// 27 cells around the ring centre = NeighborSearch.search(center, 6.0) (I:960).
+// One wavefront per ring; lanes sweep the atoms of the 27 cells around the ring centre =
+// NeighborSearch.search(center, 6.0) (I:960).  The grid is the all-atom 6 A grid of the
+// selection expansion; membership of the selection_plus tree (I:1442) and the hydrogen
+// filter (I:964) are applied per atom.
 __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __restrict__ start,
                                                     const float4* __restrict__ s_xyzm, const int4* __restrict__ s_aux,
                                                     int nring, const double* __restrict__ ring_c,
                                                     const double* __restrict__ ring_n, const int* __restrict__ ring_res,
                                                     const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
+                                                    const uint8_t* __restrict__ plus,
                                                     const int* __restrict__ gid, long long cap, int* __restrict__ out_atom,
                                                     int* __restrict__ out_ring, double* __restrict__ out_dist,
                                                     double* __restrict__ out_theta, uint8_t* __restrict__ out_mask,
@@ -78,10 +81,11 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
                         const float4 v = s_xyzm[j];
                         const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
                         m = __float_as_uint(v.w);
-                        // I:960 tree membership (float64, inclusive); hydrogens are not in the grid (I:964)
-                        if (num::dist2_kd(ctr_, x) <= 36.0 && !(m & ARP_T_AROMATIC)) {  // I:975
+                        // I:960 tree membership (float64, inclusive), I:964 hydrogens, I:975 aromatic atoms
+                        if (num::dist2_kd(ctr_, x) <= 36.0 && !(m & (M_HYDROGEN | ARP_T_AROMATIC)) &&
+                            plus[lid = s_aux[j].x]) {
                             dist = num::norm(num::sub(x, ctr_));                        // I:972
-                            ct = plane_ctype(rsel, m & M_SEL, true, m & M_PLUS);        // I:985-997
+                            ct = plane_ctype(rsel, m & M_SEL, true, true);              // I:985-997
                             theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
                             if (dist <= 4.5 && theta <= 30.0) {                         // I:1007
                                 if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
@@ -93,7 +97,6 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
                                 if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
                             }
                             emit = mask != 0;                                           // I:1026
-                            lid = s_aux[j].x;
                         }
                     }
                     const unsigned long long me = __ballot(emit);
