@@ -120,6 +120,7 @@ struct arp_ctx {
     u64 h_ctr[C_COUNT] = {0};
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t contact_cells = 0;
+    bool ctr_clean = false;
     bool grid_all_atoms = false;  // atom_grid currently holds every atom (selection-expansion grid)
     // ---- device-resident result bags of the ring / amide kernels
     Bag bag_ap, bag_pp, bag_gg, bag_gp;
@@ -239,13 +240,17 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     const int ncell = G.d.ncell;
     HIPCHK(c, G.cell_of.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, G.perm.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, G.cnt.reserve((size_t)ncell + 1));
+    {   // the histogram is zero on entry: k_scatter's atomicSub takes every counter back to 0,
+        // so only a fresh allocation needs clearing
+        int* before = G.cnt.p;
+        HIPCHK(c, G.cnt.reserve((size_t)ncell + 1));
+        if (G.cnt.p != before) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), c->stream));
+    }
     HIPCHK(c, G.start.reserve((size_t)ncell + 2));
     const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
     HIPCHK(c, G.sums.reserve((size_t)nb_scan + 2));
     {
         Prof p(c, SLOT_BIN);
-        HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, ((size_t)ncell + 1) * sizeof(int), c->stream));
         if (n > 0) {
             hipLaunchKernelGGL((k_bin<P, FILTER>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, pts, n, G.d, active,
                                xyzm, req, forb, G.cell_of.p, G.cnt.p);
@@ -324,6 +329,7 @@ int search_blocks(const GridDesc& d) {
 }
 
 int zero_counter(arp_ctx* c, int first, int count) {
+    if (c->ctr_clean) return ARP_OK;  // arp_run_launch cleared the whole block with one memset
     HIPCHK(c, hipMemsetAsync(c->d_ctr + first, 0, sizeof(u64) * (size_t)count, c->stream));
     return ARP_OK;
 }
@@ -390,19 +396,19 @@ int enqueue_selection(arp_ctx* c, double radius) {
     }
     // I:1413-1437 residue, ring and amide sets
     const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
-    HIPCHK(c, c->res_sel.reserve(nres));
-    HIPCHK(c, c->res_plus.reserve(nres));
-    HIPCHK(c, hipMemsetAsync(c->res_sel.p, 0, nres, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->res_plus.p, 0, nres, c->stream));
+    HIPCHK(c, c->res_sel.reserve(2 * nres));   // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
+    uint8_t* res_sel = c->res_sel.p;
+    uint8_t* res_plus = c->res_sel.p + nres;
+    HIPCHK(c, hipMemsetAsync(res_sel, 0, 2 * nres, c->stream));
     if (n > 0)
         hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
-                           c->res_sel.p, c->res_plus.p);
+                           res_sel, res_plus);
     if (c->nring > 0)
         hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, (int)c->nring, c->ring_res.p,
-                           c->res_sel.p, c->res_plus.p, c->ring_sel.p, c->ring_plus.p);
+                           res_sel, res_plus, c->ring_sel.p, c->ring_plus.p);
     if (c->namide > 0)
         hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, (int)c->namide, c->am_res.p,
-                           c->res_sel.p, c->res_plus.p, c->am_sel.p, c->am_plus.p);
+                           res_sel, res_plus, c->am_sel.p, c->am_plus.p);
     CHK(check_launch(c, "selection masks"));
     c->records_dirty = true;   // M_PLUS changed; the next grid build refreshes the records
     c->grid_all_atoms = true;  // the 6 A all-atom grid stays usable for the atom-plane kernel (reads plus[] directly)
@@ -476,7 +482,7 @@ int enqueue_atom_plane(arp_ctx* c) {  // I:947-1062
         c->atom_grid.valid = true;
     }
     Prof p(c, SLOT_PLANES);
-    hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
+    hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256, 8192)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
                        c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p,
                        c->ring_plus.p, c->plus.p, c->has_gid ? c->gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p,
                        b.u0.p, b.u1.p, c->d_ctr + C_AP);
@@ -490,7 +496,7 @@ int enqueue_plane_plane(arp_ctx* c) {  // I:1064-1194
     if (c->nring == 0) return ARP_OK;
     CHK(ensure_ring_grid(c));
     Prof p(c, SLOT_PLANES);
-    hipLaunchKernelGGL(k_plane_plane, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
+    hipLaunchKernelGGL(k_plane_plane, dim3(nblocks(c->nring * 64, 256, 8192)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
                        c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p, c->ring_plus.p,
                        (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP);
     return check_launch(c, "k_plane_plane");
@@ -503,7 +509,7 @@ int enqueue_group_group(arp_ctx* c) {  // I:1217-1300
     if (c->namide == 0) return ARP_OK;
     CHK(ensure_amide_grid(c));
     Prof p(c, SLOT_PLANES);
-    hipLaunchKernelGGL(k_group_group, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->amide_grid.d, c->amide_grid.start.p,
+    hipLaunchKernelGGL(k_group_group, dim3(nblocks(c->namide * 64, 256, 8192)), dim3(256), 0, c->stream, c->amide_grid.d, c->amide_grid.start.p,
                        c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, (long long)b.cap,
                        b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p, b.u0.p, c->d_ctr + C_GG);
     return check_launch(c, "k_group_group");
@@ -516,7 +522,7 @@ int enqueue_group_plane(arp_ctx* c) {  // I:1302-1382
     if (c->namide == 0 || c->nring == 0) return ARP_OK;
     CHK(ensure_ring_grid(c));
     Prof p(c, SLOT_PLANES);
-    hipLaunchKernelGGL(k_group_plane, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
+    hipLaunchKernelGGL(k_group_plane, dim3(nblocks(c->namide * 64, 256, 8192)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
                        c->ring_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, c->ring_c.p,
                        c->ring_n.p, c->ring_sel.p, c->ring_plus.p, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.u0.p,
                        c->d_ctr + C_GP);
@@ -983,6 +989,9 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
     }
     for (int attempt = 0;; ++attempt) {
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
+        c->ctr_clean = true;
+        struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
         CHK(enqueue_selection(c, expand_radius));                                   // I:342
         CHK(enqueue_atom_plane(c));                                                 // I:346 (I:945), reuses the 6 A grid
         CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345

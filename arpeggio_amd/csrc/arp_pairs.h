@@ -79,11 +79,12 @@ __global__ __launch_bounds__(256) void k_build_records(int n, const float4* __re
 
 enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
 
-// One wavefront per home cell.  Lanes hold the atoms of a neighbour range in registers
-// (coalesced float4 loads of the cell-sorted records), the home atoms are wave-uniform,
-// so each neighbour record is loaded once per home cell and reused for every home atom.
-// Half stencil: own cell (later entries) + 13 forward cells, expressed as 5 contiguous
-// ranges of the sorted array (cells are x-fastest, so 3 x-neighbours are contiguous).
+// One wavefront per home cell.  Half stencil: own cell (later entries) + 13 forward cells,
+// expressed as 5 contiguous ranges of the cell-sorted array (cells are x-fastest, so 3
+// x-neighbours are contiguous).  The ~87 candidate atoms of the 5 ranges are flattened over
+// the lanes and held in registers; the home atoms are broadcast from registers with
+// v_readlane, so each record is loaded once per home cell and the inner loop touches no
+// memory.
 // Accepted pairs are compacted with __ballot into a per-wave LDS queue that is flushed
 // to global memory with one atomicAdd per ~QCAP pairs.
 template <int MODE>
@@ -130,6 +131,29 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         const int rem = cell - cz * g.nx * g.ny;
         const int cy = rem / g.nx;
         const int cx = rem - cy * g.nx;
+        // Lanes 0..4 fetch the bounds of the 5 neighbour ranges in parallel (one load latency):
+        // range 0 = home pencil [own cell, cx+1], ranges 1..4 = the forward pencils [cx-1, cx+1].
+        int my_js = 0, my_len = 0;
+        if (lane < 5) {
+            const int dy = (lane == 0) ? 0 : (lane == 1) ? 1 : (lane - 3);
+            const int dz = (lane <= 1) ? 0 : 1;
+            const int y2 = cy + dy, z2 = cz + dz;
+            if (y2 >= 0 && y2 < g.ny && z2 < g.nz) {
+                const int rowbase = (z2 * g.ny + y2) * g.nx;
+                const int xlo = (lane == 0) ? cx : max(cx - 1, 0);
+                const int xhi = min(cx + 1, g.nx - 1);
+                my_js = (lane == 0) ? hs : start[rowbase + xlo];
+                my_len = start[rowbase + xhi + 1] - my_js;
+            }
+        }
+        const int js0 = __builtin_amdgcn_readlane(my_js, 0), js1 = __builtin_amdgcn_readlane(my_js, 1),
+                  js2 = __builtin_amdgcn_readlane(my_js, 2), js3 = __builtin_amdgcn_readlane(my_js, 3),
+                  js4 = __builtin_amdgcn_readlane(my_js, 4);
+        const int o1 = __builtin_amdgcn_readlane(my_len, 0);           // candidates [0, o1) come from range 0
+        const int o2 = o1 + __builtin_amdgcn_readlane(my_len, 1);
+        const int o3 = o2 + __builtin_amdgcn_readlane(my_len, 2);
+        const int o4 = o3 + __builtin_amdgcn_readlane(my_len, 3);
+        const int total = o4 + __builtin_amdgcn_readlane(my_len, 4);
 #pragma unroll 1
         for (int hb = hs; hb < he; hb += 64) {  // home atoms, 64 at a time, one per lane
             const int hcount = min(64, he - hb);
@@ -139,82 +163,71 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
             if (MODE != MODE_PAIRS && hvalid) hauxreg = s_aux[hb + lane];
             if (MODE == MODE_PAIRS && hvalid) hauxreg.x = s_aux[hb + lane].x;
 #pragma unroll 1
-            for (int r = 0; r < 5; ++r) {
-                // (dy, dz) of the 5 ranges: home pencil, then the 4 forward pencils
-                const int dy = (r == 0) ? 0 : (r == 1) ? 1 : (r - 3);
-                const int dz = (r <= 1) ? 0 : 1;
-                const int y2 = cy + dy, z2 = cz + dz;
-                if (y2 < 0 || y2 >= g.ny || z2 >= g.nz) continue;
-                const int rowbase = (z2 * g.ny + y2) * g.nx;
-                const int xlo = (r == 0) ? cx : max(cx - 1, 0);
-                const int xhi = min(cx + 1, g.nx - 1);
-                const int js = (r == 0) ? hb : __builtin_amdgcn_readfirstlane(start[rowbase + xlo]);
-                const int je = __builtin_amdgcn_readfirstlane(start[rowbase + xhi + 1]);
+            for (int kb = 0; kb < total; kb += 64) {  // the ~87 candidates of this cell, flattened over the lanes
+                const int k = kb + lane;
+                const bool valid = k < total;
+                const bool in_r0 = k < o1;
+                const int j = in_r0 ? js0 + k : (k < o2) ? js1 + (k - o1) : (k < o3) ? js2 + (k - o2)
+                                              : (k < o4) ? js3 + (k - o3) : js4 + (k - o4);
+                const float4 xj = valid ? s_xyzm[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                int4 aj = make_int4(0, 0, 0, 0);
+                if (MODE != MODE_PAIRS && valid) aj = s_aux[j];
+                if (MODE == MODE_PAIRS && valid) aj.x = s_aux[j].x;
+                const num::d3 pj = {(double)xj.x, (double)xj.y, (double)xj.z};
+                const uint32_t mj = __float_as_uint(xj.w);
 #pragma unroll 1
-                for (int jb = js; jb < je; jb += 64) {
-                    const int j = jb + lane;
-                    const bool valid = j < je;
-                    const float4 xj = valid ? s_xyzm[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    int4 aj = make_int4(0, 0, 0, 0);
-                    if (MODE != MODE_PAIRS && valid) aj = s_aux[j];
-                    if (MODE == MODE_PAIRS && valid) aj.x = s_aux[j].x;
-                    const num::d3 pj = {(double)xj.x, (double)xj.y, (double)xj.z};
-                    const uint32_t mj = __float_as_uint(xj.w);
-                    // in range 0 only later entries of the sorted array (j > h) pair up
-                    const int hh_end = (r == 0) ? min(hcount, jb + 64 - hb) : hcount;
-#pragma unroll 1
-                    for (int hh = 0; hh < hh_end; ++hh) {
-                        const int h = hb + hh;
-                        // broadcast the home atom from lane hh (v_readlane, no memory traffic)
-                        const num::d3 ph = {(double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh)),
-                                            (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh)),
-                                            (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.z), hh))};
-                        const bool tested = valid && (r != 0 || j > h);
-                        const bool hit = tested && (num::dist2_kd(ph, pj) <= r2);
-                        n_cand += __popcll(__ballot(tested));
-                        const unsigned long long mhit = __ballot(hit);
-                        if (mhit == 0) continue;
-                        n_acc += __popcll(mhit);
-                        const uint32_t mh = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
-                        const int4 ah = make_int4(__builtin_amdgcn_readlane(hauxreg.x, hh), __builtin_amdgcn_readlane(hauxreg.y, hh),
-                                                  __builtin_amdgcn_readlane(hauxreg.z, hh), __builtin_amdgcn_readlane(hauxreg.w, hh));
-                        if (MODE == MODE_MARK) {
-                            // interactions.py:1420-1424: either atom selected -> both join selection_plus
-                            if (hit && ((mh | mj) & M_SEL)) {
-                                plus[aj.x] = 1;
-                                plus[ah.x] = 1;
-                            }
-                            continue;
+                for (int hh = 0; hh < hcount; ++hh) {
+                    const int h = hb + hh;
+                    // broadcast the home atom from lane hh (v_readlane, no memory traffic)
+                    const num::d3 ph = {(double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh)),
+                                        (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh)),
+                                        (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.z), hh))};
+                    // inside the home pencil only later entries of the sorted array (j > h) pair up
+                    const bool tested = valid && (!in_r0 || j > h);
+                    const bool hit = tested && (num::dist2_kd(ph, pj) <= r2);
+                    n_cand += __popcll(__ballot(tested));
+                    const unsigned long long mhit = __ballot(hit);
+                    if (mhit == 0) continue;
+                    n_acc += __popcll(mhit);
+                    const uint32_t mh = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
+                    const int4 ah = make_int4(__builtin_amdgcn_readlane(hauxreg.x, hh), __builtin_amdgcn_readlane(hauxreg.y, hh),
+                                              __builtin_amdgcn_readlane(hauxreg.z, hh), __builtin_amdgcn_readlane(hauxreg.w, hh));
+                    if (MODE == MODE_MARK) {
+                        // interactions.py:1420-1424: either atom selected -> both join selection_plus
+                        if (hit && ((mh | mj) & M_SEL)) {
+                            plus[aj.x] = 1;
+                            plus[ah.x] = 1;
                         }
-                        bool pass = hit;
-                        int pb, pe;
-                        if (MODE == MODE_CONTACTS) {
-                            // canonical orientation: bgn = lower packed index
-                            const bool h_first = ah.x < aj.x;
-                            const int4 ab = h_first ? ah : aj;
-                            const int4 ae = h_first ? aj : ah;
-                            const uint32_t mb = h_first ? mh : mj;
-                            const uint32_t me = h_first ? mj : mh;
-                            pb = h_first ? h : j;
-                            pe = h_first ? j : h;
-                            // interactions.py:729 same residue
-                            if (ab.y == ae.y) pass = false;
-                            // interactions.py:733-741 sequence-adjacent residues (res_end tested twice)
-                            if (!include_seq_adj && (me & M_RES_POLY) && (mb & M_RES_HASSEQ) && (me & M_RES_HASSEQ)) {
-                                if (ab.w == ae.y || ab.z == ae.y || ae.w == ab.y || ae.z == ab.y) pass = false;
-                            }
-                            // multi-GPU ownership: the rank owning the bgn atom emits the pair
-                            if (!(mb & M_HOME)) pass = false;
-                        } else {  // MODE_PAIRS: raw search_all, report packed ids (i < j)
-                            pb = min(ah.x, aj.x);
-                            pe = max(ah.x, aj.x);
+                        continue;
+                    }
+                    bool pass = hit;
+                    int pb, pe;
+                    if (MODE == MODE_CONTACTS) {
+                        // canonical orientation: bgn = lower packed index
+                        const bool h_first = ah.x < aj.x;
+                        const int4 ab = h_first ? ah : aj;
+                        const int4 ae = h_first ? aj : ah;
+                        const uint32_t mb = h_first ? mh : mj;
+                        const uint32_t me = h_first ? mj : mh;
+                        pb = h_first ? h : j;
+                        pe = h_first ? j : h;
+                        // interactions.py:729 same residue
+                        if (ab.y == ae.y) pass = false;
+                        // interactions.py:733-741 sequence-adjacent residues (res_end tested twice)
+                        if (!include_seq_adj && (me & M_RES_POLY) && (mb & M_RES_HASSEQ) && (me & M_RES_HASSEQ)) {
+                            if (ab.w == ae.y || ab.z == ae.y || ae.w == ab.y || ae.z == ab.y) pass = false;
                         }
-                        const unsigned long long mp = __ballot(pass);
-                        if (mp) {
-                            if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
-                            qn += __popcll(mp);
-                            if (qn > QCAP - 64) flush();
-                        }
+                        // multi-GPU ownership: the rank owning the bgn atom emits the pair
+                        if (!(mb & M_HOME)) pass = false;
+                    } else {  // MODE_PAIRS: raw search_all, report packed ids (i < j)
+                        pb = min(ah.x, aj.x);
+                        pe = max(ah.x, aj.x);
+                    }
+                    const unsigned long long mp = __ballot(pass);
+                    if (mp) {
+                        if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
+                        qn += __popcll(mp);
+                        if (qn > QCAP - 64) flush();
                     }
                 }
             }

@@ -41,6 +41,51 @@ __device__ __forceinline__ CellBox cell_box(const GridDesc& g, num::d3 p) {
             cell_coord_raw(p.z, g.oz, g.inv, g.nz)};
 }
 
+// ---- 27-cell stencil, flattened over the lanes of one wavefront ------------------------------
+// Lane r < 9 owns one (dy, dz) row of the stencil: three x-neighbour cells are contiguous in
+// the cell-sorted array, so a row is one run [js, js+len).  All 18 bounds are fetched in one
+// load round; candidate k of the concatenated runs is then mapped to a sorted position.
+struct Stencil {
+    int js[9];
+    int pre[10];  // pre[r] = candidates before row r; pre[9] = total
+};
+__device__ __forceinline__ Stencil stencil_load(const GridDesc& g, const int* __restrict__ start, CellBox cb, int lane) {
+    int my_js = 0, my_len = 0;
+    if (lane < 9) {
+        const int y2 = cb.cy + (lane % 3) - 1, z2 = cb.cz + (lane / 3) - 1;
+        const int xlo = max(cb.cx - 1, 0), xhi = min(cb.cx + 1, g.nx - 1);
+        if (y2 >= 0 && y2 < g.ny && z2 >= 0 && z2 < g.nz && xlo <= xhi) {
+            const int rowbase = (z2 * g.ny + y2) * g.nx;
+            my_js = start[rowbase + xlo];
+            my_len = start[rowbase + xhi + 1] - my_js;
+        }
+    }
+    Stencil st;
+    st.pre[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        st.js[r] = __builtin_amdgcn_readlane(my_js, r);
+        st.pre[r + 1] = st.pre[r] + __builtin_amdgcn_readlane(my_len, r);
+    }
+    return st;
+}
+__device__ __forceinline__ int stencil_pos(const Stencil& st, int k) {
+    int pos = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+        if (k >= st.pre[r] && k < st.pre[r + 1]) pos = st.js[r] + (k - st.pre[r]);
+    return pos;
+}
+// slot allocation for the lanes with emit == true: one atomicAdd per wavefront
+__device__ __forceinline__ long long wave_slot(bool emit, u64* __restrict__ n_out, int lane) {
+    const unsigned long long me = __ballot(emit);
+    if (!me) return -1;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(me));
+    base = __shfl(base, 0);
+    return (long long)(base + __popcll(me & ((1ull << lane) - 1ull)));
+}
+
 // One wavefront per ring; lanes sweep the atoms of the 27 cells around the ring centre =
 // NeighborSearch.search(center, 6.0) (I:960).  The grid is the all-atom 6 A grid of the
 // selection expansion; membership of the selection_plus tree (I:1442) and the hydrogen
@@ -62,65 +107,50 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
         if (!ring_plus[r]) continue;  // I:957
         const num::d3 ctr_ = ld3(ring_c, r), nrm = ld3(ring_n, r);
         const bool rsel = ring_sel[r];
-        const CellBox cb = cell_box(g, ctr_);
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int y2 = cb.cy + dy, z2 = cb.cz + dz;
-                if (y2 < 0 || y2 >= g.ny || z2 < 0 || z2 >= g.nz) continue;
-                const int xlo = max(cb.cx - 1, 0), xhi = min(cb.cx + 1, g.nx - 1);
-                if (xlo > xhi) continue;
-                const int rowbase = (z2 * g.ny + y2) * g.nx;
-                const int js = start[rowbase + xlo], je = start[rowbase + xhi + 1];
-                for (int jb = js; jb < je; jb += 64) {
-                    const int j = jb + lane;
-                    bool emit = false;
-                    double dist = 0, theta = 0;
-                    uint32_t mask = 0, m = 0;
-                    int ct = 0, lid = 0;
-                    if (j < je) {
-                        const float4 v = s_xyzm[j];
-                        const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
-                        m = __float_as_uint(v.w);
-                        // I:960 tree membership (float64, inclusive), I:964 hydrogens, I:975 aromatic atoms
-                        if (num::dist2_kd(ctr_, x) <= 36.0 && !(m & (M_HYDROGEN | ARP_T_AROMATIC)) &&
-                            plus[lid = s_aux[j].x]) {
-                            dist = num::norm(num::sub(x, ctr_));                        // I:972
-                            ct = plane_ctype(rsel, m & M_SEL, true, true);              // I:985-997
-                            theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
-                            if (dist <= 4.5 && theta <= 30.0) {                         // I:1007
-                                if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
-                                if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
-                                if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
-                                if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
-                            }
-                            if (dist <= 6.0) {                                          // I:1021
-                                if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
-                            }
-                            emit = mask != 0;                                           // I:1026
-                        }
+        const Stencil st = stencil_load(g, start, cell_box(g, ctr_), lane);
+        for (int kb = 0; kb < st.pre[9]; kb += 64) {
+            const int k = kb + lane;
+            bool emit = false;
+            double dist = 0, theta = 0;
+            uint32_t mask = 0;
+            int ct = 0, lid = 0;
+            if (k < st.pre[9]) {
+                const int j = stencil_pos(st, k);
+                const float4 v = s_xyzm[j];
+                const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
+                const uint32_t m = __float_as_uint(v.w);
+                // I:960 tree membership (float64, inclusive), I:964 hydrogens, I:975 aromatic atoms
+                if (num::dist2_kd(ctr_, x) <= 36.0 && !(m & (M_HYDROGEN | ARP_T_AROMATIC)) && plus[lid = s_aux[j].x]) {
+                    dist = num::norm(num::sub(x, ctr_));                        // I:972
+                    ct = plane_ctype(rsel, m & M_SEL, true, true);              // I:985-997
+                    theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
+                    if (dist <= 4.5 && theta <= 30.0) {                         // I:1007
+                        if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
+                        if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
+                        if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
+                        if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
                     }
-                    const unsigned long long me = __ballot(emit);
-                    if (me) {
-                        unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(me));
-                        base = __shfl(base, 0);
-                        const long long slot = (long long)(base + __popcll(me & ((1ull << lane) - 1ull)));
-                        if (emit && slot < cap) {
-                            out_atom[slot] = gid ? gid[lid] : lid;
-                            out_ring[slot] = r;
-                            out_dist[slot] = dist;
-                            out_theta[slot] = theta;
-                            out_mask[slot] = (uint8_t)mask;
-                            out_ct[slot] = (uint8_t)ct;
-                        }
+                    if (dist <= 6.0) {                                          // I:1021
+                        if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
                     }
+                    emit = mask != 0;                                           // I:1026
                 }
             }
+            const long long slot = wave_slot(emit, n_out, lane);
+            if (emit && slot < cap) {
+                out_atom[slot] = gid ? gid[lid] : lid;
+                out_ring[slot] = r;
+                out_dist[slot] = dist;
+                out_theta[slot] = theta;
+                out_mask[slot] = (uint8_t)mask;
+                out_ct[slot] = (uint8_t)ct;
+            }
+        }
     }
 }
 
-// Thread per ring a; partners b > a in the 27 cells around it.  Reproduces both visits
-// (a,b) and (b,a) of the reference's ordered double loop and its dedupe (I:1181-1194).
+// One wavefront per ring a; lanes = partner rings b > a of the 27 cells around it.  Reproduces
+// both visits (a,b) and (b,a) of the reference's ordered double loop and its dedupe (I:1181-1194).
 __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
                                                      int nring, const double* __restrict__ ring_c,
                                                      const double* __restrict__ ring_n, const int* __restrict__ ring_res,
@@ -130,58 +160,62 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
                                                      double* __restrict__ out_t1, double* __restrict__ out_t2,
                                                      uint8_t* __restrict__ out_y1, uint8_t* __restrict__ out_y2,
                                                      uint8_t* __restrict__ out_ct, u64* __restrict__ n_out) {
-    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < nring; a += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int a = wave; a < nring; a += nwave) {
         if (!ring_plus[a]) continue;  // I:1081
         const num::d3 ca = ld3(ring_c, a), na = ld3(ring_n, a);
         const int ra = ring_res[a];
         const bool asel = ring_sel[a];
-        const CellBox cb = cell_box(g, ca);
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int y2 = cb.cy + dy, z2 = cb.cz + dz;
-                if (y2 < 0 || y2 >= g.ny || z2 < 0 || z2 >= g.nz) continue;
-                const int xlo = max(cb.cx - 1, 0), xhi = min(cb.cx + 1, g.nx - 1);
-                if (xlo > xhi) continue;
-                const int rowbase = (z2 * g.ny + y2) * g.nx;
-                for (int p = start[rowbase + xlo], pe = start[rowbase + xhi + 1]; p < pe; ++p) {
-                    const int b = perm[p];
-                    if (b <= a || !ring_plus[b]) continue;  // unordered pair once; I:1081, 1085
+        const Stencil st = stencil_load(g, start, cell_box(g, ca), lane);
+        for (int kb = 0; kb < st.pre[9]; kb += 64) {
+            const int k = kb + lane;
+            bool emit = false, first = true;
+            int b = 0, y1 = 0, y2 = 0, ct = 0;
+            double dist = 0, dih = 0, t1 = 0, t2 = 0;
+            if (k < st.pre[9]) {
+                b = perm[stencil_pos(st, k)];
+                if (b > a && ring_plus[b]) {  // unordered pair once; I:1081, 1085
                     const num::d3 cbv = ld3(ring_c, b), nb = ld3(ring_n, b);
                     const num::d3 pab = num::sub(ca, cbv);
-                    const double dist = num::norm(pab);       // I:1111 (same value for both visits)
-                    if (dist > 6.0) continue;                  // I:1113
-                    const bool intra = ra == ring_res[b];     // I:1091
-                    const int ct = plane_ctype(asel, ring_sel[b], true, true);
-                    const double cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
-                    const double dih = num::fold_deg(acos(cosd));                 // I:1122
-                    const double t_ab = num::group_angle(na, pab);                // I:1123, visit (a,b)
-                    const double t_ba = num::group_angle(nb, num::sub(cbv, ca));  // visit (b,a)
-                    int y_ab = num::pp_class(dih, t_ab), y_ba = num::pp_class(dih, t_ba);
-                    const bool skip_ab = intra && y_ab == ARP_PP_EE;  // I:1154
-                    const bool skip_ba = intra && y_ba == ARP_PP_EE;
-                    if (skip_ab && skip_ba) continue;
-                    const long long slot = (long long)atomicAdd(n_out, 1ull);
-                    if (slot >= cap) continue;
-                    if (!skip_ab) {  // record created by the first visit (a,b); (b,a) may append its class
-                        out_bgn[slot] = a; out_end[slot] = b;
-                        out_t1[slot] = t_ab; out_t2[slot] = skip_ba ? NAN : t_ba;
-                        out_y1[slot] = (uint8_t)y_ab;
-                        out_y2[slot] = (skip_ba || y_ba == y_ab) ? ARP_PP_SKIPPED : (uint8_t)y_ba;
-                    } else {         // first visit skipped: the reverse visit creates the record
-                        out_bgn[slot] = b; out_end[slot] = a;
-                        out_t1[slot] = t_ba; out_t2[slot] = NAN;
-                        out_y1[slot] = (uint8_t)y_ba;
-                        out_y2[slot] = ARP_PP_SKIPPED;
+                    dist = num::norm(pab);                 // I:1111 (same value for both visits)
+                    if (!(dist > 6.0)) {                   // I:1113
+                        const bool intra = ra == ring_res[b];  // I:1091
+                        ct = plane_ctype(asel, ring_sel[b], true, true);
+                        const double cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
+                        dih = num::fold_deg(acos(cosd));                              // I:1122
+                        const double t_ab = num::group_angle(na, pab);                // I:1123, visit (a,b)
+                        const double t_ba = num::group_angle(nb, num::sub(cbv, ca));  // visit (b,a)
+                        const int y_ab = num::pp_class(dih, t_ab), y_ba = num::pp_class(dih, t_ba);
+                        const bool skip_ab = intra && y_ab == ARP_PP_EE;  // I:1154
+                        const bool skip_ba = intra && y_ba == ARP_PP_EE;
+                        emit = !(skip_ab && skip_ba);
+                        first = !skip_ab;
+                        if (first) {  // record created by visit (a,b); visit (b,a) may append its class
+                            t1 = t_ab; t2 = skip_ba ? NAN : t_ba;
+                            y1 = y_ab; y2 = (skip_ba || y_ba == y_ab) ? ARP_PP_SKIPPED : y_ba;
+                        } else {      // first visit skipped: the reverse visit creates the record
+                            t1 = t_ba; t2 = NAN;
+                            y1 = y_ba; y2 = ARP_PP_SKIPPED;
+                        }
                     }
-                    out_dist[slot] = dist;
-                    out_dih[slot] = dih;
-                    out_ct[slot] = (uint8_t)ct;
                 }
             }
+            const long long slot = wave_slot(emit, n_out, lane);
+            if (emit && slot < cap) {
+                out_bgn[slot] = first ? a : b;
+                out_end[slot] = first ? b : a;
+                out_dist[slot] = dist; out_dih[slot] = dih;
+                out_t1[slot] = t1; out_t2[slot] = t2;
+                out_y1[slot] = (uint8_t)y1; out_y2[slot] = (uint8_t)y2;
+                out_ct[slot] = (uint8_t)ct;
+            }
+        }
     }
 }
 
-// Thread per amide a; every other amide b in the 27 cells: ordered pairs, float32 (I:1217-1300).
+// One wavefront per amide a; lanes = every other amide b of the 27 cells: ordered pairs, float32 (I:1217-1300).
 __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
                                                      int namide, const float* __restrict__ am_c, const float* __restrict__ am_n,
                                                      const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
@@ -189,40 +223,45 @@ __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __re
                                                      float* __restrict__ out_dist, float* __restrict__ out_dih,
                                                      float* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
                                                      u64* __restrict__ n_out) {
-    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < namide; a += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
         const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
         const bool asel = am_sel[a];
-        const CellBox cb = cell_box(g, num::to_d3(ca));
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int y2 = cb.cy + dy, z2 = cb.cz + dz;
-                if (y2 < 0 || y2 >= g.ny || z2 < 0 || z2 >= g.nz) continue;
-                const int xlo = max(cb.cx - 1, 0), xhi = min(cb.cx + 1, g.nx - 1);
-                if (xlo > xhi) continue;
-                const int rowbase = (z2 * g.ny + y2) * g.nx;
-                for (int p = start[rowbase + xlo], pe = start[rowbase + xhi + 1]; p < pe; ++p) {
-                    const int b = perm[p];
-                    if (b == a || !am_plus[b]) continue;  // I:1233, 1237
+        const Stencil st = stencil_load(g, start, cell_box(g, num::to_d3(ca)), lane);
+        for (int kb = 0; kb < st.pre[9]; kb += 64) {
+            const int k = kb + lane;
+            bool emit = false;
+            int b = 0, ct = 0;
+            float dist = 0, dih = 0, theta = 0;
+            if (k < st.pre[9]) {
+                b = perm[stencil_pos(st, k)];
+                if (b != a && am_plus[b]) {  // I:1233, 1237
                     const num::f3 cbv = lf3(am_c, b), nb = lf3(am_n, b);
                     const num::f3 pab = num::sub(ca, cbv);
-                    const float dist = num::norm(pab);    // I:1268
-                    if (dist > (float)6.0) continue;      // I:1270
-                    const float cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
-                    const float dih = num::fold_deg(acosf(cosd));   // I:1278
-                    const float theta = num::group_angle(na, pab);  // I:1279
-                    if (dih > 30.0f || theta > 30.0f) continue;     // I:1282
-                    const long long slot = (long long)atomicAdd(n_out, 1ull);
-                    if (slot >= cap) continue;
-                    out_bgn[slot] = a; out_end[slot] = b;
-                    out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
-                    out_ct[slot] = (uint8_t)plane_ctype(asel, am_sel[b], true, true);
+                    dist = num::norm(pab);                 // I:1268
+                    if (!(dist > (float)6.0)) {            // I:1270
+                        const float cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
+                        dih = num::fold_deg(acosf(cosd));  // I:1278
+                        theta = num::group_angle(na, pab); // I:1279
+                        emit = !(dih > 30.0f || theta > 30.0f);  // I:1282
+                        ct = plane_ctype(asel, am_sel[b], true, true);
+                    }
                 }
             }
+            const long long slot = wave_slot(emit, n_out, lane);
+            if (emit && slot < cap) {
+                out_bgn[slot] = a; out_end[slot] = b;
+                out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
+                out_ct[slot] = (uint8_t)ct;
+            }
+        }
     }
 }
 
-// Thread per amide; rings of the 27 cells of the RING grid around the amide centre (I:1302-1382).
+// One wavefront per amide; lanes = rings of the 27 cells of the RING grid around the amide centre (I:1302-1382).
 __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
                                                      int namide, const float* __restrict__ am_c, const float* __restrict__ am_n,
                                                      const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
@@ -232,36 +271,41 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
                                                      u64* __restrict__ n_out) {
-    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < namide; a += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
         const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
         const num::d3 cad = num::to_d3(ca);
         const bool asel = am_sel[a];
-        const CellBox cb = cell_box(g, cad);
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int y2 = cb.cy + dy, z2 = cb.cz + dz;
-                if (y2 < 0 || y2 >= g.ny || z2 < 0 || z2 >= g.nz) continue;
-                const int xlo = max(cb.cx - 1, 0), xhi = min(cb.cx + 1, g.nx - 1);
-                if (xlo > xhi) continue;
-                const int rowbase = (z2 * g.ny + y2) * g.nx;
-                for (int p = start[rowbase + xlo], pe = start[rowbase + xhi + 1]; p < pe; ++p) {
-                    const int r = perm[p];
-                    if (!ring_plus[r]) continue;  // I:1318
+        const Stencil st = stencil_load(g, start, cell_box(g, cad), lane);
+        for (int kb = 0; kb < st.pre[9]; kb += 64) {
+            const int k = kb + lane;
+            bool emit = false;
+            int r = 0, ct = 0;
+            double dist = 0, dih = 0, theta = 0;
+            if (k < st.pre[9]) {
+                r = perm[stencil_pos(st, k)];
+                if (ring_plus[r]) {  // I:1318
                     const num::d3 cr = ld3(ring_c, r), nr = ld3(ring_n, r);
                     const num::d3 par = num::sub(cad, cr);
-                    const double dist = num::norm(par);  // I:1349
-                    if (dist > 6.0) continue;            // I:1351
-                    const double cosd = num::dot(num::to_d3(na), nr) / ((double)num::norm(na) * num::norm(nr));
-                    const double dih = num::fold_deg(acos(cosd));   // I:1359
-                    const double theta = num::group_angle(na, par); // I:1360
-                    if (dih > 30.0 || theta > 30.0) continue;       // I:1363
-                    const long long slot = (long long)atomicAdd(n_out, 1ull);
-                    if (slot >= cap) continue;
-                    out_amide[slot] = a; out_ring[slot] = r;
-                    out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
-                    out_ct[slot] = (uint8_t)plane_ctype(asel, ring_sel[r], true, true);
+                    dist = num::norm(par);         // I:1349
+                    if (!(dist > 6.0)) {           // I:1351
+                        const double cosd = num::dot(num::to_d3(na), nr) / ((double)num::norm(na) * num::norm(nr));
+                        dih = num::fold_deg(acos(cosd));    // I:1359
+                        theta = num::group_angle(na, par);  // I:1360
+                        emit = !(dih > 30.0 || theta > 30.0);  // I:1363
+                        ct = plane_ctype(asel, ring_sel[r], true, true);
+                    }
                 }
             }
+            const long long slot = wave_slot(emit, n_out, lane);
+            if (emit && slot < cap) {
+                out_amide[slot] = a; out_ring[slot] = r;
+                out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
+                out_ct[slot] = (uint8_t)ct;
+            }
+        }
     }
 }
