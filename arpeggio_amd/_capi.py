@@ -26,7 +26,7 @@ SYMBOLS = (
     'arp_set_ownership', 'arp_get_stats', 'arp_set_profiling', 'arp_get_kernel_times', 'arp_stream_handle',
     'arp_set_selection', 'arp_run_launch', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
-    'arp_group_plane_fetch',
+    'arp_group_plane_fetch', 'arp_get_selection',
 )
 
 _lib = None
@@ -68,6 +68,7 @@ def load():
     L.arp_group_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_set_ownership.argtypes = [vp, vp, vp]
     L.arp_set_selection.argtypes = [vp, vp]
+    L.arp_get_selection.argtypes = [vp, vp, vp, vp, vp, vp]
     L.arp_run_launch.argtypes = [vp, dbl, dbl, i32, dbl, vp]
     for nm in ('atom_plane', 'plane_plane', 'group_group', 'group_plane'):
         getattr(L, f'arp_{nm}_launch').argtypes = [vp, C.POINTER(i64)]
@@ -177,6 +178,15 @@ class Context:
                                            float(expand_radius), _p(counts)), 'arp_run_launch')
         return dict(atom_atom=int(counts[0]), plane_plane=int(counts[1]), atom_plane=int(counts[2]),
                     group_group=int(counts[3]), group_plane=int(counts[4]))
+
+    def make_selection_masks(self):
+        """Masks computed by the last selection expansion (downloads only; no recomputation)."""
+        L = self._L
+        plus = np.empty(self.n, np.uint8)
+        rs, rp = np.empty(self.n_rings, np.uint8), np.empty(self.n_rings, np.uint8)
+        as_, ap = np.empty(self.n_amides, np.uint8), np.empty(self.n_amides, np.uint8)
+        self._check(L.arp_get_selection(self._h, _p(plus), _p(rs), _p(rp), _p(as_), _p(ap)), 'arp_get_selection')
+        return dict(plus=plus, ring_sel=rs, ring_plus=rp, amide_sel=as_, amide_plus=ap)
 
     def make_selection(self, in_selection=None, radius=6.0):
         sel = np.ones(self.n, np.uint8) if in_selection is None else np.ascontiguousarray(in_selection, np.uint8)

@@ -63,3 +63,14 @@ CONTACT_TYPES = {
 }
 # literal radii in the reference code: selection expansion (interactions.py:1420)
 SELECTION_EXPANSION_RADIUS = 6.0
+
+
+def _load_common_solvents():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'common_solvents.txt')
+    with open(path) as fh:
+        return frozenset(line.strip() for line in fh if line.strip() and not line.startswith('#'))
+
+
+# residue names excluded by the LIGANDS selector (utils.py:453 of the reference)
+COMMON_SOLVENTS = _load_common_solvents()

@@ -1,0 +1,325 @@
+"""InteractionComplex — drop-in counterpart of ``arpeggio.core.InteractionComplex`` for the
+``run_arpeggio`` / ``get_contacts`` path (reference: arpeggio/core/interactions.py:36-347, 2063-2113).
+
+Same class name, method names, positional signatures and result attributes; the work is
+done by the HIP library behind include/arpeggio_hip.h on a device-resident PackedComplex.
+What the reference computes with BioPython/OpenBabel/gemmi before the hot path
+(``__init__`` parsing and ``initialize()``'s typing, I:37-105, 288-327) is the *input
+contract* here: the constructor takes a PackedComplex (or a ``.npz`` written by
+``PackedComplex.save``); ``pack_from_reference_objects`` documents how a reference-side
+object maps onto it.
+
+There is no CPU fallback: without the HIP library and a GPU every compute method raises
+NativeLibraryError.
+"""
+from __future__ import annotations
+
+import collections
+import logging
+import os
+from functools import reduce
+
+import numpy as np
+
+from . import config, utils
+from .exceptions import AtomSerialError, NativeLibraryError
+from .packed import PackedComplex
+
+# result records: same field names as the reference (I:19-33); atoms / residues are packed indices
+AtomPlaneContact = collections.namedtuple('AtomPlaneContact',
+                                          ['bgn_atom', 'end_res', 'end_res_atoms', 'distance', 'sifts', 'text'])
+PlanePlaneContact = collections.namedtuple('PlanePlaneContact',
+                                           ['bgn_id', 'bgn_res', 'bgn_res_atoms', 'end_id', 'end_res', 'end_res_atoms',
+                                            'distance', 'contact_type', 'text'])
+AtomAtomContact = collections.namedtuple('AtomAtomContact', ['bgn_atom', 'end_atom', 'sifts', 'contact_type', 'distance'])
+Parameters = collections.namedtuple('Parameters', ['vdw_comp_factor', 'interacting_threshold', 'has_hydrogens', 'ph'])
+
+
+class InteractionComplex:
+    def __init__(self, filename, vdw_comp=0.1, interacting=5.0, ph=7.4, device=0):
+        """Args mirror I:37.  ``filename``: a PackedComplex or the path of a packed ``.npz``."""
+        if isinstance(filename, PackedComplex):
+            self.pc = filename
+            self.id = filename.id
+        elif isinstance(filename, (str, os.PathLike)) and str(filename).endswith('.npz'):
+            self.pc = PackedComplex.load(filename)
+            self.id = os.path.basename(str(filename)).split('.')[0]        # I:51
+        else:
+            raise NotImplementedError(
+                'Reading mmCIF/PDB needs the reference\'s BioPython/OpenBabel/gemmi preparation (I:53-105, 288-327), '
+                'which is outside the accelerated path: pass a PackedComplex (see pack_from_reference_objects).')
+        self.pc.ensure_labels()
+        self.device = device
+        self._ctx = None
+        self.component_types = self.pc.component_types                     # I:70
+
+        # helper structures (I:73-81) — packed atom / ring / amide indices
+        self.selection = []
+        self.selection_ring_ids = []
+        self.selection_amide_ids = []
+        self.selection_plus = []
+        self.selection_plus_residues = []
+        self.selection_plus_ring_ids = []
+        self.selection_plus_amide_ids = []
+        # result bags (I:84-88)
+        self._bags = {}
+        self.params = Parameters(vdw_comp_factor=vdw_comp, interacting_threshold=interacting,
+                                 has_hydrogens=bool(np.any(self.pc.flags & config.F_HYDROGEN)) or self.pc.h_xyz.shape[0] > 0,
+                                 ph=ph)                                    # I:90-94
+
+    # region public methods
+    def structure_checks(self):
+        """I:109-118."""
+        serials = self.pc.serial
+        if len(serials) > len(set(serials.tolist())):
+            raise AtomSerialError
+
+    def address_ambiguities(self):
+        """I:120-133 edits the typing tables *before* typing; here typing is part of the packed
+        input, so the ambiguity choice has to be made by whoever builds the PackedComplex."""
+        logging.warning('address_ambiguities(): atom typing is part of the packed input; no effect on a PackedComplex.')
+
+    def initialize(self):
+        """I:288-327 prepares per-atom state; here: create the GPU context and upload the pack."""
+        from .. import _capi
+        if self._ctx is None:
+            self._ctx = _capi.Context(self.device)
+        self._ctx.set_complex(self.pc)
+        logging.debug('Uploaded packed structure to the GPU.')
+
+    def run_arpeggio(self, user_selections, interacting_cutoff, vdw_comp, include_sequence_adjacent):
+        """I:329-347: selection + binding-site expansion, atom, ring and amide contacts (all on the GPU)."""
+        if self._ctx is None:
+            self.initialize()
+        pc, ctx = self.pc, self._ctx
+        # I:1395: no selectors -> the whole structure
+        if user_selections:
+            idx = utils.selection_parser(user_selections, pc)
+        else:
+            idx = np.arange(pc.n_atoms, dtype=np.int64)
+        if idx.size == 0:                                                   # I:1399-1401
+            logging.error('Selection was empty.')
+            raise AttributeError('Selection must not be empty.')
+        mask = np.zeros(pc.n_atoms, np.uint8)
+        mask[idx] = 1
+        ctx.set_selection(mask)
+        counts = ctx.run_launch(interacting_cutoff, vdw_comp, include_sequence_adjacent,
+                                config.SELECTION_EXPANSION_RADIUS)
+        logging.debug('Completed new NeighbourSearch.')
+        masks = ctx.make_selection_masks()
+        self.selection = idx
+        self.selection_plus = np.nonzero(masks['plus'])[0]
+        self.selection_plus_residues = np.unique(pc.res_id[self.selection_plus])
+        self.selection_ring_ids = set(np.nonzero(masks['ring_sel'])[0].tolist())
+        self.selection_plus_ring_ids = set(np.nonzero(masks['ring_plus'])[0].tolist())
+        self.selection_amide_ids = set(np.nonzero(masks['amide_sel'])[0].tolist())
+        self.selection_plus_amide_ids = set(np.nonzero(masks['amide_plus'])[0].tolist())
+        self._bags = {
+            'atom_atom': ctx.atom_contacts_fetch(counts['atom_atom']),
+            'plane_plane': ctx.fetch_bag('plane_plane'),
+            'atom_plane': ctx.fetch_bag('atom_plane'),
+            'group_group': ctx.fetch_bag('group_group'),
+            'group_plane': ctx.fetch_bag('group_plane'),
+        }
+        self.stats = ctx.stats()
+
+    # ---- result bags as lists of the reference's namedtuples (built on demand) ----
+    def _ring_names(self, r):
+        return sorted(self.pc.atom_name[a] for a in self.pc.ring_atoms[r]) if self.pc.ring_atoms else []
+
+    def _amide_names(self, a):
+        return sorted(self.pc.atom_name[i] for i in self.pc.amide_atoms[a] if i >= 0)
+
+    @property
+    def atom_contacts(self):
+        b = self._bags.get('atom_atom')
+        if b is None:
+            return []
+        return [AtomAtomContact(int(i), int(j), [(int(s) >> k) & 1 for k in range(15)], config.CONTACT_TYPE_NAMES[c], d)
+                for i, j, s, c, d in zip(b['i'], b['j'], b['sift'], b['ctype'], b['dist'])]
+
+    @property
+    def plane_plane_contacts(self):
+        b = self._bags.get('plane_plane')
+        if b is None:
+            return []
+        out = []
+        for k in range(len(b['bgn'])):
+            types = [config.PLANE_PLANE_NAMES[b['type1'][k]]]
+            if b['type2'][k] != config.PP_SKIPPED:
+                types.append(config.PLANE_PLANE_NAMES[b['type2'][k]])
+            r1, r2 = int(b['bgn'][k]), int(b['end'][k])
+            out.append(PlanePlaneContact(r1, int(self.pc.ring_res[r1]), self._ring_names(r1), r2, int(self.pc.ring_res[r2]),
+                                         self._ring_names(r2), b['dist'][k], types, config.CONTACT_TYPE_NAMES[b['ctype'][k]]))
+        return out
+
+    @property
+    def atom_plane_contacts(self):
+        b = self._bags.get('atom_plane')
+        if b is None:
+            return []
+        return [AtomPlaneContact(int(a), int(self.pc.ring_res[r]), self._ring_names(int(r)), d,
+                                 [n for bit, n in enumerate(config.ATOM_PLANE_NAMES) if (int(m) >> bit) & 1],
+                                 config.CONTACT_TYPE_NAMES[c])
+                for a, r, d, m, c in zip(b['atom'], b['ring'], b['dist'], b['mask'], b['ctype'])]
+
+    @property
+    def group_group_contacts(self):
+        b = self._bags.get('group_group')
+        if b is None:
+            return []
+        return [PlanePlaneContact(int(a1), int(self.pc.amide_res[a1]), self._amide_names(int(a1)), int(a2),
+                                  int(self.pc.amide_res[a2]), self._amide_names(int(a2)), d, ['AMIDEAMIDE'],
+                                  config.CONTACT_TYPE_NAMES[c])
+                for a1, a2, d, c in zip(b['bgn'], b['end'], b['dist'], b['ctype'])]
+
+    @property
+    def group_plane_contacts(self):
+        b = self._bags.get('group_plane')
+        if b is None:
+            return []
+        return [PlanePlaneContact(int(a), int(self.pc.amide_res[a]), self._amide_names(int(a)), int(r),
+                                  int(self.pc.ring_res[r]), self._ring_names(int(r)), d, ['AMIDERING'],
+                                  config.CONTACT_TYPE_NAMES[c])
+                for a, r, d, c in zip(b['amide'], b['ring'], b['dist'], b['ctype'])]
+
+    def get_contacts(self):
+        """I:172-212: JSON-able list, bags in the reference's order, canonical order inside a bag."""
+        pc = self.pc
+        contacts = config.SIFT_NAMES
+        result_bag = []
+        for contact in self.atom_contacts:
+            result_entry = {}
+            result_entry['bgn'] = utils.make_pymol_json(pc, atom=contact.bgn_atom)
+            result_entry['bgn']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, atom=contact.bgn_atom)]
+            result_entry['end'] = utils.make_pymol_json(pc, atom=contact.end_atom)
+            result_entry['end']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, atom=contact.end_atom)]
+            result_entry['type'] = 'atom-atom'
+            result_entry['distance'] = round(np.float64(contact.distance), 2)
+            result_entry['contact'] = [k for k, v in zip(contacts, contact.sifts) if v == 1]
+            result_entry['interacting_entities'] = contact.contact_type
+            result_bag.append(result_entry)
+        for contact in self.plane_plane_contacts:
+            result_bag.append(self._prepare_plane_plane_contact_for_export(contact, 'plane-plane'))
+        for contact in self.atom_plane_contacts:
+            result_bag.append(self._prepare_atom_plane_contact_for_export(contact, 'atom-plane'))
+        for contact in self.group_group_contacts:
+            result_bag.append(self._prepare_plane_plane_contact_for_export(contact, 'group-group'))
+        for contact in self.group_plane_contacts:
+            result_bag.append(self._prepare_plane_plane_contact_for_export(contact, 'group-plane'))
+        return result_bag
+
+    # endregion
+
+    def _prepare_plane_plane_contact_for_export(self, contact, contact_type):
+        """I:2063-2087."""
+        pc = self.pc
+        result_entry = {}
+        result_entry['bgn'] = utils.make_pymol_json(pc, residue=contact.bgn_res)
+        result_entry['bgn']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, residue=contact.bgn_res)]
+        result_entry['bgn']['auth_atom_id'] = reduce(lambda l, m: f'{l},{m}', contact.bgn_res_atoms)
+        result_entry['end'] = utils.make_pymol_json(pc, residue=contact.end_res)
+        result_entry['end']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, residue=contact.end_res)]
+        result_entry['end']['auth_atom_id'] = reduce(lambda l, m: f'{l},{m}', contact.end_res_atoms)
+        result_entry['type'] = contact_type
+        result_entry['distance'] = round(np.float64(contact.distance), 2)
+        result_entry['contact'] = contact.contact_type
+        result_entry['interacting_entities'] = contact.text
+        return result_entry
+
+    def _prepare_atom_plane_contact_for_export(self, contact, contact_type):
+        """I:2090-2113."""
+        pc = self.pc
+        result_entry = {}
+        result_entry['bgn'] = utils.make_pymol_json(pc, atom=contact.bgn_atom)
+        result_entry['bgn']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, atom=contact.bgn_atom)]
+        result_entry['end'] = utils.make_pymol_json(pc, residue=contact.end_res)
+        result_entry['end']['auth_atom_id'] = reduce(lambda l, m: f'{l},{m}', contact.end_res_atoms)
+        result_entry['end']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, residue=contact.end_res)]
+        result_entry['type'] = contact_type
+        result_entry['distance'] = round(np.float64(contact.distance), 2)
+        result_entry['contact'] = contact.sifts
+        result_entry['interacting_entities'] = contact.text
+        return result_entry
+
+
+def pack_from_reference_objects(ic):
+    """Build a PackedComplex from a *reference* ``arpeggio.core.InteractionComplex`` on which
+    ``initialize()`` has run (needs BioPython + OpenBabel, so it cannot be exercised in this
+    repository's environment; it documents the mapping of I:54-60, 1494-1529, 1591-1733,
+    1531-1589, 1923-1991 onto the packed arrays).
+    """
+    from openbabel import openbabel as ob  # noqa: F401  (import-guard: reference environment only)
+    atoms = list(ic.s_atoms)
+    index = {a: i for i, a in enumerate(atoms)}
+    residues, res_index = [], {}
+    for a in atoms:
+        r = a.get_parent()
+        if id(r) not in res_index:
+            res_index[id(r)] = len(residues)
+            residues.append(r)
+    T = config.ATOM_TYPE_BIT
+    n = len(atoms)
+    xyz = np.array([a.coord for a in atoms], np.float32)
+    flags = np.zeros(n, np.uint16)
+    tmask = np.zeros(n, np.uint16)
+    for i, a in enumerate(atoms):
+        tmask[i] = sum(T[t] for t in a.atom_types)
+        f = 0
+        f |= config.F_METAL if a.is_metal else 0
+        f |= config.F_HALOGEN if a.is_halogen else 0
+        f |= config.F_WATER if a.get_full_id()[3][0] == 'W' else 0
+        f |= config.F_HYDROGEN if a.element.strip() == 'H' else 0
+        f |= config.F_ELEM_C if a.element == 'C' else 0
+        f |= config.F_ELEM_S if a.element == 'S' else 0
+        f |= config.F_RES_MET if a.get_parent().resname == 'MET' else 0
+        flags[i] = f
+    res_flags = np.zeros(len(residues), np.uint8)
+    res_prev = np.full(len(residues), -1, np.int32)
+    res_next = np.full(len(residues), -1, np.int32)
+    for k, r in enumerate(residues):
+        if getattr(r, 'is_polypeptide', False):
+            res_flags[k] |= config.R_POLYPEPTIDE
+        if hasattr(r, 'prev_residue') and hasattr(r, 'next_residue'):
+            res_flags[k] |= config.R_HAS_SEQ
+            if r.prev_residue is not None:
+                res_prev[k] = res_index[id(r.prev_residue)]
+            if r.next_residue is not None:
+                res_next[k] = res_index[id(r.next_residue)]
+    adj, sb = [[] for _ in range(n)], np.full(n, -1, np.int32)
+    for i, a in enumerate(atoms):
+        ob_atom = ic.ob_mol.GetAtomById(ic.bio_to_ob[a])
+        for nb in ob.OBAtomAtomIter(ob_atom):
+            if nb.GetId() in ic.ob_to_bio:
+                adj[i].append(index[ic.ob_to_bio[nb.GetId()]])
+        for bond in ob.OBAtomBondIter(ob_atom):                           # utils.py:612-635
+            if not (bond.GetBondOrder() == 1 and not bond.IsAromatic()):
+                continue
+            nbr = bond.GetNbrAtom(ob_atom)
+            if nbr.GetAtomicNum() == 1:
+                continue
+            sb[i] = index[ic.ob_to_bio[nbr.GetId()]]
+            break
+    bond_off = np.concatenate([[0], np.cumsum([len(x) for x in adj])]).astype(np.int32)
+    bond_idx = np.array([j for x in adj for j in x], np.int32)
+    h_off = np.concatenate([[0], np.cumsum([len(a.h_coords) for a in atoms])]).astype(np.int32)
+    h_xyz = np.array([h for a in atoms for h in a.h_coords], np.float64).reshape(-1, 3)
+    rings = ic.biopython_str.rings
+    amides = ic.biopython_str.amides
+    rkeys, akeys = list(rings), list(amides)
+    return PackedComplex(
+        xyz=xyz, vdw=[a.vdw_radius for a in atoms], cov=[a.cov_radius for a in atoms], type_mask=tmask, flags=flags,
+        res_id=[res_index[id(a.get_parent())] for a in atoms], res_flags=res_flags, res_prev=res_prev, res_next=res_next,
+        bond_off=bond_off, bond_idx=bond_idx, h_off=h_off, h_xyz=h_xyz, sb_nbr=sb,
+        ring_center=np.array([rings[k]['center'] for k in rkeys], np.float64).reshape(-1, 3),
+        ring_normal=np.array([rings[k]['normal'] for k in rkeys], np.float64).reshape(-1, 3),
+        ring_res=[res_index[id(rings[k]['residue'])] if rings[k].get('residue') is not None else -1 for k in rkeys],
+        ring_atoms=[np.array([index[a] for a in rings[k]['atoms']], np.int32) for k in rkeys],
+        amide_center=np.array([amides[k]['center'] for k in akeys], np.float32).reshape(-1, 3),
+        amide_normal=np.array([amides[k]['normal'] for k in akeys], np.float32).reshape(-1, 3),
+        amide_res=[res_index[id(amides[k]['residue'])] for k in akeys],
+        amide_atoms=np.array([[index[a] for a in amides[k]['atoms']] for k in akeys], np.int32).reshape(-1, 4),
+        atom_name=[a.name for a in atoms], element=[a.element for a in atoms],
+        serial=[a.serial_number for a in atoms], res_name=[r.resname for r in residues],
+        res_seq=[r.id[1] for r in residues], res_icode=[r.id[2] for r in residues],
+        res_chain=[r.get_parent().id for r in residues], component_types=dict(ic.component_types), id=ic.id)

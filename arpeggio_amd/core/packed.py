@@ -167,3 +167,36 @@ class PackedComplex:
     def type_names(self, i):
         m = int(self.type_mask[i])
         return {name for b, name in enumerate(config.ATOM_TYPE_NAMES) if m >> b & 1}
+
+    # ---- persistence (a packed structure is the "file" this implementation reads) ----
+    _ARRAYS = ('xyz', 'vdw', 'cov', 'type_mask', 'flags', 'res_id', 'res_flags', 'res_prev', 'res_next', 'bond_off',
+               'bond_idx', 'h_off', 'h_xyz', 'sb_nbr', 'ring_center', 'ring_normal', 'ring_res', 'amide_center',
+               'amide_normal', 'amide_res', 'amide_atoms', 'serial', 'res_seq')
+    _LISTS = ('atom_name', 'element', 'res_name', 'res_icode', 'res_chain')
+
+    def save(self, path):
+        """Write the pack to a ``.npz`` file (numeric arrays + string tables)."""
+        self.ensure_labels()
+        d = {k: getattr(self, k) for k in self._ARRAYS}
+        for k in self._LISTS:
+            d[k] = np.array(getattr(self, k), dtype=np.str_)
+        ro = np.concatenate([[0], np.cumsum([len(a) for a in self.ring_atoms])]).astype(np.int32) if self.ring_atoms \
+            else np.zeros(self.n_rings + 1, np.int32)
+        d['ring_atoms_off'] = ro
+        d['ring_atoms_idx'] = (np.concatenate(self.ring_atoms).astype(np.int32) if self.ring_atoms and ro[-1] else np.zeros(0, np.int32))
+        d['component_types_keys'] = np.array(list(self.component_types.keys()), dtype=np.str_)
+        d['component_types_vals'] = np.array(list(self.component_types.values()), dtype=np.str_)
+        d['id'] = np.array(self.id)
+        np.savez_compressed(path, **d)
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path, allow_pickle=False)
+        kw = {k: z[k] for k in cls._ARRAYS}
+        for k in cls._LISTS:
+            kw[k] = [str(x) for x in z[k]]
+        ro, ri = z['ring_atoms_off'], z['ring_atoms_idx']
+        kw['ring_atoms'] = [ri[ro[r]:ro[r + 1]] for r in range(len(ro) - 1)]
+        kw['component_types'] = {str(k): str(v) for k, v in zip(z['component_types_keys'], z['component_types_vals'])}
+        kw['id'] = str(z['id'])
+        return cls(**kw)

@@ -853,6 +853,19 @@ int arp_make_selection(arp_ctx* c, const uint8_t* in_selection, double expand_ra
     return ARP_OK;
 }
 
+int arp_get_selection(arp_ctx* c, uint8_t* out_plus, uint8_t* out_ring_sel, uint8_t* out_ring_plus, uint8_t* out_amide_sel,
+                      uint8_t* out_amide_plus) {
+    if (!c) return ARP_E_ARG;
+    if (!c->sel_made) FAIL(c, ARP_E_ARG, "arp_get_selection: no selection has been expanded yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(download(c, out_plus, c->plus.p, out_plus ? (size_t)c->n : 0));
+    CHK(download(c, out_ring_sel, c->ring_sel.p, out_ring_sel ? (size_t)c->nring : 0));
+    CHK(download(c, out_ring_plus, c->ring_plus.p, out_ring_plus ? (size_t)c->nring : 0));
+    CHK(download(c, out_amide_sel, c->am_sel.p, out_amide_sel ? (size_t)c->namide : 0));
+    CHK(download(c, out_amide_plus, c->am_plus.p, out_amide_plus ? (size_t)c->namide : 0));
+    return ARP_OK;
+}
+
 // ---- _calculate_atom_contacts -------------------------------------------------------------
 int arp_atom_contacts_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, int64_t* count) {
     if (!c || !(cutoff > 0)) return ARP_E_ARG;

@@ -169,6 +169,10 @@ int arp_make_selection(arp_ctx* ctx, const uint8_t* in_selection, double expand_
                        uint8_t* out_ring_plus /*nring*/, uint8_t* out_amide_sel /*namide*/,
                        uint8_t* out_amide_plus /*namide*/);
 
+/* Download the sets computed by the last expansion (selection_plus, I:1444-1451). */
+int arp_get_selection(arp_ctx* ctx, uint8_t* out_plus, uint8_t* out_ring_sel, uint8_t* out_ring_plus,
+                      uint8_t* out_amide_sel, uint8_t* out_amide_plus);
+
 /* Upload a selection mask without expanding it yet (arp_run_launch expands it). */
 int arp_set_selection(arp_ctx* ctx, const uint8_t* in_selection);
 

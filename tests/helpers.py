@@ -58,3 +58,111 @@ def deg_close(a, b, tol=1e-4):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     both_nan = np.isnan(a) & np.isnan(b)
     return np.all(both_nan | (np.abs(a - b) <= tol))
+
+
+def known_answer_packs():
+    """Tiny packs that isolate one branch each of interactions.py:693-936 (used on CPU and GPU)."""
+    from arpeggio_amd.core import config
+    T = config.ATOM_TYPE_BIT
+    P = config.R_POLYPEPTIDE | config.R_HAS_SEQ
+    da = T['hbond acceptor'] | T['hbond donor']
+    acc_wd = T['hbond acceptor'] | T['weak hbond donor']
+    xd, xa = T['xbond donor'], T['xbond acceptor']
+    c, s = np.cos, np.sin
+    r = np.deg2rad
+    packs = []
+    for d in (1.0, 1.52, 3.39, 3.4, 3.5, 3.51, 4.5, 4.9, 5.0):
+        packs.append((f'ladder_{d}', tiny_complex([[0, 0, 0], [d, 0, 0]], type_mask=T['hydrophobe'] | T['aromatic'])))
+    packs.append(('covalent', tiny_complex([[0, 0, 0], [1.0, 0, 0]], bonds=[(0, 1)], type_mask=T['hydrophobe'])))
+    packs.append(('metal', tiny_complex([[0, 0, 0], [1.0, 0, 0], [2.8, 0.1, 0]], type_mask=[T['hbond acceptor'], 0, T['hbond acceptor']],
+                                        flags=[0, config.F_METAL, 0])))
+    packs.append(('hydrogen_atom', tiny_complex([[0, 0, 0], [3.0, 0, 0], [0, 3, 0]], flags=[config.F_HYDROGEN, 0, 0])))
+    packs.append(('same_residue', tiny_complex([[0, 0, 0], [3.0, 0, 0], [0, 3, 0]], res_id=[0, 0, 1])))
+    packs.append(('seq_adjacent', tiny_complex([[0, 0, 0], [3.0, 0, 0], [0, 3, 0]], res_id=[0, 1, 2], res_flags=[P, P, 0],
+                                               res_prev=[-1, 0, -1], res_next=[1, -1, -1])))
+    packs.append(('seq_adjacent_end_not_poly', tiny_complex([[0, 0, 0], [3.0, 0, 0]], res_id=[0, 1], res_flags=[P, config.R_HAS_SEQ],
+                                                            res_prev=[-1, 0], res_next=[1, -1])))
+    packs.append(('seq_adjacent_bgn_not_poly', tiny_complex([[0, 0, 0], [3.0, 0, 0]], res_id=[0, 1], res_flags=[config.R_HAS_SEQ, P],
+                                                            res_prev=[-1, 0], res_next=[1, -1])))
+    packs.append(('water_near', tiny_complex([[0, 0, 0], [3.4, 0, 0]], type_mask=[da, T['hbond acceptor']], flags=[config.F_WATER, 0])))
+    packs.append(('water_far', tiny_complex([[0, 0, 0], [3.6, 0, 0]], type_mask=[T['hbond acceptor'], da], flags=[0, config.F_WATER])))
+    packs.append(('water_water', tiny_complex([[0, 0, 0], [2.8, 0, 0]], type_mask=da, flags=config.F_WATER,
+                                              h={0: [[0.96, 0, 0], [-0.3, 0.9, 0]], 1: [[3.5, 0.5, 0], [3.0, -0.9, 0]]})))
+    for ang in (60, 80, 95, 180):
+        packs.append((f'hbond_{ang}', tiny_complex([[0, 0, 0], [2.9, 0, 0]], type_mask=[da, da], h={0: [[c(r(ang)), s(r(ang)), 0]]})))
+        packs.append((f'hbond_rev_{ang}', tiny_complex([[2.9, 0, 0], [0, 0, 0]], type_mask=[da, da], h={1: [[c(r(ang)), s(r(ang)), 0]]})))
+    packs.append(('weak_overwrite', tiny_complex([[0, 0, 0], [3.0, 0, 0]], type_mask=[acc_wd, acc_wd], h={1: [[2.0, 0, 0]]})))
+    packs.append(('weak_single', tiny_complex([[0, 0, 0], [3.0, 0, 0]], type_mask=[T['hbond acceptor'], T['weak hbond donor']], h={1: [[2.0, 0, 0]]})))
+    packs.append(('weak_single_rev', tiny_complex([[3.0, 0, 0], [0, 0, 0]], type_mask=[T['weak hbond donor'], T['hbond acceptor']], h={0: [[2.0, 0, 0]]})))
+    for ang in (100, 119, 121, 180):
+        packs.append((f'xbond_{ang}', tiny_complex([[1.7 * c(r(ang)), 1.7 * s(r(ang)), 0], [0, 0, 0], [3.3, 0, 0]],
+                                                   type_mask=[0, xd, xa], bonds=[(0, 1)], res_id=[0, 0, 1])))
+        packs.append((f'xbond_rev_{ang}', tiny_complex([[3.3, 0, 0], [0, 0, 0], [1.7 * c(r(ang)), 1.7 * s(r(ang)), 0]],
+                                                       type_mask=[xa, xd, 0], bonds=[(1, 2)], res_id=[1, 0, 0])))
+    # halogen weak hydrogen bond: C-Cl ... H-N, both orientations
+    for ang in (20, 40, 90, 149, 160):
+        hx = [3.0 * c(r(ang)) * 0 + 2.2, 0, 0]
+        nb = [-1.7 * c(r(ang)), 1.7 * s(r(ang)), 0]
+        packs.append((f'halogen_weak_{ang}', tiny_complex([nb, [0, 0, 0], [3.2, 0, 0]],
+                                                          type_mask=[0, T['weak hbond acceptor'], T['hbond donor']],
+                                                          flags=[0, config.F_HALOGEN, 0], bonds=[(0, 1)], res_id=[0, 0, 1],
+                                                          h={2: [hx]})))
+        packs.append((f'halogen_weak_rev_{ang}', tiny_complex([[3.2, 0, 0], [0, 0, 0], nb],
+                                                              type_mask=[T['weak hbond donor'], T['weak hbond acceptor'], 0],
+                                                              flags=[0, config.F_HALOGEN, 0], bonds=[(1, 2)], res_id=[1, 0, 0],
+                                                              h={0: [hx]})))
+    packs.append(('halogen_no_neighbour', tiny_complex([[0, 0, 0], [3.2, 0, 0]], type_mask=[T['weak hbond acceptor'], T['hbond donor']],
+                                                       flags=[config.F_HALOGEN, 0], h={1: [[2.2, 0, 0]]}, sb_nbr=[-1, -1])))
+    for d in (3.6, 3.61, 4.0, 4.01, 4.5, 4.51):
+        packs.append((f'features_{d}', tiny_complex([[0, 0, 0], [d, 0, 0], [0, d, 0]],
+                                                    type_mask=[T['pos ionisable'] | T['carbonyl oxygen'] | T['aromatic'] | T['hydrophobe'],
+                                                               T['neg ionisable'] | T['carbonyl carbon'] | T['aromatic'] | T['hydrophobe'],
+                                                               T['neg ionisable'] | T['carbonyl carbon']])))
+    packs.append(('collinear_angle_nan', tiny_complex([[0, 0, 0], [3, 0, 0]], type_mask=[T['hbond donor'], T['hbond acceptor']],
+                                                      h={0: [[0, 0, 0]]})))   # hydrogen on top of the donor: NaN -> pi
+    return packs
+
+
+def random_dense_pack(seed, n=400, box=14.0):
+    """Dense random soup with every atom type / flag and random bonds, hydrogens and neighbours."""
+    from arpeggio_amd.core import config
+    rng = np.random.default_rng(seed)
+    xyz = (rng.random((n, 3)) * box).astype(np.float32)
+    tm = np.zeros(n, np.uint16)
+    for b in range(12):
+        tm |= ((rng.random(n) < 0.3).astype(np.uint16) << b)
+    fl = np.zeros(n, np.uint16)
+    fl |= (rng.random(n) < 0.05).astype(np.uint16) * config.F_METAL
+    fl |= (rng.random(n) < 0.10).astype(np.uint16) * config.F_HALOGEN
+    fl |= (rng.random(n) < 0.10).astype(np.uint16) * config.F_WATER
+    fl |= (rng.random(n) < 0.05).astype(np.uint16) * config.F_HYDROGEN
+    fl |= (rng.random(n) < 0.4).astype(np.uint16) * config.F_ELEM_C
+    fl |= (rng.random(n) < 0.1).astype(np.uint16) * config.F_ELEM_S
+    fl |= (rng.random(n) < 0.2).astype(np.uint16) * config.F_RES_MET
+    res_id = np.sort(rng.integers(0, n // 3, n)).astype(np.int32)
+    res_id = np.unique(res_id, return_inverse=True)[1].astype(np.int32)
+    nres = int(res_id.max()) + 1
+    poly = rng.random(nres) < 0.7
+    res_flags = np.where(poly, config.R_POLYPEPTIDE | config.R_HAS_SEQ, np.where(rng.random(nres) < 0.3, config.R_HAS_SEQ, 0)).astype(np.uint8)
+    res_prev = np.where(np.arange(nres) > 0, np.arange(nres) - 1, -1).astype(np.int32)
+    res_next = np.where(np.arange(nres) < nres - 1, np.arange(nres) + 1, -1).astype(np.int32)
+    res_prev[rng.random(nres) < 0.2] = -1
+    res_next[rng.random(nres) < 0.2] = -1
+    d = np.linalg.norm(xyz[:, None, :].astype(np.float64) - xyz[None, :, :].astype(np.float64), axis=2)
+    bi, bj = np.nonzero(np.triu(d < 1.9, 1))
+    keep = rng.random(len(bi)) < 0.7
+    bonds = list(zip(bi[keep].tolist(), bj[keep].tolist()))
+    h = {}
+    for i in range(n):
+        k = int(rng.integers(0, 4)) if rng.random() < 0.5 else 0
+        if k:
+            v = rng.standard_normal((k, 3))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            h[i] = (xyz[i].astype(np.float64) + v * rng.uniform(0.9, 1.1)).tolist()
+    pc = tiny_complex(xyz, vdw=rng.choice([1.2, 1.52, 1.55, 1.7, 1.8, 1.75, 1.39], n), cov=rng.choice([0.31, 0.66, 0.71, 0.76, 1.05, 1.02, 1.22], n),
+                      type_mask=tm, flags=fl, res_id=res_id, res_flags=res_flags, res_prev=res_prev, res_next=res_next, bonds=bonds, h=h)
+    # xbond donors without a neighbour would make the reference raise: give every xbond donor a neighbour
+    xd = (pc.type_mask & config.ATOM_TYPE_BIT['xbond donor']) != 0
+    lonely = xd & (pc.sb_nbr < 0)
+    pc.sb_nbr[lonely] = (np.nonzero(lonely)[0] + 1) % n
+    return pc

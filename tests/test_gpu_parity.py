@@ -222,3 +222,92 @@ def test_run_launch_single_sync_path(ctx):
     counts2 = ctx.run_launch(5.0, 0.1, False, 6.0)
     assert counts2 == counts
     _assert_contacts_equal(ctx.atom_contacts_fetch(counts2['atom_atom']), exp)
+
+
+def test_known_answer_packs_on_gpu(ctx):
+    """Every branch / quirk pack (tests/helpers.known_answer_packs): HIP == oracle, canonical orientation."""
+    import oracle
+    from helpers import known_answer_packs
+    packs = known_answer_packs()
+    assert len(packs) > 50
+    for name, pc in packs:
+        ctx.set_complex(pc)
+        ctx.make_selection(None)
+        oc = oracle.OracleComplex(pc)
+        oc.make_selection(None)
+        exp = oc.atom_contacts(5.0, 0.1, False, use_grid=False)
+        if exp['err'] == -4:
+            with pytest.raises(AttributeError):
+                ctx.atom_contacts(5.0, 0.1, False)
+            continue
+        got = ctx.atom_contacts(5.0, 0.1, False)
+        assert len(got['i']) == len(exp['i']), name
+        for k in ('i', 'j', 'sift', 'ctype'):
+            assert np.array_equal(got[k], exp[k]), (name, k, got[k], exp[k])
+        assert np.array_equal(got['dist'].view(np.uint32), exp['dist'].view(np.uint32)), name
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6])
+def test_random_dense_soup(ctx, seed):
+    """Dense random packs with every type/flag combination, partial selections and both filter settings."""
+    import oracle
+    from helpers import random_dense_pack
+    pc = random_dense_pack(seed)
+    rng = np.random.default_rng(seed)
+    sel = (rng.random(pc.n_atoms) < 0.3).astype(np.uint8)
+    sel[0] = 1
+    ctx.set_complex(pc)
+    masks = ctx.make_selection(sel)
+    oc = oracle.OracleComplex(pc)
+    plus = oc.make_selection(sel, use_grid=False)
+    assert np.array_equal(masks['plus'], plus)
+    for seq_adj, comp in ((False, 0.1), (True, 0.0), (False, 0.37)):
+        got = ctx.atom_contacts(5.0, comp, seq_adj)
+        exp = oc.atom_contacts(5.0, comp, seq_adj, use_grid=False)
+        assert exp['err'] == 0
+        _assert_contacts_equal(got, exp)
+    assert len(np.unique(exp['ctype'])) == 6
+
+
+def test_interaction_complex_drop_in(ctx):
+    """The reference's call sequence (process_protein_cli.py:159-182) on the mirror class; JSON schema of README.md:127-241."""
+    import oracle
+    from arpeggio_amd import synth
+    from arpeggio_amd.core import InteractionComplex, config
+    pc = synth.config3(8000, seed=21)
+    ic = InteractionComplex(pc, 0.1, 5.0, 7.4)
+    ic.structure_checks()
+    ic.initialize()
+    ic.run_arpeggio(['/A/5/', '/A/6/', 'RESNAME:BNZ'], 5.0, 0.1, False)
+    contacts = ic.get_contacts()
+    s = json.dumps(contacts, indent=4, sort_keys=True)
+    assert json.loads(s) == contacts
+    types = [c['type'] for c in contacts]
+    order = ['atom-atom', 'plane-plane', 'atom-plane', 'group-group', 'group-plane']
+    assert [t for t in order if t in types] == sorted(set(types), key=order.index)
+    assert types == sorted(types, key=order.index)          # bags in the reference's order (I:183-210)
+    for c in contacts:
+        assert set(c) == {'bgn', 'end', 'type', 'distance', 'contact', 'interacting_entities'}
+        assert set(c['bgn']) == {'label_comp_id', 'auth_seq_id', 'auth_asym_id', 'auth_atom_id', 'pdbx_PDB_ins_code', 'label_comp_type'}
+        assert set(c['end']) == set(c['bgn'])
+        assert isinstance(c['distance'], float) and round(c['distance'], 2) == c['distance']
+        assert isinstance(c['contact'], list) and c['interacting_entities'] in config.CONTACT_TYPE_NAMES
+    aa = [c for c in contacts if c['type'] == 'atom-atom']
+    assert all(set(c['contact']) <= set(config.SIFT_NAMES) for c in aa)
+    # same selection through the oracle
+    from arpeggio_amd.core import utils
+    idx = utils.selection_parser(['/A/5/', '/A/6/', 'RESNAME:BNZ'], pc)
+    sel = np.zeros(pc.n_atoms, np.uint8)
+    sel[idx] = 1
+    oc = oracle.OracleComplex(pc)
+    plus = oc.make_selection(sel)
+    exp = oc.atom_contacts()
+    assert len(aa) == len(exp['i'])
+    assert np.array_equal(ic.selection_plus, np.nonzero(plus)[0])
+    assert ic.selection_plus_ring_ids == set(np.nonzero(oc.ring_plus)[0].tolist())
+    first = ic.atom_contacts[0]
+    assert (first.bgn_atom, first.end_atom) == (int(exp['i'][0]), int(exp['j'][0]))
+    assert first.sifts == [(int(exp['sift'][0]) >> k) & 1 for k in range(15)]
+    from arpeggio_amd.core import SelectionError
+    with pytest.raises(SelectionError):
+        ic.run_arpeggio(['/A/999999/'], 5.0, 0.1, False)

@@ -1,0 +1,139 @@
+"""Host-side mirror of the reference interface (no GPU): selection parser, labels, packing, C ABI symbols."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from arpeggio_amd import synth
+from arpeggio_amd.core import (AtomSerialError, InteractionComplex, NativeLibraryError, PackedComplex,
+                               SelectionError, config, utils)
+from helpers import tiny_complex
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pack_from_rows(rows):
+    res_keys, res_id = {}, []
+    for r in rows:
+        key = (r['chain'], r['resname'], r['het'], r['seq'], r['icode'])
+        res_keys.setdefault(key, len(res_keys))
+        res_id.append(res_keys[key])
+    keys = list(res_keys)
+    pc = tiny_complex(np.zeros((len(rows), 3), np.float32), res_id=res_id,
+                      res_flags=[config.R_POLYPEPTIDE if rows[res_id.index(k)]['poly'] else 0 for k in range(len(keys))])
+    pc.atom_name = [r['name'] for r in rows]
+    pc.element = [r['element'] for r in rows]
+    pc.res_name = [k[1] for k in keys]
+    pc.res_chain = [k[0] for k in keys]
+    pc.res_seq = np.array([k[3] for k in keys], np.int32)
+    pc.res_icode = [k[4] for k in keys]
+    return pc
+
+
+def test_selection_parser_matches_executed_reference(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, 'selection_parser.json')))
+    pc = _pack_from_rows(g['atoms'])
+    assert len(g['cases']) >= 20
+    for case in g['cases']:
+        if 'error' in case:
+            with pytest.raises(SelectionError) as ei:
+                utils.selection_parser(case['selectors'], pc)
+            assert [str(a) for a in ei.value.args] == case['args'], case
+        else:
+            got = utils.selection_parser(case['selectors'], pc)
+            assert got.tolist() == case['atoms'], case
+
+
+def test_labels_and_json_schema_keys():
+    pc = synth.config3(2000, seed=1).ensure_labels()
+    a = utils.make_pymol_json(pc, atom=5)
+    assert set(a) == {'label_comp_id', 'auth_seq_id', 'auth_asym_id', 'auth_atom_id', 'pdbx_PDB_ins_code'}
+    assert isinstance(a['auth_seq_id'], int)
+    r = utils.make_pymol_json(pc, residue=3)
+    assert set(r) == {'label_comp_id', 'auth_seq_id', 'auth_asym_id', 'pdbx_PDB_ins_code'}
+    assert utils.make_pymol_string(pc, atom=5).count('/') == 2
+    with pytest.raises(TypeError):
+        utils.make_pymol_json(pc)
+
+
+def test_packed_complex_roundtrip_and_validation(tmp_path):
+    pc = synth.config3(3000, seed=2)
+    p = tmp_path / 'x.npz'
+    pc.save(p)
+    q = PackedComplex.load(p)
+    for k in PackedComplex._ARRAYS:
+        assert np.array_equal(getattr(pc, k), getattr(q, k)), k
+    assert q.atom_name == pc.atom_name and q.component_types == pc.component_types
+    assert all(np.array_equal(a, b) for a, b in zip(pc.ring_atoms, q.ring_atoms))
+    with pytest.raises(ValueError):
+        tiny_complex(np.zeros((3, 3)), res_id=[0, 1, 5], res_flags=[0, 0])
+    bad = synth.config3(500, seed=1)
+    bad.bond_off = bad.bond_off[:-1]
+    with pytest.raises(ValueError):
+        bad.validate()
+
+
+def test_interaction_complex_constructor_and_checks(tmp_path):
+    pc = synth.config3(1000, seed=4)
+    ic = InteractionComplex(pc, 0.1, 5.0, 7.4)
+    ic.structure_checks()
+    assert ic.params.vdw_comp_factor == 0.1 and ic.params.interacting_threshold == 5.0
+    assert ic.atom_contacts == [] and ic.get_contacts() == []
+    pc.serial[10] = pc.serial[11]
+    with pytest.raises(AtomSerialError):
+        InteractionComplex(pc).structure_checks()
+    with pytest.raises(NotImplementedError):
+        InteractionComplex('1tqn_h.cif')
+    p = tmp_path / '1abc_h.npz'
+    synth.config3(600, seed=1).save(p)
+    assert InteractionComplex(str(p)).id == '1abc_h'
+
+
+def test_synthetic_generator_is_deterministic():
+    a, b = synth.config3(5000, seed=3), synth.config3(5000, seed=3)
+    for k in PackedComplex._ARRAYS:
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    c = synth.config3(5000, seed=4)
+    assert not np.array_equal(a.xyz, c.xyz)
+    # splitmix64 known answers (seed 0: first outputs of the reference splitmix64 sequence)
+    assert int(synth.splitmix64(0, [0])[0]) == 0xE220A8397B1DCDAF
+    assert int(synth.splitmix64(0, [1])[0]) == 0x6E789E6AA1B965F4
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/arpeggio_hip.h declares."""
+    from arpeggio_amd import _capi
+    hdr = open(os.path.join(ROOT, 'include', 'arpeggio_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(arp_[a-z_0-9]+)\s*\(', hdr))
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for s in declared:
+        assert hasattr(lib, s), s
+    L = _capi.load()
+    assert b'gfx950' in L.arp_version()
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from arpeggio_amd import _capi
+    with pytest.raises(NativeLibraryError):
+        _capi.Context(0)
+    ic = InteractionComplex(synth.config3(500, seed=1))
+    with pytest.raises(NativeLibraryError):
+        ic.run_arpeggio([], 5.0, 0.1, False)
+
+
+def test_product_never_imports_the_oracle():
+    """A product path routed through oracle/ would void every parity claim."""
+    for base, _, files in os.walk(os.path.join(ROOT, 'arpeggio_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(base, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle\b', src, flags=re.M), f
+                assert 'liborc' not in src and 'ref_c' not in src, f
