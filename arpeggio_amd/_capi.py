@@ -26,7 +26,8 @@ SYMBOLS = (
     'arp_set_ownership', 'arp_get_stats', 'arp_set_profiling', 'arp_get_kernel_times', 'arp_stream_handle',
     'arp_set_selection', 'arp_run_launch', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
-    'arp_group_plane_fetch', 'arp_get_selection',
+    'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
+    'arp_set_selection_state',
 )
 
 _lib = None
@@ -68,6 +69,9 @@ def load():
     L.arp_group_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_set_ownership.argtypes = [vp, vp, vp]
     L.arp_set_selection.argtypes = [vp, vp]
+    L.arp_set_group_ownership.argtypes = [vp, vp, vp, vp, vp]
+    L.arp_set_single_bond_neighbour_coords.argtypes = [vp, vp, vp]
+    L.arp_set_selection_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.arp_get_selection.argtypes = [vp, vp, vp, vp, vp, vp]
     L.arp_run_launch.argtypes = [vp, dbl, dbl, i32, dbl, vp]
     for nm in ('atom_plane', 'plane_plane', 'group_group', 'group_plane'):
@@ -148,6 +152,25 @@ class Context:
         home = None if is_home is None else np.ascontiguousarray(is_home, np.uint8)
         gid = None if global_id is None else np.ascontiguousarray(global_id, np.int32)
         self._check(self._L.arp_set_ownership(self._h, _p(home), _p(gid)), 'arp_set_ownership')
+
+    def set_group_ownership(self, ring_home, ring_gid, amide_home, amide_gid):
+        a = [np.ascontiguousarray(ring_home, np.uint8), np.ascontiguousarray(ring_gid, np.int32),
+             np.ascontiguousarray(amide_home, np.uint8), np.ascontiguousarray(amide_gid, np.int32)]
+        self._check(self._L.arp_set_group_ownership(self._h, *[_p(x) for x in a]), 'arp_set_group_ownership')
+
+    def set_single_bond_neighbour_coords(self, sb_xyz, sb_present):
+        x = np.ascontiguousarray(sb_xyz, np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(sb_present, np.uint8)
+        self._check(self._L.arp_set_single_bond_neighbour_coords(self._h, _p(x), _p(f)), 'arp_set_single_bond_neighbour_coords')
+
+    def set_selection_state(self, sel, plus, ring_sel, ring_plus, amide_sel, amide_plus):
+        a = [np.ascontiguousarray(x, np.uint8) for x in (sel, plus, ring_sel, ring_plus, amide_sel, amide_plus)]
+        self._check(self._L.arp_set_selection_state(self._h, *[_p(x) for x in a]), 'arp_set_selection_state')
+
+    def launch_bag(self, name):
+        cnt = C.c_int64(0)
+        self._check(getattr(self._L, f'arp_{name}_launch')(self._h, C.byref(cnt)), f'arp_{name}_launch')
+        return int(cnt.value)
 
     # ---- searches ----
     def search_all(self, radius, active=None):

@@ -26,12 +26,14 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
-    hipError_t reserve(size_t n) {
+    // *fresh (optional) is set when new memory was allocated (contents undefined)
+    hipError_t reserve(size_t n, bool* fresh = nullptr) {
+        if (fresh) *fresh = false;
         if (n <= cap && p) return hipSuccess;
         release();
         size_t c = n + n / 4 + 64;
         hipError_t e = hipMalloc((void**)&p, c * sizeof(T));
-        if (e == hipSuccess) cap = c;
+        if (e == hipSuccess) { cap = c; if (fresh) *fresh = true; }
         else p = nullptr;
         return e;
     }
@@ -102,6 +104,9 @@ struct arp_ctx {
     DevBuf<float> am_c, am_n;
     DevBuf<int> am_res;
     DevBuf<uint8_t> am_sel, am_plus;
+    DevBuf<uint8_t> ring_home, am_home;
+    DevBuf<int> ring_gid, am_gid;
+    bool has_group_owner = false;
     // ---- derived
     DevBuf<float4> xyzm, s_xyzm;
     DevBuf<int4> aux, s_aux;
@@ -242,9 +247,9 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     HIPCHK(c, G.perm.reserve((size_t)std::max(n, 1)));
     {   // the histogram is zero on entry: k_scatter's atomicSub takes every counter back to 0,
         // so only a fresh allocation needs clearing
-        int* before = G.cnt.p;
-        HIPCHK(c, G.cnt.reserve((size_t)ncell + 1));
-        if (G.cnt.p != before) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), c->stream));
+        bool fresh = false;
+        HIPCHK(c, G.cnt.reserve((size_t)ncell + 1, &fresh));
+        if (fresh) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), c->stream));
     }
     HIPCHK(c, G.start.reserve((size_t)ncell + 2));
     const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
@@ -390,7 +395,7 @@ int enqueue_selection(arp_ctx* c, double radius) {
     if (n > 0) {
         Prof p(c, SLOT_MARK);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, (int2*)nullptr,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, (int2*)nullptr,
                            0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
         CHK(check_launch(c, "k_search<MARK>"));
     }
@@ -445,7 +450,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             Prof p(c, SLOT_SEARCH);
             hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->pairs.p, (u64)cap, c->d_ctr + C_PAIRS, c->d_ctr + C_STAT_CAND, c->d_ctr + C_STAT_ACC,
+                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)cap, c->d_ctr + C_PAIRS, c->d_ctr + C_STAT_CAND, c->d_ctr + C_STAT_ACC,
                                (uint8_t*)nullptr);
             CHK(check_launch(c, "k_search<CONTACTS>"));
         }
@@ -484,7 +489,8 @@ int enqueue_atom_plane(arp_ctx* c) {  // I:947-1062
     Prof p(c, SLOT_PLANES);
     hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256, 8192)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
                        c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p,
-                       c->ring_plus.p, c->plus.p, c->has_gid ? c->gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p,
+                       c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
+                       c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p,
                        b.u0.p, b.u1.p, c->d_ctr + C_AP);
     return check_launch(c, "k_atom_plane");
 }
@@ -498,6 +504,7 @@ int enqueue_plane_plane(arp_ctx* c) {  // I:1064-1194
     Prof p(c, SLOT_PLANES);
     hipLaunchKernelGGL(k_plane_plane, dim3(nblocks(c->nring * 64, 256, 8192)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
                        c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p, c->ring_plus.p,
+                       c->has_group_owner ? c->ring_home.p : nullptr, c->has_group_owner ? c->ring_gid.p : nullptr,
                        (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP);
     return check_launch(c, "k_plane_plane");
 }
@@ -510,7 +517,8 @@ int enqueue_group_group(arp_ctx* c) {  // I:1217-1300
     CHK(ensure_amide_grid(c));
     Prof p(c, SLOT_PLANES);
     hipLaunchKernelGGL(k_group_group, dim3(nblocks(c->namide * 64, 256, 8192)), dim3(256), 0, c->stream, c->amide_grid.d, c->amide_grid.start.p,
-                       c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, (long long)b.cap,
+                       c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p,
+                       c->has_group_owner ? c->am_home.p : nullptr, c->has_group_owner ? c->am_gid.p : nullptr, (long long)b.cap,
                        b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p, b.u0.p, c->d_ctr + C_GG);
     return check_launch(c, "k_group_group");
 }
@@ -524,8 +532,9 @@ int enqueue_group_plane(arp_ctx* c) {  // I:1302-1382
     Prof p(c, SLOT_PLANES);
     hipLaunchKernelGGL(k_group_plane, dim3(nblocks(c->namide * 64, 256, 8192)), dim3(256), 0, c->stream, c->ring_grid.d, c->ring_grid.start.p,
                        c->ring_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, c->ring_c.p,
-                       c->ring_n.p, c->ring_sel.p, c->ring_plus.p, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.u0.p,
-                       c->d_ctr + C_GP);
+                       c->ring_n.p, c->ring_sel.p, c->ring_plus.p, c->has_group_owner ? c->am_home.p : nullptr,
+                       c->has_group_owner ? c->am_gid.p : nullptr, c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap,
+                       b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.u0.p, c->d_ctr + C_GP);
     return check_launch(c, "k_group_plane");
 }
 
@@ -636,6 +645,7 @@ void arp_destroy(arp_ctx* c) {
     c->atom_grid.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
+    c->ring_home.release(); c->am_home.release(); c->ring_gid.release(); c->am_gid.release();
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -750,6 +760,7 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
     HIPCHK(c, c->ring_plus.reserve((size_t)std::max<int64_t>(nring, 1)));
     c->ring_grid.valid = false;
     c->sel_made = false;
+    c->has_group_owner = false;
     return ARP_OK;
 }
 
@@ -766,6 +777,7 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
     HIPCHK(c, c->am_plus.reserve((size_t)std::max<int64_t>(namide, 1)));
     c->amide_grid.valid = false;
     c->sel_made = false;
+    c->has_group_owner = false;
     return ARP_OK;
 }
 
@@ -782,6 +794,55 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
     } else c->has_gid = false;
     c->records_dirty = true;
     c->contacts_valid = false;
+    return ARP_OK;
+}
+
+int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t* ring_gid, const uint8_t* amide_home,
+                            const int32_t* amide_gid) {
+    if (!c) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!ring_home && !ring_gid && !amide_home && !amide_gid) { c->has_group_owner = false; return ARP_OK; }
+    if ((c->nring > 0 && (!ring_home || !ring_gid)) || (c->namide > 0 && (!amide_home || !amide_gid)))
+        FAIL(c, ARP_E_ARG, "arp_set_group_ownership: all four arrays are required");
+    for (int64_t i = 1; i < c->nring; ++i)
+        if (ring_gid[i] <= ring_gid[i - 1]) FAIL(c, ARP_E_ARG, "arp_set_group_ownership: ring_gid must be strictly increasing");
+    for (int64_t i = 1; i < c->namide; ++i)
+        if (amide_gid[i] <= amide_gid[i - 1]) FAIL(c, ARP_E_ARG, "arp_set_group_ownership: amide_gid must be strictly increasing");
+    CHK(upload(c, c->ring_home, ring_home, (size_t)c->nring)); CHK(upload(c, c->ring_gid, ring_gid, (size_t)c->nring));
+    CHK(upload(c, c->am_home, amide_home, (size_t)c->namide)); CHK(upload(c, c->am_gid, amide_gid, (size_t)c->namide));
+    c->has_group_owner = true;
+    return ARP_OK;
+}
+
+int arp_set_single_bond_neighbour_coords(arp_ctx* c, const float* sb_xyz, const uint8_t* sb_present) {
+    if (!c || (c->n > 0 && (!sb_xyz || !sb_present))) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<float4> sb((size_t)c->n);
+    for (int64_t i = 0; i < c->n; ++i)
+        sb[i] = sb_present[i] ? make_float4(sb_xyz[3 * i], sb_xyz[3 * i + 1], sb_xyz[3 * i + 2], 1.0f) : make_float4(0, 0, 0, 0);
+    CHK(upload(c, c->sb, sb.data(), (size_t)c->n));
+    c->has_sb = true;
+    c->contacts_valid = false;
+    return ARP_OK;
+}
+
+int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8_t* in_plus, const uint8_t* ring_sel,
+                            const uint8_t* ring_plus, const uint8_t* amide_sel, const uint8_t* amide_plus) {
+    if (!c) return ARP_E_ARG;
+    if ((c->n > 0 && (!in_selection || !in_plus)) || (c->nring > 0 && (!ring_sel || !ring_plus)) ||
+        (c->namide > 0 && (!amide_sel || !amide_plus)))
+        FAIL(c, ARP_E_ARG, "arp_set_selection_state: null input");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(upload(c, c->sel, in_selection, (size_t)c->n));
+    CHK(upload(c, c->plus, in_plus, (size_t)c->n));
+    CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));
+    CHK(upload(c, c->am_sel, amide_sel, (size_t)c->namide)); CHK(upload(c, c->am_plus, amide_plus, (size_t)c->namide));
+    c->sel_made = true;
+    c->records_dirty = true;
+    c->atom_grid.valid = false;
+    c->grid_all_atoms = false;
+    c->contacts_valid = false;
+    c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
     return ARP_OK;
 }
 
@@ -812,7 +873,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, c->pairs.p,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
                            (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, (uint8_t*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }

@@ -91,7 +91,7 @@ template <int MODE>
 __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
-                                                               int include_seq_adj, int2* __restrict__ pairs,
+                                                               int include_seq_adj, int count_owned, int2* __restrict__ pairs,
                                                                unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus) {
@@ -185,7 +185,15 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                     // inside the home pencil only later entries of the sorted array (j > h) pair up
                     const bool tested = valid && (!in_r0 || j > h);
                     const bool hit = tested && (num::dist2_kd(ph, pj) <= r2);
-                    n_cand += __popcll(__ballot(tested));
+                    if (count_owned) {
+                        // sharded run: a boundary pair is tested on two ranks; count it for the owner of its bgn atom only
+                        const int lh = __builtin_amdgcn_readlane(hauxreg.x, hh);
+                        const uint32_t mh0 = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
+                        const bool owned = ((lh < aj.x) ? mh0 : mj) & M_HOME;
+                        n_cand += __popcll(__ballot(tested && owned));
+                    } else {
+                        n_cand += __popcll(__ballot(tested));
+                    }
                     const unsigned long long mhit = __ballot(hit);
                     if (mhit == 0) continue;
                     n_acc += __popcll(mhit);

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
                                                     int nring, const double* __restrict__ ring_c,
                                                     const double* __restrict__ ring_n, const int* __restrict__ ring_res,
                                                     const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
-                                                    const uint8_t* __restrict__ plus,
+                                                    const uint8_t* __restrict__ plus, const uint8_t* __restrict__ ring_home,
+                                                    const int* __restrict__ ring_gid,
                                                     const int* __restrict__ gid, long long cap, int* __restrict__ out_atom,
                                                     int* __restrict__ out_ring, double* __restrict__ out_dist,
                                                     double* __restrict__ out_theta, uint8_t* __restrict__ out_mask,
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     for (int r = wave; r < nring; r += nwave) {
         if (!ring_plus[r]) continue;  // I:957
+        if (ring_home && !ring_home[r]) continue;  // multi-GPU: the rank owning the ring emits
         const num::d3 ctr_ = ld3(ring_c, r), nrm = ld3(ring_n, r);
         const bool rsel = ring_sel[r];
         const Stencil st = stencil_load(g, start, cell_box(g, ctr_), lane);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
             const long long slot = wave_slot(emit, n_out, lane);
             if (emit && slot < cap) {
                 out_atom[slot] = gid ? gid[lid] : lid;
-                out_ring[slot] = r;
+                out_ring[slot] = ring_gid ? ring_gid[r] : r;
                 out_dist[slot] = dist;
                 out_theta[slot] = theta;
                 out_mask[slot] = (uint8_t)mask;
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
                                                      int nring, const double* __restrict__ ring_c,
                                                      const double* __restrict__ ring_n, const int* __restrict__ ring_res,
                                                      const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
+                                                     const uint8_t* __restrict__ ring_home, const int* __restrict__ ring_gid,
                                                      long long cap, int* __restrict__ out_bgn, int* __restrict__ out_end,
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_t1, double* __restrict__ out_t2,
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     for (int a = wave; a < nring; a += nwave) {
         if (!ring_plus[a]) continue;  // I:1081
+        if (ring_home && !ring_home[a]) continue;  // multi-GPU: owner of the lower ring id emits the pair
         const num::d3 ca = ld3(ring_c, a), na = ld3(ring_n, a);
         const int ra = ring_res[a];
         const bool asel = ring_sel[a];
@@ -204,8 +208,9 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
             }
             const long long slot = wave_slot(emit, n_out, lane);
             if (emit && slot < cap) {
-                out_bgn[slot] = first ? a : b;
-                out_end[slot] = first ? b : a;
+                const int ga = ring_gid ? ring_gid[a] : a, gb = ring_gid ? ring_gid[b] : b;
+                out_bgn[slot] = first ? ga : gb;
+                out_end[slot] = first ? gb : ga;
                 out_dist[slot] = dist; out_dih[slot] = dih;
                 out_t1[slot] = t1; out_t2[slot] = t2;
                 out_y1[slot] = (uint8_t)y1; out_y2[slot] = (uint8_t)y2;
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
 __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
                                                      int namide, const float* __restrict__ am_c, const float* __restrict__ am_n,
                                                      const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
+                                                     const uint8_t* __restrict__ am_home, const int* __restrict__ am_gid,
                                                      long long cap, int* __restrict__ out_bgn, int* __restrict__ out_end,
                                                      float* __restrict__ out_dist, float* __restrict__ out_dih,
                                                      float* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __re
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
+        if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the bgn amide emits
         const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
         const bool asel = am_sel[a];
         const Stencil st = stencil_load(g, start, cell_box(g, num::to_d3(ca)), lane);
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __re
             }
             const long long slot = wave_slot(emit, n_out, lane);
             if (emit && slot < cap) {
-                out_bgn[slot] = a; out_end[slot] = b;
+                out_bgn[slot] = am_gid ? am_gid[a] : a; out_end[slot] = am_gid ? am_gid[b] : b;
                 out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
                 out_ct[slot] = (uint8_t)ct;
             }
@@ -267,6 +274,8 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
                                                      const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
                                                      const double* __restrict__ ring_c, const double* __restrict__ ring_n,
                                                      const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
+                                                     const uint8_t* __restrict__ am_home, const int* __restrict__ am_gid,
+                                                     const int* __restrict__ ring_gid,
                                                      long long cap, int* __restrict__ out_amide, int* __restrict__ out_ring,
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
@@ -276,6 +285,7 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
+        if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the amide emits
         const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
         const num::d3 cad = num::to_d3(ca);
         const bool asel = am_sel[a];
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
             }
             const long long slot = wave_slot(emit, n_out, lane);
             if (emit && slot < cap) {
-                out_amide[slot] = a; out_ring[slot] = r;
+                out_amide[slot] = am_gid ? am_gid[a] : a; out_ring[slot] = ring_gid ? ring_gid[r] : r;
                 out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
                 out_ct[slot] = (uint8_t)ct;
             }

@@ -64,12 +64,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
+    # ARP_BENCH_SHARE_GPU=1 (debug only): every rank uses GPU 0 and the exchange goes over gloo, so the
+    # N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
+    share_gpu = os.environ.get('ARP_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
+    dist, comm_device = None, torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if share_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            comm_device = None
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=comm_device)
 
     from arpeggio_amd import synth, _capi
 
@@ -87,7 +96,7 @@ def main():
         full = synth.slab_config(args.atoms, world, seed=4)
         workload = (f'synthetic {args.atoms * world} atoms in {world} x-slabs of {args.atoms} '
                     f'(BASELINE configs[3] family), one-cell halo over RCCL')
-        shard = sharding.make_shard_distributed(full, rank, world, dist, device=torch.device('cuda', local_rank))
+        shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
         halo_ms = shard.halo_ms
         ctx = _capi.Context(local_rank)
         sharding.upload_shard(ctx, shard)
@@ -95,8 +104,12 @@ def main():
         pc = shard.pc
     gen_s = time.perf_counter() - t0
 
-    def step():
-        return ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+    if world == 1:
+        def step():
+            return ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+    else:
+        def step():   # local 6 A expansion, selection-bit halo exchange + residue all-reduce, then the five bags
+            return sharding.run_shard(ctx, shard, dist, comm_device, args.cutoff, args.vdw_comp, False)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -121,10 +134,11 @@ def main():
     # max over ranks of the elapsed time, sum over ranks of the work
     cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        rdev = 'cpu' if comm_device is None else comm_device
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        w = torch.tensor([cand, acc, emitted, st['expand_candidates']], dtype=torch.float64, device='cuda')
+        w = torch.tensor([cand, acc, emitted, st['expand_candidates']], dtype=torch.float64, device=rdev)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         cand_all, acc_all, emitted_all, exp_all = (float(x) for x in w.tolist())
     else:
@@ -182,7 +196,7 @@ def main():
         'accepted_pairs_per_s': round(acc_all * args.steps / elapsed, 1),
         'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()},
         'kernel_launches_per_step': {k: v['launches'] / args.steps for k, v in ktimes.items() if v['launches']},
-        'halo_exchange_ms': round(halo_ms, 3), 'setup_s': round(gen_s, 2),
+        'halo_exchange_ms': round(halo_ms, 3), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(line))

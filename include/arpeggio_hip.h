@@ -253,6 +253,21 @@ int arp_group_plane(arp_ctx* ctx, int64_t cap, int32_t* out_amide, int32_t* out_
  * the local index (NULL = local index). */
 int arp_set_ownership(arp_ctx* ctx, const uint8_t* is_home, const int32_t* global_id);
 
+/* Same for rings and amides: which ones this rank owns and their global ids (strictly
+ * increasing).  plane-plane pairs are emitted by the owner of the lower ring id, atom-plane
+ * records by the owner of the ring, group-group / group-plane by the owner of the (bgn) amide. */
+int arp_set_group_ownership(arp_ctx* ctx, const uint8_t* ring_home, const int32_t* ring_gid,
+                            const uint8_t* amide_home, const int32_t* amide_gid);
+/* Coordinates of utils.get_single_bond_neighbour (U:612-635) given inline (float32[n,3] +
+ * presence flag), for shards whose neighbour atom lives on another rank. */
+int arp_set_single_bond_neighbour_coords(arp_ctx* ctx, const float* sb_xyz, const uint8_t* sb_present);
+/* Install an externally combined _make_selection result (I:1444-1451): used by the slab
+ * sharding after the halo exchange of selection_plus bits and the all-reduce of the
+ * residue sets. */
+int arp_set_selection_state(arp_ctx* ctx, const uint8_t* in_selection, const uint8_t* in_plus,
+                            const uint8_t* ring_sel, const uint8_t* ring_plus,
+                            const uint8_t* amide_sel, const uint8_t* amide_plus);
+
 /* ---- measurement ---------------------------------------------------------- */
 /* stats[0]=candidate pairs tested by the last atom-contact search,
  * stats[1]=pairs with d<=cutoff, stats[2]=pairs passing the residue filters

@@ -1,0 +1,178 @@
+"""Slab sharding on CPU: partition + halo exchange + ownership, world_size 2 and 3 over gloo.
+
+The compute backend in these tests is the oracle (allowed in tests/): each rank evaluates its
+shard, keeps what it owns, and the union must equal the unsharded result with global ids.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle
+from arpeggio_amd import sharding, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _eval_shard(sh, masks):
+    """Oracle on one shard + ownership rule; ids mapped to global."""
+    oc = oracle.OracleComplex(sh.pc, in_sel=masks['sel'], in_plus=masks['plus'])
+    oc.ring_sel[:] = masks['ring_sel']; oc.ring_plus[:] = masks['ring_plus']
+    oc.amide_sel[:] = masks['amide_sel']; oc.amide_plus[:] = masks['amide_plus']
+    # the shard's single-bond neighbours are inline coordinates; the oracle wants an index: append ghost atoms
+    r = oc.atom_contacts(use_grid=False) if not sh.sb_has.any() else _contacts_with_inline_sb(sh, masks)
+    own = sh.is_home[r['i']] == 1
+    aa = np.stack([sh.global_id[r['i'][own]], sh.global_id[r['j'][own]], r['sift'][own].astype(np.int64),
+                   r['ctype'][own].astype(np.int64), r['dist'][own].view(np.uint32).astype(np.int64)], axis=1)
+    pp = oc.plane_plane()
+    lo = np.minimum(pp['bgn'], pp['end'])
+    ownp = sh.ring_home[lo] == 1
+    ppo = np.stack([sh.ring_gid[pp['bgn'][ownp]], sh.ring_gid[pp['end'][ownp]], pp['type1'][ownp].astype(np.int64),
+                    pp['type2'][ownp].astype(np.int64), pp['ctype'][ownp].astype(np.int64)], axis=1)
+    ap = oc.atom_plane()
+    owna = sh.ring_home[ap['ring']] == 1
+    apo = np.stack([sh.ring_gid[ap['ring'][owna]], sh.global_id[ap['atom'][owna]], ap['mask'][owna].astype(np.int64),
+                    ap['ctype'][owna].astype(np.int64)], axis=1)
+    gg = oc.group_group()
+    owng = sh.amide_home[gg['bgn']] == 1
+    ggo = np.stack([sh.amide_gid[gg['bgn'][owng]], sh.amide_gid[gg['end'][owng]], gg['ctype'][owng].astype(np.int64)], axis=1)
+    gp = oc.group_plane()
+    ownq = sh.amide_home[gp['amide']] == 1
+    gpo = np.stack([sh.amide_gid[gp['amide'][ownq]], sh.ring_gid[gp['ring'][ownq]], gp['ctype'][ownq].astype(np.int64)], axis=1)
+    return dict(aa=aa, pp=ppo, ap=apo, gg=ggo, gp=gpo)
+
+
+def _contacts_with_inline_sb(sh, masks):
+    """Give the oracle an index for every inline single-bond neighbour by appending inert ghost atoms."""
+    from arpeggio_amd.core.packed import PackedComplex
+    pc = sh.pc
+    n = pc.n_atoms
+    need = np.nonzero(sh.sb_has)[0]
+    g = need.size
+    sb = pc.sb_nbr.copy()
+    sb[need] = n + np.arange(g)
+    ghost_res = pc.n_residues + np.arange(g)
+    pc2 = PackedComplex(
+        xyz=np.concatenate([pc.xyz, sh.sb_xyz[need]]), vdw=np.concatenate([pc.vdw, np.ones(g)]), cov=np.concatenate([pc.cov, np.ones(g)]),
+        type_mask=np.concatenate([pc.type_mask, np.zeros(g, np.uint16)]), flags=np.concatenate([pc.flags, np.zeros(g, np.uint16)]),
+        res_id=np.concatenate([pc.res_id, ghost_res]), res_flags=np.concatenate([pc.res_flags, np.zeros(g, np.uint8)]),
+        res_prev=np.concatenate([pc.res_prev, np.full(g, -1)]), res_next=np.concatenate([pc.res_next, np.full(g, -1)]),
+        bond_off=np.concatenate([pc.bond_off, np.full(g, pc.bond_off[-1])]), bond_idx=pc.bond_idx,
+        h_off=np.concatenate([pc.h_off, np.full(g, pc.h_off[-1])]), h_xyz=pc.h_xyz, sb_nbr=np.concatenate([sb, np.full(g, -1)]),
+        ring_center=pc.ring_center, ring_normal=pc.ring_normal, ring_res=pc.ring_res,
+        amide_center=pc.amide_center, amide_normal=pc.amide_normal, amide_res=pc.amide_res)
+    plus = np.concatenate([masks['plus'], np.zeros(g, np.uint8)])     # ghosts are outside the selection_plus tree
+    sel = np.concatenate([masks['sel'], np.zeros(g, np.uint8)])
+    oc = oracle.OracleComplex(pc2, in_sel=sel, in_plus=plus)
+    return oc.atom_contacts(use_grid=False)
+
+
+def _reference(full, sel):
+    oc = oracle.OracleComplex(full)
+    oc.make_selection(sel)
+    r = oc.atom_contacts()
+    aa = np.stack([r['i'], r['j'], r['sift'].astype(np.int64), r['ctype'].astype(np.int64),
+                   r['dist'].view(np.uint32).astype(np.int64)], axis=1)
+    pp, ap, gg, gp = oc.plane_plane(), oc.atom_plane(), oc.group_group(), oc.group_plane()
+    return dict(
+        aa=aa,
+        pp=np.stack([pp['bgn'], pp['end'], pp['type1'].astype(np.int64), pp['type2'].astype(np.int64), pp['ctype'].astype(np.int64)], axis=1),
+        ap=np.stack([ap['ring'], ap['atom'], ap['mask'].astype(np.int64), ap['ctype'].astype(np.int64)], axis=1),
+        gg=np.stack([gg['bgn'], gg['end'], gg['ctype'].astype(np.int64)], axis=1),
+        gp=np.stack([gp['amide'], gp['ring'], gp['ctype'].astype(np.int64)], axis=1)), oc
+
+
+def _canon(a):
+    a = np.asarray(a, np.int64).reshape(-1, a.shape[1] if a.ndim == 2 else 1)
+    return a[np.lexsort(a.T[::-1])] if a.size else a
+
+
+def _workload():
+    full = synth.slab_config(2500, 3, seed=8)      # 7500 atoms, 3 slabs of ~58 A
+    rng = np.random.default_rng(3)
+    sel = np.zeros(full.n_atoms, np.uint8)
+    sel[np.isin(full.res_id, rng.choice(full.n_residues, full.n_residues // 15, replace=False))] = 1
+    return full, sel
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_local_shards_union_equals_unsharded(world):
+    """No communication: shards cut from global knowledge + global selection masks."""
+    full, sel = _workload()
+    exp, oc = _reference(full, sel)
+    got = {k: [] for k in exp}
+    for rank in range(world):
+        sh = sharding.make_shard_local(full, rank, world, sel)
+        assert np.all(np.diff(sh.global_id) > 0) and sh.is_home.sum() > 0 and (sh.is_home == 0).sum() > 0
+        masks = dict(sel=sel[sh.global_id], plus=oc.in_plus[sh.global_id], ring_sel=oc.ring_sel[sh.ring_gid],
+                     ring_plus=oc.ring_plus[sh.ring_gid], amide_sel=oc.amide_sel[sh.amide_gid], amide_plus=oc.amide_plus[sh.amide_gid])
+        # the shard-local expansion + combine (single process: no exchange) reproduces the masks of home atoms
+        loc = oracle.OracleComplex(sh.pc)
+        plus_local = loc.make_selection(sh.sel, use_grid=False)
+        hm = sh.is_home == 1
+        assert np.array_equal(plus_local[hm], masks['plus'][hm])
+        out = _eval_shard(sh, masks)
+        for k in got:
+            got[k].append(out[k])
+    for k in exp:
+        g = np.concatenate(got[k], axis=0)
+        assert np.array_equal(_canon(g), _canon(exp[k])), k
+    assert len(exp['aa']) > 1000 and len(exp['pp']) > 0 and len(exp['ap']) > 0
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        full, sel = _workload()
+        sh = sharding.make_shard_distributed(full, rank, world, dist, device=None, sel=sel)
+        ref = sharding.make_shard_local(full, rank, world, sel)
+        same = all(np.array_equal(getattr(sh.pc, k), getattr(ref.pc, k)) for k in
+                   ('xyz', 'vdw', 'type_mask', 'flags', 'res_id', 'res_prev', 'res_next', 'bond_off', 'bond_idx', 'h_off', 'h_xyz',
+                    'ring_center', 'ring_res', 'amide_center', 'amide_res'))
+        same = same and np.array_equal(sh.global_id, ref.global_id) and np.array_equal(sh.is_home, ref.is_home) \
+            and np.array_equal(sh.sb_xyz, ref.sb_xyz) and np.array_equal(sh.origin, ref.origin)
+        loc = oracle.OracleComplex(sh.pc)
+        plus_local = loc.make_selection(sh.sel, use_grid=False)
+        masks = sharding.combine_selection(sh, plus_local, dist, device=None)   # plus-bit halo exchange + residue all-reduce
+        out = _eval_shard(sh, masks)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (same, out, masks['plus'], sh.global_id))
+        if rank == 0:
+            q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_gloo_halo_exchange_and_selection_combine(world):
+    """One process per rank over gloo: exchanged halos == global-knowledge halos, combined masks == global
+    _make_selection, union of owned results == unsharded result."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full, sel = _workload()
+    exp, oc = _reference(full, sel)
+    assert all(g[0] for g in gathered), 'exchanged shard differs from the global-knowledge shard'
+    for _, _, plus, gid in gathered:
+        assert np.array_equal(plus, oc.in_plus[gid]), 'combined selection_plus differs from the global one'
+    for k in exp:
+        g = np.concatenate([x[1][k] for x in gathered], axis=0)
+        assert np.array_equal(_canon(g), _canon(exp[k])), k
