@@ -21,6 +21,7 @@
 namespace {
 
 std::string g_create_error;
+uint64_t g_alloc_epoch = 0;   // bumped by every device (re)allocation: invalidates captured graphs
 
 template <class T>
 struct DevBuf {
@@ -33,7 +34,7 @@ struct DevBuf {
         release();
         size_t c = n + n / 4 + 64;
         hipError_t e = hipMalloc((void**)&p, c * sizeof(T));
-        if (e == hipSuccess) { cap = c; if (fresh) *fresh = true; }
+        if (e == hipSuccess) { cap = c; ++g_alloc_epoch; if (fresh) *fresh = true; }
         else p = nullptr;
         return e;
     }
@@ -108,8 +109,9 @@ struct arp_ctx {
     DevBuf<int> ring_gid, am_gid;
     bool has_group_owner = false;
     // ---- derived
-    DevBuf<float4> xyzm, s_xyzm;
-    DevBuf<int4> aux, s_aux;
+    DevBuf<float4> s_xyzm;
+    DevBuf<int4> s_aux;
+    DevBuf<SiftRec> s_rec;
     bool records_dirty = true;
     Grid atom_grid, ring_grid, amide_grid;
     DevBuf<uint8_t> tmp_u8;
@@ -126,6 +128,14 @@ struct arp_ctx {
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t contact_cells = 0;
     bool ctr_clean = false;
+    // ---- hipGraph of the whole run_arpeggio pass (captured on the 2nd identical call, replayed afterwards)
+    u64* h_ctr_pinned = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_ok = true;          // set false if capture/instantiate ever fails: direct launches from then on
+    uint64_t input_epoch = 0;      // bumped by every call that changes sizes / pointers / flags baked into kernel args
+    struct GraphKey { double cutoff, comp, expand; int seq_adj; uint64_t alloc_epoch, input_epoch; bool valid; } gkey{0, 0, 0, 0, 0, 0, false},
+        last_key{0, 0, 0, 0, 0, 0, false};
     bool grid_all_atoms = false;  // atom_grid currently holds every atom (selection-expansion grid)
     // ---- device-resident result bags of the ring / amide kernels
     Bag bag_ap, bag_pp, bag_gg, bag_gp;
@@ -235,7 +245,41 @@ void make_grid_desc(GridDesc& d, const double lo[3], const double hi[3], double 
     d.inv = 1.0 / edge;
 }
 
-// bin + scan + scatter + cell sort.  P = point accessor; filter as in k_bin.
+// exclusive scan of the cell histogram: one launch for small grids, three-phase otherwise
+int enqueue_scan(arp_ctx* c, Grid& G) {
+    const int ncell = G.d.ncell;
+    Prof p(c, SLOT_SCAN);
+    if (ncell <= 4096) {
+        hipLaunchKernelGGL((k_scan_small<4>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+    } else if (ncell <= 16384) {
+        hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+    } else if (ncell <= 65536) {
+        hipLaunchKernelGGL((k_scan_small<64>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+    } else {
+        const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_scan_local, dim3(nb_scan), dim3(SCAN_THREADS), 0, c->stream, G.cnt.p, ncell, G.start.p, G.sums.p);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, G.sums.p, nb_scan);
+        hipLaunchKernelGGL(k_scan_add, dim3((ncell + 1 + 255) / 256), dim3(256), 0, c->stream, G.start.p, ncell, G.sums.p, nb_scan);
+    }
+    return check_launch(c, "k_scan");
+}
+
+// grid buffers sized for the current descriptor; the histogram is zero on entry (see below)
+int reserve_grid(arp_ctx* c, Grid& G, int n) {
+    const int ncell = G.d.ncell;
+    HIPCHK(c, G.cell_of.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, G.perm.reserve((size_t)std::max(n, 1)));
+    {   // k_scatter's atomicSub takes every counter back to 0, so only a fresh allocation needs clearing
+        bool fresh = false;
+        HIPCHK(c, G.cnt.reserve(std::max<size_t>((size_t)ncell + 1, 65536 + 8), &fresh));
+        if (fresh) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), c->stream));
+    }
+    HIPCHK(c, G.start.reserve(std::max<size_t>((size_t)ncell + 2, 65536 + 8)));
+    HIPCHK(c, G.sums.reserve((size_t)(ncell + SCAN_TILE - 1) / SCAN_TILE + 2));
+    return ARP_OK;
+}
+
+// bin + scan + scatter (+ optional cell sort) for rings / amides.  P = point accessor; filter as in k_bin.
 template <class P, int FILTER>
 int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const double hi[3], double radius,
                const uint8_t* active, const float4* xyzm, uint32_t req, uint32_t forb) {
@@ -243,17 +287,7 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     G.radius = radius;
     G.n_points = n;
     const int ncell = G.d.ncell;
-    HIPCHK(c, G.cell_of.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, G.perm.reserve((size_t)std::max(n, 1)));
-    {   // the histogram is zero on entry: k_scatter's atomicSub takes every counter back to 0,
-        // so only a fresh allocation needs clearing
-        bool fresh = false;
-        HIPCHK(c, G.cnt.reserve((size_t)ncell + 1, &fresh));
-        if (fresh) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), c->stream));
-    }
-    HIPCHK(c, G.start.reserve((size_t)ncell + 2));
-    const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
-    HIPCHK(c, G.sums.reserve((size_t)nb_scan + 2));
+    CHK(reserve_grid(c, G, n));
     {
         Prof p(c, SLOT_BIN);
         if (n > 0) {
@@ -262,13 +296,7 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
             CHK(check_launch(c, "k_bin"));
         }
     }
-    {
-        Prof p(c, SLOT_SCAN);
-        hipLaunchKernelGGL(k_scan_local, dim3(nb_scan), dim3(SCAN_THREADS), 0, c->stream, G.cnt.p, ncell, G.start.p, G.sums.p);
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, G.sums.p, nb_scan);
-        hipLaunchKernelGGL(k_scan_add, dim3((ncell + 1 + 255) / 256), dim3(256), 0, c->stream, G.start.p, ncell, G.sums.p, nb_scan);
-        CHK(check_launch(c, "k_scan"));
-    }
+    CHK(enqueue_scan(c, G));
     {
         Prof p(c, SLOT_SCATTER);
         if (n > 0) {
@@ -285,49 +313,58 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     return ARP_OK;
 }
 
-int ensure_records(arp_ctx* c) {
-    if (!c->records_dirty) return ARP_OK;
-    const int n = (int)c->n;
-    HIPCHK(c, c->xyzm.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->aux.reserve((size_t)std::max(n, 1)));
-    if (n > 0) {
-        hipLaunchKernelGGL(k_build_records, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->xyz.p, c->tmask.p, c->flags.p,
-                           c->res_id.p, c->has_res ? c->res_flags.p : nullptr, c->has_res ? c->res_prev.p : nullptr,
-                           c->has_res ? c->res_next.p : nullptr, c->sel_made ? c->sel.p : nullptr,
-                           c->sel_made ? c->plus.p : nullptr, c->has_home ? c->home.p : nullptr, c->xyzm.p, c->aux.p);
-        CHK(check_launch(c, "k_build_records"));
-    }
-    c->records_dirty = false;
-    c->atom_grid.valid = false;
-    return ARP_OK;
+RawAtoms raw_atoms(arp_ctx* c) {
+    RawAtoms r;
+    r.xyz = c->xyz.p; r.tmask = c->tmask.p; r.flags = c->flags.p; r.res_id = c->res_id.p;
+    r.res_flags = c->has_res ? c->res_flags.p : nullptr;
+    r.res_prev = c->has_res ? c->res_prev.p : nullptr;
+    r.res_next = c->has_res ? c->res_next.p : nullptr;
+    r.sel = c->sel_made ? c->sel.p : nullptr;
+    r.plus = c->sel_made ? c->plus.p : nullptr;
+    r.home = c->has_home ? c->home.p : nullptr;
+    r.rad = c->rad.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.sb = c->sb.p;
+    return r;
 }
 
-// grid over the atoms selected by (req, forb) meta masks, plus cell-sorted record copies
+// Grid over the atoms selected by the (req, forb) meta masks (or an explicit mask): three launches —
+// k_bin_atoms (records composed on the fly), scan, k_scatter_atoms (writes the cell-sorted search and
+// sift records directly).
 int build_atom_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active) {
     c->grid_all_atoms = false;
-    CHK(ensure_records(c));
     const int n = (int)c->n;
-    PtsF4 pts{c->xyzm.p};
-    if (active) CHK((build_grid<PtsF4, 1>(c, c->atom_grid, pts, n, c->lo, c->hi, radius, active, c->xyzm.p, 0, 0)));
-    else CHK((build_grid<PtsF4, 2>(c, c->atom_grid, pts, n, c->lo, c->hi, radius, nullptr, c->xyzm.p, req, forb)));
+    Grid& G = c->atom_grid;
+    make_grid_desc(G.d, c->lo, c->hi, radius);
+    G.radius = radius;
+    G.n_points = n;
+    CHK(reserve_grid(c, G, n));
     HIPCHK(c, c->s_xyzm.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->s_aux.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_rec.reserve((size_t)std::max(n, 1)));
+    const RawAtoms r = raw_atoms(c);
     {
-        Prof p(c, SLOT_GATHER);
+        Prof p(c, SLOT_BIN);
         if (n > 0) {
-            hipLaunchKernelGGL(k_gather, dim3(nblocks(n, 256)), dim3(256), 0, c->stream,
-                               c->atom_grid.start.p + c->atom_grid.d.ncell, c->atom_grid.perm.p, c->xyzm.p, c->aux.p,
-                               c->s_xyzm.p, c->s_aux.p);
-            CHK(check_launch(c, "k_gather"));
+            if (active) hipLaunchKernelGGL((k_bin_atoms<1>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, active, 0u, 0u, G.cell_of.p, G.cnt.p);
+            else hipLaunchKernelGGL((k_bin_atoms<2>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, (const uint8_t*)nullptr, req, forb, G.cell_of.p, G.cnt.p);
+            CHK(check_launch(c, "k_bin_atoms"));
         }
     }
-    c->atom_grid.n_binned = -1;  // known on the device only; fetched with the counters when needed
+    CHK(enqueue_scan(c, G));
+    {
+        Prof p(c, SLOT_SCATTER);
+        if (n > 0) {
+            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.cell_of.p, G.start.p, G.cnt.p,
+                               c->s_xyzm.p, c->s_aux.p, c->s_rec.p);
+            CHK(check_launch(c, "k_scatter_atoms"));
+        }
+    }
+    G.valid = true;
+    G.n_binned = -1;  // known on the device only (start[ncell])
     return ARP_OK;
 }
 
 // Blocks of the neighbour search: ~ARP_SEARCH_CPW cells per wave, a multiple of 8 (one per XCD).
-int search_blocks(const GridDesc& d) {
-    static const int cpw = std::max(1, env_int("ARP_SEARCH_CPW", 1));
+int search_blocks(const GridDesc& d, int cpw = 1) {
     int nb = (d.ncell + SEARCH_WAVES * cpw - 1) / (SEARCH_WAVES * cpw);
     nb = std::max(8, std::min(nb, 8192));
     return (nb + 7) & ~7;
@@ -338,9 +375,13 @@ int zero_counter(arp_ctx* c, int first, int count) {
     HIPCHK(c, hipMemsetAsync(c->d_ctr + first, 0, sizeof(u64) * (size_t)count, c->stream));
     return ARP_OK;
 }
-int read_counters(arp_ctx* c) {  // one D2H copy + the only stream sync of a pass
-    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(u64) * C_COUNT, hipMemcpyDeviceToHost, c->stream));
+int enqueue_counter_copy(arp_ctx* c) {  // D2H of the counter block into pinned memory (capturable)
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr_pinned, c->d_ctr, sizeof(u64) * C_COUNT, hipMemcpyDeviceToHost, c->stream));
+    return ARP_OK;
+}
+int collect_counters(arp_ctx* c) {  // the only stream sync of a pass
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_ctr, c->h_ctr_pinned, sizeof(u64) * C_COUNT);
     auto fold = [&](int first, int into) {
         u64 t = 0;
         for (int k = 0; k < STAT_SLOTS; ++k) t += c->h_ctr[first + k];
@@ -348,6 +389,17 @@ int read_counters(arp_ctx* c) {  // one D2H copy + the only stream sync of a pas
     };
     fold(C_STAT_CAND, C_CAND); fold(C_STAT_ACC, C_ACC); fold(C_STAT_MCAND, C_MARK_CAND); fold(C_STAT_MACC, C_MARK_ACC);
     return ARP_OK;
+}
+int read_counters(arp_ctx* c) {
+    CHK(enqueue_counter_copy(c));
+    return collect_counters(c);
+}
+void drop_graph(arp_ctx* c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr;
+    c->graph = nullptr;
+    c->gkey.valid = false;
 }
 
 void host_bbox(const float* xyz, int64_t n, double lo[3], double hi[3]) {
@@ -395,7 +447,7 @@ int enqueue_selection(arp_ctx* c, double radius) {
     if (n > 0) {
         Prof p(c, SLOT_MARK);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, (int2*)nullptr,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, env_int("ARP_ABLATE", 0), (int2*)nullptr,
                            0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
         CHK(check_launch(c, "k_search<MARK>"));
     }
@@ -435,11 +487,12 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
     CHK(build_atom_grid(c, cutoff, M_PLUS, M_HYDROGEN, nullptr));
     c->contact_cells = c->atom_grid.d.ncell;
-    if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 1024));
-    const size_t cap = c->pairs.cap;
+    if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 8192));
+    const size_t segcap = c->pairs.cap / PAIR_SEGS;   // the pair list is PAIR_SEGS segments of segcap entries
+    const size_t cap = segcap * PAIR_SEGS;
     HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
-    CHK(zero_counter(c, C_PAIRS, 1));
+    CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
     CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
     CHK(zero_counter(c, C_BINNED, 1));
     CHK(zero_counter(c, C_ERR, 1));
@@ -448,18 +501,21 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     if (c->n > 0) {
         {
             Prof p(c, SLOT_SEARCH);
-            hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0,
+            // the contact search ends with a block-level flush of its pair queues, which amortises better over
+            // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
+            static const int cpw = std::max(1, env_int("ARP_SEARCH_CPW", 3));
+            hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)cap, c->d_ctr + C_PAIRS, c->d_ctr + C_STAT_CAND, c->d_ctr + C_STAT_ACC,
+                               include_seq_adj, c->has_home ? 1 : 0, env_int("ARP_ABLATE", 0), c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
+                               c->d_ctr + C_STAT_ACC,
                                (uint8_t*)nullptr);
             CHK(check_launch(c, "k_search<CONTACTS>"));
         }
         {
             Prof p(c, SLOT_SIFT);
-            hipLaunchKernelGGL(k_sift, dim3(c->num_cu * 8), dim3(256), 0, c->stream, c->pairs.p, c->d_ctr + C_PAIRS, (u64)cap,
-                               c->s_xyzm.p, c->s_aux.p, c->rad.p, c->bond_off.p, c->bond_idx.p, c->h_off.p, c->h_xyz_d.p, c->sb.p,
-                               c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p,
-                               c->out_ct.p, (int*)(c->d_ctr + C_ERR));
+            hipLaunchKernelGGL(k_sift, dim3(c->num_cu * 8), dim3(256), 0, c->stream, c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap,
+                               c->s_rec.p, c->bond_idx.p, c->h_xyz_d.p, c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p,
+                               c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p, (int*)(c->d_ctr + C_ERR));
             CHK(check_launch(c, "k_sift"));
         }
     }
@@ -540,8 +596,12 @@ int enqueue_group_plane(arp_ctx* c) {  // I:1302-1382
 
 // After read_counters(): publish contact results; returns true when the pair buffer overflowed.
 bool finish_contacts(arp_ctx* c) {
-    const u64 np = c->h_ctr[C_PAIRS];
-    if (np > c->pairs.cap) return true;
+    const u64 segcap = c->pairs.cap / PAIR_SEGS;
+    u64 np = 0, worst = 0;
+    for (int k = 0; k < PAIR_SEGS; ++k) { np += c->h_ctr[C_SEG_PAIRS + k]; worst = std::max(worst, c->h_ctr[C_SEG_PAIRS + k]); }
+    c->h_ctr[C_PAIRS] = np;
+    c->h_ctr[C_SCRATCH0] = worst;
+    if (worst > segcap) return true;
     c->n_contacts = (int64_t)np;
     c->contacts_valid = true;
     c->stats[0] = (int64_t)c->h_ctr[C_CAND];
@@ -559,7 +619,7 @@ bool finish_bag(arp_ctx* c, Bag& b, int slot) {
     return false;
 }
 int grow_pairs(arp_ctx* c) {
-    const size_t need = (size_t)c->h_ctr[C_PAIRS];
+    const size_t need = ((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 64) * PAIR_SEGS;
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     HIPCHK(c, c->pairs.reserve(need));
     return ARP_OK;
@@ -621,6 +681,7 @@ int arp_create(int device, arp_ctx** out) {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_COUNT);
     if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(u64) * C_COUNT);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_ctr_pinned, sizeof(u64) * C_COUNT, hipHostMallocDefault);
     if (e != hipSuccess) {
         g_create_error = hipGetErrorString(e);
         delete c;
@@ -641,11 +702,13 @@ void arp_destroy(arp_ctx* c) {
     c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
-    c->xyzm.release(); c->s_xyzm.release(); c->aux.release(); c->s_aux.release();
+    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release();
     c->atom_grid.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->ring_home.release(); c->am_home.release(); c->ring_gid.release(); c->am_gid.release();
+    drop_graph(c);
+    if (c->h_ctr_pinned) (void)hipHostFree(c->h_ctr_pinned);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -660,6 +723,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     if (n < 0 || n > 0x7FFFFFF0LL) FAIL(c, ARP_E_ARG, "arp_set_atoms: n out of range");
     if (n > 0 && (!xyz || !vdw || !cov || !type_mask || !flags || !res_id)) FAIL(c, ARP_E_ARG, "arp_set_atoms: null input");
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     c->n = n;
     c->h_xyz.assign(xyz, xyz + 3 * n);
     host_bbox(xyz, n, c->lo, c->hi);
@@ -694,12 +758,15 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
     if (!c) return ARP_E_ARG;
     if (nres < 0 || (nres > 0 && (!res_flags || !prev || !next))) FAIL(c, ARP_E_ARG, "arp_set_residues: bad input");
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     c->nres = nres;
     CHK(upload(c, c->res_flags, res_flags, (size_t)nres));
     CHK(upload(c, c->res_prev, prev, (size_t)nres));
     CHK(upload(c, c->res_next, next, (size_t)nres));
     c->has_res = true;
     c->records_dirty = true;
+    c->atom_grid.valid = false;
+    c->grid_all_atoms = false;
     c->sel_made = false;
     c->contacts_valid = false;
     return ARP_OK;
@@ -708,6 +775,7 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
 int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) {
     if (!c || !bond_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     const int64_t m = bond_off[c->n];
     if (m < 0 || (m > 0 && !bond_idx)) FAIL(c, ARP_E_ARG, "arp_set_bonds: bad CSR");
     CHK(upload(c, c->bond_off, bond_off, (size_t)c->n + 1));
@@ -721,6 +789,7 @@ int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) 
 int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
     if (!c || !h_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     const int64_t m = h_off[c->n];
     if (m < 0 || (m > 0 && !h_xyz)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: bad CSR");
     CHK(upload(c, c->h_off, h_off, (size_t)c->n + 1));
@@ -734,6 +803,7 @@ int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
 int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
     if (!c || (c->n > 0 && !sb_nbr)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     std::vector<float4> sb((size_t)c->n);
     for (int64_t i = 0; i < c->n; ++i) {
         int k = sb_nbr[i];
@@ -751,6 +821,7 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
     if (!c) return ARP_E_ARG;
     if (nring < 0 || (nring > 0 && (!center || !normal || !ring_res))) FAIL(c, ARP_E_ARG, "arp_set_rings: bad input");
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     c->nring = nring;
     host_bbox_d(center, nring, c->ring_lo, c->ring_hi);
     CHK(upload(c, c->ring_c, center, (size_t)nring * 3));
@@ -768,6 +839,7 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
     if (!c) return ARP_E_ARG;
     if (namide < 0 || (namide > 0 && (!center || !normal || !amide_res))) FAIL(c, ARP_E_ARG, "arp_set_amides: bad input");
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     c->namide = namide;
     host_bbox(center, namide, c->am_lo, c->am_hi);
     CHK(upload(c, c->am_c, center, (size_t)namide * 3));
@@ -784,6 +856,7 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
 int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_id) {
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     if (is_home) { CHK(upload(c, c->home, is_home, (size_t)c->n)); c->has_home = true; }
     else c->has_home = false;
     if (global_id) {
@@ -793,6 +866,8 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
         c->has_gid = true;
     } else c->has_gid = false;
     c->records_dirty = true;
+    c->atom_grid.valid = false;   // M_HOME is part of the sorted records
+    c->grid_all_atoms = false;
     c->contacts_valid = false;
     return ARP_OK;
 }
@@ -801,6 +876,7 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
                             const int32_t* amide_gid) {
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     if (!ring_home && !ring_gid && !amide_home && !amide_gid) { c->has_group_owner = false; return ARP_OK; }
     if ((c->nring > 0 && (!ring_home || !ring_gid)) || (c->namide > 0 && (!amide_home || !amide_gid)))
         FAIL(c, ARP_E_ARG, "arp_set_group_ownership: all four arrays are required");
@@ -817,6 +893,7 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
 int arp_set_single_bond_neighbour_coords(arp_ctx* c, const float* sb_xyz, const uint8_t* sb_present) {
     if (!c || (c->n > 0 && (!sb_xyz || !sb_present))) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     std::vector<float4> sb((size_t)c->n);
     for (int64_t i = 0; i < c->n; ++i)
         sb[i] = sb_present[i] ? make_float4(sb_xyz[3 * i], sb_xyz[3 * i + 1], sb_xyz[3 * i + 2], 1.0f) : make_float4(0, 0, 0, 0);
@@ -833,6 +910,7 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
         (c->namide > 0 && (!amide_sel || !amide_plus)))
         FAIL(c, ARP_E_ARG, "arp_set_selection_state: null input");
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->input_epoch;   // invalidates a captured graph
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     CHK(upload(c, c->plus, in_plus, (size_t)c->n));
     CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));
@@ -873,7 +951,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, 0, c->pairs.p,
                            (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, (uint8_t*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
@@ -1062,7 +1140,8 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
         HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
     }
-    for (int attempt = 0;; ++attempt) {
+    // every stage enqueued back to back (no host synchronisation, no allocation once the buffers are sized)
+    auto enqueue_all = [&]() -> int {
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
@@ -1072,17 +1151,71 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         CHK(enqueue_plane_plane(c));                                                // I:346 (I:944)
         CHK(enqueue_group_group(c));                                                // I:347 (I:1214)
         CHK(enqueue_group_plane(c));                                                //       (I:1215)
-        CHK(read_counters(c));
+        return enqueue_counter_copy(c);
+    };
+    auto any_overflow = [&](bool grow) -> int {   // returns 1 when a buffer was too small (and regrows it if asked)
+        int again = 0;
+        if (finish_contacts(c)) { if (grow) CHK(grow_pairs(c)); again = 1; }
+        if (finish_bag(c, c->bag_ap, C_AP)) { if (grow) CHK(grow_bag(c, c->bag_ap, C_AP, true, false)); again = 1; }
+        if (finish_bag(c, c->bag_pp, C_PP)) { if (grow) CHK(grow_bag(c, c->bag_pp, C_PP, true, false)); again = 1; }
+        if (finish_bag(c, c->bag_gg, C_GG)) { if (grow) CHK(grow_bag(c, c->bag_gg, C_GG, false, true)); again = 1; }
+        if (finish_bag(c, c->bag_gp, C_GP)) { if (grow) CHK(grow_bag(c, c->bag_gp, C_GP, true, false)); again = 1; }
+        return again;
+    };
+    static const int use_graph = env_int("ARP_GRAPH", 1);
+    const arp_ctx::GraphKey key{cutoff, vdw_comp, expand_radius, include_sequence_adjacent, g_alloc_epoch, c->input_epoch, true};
+    auto same = [](const arp_ctx::GraphKey& a, const arp_ctx::GraphKey& b) {
+        return a.valid && b.valid && a.cutoff == b.cutoff && a.comp == b.comp && a.expand == b.expand && a.seq_adj == b.seq_adj &&
+               a.alloc_epoch == b.alloc_epoch && a.input_epoch == b.input_epoch;
+    };
+    bool done = false;
+    if (use_graph && c->graph_ok && !c->profiling) {
+        if (c->graph_exec && same(c->gkey, key)) {
+            // replay: the launch-bound chain of ~25 small kernels costs one graph launch on the host
+            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+            CHK(collect_counters(c));
+            const int ov = any_overflow(false);
+            if (ov < 0) return ov;
+            if (ov == 0) done = true;        // (an overflow cannot happen with unchanged inputs; fall through if it does)
+            else drop_graph(c);
+        } else if (same(c->last_key, key)) {
+            // second identical call: everything is sized, capture the pass
+            drop_graph(c);
+            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            int rc = ARP_OK;
+            if (ok) {
+                rc = enqueue_all();
+                hipGraph_t g = nullptr;
+                ok = (hipStreamEndCapture(c->stream, &g) == hipSuccess) && g && rc == ARP_OK && g_alloc_epoch == key.alloc_epoch;
+                if (ok) ok = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+                if (ok) { c->graph = g; c->gkey = key; }
+                else if (g) (void)hipGraphDestroy(g);
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                c->graph_ok = false;         // direct launches from now on
+                drop_graph(c);
+            } else {
+                HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+                CHK(collect_counters(c));
+                const int ov = any_overflow(false);
+                if (ov < 0) return ov;
+                if (ov == 0) done = true;
+                else drop_graph(c);
+            }
+        }
+    }
+    for (int attempt = 0; !done; ++attempt) {
+        CHK(enqueue_all());
+        CHK(collect_counters(c));
         collect_events(c);
-        bool again = false;
-        if (finish_contacts(c)) { CHK(grow_pairs(c)); again = true; }
-        if (finish_bag(c, c->bag_ap, C_AP)) { CHK(grow_bag(c, c->bag_ap, C_AP, true, false)); again = true; }
-        if (finish_bag(c, c->bag_pp, C_PP)) { CHK(grow_bag(c, c->bag_pp, C_PP, true, false)); again = true; }
-        if (finish_bag(c, c->bag_gg, C_GG)) { CHK(grow_bag(c, c->bag_gg, C_GG, false, true)); again = true; }
-        if (finish_bag(c, c->bag_gp, C_GP)) { CHK(grow_bag(c, c->bag_gp, C_GP, true, false)); again = true; }
+        const int again = any_overflow(true);
+        if (again < 0) return again;
         if (!again) break;
         if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_launch: result buffers could not be sized");
     }
+    c->last_key = key;
+    c->last_key.alloc_epoch = g_alloc_epoch;
     c->stats[5] = (int64_t)c->h_ctr[C_MARK_CAND];
     c->stats[6] = (int64_t)c->h_ctr[C_MARK_ACC];
     if (counts) {
@@ -1101,7 +1234,7 @@ int arp_get_stats(arp_ctx* c, int64_t stats[8]) {
 
 int arp_set_profiling(arp_ctx* c, int enabled) {
     if (!c) return ARP_E_ARG;
-    c->profiling = enabled != 0;
+    c->profiling = enabled != 0;   // profiled passes use direct launches bracketed by events (no graph replay)
     return ARP_OK;
 }
 

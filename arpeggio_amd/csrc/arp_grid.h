@@ -80,6 +80,46 @@ __global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, const uin
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
+// Small grids (<= 65536 cells): the whole exclusive scan in ONE 1024-thread block (one launch
+// instead of three).  Thread t owns ITEMS consecutive counters (int4 loads, kept in registers);
+// out[n] = grand total.  Both arrays must be readable/writable up to ITEMS * 1024 elements.
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in, int n, int* __restrict__ out) {
+    __shared__ int sh[1024];
+    const int base = threadIdx.x * ITEMS;
+    int v[ITEMS];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 4) {
+        const int4 q = *reinterpret_cast<const int4*>(in + base + k);
+        v[k] = (base + k < n) ? q.x : 0;
+        v[k + 1] = (base + k + 1 < n) ? q.y : 0;
+        v[k + 2] = (base + k + 2 < n) ? q.z : 0;
+        v[k + 3] = (base + k + 3 < n) ? q.w : 0;
+        sum += v[k] + v[k + 1] + v[k + 2] + v[k + 3];
+    }
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 4) {
+        int4 q;
+        q.x = run; run += v[k];
+        q.y = run; run += v[k + 1];
+        q.z = run; run += v[k + 2];
+        q.w = run; run += v[k + 3];
+        if (base + k < n) *reinterpret_cast<int4*>(out + base + k) = q;   // may spill past n inside the padded buffer
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) out[n] = sh[1023];
+}
+
 // Phase A: exclusive scan inside tiles of SCAN_TILE counters; tile totals to block_sums.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const int* __restrict__ in, int n, int* __restrict__ out,
                                                               int* __restrict__ block_sums) {

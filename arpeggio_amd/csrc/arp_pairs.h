@@ -45,31 +45,104 @@ enum {
     // statistics counters are spread over STAT_SLOTS addresses (hashed by block) so that the
     // end-of-block atomics of thousands of blocks do not serialise on one L2 line
     C_STAT_CAND = 16, C_STAT_ACC = 16 + 64, C_STAT_MCAND = 16 + 128, C_STAT_MACC = 16 + 192,
-    C_COUNT = 16 + 256
+    // the pair list is written in PAIR_SEGS segments, one queue head per XCD (blockIdx % 8): the
+    // per-block atomicAdd then runs on 8 different L2s instead of serialising on one address
+    C_SEG_PAIRS = 16 + 256,
+    C_COUNT = 16 + 256 + 8
 };
 #define STAT_SLOTS 64
+#define PAIR_SEGS 1
 typedef unsigned long long u64;
 
-// atom records: xyzm = {x, y, z, meta}; aux = {local id, residue, prev residue, next residue}
-__global__ __launch_bounds__(256) void k_build_records(int n, const float4* __restrict__ xyz, const uint16_t* __restrict__ tmask,
-                                                       const uint16_t* __restrict__ flags, const int* __restrict__ res_id,
-                                                       const uint8_t* __restrict__ res_flags, const int* __restrict__ res_prev,
-                                                       const int* __restrict__ res_next, const uint8_t* __restrict__ sel,
-                                                       const uint8_t* __restrict__ plus, const uint8_t* __restrict__ home,
-                                                       float4* __restrict__ xyzm, int4* __restrict__ aux) {
+#define M_HAS_SB (1u << 23)
+
+// raw per-atom inputs as uploaded through the C ABI (pointers may be null where noted)
+struct RawAtoms {
+    const float4* xyz;          // w unused
+    const uint16_t* tmask;
+    const uint16_t* flags;
+    const int* res_id;
+    const uint8_t* res_flags;   // null: no residue table
+    const int* res_prev;
+    const int* res_next;
+    const uint8_t* sel;         // null: nothing selected
+    const uint8_t* plus;        // null: everything in selection_plus
+    const uint8_t* home;        // null: every atom owned by this rank
+    const double2* rad;         // {vdw, cov}
+    const int* h_off;
+    const int* bond_off;
+    const float4* sb;           // single-bond neighbour xyz, w = present
+};
+
+// 64-byte (one cache line) record read by k_sift for each atom of a pair
+struct __attribute__((aligned(64))) SiftRec {
+    float4 xyzm;      // x, y, z, meta
+    double2 rad;      // vdw, cov
+    int4 csr;         // h_off, h_count, bond_off, bond_count
+    float4 sbl;       // single-bond neighbour x, y, z; w = bit pattern of the local atom id
+};
+
+// atom record: xyzm = {x, y, z, meta}; aux = {local id, residue, prev residue, next residue}
+__device__ __forceinline__ void compose_record(const RawAtoms& r, int i, float4& xyzm, int4& aux) {
+    float4 v = r.xyz[i];
+    const int res = r.res_id[i];
+    uint32_t m = (uint32_t)(r.tmask[i] & M_TMASK) | ((uint32_t)(r.flags[i] & 0x7F) << M_FLAG_SHIFT);
+    if (r.sel && r.sel[i]) m |= M_SEL;
+    if (!r.plus || r.plus[i]) m |= M_PLUS;
+    if (!r.home || r.home[i]) m |= M_HOME;
+    const uint8_t rf = r.res_flags ? r.res_flags[res] : 0;
+    if (rf & ARP_R_POLYPEPTIDE) m |= M_RES_POLY;
+    if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
+    if (r.sb[i].w != 0.0f) m |= M_HAS_SB;
+    v.w = __uint_as_float(m);
+    xyzm = v;
+    aux = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
+}
+
+// cell id + histogram of the atoms passing the filter:
+// FILTER 1: active[i] != 0;  FILTER 2: (meta & req) == req && !(meta & forb)
+template <int FILTER>
+__global__ __launch_bounds__(256) void k_bin_atoms(RawAtoms r, int n, GridDesc g, const uint8_t* __restrict__ active,
+                                                   uint32_t req, uint32_t forb, int* __restrict__ cell_of,
+                                                   int* __restrict__ cell_cnt) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 v = xyz[i];
-        int r = res_id[i];
-        uint32_t m = (uint32_t)(tmask[i] & M_TMASK) | ((uint32_t)(flags[i] & 0x7F) << M_FLAG_SHIFT);
-        if (sel && sel[i]) m |= M_SEL;
-        if (!plus || plus[i]) m |= M_PLUS;
-        if (!home || home[i]) m |= M_HOME;
-        uint8_t rf = res_flags ? res_flags[r] : 0;
-        if (rf & ARP_R_POLYPEPTIDE) m |= M_RES_POLY;
-        if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
-        v.w = __uint_as_float(m);
-        xyzm[i] = v;
-        aux[i] = make_int4(i, r, res_prev ? res_prev[r] : -1, res_next ? res_next[r] : -1);
+        float4 xyzm;
+        int4 aux;
+        compose_record(r, i, xyzm, aux);
+        const uint32_t m = __float_as_uint(xyzm.w);
+        const bool on = (FILTER == 1) ? (active[i] != 0) : (((m & req) == req) && !(m & forb));
+        int c = -1;
+        if (on) {
+            c = cell_index(g, num::d3{(double)xyzm.x, (double)xyzm.y, (double)xyzm.z});
+            atomicAdd(&cell_cnt[c], 1);
+        }
+        cell_of[i] = c;
+    }
+}
+
+// counting-sort scatter fused with the record build: every binned atom writes its cell-sorted
+// search record (xyzm + aux, 32 B) and its one-line sift record (64 B).
+__global__ __launch_bounds__(256) void k_scatter_atoms(RawAtoms r, int n, const int* __restrict__ cell_of,
+                                                       const int* __restrict__ start, int* __restrict__ cell_cnt,
+                                                       float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
+                                                       SiftRec* __restrict__ s_rec) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = cell_of[i];
+        if (c < 0) continue;
+        const int pos = start[c] + atomicSub(&cell_cnt[c], 1) - 1;
+        float4 xyzm;
+        int4 aux;
+        compose_record(r, i, xyzm, aux);
+        s_xyzm[pos] = xyzm;
+        s_aux[pos] = aux;
+        SiftRec q;
+        q.xyzm = xyzm;
+        q.rad = r.rad[i];
+        const int h0 = r.h_off[i], b0 = r.bond_off[i];
+        q.csr = make_int4(h0, r.h_off[i + 1] - h0, b0, r.bond_off[i + 1] - b0);
+        const float4 sb = r.sb[i];
+        q.sbl = make_float4(sb.x, sb.y, sb.z, __int_as_float(i));
+        s_rec[pos] = q;
     }
 }
 
@@ -91,7 +164,7 @@ template <int MODE>
 __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
-                                                               int include_seq_adj, int count_owned, int2* __restrict__ pairs,
+                                                               int include_seq_adj, int count_owned, int ablate, int2* __restrict__ pairs,
                                                                unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus) {
@@ -111,14 +184,19 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
 
     int qn = 0;
     unsigned long long n_cand = 0, n_acc = 0;
+    const float r2_lo = (float)(r2 * (1.0 - 1e-5)), r2_hi = (float)(r2 * (1.0 + 1e-5));
 
+    // output segment of this block (cap = capacity of ONE segment)
+    const int seg = (MODE == MODE_CONTACTS) ? (blockIdx.x & (PAIR_SEGS - 1)) : 0;
+    u64* const seg_ctr = ctr_pairs + seg;
+    int2* const seg_pairs = pairs + (size_t)seg * cap;
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(ctr_pairs, (unsigned long long)qn);
+        if (lane == 0) base = atomicAdd(seg_ctr, (unsigned long long)qn);
         base = __shfl(base, 0);
         for (int k = lane; k < qn; k += 64)
-            if (base + k < cap) pairs[base + k] = q[w][k];
+            if (base + k < cap) seg_pairs[base + k] = q[w][k];
         __builtin_amdgcn_wave_barrier();
         qn = 0;
     };
@@ -153,10 +231,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         const int o2 = o1 + __builtin_amdgcn_readlane(my_len, 1);
         const int o3 = o2 + __builtin_amdgcn_readlane(my_len, 2);
         const int o4 = o3 + __builtin_amdgcn_readlane(my_len, 3);
-        const int total = o4 + __builtin_amdgcn_readlane(my_len, 4);
+        const int total = (ablate & 8) ? 0 : o4 + __builtin_amdgcn_readlane(my_len, 4);
 #pragma unroll 1
         for (int hb = hs; hb < he; hb += 64) {  // home atoms, 64 at a time, one per lane
-            const int hcount = min(64, he - hb);
+            const int hcount = (ablate & 4) ? 0 : min(64, he - hb);
             const bool hvalid = lane < hcount;
             const float4 hreg = hvalid ? s_xyzm[hb + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
             int4 hauxreg = make_int4(0, 0, 0, 0);
@@ -175,27 +253,43 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                 if (MODE == MODE_PAIRS && valid) aj.x = s_aux[j].x;
                 const num::d3 pj = {(double)xj.x, (double)xj.y, (double)xj.z};
                 const uint32_t mj = __float_as_uint(xj.w);
+                // wave-uniform lane masks of this chunk: valid candidates, and those inside the home pencil
+                const unsigned long long m_valid = __ballot(valid);
+                const unsigned long long m_r0 = __ballot(valid && in_r0);
 #pragma unroll 1
                 for (int hh = 0; hh < hcount; ++hh) {
                     const int h = hb + hh;
                     // broadcast the home atom from lane hh (v_readlane, no memory traffic)
-                    const num::d3 ph = {(double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh)),
-                                        (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh)),
-                                        (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.z), hh))};
-                    // inside the home pencil only later entries of the sorted array (j > h) pair up
-                    const bool tested = valid && (!in_r0 || j > h);
-                    const bool hit = tested && (num::dist2_kd(ph, pj) <= r2);
+                    const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh));
+                    const float hy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh));
+                    const float hz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.z), hh));
+                    // inside the home pencil only later entries of the sorted array (j > h) pair up:
+                    // candidate k of range 0 is position hs + k, so lanes with kb + lane <= h - hs drop out
+                    const int t = h - hs - kb;
+                    const unsigned long long low = (t < 0) ? 0ull : (t >= 63 ? ~0ull : ((2ull << t) - 1ull));
+                    const unsigned long long m_tested = m_valid & ~(m_r0 & low);
+                    // float32 pre-filter.  |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded
+                    // squares, two rounded sums), so outside the +-1e-5 band the float32 answer IS the
+                    // float64 answer; inside the band (rare) the whole wave takes the exact float64 test.
+                    const float dxf = hx - xj.x, dyf = hy - xj.y, dzf = hz - xj.z;
+                    const float d2f = dxf * dxf + dyf * dyf + dzf * dzf;
+                    unsigned long long mhit = __ballot(d2f <= r2_lo) & m_tested;
+                    const unsigned long long m_band = __ballot(d2f > r2_lo && d2f <= r2_hi) & m_tested;
+                    if (m_band) {
+                        const num::d3 ph = {(double)hx, (double)hy, (double)hz};
+                        mhit = __ballot(num::dist2_kd(ph, pj) <= r2) & m_tested;   // Bio.PDB.kdtrees test, exact
+                    }
+                    const bool hit = (mhit >> lane) & 1ull;
                     if (count_owned) {
                         // sharded run: a boundary pair is tested on two ranks; count it for the owner of its bgn atom only
                         const int lh = __builtin_amdgcn_readlane(hauxreg.x, hh);
                         const uint32_t mh0 = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
                         const bool owned = ((lh < aj.x) ? mh0 : mj) & M_HOME;
-                        n_cand += __popcll(__ballot(tested && owned));
+                        n_cand += __popcll(__ballot(owned) & m_tested);
                     } else {
-                        n_cand += __popcll(__ballot(tested));
+                        n_cand += __popcll(m_tested);
                     }
-                    const unsigned long long mhit = __ballot(hit);
-                    if (mhit == 0) continue;
+                    if (mhit == 0 || (ablate & 2)) continue;
                     n_acc += __popcll(mhit);
                     const uint32_t mh = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
                     const int4 ah = make_int4(__builtin_amdgcn_readlane(hauxreg.x, hh), __builtin_amdgcn_readlane(hauxreg.y, hh),
@@ -231,7 +325,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                         pb = min(ah.x, aj.x);
                         pe = max(ah.x, aj.x);
                     }
-                    const unsigned long long mp = __ballot(pass);
+                    const unsigned long long mp = (ablate & 1) ? 0ull : __ballot(pass);
                     if (mp) {
                         if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
                         qn += __popcll(mp);
@@ -251,7 +345,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         int tot = 0;
         u64 tc = 0, ta = 0;
         for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
-        s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(ctr_pairs, (u64)tot) : 0;
+        s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot) : 0;
         const int slot = blockIdx.x & (STAT_SLOTS - 1);
         atomicAdd(ctr_cand + slot, tc);
         atomicAdd(ctr_acc + slot, ta);
@@ -261,7 +355,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         u64 base = s_base;
         for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
         for (int k = lane; k < qn; k += 64)
-            if (base + k < cap) pairs[base + k] = q[w][k];
+            if (base + k < cap) seg_pairs[base + k] = q[w][k];
     }
 }
 
@@ -327,33 +421,41 @@ __device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) 
 
 // One thread per accepted pair (full 64-lane occupancy for the divergent chemistry).
 __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
-                                              const float4* __restrict__ s_xyzm, const int4* __restrict__ s_aux,
-                                              const double2* __restrict__ rad, const int* __restrict__ bond_off,
-                                              const int* __restrict__ bond_idx, const int* __restrict__ h_off,
-                                              const double* __restrict__ h_xyz, const float4* __restrict__ sb,
+                                              const SiftRec* __restrict__ s_rec, const int* __restrict__ bond_idx,
+                                              const double* __restrict__ h_xyz,
                                               const int* __restrict__ gid, double comp, int* __restrict__ out_i,
                                               int* __restrict__ out_j, float* __restrict__ out_d,
                                               uint16_t* __restrict__ out_s, uint8_t* __restrict__ out_ct,
                                               int* __restrict__ err) {
-    // the pair count is read on the device: no host round trip between search and sift
-    const long long npairs = (long long)min(*npairs_ptr, cap);
+    // the segment fill counts are read on the device: no host round trip between search and sift
+    long long pre[PAIR_SEGS + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int sgm = 0; sgm < PAIR_SEGS; ++sgm) pre[sgm + 1] = pre[sgm] + (long long)min(npairs_ptr[sgm], cap);
+    const long long npairs = pre[PAIR_SEGS];
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npairs;
          p += (long long)gridDim.x * blockDim.x) {
-        const int2 pr = pairs[p];
-        const float4 vb = s_xyzm[pr.x], ve = s_xyzm[pr.y];
-        const int b = s_aux[pr.x].x, e = s_aux[pr.y].x;
+        int sgm = 0;
+#pragma unroll
+        for (int q_ = 1; q_ < PAIR_SEGS; ++q_) sgm += (p >= pre[q_]) ? 1 : 0;
+        const int2 pr = pairs[(size_t)sgm * cap + (size_t)(p - pre[sgm])];
+        const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // one 64-byte line per atom
+        const float4 vb = qb.xyzm, ve = qe.xyzm;
+        const int b = __float_as_int(qb.sbl.w), e = __float_as_int(qe.sbl.w);
+        const float4 sbb = make_float4(qb.sbl.x, qb.sbl.y, qb.sbl.z, (__float_as_uint(vb.w) & M_HAS_SB) ? 1.0f : 0.0f);
+        const float4 sbe = make_float4(qe.sbl.x, qe.sbl.y, qe.sbl.z, (__float_as_uint(ve.w) & M_HAS_SB) ? 1.0f : 0.0f);
         const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
         const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
         const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
         const bool bw = mb & M_WATER, ew = me & M_WATER;
         const int ct = contact_type(mb & M_SEL, me & M_SEL, bw, ew);  // interactions.py:715
-        const double2 rb = rad[b], re = rad[e];                         // {vdw, cov}
+        const double2 rb = qb.rad, re = qe.rad;                         // {vdw, cov}
         const double sum_cov = rb.y + re.y, sum_vdw = rb.x + re.x;      // interactions.py:717-718
         const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
         uint32_t s = 0;
         // interactions.py:748-757: end among the bonded neighbours of bgn
         bool cov = false;
-        for (int k = bond_off[b], k1 = bond_off[b + 1]; k < k1; ++k)
+        for (int k = qb.csr.z, k1 = qb.csr.z + qb.csr.w; k < k1; ++k)
             if (bond_idx[k] == e) { cov = true; break; }
         // interactions.py:756-773: float32 distance against Python floats -> float32 compare
         const double vdw_comp = sum_vdw + comp;
@@ -370,7 +472,7 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, co
         }
         // interactions.py:786: not clash (covalent pairs do get feature flags) and d <= 4.5
         if (!(s & ARP_S_CLASH) && d <= (float)4.5) {
-            const int hb0 = h_off[b], hb1 = h_off[b + 1], he0 = h_off[e], he1 = h_off[e + 1];
+            const int hb0 = qb.csr.x, hb1 = qb.csr.x + qb.csr.y, he0 = qe.csr.x, he1 = qe.csr.x + qe.csr.y;
             // interactions.py:791-819
             if (bw && d <= f_vdw_comp) {
                 if (te & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
@@ -398,21 +500,21 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, co
             }
             if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) &&
                 (te & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) {
-                weak = halogen_weak(xb, sb[b], rb.x, h_xyz, he0, he1, comp);
+                weak = halogen_weak(xb, sbb, rb.x, h_xyz, he0, he1, comp);
                 if (wp) s |= ARP_S_WEAK_POLAR;
             }
             if ((te & ARP_T_WEAK_HBOND_ACCEPTOR) && (me & M_HALOGEN) &&
                 (tb & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) {
-                weak = halogen_weak(xe, sb[e], re.x, h_xyz, hb0, hb1, comp);
+                weak = halogen_weak(xe, sbe, re.x, h_xyz, hb0, hb1, comp);
                 if (wp) s |= ARP_S_WEAK_POLAR;
             }
             if (weak) s |= ARP_S_WEAK_HBOND;
             // interactions.py:889-895
             if (d <= f_vdw_comp) {
                 if ((tb & ARP_T_XBOND_DONOR) && (te & ARP_T_XBOND_ACCEPTOR)) {
-                    if (xbond(sb[b], xb, xe, err)) s |= ARP_S_XBOND;
+                    if (xbond(sbb, xb, xe, err)) s |= ARP_S_XBOND;
                 } else if ((te & ARP_T_XBOND_DONOR) && (tb & ARP_T_XBOND_ACCEPTOR)) {
-                    if (xbond(sb[e], xe, xb, err)) s |= ARP_S_XBOND;
+                    if (xbond(sbe, xe, xb, err)) s |= ARP_S_XBOND;
                 }
             }
             // interactions.py:898-904

@@ -219,9 +219,22 @@ def test_run_launch_single_sync_path(ctx):
     _assert_planes_equal(ctx.fetch_bag('group_plane'), oc.group_plane(), ('amide', 'ring', 'ctype', 'dist'), ('dihedral', 'theta'))
     assert counts['plane_plane'] == len(epp['bgn'])
     # a second run on the same context (buffers already sized) gives the same answer
-    counts2 = ctx.run_launch(5.0, 0.1, False, 6.0)
-    assert counts2 == counts
-    _assert_contacts_equal(ctx.atom_contacts_fetch(counts2['atom_atom']), exp)
+    # the 2nd identical call captures the pass into a hipGraph, later calls replay it
+    for _ in range(3):
+        counts2 = ctx.run_launch(5.0, 0.1, False, 6.0)
+        assert counts2 == counts
+        _assert_contacts_equal(ctx.atom_contacts_fetch(counts2['atom_atom']), exp)
+    # a new selection re-uses the captured graph (same buffers, new mask contents)
+    sel2 = np.zeros(pc.n_atoms, np.uint8)
+    sel2[(pc.res_id % 7) == 1] = 1
+    ctx.set_selection(sel2)
+    c3 = ctx.run_launch(5.0, 0.1, False, 6.0)
+    oc.make_selection(sel2)
+    _assert_contacts_equal(ctx.atom_contacts_fetch(c3['atom_atom']), oc.atom_contacts())
+    _assert_planes_equal(ctx.fetch_bag('atom_plane'), oc.atom_plane(), ('atom', 'ring', 'mask', 'ctype', 'dist'), ('theta',))
+    # different parameters invalidate it
+    c4 = ctx.run_launch(4.0, 0.2, True, 6.0)
+    _assert_contacts_equal(ctx.atom_contacts_fetch(c4['atom_atom']), oc.atom_contacts(4.0, 0.2, True))
 
 
 def test_known_answer_packs_on_gpu(ctx):
