@@ -92,6 +92,50 @@ __device__ __forceinline__ double get_angle_mixed(f3 a, f3 b, d3 c) {
     return ang;
 }
 
+// ---- decision shortcuts ---------------------------------------------------------------------------
+// The reference decides "angle >= a_min" via normalise / dot / acos (2 sqrt, 6 divisions and an acos
+// per hydrogen).  cosA = (v1.v2) / sqrt(|v1|^2 |v2|^2) is the same quantity up to ~1e-15 (1e-7 when one
+// vector went through float32, utils.py:151), so away from the threshold by a margin delta the decision
+// can be taken on squared quantities alone; the exact sequence above runs only inside the margin, when a
+// vector has zero length (NaN -> pi, utils.py:741-743) or when |cosA| is within 1e-12 of 1 (rounding can
+// push the reference's cosine past 1, which also ends in the NaN -> pi substitution).
+__device__ __forceinline__ bool cos_le(double dot, double q, double t) {  // cosA <= t ?
+    return (t >= 0) ? (dot <= 0 || dot * dot <= t * t * q) : (dot <= 0 && dot * dot >= t * t * q);
+}
+__device__ __forceinline__ bool cos_ge(double dot, double q, double t) {  // cosA >= t ?
+    return (t >= 0) ? (dot >= 0 && dot * dot >= t * t * q) : (dot >= 0 || dot * dot <= t * t * q);
+}
+// 1: angle(a,b,c) >= a_min surely; 0: surely not; -1: run the exact test.  c_min = cos(a_min).
+__device__ __forceinline__ int angle_ge_fast(d3 a, d3 b, d3 c, double c_min, double delta) {
+    const d3 v1 = sub(a, b), v2 = sub(c, b);
+    const double dot_ = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    const double q = (v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) * (v2.x * v2.x + v2.y * v2.y + v2.z * v2.z);
+    if (!(q > 0.0) || !(dot_ * dot_ < (1.0 - 2e-12) * q)) return -1;
+    if (cos_le(dot_, q, c_min - delta)) return 1;
+    if (cos_ge(dot_, q, c_min + delta)) return 0;
+    return -1;
+}
+// 1: a_lo <= angle(a,b,c) <= a_hi surely; 0: surely not; -1: exact.  c_lo = cos(a_lo) > c_hi = cos(a_hi).
+__device__ __forceinline__ int angle_in_fast(d3 a, d3 b, d3 c, double c_lo, double c_hi, double delta) {
+    const d3 v1 = sub(a, b), v2 = sub(c, b);
+    const double dot_ = v1.x * v2.x + v1.y * v2.y + v1.z * v2.z;
+    const double q = (v1.x * v1.x + v1.y * v1.y + v1.z * v1.z) * (v2.x * v2.x + v2.y * v2.y + v2.z * v2.z);
+    if (!(q > 0.0) || !(dot_ * dot_ < (1.0 - 2e-12) * q)) return -1;
+    if (cos_le(dot_, q, c_lo - delta) && cos_ge(dot_, q, c_hi + delta)) return 1;
+    if (cos_ge(dot_, q, c_lo + delta) || cos_le(dot_, q, c_hi - delta)) return 0;
+    return -1;
+}
+// 1: sqrt(s) <= thr surely (s = exact sum of squares, thr2 = thr * thr); 0: surely not; -1: take the sqrt
+__device__ __forceinline__ int dist_le_fast(double s, double thr2) {
+    if (s <= thr2 * (1.0 - 1e-14)) return 1;
+    if (s >= thr2 * (1.0 + 1e-14)) return 0;
+    return -1;
+}
+#define ARP_COS_1_57 0.0007963267107332633
+#define ARP_COS_2_27 (-0.6436084187135406)
+#define ARP_COS_0_52 0.8678191796776499
+#define ARP_COS_2_62 (-0.8670267214458024)
+
 // degrees + "signed" folding, utils.py:656-660 / 689-693, then abs() at the call site
 __device__ __forceinline__ double fold_deg(double rad) {
     if (rad > ARP_PI / 2) rad = rad - ARP_PI;

@@ -362,17 +362,24 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
 // ---- per-pair SIFt --------------------------------------------------------------------
 __device__ __forceinline__ num::f3 xyz_of(float4 v) { return {v.x, v.y, v.z}; }
 
-// utils.is_hbond (utils.py:73-93, angle_min 1.57) / is_weak_hbond (utils.py:96-116, 2.27)
+// utils.is_hbond (utils.py:73-93, angle_min 1.57) / is_weak_hbond (utils.py:96-116, 2.27).
+// cos_min = cos(angle_min).  Decisions away from a threshold use the squared-quantity shortcuts of
+// arp_numerics.h; inside the safety margins the reference's exact operation sequence decides.
 __device__ __forceinline__ bool hbond_like(num::f3 donor, const double* __restrict__ hx, int h0, int h1, num::f3 acc,
-                                           double acc_vdw, double comp, double angle_min) {
+                                           double acc_vdw, double comp, double angle_min, double cos_min) {
     const num::d3 d = num::to_d3(donor), a = num::to_d3(acc);
     const double thr = 1.2 + acc_vdw + comp;  // config.VDW_RADII['H'] + vdw + comp
+    const double thr2 = thr * thr;
     for (int k = h0; k < h1; ++k) {
         const num::d3 h = {hx[3 * (size_t)k], hx[3 * (size_t)k + 1], hx[3 * (size_t)k + 2]};
-        const double h_dist = num::norm(num::sub(h, a));
-        if (h_dist <= thr) {
-            if (num::get_angle(d, h, a) >= angle_min) return true;
-        }
+        const num::d3 v = num::sub(h, a);
+        const double s = num::dot(v, v);                       // np.linalg.norm's sum of squares (FMA chain)
+        int near = num::dist_le_fast(s, thr2);
+        if (near < 0) near = (sqrt(s) <= thr) ? 1 : 0;         // h_dist <= thr, exact
+        if (!near) continue;
+        int ok = num::angle_ge_fast(d, h, a, cos_min, 1e-12);
+        if (ok < 0) ok = (num::get_angle(d, h, a) >= angle_min) ? 1 : 0;
+        if (ok) return true;
     }
     return false;
 }
@@ -384,13 +391,21 @@ __device__ __forceinline__ bool halogen_weak(num::f3 hal, float4 sbh, double hal
     const num::d3 hd = num::to_d3(hal);
     const num::f3 nbr = {sbh.x, sbh.y, sbh.z};
     const double thr = 1.2 + hal_vdw + comp;
+    const double thr2 = thr * thr;
     for (int k = h0; k < h1; ++k) {
         const num::d3 h = {hx[3 * (size_t)k], hx[3 * (size_t)k + 1], hx[3 * (size_t)k + 2]};
-        const double h_dist = num::norm(num::sub(hd, h));
-        if (h_dist <= thr) {
+        const num::d3 v = num::sub(hd, h);
+        const double s = num::dot(v, v);
+        int near = num::dist_le_fast(s, thr2);
+        if (near < 0) near = (sqrt(s) <= thr) ? 1 : 0;
+        if (!near) continue;
+        // the reference normalises (nbr - hal) in float32 (utils.py:151): 1e-5 covers that rounding
+        int ok = num::angle_in_fast(num::to_d3(nbr), hd, h, ARP_COS_0_52, ARP_COS_2_62, 1e-5);
+        if (ok < 0) {
             const double ang = num::get_angle_mixed(nbr, hal, h);
-            if (0.52 <= ang && ang <= 2.62) return true;
+            ok = (0.52 <= ang && ang <= 2.62) ? 1 : 0;
         }
+        if (ok) return true;
     }
     return false;
 }
@@ -480,10 +495,10 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, co
                 if (tb & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
             } else {
                 if ((tb & ARP_T_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) {
-                    if (hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 1.57)) s |= ARP_S_HBOND;
+                    if (hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 1.57, ARP_COS_1_57)) s |= ARP_S_HBOND;
                     if (d <= (float)3.5) s |= ARP_S_POLAR;
                 } else if ((te & ARP_T_HBOND_DONOR) && (tb & ARP_T_HBOND_ACCEPTOR)) {
-                    if (hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 1.57)) s |= ARP_S_HBOND;
+                    if (hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 1.57, ARP_COS_1_57)) s |= ARP_S_HBOND;
                     if (d <= (float)3.5) s |= ARP_S_POLAR;
                 }
             }
@@ -491,11 +506,11 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, co
             bool weak = false;
             const bool wp = d <= (float)3.5;
             if ((tb & ARP_T_HBOND_ACCEPTOR) && (te & ARP_T_WEAK_HBOND_DONOR)) {
-                weak = hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 2.27);
+                weak = hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 2.27, ARP_COS_2_27);
                 if (wp) s |= ARP_S_WEAK_POLAR;
             }
             if ((tb & ARP_T_WEAK_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) {
-                weak = hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 2.27);
+                weak = hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 2.27, ARP_COS_2_27);
                 if (wp) s |= ARP_S_WEAK_POLAR;
             }
             if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) &&
