@@ -135,14 +135,16 @@ __global__ __launch_bounds__(256) void k_scatter_atoms(RawAtoms r, int n, const 
         compose_record(r, i, xyzm, aux);
         s_xyzm[pos] = xyzm;
         s_aux[pos] = aux;
-        SiftRec q;
-        q.xyzm = xyzm;
-        q.rad = r.rad[i];
-        const int h0 = r.h_off[i], b0 = r.bond_off[i];
-        q.csr = make_int4(h0, r.h_off[i + 1] - h0, b0, r.bond_off[i + 1] - b0);
-        const float4 sb = r.sb[i];
-        q.sbl = make_float4(sb.x, sb.y, sb.z, __int_as_float(i));
-        s_rec[pos] = q;
+        if (s_rec) {   // the contact grid also carries the one-line sift record
+            SiftRec q;
+            q.xyzm = xyzm;
+            q.rad = r.rad[i];
+            const int h0 = r.h_off[i], b0 = r.bond_off[i];
+            q.csr = make_int4(h0, r.h_off[i + 1] - h0, b0, r.bond_off[i + 1] - b0);
+            const float4 sb = r.sb[i];
+            q.sbl = make_float4(sb.x, sb.y, sb.z, __int_as_float(i));
+            s_rec[pos] = q;
+        }
     }
 }
 
