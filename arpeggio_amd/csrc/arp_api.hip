@@ -260,6 +260,8 @@ int enqueue_scan(arp_ctx* c, Grid& G) {
         hipLaunchKernelGGL((k_scan_small<4>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
     } else if (ncell <= 16384) {
         hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+    } else if (ncell <= 32768) {
+        hipLaunchKernelGGL((k_scan_small<32>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
     } else if (ncell <= 65536) {
         hipLaunchKernelGGL((k_scan_small<64>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
     } else {

@@ -51,7 +51,7 @@ enum {
     C_COUNT = 16 + 256 + 8
 };
 #define STAT_SLOTS 64
-#define PAIR_SEGS 1
+#define PAIR_SEGS 8
 typedef unsigned long long u64;
 
 #define M_HAS_SB (1u << 23)
@@ -444,18 +444,20 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, co
                                               int* __restrict__ out_j, float* __restrict__ out_d,
                                               uint16_t* __restrict__ out_s, uint8_t* __restrict__ out_ct,
                                               int* __restrict__ err) {
-    // the segment fill counts are read on the device: no host round trip between search and sift
-    long long pre[PAIR_SEGS + 1];
-    pre[0] = 0;
+    // The segment fill counts are read on the device: no host round trip between search and sift.
+    // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
+    // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
+    const int sgm = blockIdx.x & (PAIR_SEGS - 1);
+    long long out_base = 0;
 #pragma unroll
-    for (int sgm = 0; sgm < PAIR_SEGS; ++sgm) pre[sgm + 1] = pre[sgm] + (long long)min(npairs_ptr[sgm], cap);
-    const long long npairs = pre[PAIR_SEGS];
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npairs;
-         p += (long long)gridDim.x * blockDim.x) {
-        int sgm = 0;
-#pragma unroll
-        for (int q_ = 1; q_ < PAIR_SEGS; ++q_) sgm += (p >= pre[q_]) ? 1 : 0;
-        const int2 pr = pairs[(size_t)sgm * cap + (size_t)(p - pre[sgm])];
+    for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
+        if (q_ < sgm) out_base += (long long)min(npairs_ptr[q_], cap);
+    const long long nseg = (long long)min(npairs_ptr[sgm], cap);
+    const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
+    const long long stride = (long long)(gridDim.x / PAIR_SEGS) * blockDim.x;
+    for (long long ps = (long long)(blockIdx.x / PAIR_SEGS) * blockDim.x + threadIdx.x; ps < nseg; ps += stride) {
+        const long long p = out_base + ps;
+        const int2 pr = seg_pairs[ps];
         const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // one 64-byte line per atom
         const float4 vb = qb.xyzm, ve = qe.xyzm;
         const int b = __float_as_int(qb.sbl.w), e = __float_as_int(qe.sbl.w);

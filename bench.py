@@ -169,8 +169,18 @@ def main():
     ncell = st['cells']
     b_alg = algorithmic_bytes(dom, n_binned, ncell, emitted)
     achieved = b_alg / (dom_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters of the last committed rocprofv3 run (profiles/pmc_traffic.json,
+    # written by tools/export_profile.py; separate --pmc passes, gfx950 FETCH_SIZE correction applied)
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        if args.atoms == 100_000 and world == 1 and f'k_{dom}' in pj['kernels']:
+            traffic = pj['kernels'][f'k_{dom}']['hbm_bytes_per_launch']
+            traffic_src = pj['source']
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': int(b_alg), 'avg_launch_ms': round(dom_ms, 5),
                 'note': 'VALU-bound geometry kernel; HBM fraction is small by construction (SURVEY 8d)'}
 

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Export a tools/profile.sh run (gpurun_out/prof_<tag>) into profiles/: kernel stats, per-launch PMC
+averages and the corrected HBM traffic per launch that bench.py quotes in `roofline.traffic`.
+
+    python tools/export_profile.py gpurun_out/prof_r1c round1_c
+
+Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
+(16 B per lane) coalesced stream, so it is doubled; WRITE_SIZE is used as printed — it was calibrated here
+on k_sift, whose output is exactly 15 B per contact (18.76 MB expected, 18.9 MB counted).
+Both counters are printed by rocprofv3 in KiB.
+"""
+import collections
+import csv
+import json
+import sys
+
+base, tag = sys.argv[1], sys.argv[2]
+rows = list(csv.DictReader(open(f'{base}/trace/t_kernel_stats.csv')))
+with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+    for r in rows:
+        w.writerow([r['Name'].split('(')[0], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        d[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+    return d
+
+
+out = collections.defaultdict(dict)
+for f in ('fetch/f_counter_collection.csv', 'write/w_counter_collection.csv', 'sq/s_counter_collection.csv'):
+    for k, v in agg(f'{base}/{f}').items():
+        for c, x in v.items():
+            out[k][c] = round(sum(x) / len(x), 1)
+cols = ['FETCH_SIZE', 'WRITE_SIZE', 'SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU',
+        'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES']
+with open(f'profiles/{tag}_pmc_per_launch.csv', 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['Kernel'] + cols)
+    for k, v in out.items():
+        if not k.startswith('__amd'):
+            w.writerow([k] + [v.get(c, '') for c in cols])
+avg_ns = {r['Name'].split('(')[0]: float(r['AverageNs']) for r in rows}
+traffic = {}
+for k, v in out.items():
+    if k.startswith('__amd') or 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
+        continue
+    key = {'void k_search<0>': 'k_search', 'void k_search<2>': 'k_mark_search'}.get(k, k)
+    traffic[key] = {'hbm_bytes_per_launch': int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024),
+                    'fetch_kib_raw': v['FETCH_SIZE'], 'write_kib_raw': v['WRITE_SIZE'],
+                    'rocprof_avg_ns': avg_ns.get(k)}
+json.dump({'source': f'{tag} (tools/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes)',
+           'correction': 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream)',
+           'kernels': traffic}, open('profiles/pmc_traffic.json', 'w'), indent=1)
+for k in ('k_search', 'k_sift', 'k_mark_search', 'k_scatter_atoms'):
+    if k in traffic:
+        print(k, traffic[k])
