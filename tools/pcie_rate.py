@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""End-to-end (PCIe-inclusive) time per structure on config 3: upload + run + download.  GPU box only."""
+import sys
+import time
+
+sys.path.insert(0, '.')
+import numpy as np
+from arpeggio_amd import synth, _capi
+
+pc = synth.config3(100_000, seed=3)
+ctx = _capi.Context(0)
+ts = {'upload': [], 'run': [], 'download': []}
+for it in range(8):
+    t0 = time.perf_counter(); ctx.set_complex(pc); t1 = time.perf_counter()
+    counts = ctx.run_launch(); t2 = time.perf_counter()
+    out = ctx.atom_contacts_fetch(counts['atom_atom'], sort=False)
+    for b in ('plane_plane', 'atom_plane', 'group_group', 'group_plane'):
+        ctx.fetch_bag(b)
+    t3 = time.perf_counter()
+    if it >= 2:
+        ts['upload'].append(t1 - t0); ts['run'].append(t2 - t1); ts['download'].append(t3 - t2)
+med = {k: float(np.median(v)) * 1e3 for k, v in ts.items()}
+cand = ctx.stats()['candidates']
+tot = sum(med.values())
+print({k: round(v, 3) for k, v in med.items()}, 'total_ms', round(tot, 3), 'pairs/s', f'{cand / (tot * 1e-3):.3e}',
+      'upload_MB', round(sum(getattr(pc, k).nbytes for k in pc._ARRAYS[:21]) / 1e6, 1), 'download_MB', round(15 * len(out['i']) / 1e6, 1))
