@@ -253,22 +253,23 @@ void make_grid_desc(GridDesc& d, const double lo[3], const double hi[3], double 
 }
 
 // exclusive scan of the cell histogram: one launch for small grids, three-phase otherwise
-int enqueue_scan(arp_ctx* c, Grid& G) {
+int enqueue_scan(arp_ctx* c, Grid& G, u64* total_out = nullptr) {
     const int ncell = G.d.ncell;
     Prof p(c, SLOT_SCAN);
     if (ncell <= 4096) {
-        hipLaunchKernelGGL((k_scan_small<4>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+        hipLaunchKernelGGL((k_scan_small<4>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
     } else if (ncell <= 16384) {
-        hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+        hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
     } else if (ncell <= 32768) {
-        hipLaunchKernelGGL((k_scan_small<32>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+        hipLaunchKernelGGL((k_scan_small<32>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
     } else if (ncell <= 65536) {
-        hipLaunchKernelGGL((k_scan_small<64>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p);
+        hipLaunchKernelGGL((k_scan_small<64>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
     } else {
         const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
         hipLaunchKernelGGL(k_scan_local, dim3(nb_scan), dim3(SCAN_THREADS), 0, c->stream, G.cnt.p, ncell, G.start.p, G.sums.p);
         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, G.sums.p, nb_scan);
         hipLaunchKernelGGL(k_scan_add, dim3((ncell + 1 + 255) / 256), dim3(256), 0, c->stream, G.start.p, ncell, G.sums.p, nb_scan);
+        if (total_out) HIPCHK(c, hipMemcpyAsync(total_out, G.start.p + ncell, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     }
     return check_launch(c, "k_scan");
 }
@@ -339,7 +340,7 @@ RawAtoms raw_atoms(arp_ctx* c) {
 // k_bin_atoms (records composed on the fly), scan, k_scatter_atoms (writes the cell-sorted search and
 // sift records directly).
 int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, DevBuf<SiftRec>* srec, double radius,
-                    uint32_t req, uint32_t forb, const uint8_t* active) {
+                    uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr, uint8_t* plus_init = nullptr) {
     const int n = (int)c->n;
     make_grid_desc(G.d, c->lo, c->hi, radius);
     G.radius = radius;
@@ -352,12 +353,12 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
     {
         Prof p(c, SLOT_BIN);
         if (n > 0) {
-            if (active) hipLaunchKernelGGL((k_bin_atoms<1>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, active, 0u, 0u, G.cell_of.p, G.cnt.p);
-            else hipLaunchKernelGGL((k_bin_atoms<2>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, (const uint8_t*)nullptr, req, forb, G.cell_of.p, G.cnt.p);
+            if (active) hipLaunchKernelGGL((k_bin_atoms<1>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, active, 0u, 0u, G.cell_of.p, G.cnt.p, plus_init);
+            else hipLaunchKernelGGL((k_bin_atoms<2>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, (const uint8_t*)nullptr, req, forb, G.cell_of.p, G.cnt.p, plus_init);
             CHK(check_launch(c, "k_bin_atoms"));
         }
     }
-    CHK(enqueue_scan(c, G));
+    CHK(enqueue_scan(c, G, total_out));
     {
         Prof p(c, SLOT_SCATTER);
         if (n > 0) {
@@ -370,11 +371,12 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
     G.n_binned = -1;  // known on the device only (start[ncell])
     return ARP_OK;
 }
-int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active) {
-    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active);
+int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr) {
+    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out);
 }
-int build_all_grid(arp_ctx* c, double radius) {   // every atom (hydrogens included), used by the expansion and atom-plane
-    CHK(build_atom_grid(c, c->all_grid, c->a_xyzm, c->a_aux, nullptr, radius, 0, 0, nullptr));
+// every atom (hydrogens included), used by the expansion and atom-plane; plus_init: also start selection_plus
+int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr) {
+    CHK(build_atom_grid(c, c->all_grid, c->a_xyzm, c->a_aux, nullptr, radius, 0, 0, nullptr, nullptr, plus_init));
     c->all_grid_current = true;
     return ARP_OK;
 }
@@ -450,15 +452,14 @@ int ensure_amide_grid(arp_ctx* c) {
 
 // ---- enqueue-only building blocks (no host synchronisation) -----------------------------------
 
-// _make_selection (I:1384-1451) from the selection mask already in c->sel
-int enqueue_selection(arp_ctx* c, double radius) {
+// _make_selection, part 1 (I:1384-1424): selection_plus from the selection mask already in c->sel
+int enqueue_expansion(arp_ctx* c, double radius) {
     const int n = (int)c->n;
     HIPCHK(c, c->plus.reserve((size_t)std::max(n, 1)));
-    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->plus.p, c->sel.p, (size_t)n, hipMemcpyDeviceToDevice, c->stream));  // I:1407
-    c->sel_made = true;
+    c->sel_made = true;   // (I:1407 selection_plus = selection is written by the binning kernel below)
     c->records_dirty = true;
     // I:1420-1424: search_all(6.0) over ALL atoms (hydrogens included)
-    CHK(build_all_grid(c, radius));
+    CHK(build_all_grid(c, radius, c->plus.p));
     CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
     if (n > 0) {
         Prof p(c, SLOT_MARK);
@@ -467,27 +468,34 @@ int enqueue_selection(arp_ctx* c, double radius) {
                            0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
         CHK(check_launch(c, "k_search<MARK>"));
     }
-    // I:1413-1437 residue, ring and amide sets
-    const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
-    HIPCHK(c, c->res_sel.reserve(2 * nres));   // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
-    uint8_t* res_sel = c->res_sel.p;
-    uint8_t* res_plus = c->res_sel.p + nres;
-    HIPCHK(c, hipMemsetAsync(res_sel, 0, 2 * nres, c->stream));
-    if (n > 0)
-        hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
-                           res_sel, res_plus);
-    if (c->nring > 0)
-        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->nring, 256)), dim3(256), 0, c->stream, (int)c->nring, c->ring_res.p,
-                           res_sel, res_plus, c->ring_sel.p, c->ring_plus.p);
-    if (c->namide > 0)
-        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->namide, 256)), dim3(256), 0, c->stream, (int)c->namide, c->am_res.p,
-                           res_sel, res_plus, c->am_sel.p, c->am_plus.p);
-    CHK(check_launch(c, "selection masks"));
     c->records_dirty = true;   // M_PLUS changed; the contact grid composes fresh records
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
     c->contacts_valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
     return ARP_OK;
+}
+
+// I:1413-1437: residue, ring and amide sets of the selection and of selection_plus.  Only the ring / amide
+// kernels consume them, so arp_run_launch puts this stage on their stream.
+int enqueue_selection_sets(arp_ctx* c, hipStream_t st) {
+    const int n = (int)c->n;
+    const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+    HIPCHK(c, c->res_sel.reserve(2 * nres));   // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
+    uint8_t* res_sel = c->res_sel.p;
+    uint8_t* res_plus = c->res_sel.p + nres;
+    HIPCHK(c, hipMemsetAsync(res_sel, 0, 2 * nres, st));
+    if (n > 0)
+        hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, st, n, c->res_id.p, c->sel.p, c->plus.p,
+                           res_sel, res_plus);
+    if (c->nring + c->namide > 0)
+        hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, st, (int)c->nring, (int)c->namide,
+                           c->ring_res.p, c->am_res.p, res_sel, res_plus, c->ring_sel.p, c->ring_plus.p, c->am_sel.p, c->am_plus.p);
+    return check_launch(c, "selection sets");
+}
+
+int enqueue_selection(arp_ctx* c, double radius) {   // the whole _make_selection on the main stream
+    CHK(enqueue_expansion(c, radius));
+    return enqueue_selection_sets(c, c->stream);
 }
 
 int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 with no selectors)
@@ -501,7 +509,8 @@ int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 
 // _calculate_atom_contacts (I:693-936): bin + sort + search + sift with the current capacities
 int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq_adj) {
     // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
-    CHK(build_contact_grid(c, cutoff, M_PLUS, M_HYDROGEN, nullptr));
+    if (!c->ctr_clean) CHK(zero_counter(c, C_BINNED, 1));
+    CHK(build_contact_grid(c, cutoff, M_PLUS, M_HYDROGEN, nullptr, c->d_ctr + C_BINNED));
     c->contact_cells = c->atom_grid.d.ncell;
     if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 8192));
     const size_t segcap = c->pairs.cap / PAIR_SEGS;   // the pair list is PAIR_SEGS segments of segcap entries
@@ -510,10 +519,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
     CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
     CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
-    CHK(zero_counter(c, C_BINNED, 1));
     CHK(zero_counter(c, C_ERR, 1));
-    HIPCHK(c, hipMemcpyAsync(c->d_ctr + C_BINNED, c->atom_grid.start.p + c->atom_grid.d.ncell, sizeof(int),
-                             hipMemcpyDeviceToDevice, c->stream));
     if (c->n > 0) {
         {
             Prof p(c, SLOT_SEARCH);
@@ -1166,14 +1172,15 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
-        CHK(enqueue_selection(c, expand_radius));                                   // I:342
+        CHK(enqueue_expansion(c, expand_radius));                                   // I:342 (I:1384-1424)
         // ring grids are built (once) on the main stream before the fork
         if (c->nring > 0) CHK(ensure_ring_grid(c));
         if (c->namide > 0) CHK(ensure_amide_grid(c));
-        // fork: the four small ring/amide kernels only need the selection sets and the 6 A grid; they run on
-        // stream2 underneath the contact pipeline (grid build + search + sift) of the main stream
+        // fork: the residue/ring/amide sets and the four small ring/amide kernels only need selection_plus and
+        // the 6 A grid; they run on stream2 underneath the contact pipeline (grid build + search + sift)
         HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
+        CHK(enqueue_selection_sets(c, c->stream2));                                 // I:1413-1437
         CHK(enqueue_atom_plane(c, c->stream2));                                     // I:346 (I:945), reuses the 6 A grid
         CHK(enqueue_plane_plane(c, c->stream2));                                    // I:346 (I:944)
         CHK(enqueue_group_group(c, c->stream2));                                    // I:347 (I:1214)

@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, const uin
 // instead of three).  Thread t owns ITEMS consecutive counters (int4 loads, kept in registers);
 // out[n] = grand total.  Both arrays must be readable/writable up to ITEMS * 1024 elements.
 template <int ITEMS>
-__global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in, int n, int* __restrict__ out) {
-    __shared__ int sh[1024];
+__global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in, int n, int* __restrict__ out,
+                                                     unsigned long long* __restrict__ total_out) {
+    __shared__ int sh[32];
     const int base = threadIdx.x * ITEMS;
     int v[ITEMS];
     int sum = 0;
@@ -98,15 +99,29 @@ __global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in,
         v[k + 3] = (base + k + 3 < n) ? q.w : 0;
         sum += v[k] + v[k + 1] + v[k + 2] + v[k + 3];
     }
-    sh[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
+    // inclusive scan of the 1024 thread sums: shuffles inside each wavefront (no barrier), then the 16
+    // wave totals through LDS (two barriers in all)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
     }
-    int run = sh[threadIdx.x] - sum;
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        int w_incl = (lane < 16) ? sh[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int t = __shfl_up(w_incl, off);
+            if (lane >= off) w_incl += t;
+        }
+        if (lane < 16) sh[16 + lane] = w_incl;   // inclusive totals of waves 0..lane
+    }
+    __syncthreads();
+    const int wave_base = (wv == 0) ? 0 : sh[16 + wv - 1];
+    int run = wave_base + incl - sum;
 #pragma unroll
     for (int k = 0; k < ITEMS; k += 4) {
         int4 q;
@@ -116,8 +131,10 @@ __global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in,
         q.w = run; run += v[k + 3];
         if (base + k < n) *reinterpret_cast<int4*>(out + base + k) = q;   // may spill past n inside the padded buffer
     }
-    __syncthreads();
-    if (threadIdx.x == 1023) out[n] = sh[1023];
+    if (threadIdx.x == 1023) {
+        out[n] = sh[16 + 15];
+        if (total_out) *total_out = (unsigned long long)sh[16 + 15];   // number of binned points, for the host statistics
+    }
 }
 
 // Phase A: exclusive scan inside tiles of SCAN_TILE counters; tile totals to block_sums.

@@ -104,11 +104,12 @@ __device__ __forceinline__ void compose_record(const RawAtoms& r, int i, float4&
 template <int FILTER>
 __global__ __launch_bounds__(256) void k_bin_atoms(RawAtoms r, int n, GridDesc g, const uint8_t* __restrict__ active,
                                                    uint32_t req, uint32_t forb, int* __restrict__ cell_of,
-                                                   int* __restrict__ cell_cnt) {
+                                                   int* __restrict__ cell_cnt, uint8_t* __restrict__ plus_init) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 xyzm;
         int4 aux;
         compose_record(r, i, xyzm, aux);
+        if (plus_init) plus_init[i] = r.sel[i];   // I:1407: selection_plus starts as the selection
         const uint32_t m = __float_as_uint(xyzm.w);
         const bool on = (FILTER == 1) ? (active[i] != 0) : (((m & req) == req) && !(m & forb));
         int c = -1;
@@ -567,12 +568,19 @@ __global__ __launch_bounds__(256) void k_res_mark(int n, const int* __restrict__
         if (plus[i]) res_plus[res_id[i]] = 1;
     }
 }
-__global__ __launch_bounds__(256) void k_group_mask(int m, const int* __restrict__ grp_res, const uint8_t* __restrict__ res_sel,
-                                                    const uint8_t* __restrict__ res_plus, uint8_t* __restrict__ g_sel,
-                                                    uint8_t* __restrict__ g_plus) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        int r = grp_res[i];
-        g_sel[i] = (r >= 0 && res_sel[r]) ? 1 : 0;    // a ring whose residue is None never qualifies
-        g_plus[i] = (r >= 0 && res_plus[r]) ? 1 : 0;
+// rings [0, nring) and amides [nring, nring + namide) in one launch
+__global__ __launch_bounds__(256) void k_group_mask(int nring, int namide, const int* __restrict__ ring_res,
+                                                    const int* __restrict__ amide_res, const uint8_t* __restrict__ res_sel,
+                                                    const uint8_t* __restrict__ res_plus, uint8_t* __restrict__ ring_sel,
+                                                    uint8_t* __restrict__ ring_plus, uint8_t* __restrict__ amide_sel,
+                                                    uint8_t* __restrict__ amide_plus) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nring + namide; i += gridDim.x * blockDim.x) {
+        const bool ring = i < nring;
+        const int k = ring ? i : i - nring;
+        const int r = ring ? ring_res[k] : amide_res[k];
+        const uint8_t s_ = (r >= 0 && res_sel[r]) ? 1 : 0;    // a ring whose residue is None never qualifies
+        const uint8_t p_ = (r >= 0 && res_plus[r]) ? 1 : 0;
+        if (ring) { ring_sel[k] = s_; ring_plus[k] = p_; }
+        else { amide_sel[k] = s_; amide_plus[k] = p_; }
     }
 }
