@@ -27,7 +27,7 @@ SYMBOLS = (
     'arp_set_selection', 'arp_run_launch', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
-    'arp_set_selection_state',
+    'arp_set_selection_state', 'arp_atom_accumulators',
 )
 
 _lib = None
@@ -69,6 +69,7 @@ def load():
     L.arp_group_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_set_ownership.argtypes = [vp, vp, vp]
     L.arp_set_selection.argtypes = [vp, vp]
+    L.arp_atom_accumulators.argtypes = [vp, vp, vp]
     L.arp_set_group_ownership.argtypes = [vp, vp, vp, vp, vp]
     L.arp_set_single_bond_neighbour_coords.argtypes = [vp, vp, vp]
     L.arp_set_selection_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -248,6 +249,13 @@ class Context:
         out = self.atom_contacts_fetch(n, sort=sort)
         out['stats'] = self.stats()
         return out
+
+    def atom_accumulators(self):
+        """Per-atom sift masks (n,4) and hbond/polar counters (n,8) of the last contact launch."""
+        sift = np.zeros((max(self.n, 1), 4), np.uint16)
+        cnt = np.zeros((max(self.n, 1), 8), np.int32)
+        self._check(self._L.arp_atom_accumulators(self._h, _p(sift), _p(cnt)), 'arp_atom_accumulators')
+        return dict(sift=sift[:self.n], counts=cnt[:self.n])
 
     # ---- ring / amide contacts ----
     def fetch_bag(self, name):

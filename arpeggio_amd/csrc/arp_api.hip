@@ -1069,6 +1069,39 @@ int arp_atom_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_se
     return arp_atom_contacts_fetch(c, cap, out_i, out_j, out_dist, out_sift, out_ctype, count);
 }
 
+// ---- per-atom accumulators of the contact loop (I:821-852, 923-934; U:182-221) ------------------------------
+int arp_atom_accumulators(arp_ctx* c, uint16_t* out_sift4, int32_t* out_counts8) {
+    if (!c || !out_sift4 || !out_counts8) return ARP_E_ARG;
+    if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_atom_accumulators: no atom-contact results (call a launch first)");
+    if (c->has_gid) FAIL(c, ARP_E_ARG, "arp_atom_accumulators: not available on a shard (contacts carry global ids)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)std::max<int64_t>(c->n, 1);
+    DevBuf<unsigned int> acc_s;
+    DevBuf<int> acc_c;
+    HIPCHK(c, acc_s.reserve(2 * n));
+    HIPCHK(c, acc_c.reserve(8 * n));
+    HIPCHK(c, hipMemsetAsync(acc_s.p, 0, 2 * n * sizeof(unsigned int), c->stream));
+    HIPCHK(c, hipMemsetAsync(acc_c.p, 0, 8 * n * sizeof(int), c->stream));
+    if (c->n_contacts > 0) {
+        hipLaunchKernelGGL(k_accumulate, dim3(nblocks(c->n_contacts, 256, 4096)), dim3(256), 0, c->stream, (long long)c->n_contacts,
+                           c->out_i.p, c->out_j.p, c->out_s.p, c->out_ct.p, acc_s.p, acc_c.p);
+        CHK(check_launch(c, "k_accumulate"));
+    }
+    std::vector<unsigned int> hs(2 * n);
+    int rc = download(c, hs.data(), acc_s.p, 2 * (size_t)c->n);
+    if (rc == ARP_OK) rc = download(c, out_counts8, acc_c.p, 8 * (size_t)c->n);
+    acc_s.release();
+    acc_c.release();
+    CHK(rc);
+    for (int64_t a = 0; a < c->n; ++a) {   // {all, inter_only, intra_only, water_only}
+        out_sift4[4 * a] = (uint16_t)(hs[2 * a] & 0x7FFF);
+        out_sift4[4 * a + 1] = (uint16_t)((hs[2 * a] >> 16) & 0x7FFF);
+        out_sift4[4 * a + 2] = (uint16_t)(hs[2 * a + 1] & 0x7FFF);
+        out_sift4[4 * a + 3] = (uint16_t)((hs[2 * a + 1] >> 16) & 0x7FFF);
+    }
+    return ARP_OK;
+}
+
 // ---- ring / amide contacts: launch (results stay in HBM) + fetch ----------------------------------
 int arp_atom_plane_launch(arp_ctx* c, int64_t* count) {
     if (!c) return ARP_E_ARG;

@@ -559,6 +559,42 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, co
     }
 }
 
+// Per-atom accumulators of the contact loop (interactions.py:821-852, 923-934; utils.py:182-221) from the
+// resident contact list: OR of the pair SIFt into sift / sift_inter_only (type == 'INTER') / sift_intra_only
+// ('INTRA' in type) / sift_water_only ('WATER' in type), and the hbond / polar counters with the
+// INTRA -> INTER -> WATER elif chain.  The feature SIFt (actual_fsift*) is bits 5..14 of the same masks.
+// acc_sift: u32[2n] = {all | inter << 16, intra | water << 16}; acc_cnt: i32[8n] =
+// {hbonds, hbonds_intra, hbonds_inter, hbonds_water, polars, polars_intra, polars_inter, polars_water}.
+__global__ __launch_bounds__(256) void k_accumulate(long long np, const int* __restrict__ ci, const int* __restrict__ cj,
+                                                    const uint16_t* __restrict__ cs, const uint8_t* __restrict__ cct,
+                                                    unsigned int* __restrict__ acc_sift, int* __restrict__ acc_cnt) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (long long)gridDim.x * blockDim.x) {
+        const unsigned int s = cs[p];
+        const int ct = cct[p];
+        const bool inter = ct == ARP_CT_INTER;
+        const bool intra = ct == ARP_CT_INTRA_NON_SELECTION || ct == ARP_CT_INTRA_SELECTION;
+        const bool water = ct == ARP_CT_SELECTION_WATER || ct == ARP_CT_NON_SELECTION_WATER || ct == ARP_CT_WATER_WATER;
+        const unsigned int w0 = s | (inter ? s << 16 : 0u);
+        const unsigned int w1 = (intra ? s : 0u) | (water ? s << 16 : 0u);
+        const int slot = intra ? 1 : (inter ? 2 : (water ? 3 : -1));   // 'INTRA' / elif 'INTER' / elif 'WATER'
+        const int atoms[2] = {ci[p], cj[p]};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int a = atoms[k];
+            atomicOr(&acc_sift[2 * (size_t)a], w0);
+            if (w1) atomicOr(&acc_sift[2 * (size_t)a + 1], w1);
+            if (s & ARP_S_HBOND) {
+                atomicAdd(&acc_cnt[8 * (size_t)a], 1);
+                if (slot > 0) atomicAdd(&acc_cnt[8 * (size_t)a + slot], 1);
+            }
+            if (s & ARP_S_POLAR) {
+                atomicAdd(&acc_cnt[8 * (size_t)a + 4], 1);
+                if (slot > 0) atomicAdd(&acc_cnt[8 * (size_t)a + 4 + slot], 1);
+            }
+        }
+    }
+}
+
 // residue / ring / amide membership of _make_selection (interactions.py:1413-1437)
 __global__ __launch_bounds__(256) void k_res_mark(int n, const int* __restrict__ res_id, const uint8_t* __restrict__ sel,
                                                   const uint8_t* __restrict__ plus, uint8_t* __restrict__ res_sel,

@@ -204,6 +204,15 @@ int arp_atom_contacts(arp_ctx* ctx, double cutoff, double vdw_comp,
                       int32_t* out_j, float* out_dist, uint16_t* out_sift,
                       uint8_t* out_ctype, int64_t* count);
 
+/* Per-atom side effects of the contact loop, computed from the contact list of the last
+ * launch (I:821-852, 923-934; utils.update_atom_sift / update_atom_fsift U:182-221):
+ *   out_sift4[4*a + {0,1,2,3}] = atom.sift / sift_inter_only / sift_intra_only / sift_water_only as
+ *       15-bit masks (actual_fsift* = the same masks >> 5);
+ *   out_counts8[8*a + k] = actual_hbonds, _intra_only, _inter_only, _water_only, actual_polars, ... (same order).
+ * utils.update_atom_integer_sift (U:224-242) is NOT provided: its value depends on the order in which
+ * the reference's KD-tree happens to deliver the pairs (it is "sift before the last pair + last pair"). */
+int arp_atom_accumulators(arp_ctx* ctx, uint16_t* out_sift4, int32_t* out_counts8);
+
 /* ---- _calculate_ring_contacts (I:938-1206) ------------------------------- */
 /* __calculate_atom_plane_contacts (I:947-1062). mask = ARP_AP_* bits. */
 int arp_atom_plane(arp_ctx* ctx, int64_t cap, int32_t* out_atom, int32_t* out_ring,

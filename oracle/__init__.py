@@ -211,6 +211,18 @@ class OracleComplex:
         return dict(amide=oa[:k], ring=orr[:k], dist=od[:k], dihedral=odi[:k], theta=ot[:k], ctype=oc[:k])
 
 
+def atom_accumulators(n, contacts):
+    """Per-atom sift masks (n,4) and hbond/polar counters (n,8) from a contact list (I:821-852, 923-934)."""
+    ci = np.ascontiguousarray(contacts['i'], np.int32)
+    cj = np.ascontiguousarray(contacts['j'], np.int32)
+    cs = np.ascontiguousarray(contacts['sift'], np.uint16)
+    cc = np.ascontiguousarray(contacts['ctype'], np.uint8)
+    sift = np.zeros((max(n, 1), 4), np.uint16)
+    cnt = np.zeros((max(n, 1), 8), np.int32)
+    lib().orc_atom_accumulators(C.c_int64(n), C.c_int64(len(ci)), _p(ci), _p(cj), _p(cs), _p(cc), _p(sift), _p(cnt))
+    return dict(sift=sift[:n], counts=cnt[:n])
+
+
 def sort_pairs(out, ki='i', kj='j'):
     """Canonical order: ascending (i, j)."""
     o = np.lexsort((out[kj], out[ki]))

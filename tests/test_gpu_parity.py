@@ -375,3 +375,24 @@ def test_sharded_union_on_one_gpu(ctx, capi, world):
             a, b = g[f][o], ref_bags[k][f]
             assert np.array_equal(a, b) or (a.dtype.kind == 'f' and np.array_equal(np.isnan(a), np.isnan(b))
                                             and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])), (k, f)
+
+
+def test_atom_accumulators(ctx):
+    """per-atom sift masks and hbond/polar counters (I:821-852, 923-934; U:182-221)."""
+    import oracle
+    from helpers import random_dense_pack
+    for seed in (11, 12):
+        pc = random_dense_pack(seed, n=600, box=16.0)
+        sel = (np.arange(pc.n_atoms) % 3 == 0).astype(np.uint8)
+        ctx.set_complex(pc)
+        ctx.make_selection(sel)
+        got_c = ctx.atom_contacts()
+        got = ctx.atom_accumulators()
+        oc = oracle.OracleComplex(pc)
+        oc.make_selection(sel, use_grid=False)
+        exp_c = oc.atom_contacts(use_grid=False)
+        _assert_contacts_equal(got_c, exp_c)
+        exp = oracle.atom_accumulators(pc.n_atoms, exp_c)
+        assert np.array_equal(got['sift'], exp['sift'])
+        assert np.array_equal(got['counts'], exp['counts'])
+        assert exp['counts'][:, 0].sum() > 0 and exp['counts'][:, 3].sum() > 0 and (exp['sift'][:, 1] != 0).any()

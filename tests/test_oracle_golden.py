@@ -149,3 +149,19 @@ def test_group_plane_loop_matches_reference(planes):
         assert (got['amide'][k], got['ring'][k]) == (rec['bgn_id'], rec['end_id'])
         assert got['dist'][k] == rec['distance']
         assert config.CONTACT_TYPE_NAMES[got['ctype'][k]] == rec['text']
+
+
+def test_accumulator_restatement_matches_reference_updates(golden_dir):
+    """orc_atom_accumulators (contact-list form) == the reference's update_atom_sift sequence (sift_updates.json)."""
+    cases = json.load(open(os.path.join(golden_dir, 'sift_updates.json')))
+    code = {n: i for i, n in enumerate(config.CONTACT_TYPE_NAMES)}
+    for case in cases:
+        steps = case['steps']
+        contacts = dict(i=np.zeros(len(steps), np.int32), j=np.ones(len(steps), np.int32),
+                        sift=np.array([sum(b << k for k, b in enumerate(st['addition'])) for st in steps], np.uint16),
+                        ctype=np.array([code[st['contact_type']] for st in steps], np.uint8))
+        acc = oracle.atom_accumulators(2, contacts)
+        fin = case['final']
+        for slot, nm in enumerate(('sift', 'sift_inter_only', 'sift_intra_only', 'sift_water_only')):
+            assert [(int(acc['sift'][0, slot]) >> k) & 1 for k in range(15)] == fin[nm]
+            assert [(int(acc['sift'][1, slot]) >> (k + 5)) & 1 for k in range(10)] == fin['actual_f' + nm]
