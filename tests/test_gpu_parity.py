@@ -396,3 +396,49 @@ def test_atom_accumulators(ctx):
         assert np.array_equal(got['sift'], exp['sift'])
         assert np.array_equal(got['counts'], exp['counts'])
         assert exp['counts'][:, 0].sum() > 0 and exp['counts'][:, 3].sum() > 0 and (exp['sift'][:, 1] != 0).any()
+
+
+def test_config5_full_size(ctx):
+    """BASELINE configs[4] at full size: 10k aromatic rings + 10k amides, every ring/amide kernel vs the oracle."""
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.config5()
+    assert pc.n_rings == 10_000 and pc.n_amides == 10_000
+    ctx.set_complex(pc)
+    ctx.make_selection(None)
+    oc = oracle.OracleComplex(pc)
+    oc.make_selection(None)
+    epp = oc.plane_plane()
+    o = np.lexsort((epp['end'], epp['bgn']))
+    epp = {k: v[o] for k, v in epp.items()}
+    gpp = ctx.plane_plane()
+    assert len(gpp['bgn']) > 40_000
+    _assert_planes_equal(gpp, epp, ('bgn', 'end', 'type1', 'type2', 'ctype', 'dist'), ('dihedral', 'theta_bgn', 'theta_end'))
+    assert set(np.unique(gpp['type1'])) == set(range(9))          # all nine FF..EF classes occur
+    _assert_planes_equal(ctx.group_group(), oc.group_group(), ('bgn', 'end', 'ctype', 'dist'), ('dihedral', 'theta'), tol=2e-4)
+    _assert_planes_equal(ctx.group_plane(), oc.group_plane(), ('amide', 'ring', 'ctype', 'dist'), ('dihedral', 'theta'))
+    _assert_planes_equal(ctx.atom_plane(), oc.atom_plane(), ('atom', 'ring', 'mask', 'ctype', 'dist'), ('theta',))
+    # properties of the plane-plane bag: one record per unordered pair, centroid distance <= 6
+    key = np.minimum(gpp['bgn'], gpp['end']).astype(np.int64) * pc.n_rings + np.maximum(gpp['bgn'], gpp['end'])
+    assert len(np.unique(key)) == len(key) and gpp['dist'].max() <= 6.0
+
+
+def test_one_million_atoms_single_gpu(ctx):
+    """Half of BASELINE configs[3] (2M atoms over 8 GPUs = 250k per GPU) times four on ONE GPU: parity with the
+    grid oracle and the size-independent properties of the contact list."""
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.config3(1_000_000, seed=4)
+    ctx.set_complex(pc)
+    counts = ctx.run_launch()
+    got = ctx.atom_contacts_fetch(counts['atom_atom'])
+    assert np.all(got['i'] < got['j'])
+    key = got['i'].astype(np.int64) * pc.n_atoms + got['j']
+    assert len(np.unique(key)) == len(key)
+    ladder = got['sift'] & 0x1F
+    assert np.all((ladder & (ladder - 1)) == 0) and np.all(ladder != 0)
+    assert np.all(pc.res_id[got['i']] != pc.res_id[got['j']])       # I:729
+    assert got['dist'].max() <= np.float32(5.0) * np.float32(1.000001)
+    oc = oracle.OracleComplex(pc)
+    oc.make_selection(None)
+    _assert_contacts_equal(got, oc.atom_contacts())
