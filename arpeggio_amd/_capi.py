@@ -27,7 +27,7 @@ SYMBOLS = (
     'arp_set_selection', 'arp_run_launch', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
-    'arp_set_selection_state', 'arp_atom_accumulators',
+    'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage',
 )
 
 _lib = None
@@ -70,6 +70,8 @@ def load():
     L.arp_set_ownership.argtypes = [vp, vp, vp]
     L.arp_set_selection.argtypes = [vp, vp]
     L.arp_atom_accumulators.argtypes = [vp, vp, vp]
+    L.arp_device_buffer.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(i64)]
+    L.arp_run_stage.argtypes = [vp, i32, dbl, dbl, i32, dbl, vp]
     L.arp_set_group_ownership.argtypes = [vp, vp, vp, vp, vp]
     L.arp_set_single_bond_neighbour_coords.argtypes = [vp, vp, vp]
     L.arp_set_selection_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -167,6 +169,21 @@ class Context:
     def set_selection_state(self, sel, plus, ring_sel, ring_plus, amide_sel, amide_plus):
         a = [np.ascontiguousarray(x, np.uint8) for x in (sel, plus, ring_sel, ring_plus, amide_sel, amide_plus)]
         self._check(self._L.arp_set_selection_state(self._h, *[_p(x) for x in a]), 'arp_set_selection_state')
+
+    BUF_PLUS, BUF_RES_SETS = 0, 1
+
+    def device_buffer(self, which):
+        """(device pointer, bytes) of a context buffer, for torch tensors that alias it (sharded runs)."""
+        ptr, nb = C.c_uint64(0), C.c_int64(0)
+        self._check(self._L.arp_device_buffer(self._h, int(which), C.byref(ptr), C.byref(nb)), 'arp_device_buffer')
+        return int(ptr.value), int(nb.value)
+
+    def run_stage(self, stage, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, expand_radius=6.0):
+        counts = np.zeros(5, np.int64)
+        self._check(self._L.arp_run_stage(self._h, int(stage), float(cutoff), float(vdw_comp), int(bool(include_sequence_adjacent)),
+                                          float(expand_radius), _p(counts)), 'arp_run_stage')
+        return dict(atom_atom=int(counts[0]), plane_plane=int(counts[1]), atom_plane=int(counts[2]),
+                    group_group=int(counts[3]), group_plane=int(counts[4]))
 
     def launch_bag(self, name):
         cnt = C.c_int64(0)

@@ -1297,6 +1297,99 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
     return device_error(c);
 }
 
+// ---- staged run_arpeggio for sharded runs ------------------------------------------------------------
+int arp_device_buffer(arp_ctx* c, int which, uint64_t* device_ptr, int64_t* bytes) {
+    if (!c || !device_ptr || !bytes) return ARP_E_ARG;
+    if (which == ARP_BUF_PLUS) {
+        if (!c->plus.p) FAIL(c, ARP_E_ARG, "arp_device_buffer: selection_plus does not exist yet (run stage 0 first)");
+        *device_ptr = (uint64_t)(uintptr_t)c->plus.p;
+        *bytes = c->n;
+    } else if (which == ARP_BUF_RES_SETS) {
+        if (!c->res_sel.p) FAIL(c, ARP_E_ARG, "arp_device_buffer: residue sets do not exist yet (run stage 1 first)");
+        *device_ptr = (uint64_t)(uintptr_t)c->res_sel.p;
+        *bytes = 2 * std::max<int64_t>(c->nres, 1);
+    } else FAIL(c, ARP_E_ARG, "arp_device_buffer: unknown buffer");
+    return ARP_OK;
+}
+
+int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius,
+                  int64_t counts[5]) {
+    if (!c || stage < 0 || stage > 2) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (stage == 0) {          // I:1384-1424 on the local atoms; exact for the atoms this rank owns
+        if (!(expand_radius > 0)) return ARP_E_ARG;
+        if (!c->sel.p || c->sel.cap < (size_t)std::max<int64_t>(c->n, 1)) {
+            HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
+            HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
+        c->ctr_clean = true;
+        int rc = enqueue_expansion(c, expand_radius);
+        c->ctr_clean = false;
+        CHK(rc);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return ARP_OK;
+    }
+    if (!c->sel_made) FAIL(c, ARP_E_ARG, "arp_run_stage: stage 0 has not run");
+    if (stage == 1) {          // I:1413, 1431 residue sets from the (now globally correct) selection_plus bits
+        const int n = (int)c->n;
+        const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+        HIPCHK(c, c->res_sel.reserve(2 * nres));
+        HIPCHK(c, hipMemsetAsync(c->res_sel.p, 0, 2 * nres, c->stream));
+        if (n > 0)
+            hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
+                               c->res_sel.p, c->res_sel.p + nres);
+        CHK(check_launch(c, "k_res_mark"));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return ARP_OK;
+    }
+    // stage 2: ring / amide sets from the (now globally reduced) residue sets, then every contact bag
+    if (!(cutoff > 0)) return ARP_E_ARG;
+    if (!c->res_sel.p) FAIL(c, ARP_E_ARG, "arp_run_stage: stage 1 has not run");
+    for (int attempt = 0;; ++attempt) {
+        const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+        // the expansion statistics of stage 0 live in the counter block: keep them, clear the rest
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_STAT_MCAND, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + C_SEG_PAIRS, 0, sizeof(u64) * PAIR_SEGS, c->stream));
+        c->ctr_clean = true;
+        struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
+        if (c->nring + c->namide > 0)
+            hipLaunchKernelGGL(k_group_mask, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, c->stream, (int)c->nring,
+                               (int)c->namide, c->ring_res.p, c->am_res.p, c->res_sel.p, c->res_sel.p + nres, c->ring_sel.p,
+                               c->ring_plus.p, c->am_sel.p, c->am_plus.p);
+        CHK(check_launch(c, "k_group_mask"));
+        if (c->nring > 0) CHK(ensure_ring_grid(c));
+        if (c->namide > 0) CHK(ensure_amide_grid(c));
+        HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
+        CHK(enqueue_atom_plane(c, c->stream2));
+        CHK(enqueue_plane_plane(c, c->stream2));
+        CHK(enqueue_group_group(c, c->stream2));
+        CHK(enqueue_group_plane(c, c->stream2));
+        HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
+        CHK(enqueue_counter_copy(c));
+        CHK(collect_counters(c));
+        collect_events(c);
+        int again = 0;
+        if (finish_contacts(c)) { CHK(grow_pairs(c)); again = 1; }
+        if (finish_bag(c, c->bag_ap, C_AP)) { CHK(grow_bag(c, c->bag_ap, C_AP, true, false)); again = 1; }
+        if (finish_bag(c, c->bag_pp, C_PP)) { CHK(grow_bag(c, c->bag_pp, C_PP, true, false)); again = 1; }
+        if (finish_bag(c, c->bag_gg, C_GG)) { CHK(grow_bag(c, c->bag_gg, C_GG, false, true)); again = 1; }
+        if (finish_bag(c, c->bag_gp, C_GP)) { CHK(grow_bag(c, c->bag_gp, C_GP, true, false)); again = 1; }
+        if (!again) break;
+        if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_stage: result buffers could not be sized");
+    }
+    c->stats[5] = (int64_t)c->h_ctr[C_MARK_CAND];
+    c->stats[6] = (int64_t)c->h_ctr[C_MARK_ACC];
+    if (counts) {
+        counts[0] = c->n_contacts; counts[1] = c->bag_pp.count; counts[2] = c->bag_ap.count;
+        counts[3] = c->bag_gg.count; counts[4] = c->bag_gp.count;
+    }
+    return device_error(c);
+}
+
 // ---- measurement -------------------------------------------------------------------------------
 int arp_get_stats(arp_ctx* c, int64_t stats[8]) {
     if (!c || !stats) return ARP_E_ARG;

@@ -161,20 +161,21 @@ def assemble_shard(home: Dict[str, np.ndarray], halos: Dict[int, Dict[str, np.nd
     ring_gid, amide_gid = rec['ring_gid'][ro], rec['amide_gid'][ao]
     ring_res_g, amide_res_g = rec['ring_res'][ro], rec['amide_res'][ao]
 
-    # local residue table: every residue referenced by a local atom, ring or amide
-    res_g_atoms = rec['res_gid'][order]
-    all_res = np.concatenate([res_g_atoms, ring_res_g[ring_res_g >= 0], amide_res_g[amide_res_g >= 0]])
-    res_gid = np.unique(all_res).astype(np.int32)
-    res_local = _lookup(res_gid, res_g_atoms)
-    nres = res_gid.size
+    # The shard keeps GLOBAL residue ids (a table of n_res_global rows of which only the rows of local residues
+    # are filled): residue links, ring/amide residues and the residue sets then have the same layout on every
+    # rank, so the sets can be all-reduced in place on the device.
+    res_g_atoms = rec['res_gid'][order].astype(np.int64)
+    nres = int(n_res_global)
+    res_gid = np.arange(nres, dtype=np.int32)
+    res_local = res_g_atoms
     res_flags = np.zeros(nres, np.uint8)
     res_prev = np.full(nres, -1, np.int32)
     res_next = np.full(nres, -1, np.int32)
     res_flags[res_local] = rec['res_flags'][order]
-    res_prev[res_local] = _lookup(res_gid, rec['res_prev'][order])
-    res_next[res_local] = _lookup(res_gid, rec['res_next'][order])
-    ring_res = np.where(ring_res_g >= 0, _lookup(res_gid, np.maximum(ring_res_g, 0)), -1).astype(np.int32)
-    amide_res = np.where(amide_res_g >= 0, _lookup(res_gid, np.maximum(amide_res_g, 0)), -1).astype(np.int32)
+    res_prev[res_local] = rec['res_prev'][order]
+    res_next[res_local] = rec['res_next'][order]
+    ring_res = ring_res_g.astype(np.int32)
+    amide_res = amide_res_g.astype(np.int32)
 
     pc = PackedComplex(
         xyz=rec['xyz'][order], vdw=rec['vdw'][order], cov=rec['cov'][order], type_mask=rec['tmask'][order],
@@ -324,6 +325,7 @@ def upload_shard(ctx, sh: Shard):
     ctx.set_single_bond_neighbour_coords(sh.sb_xyz, sh.sb_has)
     ctx.set_ownership(sh.is_home, sh.global_id)
     ctx.set_group_ownership(sh.ring_home, sh.ring_gid, sh.amide_home, sh.amide_gid)
+    ctx.set_selection(sh.sel)
 
 
 def run_shard(ctx, sh: Shard, dist=None, device=None, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
@@ -335,3 +337,72 @@ def run_shard(ctx, sh: Shard, dist=None, device=None, cutoff=5.0, vdw_comp=0.1, 
     for name in ('plane_plane', 'atom_plane', 'group_group', 'group_plane'):
         counts[name] = ctx.launch_bag(name)
     return counts
+
+
+class DeviceExchange:
+    """Selection exchange of one shard on the device: torch tensors alias the context's selection_plus and
+    residue-set buffers (``arp_device_buffer``), the halo bits travel with grouped isend/irecv and the residue
+    sets with one all-reduce (MAX) — RCCL over xGMI when ``dist`` runs the nccl backend."""
+
+    class _Alias:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
+
+    def __init__(self, ctx, sh: Shard, dist, device):
+        import torch
+        self.torch, self.ctx, self.sh, self.dist, self.device = torch, ctx, sh, dist, device
+        self.t_plus = self.t_res = None
+        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(device if device is not None else 'cpu')
+        self.send_idx, self.recv_idx, self.recv_buf = {}, {}, {}
+        for side, ids in ((-1, sh.send_left), (+1, sh.send_right)):
+            if ids is not None and 0 <= sh.rank + side < sh.world:
+                self.send_idx[side] = to_dev(_lookup(sh.global_id, ids))
+                self.recv_idx[side] = to_dev(np.nonzero(sh.origin == side)[0])
+                self.recv_buf[side] = torch.empty(int((sh.origin == side).sum()), dtype=torch.uint8,
+                                                  device=device if device is not None else 'cpu')
+
+    def _on_gpu(self):
+        return self.device is not None and getattr(self.device, 'type', str(self.device)) == 'cuda'
+
+    def _alias(self, which):
+        if not self._on_gpu():     # CPU tests (gloo): the "context" exposes NumPy buffers
+            return self.torch.from_numpy(self.ctx.host_buffer(which))
+        ptr, nb = self.ctx.device_buffer(which)
+        return self.torch.as_tensor(self._Alias(ptr, nb), device=self.device)
+
+    def _sync(self):
+        if self._on_gpu():
+            self.torch.cuda.current_stream(self.device).synchronize()
+
+    def exchange_plus(self):
+        torch, dist = self.torch, self.dist
+        if self.t_plus is None:
+            self.t_plus = self._alias(self.ctx.BUF_PLUS)
+        ops, keep = [], []
+        for side, idx in self.send_idx.items():
+            buf = self.t_plus[idx]
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, self.sh.rank + side))
+            ops.append(dist.P2POp(dist.irecv, self.recv_buf[side], self.sh.rank + side))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for side, idx in self.recv_idx.items():
+            self.t_plus[idx] = self.recv_buf[side]
+        self._sync()
+
+    def reduce_residue_sets(self):
+        torch, dist = self.torch, self.dist
+        if self.t_res is None:
+            self.t_res = self._alias(self.ctx.BUF_RES_SETS)
+        dist.all_reduce(self.t_res, op=dist.ReduceOp.MAX)
+        self._sync()
+
+
+def run_shard_device(ctx, ex: DeviceExchange, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
+    """run_arpeggio on one shard with the selection state combined on the device (three stages, two exchanges)."""
+    ctx.run_stage(0, cutoff, vdw_comp, include_sequence_adjacent)
+    ex.exchange_plus()
+    ctx.run_stage(1, cutoff, vdw_comp, include_sequence_adjacent)
+    ex.reduce_residue_sets()
+    return ctx.run_stage(2, cutoff, vdw_comp, include_sequence_adjacent)

@@ -107,8 +107,15 @@ def main():
     if world == 1:
         def step():
             return ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+    elif comm_device is not None:
+        # device-resident exchange: torch tensors alias the context's buffers, RCCL moves the halo bits and reduces
+        # the residue sets between the three stages of the pass
+        exchange = sharding.DeviceExchange(ctx, shard, dist, comm_device)
+
+        def step():
+            return sharding.run_shard_device(ctx, exchange, args.cutoff, args.vdw_comp, False)
     else:
-        def step():   # local 6 A expansion, selection-bit halo exchange + residue all-reduce, then the five bags
+        def step():   # debug path (gloo, host buffers)
             return sharding.run_shard(ctx, shard, dist, comm_device, args.cutoff, args.vdw_comp, False)
 
     def sync_all():

@@ -277,6 +277,22 @@ int arp_set_selection_state(arp_ctx* ctx, const uint8_t* in_selection, const uin
                             const uint8_t* ring_sel, const uint8_t* ring_plus,
                             const uint8_t* amide_sel, const uint8_t* amide_plus);
 
+/* Staged form of arp_run_launch for slab-sharded runs: between the stages the caller combines the
+ * selection state of the ranks ON THE DEVICE (RCCL on tensors that alias the context's buffers).
+ *   stage 0  selection_plus of the local atoms (I:1384-1424); exact for the atoms this rank owns.
+ *            -> caller overwrites the bits of its halo atoms with their owners' (ARP_BUF_PLUS).
+ *   stage 1  residue sets of the selection and of selection_plus (I:1413, 1431).
+ *            -> caller all-reduces (MAX) the set over the ranks (ARP_BUF_RES_SETS; the shard uses
+ *               global residue ids, so the buffer has the same layout on every rank).
+ *   stage 2  ring / amide id sets (I:1416-1437), atom contacts, ring and group contacts; fills counts
+ *            like arp_run_launch.
+ * Each stage returns after the context's streams have drained. */
+#define ARP_BUF_PLUS      0   /* u8[n]        selection_plus                                            */
+#define ARP_BUF_RES_SETS  1   /* u8[2 * nres] [0,nres) selection residues, [nres,2nres) selection_plus  */
+int arp_device_buffer(arp_ctx* ctx, int which, uint64_t* device_ptr, int64_t* bytes);
+int arp_run_stage(arp_ctx* ctx, int stage, double cutoff, double vdw_comp, int include_sequence_adjacent,
+                  double expand_radius, int64_t counts[5]);
+
 /* ---- measurement ---------------------------------------------------------- */
 /* stats[0]=candidate pairs tested by the last atom-contact search,
  * stats[1]=pairs with d<=cutoff, stats[2]=pairs passing the residue filters

@@ -442,3 +442,70 @@ def test_one_million_atoms_single_gpu(ctx):
     oc = oracle.OracleComplex(pc)
     oc.make_selection(None)
     _assert_contacts_equal(got, oc.atom_contacts())
+
+
+def test_staged_run_equals_run_launch(ctx):
+    """arp_run_stage 0/1/2 (the sharded protocol, here without neighbours) == arp_run_launch."""
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.config3(15000, seed=17)
+    sel = (pc.res_id % 9 == 2).astype(np.uint8)
+    ctx.set_complex(pc)
+    ctx.set_selection(sel)
+    ref_counts = ctx.run_launch()
+    ref = ctx.atom_contacts_fetch(ref_counts['atom_atom'])
+    ref_bags = {k: ctx.fetch_bag(k) for k in ('plane_plane', 'atom_plane', 'group_group', 'group_plane')}
+    ctx.set_selection(sel)
+    ctx.run_stage(0)
+    ptr, nb = ctx.device_buffer(ctx.BUF_PLUS)
+    assert ptr != 0 and nb == pc.n_atoms
+    ctx.run_stage(1)
+    ptr, nb = ctx.device_buffer(ctx.BUF_RES_SETS)
+    assert nb == 2 * pc.n_residues
+    counts = ctx.run_stage(2)
+    assert counts == ref_counts
+    _assert_contacts_equal(ctx.atom_contacts_fetch(counts['atom_atom']), ref)
+    for k, b in ref_bags.items():
+        g = ctx.fetch_bag(k)
+        for f in b:
+            assert np.array_equal(g[f], b[f], equal_nan=True) if b[f].dtype.kind == 'f' else np.array_equal(g[f], b[f]), (k, f)
+    assert ctx.stats()['expand_candidates'] > 0
+
+
+def test_device_exchange_over_nccl_world1():
+    """DeviceExchange on the real backend (nccl = RCCL) with a one-rank group: tensors aliasing the context's buffers,
+    in-place all-reduce of the residue sets, staged pass == arp_run_launch.  Runs in a subprocess (own process group)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1')
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+from arpeggio_amd import synth, sharding, _capi
+full = synth.slab_config(6000, 2, seed=8)
+sel = (full.res_id % 7 == 1).astype(np.uint8)
+sh = sharding.make_shard_distributed(full, 0, 1, dist, device=dev, sel=sel)
+ctx = _capi.Context(0)
+sharding.upload_shard(ctx, sh)
+ex = sharding.DeviceExchange(ctx, sh, dist, dev)
+c1 = sharding.run_shard_device(ctx, ex)
+a = ctx.atom_contacts_fetch(c1['atom_atom'])
+assert ex.t_plus.data_ptr() == ctx.device_buffer(ctx.BUF_PLUS)[0] and int(ex.t_plus.sum().item()) > 0
+ref = _capi.Context(0)
+ref.set_complex(full)
+ref.set_selection(sel)
+c2 = ref.run_launch()
+b = ref.atom_contacts_fetch(c2['atom_atom'])
+assert c1 == c2, (c1, c2)
+for k in ('i', 'j', 'sift', 'ctype'):
+    assert np.array_equal(a[k], b[k]), k
+assert np.array_equal(a['dist'].view(np.uint32), b['dist'].view(np.uint32))
+dist.destroy_process_group()
+print('NCCL_WORLD1_OK')
+'''
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert 'NCCL_WORLD1_OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -127,6 +127,55 @@ def test_local_shards_union_equals_unsharded(world):
     assert len(exp['aa']) > 1000 and len(exp['pp']) > 0 and len(exp['ap']) > 0
 
 
+class _OracleStageContext:
+    """Stand-in for the GPU context in the staged (run_stage) protocol: same three stages, NumPy buffers, the oracle
+    as compute.  Exercises sharding.DeviceExchange / run_shard_device over gloo."""
+    BUF_PLUS, BUF_RES_SETS = 0, 1
+
+    def __init__(self, sh):
+        self.sh = sh
+        self.plus = np.zeros(sh.pc.n_atoms, np.uint8)
+        self.res = np.zeros(2 * sh.n_res_global, np.uint8)
+
+    def host_buffer(self, which):
+        return self.plus if which == self.BUF_PLUS else self.res
+
+    def run_stage(self, stage, *a):
+        sh = self.sh
+        if stage == 0:
+            self.plus[:] = oracle.OracleComplex(sh.pc).make_selection(sh.sel, use_grid=False)
+        elif stage == 1:
+            self.res[:] = 0
+            self.res[sh.pc.res_id[sh.sel == 1]] = 1
+            self.res[sh.n_res_global + sh.pc.res_id[self.plus == 1]] = 1
+        else:
+            nr = sh.n_res_global
+            rs, rp = self.res[:nr], self.res[nr:]
+            pick = lambda r, m: np.where(r >= 0, m[np.maximum(r, 0)], 0).astype(np.uint8)
+            self.masks = dict(sel=sh.sel, plus=self.plus.copy(), ring_sel=pick(sh.pc.ring_res, rs), ring_plus=pick(sh.pc.ring_res, rp),
+                              amide_sel=pick(sh.pc.amide_res, rs), amide_plus=pick(sh.pc.amide_res, rp))
+            return _eval_shard(sh, self.masks)
+
+
+def _worker_staged(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        full, sel = _workload()
+        sh = sharding.make_shard_distributed(full, rank, world, dist, device=None, sel=sel)
+        ctx = _OracleStageContext(sh)
+        ex = sharding.DeviceExchange(ctx, sh, dist, None)
+        out = sharding.run_shard_device(ctx, ex)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (True, out, ctx.masks['plus'], sh.global_id))
+        if rank == 0:
+            q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -153,15 +202,15 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_gloo_halo_exchange_and_selection_combine(world):
+@pytest.mark.parametrize('world,worker', [(2, '_worker'), (3, '_worker'), (2, '_worker_staged'), (3, '_worker_staged')])
+def test_gloo_halo_exchange_and_selection_combine(world, worker):
     """One process per rank over gloo: exchanged halos == global-knowledge halos, combined masks == global
     _make_selection, union of owned results == unsharded result."""
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=globals()[worker], args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     gathered = q.get(timeout=300)
