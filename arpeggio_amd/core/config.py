@@ -34,7 +34,8 @@ ATOM_PLANE_NAMES = ('CARBONPI', 'CATIONPI', 'DONORPI', 'HALOGENPI', 'METSULPHURP
 
 # plane-plane classes (ARP_PP_*), interactions.py:1127-1148; index 9 is the '' class
 PLANE_PLANE_NAMES = ('FF', 'OF', 'EE', 'FT', 'OT', 'ET', 'FE', 'OE', 'EF', '')
-PP_SKIPPED = 255
+PP_SAME = 254      # the reverse visit gave the same class: nothing appended (interactions.py:1184)
+PP_SKIPPED = 255   # no reverse visit (dropped by the intra-residue EE rule, interactions.py:1154)
 
 VDW_RADII = {'H': 1.2}
 

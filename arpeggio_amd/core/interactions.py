@@ -146,7 +146,7 @@ class InteractionComplex:
         out = []
         for k in range(len(b['bgn'])):
             types = [config.PLANE_PLANE_NAMES[b['type1'][k]]]
-            if b['type2'][k] != config.PP_SKIPPED:
+            if b['type2'][k] < config.PP_SAME:
                 types.append(config.PLANE_PLANE_NAMES[b['type2'][k]])
             r1, r2 = int(b['bgn'][k]), int(b['end'][k])
             out.append(PlanePlaneContact(r1, int(self.pc.ring_res[r1]), self._ring_names(r1), r2, int(self.pc.ring_res[r2]),
@@ -182,6 +182,16 @@ class InteractionComplex:
                                   int(self.pc.ring_res[r]), self._ring_names(int(r)), d, ['AMIDERING'],
                                   config.CONTACT_TYPE_NAMES[c])
                 for a, r, d, c in zip(b['amide'], b['ring'], b['dist'], b['ctype'])]
+
+    def residue_plane_sifts(self):
+        """Per-residue integer SIFts of the ring / amide loops (I:1040-1057, 1171-1176, 1290-1291, 1371-1373).
+
+        Returns int arrays indexed by residue: ``ring_ring_inter_integer_sift`` [NR,9] (FF..EF),
+        ``ring_atom_inter_integer_sift`` / ``atom_ring_inter_integer_sift`` / ``mc_atom_ring_...`` / ``sc_atom_ring_...``
+        [NR,5] (CARBONPI..METSULPHURPI), ``amide_amide_inter_integer_sift``, ``amide_ring_inter_integer_sift``,
+        ``ring_amide_inter_integer_sift`` [NR,1].  Only contacts of type INTER between different residues count.
+        """
+        return residue_plane_sifts(self.pc, self._bags)
 
     def get_contacts(self):
         """I:172-212: JSON-able list, bags in the reference's order, canonical order inside a bag."""
@@ -241,6 +251,59 @@ class InteractionComplex:
         result_entry['contact'] = contact.sifts
         result_entry['interacting_entities'] = contact.text
         return result_entry
+
+
+def residue_plane_sifts(pc, bags):
+    """See InteractionComplex.residue_plane_sifts; `bags` = dict of the four ring/amide result bags (arrays)."""
+    nr = pc.n_residues
+    inter = config.CONTACT_TYPE_NAMES.index('INTER')
+    out = {
+        'ring_ring_inter_integer_sift': np.zeros((nr, 9), np.int64),
+        'ring_atom_inter_integer_sift': np.zeros((nr, 5), np.int64),
+        'atom_ring_inter_integer_sift': np.zeros((nr, 5), np.int64),
+        'mc_atom_ring_inter_integer_sift': np.zeros((nr, 5), np.int64),
+        'sc_atom_ring_inter_integer_sift': np.zeros((nr, 5), np.int64),
+        'amide_amide_inter_integer_sift': np.zeros((nr, 1), np.int64),
+        'amide_ring_inter_integer_sift': np.zeros((nr, 1), np.int64),
+        'ring_amide_inter_integer_sift': np.zeros((nr, 1), np.int64),
+    }
+    b = bags.get('plane_plane')
+    if b is not None and len(b['bgn']):
+        r1, r2 = pc.ring_res[b['bgn']], pc.ring_res[b['end']]
+        ok = (b['ctype'] == inter) & (r1 != r2)                     # I:1171
+        t1, t2 = b['type1'].astype(np.int64), b['type2'].astype(np.int64)
+        # the visit that created the record counts for the bgn ring's residue (I:1173-1176) ...
+        m = ok & (t1 < 9)
+        np.add.at(out['ring_ring_inter_integer_sift'], (r1[m], t1[m]), 1)
+        # ... the reverse visit, when it happened, for the end ring's residue with its own class
+        rev = np.where(t2 == config.PP_SAME, t1, t2)
+        m = ok & (t2 != config.PP_SKIPPED) & (rev < 9)
+        np.add.at(out['ring_ring_inter_integer_sift'], (r2[m], rev[m]), 1)
+    b = bags.get('atom_plane')
+    if b is not None and len(b['atom']):
+        ra, rr = pc.res_id[b['atom']], pc.ring_res[b['ring']]
+        ok = (b['ctype'] == inter) & (ra != rr)                     # I:1040
+        poly = (pc.res_flags[ra] & config.R_POLYPEPTIDE) != 0       # atom.get_parent() in self.polypeptide_residues
+        names = np.asarray(pc.atom_name, dtype=object)[b['atom']]
+        mc = np.array([n in config.MAINCHAIN_ATOMS for n in names], bool) if len(names) else np.zeros(0, bool)
+        for k in range(5):
+            m = ok & (((b['mask'] >> k) & 1) == 1)
+            np.add.at(out['ring_atom_inter_integer_sift'], (rr[m], k), 1)
+            np.add.at(out['atom_ring_inter_integer_sift'], (ra[m], k), 1)
+            np.add.at(out['mc_atom_ring_inter_integer_sift'], (ra[m & poly & mc], k), 1)
+            np.add.at(out['sc_atom_ring_inter_integer_sift'], (ra[m & poly & ~mc], k), 1)
+    b = bags.get('group_group')
+    if b is not None and len(b['bgn']):
+        r1, r2 = pc.amide_res[b['bgn']], pc.amide_res[b['end']]
+        m = (b['ctype'] == inter) & (r1 != r2)                      # I:1290
+        np.add.at(out['amide_amide_inter_integer_sift'], (r1[m], 0), 1)
+    b = bags.get('group_plane')
+    if b is not None and len(b['amide']):
+        ra, rr = pc.amide_res[b['amide']], pc.ring_res[b['ring']]
+        m = (b['ctype'] == inter) & (ra != rr)                      # I:1371
+        np.add.at(out['amide_ring_inter_integer_sift'], (ra[m], 0), 1)
+        np.add.at(out['ring_amide_inter_integer_sift'], (rr[m], 0), 1)
+    return out
 
 
 def pack_from_reference_objects(ic):

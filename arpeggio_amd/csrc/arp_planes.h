@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
                         first = !skip_ab;
                         if (first) {  // record created by visit (a,b); visit (b,a) may append its class
                             t1 = t_ab; t2 = skip_ba ? NAN : t_ba;
-                            y1 = y_ab; y2 = (skip_ba || y_ba == y_ab) ? ARP_PP_SKIPPED : y_ba;
+                            y1 = y_ab; y2 = skip_ba ? ARP_PP_SKIPPED : (y_ba == y_ab ? ARP_PP_SAME : y_ba);
                         } else {      // first visit skipped: the reverse visit creates the record
                             t1 = t_ba; t2 = NAN;
                             y1 = y_ba; y2 = ARP_PP_SKIPPED;

@@ -101,7 +101,7 @@ extern "C" {
 #define ARP_AP_HALOGENPI     (1u << 3)
 #define ARP_AP_METSULPHURPI  (1u << 4)
 
-/* ---- plane-plane classes (I:1127-1148); 9 = '' (NaN angles), 255 = visit skipped */
+/* ---- plane-plane classes (I:1127-1148); 9 = '' (NaN angles) */
 #define ARP_PP_FF 0
 #define ARP_PP_OF 1
 #define ARP_PP_EE 2
@@ -112,7 +112,8 @@ extern "C" {
 #define ARP_PP_OE 7
 #define ARP_PP_EF 8
 #define ARP_PP_NONE 9
-#define ARP_PP_SKIPPED 255
+#define ARP_PP_SAME 254      /* reverse visit happened and produced the same class (nothing appended) */
+#define ARP_PP_SKIPPED 255   /* reverse visit dropped by the intra-residue EE rule (I:1154) or never made */
 
 typedef struct arp_ctx arp_ctx;
 
@@ -220,7 +221,7 @@ int arp_atom_plane(arp_ctx* ctx, int64_t cap, int32_t* out_atom, int32_t* out_ri
                    uint8_t* out_ctype, int64_t* count);
 /* __calculate_plane_plane_contacts (I:1064-1194), one record per unordered ring
  * pair after the reference's dedupe: type1 = class from the creating visit,
- * type2 = class appended by the reverse visit or ARP_PP_SKIPPED. */
+ * type2 = class appended by the reverse visit, ARP_PP_SAME or ARP_PP_SKIPPED. */
 int arp_plane_plane(arp_ctx* ctx, int64_t cap, int32_t* out_bgn, int32_t* out_end,
                     double* out_dist, double* out_dihedral, double* out_theta_bgn,
                     double* out_theta_end, uint8_t* out_type1, uint8_t* out_type2,

@@ -289,6 +289,9 @@ def main():
                'group_group': dump(self_.group_group_contacts),
                'group_plane': dump(self_.group_plane_contacts),
                'ring_ring_inter_integer_sift': {str(r.idx): r.ring_ring_inter_integer_sift for r in residues if any(r.ring_ring_inter_integer_sift)},
+               'amide_amide_inter_integer_sift': {str(r.idx): r.amide_amide_inter_integer_sift for r in residues if any(r.amide_amide_inter_integer_sift)},
+               'amide_ring_inter_integer_sift': {str(r.idx): r.amide_ring_inter_integer_sift for r in residues if any(r.amide_ring_inter_integer_sift)},
+               'ring_amide_inter_integer_sift': {str(r.idx): r.ring_amide_inter_integer_sift for r in residues if any(r.ring_amide_inter_integer_sift)},
                }, open(os.path.join(HERE, 'planes_expected.json'), 'w'))
     print('planes:', len(self_.plane_plane_contacts), len(self_.group_group_contacts), len(self_.group_plane_contacts))
 

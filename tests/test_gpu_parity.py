@@ -163,7 +163,7 @@ def test_golden_plane_fixtures_on_gpu(ctx, golden_dir):
         rec = key[(int(got['bgn'][k]), int(got['end'][k]))]
         assert got['dist'][k] == rec['distance']
         types = [config.PLANE_PLANE_NAMES[got['type1'][k]]]
-        if got['type2'][k] != config.PP_SKIPPED:
+        if got['type2'][k] < config.PP_SAME:
             types.append(config.PLANE_PLANE_NAMES[got['type2'][k]])
         assert types == rec['contact_type']
     gg = ctx.group_group()

@@ -122,7 +122,7 @@ def test_plane_plane_loop_matches_reference(planes):
         assert (got['bgn'][k], got['end'][k]) == (rec['bgn_id'], rec['end_id'])
         assert got['dist'][k] == rec['distance']            # float64, bit-exact
         types = [config.PLANE_PLANE_NAMES[got['type1'][k]]]
-        if got['type2'][k] != config.PP_SKIPPED:
+        if got['type2'][k] < config.PP_SAME:
             types.append(config.PLANE_PLANE_NAMES[got['type2'][k]])
         assert types == rec['contact_type'], (k, rec)
         assert config.CONTACT_TYPE_NAMES[got['ctype'][k]] == rec['text']
@@ -165,3 +165,22 @@ def test_accumulator_restatement_matches_reference_updates(golden_dir):
         for slot, nm in enumerate(('sift', 'sift_inter_only', 'sift_intra_only', 'sift_water_only')):
             assert [(int(acc['sift'][0, slot]) >> k) & 1 for k in range(15)] == fin[nm]
             assert [(int(acc['sift'][1, slot]) >> (k + 5)) & 1 for k in range(10)] == fin['actual_f' + nm]
+
+
+def test_residue_ring_sifts_match_reference(planes, golden_dir):
+    """Host computation of the per-residue ring-ring integer SIFt (I:1171-1176) from the plane-plane bag
+    == the counters the reference's own loop left on the residues (planes_expected.json)."""
+    from arpeggio_amd.core.interactions import residue_plane_sifts
+    oc, exp = planes
+    pp = oc.plane_plane()
+    got = residue_plane_sifts(oc.pc, {'plane_plane': pp, 'group_group': oc.group_group(), 'group_plane': oc.group_plane()})
+    want = np.zeros_like(got['ring_ring_inter_integer_sift'])
+    for r, v in exp['ring_ring_inter_integer_sift'].items():
+        want[int(r)] = v
+    assert want.sum() > 100
+    assert np.array_equal(got['ring_ring_inter_integer_sift'], want)
+    for name in ('amide_amide_inter_integer_sift', 'amide_ring_inter_integer_sift', 'ring_amide_inter_integer_sift'):
+        w = np.zeros_like(got[name])
+        for r, v in exp[name].items():
+            w[int(r)] = v
+        assert w.sum() > 0 and np.array_equal(got[name], w), name
