@@ -243,6 +243,9 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
             int4 hauxreg = make_int4(0, 0, 0, 0);
             if (MODE != MODE_PAIRS && hvalid) hauxreg = s_aux[hb + lane];
             if (MODE == MODE_PAIRS && hvalid) hauxreg.x = s_aux[hb + lane].x;
+            // expansion search: which home atoms are selected (lane = home atom)
+            const unsigned long long m_hvalid = __ballot(hvalid);
+            const unsigned long long m_selh = (MODE == MODE_MARK) ? __ballot(hvalid && (__float_as_uint(hreg.w) & M_SEL)) : 0ull;
 #pragma unroll 1
             for (int kb = 0; kb < total; kb += 64) {  // the ~87 candidates of this cell, flattened over the lanes
                 const int k = kb + lane;
@@ -259,6 +262,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                 // wave-uniform lane masks of this chunk: valid candidates, and those inside the home pencil
                 const unsigned long long m_valid = __ballot(valid);
                 const unsigned long long m_r0 = __ballot(valid && in_r0);
+                // Expansion search (I:1420-1424): a pair changes selection_plus only if exactly ONE of its atoms is
+                // selected (both selected: already members; neither: not concerned), so only those pairs are tested.
+                const unsigned long long m_selj = (MODE == MODE_MARK) ? __ballot(valid && (mj & M_SEL)) : 0ull;
+                if (MODE == MODE_MARK && ((m_selh == m_hvalid && m_selj == m_valid) || (m_selh == 0 && m_selj == 0))) continue;
 #pragma unroll 1
                 for (int hh = 0; hh < hcount; ++hh) {
                     const int h = hb + hh;
@@ -270,7 +277,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                     // candidate k of range 0 is position hs + k, so lanes with kb + lane <= h - hs drop out
                     const int t = h - hs - kb;
                     const unsigned long long low = (t < 0) ? 0ull : (t >= 63 ? ~0ull : ((2ull << t) - 1ull));
-                    const unsigned long long m_tested = m_valid & ~(m_r0 & low);
+                    unsigned long long m_tested = m_valid & ~(m_r0 & low);
+                    if (MODE == MODE_MARK) {
+                        m_tested &= ((m_selh >> hh) & 1ull) ? ~m_selj : m_selj;
+                        if (m_tested == 0) continue;
+                    }
                     // float32 pre-filter.  |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded
                     // squares, two rounded sums), so outside the +-1e-5 band the float32 answer IS the
                     // float64 answer; inside the band (rare) the whole wave takes the exact float64 test.
