@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--atoms', type=int, default=100_000, help='atoms per GPU (configs[2]: 100k; configs[3]: 250k x 8)')
     ap.add_argument('--cutoff', type=float, default=5.0)
     ap.add_argument('--vdw-comp', type=float, default=0.1)

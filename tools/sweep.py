@@ -10,7 +10,7 @@ extra = sys.argv[3:]
 for v in values:
     env = dict(os.environ)
     env[var] = v
-    out = subprocess.run([sys.executable, 'bench.py', '--no-cpu-baseline', '--steps', '30', '--warmup', '3'] + extra,
+    out = subprocess.run([sys.executable, 'bench.py', '--no-cpu-baseline', '--steps', '200', '--warmup', '5'] + extra,
                          env=env, capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith('{')]
     if not line:
