@@ -97,7 +97,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-KERNEL_SLOTS = ('bin', 'scan', 'scatter_cellsort', 'gather', 'search', 'sift', 'mark_search', 'planes')
+KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')
 
 
 class Context:

@@ -67,7 +67,7 @@ struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
                      f1.release(); f2.release(); u0.release(); u1.release(); u2.release(); cap = 0; valid = false; }
 };
 
-enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_GATHER = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
+enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_UNUSED = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
 
 struct EventPair { int slot; hipEvent_t a, b; };
 
@@ -80,7 +80,7 @@ struct arp_ctx {
     int num_cu = 256;
 
     // ---- sizes
-    int64_t n = 0, nres = 0, nring = 0, namide = 0, nh = 0, nbond = 0;
+    int64_t n = 0, nres = 0, nring = 0, namide = 0;
     // ---- host mirrors needed for later set_* calls / grid boxes
     std::vector<float> h_xyz;
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -97,7 +97,7 @@ struct arp_ctx {
     DevBuf<float4> sb;           // single-bond neighbour xyz, w = 1 if present
     DevBuf<int> gid;
     DevBuf<uint8_t> home, sel, plus, res_sel, res_plus;
-    bool has_res = false, has_bonds = false, has_h = false, has_sb = false, has_gid = false, has_home = false;
+    bool has_res = false, has_gid = false, has_home = false;
     bool sel_made = false;
     DevBuf<double> ring_c, ring_n;
     DevBuf<int> ring_res;
@@ -112,7 +112,6 @@ struct arp_ctx {
     DevBuf<float4> s_xyzm;
     DevBuf<int4> s_aux;
     DevBuf<SiftRec> s_rec;
-    bool records_dirty = true;
     Grid atom_grid, all_grid, ring_grid, amide_grid;   // contact grid (selection_plus, no H) / every atom at 6 A
     DevBuf<float4> a_xyzm;        // cell-sorted records of all_grid
     DevBuf<int4> a_aux;
@@ -289,10 +288,9 @@ int reserve_grid(arp_ctx* c, Grid& G, int n) {
     return ARP_OK;
 }
 
-// bin + scan + scatter (+ optional cell sort) for rings / amides.  P = point accessor; filter as in k_bin.
-template <class P, int FILTER>
-int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const double hi[3], double radius,
-               const uint8_t* active, const float4* xyzm, uint32_t req, uint32_t forb) {
+// bin + scan + scatter (+ optional cell sort) for rings / amides.  P = point accessor.
+template <class P>
+int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const double hi[3], double radius) {
     make_grid_desc(G.d, lo, hi, radius);
     G.radius = radius;
     G.n_points = n;
@@ -301,8 +299,7 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     {
         Prof p(c, SLOT_BIN);
         if (n > 0) {
-            hipLaunchKernelGGL((k_bin<P, FILTER>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, pts, n, G.d, active,
-                               xyzm, req, forb, G.cell_of.p, G.cnt.p);
+            hipLaunchKernelGGL((k_bin<P>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, pts, n, G.d, G.cell_of.p, G.cnt.p);
             CHK(check_launch(c, "k_bin"));
         }
     }
@@ -442,12 +439,12 @@ void host_bbox_d(const double* xyz, int64_t n, double lo[3], double hi[3]) {
 int ensure_ring_grid(arp_ctx* c) {
     if (c->ring_grid.valid) return ARP_OK;
     PtsD3 pts{c->ring_c.p};
-    return build_grid<PtsD3, 0>(c, c->ring_grid, pts, (int)c->nring, c->ring_lo, c->ring_hi, 6.0, nullptr, nullptr, 0, 0);
+    return build_grid<PtsD3>(c, c->ring_grid, pts, (int)c->nring, c->ring_lo, c->ring_hi, 6.0);
 }
 int ensure_amide_grid(arp_ctx* c) {
     if (c->amide_grid.valid) return ARP_OK;
     PtsF3 pts{c->am_c.p};
-    return build_grid<PtsF3, 0>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0, nullptr, nullptr, 0, 0);
+    return build_grid<PtsF3>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0);
 }
 
 // ---- enqueue-only building blocks (no host synchronisation) -----------------------------------
@@ -457,7 +454,6 @@ int enqueue_expansion(arp_ctx* c, double radius) {
     const int n = (int)c->n;
     HIPCHK(c, c->plus.reserve((size_t)std::max(n, 1)));
     c->sel_made = true;   // (I:1407 selection_plus = selection is written by the binning kernel below)
-    c->records_dirty = true;
     // I:1420-1424: search_all(6.0) over ALL atoms (hydrogens included)
     CHK(build_all_grid(c, radius, c->plus.p));
     CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
@@ -468,7 +464,6 @@ int enqueue_expansion(arp_ctx* c, double radius) {
                            0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
         CHK(check_launch(c, "k_search<MARK>"));
     }
-    c->records_dirty = true;   // M_PLUS changed; the contact grid composes fresh records
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
     c->contacts_valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
@@ -772,9 +767,8 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     HIPCHK(c, c->h_xyz_d.reserve(3));
     std::vector<float4> sb0((size_t)n, make_float4(0, 0, 0, 0));
     CHK(upload(c, c->sb, sb0.data(), (size_t)n));
-    c->has_bonds = c->has_h = c->has_sb = c->has_gid = c->has_home = false;
+    c->has_gid = c->has_home = false;
     c->sel_made = false;
-    c->records_dirty = true;
     c->contacts_valid = false;
     c->atom_grid.valid = false;
     c->all_grid_current = false;
@@ -791,7 +785,6 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
     CHK(upload(c, c->res_prev, prev, (size_t)nres));
     CHK(upload(c, c->res_next, next, (size_t)nres));
     c->has_res = true;
-    c->records_dirty = true;
     c->atom_grid.valid = false;
     c->all_grid_current = false;
     c->sel_made = false;
@@ -807,8 +800,6 @@ int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) 
     if (m < 0 || (m > 0 && !bond_idx)) FAIL(c, ARP_E_ARG, "arp_set_bonds: bad CSR");
     CHK(upload(c, c->bond_off, bond_off, (size_t)c->n + 1));
     CHK(upload(c, c->bond_idx, bond_idx, (size_t)m));
-    c->nbond = m;
-    c->has_bonds = true;
     c->contacts_valid = false;
     return ARP_OK;
 }
@@ -821,8 +812,6 @@ int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
     if (m < 0 || (m > 0 && !h_xyz)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: bad CSR");
     CHK(upload(c, c->h_off, h_off, (size_t)c->n + 1));
     CHK(upload(c, c->h_xyz_d, h_xyz, (size_t)m * 3));
-    c->nh = m;
-    c->has_h = true;
     c->contacts_valid = false;
     return ARP_OK;
 }
@@ -839,7 +828,6 @@ int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
                       : make_float4(c->h_xyz[3 * (size_t)k], c->h_xyz[3 * (size_t)k + 1], c->h_xyz[3 * (size_t)k + 2], 1.0f);
     }
     CHK(upload(c, c->sb, sb.data(), (size_t)c->n));
-    c->has_sb = true;
     c->contacts_valid = false;
     return ARP_OK;
 }
@@ -892,7 +880,6 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
         CHK(upload(c, c->gid, global_id, (size_t)c->n));
         c->has_gid = true;
     } else c->has_gid = false;
-    c->records_dirty = true;
     c->atom_grid.valid = false;   // M_HOME is part of the sorted records
     c->all_grid_current = false;
     c->contacts_valid = false;
@@ -925,7 +912,6 @@ int arp_set_single_bond_neighbour_coords(arp_ctx* c, const float* sb_xyz, const 
     for (int64_t i = 0; i < c->n; ++i)
         sb[i] = sb_present[i] ? make_float4(sb_xyz[3 * i], sb_xyz[3 * i + 1], sb_xyz[3 * i + 2], 1.0f) : make_float4(0, 0, 0, 0);
     CHK(upload(c, c->sb, sb.data(), (size_t)c->n));
-    c->has_sb = true;
     c->contacts_valid = false;
     return ARP_OK;
 }
@@ -943,7 +929,6 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
     CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));
     CHK(upload(c, c->am_sel, amide_sel, (size_t)c->namide)); CHK(upload(c, c->am_plus, amide_plus, (size_t)c->namide));
     c->sel_made = true;
-    c->records_dirty = true;
     c->atom_grid.valid = false;
     c->all_grid_current = false;
     c->contacts_valid = false;
@@ -957,7 +942,6 @@ int arp_set_selection(arp_ctx* c, const uint8_t* in_selection) {
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     c->sel_made = false;  // expansion pending
     c->all_grid_current = false;
-    c->records_dirty = true;
     c->contacts_valid = false;
     return ARP_OK;
 }

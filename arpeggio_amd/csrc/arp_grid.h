@@ -3,10 +3,11 @@
 // Stands in for Bio.PDB.NeighborSearch's KD-tree build (interactions.py:1394,1442).
 // Points are binned in float64 with a cell edge >= the search radius, so every pair
 // within the radius lies in a 27-cell stencil.  The sort is a counting sort:
-//   k_bin      cell id per point + histogram (atomicAdd on the cell counter)
-//   k_scan_*   exclusive prefix sum of the histogram (3-phase, LDS block scan)
-//   k_scatter  point -> slot inside its cell (atomicSub on the same counter)
-//   k_cellsort ascending point id inside each cell (deterministic order)
+//   k_bin      cell id per point + histogram (atomicAdd on the cell counter)   [rings / amides;
+//              atoms use k_bin_atoms / k_scatter_atoms of arp_pairs.h, which also build the records]
+//   k_scan_*   exclusive prefix sum of the histogram (one block up to 65 536 cells, 3-phase above)
+//   k_scatter  point -> slot inside its cell (atomicSub on the same counter, which ends at zero)
+//   k_cellsort ascending point id inside each cell (optional: deterministic device-side order)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,13 +19,6 @@ struct GridDesc {
     int nx, ny, nz, ncell;
 };
 
-struct PtsF4 {  // float4 records (atoms)
-    const float4* p;
-    __device__ __forceinline__ num::d3 get(int i) const {
-        float4 v = p[i];
-        return {(double)v.x, (double)v.y, (double)v.z};
-    }
-};
 struct PtsF3 {  // packed float32[3] (amide centres)
     const float* p;
     __device__ __forceinline__ num::d3 get(int i) const {
@@ -55,23 +49,12 @@ __device__ __forceinline__ int cell_index(const GridDesc& g, num::d3 p) {
     return (cz * g.ny + cy) * g.nx + cx;
 }
 
-// FILTER: 0 = every point, 1 = active[i] != 0, 2 = (meta & req) == req && !(meta & forb)
-template <class P, int FILTER>
-__global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, const uint8_t* __restrict__ active,
-                                             const float4* __restrict__ xyzm, uint32_t req, uint32_t forb,
-                                             int* __restrict__ cell_of, int* __restrict__ cell_cnt) {
+// cell id + histogram for every point (ring and amide centres)
+template <class P>
+__global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, int* __restrict__ cell_of, int* __restrict__ cell_cnt) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        bool on = true;
-        if (FILTER == 1) on = active[i] != 0;
-        if (FILTER == 2) {
-            uint32_t m = __float_as_uint(xyzm[i].w);
-            on = ((m & req) == req) && !(m & forb);
-        }
-        int c = -1;
-        if (on) {
-            c = cell_index(g, pts.get(i));
-            atomicAdd(&cell_cnt[c], 1);
-        }
+        const int c = cell_index(g, pts.get(i));
+        atomicAdd(&cell_cnt[c], 1);
         cell_of[i] = c;
     }
 }
@@ -223,19 +206,5 @@ __global__ __launch_bounds__(256) void k_cellsort(int ncell, const int* __restri
             }
             perm[b + 1] = v;
         }
-    }
-}
-
-// sorted (cell-ordered) copies of the atom records: coalesced writes, gathered reads.
-// The number of binned points is read on the device (start[ncell]) so that the host does
-// not have to synchronise between the sort and the search.
-__global__ __launch_bounds__(256) void k_gather(const int* __restrict__ m_ptr, const int* __restrict__ perm,
-                                                const float4* __restrict__ xyzm, const int4* __restrict__ aux,
-                                                float4* __restrict__ s_xyzm, int4* __restrict__ s_aux) {
-    const int m = *m_ptr;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) {
-        int i = perm[p];
-        s_xyzm[p] = xyzm[i];
-        s_aux[p] = aux[i];
     }
 }

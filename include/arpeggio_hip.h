@@ -302,7 +302,7 @@ int arp_run_stage(arp_ctx* ctx, int stage, double cutoff, double vdw_comp, int i
 int arp_get_stats(arp_ctx* ctx, int64_t stats[8]);
 /* When enabled, every kernel of arp_atom_contacts_launch is bracketed by
  * hipEvents on the context stream.  ms[k], launches[k] accumulate per kernel
- * slot: 0 bin, 1 scan, 2 scatter+cellsort, 3 gather, 4 contact search, 5 sift,
+ * slot: 0 bin, 1 scan, 2 scatter (+ record build), 3 unused, 4 contact search, 5 sift,
  * 6 selection-expansion search, 7 ring/amide kernels.
  * reset != 0 clears the accumulators after reading. */
 int arp_set_profiling(arp_ctx* ctx, int enabled);
