@@ -316,3 +316,183 @@ def slab_config(n_per_slab: int, n_slabs: int, seed: int = 4) -> PackedComplex:
     n_rings, n_amides = n // 100, n // 50
     return make_synthetic(n - 6 * n_rings - 4 * n_amides, seed=seed, box=(L * n_slabs, L, L), n_rings=n_rings,
                           n_amides=n_amides, id=f'slab_{n_slabs}x{n_per_slab}')
+
+
+def proteinlike(n_res: int = 480, seed: int = 2, n_waters: int = 300, id: str = 'proteinlike') -> PackedComplex:
+    """Stand-in for BASELINE configs[0]/[1] (`1tqn_h.cif`, ~7.7 k atoms incl. hydrogens; the file itself is not
+    available): one polypeptide chain 'A' laid out as a compact self-avoiding walk, explicit hydrogens present BOTH as
+    atoms (element H, like a hydrogenated mmCIF) and as `h_coords` of their parents, backbone + side-chain bonds,
+    phenyl rings on ~8 % of the residues, one amide per peptide bond, a haem-like ligand residue 508 (metal + four
+    five-membered rings), and waters (chain 'A', het flag W).  Deterministic (splitmix64)."""
+    rs = np.random.RandomState(splitmix64(seed, [0])[0] % (2 ** 31))   # only for the walk; everything is seeded
+    atoms = []      # dict(xyz, el, name, res, tmask, flags, hpar)
+    bonds = []
+    residues = []   # dict(name, seq, chain, poly)
+    rings = []      # (atom indices, residue)
+    amides = []     # (N, C, O, CA) atom indices, residue
+
+    def unit(v):
+        return v / np.linalg.norm(v)
+
+    def add_atom(xyz, el, name, res, tm=0, fl=0):
+        atoms.append(dict(xyz=np.asarray(xyz, float), el=el, name=name, res=res, tm=tm, fl=fl, h=[]))
+        return len(atoms) - 1
+
+    def add_h(parent, direction, name):
+        p = atoms[parent]
+        hx = p['xyz'] + 1.0 * unit(direction)
+        i = add_atom(hx, 'H', name, p['res'], 0, config.F_HYDROGEN)
+        p['h'].append(i)
+        bonds.append((parent, i))
+        return i
+
+    # compact walk of CA positions: steps of 3.8 A biased towards the centroid
+    ca = [np.zeros(3)]
+    for k in range(1, n_res):
+        for _ in range(200):
+            d = unit(rs.normal(size=3))
+            cand = ca[-1] + 3.8 * d - 0.02 * (ca[-1] - np.mean(ca, axis=0))
+            cand = ca[-1] + 3.8 * unit(cand - ca[-1])
+            if all(np.linalg.norm(cand - c) > 4.2 for c in ca[-40:-1]) and np.linalg.norm(cand - np.mean(ca, axis=0)) < 4.0 * n_res ** (1 / 3) + 6:
+                break
+        ca.append(cand)
+    ca = np.array(ca)
+    prev_c = None
+    for k in range(n_res):
+        aromatic = (splitmix64(seed, [1000 + k])[0] % 100) < 8
+        charged = (splitmix64(seed, [2000 + k])[0] % 100)
+        rname = 'PHE' if aromatic else ('MET' if charged < 4 else ('LYS' if charged < 12 else ('ASP' if charged < 20 else 'ALA')))
+        residues.append(dict(name=rname, seq=k + 1, chain='A', poly=True))
+        fwd = unit(ca[min(k + 1, n_res - 1)] - ca[max(k - 1, 0)] + 1e-3)
+        side = unit(np.cross(fwd, rs.normal(size=3)))
+        up = np.cross(fwd, side)
+        met = config.F_RES_MET if rname == 'MET' else 0
+        n_ = add_atom(ca[k] - 1.2 * fwd + 0.5 * side, 'N', 'N', k, T['hbond donor'], met)
+        a_ = add_atom(ca[k], 'C', 'CA', k, T['weak hbond donor'], config.F_ELEM_C | met)
+        c_ = add_atom(ca[k] + 1.25 * fwd + 0.55 * side, 'C', 'C', k, T['carbonyl carbon'], config.F_ELEM_C | met)
+        o_ = add_atom(atoms[c_]['xyz'] + 1.23 * unit(side + 0.3 * up), 'O', 'O', k,
+                      T['hbond acceptor'] | T['weak hbond acceptor'] | T['xbond acceptor'] | T['carbonyl oxygen'], met)
+        bonds.extend([(n_, a_), (a_, c_), (c_, o_)])
+        if prev_c is not None:
+            bonds.append((prev_c, n_))
+            amides.append(((n_, prev_c, prev_o, prev_ca), k - 1))
+        add_h(n_, -fwd + up, 'H')
+        add_h(a_, up - side, 'HA')
+        cb = add_atom(ca[k] - 1.5 * unit(side - 0.4 * up), 'C', 'CB', k, T['hydrophobe'] | T['weak hbond donor'], config.F_ELEM_C | met)
+        bonds.append((a_, cb))
+        add_h(cb, up, 'HB2'); add_h(cb, -fwd, 'HB3')
+        out = unit(atoms[cb]['xyz'] - ca[k])
+        if aromatic:      # phenyl ring hanging off CB
+            e1, e2 = out, unit(np.cross(out, up))
+            cen = atoms[cb]['xyz'] + 2.9 * out
+            ids = []
+            for q in range(6):
+                ang = q * np.pi / 3
+                ids.append(add_atom(cen + 1.39 * (np.cos(ang) * -e1 + np.sin(ang) * e2), 'C', ('CG', 'CD1', 'CE1', 'CZ', 'CE2', 'CD2')[q], k,
+                                    T['aromatic'] | T['hydrophobe'], config.F_ELEM_C))
+            for q in range(6):
+                bonds.append((ids[q], ids[(q + 1) % 6]))
+                if q:
+                    add_h(ids[q], atoms[ids[q]]['xyz'] - cen, 'H' + atoms[ids[q]]['name'][1:])
+            bonds.append((cb, ids[0]))
+            rings.append((ids, k))
+        elif rname == 'MET':
+            sd = add_atom(atoms[cb]['xyz'] + 1.8 * out, 'S', 'SD', k, T['hbond acceptor'] | T['hydrophobe'], config.F_ELEM_S | met)
+            ce = add_atom(atoms[sd]['xyz'] + 1.8 * unit(out + up), 'C', 'CE', k, T['hydrophobe'] | T['weak hbond donor'], config.F_ELEM_C | met)
+            bonds.extend([(cb, sd), (sd, ce)])
+            add_h(ce, up, 'HE1'); add_h(ce, out, 'HE2')
+        elif rname == 'LYS':
+            nz = add_atom(atoms[cb]['xyz'] + 1.5 * out, 'N', 'NZ', k, T['hbond donor'] | T['pos ionisable'], 0)
+            bonds.append((cb, nz))
+            add_h(nz, out, 'HZ1'); add_h(nz, up, 'HZ2'); add_h(nz, -up, 'HZ3')
+        elif rname == 'ASP':
+            cg = add_atom(atoms[cb]['xyz'] + 1.5 * out, 'C', 'CG', k, T['carbonyl carbon'], config.F_ELEM_C)
+            o1 = add_atom(atoms[cg]['xyz'] + 1.25 * unit(out + up), 'O', 'OD1', k, T['hbond acceptor'] | T['neg ionisable'] | T['carbonyl oxygen'] | T['weak hbond acceptor'], 0)
+            o2 = add_atom(atoms[cg]['xyz'] + 1.25 * unit(out - up), 'O', 'OD2', k, T['hbond acceptor'] | T['neg ionisable'] | T['weak hbond acceptor'], 0)
+            bonds.extend([(cb, cg), (cg, o1), (cg, o2)])
+        prev_c, prev_o, prev_ca = c_, o_, a_
+    # haem-like ligand, residue 508: metal + four pyrrole-like rings + a chlorinated tail, placed beside the chain centre
+    lig = len(residues)
+    residues.append(dict(name='HEM', seq=508, chain='A', poly=False))
+    c0 = np.mean(ca, axis=0) + np.array([0.0, 0.0, 1.5])
+    fe = add_atom(c0, 'FE', 'FE', lig, 0, config.F_METAL)
+    for q in range(4):
+        ang = q * np.pi / 2
+        cen = c0 + 3.0 * np.array([np.cos(ang), np.sin(ang), 0.0])
+        ids = []
+        for w in range(5):
+            a2 = ang + np.pi + w * 2 * np.pi / 5
+            el, nm = ('N', 'N' + 'ABCD'[q]) if w == 0 else ('C', f'C{w}' + 'ABCD'[q])
+            tm = (T['aromatic'] | T['hbond acceptor']) if w == 0 else (T['aromatic'] | T['hydrophobe'])
+            ids.append(add_atom(cen + 1.15 * np.array([np.cos(a2), np.sin(a2), 0.0]), el, nm, lig, tm, config.F_ELEM_C if w else 0))
+        for w in range(5):
+            bonds.append((ids[w], ids[(w + 1) % 5]))
+        bonds.append((fe, ids[0]))
+        rings.append((ids, lig))
+    cl_c = add_atom(c0 + np.array([0, 0, -2.0]), 'C', 'CBB', lig, T['hydrophobe'] | T['weak hbond donor'], config.F_ELEM_C)
+    cl = add_atom(c0 + np.array([0, 0, -3.75]), 'CL', 'CL1', lig, T['xbond donor'] | T['weak hbond acceptor'] | T['hydrophobe'], config.F_HALOGEN)
+    bonds.extend([(fe, cl_c), (cl_c, cl)])
+    # waters around the structure
+    wi = np.arange(n_waters, dtype=np.uint64)
+    span = ca.max(axis=0) - ca.min(axis=0) + 8.0
+    for k in range(n_waters):
+        r = len(residues)
+        residues.append(dict(name='HOH', seq=600 + k, chain='A', poly=False))
+        pos = ca.min(axis=0) - 4.0 + span * np.array([u01(seed, 90, wi[k:k + 1])[0], u01(seed, 91, wi[k:k + 1])[0], u01(seed, 92, wi[k:k + 1])[0]])
+        o = add_atom(pos, 'O', 'O', r, T['hbond acceptor'] | T['hbond donor'], config.F_WATER)
+        d1 = _unit_vectors(seed, 93, wi[k:k + 1])[0]
+        d2 = unit(np.cross(d1, [0.3, 0.5, 0.8]) - 0.3 * d1)
+        h1 = add_h(o, d1, 'H1'); h2 = add_h(o, d2, 'H2')
+        atoms[h1]['fl'] |= config.F_WATER; atoms[h2]['fl'] |= config.F_WATER
+
+    n = len(atoms)
+    xyz = np.array([a['xyz'] for a in atoms]).astype(np.float32)
+    el = [a['el'] for a in atoms]
+    vdw_t = {'C': 1.7, 'N': 1.55, 'O': 1.52, 'S': 1.8, 'H': 1.1, 'FE': 2.05, 'CL': 1.75}
+    cov_t = {'C': 0.76, 'N': 0.71, 'O': 0.66, 'S': 1.05, 'H': 0.31, 'FE': 1.32, 'CL': 1.02}
+    adj = [[] for _ in range(n)]
+    for i, j in bonds:
+        adj[i].append(j); adj[j].append(i)
+    bond_off = np.concatenate([[0], np.cumsum([len(a) for a in adj])]).astype(np.int32)
+    bond_idx = np.array([j for a in adj for j in a], np.int32)
+    # single-bond heavy neighbour: first bonded non-hydrogen atom outside an aromatic ring bond
+    ring_bonds = {frozenset((ids[q], ids[(q + 1) % len(ids)])) for ids, _ in rings for q in range(len(ids))}
+    sb = np.full(n, -1, np.int32)
+    for i in range(n):
+        for j in adj[i]:
+            if el[j] != 'H' and frozenset((i, j)) not in ring_bonds:
+                sb[i] = j
+                break
+    h_lists = [[xyz[h].astype(np.float64) for h in a['h']] for a in atoms]    # hydrogens as read from the (float32) atoms
+    h_off = np.concatenate([[0], np.cumsum([len(h) for h in h_lists])]).astype(np.int32)
+    h_xyz = np.array([h for hs in h_lists for h in hs]).reshape(-1, 3)
+    nres = len(residues)
+    res_flags = np.array([(config.R_POLYPEPTIDE | config.R_HAS_SEQ) if r['poly'] else 0 for r in residues], np.uint8)
+    res_prev = np.array([k - 1 if (r['poly'] and k > 0) else -1 for k, r in enumerate(residues)], np.int32)
+    res_next = np.array([k + 1 if (r['poly'] and k + 1 < n_res) else -1 for k, r in enumerate(residues)], np.int32)
+    rp = np.array([[xyz[i].astype(np.float64) for i in ids] for ids, _ in rings if len(ids) == 6]).reshape(-1, 6, 3)
+    ring_center, ring_normal = [], []
+    for ids, _ in rings:
+        pts = xyz[ids].astype(np.float64)
+        cen = pts.mean(axis=0)
+        v = pts - cen
+        nv = np.cross(v, np.roll(v, -1, axis=0)).sum(axis=0)
+        ring_center.append(cen); ring_normal.append(nv / np.linalg.norm(nv))
+    am_c, am_n = [], []
+    for (n_i, c_i, o_i, ca_i), _ in amides:
+        am_c.append(((xyz[c_i] + xyz[n_i]) / np.float32(2.0)).astype(np.float32))
+        nv = np.cross((xyz[o_i] - xyz[c_i]).astype(np.float64), (xyz[n_i] - xyz[c_i]).astype(np.float64))
+        am_n.append((nv / np.linalg.norm(nv)).astype(np.float32))
+    del rp
+    comp = {'ALA': 'P', 'PHE': 'P', 'MET': 'P', 'LYS': 'P', 'ASP': 'P', 'HEM': 'B', 'HOH': 'W'}
+    return PackedComplex(
+        xyz=xyz, vdw=[vdw_t[e] for e in el], cov=[cov_t[e] for e in el], type_mask=[a['tm'] for a in atoms],
+        flags=[a['fl'] for a in atoms], res_id=[a['res'] for a in atoms], res_flags=res_flags, res_prev=res_prev, res_next=res_next,
+        bond_off=bond_off, bond_idx=bond_idx, h_off=h_off, h_xyz=h_xyz, sb_nbr=sb,
+        ring_center=np.array(ring_center).reshape(-1, 3), ring_normal=np.array(ring_normal).reshape(-1, 3),
+        ring_res=[r for _, r in rings], ring_atoms=[np.array(ids, np.int32) for ids, _ in rings],
+        amide_center=np.array(am_c, np.float32).reshape(-1, 3), amide_normal=np.array(am_n, np.float32).reshape(-1, 3),
+        amide_res=[r for _, r in amides], amide_atoms=np.array([list(t) for t, _ in amides], np.int32).reshape(-1, 4),
+        atom_name=[a['name'] for a in atoms], element=el, serial=np.arange(1, n + 1, dtype=np.int32),
+        res_name=[r['name'] for r in residues], res_seq=[r['seq'] for r in residues], res_icode=[' '] * nres,
+        res_chain=[r['chain'] for r in residues], component_types=comp, id=id)

@@ -509,3 +509,42 @@ print('NCCL_WORLD1_OK')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert 'NCCL_WORLD1_OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize('selectors', [['/A/508/'], [], ['RESNAME:PHE'], ['LIGANDS']])
+def test_proteinlike_stand_in_for_1tqn(ctx, selectors):
+    """BASELINE configs[0]/[1] stand-in (`1tqn_h.cif` itself is unavailable): hydrogenated protein-like structure,
+    `-s /A/508/` and whole-structure runs through the drop-in class, every bag against the oracle."""
+    import oracle
+    from arpeggio_amd import synth
+    from arpeggio_amd.core import InteractionComplex, config, utils
+    pc = synth.proteinlike()
+    assert (pc.flags & config.F_HYDROGEN).astype(bool).sum() > 2000          # explicit hydrogens are atoms too
+    ic = InteractionComplex(pc)
+    ic._ctx = ctx
+    ic.initialize()
+    ic.run_arpeggio(selectors, 5.0, 0.1, False)
+    sel = np.zeros(pc.n_atoms, np.uint8)
+    sel[utils.selection_parser(selectors, pc) if selectors else slice(None)] = 1
+    oc = oracle.OracleComplex(pc)
+    plus = oc.make_selection(sel, use_grid=False)
+    assert np.array_equal(ic.selection_plus, np.nonzero(plus)[0])
+    exp = oc.atom_contacts(use_grid=False)
+    _assert_contacts_equal(ic._bags['atom_atom'], exp)
+    assert not (pc.flags[exp['i']] & config.F_HYDROGEN).any() and not (pc.flags[exp['j']] & config.F_HYDROGEN).any()
+    epp = oc.plane_plane()
+    o = np.lexsort((epp['end'], epp['bgn']))
+    epp = {k: v[o] for k, v in epp.items()}
+    _assert_planes_equal(ic._bags['plane_plane'], epp, ('bgn', 'end', 'type1', 'type2', 'ctype', 'dist'), ('dihedral', 'theta_bgn', 'theta_end'))
+    _assert_planes_equal(ic._bags['atom_plane'], oc.atom_plane(), ('atom', 'ring', 'mask', 'ctype', 'dist'), ('theta',))
+    _assert_planes_equal(ic._bags['group_group'], oc.group_group(), ('bgn', 'end', 'ctype', 'dist'), ('dihedral', 'theta'), tol=2e-4)
+    _assert_planes_equal(ic._bags['group_plane'], oc.group_plane(), ('amide', 'ring', 'ctype', 'dist'), ('dihedral', 'theta'))
+    contacts = ic.get_contacts()
+    assert len(contacts) == len(exp['i']) + len(epp['bgn']) + len(ic._bags['atom_plane']['atom']) + \
+        len(ic._bags['group_group']['bgn']) + len(ic._bags['group_plane']['amide'])
+    if selectors == ['/A/508/']:
+        ents = {c['interacting_entities'] for c in contacts}
+        assert 'INTER' in ents and 'INTRA_NON_SELECTION' in ents
+        hem = [c for c in contacts if c['type'] == 'atom-atom' and 'HEM' in (c['bgn']['label_comp_id'], c['end']['label_comp_id'])]
+        assert hem and all(c['bgn']['auth_seq_id'] == 508 or c['end']['auth_seq_id'] == 508 for c in hem)
+    ic._ctx = None     # the fixture owns the context

@@ -137,3 +137,16 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(base, f)).read()
                 assert not re.search(r'^\s*(import|from)\s+oracle\b', src, flags=re.M), f
                 assert 'liborc' not in src and 'ref_c' not in src, f
+
+
+def test_proteinlike_generator():
+    a, b = synth.proteinlike(n_res=60, seed=2, n_waters=20), synth.proteinlike(n_res=60, seed=2, n_waters=20)
+    assert np.array_equal(a.xyz, b.xyz) and np.array_equal(a.bond_idx, b.bond_idx)
+    a.validate()
+    h = (a.flags & config.F_HYDROGEN) != 0
+    assert h.sum() > 100 and a.h_xyz.shape[0] == h.sum()                 # every hydrogen atom is also its parent's h_coord
+    assert set(a.res_name) >= {'ALA', 'HEM', 'HOH'} and a.n_rings >= 4 and a.n_amides == 59
+    sel = utils.selection_parser(['/A/508/'], a)
+    assert len(sel) > 20 and {a.res_name[r] for r in a.res_id[sel]} == {'HEM'}
+    # peptide-bonded neighbours are sequence neighbours
+    assert a.res_next[0] == 1 and a.res_prev[1] == 0 and a.res_prev[0] == -1
