@@ -75,7 +75,9 @@ struct EventPair { int slot; hipEvent_t a, b; };
 
 struct arp_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream every pass is enqueued on (own_stream unless arp_use_stream)
+    hipStream_t own_stream = nullptr;
+    bool external_stream = false;
     std::string err;
     int num_cu = 256;
 
@@ -692,7 +694,8 @@ int arp_create(int device, arp_ctx** out) {
     c->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    c->stream = c->own_stream;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming);
@@ -731,7 +734,7 @@ void arp_destroy(arp_ctx* c) {
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -1312,7 +1315,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         int rc = enqueue_expansion(c, expand_radius);
         c->ctr_clean = false;
         CHK(rc);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->external_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
         return ARP_OK;
     }
     if (!c->sel_made) FAIL(c, ARP_E_ARG, "arp_run_stage: stage 0 has not run");
@@ -1325,7 +1328,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
             hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
                                c->res_sel.p, c->res_sel.p + nres);
         CHK(check_launch(c, "k_res_mark"));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->external_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
         return ARP_OK;
     }
     // stage 2: ring / amide sets from the (now globally reduced) residue sets, then every contact bag
@@ -1396,5 +1399,20 @@ int arp_get_kernel_times(arp_ctx* c, double ms[8], int64_t launches[8], int rese
 }
 
 uint64_t arp_stream_handle(arp_ctx* c) { return c ? (uint64_t)(uintptr_t)c->stream : 0; }
+
+int arp_use_stream(arp_ctx* c, uint64_t stream) {
+    if (!c) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (stream == 0) {
+        c->stream = c->own_stream;
+        c->external_stream = false;
+    } else {
+        c->stream = (hipStream_t)(uintptr_t)stream;
+        c->external_stream = true;
+    }
+    ++c->input_epoch;
+    return ARP_OK;
+}
 
 }  // extern "C"

@@ -348,10 +348,17 @@ class DeviceExchange:
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
 
-    def __init__(self, ctx, sh: Shard, dist, device):
+    def __init__(self, ctx, sh: Shard, dist, device, share_stream: bool = True):
         import torch
         self.torch, self.ctx, self.sh, self.dist, self.device = torch, ctx, sh, dist, device
         self.t_plus = self.t_res = None
+        self._keep = []
+        # On the GPU the context is told to enqueue on a torch stream: kernels of the stages and the exchange
+        # ops are then ordered on ONE stream and stages 0 / 1 need no host synchronisation.
+        self.stream = None
+        if share_stream and device is not None and getattr(device, 'type', '') == 'cuda':
+            self.stream = torch.cuda.Stream(device=device)
+            ctx.use_stream(self.stream.cuda_stream)
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(device if device is not None else 'cpu')
         self.send_idx, self.recv_idx, self.recv_buf = {}, {}, {}
         for side, ids in ((-1, sh.send_left), (+1, sh.send_right)):
@@ -371,31 +378,38 @@ class DeviceExchange:
         return self.torch.as_tensor(self._Alias(ptr, nb), device=self.device)
 
     def _sync(self):
-        if self._on_gpu():
+        if self._on_gpu() and self.stream is None:     # own-stream contexts: hand over through the host
             self.torch.cuda.current_stream(self.device).synchronize()
 
+    def _scope(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def exchange_plus(self):
-        torch, dist = self.torch, self.dist
+        dist = self.dist
         if self.t_plus is None:
             self.t_plus = self._alias(self.ctx.BUF_PLUS)
-        ops, keep = [], []
-        for side, idx in self.send_idx.items():
-            buf = self.t_plus[idx]
-            keep.append(buf)
-            ops.append(dist.P2POp(dist.isend, buf, self.sh.rank + side))
-            ops.append(dist.P2POp(dist.irecv, self.recv_buf[side], self.sh.rank + side))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for side, idx in self.recv_idx.items():
-            self.t_plus[idx] = self.recv_buf[side]
+        with self._scope():
+            ops, keep = [], []
+            for side, idx in self.send_idx.items():
+                buf = self.t_plus[idx]
+                keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, self.sh.rank + side))
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf[side], self.sh.rank + side))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for side, idx in self.recv_idx.items():
+                self.t_plus[idx] = self.recv_buf[side]
+            self._keep = keep      # send buffers stay referenced until the next exchange
         self._sync()
 
     def reduce_residue_sets(self):
-        torch, dist = self.torch, self.dist
+        dist = self.dist
         if self.t_res is None:
             self.t_res = self._alias(self.ctx.BUF_RES_SETS)
-        dist.all_reduce(self.t_res, op=dist.ReduceOp.MAX)
+        with self._scope():
+            dist.all_reduce(self.t_res, op=dist.ReduceOp.MAX)
         self._sync()
 
 

@@ -307,9 +307,14 @@ int arp_get_stats(arp_ctx* ctx, int64_t stats[8]);
  * reset != 0 clears the accumulators after reading. */
 int arp_set_profiling(arp_ctx* ctx, int enabled);
 int arp_get_kernel_times(arp_ctx* ctx, double ms[8], int64_t launches[8], int reset);
-/* Address of the context's hipStream_t (as an integer), for callers that
- * want to order their own work against it. */
+/* The context's hipStream_t (as an integer), for callers that want to order their own work
+ * against it. */
 uint64_t arp_stream_handle(arp_ctx* ctx);
+/* Enqueue every pass on the caller's stream instead (0 = back to the context's own stream).
+ * With a caller stream, stages 0 and 1 of arp_run_stage return WITHOUT synchronising: the caller
+ * orders its exchange (e.g. RCCL through torch.distributed) on the same stream, and only stage 2
+ * blocks.  The stream must outlive the context or be reset with 0 first. */
+int arp_use_stream(arp_ctx* ctx, uint64_t stream);
 
 #ifdef __cplusplus
 }

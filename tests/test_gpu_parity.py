@@ -490,9 +490,14 @@ sel = (full.res_id % 7 == 1).astype(np.uint8)
 sh = sharding.make_shard_distributed(full, 0, 1, dist, device=dev, sel=sel)
 ctx = _capi.Context(0)
 sharding.upload_shard(ctx, sh)
-ex = sharding.DeviceExchange(ctx, sh, dist, dev)
-c1 = sharding.run_shard_device(ctx, ex)
+ex = sharding.DeviceExchange(ctx, sh, dist, dev)          # shares one torch stream with the context: no host syncs in stages 0/1
+assert ex.stream is not None and ctx.stream_handle() == ex.stream.cuda_stream
+for _ in range(3):
+    c1 = sharding.run_shard_device(ctx, ex)
 a = ctx.atom_contacts_fetch(c1['atom_atom'])
+ctx.use_stream(0)
+ex2 = sharding.DeviceExchange(ctx, sh, dist, dev, share_stream=False)   # host-synchronised variant
+assert sharding.run_shard_device(ctx, ex2) == c1
 assert ex.t_plus.data_ptr() == ctx.device_buffer(ctx.BUF_PLUS)[0] and int(ex.t_plus.sum().item()) > 0
 ref = _capi.Context(0)
 ref.set_complex(full)
