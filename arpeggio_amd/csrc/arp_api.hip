@@ -534,7 +534,8 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             Prof p(c, SLOT_SIFT);
             static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 8));
             hipLaunchKernelGGL(k_sift, dim3(c->num_cu * sift_blocks_per_cu), dim3(256), 0, c->stream, c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap,
-                               c->s_rec.p, c->bond_idx.p, c->h_xyz_d.p, c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p,
+                               c->s_rec.p, c->bond_idx.p, c->h_xyz_d.p, c->has_gid ? c->gid.p : nullptr, vdw_comp, env_int("ARP_ABLATE", 0),
+                               c->out_i.p,
                                c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p, (int*)(c->d_ctr + C_ERR));
             CHK(check_launch(c, "k_sift"));
         }

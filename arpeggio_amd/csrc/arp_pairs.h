@@ -452,7 +452,7 @@ __device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) 
 __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
                                               const SiftRec* __restrict__ s_rec, const int* __restrict__ bond_idx,
                                               const double* __restrict__ h_xyz,
-                                              const int* __restrict__ gid, double comp, int* __restrict__ out_i,
+                                              const int* __restrict__ gid, double comp, int ablate, int* __restrict__ out_i,
                                               int* __restrict__ out_j, float* __restrict__ out_d,
                                               uint16_t* __restrict__ out_s, uint8_t* __restrict__ out_ct,
                                               int* __restrict__ err) {
@@ -503,43 +503,57 @@ __global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, co
         }
         // interactions.py:786: not clash (covalent pairs do get feature flags) and d <= 4.5
         if (!(s & ARP_S_CLASH) && d <= (float)4.5) {
-            const int hb0 = qb.csr.x, hb1 = qb.csr.x + qb.csr.y, he0 = qe.csr.x, he1 = qe.csr.x + qe.csr.y;
-            // interactions.py:791-819
+            const int hb0 = qb.csr.x, hb1 = (ablate & 16) ? hb0 : qb.csr.x + qb.csr.y, he0 = qe.csr.x,
+                      he1 = (ablate & 16) ? he0 : qe.csr.x + qe.csr.y;   // (ablate: profiling aid, ARP_ABLATE)
+            // interactions.py:791-819 (hbond / polar) and 857-886 (weak hbond / weak polar).  The flags that need no
+            // geometry are set here; the up-to-six hydrogen-geometry evaluations of a pair become a per-lane task list
+            // so that lanes needing DIFFERENT branches run side by side in one pass of the wave instead of one
+            // mostly-idle pass per branch:
+            //   0 is_hbond(bgn, end)   1 is_hbond(end, bgn)          (if / elif, I:804-819)
+            //   2 is_weak_hbond(end, bgn)   3 is_weak_hbond(bgn, end)   4 / 5 is_halogen_weak_hbond  (I:857-886)
+            unsigned need = 0;
             if (bw && d <= f_vdw_comp) {
                 if (te & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
             } else if (ew && d <= f_vdw_comp) {
                 if (tb & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
             } else {
                 if ((tb & ARP_T_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) {
-                    if (hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 1.57, ARP_COS_1_57)) s |= ARP_S_HBOND;
+                    need |= 1u;
                     if (d <= (float)3.5) s |= ARP_S_POLAR;
                 } else if ((te & ARP_T_HBOND_DONOR) && (tb & ARP_T_HBOND_ACCEPTOR)) {
-                    if (hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 1.57, ARP_COS_1_57)) s |= ARP_S_HBOND;
+                    need |= 2u;
                     if (d <= (float)3.5) s |= ARP_S_POLAR;
                 }
             }
-            // interactions.py:857-886: four independent ifs, each overwrites SIFt[6]
-            bool weak = false;
-            const bool wp = d <= (float)3.5;
-            if ((tb & ARP_T_HBOND_ACCEPTOR) && (te & ARP_T_WEAK_HBOND_DONOR)) {
-                weak = hbond_like(xe, h_xyz, he0, he1, xb, rb.x, comp, 2.27, ARP_COS_2_27);
-                if (wp) s |= ARP_S_WEAK_POLAR;
+            if ((tb & ARP_T_HBOND_ACCEPTOR) && (te & ARP_T_WEAK_HBOND_DONOR)) need |= 4u;
+            if ((tb & ARP_T_WEAK_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) need |= 8u;
+            if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) && (te & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 16u;
+            if ((te & ARP_T_WEAK_HBOND_ACCEPTOR) && (me & M_HALOGEN) && (tb & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 32u;
+            if ((need & 60u) && d <= (float)3.5) s |= ARP_S_WEAK_POLAR;   // each applicable weak branch sets it (I:861,869,877,885)
+            unsigned todo = need, res = 0;
+            while (todo) {                     // divergent trip counts: a lane leaves when its list is empty
+                const int kind = __ffs(todo) - 1;
+                todo &= todo - 1;
+                bool r;
+                if (kind < 4) {
+                    const bool donor_b = (kind == 0) || (kind == 3);
+                    const double amin = (kind < 2) ? 1.57 : 2.27;
+                    const double cmin = (kind < 2) ? ARP_COS_1_57 : ARP_COS_2_27;
+                    r = hbond_like(donor_b ? xb : xe, h_xyz, donor_b ? hb0 : he0, donor_b ? hb1 : he1, donor_b ? xe : xb,
+                                   donor_b ? re.x : rb.x, comp, amin, cmin);
+                } else {
+                    const bool hal_b = kind == 4;
+                    r = halogen_weak(hal_b ? xb : xe, hal_b ? sbb : sbe, hal_b ? rb.x : re.x, h_xyz, hal_b ? he0 : hb0,
+                                     hal_b ? he1 : hb1, comp);
+                }
+                res |= (r ? 1u : 0u) << kind;
             }
-            if ((tb & ARP_T_WEAK_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) {
-                weak = hbond_like(xb, h_xyz, hb0, hb1, xe, re.x, comp, 2.27, ARP_COS_2_27);
-                if (wp) s |= ARP_S_WEAK_POLAR;
+            if (res & 3u) s |= ARP_S_HBOND;
+            // the LAST applicable weak branch decides SIFt[6] (every branch overwrites it)
+            if (need & 60u) {
+                const int last = 31 - __clz((int)(need & 60u));
+                if ((res >> last) & 1u) s |= ARP_S_WEAK_HBOND;
             }
-            if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) &&
-                (te & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) {
-                weak = halogen_weak(xb, sbb, rb.x, h_xyz, he0, he1, comp);
-                if (wp) s |= ARP_S_WEAK_POLAR;
-            }
-            if ((te & ARP_T_WEAK_HBOND_ACCEPTOR) && (me & M_HALOGEN) &&
-                (tb & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) {
-                weak = halogen_weak(xe, sbe, re.x, h_xyz, hb0, hb1, comp);
-                if (wp) s |= ARP_S_WEAK_POLAR;
-            }
-            if (weak) s |= ARP_S_WEAK_HBOND;
             // interactions.py:889-895
             if (d <= f_vdw_comp) {
                 if ((tb & ARP_T_XBOND_DONOR) && (te & ARP_T_XBOND_ACCEPTOR)) {
