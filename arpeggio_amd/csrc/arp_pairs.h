@@ -449,7 +449,10 @@ __device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) 
 }
 
 // One thread per accepted pair (full 64-lane occupancy for the divergent chemistry).
-__global__ __launch_bounds__(256) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
+#ifndef SIFT_MIN_WAVES
+#define SIFT_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for (sweep in profiles/README.md)
+#endif
+__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
                                               const SiftRec* __restrict__ s_rec, const int* __restrict__ bond_idx,
                                               const double* __restrict__ h_xyz,
                                               const int* __restrict__ gid, double comp, int ablate, int* __restrict__ out_i,
