@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                     // squares, two rounded sums), so outside the +-1e-5 band the float32 answer IS the
                     // float64 answer; inside the band (rare) the whole wave takes the exact float64 test.
                     const float dxf = hx - xj.x, dyf = hy - xj.y, dzf = hz - xj.z;
-                    const float d2f = dxf * dxf + dyf * dyf + dzf * dzf;
+                    const float d2f = fmaf(dzf, dzf, fmaf(dyf, dyf, dxf * dxf));   // any rounding order fits the 4e-7 bound
                     unsigned long long mhit = __ballot(d2f <= r2_lo) & m_tested;
                     const unsigned long long m_band = __ballot(d2f > r2_lo && d2f <= r2_hi) & m_tested;
                     if (m_band) {
@@ -319,22 +319,23 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                     bool pass = hit;
                     int pb, pe;
                     if (MODE == MODE_CONTACTS) {
-                        // canonical orientation: bgn = lower packed index
+                        // canonical orientation: bgn = lower packed index.  Only three things depend on it — which
+                        // residue's polypeptide flag is read (I:734 tests res_end twice), whose HOME bit decides
+                        // ownership, and the order of the stored positions; the same-residue and sequence-neighbour
+                        // tests are symmetric in the two atoms.
                         const bool h_first = ah.x < aj.x;
-                        const int4 ab = h_first ? ah : aj;
-                        const int4 ae = h_first ? aj : ah;
-                        const uint32_t mb = h_first ? mh : mj;
-                        const uint32_t me = h_first ? mj : mh;
+                        const uint32_t m_bgn = h_first ? mh : mj;
+                        const uint32_t m_end = h_first ? mj : mh;
                         pb = h_first ? h : j;
                         pe = h_first ? j : h;
                         // interactions.py:729 same residue
-                        if (ab.y == ae.y) pass = false;
-                        // interactions.py:733-741 sequence-adjacent residues (res_end tested twice)
-                        if (!include_seq_adj && (me & M_RES_POLY) && (mb & M_RES_HASSEQ) && (me & M_RES_HASSEQ)) {
-                            if (ab.w == ae.y || ab.z == ae.y || ae.w == ab.y || ae.z == ab.y) pass = false;
+                        if (ah.y == aj.y) pass = false;
+                        // interactions.py:733-741 sequence-adjacent residues
+                        if (!include_seq_adj && (m_end & M_RES_POLY) && (mh & mj & M_RES_HASSEQ)) {
+                            if (ah.w == aj.y || ah.z == aj.y || aj.w == ah.y || aj.z == ah.y) pass = false;
                         }
                         // multi-GPU ownership: the rank owning the bgn atom emits the pair
-                        if (!(mb & M_HOME)) pass = false;
+                        if (!(m_bgn & M_HOME)) pass = false;
                     } else {  // MODE_PAIRS: raw search_all, report packed ids (i < j)
                         pb = min(ah.x, aj.x);
                         pe = max(ah.x, aj.x);
