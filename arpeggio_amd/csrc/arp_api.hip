@@ -114,6 +114,11 @@ struct arp_ctx {
     DevBuf<float4> s_xyzm;
     DevBuf<int4> s_aux;
     DevBuf<SiftRec> s_rec;
+    DevBuf<int4> st_csr;          // selection-independent record columns, composed once per structure (k_prepare_static)
+    DevBuf<float4> st_sbl;
+    DevBuf<int4> st_aux;
+    DevBuf<float4> st_xyzm;
+    bool static_dirty = true;
     Grid atom_grid, all_grid, ring_grid, amide_grid;   // contact grid (selection_plus, no H) / every atom at 6 A
     DevBuf<float4> a_xyzm;        // cell-sorted records of all_grid
     DevBuf<int4> a_aux;
@@ -322,16 +327,38 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     return ARP_OK;
 }
 
-RawAtoms raw_atoms(arp_ctx* c) {
+// selection-independent part of every atom record, rebuilt only when an input changed
+int ensure_static(arp_ctx* c) {
+    if (!c->static_dirty) return ARP_OK;
+    const int n = (int)c->n;
+    HIPCHK(c, c->st_csr.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->st_sbl.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->st_xyzm.reserve((size_t)std::max(n, 1)));
     RawAtoms r;
     r.xyz = c->xyz.p; r.tmask = c->tmask.p; r.flags = c->flags.p; r.res_id = c->res_id.p;
     r.res_flags = c->has_res ? c->res_flags.p : nullptr;
     r.res_prev = c->has_res ? c->res_prev.p : nullptr;
     r.res_next = c->has_res ? c->res_next.p : nullptr;
-    r.sel = c->sel_made ? c->sel.p : nullptr;
-    r.plus = c->sel_made ? c->plus.p : nullptr;
     r.home = c->has_home ? c->home.p : nullptr;
     r.rad = c->rad.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.sb = c->sb.p;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_csr.p, c->st_sbl.p);
+        CHK(check_launch(c, "k_prepare_static"));
+    }
+    c->static_dirty = false;
+    return ARP_OK;
+}
+
+StaticAtoms static_atoms(arp_ctx* c) {
+    StaticAtoms r;
+    r.xyzm = c->st_xyzm.p;
+    r.rad = c->rad.p;
+    r.csr = c->st_csr.p;
+    r.sbl = c->st_sbl.p;
+    r.aux = c->st_aux.p;
+    r.sel = c->sel_made ? c->sel.p : nullptr;
+    r.plus = c->sel_made ? c->plus.p : nullptr;
     return r;
 }
 
@@ -348,7 +375,8 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
     HIPCHK(c, sx.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, sa.reserve((size_t)std::max(n, 1)));
     if (srec) HIPCHK(c, srec->reserve((size_t)std::max(n, 1)));
-    const RawAtoms r = raw_atoms(c);
+    CHK(ensure_static(c));
+    const StaticAtoms r = static_atoms(c);
     {
         Prof p(c, SLOT_BIN);
         if (n > 0) {
@@ -724,7 +752,7 @@ void arp_destroy(arp_ctx* c) {
     c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
-    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release();
+    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->st_csr.release(); c->st_sbl.release(); c->st_aux.release(); c->st_xyzm.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
@@ -749,6 +777,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     if (n > 0 && (!xyz || !vdw || !cov || !type_mask || !flags || !res_id)) FAIL(c, ARP_E_ARG, "arp_set_atoms: null input");
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     c->n = n;
     c->h_xyz.assign(xyz, xyz + 3 * n);
     host_bbox(xyz, n, c->lo, c->hi);
@@ -784,6 +813,7 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
     if (nres < 0 || (nres > 0 && (!res_flags || !prev || !next))) FAIL(c, ARP_E_ARG, "arp_set_residues: bad input");
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     c->nres = nres;
     CHK(upload(c, c->res_flags, res_flags, (size_t)nres));
     CHK(upload(c, c->res_prev, prev, (size_t)nres));
@@ -800,6 +830,7 @@ int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) 
     if (!c || !bond_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     const int64_t m = bond_off[c->n];
     if (m < 0 || (m > 0 && !bond_idx)) FAIL(c, ARP_E_ARG, "arp_set_bonds: bad CSR");
     CHK(upload(c, c->bond_off, bond_off, (size_t)c->n + 1));
@@ -812,6 +843,7 @@ int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
     if (!c || !h_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     const int64_t m = h_off[c->n];
     if (m < 0 || (m > 0 && !h_xyz)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: bad CSR");
     CHK(upload(c, c->h_off, h_off, (size_t)c->n + 1));
@@ -824,6 +856,7 @@ int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
     if (!c || (c->n > 0 && !sb_nbr)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     std::vector<float4> sb((size_t)c->n);
     for (int64_t i = 0; i < c->n; ++i) {
         int k = sb_nbr[i];
@@ -841,6 +874,7 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
     if (nring < 0 || (nring > 0 && (!center || !normal || !ring_res))) FAIL(c, ARP_E_ARG, "arp_set_rings: bad input");
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     c->nring = nring;
     host_bbox_d(center, nring, c->ring_lo, c->ring_hi);
     CHK(upload(c, c->ring_c, center, (size_t)nring * 3));
@@ -859,6 +893,7 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
     if (namide < 0 || (namide > 0 && (!center || !normal || !amide_res))) FAIL(c, ARP_E_ARG, "arp_set_amides: bad input");
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     c->namide = namide;
     host_bbox(center, namide, c->am_lo, c->am_hi);
     CHK(upload(c, c->am_c, center, (size_t)namide * 3));
@@ -876,6 +911,7 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     if (is_home) { CHK(upload(c, c->home, is_home, (size_t)c->n)); c->has_home = true; }
     else c->has_home = false;
     if (global_id) {
@@ -895,6 +931,7 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     if (!ring_home && !ring_gid && !amide_home && !amide_gid) { c->has_group_owner = false; return ARP_OK; }
     if ((c->nring > 0 && (!ring_home || !ring_gid)) || (c->namide > 0 && (!amide_home || !amide_gid)))
         FAIL(c, ARP_E_ARG, "arp_set_group_ownership: all four arrays are required");
@@ -912,6 +949,7 @@ int arp_set_single_bond_neighbour_coords(arp_ctx* c, const float* sb_xyz, const 
     if (!c || (c->n > 0 && (!sb_xyz || !sb_present))) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     std::vector<float4> sb((size_t)c->n);
     for (int64_t i = 0; i < c->n; ++i)
         sb[i] = sb_present[i] ? make_float4(sb_xyz[3 * i], sb_xyz[3 * i + 1], sb_xyz[3 * i + 2], 1.0f) : make_float4(0, 0, 0, 0);
@@ -928,6 +966,7 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
         FAIL(c, ARP_E_ARG, "arp_set_selection_state: null input");
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
+    c->static_dirty = true;
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     CHK(upload(c, c->plus, in_plus, (size_t)c->n));
     CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));

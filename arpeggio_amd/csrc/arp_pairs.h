@@ -65,8 +65,6 @@ struct RawAtoms {
     const uint8_t* res_flags;   // null: no residue table
     const int* res_prev;
     const int* res_next;
-    const uint8_t* sel;         // null: nothing selected
-    const uint8_t* plus;        // null: everything in selection_plus
     const uint8_t* home;        // null: every atom owned by this rank
     const double2* rad;         // {vdw, cov}
     const int* h_off;
@@ -82,33 +80,57 @@ struct __attribute__((aligned(64))) SiftRec {
     float4 sbl;       // single-bond neighbour x, y, z; w = bit pattern of the local atom id
 };
 
-// atom record: xyzm = {x, y, z, meta}; aux = {local id, residue, prev residue, next residue}
-__device__ __forceinline__ void compose_record(const RawAtoms& r, int i, float4& xyzm, int4& aux) {
-    float4 v = r.xyz[i];
-    const int res = r.res_id[i];
-    uint32_t m = (uint32_t)(r.tmask[i] & M_TMASK) | ((uint32_t)(r.flags[i] & 0x7F) << M_FLAG_SHIFT);
+// Everything of an atom record that does not depend on the selection, composed once per structure and
+// kept as 16-byte columns so that the per-pass grid builds read them coalesced.
+struct StaticAtoms {
+    const float4* xyzm;         // x, y, z, static meta
+    const int4* aux;            // local id, residue, previous residue, next residue
+    const double2* rad;         // the uploaded radii, untouched
+    const int4* csr;            // h_off, h_count, bond_off, bond_count
+    const float4* sbl;          // single-bond neighbour xyz, w = bit pattern of the local id
+    const uint8_t* sel;         // null: nothing selected
+    const uint8_t* plus;        // null: everything in selection_plus
+};
+
+__global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
+                                                        int4* __restrict__ st_csr, float4* __restrict__ st_sbl) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = r.xyz[i];
+        const int res = r.res_id[i];
+        uint32_t m = (uint32_t)(r.tmask[i] & M_TMASK) | ((uint32_t)(r.flags[i] & 0x7F) << M_FLAG_SHIFT);
+        if (!r.home || r.home[i]) m |= M_HOME;
+        const uint8_t rf = r.res_flags ? r.res_flags[res] : 0;
+        if (rf & ARP_R_POLYPEPTIDE) m |= M_RES_POLY;
+        if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
+        const float4 sb = r.sb[i];
+        if (sb.w != 0.0f) m |= M_HAS_SB;
+        v.w = __uint_as_float(m);
+        const int h0 = r.h_off[i], b0 = r.bond_off[i];
+        st_xyzm[i] = v;
+        st_csr[i] = make_int4(h0, r.h_off[i + 1] - h0, b0, r.bond_off[i + 1] - b0);
+        st_sbl[i] = make_float4(sb.x, sb.y, sb.z, __int_as_float(i));
+        st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
+    }
+}
+
+// search record of atom i: static part + the selection bits of the moment
+__device__ __forceinline__ float4 compose_xyzm(const StaticAtoms& r, int i) {
+    float4 v = r.xyzm[i];
+    uint32_t m = __float_as_uint(v.w);
     if (r.sel && r.sel[i]) m |= M_SEL;
     if (!r.plus || r.plus[i]) m |= M_PLUS;
-    if (!r.home || r.home[i]) m |= M_HOME;
-    const uint8_t rf = r.res_flags ? r.res_flags[res] : 0;
-    if (rf & ARP_R_POLYPEPTIDE) m |= M_RES_POLY;
-    if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
-    if (r.sb[i].w != 0.0f) m |= M_HAS_SB;
     v.w = __uint_as_float(m);
-    xyzm = v;
-    aux = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
+    return v;
 }
 
 // cell id + histogram of the atoms passing the filter:
 // FILTER 1: active[i] != 0;  FILTER 2: (meta & req) == req && !(meta & forb)
 template <int FILTER>
-__global__ __launch_bounds__(256) void k_bin_atoms(RawAtoms r, int n, GridDesc g, const uint8_t* __restrict__ active,
+__global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDesc g, const uint8_t* __restrict__ active,
                                                    uint32_t req, uint32_t forb, int* __restrict__ cell_of,
                                                    int* __restrict__ cell_cnt, uint8_t* __restrict__ plus_init) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 xyzm;
-        int4 aux;
-        compose_record(r, i, xyzm, aux);
+        const float4 xyzm = compose_xyzm(r, i);
         if (plus_init) plus_init[i] = r.sel[i];   // I:1407: selection_plus starts as the selection
         const uint32_t m = __float_as_uint(xyzm.w);
         const bool on = (FILTER == 1) ? (active[i] != 0) : (((m & req) == req) && !(m & forb));
@@ -122,28 +144,28 @@ __global__ __launch_bounds__(256) void k_bin_atoms(RawAtoms r, int n, GridDesc g
 }
 
 // counting-sort scatter fused with the record build: every binned atom writes its cell-sorted
-// search record (xyzm + aux, 32 B) and its one-line sift record (64 B).
-__global__ __launch_bounds__(256) void k_scatter_atoms(RawAtoms r, int n, const int* __restrict__ cell_of,
+// search record (xyzm + aux, 32 B) and, for the contact grid, its one-line sift record (64 B).
+__global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int* __restrict__ cell_of,
                                                        const int* __restrict__ start, int* __restrict__ cell_cnt,
                                                        float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
                                                        SiftRec* __restrict__ s_rec) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int c = cell_of[i];
         if (c < 0) continue;
+        // the record does not depend on the slot: its loads are in flight while the atomic returns
+        const float4 xyzm = compose_xyzm(r, i);
+        const int4 aux = r.aux[i];
+        SiftRec q;
+        if (s_rec) {
+            q.rad = r.rad[i];
+            q.csr = r.csr[i];
+            q.sbl = r.sbl[i];
+        }
         const int pos = start[c] + atomicSub(&cell_cnt[c], 1) - 1;
-        float4 xyzm;
-        int4 aux;
-        compose_record(r, i, xyzm, aux);
         s_xyzm[pos] = xyzm;
         s_aux[pos] = aux;
         if (s_rec) {   // the contact grid also carries the one-line sift record
-            SiftRec q;
             q.xyzm = xyzm;
-            q.rad = r.rad[i];
-            const int h0 = r.h_off[i], b0 = r.bond_off[i];
-            q.csr = make_int4(h0, r.h_off[i + 1] - h0, b0, r.bond_off[i + 1] - b0);
-            const float4 sb = r.sb[i];
-            q.sbl = make_float4(sb.x, sb.y, sb.z, __int_as_float(i));
             s_rec[pos] = q;
         }
     }
