@@ -28,6 +28,7 @@ SYMBOLS = (
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
+    'arp_get_host_times',
 )
 
 _lib = None
@@ -83,6 +84,7 @@ def load():
     L.arp_get_stats.argtypes = [vp, vp]
     L.arp_set_profiling.argtypes = [vp, i32]
     L.arp_get_kernel_times.argtypes = [vp, vp, vp, i32]
+    L.arp_get_host_times.argtypes = [vp, vp, vp, i32]
     L.arp_stream_handle.argtypes = [vp]
     L.arp_use_stream.argtypes = [vp, C.c_uint64]
     L.arp_stream_handle.restype = C.c_uint64
@@ -367,6 +369,13 @@ class Context:
         ms, ln = np.zeros(8, np.float64), np.zeros(8, np.int64)
         self._check(self._L.arp_get_kernel_times(self._h, _p(ms), _p(ln), int(reset)), 'arp_get_kernel_times')
         return {name: dict(ms=float(ms[k]), launches=int(ln[k])) for k, name in enumerate(KERNEL_SLOTS)}
+
+    def host_times(self, reset=False):
+        """Per-pass host cost of run_launch: (enqueue_us, wait_us) averaged over the passes since the last reset."""
+        us, n = np.zeros(2, np.float64), np.zeros(1, np.int64)
+        self._check(self._L.arp_get_host_times(self._h, _p(us), _p(n), int(reset)), 'arp_get_host_times')
+        k = max(int(n[0]), 1)
+        return dict(enqueue_us=float(us[0]) / k, wait_us=float(us[1]) / k, passes=int(n[0]))
 
     def use_stream(self, stream_handle):
         self._check(self._L.arp_use_stream(self._h, int(stream_handle)), 'arp_use_stream')

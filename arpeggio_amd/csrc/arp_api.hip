@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -119,6 +120,8 @@ struct arp_ctx {
     DevBuf<int4> st_aux;
     DevBuf<float4> st_xyzm;
     bool static_dirty = true;
+    double host_enqueue_us = 0, host_wait_us = 0;   // arp_run_launch: time spent enqueueing / waiting (arp_get_host_times)
+    int64_t host_passes = 0;
     Grid atom_grid, all_grid, ring_grid, amide_grid;   // contact grid (selection_plus, no H) / every atom at 6 A
     DevBuf<float4> a_xyzm;        // cell-sorted records of all_grid
     DevBuf<int4> a_aux;
@@ -139,6 +142,7 @@ struct arp_ctx {
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t contact_cells = 0;
     bool ctr_clean = false;
+    bool ctr_zero_ok = false;    // the last arp_run_launch left the whole block zeroed (k_publish_counters) and nothing touched it since
     // ---- hipGraph of the whole run_arpeggio pass (captured on the 2nd identical call, replayed afterwards)
     u64* h_ctr_pinned = nullptr;
     hipGraph_t graph = nullptr;
@@ -417,11 +421,13 @@ int search_blocks(const GridDesc& d, int cpw = 1) {
 
 int zero_counter(arp_ctx* c, int first, int count) {
     if (c->ctr_clean) return ARP_OK;  // arp_run_launch cleared the whole block with one memset
+    c->ctr_zero_ok = false;
     HIPCHK(c, hipMemsetAsync(c->d_ctr + first, 0, sizeof(u64) * (size_t)count, c->stream));
     return ARP_OK;
 }
-int enqueue_counter_copy(arp_ctx* c) {  // D2H of the counter block into pinned memory (capturable)
-    HIPCHK(c, hipMemcpyAsync(c->h_ctr_pinned, c->d_ctr, sizeof(u64) * C_COUNT, hipMemcpyDeviceToHost, c->stream));
+int enqueue_counter_copy(arp_ctx* c, int zero = 0) {  // counter block -> pinned host memory (capturable)
+    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(256), 0, c->stream, c->d_ctr, c->h_ctr_pinned, (int)C_COUNT, zero);
+    CHK(check_launch(c, "k_publish_counters"));
     return ARP_OK;
 }
 int collect_counters(arp_ctx* c) {  // the only stream sync of a pass
@@ -1229,8 +1235,13 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
     }
     // every stage enqueued back to back (no host synchronisation, no allocation once the buffers are sized)
+    // the counter block must be zero when a pass starts; a pass leaves it zeroed (k_publish_counters)
+    auto ensure_zero = [&]() -> int {
+        if (!c->ctr_zero_ok) HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
+        c->ctr_zero_ok = false;
+        return ARP_OK;
+    };
     auto enqueue_all = [&]() -> int {
-        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
         CHK(enqueue_expansion(c, expand_radius));                                   // I:342 (I:1384-1424)
@@ -1240,6 +1251,9 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         // fork: the residue/ring/amide sets and the four small ring/amide kernels only need selection_plus and
         // the 6 A grid; they run on stream2 underneath the contact pipeline (grid build + search + sift)
         HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
+        // the host needs ~3 us per launch: the critical path (contact pipeline) is enqueued first, the seven small
+        // launches of stream2 afterwards — they have ~90 us of search + sift to hide under
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
         CHK(enqueue_selection_sets(c, c->stream2));                                 // I:1413-1437
         CHK(enqueue_atom_plane(c, c->stream2));                                     // I:346 (I:945), reuses the 6 A grid
@@ -1247,9 +1261,8 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         CHK(enqueue_group_group(c, c->stream2));                                    // I:347 (I:1214)
         CHK(enqueue_group_plane(c, c->stream2));                                    //       (I:1215)
         HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
-        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));                  // join
-        return enqueue_counter_copy(c);
+        return enqueue_counter_copy(c, 1);
     };
     auto any_overflow = [&](bool grow) -> int {   // returns 1 when a buffer was too small (and regrows it if asked)
         int again = 0;
@@ -1272,8 +1285,10 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
     if (use_graph && c->graph_ok && !c->profiling) {
         if (c->graph_exec && same(c->gkey, key)) {
             // replay: the launch-bound chain of ~25 small kernels costs one graph launch on the host
+            CHK(ensure_zero());
             HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
             CHK(collect_counters(c));
+            c->ctr_zero_ok = true;
             const int ov = any_overflow(false);
             if (ov < 0) return ov;
             if (ov == 0) done = true;        // (an overflow cannot happen with unchanged inputs; fall through if it does)
@@ -1296,8 +1311,10 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
                 c->graph_ok = false;         // direct launches from now on
                 drop_graph(c);
             } else {
+                CHK(ensure_zero());
                 HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
                 CHK(collect_counters(c));
+                c->ctr_zero_ok = true;
                 const int ov = any_overflow(false);
                 if (ov < 0) return ov;
                 if (ov == 0) done = true;
@@ -1306,8 +1323,16 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         }
     }
     for (int attempt = 0; !done; ++attempt) {
+        const auto t0 = std::chrono::steady_clock::now();
+        CHK(ensure_zero());
         CHK(enqueue_all());
+        const auto t1 = std::chrono::steady_clock::now();
         CHK(collect_counters(c));
+        c->ctr_zero_ok = true;
+        const auto t2 = std::chrono::steady_clock::now();
+        c->host_enqueue_us += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        c->host_wait_us += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        ++c->host_passes;
         collect_events(c);
         const int again = any_overflow(true);
         if (again < 0) return again;
@@ -1343,6 +1368,7 @@ int arp_device_buffer(arp_ctx* c, int which, uint64_t* device_ptr, int64_t* byte
 int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius,
                   int64_t counts[5]) {
     if (!c || stage < 0 || stage > 2) return ARP_E_ARG;
+    c->ctr_zero_ok = false;
     HIPCHK(c, hipSetDevice(c->device));
     if (stage == 0) {          // I:1384-1424 on the local atoms; exact for the atoms this rank owns
         if (!(expand_radius > 0)) return ARP_E_ARG;
@@ -1389,13 +1415,13 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         if (c->nring > 0) CHK(ensure_ring_grid(c));
         if (c->namide > 0) CHK(ensure_amide_grid(c));
         HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // critical path first (see arp_run_launch)
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
         CHK(enqueue_atom_plane(c, c->stream2));
         CHK(enqueue_plane_plane(c, c->stream2));
         CHK(enqueue_group_group(c, c->stream2));
         CHK(enqueue_group_plane(c, c->stream2));
         HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
-        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
         CHK(enqueue_counter_copy(c));
         CHK(collect_counters(c));
@@ -1435,6 +1461,13 @@ int arp_get_kernel_times(arp_ctx* c, double ms[8], int64_t launches[8], int rese
     if (!c || !ms || !launches) return ARP_E_ARG;
     for (int k = 0; k < NSLOT; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
     if (reset) for (int k = 0; k < NSLOT; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+    return ARP_OK;
+}
+
+int arp_get_host_times(arp_ctx* c, double us[2], int64_t* passes, int reset) {
+    if (!c || !us || !passes) return ARP_E_ARG;
+    us[0] = c->host_enqueue_us; us[1] = c->host_wait_us; *passes = c->host_passes;
+    if (reset) { c->host_enqueue_us = c->host_wait_us = 0; c->host_passes = 0; }
     return ARP_OK;
 }
 

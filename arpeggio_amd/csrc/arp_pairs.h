@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, con
 // ---- neighbour search ---------------------------------------------------------------
 #define SEARCH_WAVES 4
 #define QCAP 512
+#define HOME_BLOCK 32
 
 enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
 
@@ -185,6 +186,16 @@ enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
 // memory.
 // Accepted pairs are compacted with __ballot into a per-wave LDS queue that is flushed
 // to global memory with one atomicAdd per ~QCAP pairs.
+// position in the cell-sorted arrays of candidate k of a home cell (five contiguous ranges, see k_search)
+__device__ __forceinline__ int cand_pos(int k, int o1, int o2, int o3, int o4, int js0, int js1, int js2, int js3, int js4) {
+    return (k < o1) ? js0 + k : (k < o2) ? js1 + (k - o1) : (k < o3) ? js2 + (k - o2) : (k < o4) ? js3 + (k - o3) : js4 + (k - o4);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
+    unsigned long long s = v;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
                                                                const float4* __restrict__ s_xyzm,
@@ -194,6 +205,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus) {
     __shared__ int2 q[SEARCH_WAVES][QCAP];
+    __shared__ float4 s_hx[SEARCH_WAVES][HOME_BLOCK];   // home atoms of the moment: x, y, z, meta
+    __shared__ int4 s_ha[SEARCH_WAVES][HOME_BLOCK];     //                         local id, residue, prev, next
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     // XCD-aware remap: blocks that land on one XCD (b % 8) walk a contiguous run of cells,
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
     const int c_end = min((vb + 1) * cells_per_block, g.ncell);
 
     int qn = 0;
-    unsigned long long n_cand = 0, n_acc = 0;
+    unsigned int n_cand = 0, n_acc = 0;   // per lane; reduced over the wave at the end
     const float r2_lo = (float)(r2 * (1.0 - 1e-5)), r2_hi = (float)(r2 * (1.0 + 1e-5));
 
     // output segment of this block (cap = capacity of ONE segment)
@@ -226,119 +239,171 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         qn = 0;
     };
 
-    for (int cell = c_begin; cell < c_end; cell += SEARCH_WAVES) {
-        const int hs = __builtin_amdgcn_readfirstlane(start[cell]);
-        const int he = __builtin_amdgcn_readfirstlane(start[cell + 1]);
-        if (hs == he) continue;
-        const int cz = cell / (g.nx * g.ny);
-        const int rem = cell - cz * g.nx * g.ny;
-        const int cy = rem / g.nx;
-        const int cx = rem - cy * g.nx;
-        // Lanes 0..4 fetch the bounds of the 5 neighbour ranges in parallel (one load latency):
-        // range 0 = home pencil [own cell, cx+1], ranges 1..4 = the forward pencils [cx-1, cx+1].
-        int my_js = 0, my_len = 0;
-        if (lane < 5) {
-            const int dy = (lane == 0) ? 0 : (lane == 1) ? 1 : (lane - 3);
-            const int dz = (lane <= 1) ? 0 : 1;
+    // The wave's cells are taken eight at a time: lane 8 * ci + r fetches the bounds of range r of cell ci
+    // (range 0 = home pencil [own cell, cx+1], ranges 1..4 = the forward pencils [cx-1, cx+1], r = 5: end of
+    // the home cell), so the start table costs ONE load latency per eight cells instead of two per cell.
+    for (int cg = c_begin; cg < c_end; cg += SEARCH_WAVES * 8) {
+      int my_js = 0, my_len = 0;
+      {
+        const int mycell = cg + (lane >> 3) * SEARCH_WAVES;
+        const int r = lane & 7;
+        if (mycell < c_end && r < 6) {
+            const int cz = mycell / (g.nx * g.ny);
+            const int rem = mycell - cz * g.nx * g.ny;
+            const int cy = rem / g.nx;
+            const int cx = rem - cy * g.nx;
+            const int dy = (r == 0 || r == 5) ? 0 : (r == 1) ? 1 : (r - 3);
+            const int dz = (r <= 1 || r == 5) ? 0 : 1;
             const int y2 = cy + dy, z2 = cz + dz;
-            if (y2 >= 0 && y2 < g.ny && z2 < g.nz) {
+            if (r == 5) {
+                my_js = start[mycell + 1];
+            } else if (y2 >= 0 && y2 < g.ny && z2 < g.nz) {
                 const int rowbase = (z2 * g.ny + y2) * g.nx;
-                const int xlo = (lane == 0) ? cx : max(cx - 1, 0);
+                const int xlo = (r == 0) ? cx : max(cx - 1, 0);
                 const int xhi = min(cx + 1, g.nx - 1);
-                my_js = (lane == 0) ? hs : start[rowbase + xlo];
+                my_js = start[rowbase + xlo];
                 my_len = start[rowbase + xhi + 1] - my_js;
             }
         }
-        const int js0 = __builtin_amdgcn_readlane(my_js, 0), js1 = __builtin_amdgcn_readlane(my_js, 1),
-                  js2 = __builtin_amdgcn_readlane(my_js, 2), js3 = __builtin_amdgcn_readlane(my_js, 3),
-                  js4 = __builtin_amdgcn_readlane(my_js, 4);
-        const int o1 = __builtin_amdgcn_readlane(my_len, 0);           // candidates [0, o1) come from range 0
-        const int o2 = o1 + __builtin_amdgcn_readlane(my_len, 1);
-        const int o3 = o2 + __builtin_amdgcn_readlane(my_len, 2);
-        const int o4 = o3 + __builtin_amdgcn_readlane(my_len, 3);
-        const int total = (ablate & 8) ? 0 : o4 + __builtin_amdgcn_readlane(my_len, 4);
+      }
 #pragma unroll 1
-        for (int hb = hs; hb < he; hb += 64) {  // home atoms, 64 at a time, one per lane
-            const int hcount = (ablate & 4) ? 0 : min(64, he - hb);
+      for (int ci = 0; ci < 8; ++ci) {
+        const int cell = cg + ci * SEARCH_WAVES;
+        if (cell >= c_end) break;
+        const int hs = __builtin_amdgcn_readlane(my_js, ci * 8);
+        const int he = __builtin_amdgcn_readlane(my_js, ci * 8 + 5);
+        if (hs == he) continue;
+        const int js0 = hs, js1 = __builtin_amdgcn_readlane(my_js, ci * 8 + 1),
+                  js2 = __builtin_amdgcn_readlane(my_js, ci * 8 + 2), js3 = __builtin_amdgcn_readlane(my_js, ci * 8 + 3),
+                  js4 = __builtin_amdgcn_readlane(my_js, ci * 8 + 4);
+        const int o1 = __builtin_amdgcn_readlane(my_len, ci * 8);      // candidates [0, o1) come from range 0
+        const int o2 = o1 + __builtin_amdgcn_readlane(my_len, ci * 8 + 1);
+        const int o3 = o2 + __builtin_amdgcn_readlane(my_len, ci * 8 + 2);
+        const int o4 = o3 + __builtin_amdgcn_readlane(my_len, ci * 8 + 3);
+        const int total = (ablate & 8) ? 0 : o4 + __builtin_amdgcn_readlane(my_len, ci * 8 + 4);
+#pragma unroll 1
+        for (int hb = hs; hb < he; hb += HOME_BLOCK) {  // home atoms, 32 at a time: one bit each in the per-lane hit masks
+            const int hcount = (ablate & 4) ? 0 : min(HOME_BLOCK, he - hb);
             const bool hvalid = lane < hcount;
             const float4 hreg = hvalid ? s_xyzm[hb + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
             int4 hauxreg = make_int4(0, 0, 0, 0);
             if (MODE != MODE_PAIRS && hvalid) hauxreg = s_aux[hb + lane];
             if (MODE == MODE_PAIRS && hvalid) hauxreg.x = s_aux[hb + lane].x;
+            // the hit stage below addresses home atoms by a per-lane index: keep them in LDS as well
+            __builtin_amdgcn_wave_barrier();
+            if (lane < HOME_BLOCK) { s_hx[w][lane] = hreg; s_ha[w][lane] = hauxreg; }
+            __builtin_amdgcn_wave_barrier();
             // expansion search: which home atoms are selected (lane = home atom)
-            const unsigned long long m_hvalid = __ballot(hvalid);
-            const unsigned long long m_selh = (MODE == MODE_MARK) ? __ballot(hvalid && (__float_as_uint(hreg.w) & M_SEL)) : 0ull;
+            const uint32_t m_hvalid = (uint32_t)__ballot(hvalid);
+            const uint32_t m_selh = (MODE == MODE_MARK) ? (uint32_t)__ballot(hvalid && (__float_as_uint(hreg.w) & M_SEL)) : 0u;
 #pragma unroll 1
-            for (int kb = 0; kb < total; kb += 64) {  // the ~87 candidates of this cell, flattened over the lanes
-                const int k = kb + lane;
-                const bool valid = k < total;
-                const bool in_r0 = k < o1;
-                const int j = in_r0 ? js0 + k : (k < o2) ? js1 + (k - o1) : (k < o3) ? js2 + (k - o2)
-                                              : (k < o4) ? js3 + (k - o3) : js4 + (k - o4);
-                const float4 xj = valid ? s_xyzm[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                int4 aj = make_int4(0, 0, 0, 0);
-                if (MODE != MODE_PAIRS && valid) aj = s_aux[j];
-                if (MODE == MODE_PAIRS && valid) aj.x = s_aux[j].x;
-                const num::d3 pj = {(double)xj.x, (double)xj.y, (double)xj.z};
-                const uint32_t mj = __float_as_uint(xj.w);
-                // wave-uniform lane masks of this chunk: valid candidates, and those inside the home pencil
-                const unsigned long long m_valid = __ballot(valid);
-                const unsigned long long m_r0 = __ballot(valid && in_r0);
-                // Expansion search (I:1420-1424): a pair changes selection_plus only if exactly ONE of its atoms is
-                // selected (both selected: already members; neither: not concerned), so only those pairs are tested.
-                const unsigned long long m_selj = (MODE == MODE_MARK) ? __ballot(valid && (mj & M_SEL)) : 0ull;
-                if (MODE == MODE_MARK && ((m_selh == m_hvalid && m_selj == m_valid) || (m_selh == 0 && m_selj == 0))) continue;
+            for (int kb = 0; kb < total; kb += 128) {  // the ~87 candidates of this cell, two per lane
+                const int k0 = kb + lane, k1 = kb + 64 + lane;
+                const bool valid0 = k0 < total, valid1 = k1 < total;
+                const int j0 = cand_pos(k0, o1, o2, o3, o4, js0, js1, js2, js3, js4);
+                const int j1 = cand_pos(k1, o1, o2, o3, o4, js0, js1, js2, js3, js4);
+                const float4 x0 = valid0 ? s_xyzm[j0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 x1 = valid1 ? s_xyzm[j1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                int4 a0 = make_int4(0, 0, 0, 0), a1 = make_int4(0, 0, 0, 0);
+                if (MODE != MODE_PAIRS) {
+                    if (valid0) a0 = s_aux[j0];
+                    if (valid1) a1 = s_aux[j1];
+                } else {
+                    if (valid0) a0.x = s_aux[j0].x;
+                    if (valid1) a1.x = s_aux[j1].x;
+                }
+                const uint32_t mj0 = __float_as_uint(x0.w), mj1 = __float_as_uint(x1.w);
+                // Inside the home pencil only later entries of the sorted array (j > h) pair up: candidate k of
+                // range 0 is position hs + k, so it is tested against home atom h iff k > h - hs.  Other valid
+                // candidates are always tested, invalid lanes never.
+                const int kk0 = valid0 ? ((k0 < o1) ? k0 : INT_MAX) : -1;
+                const int kk1 = valid1 ? ((k1 < o1) ? k1 : INT_MAX) : -1;
+                const bool selj0 = mj0 & M_SEL, selj1 = mj1 & M_SEL;
+                if (MODE == MODE_MARK) {
+                    // Expansion search (I:1420-1424): a pair changes selection_plus only if exactly ONE of its atoms is
+                    // selected (both selected: already members; neither: not concerned), so only those pairs are tested.
+                    const unsigned long long mv0 = __ballot(valid0), mv1 = __ballot(valid1);
+                    const unsigned long long ms0 = __ballot(valid0 && selj0), ms1 = __ballot(valid1 && selj1);
+                    if ((m_selh == m_hvalid && ms0 == mv0 && ms1 == mv1) || (m_selh == 0 && ms0 == 0 && ms1 == 0)) continue;
+                }
+                // ---- stage 1: distance tests only.  Bit hh of lo/hi = candidate within r2_lo / r2_hi of home atom hh.
+                // float32 pre-filter: |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded squares, two
+                // rounded sums), so outside the +-1e-5 band the float32 answer IS the float64 answer.
+                uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+                const int t0 = hb - hs;
 #pragma unroll 1
-                for (int hh = 0; hh < hcount; ++hh) {
-                    const int h = hb + hh;
+                for (int hh = hcount - 1; hh >= 0; --hh) {
                     // broadcast the home atom from lane hh (v_readlane, no memory traffic)
                     const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh));
                     const float hy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh));
                     const float hz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.z), hh));
-                    // inside the home pencil only later entries of the sorted array (j > h) pair up:
-                    // candidate k of range 0 is position hs + k, so lanes with kb + lane <= h - hs drop out
-                    const int t = h - hs - kb;
-                    const unsigned long long low = (t < 0) ? 0ull : (t >= 63 ? ~0ull : ((2ull << t) - 1ull));
-                    unsigned long long m_tested = m_valid & ~(m_r0 & low);
+                    const int t = t0 + hh;
+                    bool te0 = kk0 > t, te1 = kk1 > t;
                     if (MODE == MODE_MARK) {
-                        m_tested &= ((m_selh >> hh) & 1ull) ? ~m_selj : m_selj;
-                        if (m_tested == 0) continue;
+                        const bool sh = (m_selh >> hh) & 1u;
+                        te0 = te0 && (selj0 != sh);
+                        te1 = te1 && (selj1 != sh);
                     }
-                    // float32 pre-filter.  |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded
-                    // squares, two rounded sums), so outside the +-1e-5 band the float32 answer IS the
-                    // float64 answer; inside the band (rare) the whole wave takes the exact float64 test.
-                    const float dxf = hx - xj.x, dyf = hy - xj.y, dzf = hz - xj.z;
-                    const float d2f = fmaf(dzf, dzf, fmaf(dyf, dyf, dxf * dxf));   // any rounding order fits the 4e-7 bound
-                    unsigned long long mhit = __ballot(d2f <= r2_lo) & m_tested;
-                    const unsigned long long m_band = __ballot(d2f > r2_lo && d2f <= r2_hi) & m_tested;
-                    if (m_band) {
-                        const num::d3 ph = {(double)hx, (double)hy, (double)hz};
-                        mhit = __ballot(num::dist2_kd(ph, pj) <= r2) & m_tested;   // Bio.PDB.kdtrees test, exact
-                    }
-                    const bool hit = (mhit >> lane) & 1ull;
+                    const float dx0 = hx - x0.x, dy0 = hy - x0.y, dz0 = hz - x0.z;
+                    const float dx1 = hx - x1.x, dy1 = hy - x1.y, dz1 = hz - x1.z;
+                    const float d0 = fmaf(dz0, dz0, fmaf(dy0, dy0, dx0 * dx0));   // any rounding order fits the 4e-7 bound
+                    const float d1 = fmaf(dz1, dz1, fmaf(dy1, dy1, dx1 * dx1));
+                    lo0 = (lo0 << 1) | (uint32_t)(te0 && d0 <= r2_lo);
+                    hi0 = (hi0 << 1) | (uint32_t)(te0 && d0 <= r2_hi);
+                    lo1 = (lo1 << 1) | (uint32_t)(te1 && d1 <= r2_lo);
+                    hi1 = (hi1 << 1) | (uint32_t)(te1 && d1 <= r2_hi);
                     if (count_owned) {
                         // sharded run: a boundary pair is tested on two ranks; count it for the owner of its bgn atom only
                         const int lh = __builtin_amdgcn_readlane(hauxreg.x, hh);
                         const uint32_t mh0 = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
-                        const bool owned = ((lh < aj.x) ? mh0 : mj) & M_HOME;
-                        n_cand += __popcll(__ballot(owned) & m_tested);
+                        n_cand += (unsigned)(te0 && (((lh < a0.x) ? mh0 : mj0) & M_HOME));
+                        n_cand += (unsigned)(te1 && (((lh < a1.x) ? mh0 : mj1) & M_HOME));
                     } else {
-                        n_cand += __popcll(m_tested);
+                        n_cand += (unsigned)te0 + (unsigned)te1;
                     }
-                    if (mhit == 0 || (ablate & 2)) continue;
-                    n_acc += __popcll(mhit);
-                    const uint32_t mh = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
-                    const int4 ah = make_int4(__builtin_amdgcn_readlane(hauxreg.x, hh), __builtin_amdgcn_readlane(hauxreg.y, hh),
-                                              __builtin_amdgcn_readlane(hauxreg.z, hh), __builtin_amdgcn_readlane(hauxreg.w, hh));
+                }
+                // inside the band (rare) the exact Bio.PDB.kdtrees float64 test decides
+                uint32_t band0 = hi0 & ~lo0, band1 = hi1 & ~lo1;
+                if (__any((band0 | band1) != 0)) {
+                    const num::d3 p0 = {(double)x0.x, (double)x0.y, (double)x0.z};
+                    const num::d3 p1 = {(double)x1.x, (double)x1.y, (double)x1.z};
+                    while (band0) {
+                        const int hh = __ffs(band0) - 1;
+                        band0 &= band0 - 1;
+                        const float4 hv = s_hx[w][hh];
+                        if (num::dist2_kd(num::d3{(double)hv.x, (double)hv.y, (double)hv.z}, p0) <= r2) lo0 |= 1u << hh;
+                    }
+                    while (band1) {
+                        const int hh = __ffs(band1) - 1;
+                        band1 &= band1 - 1;
+                        const float4 hv = s_hx[w][hh];
+                        if (num::dist2_kd(num::d3{(double)hv.x, (double)hv.y, (double)hv.z}, p1) <= r2) lo1 |= 1u << hh;
+                    }
+                }
+                n_acc += __popc(lo0) + __popc(lo1);
+                if (ablate & 2) continue;
+                // ---- stage 2: every lane walks its own hits (residue filters, orientation, queueing)
+                while (__any((lo0 | lo1) != 0)) {
+                    const bool has = (lo0 | lo1) != 0;
+                    const bool use1 = lo0 == 0;
+                    const uint32_t bits = use1 ? lo1 : lo0;
+                    const int hh = has ? __ffs(bits) - 1 : 0;
+                    if (use1) lo1 &= lo1 - 1; else lo0 &= lo0 - 1;
+                    const int4 aj = use1 ? a1 : a0;
+                    const uint32_t mj = use1 ? mj1 : mj0;
+                    const int j = use1 ? j1 : j0;
+                    const int h = hb + hh;
+                    const uint32_t mh = __float_as_uint(s_hx[w][hh].w);
+                    const int4 ah = s_ha[w][hh];
                     if (MODE == MODE_MARK) {
                         // interactions.py:1420-1424: either atom selected -> both join selection_plus
-                        if (hit && ((mh | mj) & M_SEL)) {
+                        if (has && ((mh | mj) & M_SEL)) {
                             plus[aj.x] = 1;
                             plus[ah.x] = 1;
                         }
                         continue;
                     }
-                    bool pass = hit;
+                    bool pass = has;
                     int pb, pe;
                     if (MODE == MODE_CONTACTS) {
                         // canonical orientation: bgn = lower packed index.  Only three things depend on it — which
@@ -371,12 +436,14 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                 }
             }
         }
+      }
     }
     // End of block: the four per-wave queues leave with ONE atomicAdd (single-address atomics
     // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
     __shared__ int s_qn[SEARCH_WAVES];
     __shared__ u64 s_base, s_cand[SEARCH_WAVES], s_acc[SEARCH_WAVES];
-    if (lane == 0) { s_qn[w] = qn; s_cand[w] = n_cand; s_acc[w] = n_acc; }
+    const u64 w_cand = wave_sum_u32(n_cand), w_acc = wave_sum_u32(n_acc);
+    if (lane == 0) { s_qn[w] = qn; s_cand[w] = w_cand; s_acc[w] = w_acc; }
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = 0;
@@ -643,6 +710,15 @@ __global__ __launch_bounds__(256) void k_accumulate(long long np, const int* __r
                 if (slot > 0) atomicAdd(&acc_cnt[8 * (size_t)a + 4 + slot], 1);
             }
         }
+    }
+}
+
+// End of a pass: the counter block goes to the pinned host copy (a kernel store to mapped host memory costs one
+// launch; a D2H hipMemcpyAsync of 3 KB costs an SDMA round trip) and, when asked, returns to zero for the next pass.
+__global__ __launch_bounds__(256) void k_publish_counters(u64* __restrict__ ctr, u64* __restrict__ host, int n, int zero) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        host[i] = ctr[i];
+        if (zero) ctr[i] = 0;
     }
 }
 

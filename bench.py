@@ -127,11 +127,13 @@ def main():
     for _ in range(args.warmup):
         counts = step()
     sync_all()
+    ctx.host_times(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         counts = step()          # blocks until the context stream has drained (one sync per step)
     sync_all()
     elapsed = time.perf_counter() - t0
+    host_times = ctx.host_times(reset=True)
     st = ctx.stats()
     # Per-kernel durations: the same K steps once more with every launch bracketed by HIP events on the
     # context's streams (recording ~50 events per step costs ~0.1 ms per step, so it is kept out of `value`).
@@ -227,6 +229,7 @@ def main():
         'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()},
         'kernel_launches_per_step': {k: v['launches'] / args.steps for k, v in ktimes.items() if v['launches']},
         'ms_per_step_profiled_pass': round(elapsed_profiled / args.steps * 1e3, 4),
+        'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
         'launch_mode': 'direct launches on two HIP streams, one host sync per step; kernel_ms from a second pass of the same steps with HIP events',
         'halo_exchange_ms': round(halo_ms, 3), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'roofline': roofline, 'cpu_baseline': cpu,

@@ -307,6 +307,9 @@ int arp_get_stats(arp_ctx* ctx, int64_t stats[8]);
  * reset != 0 clears the accumulators after reading. */
 int arp_set_profiling(arp_ctx* ctx, int enabled);
 int arp_get_kernel_times(arp_ctx* ctx, double ms[8], int64_t launches[8], int reset);
+/* Host side of arp_run_launch, accumulated over *passes calls: us[0] = time spent enqueueing the pass
+ * (kernel launches, memsets, events), us[1] = time spent blocked in the one synchronisation. */
+int arp_get_host_times(arp_ctx* ctx, double us[2], int64_t* passes, int reset);
 /* The context's hipStream_t (as an integer), for callers that want to order their own work
  * against it. */
 uint64_t arp_stream_handle(arp_ctx* ctx);
