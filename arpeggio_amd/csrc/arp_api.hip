@@ -102,6 +102,7 @@ struct arp_ctx {
     DevBuf<uint8_t> home, sel, plus, res_sel, res_plus;
     bool has_res = false, has_gid = false, has_home = false;
     bool sel_made = false;
+    bool sel_all = false;        // the uploaded selection covers every atom: selection_plus = selection, no expansion search
     DevBuf<double> ring_c, ring_n;
     DevBuf<int> ring_res;
     DevBuf<uint8_t> ring_sel, ring_plus;
@@ -263,36 +264,38 @@ void make_grid_desc(GridDesc& d, const double lo[3], const double hi[3], double 
 }
 
 // exclusive scan of the cell histogram: one launch for small grids, three-phase otherwise
-int enqueue_scan(arp_ctx* c, Grid& G, u64* total_out = nullptr) {
+int enqueue_scan(arp_ctx* c, Grid& G, u64* total_out = nullptr, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     const int ncell = G.d.ncell;
-    Prof p(c, SLOT_SCAN);
+    Prof p(c, SLOT_SCAN, st);
     if (ncell <= 4096) {
-        hipLaunchKernelGGL((k_scan_small<4>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
+        hipLaunchKernelGGL((k_scan_small<4>), dim3(1), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, total_out);
     } else if (ncell <= 16384) {
-        hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
+        hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, total_out);
     } else if (ncell <= 32768) {
-        hipLaunchKernelGGL((k_scan_small<32>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
+        hipLaunchKernelGGL((k_scan_small<32>), dim3(1), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, total_out);
     } else if (ncell <= 65536) {
-        hipLaunchKernelGGL((k_scan_small<64>), dim3(1), dim3(1024), 0, c->stream, G.cnt.p, ncell, G.start.p, total_out);
+        hipLaunchKernelGGL((k_scan_small<64>), dim3(1), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, total_out);
     } else {
         const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(k_scan_local, dim3(nb_scan), dim3(SCAN_THREADS), 0, c->stream, G.cnt.p, ncell, G.start.p, G.sums.p);
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, G.sums.p, nb_scan);
-        hipLaunchKernelGGL(k_scan_add, dim3((ncell + 1 + 255) / 256), dim3(256), 0, c->stream, G.start.p, ncell, G.sums.p, nb_scan);
-        if (total_out) HIPCHK(c, hipMemcpyAsync(total_out, G.start.p + ncell, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_scan_local, dim3(nb_scan), dim3(SCAN_THREADS), 0, st, G.cnt.p, ncell, G.start.p, G.sums.p);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, G.sums.p, nb_scan);
+        hipLaunchKernelGGL(k_scan_add, dim3((ncell + 1 + 255) / 256), dim3(256), 0, st, G.start.p, ncell, G.sums.p, nb_scan);
+        if (total_out) HIPCHK(c, hipMemcpyAsync(total_out, G.start.p + ncell, sizeof(int), hipMemcpyDeviceToDevice, st));
     }
     return check_launch(c, "k_scan");
 }
 
 // grid buffers sized for the current descriptor; the histogram is zero on entry (see below)
-int reserve_grid(arp_ctx* c, Grid& G, int n) {
+int reserve_grid(arp_ctx* c, Grid& G, int n, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     const int ncell = G.d.ncell;
     HIPCHK(c, G.cell_of.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, G.perm.reserve((size_t)std::max(n, 1)));
     {   // k_scatter's atomicSub takes every counter back to 0, so only a fresh allocation needs clearing
         bool fresh = false;
         HIPCHK(c, G.cnt.reserve(std::max<size_t>((size_t)ncell + 1, 65536 + 8), &fresh));
-        if (fresh) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), c->stream));
+        if (fresh) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), st));
     }
     HIPCHK(c, G.start.reserve(std::max<size_t>((size_t)ncell + 2, 65536 + 8)));
     HIPCHK(c, G.sums.reserve((size_t)(ncell + SCAN_TILE - 1) / SCAN_TILE + 2));
@@ -363,6 +366,7 @@ StaticAtoms static_atoms(arp_ctx* c) {
     r.aux = c->st_aux.p;
     r.sel = c->sel_made ? c->sel.p : nullptr;
     r.plus = c->sel_made ? c->plus.p : nullptr;
+    r.all = (c->sel_made && c->sel_all) ? 1 : 0;
     return r;
 }
 
@@ -370,30 +374,32 @@ StaticAtoms static_atoms(arp_ctx* c) {
 // k_bin_atoms (records composed on the fly), scan, k_scatter_atoms (writes the cell-sorted search and
 // sift records directly).
 int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, DevBuf<SiftRec>* srec, double radius,
-                    uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr, uint8_t* plus_init = nullptr) {
+                    uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr, uint8_t* plus_init = nullptr,
+                    hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     const int n = (int)c->n;
     make_grid_desc(G.d, c->lo, c->hi, radius);
     G.radius = radius;
     G.n_points = n;
-    CHK(reserve_grid(c, G, n));
+    CHK(reserve_grid(c, G, n, st));
     HIPCHK(c, sx.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, sa.reserve((size_t)std::max(n, 1)));
     if (srec) HIPCHK(c, srec->reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c));
     const StaticAtoms r = static_atoms(c);
     {
-        Prof p(c, SLOT_BIN);
+        Prof p(c, SLOT_BIN, st);
         if (n > 0) {
-            if (active) hipLaunchKernelGGL((k_bin_atoms<1>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, active, 0u, 0u, G.cell_of.p, G.cnt.p, plus_init);
-            else hipLaunchKernelGGL((k_bin_atoms<2>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.d, (const uint8_t*)nullptr, req, forb, G.cell_of.p, G.cnt.p, plus_init);
+            if (active) hipLaunchKernelGGL((k_bin_atoms<1>), dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.d, active, 0u, 0u, G.cell_of.p, G.cnt.p, plus_init);
+            else hipLaunchKernelGGL((k_bin_atoms<2>), dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.d, (const uint8_t*)nullptr, req, forb, G.cell_of.p, G.cnt.p, plus_init);
             CHK(check_launch(c, "k_bin_atoms"));
         }
     }
-    CHK(enqueue_scan(c, G, total_out));
+    CHK(enqueue_scan(c, G, total_out, st));
     {
-        Prof p(c, SLOT_SCATTER);
+        Prof p(c, SLOT_SCATTER, st);
         if (n > 0) {
-            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, G.cell_of.p, G.start.p, G.cnt.p,
+            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_of.p, G.start.p, G.cnt.p,
                                sx.p, sa.p, srec ? srec->p : (SiftRec*)nullptr);
             CHK(check_launch(c, "k_scatter_atoms"));
         }
@@ -406,8 +412,8 @@ int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, c
     return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out);
 }
 // every atom (hydrogens included), used by the expansion and atom-plane; plus_init: also start selection_plus
-int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr) {
-    CHK(build_atom_grid(c, c->all_grid, c->a_xyzm, c->a_aux, nullptr, radius, 0, 0, nullptr, nullptr, plus_init));
+int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr, hipStream_t st = nullptr) {
+    CHK(build_atom_grid(c, c->all_grid, c->a_xyzm, c->a_aux, nullptr, radius, 0, 0, nullptr, nullptr, plus_init, st));
     c->all_grid_current = true;
     return ARP_OK;
 }
@@ -486,16 +492,19 @@ int ensure_amide_grid(arp_ctx* c) {
 // ---- enqueue-only building blocks (no host synchronisation) -----------------------------------
 
 // _make_selection, part 1 (I:1384-1424): selection_plus from the selection mask already in c->sel
-int enqueue_expansion(arp_ctx* c, double radius) {
+int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     const int n = (int)c->n;
     HIPCHK(c, c->plus.reserve((size_t)std::max(n, 1)));
     c->sel_made = true;   // (I:1407 selection_plus = selection is written by the binning kernel below)
     // I:1420-1424: search_all(6.0) over ALL atoms (hydrogens included)
-    CHK(build_all_grid(c, radius, c->plus.p));
+    CHK(build_all_grid(c, radius, c->plus.p, st));
     CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
-    if (n > 0) {
-        Prof p(c, SLOT_MARK);
-        hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
+    // With every atom selected, selection_plus = selection whatever the pairs are: the search is skipped (the
+    // grid is still built, the atom-plane kernel walks it).
+    if (n > 0 && !c->sel_all) {
+        Prof p(c, SLOT_MARK, st);
+        hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
                            c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, env_int("ARP_ABLATE", 0), (int2*)nullptr,
                            0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
         CHK(check_launch(c, "k_search<MARK>"));
@@ -534,6 +543,7 @@ int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 
     const size_t n = (size_t)std::max<int64_t>(c->n, 1);
     HIPCHK(c, c->sel.reserve(n));
     HIPCHK(c, hipMemsetAsync(c->sel.p, 1, n, c->stream));
+    c->sel_all = true;
     return enqueue_selection(c, 6.0);
 }
 
@@ -975,6 +985,7 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
     c->static_dirty = true;
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     CHK(upload(c, c->plus, in_plus, (size_t)c->n));
+    c->sel_all = false;   // the caller's masks are taken as they are
     CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));
     CHK(upload(c, c->am_sel, amide_sel, (size_t)c->namide)); CHK(upload(c, c->am_plus, amide_plus, (size_t)c->namide));
     c->sel_made = true;
@@ -989,6 +1000,9 @@ int arp_set_selection(arp_ctx* c, const uint8_t* in_selection) {
     if (!c || (c->n > 0 && !in_selection)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
+    c->sel_all = true;
+    for (int64_t i = 0; i < c->n; ++i)
+        if (!in_selection[i]) { c->sel_all = false; break; }
     c->sel_made = false;  // expansion pending
     c->all_grid_current = false;
     c->contacts_valid = false;
@@ -1038,6 +1052,7 @@ int arp_make_selection(arp_ctx* c, const uint8_t* in_selection, double expand_ra
         if (!c->sel.p || c->sel.cap < (size_t)c->n) {  // nothing uploaded yet: whole structure (I:1395)
             HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
             HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
+        c->sel_all = true;
         }
     }
     CHK(enqueue_selection(c, expand_radius));
@@ -1233,6 +1248,7 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
     if (!c->sel.p || c->sel.cap < (size_t)std::max<int64_t>(c->n, 1)) {  // no selection uploaded: whole structure
         HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
         HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
+        c->sel_all = true;
     }
     // every stage enqueued back to back (no host synchronisation, no allocation once the buffers are sized)
     // the counter block must be zero when a pass starts; a pass leaves it zeroed (k_publish_counters)
@@ -1244,17 +1260,27 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
     auto enqueue_all = [&]() -> int {
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
-        CHK(enqueue_expansion(c, expand_radius));                                   // I:342 (I:1384-1424)
+        CHK(ensure_static(c));
+        // Whole-structure selection (the reference's default, I:1395 with no selectors): selection_plus is the
+        // selection, so nothing on the contact path waits for _make_selection — the 6 A grid (still needed by the
+        // atom-plane kernel) moves to stream2 with the rest of the ring / amide work.
+        const bool fork_early = c->sel_all;
+        if (!fork_early) CHK(enqueue_expansion(c, expand_radius));                  // I:342 (I:1384-1424)
         // ring grids are built (once) on the main stream before the fork
         if (c->nring > 0) CHK(ensure_ring_grid(c));
         if (c->namide > 0) CHK(ensure_amide_grid(c));
         // fork: the residue/ring/amide sets and the four small ring/amide kernels only need selection_plus and
         // the 6 A grid; they run on stream2 underneath the contact pipeline (grid build + search + sift)
         HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
-        // the host needs ~3 us per launch: the critical path (contact pipeline) is enqueued first, the seven small
+        // the host needs ~3 us per launch: the critical path (contact pipeline) is enqueued first, the small
         // launches of stream2 afterwards — they have ~90 us of search + sift to hide under
+        if (fork_early) {
+            c->sel_made = true;
+            HIPCHK(c, c->plus.reserve((size_t)std::max<int64_t>(c->n, 1)));
+        }
         CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
+        if (fork_early) CHK(enqueue_expansion(c, expand_radius, c->stream2));
         CHK(enqueue_selection_sets(c, c->stream2));                                 // I:1413-1437
         CHK(enqueue_atom_plane(c, c->stream2));                                     // I:346 (I:945), reuses the 6 A grid
         CHK(enqueue_plane_plane(c, c->stream2));                                    // I:346 (I:944)
@@ -1375,6 +1401,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         if (!c->sel.p || c->sel.cap < (size_t)std::max<int64_t>(c->n, 1)) {
             HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
             HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
+        c->sel_all = true;
         }
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
         c->ctr_clean = true;

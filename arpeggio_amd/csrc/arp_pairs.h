@@ -90,6 +90,7 @@ struct StaticAtoms {
     const float4* sbl;          // single-bond neighbour xyz, w = bit pattern of the local id
     const uint8_t* sel;         // null: nothing selected
     const uint8_t* plus;        // null: everything in selection_plus
+    int all;                    // the selection is the whole structure (then selection_plus is, too): sel / plus not read
 };
 
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
@@ -117,8 +118,11 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
 __device__ __forceinline__ float4 compose_xyzm(const StaticAtoms& r, int i) {
     float4 v = r.xyzm[i];
     uint32_t m = __float_as_uint(v.w);
-    if (r.sel && r.sel[i]) m |= M_SEL;
-    if (!r.plus || r.plus[i]) m |= M_PLUS;
+    if (r.all) m |= M_SEL | M_PLUS;
+    else {
+        if (r.sel && r.sel[i]) m |= M_SEL;
+        if (!r.plus || r.plus[i]) m |= M_PLUS;
+    }
     v.w = __uint_as_float(m);
     return v;
 }
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDes
                                                    int* __restrict__ cell_cnt, uint8_t* __restrict__ plus_init) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 xyzm = compose_xyzm(r, i);
-        if (plus_init) plus_init[i] = r.sel[i];   // I:1407: selection_plus starts as the selection
+        if (plus_init) plus_init[i] = r.all ? (uint8_t)1 : r.sel[i];   // I:1407: selection_plus starts as the selection
         const uint32_t m = __float_as_uint(xyzm.w);
         const bool on = (FILTER == 1) ? (active[i] != 0) : (((m & req) == req) && !(m & forb));
         int c = -1;
