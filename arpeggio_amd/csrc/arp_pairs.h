@@ -719,12 +719,20 @@ __global__ __launch_bounds__(256) void k_accumulate(long long np, const int* __r
 
 // End of a pass: the counter block goes to the pinned host copy (a kernel store to mapped host memory costs one
 // launch; a D2H hipMemcpyAsync of 3 KB costs an SDMA round trip) and, when asked, returns to zero for the next pass.
-__global__ __launch_bounds__(256) void k_publish_counters(u64* __restrict__ ctr, u64* __restrict__ host, int n, int zero) {
+__global__ __launch_bounds__(256) void k_publish_counters(u64* __restrict__ ctr, u64* __restrict__ host, int n, int zero, u64 seq) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         host[i] = ctr[i];
         if (zero) ctr[i] = 0;
     }
+    // host[n] = sequence number of this pass, stored after everything else is visible to the host: the host may
+    // poll it instead of blocking in hipStreamSynchronize (this kernel is the last one of the pass)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(host + n, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
+
 
 // residue / ring / amide membership of _make_selection (interactions.py:1413-1437)
 __global__ __launch_bounds__(256) void k_res_mark(int n, const int* __restrict__ res_id, const uint8_t* __restrict__ sel,
