@@ -190,9 +190,15 @@ enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
 // memory.
 // Accepted pairs are compacted with __ballot into a per-wave LDS queue that is flushed
 // to global memory with one atomicAdd per ~QCAP pairs.
-// position in the cell-sorted arrays of candidate k of a home cell (five contiguous ranges, see k_search)
-__device__ __forceinline__ int cand_pos(int k, int o1, int o2, int o3, int o4, int js0, int js1, int js2, int js3, int js4) {
-    return (k < o1) ? js0 + k : (k < o2) ? js1 + (k - o1) : (k < o3) ? js2 + (k - o2) : (k < o4) ? js3 + (k - o3) : js4 + (k - o4);
+// position in the cell-sorted arrays of candidate k of a home cell (five contiguous ranges, see k_search);
+// dN = start of range N minus the number of candidates before it.  Straight-line selects, no branches.
+__device__ __forceinline__ int cand_pos(int k, int o1, int o2, int o3, int o4, int d0, int d1, int d2, int d3, int d4) {
+    int d = d0;
+    d = (k >= o1) ? d1 : d;
+    d = (k >= o2) ? d2 : d;
+    d = (k >= o3) ? d3 : d;
+    d = (k >= o4) ? d4 : d;
+    return d + k;
 }
 __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
     unsigned long long s = v;
@@ -289,10 +295,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         for (int hb = hs; hb < he; hb += HOME_BLOCK) {  // home atoms, 32 at a time: one bit each in the per-lane hit masks
             const int hcount = (ablate & 4) ? 0 : min(HOME_BLOCK, he - hb);
             const bool hvalid = lane < hcount;
-            const float4 hreg = hvalid ? s_xyzm[hb + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-            int4 hauxreg = make_int4(0, 0, 0, 0);
-            if (MODE != MODE_PAIRS && hvalid) hauxreg = s_aux[hb + lane];
-            if (MODE == MODE_PAIRS && hvalid) hauxreg.x = s_aux[hb + lane].x;
+            const int hpos = min(hb + lane, he - 1);   // (clamped: no branch around the loads; lanes >= hcount are never read)
+            const float4 hreg = s_xyzm[hpos];
+            int4 hauxreg;
+            if (MODE != MODE_PAIRS) hauxreg = s_aux[hpos];
+            else hauxreg = make_int4(s_aux[hpos].x, 0, 0, 0);
             // the hit stage below addresses home atoms by a per-lane index: keep them in LDS as well
             __builtin_amdgcn_wave_barrier();
             if (lane < HOME_BLOCK) { s_hx[w][lane] = hreg; s_ha[w][lane] = hauxreg; }
@@ -304,17 +311,19 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
             for (int kb = 0; kb < total; kb += 128) {  // the ~87 candidates of this cell, two per lane
                 const int k0 = kb + lane, k1 = kb + 64 + lane;
                 const bool valid0 = k0 < total, valid1 = k1 < total;
-                const int j0 = cand_pos(k0, o1, o2, o3, o4, js0, js1, js2, js3, js4);
-                const int j1 = cand_pos(k1, o1, o2, o3, o4, js0, js1, js2, js3, js4);
-                const float4 x0 = valid0 ? s_xyzm[j0] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 x1 = valid1 ? s_xyzm[j1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                int4 a0 = make_int4(0, 0, 0, 0), a1 = make_int4(0, 0, 0, 0);
+                // invalid lanes read the first home atom instead of branching around the loads: the four loads of a
+                // chunk leave back to back (their lanes never test, kk = -1 below)
+                const int j0 = valid0 ? cand_pos(k0, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4) : hs;
+                const int j1 = valid1 ? cand_pos(k1, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4) : hs;
+                const float4 x0 = s_xyzm[j0];
+                const float4 x1 = s_xyzm[j1];
+                int4 a0, a1;
                 if (MODE != MODE_PAIRS) {
-                    if (valid0) a0 = s_aux[j0];
-                    if (valid1) a1 = s_aux[j1];
+                    a0 = s_aux[j0];
+                    a1 = s_aux[j1];
                 } else {
-                    if (valid0) a0.x = s_aux[j0].x;
-                    if (valid1) a1.x = s_aux[j1].x;
+                    a0 = make_int4(s_aux[j0].x, 0, 0, 0);
+                    a1 = make_int4(s_aux[j1].x, 0, 0, 0);
                 }
                 const uint32_t mj0 = __float_as_uint(x0.w), mj1 = __float_as_uint(x1.w);
                 // Inside the home pencil only later entries of the sorted array (j > h) pair up: candidate k of
