@@ -615,63 +615,119 @@ int bag_reserve(arp_ctx* c, Bag& b, size_t cap, bool d, bool f) {
     return ARP_OK;
 }
 
-int enqueue_atom_plane(arp_ctx* c, hipStream_t st) {  // I:947-1062
+// The four ring / amide kernels: prepare_* sizes the bag, clears its counter and fills the kernel arguments
+// (nb = number of blocks, 0 when there is nothing to do); enqueue_* launches one of them, enqueue_planes all
+// four as ONE launch (k_planes).
+int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb) {  // I:947-1062
     Bag& b = c->bag_ap;
+    nb = 0;
     if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->nring * 8 + 256, true, false));
     CHK(zero_counter(c, C_AP, 1));
     if (c->nring == 0 || c->n == 0) return ARP_OK;
     // all-atom 6 A grid (I:960 radius): the one the selection expansion has just built, if it is still current
     if (!(c->all_grid_current && c->all_grid.valid && c->all_grid.radius == 6.0)) CHK(build_all_grid(c, 6.0));
-    Prof p(c, SLOT_PLANES, st);
-    hipLaunchKernelGGL(k_atom_plane, dim3(nblocks(c->nring * 64, 256, 8192)), dim3(256), 0, st, c->all_grid.d, c->all_grid.start.p,
-                       c->a_xyzm.p, c->a_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p,
-                       c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
-                       c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
-                       b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP);
-    return check_launch(c, "k_atom_plane");
+    a = AtomPlaneArgs{c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
+                      c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
+                      c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
+                      b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP};
+    nb = nblocks(c->nring * 64, 256, 8192);
+    return ARP_OK;
 }
-
-int enqueue_plane_plane(arp_ctx* c, hipStream_t st) {  // I:1064-1194
+int prepare_plane_plane(arp_ctx* c, PlanePlaneArgs& a, int& nb) {  // I:1064-1194
     Bag& b = c->bag_pp;
+    nb = 0;
     if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->nring * 16 + 256, true, false));
     CHK(zero_counter(c, C_PP, 1));
     if (c->nring == 0) return ARP_OK;
     CHK(ensure_ring_grid(c));
-    Prof p(c, SLOT_PLANES, st);
-    hipLaunchKernelGGL(k_plane_plane, dim3(nblocks(c->nring * 64, 256, 8192)), dim3(256), 0, st, c->ring_grid.d, c->ring_grid.start.p,
-                       c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p, c->ring_res.p, c->ring_sel.p, c->ring_plus.p,
-                       c->has_group_owner ? c->ring_home.p : nullptr, c->has_group_owner ? c->ring_gid.p : nullptr,
-                       (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP);
-    return check_launch(c, "k_plane_plane");
+    a = PlanePlaneArgs{c->ring_grid.d, c->ring_grid.start.p, c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
+                       c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
+                       c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
+                       b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP};
+    nb = nblocks(c->nring * 64, 256, 8192);
+    return ARP_OK;
 }
-
-int enqueue_group_group(arp_ctx* c, hipStream_t st) {  // I:1217-1300
+int prepare_group_group(arp_ctx* c, GroupGroupArgs& a, int& nb) {  // I:1217-1300
     Bag& b = c->bag_gg;
+    nb = 0;
     if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->namide * 8 + 256, false, true));
     CHK(zero_counter(c, C_GG, 1));
     if (c->namide == 0) return ARP_OK;
     CHK(ensure_amide_grid(c));
-    Prof p(c, SLOT_PLANES, st);
-    hipLaunchKernelGGL(k_group_group, dim3(nblocks(c->namide * 64, 256, 8192)), dim3(256), 0, st, c->amide_grid.d, c->amide_grid.start.p,
-                       c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p,
-                       c->has_group_owner ? c->am_home.p : nullptr, c->has_group_owner ? c->am_gid.p : nullptr, (long long)b.cap,
-                       b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p, b.u0.p, c->d_ctr + C_GG);
-    return check_launch(c, "k_group_group");
+    a = GroupGroupArgs{c->amide_grid.d, c->amide_grid.start.p, c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p,
+                       c->am_sel.p, c->am_plus.p, c->has_group_owner ? c->am_home.p : nullptr,
+                       c->has_group_owner ? c->am_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p,
+                       b.u0.p, c->d_ctr + C_GG};
+    nb = nblocks(c->namide * 64, 256, 8192);
+    return ARP_OK;
 }
-
-int enqueue_group_plane(arp_ctx* c, hipStream_t st) {  // I:1302-1382
+int prepare_group_plane(arp_ctx* c, GroupPlaneArgs& a, int& nb) {  // I:1302-1382
     Bag& b = c->bag_gp;
+    nb = 0;
     if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->namide * 8 + 256, true, false));
     CHK(zero_counter(c, C_GP, 1));
     if (c->namide == 0 || c->nring == 0) return ARP_OK;
     CHK(ensure_ring_grid(c));
+    a = GroupPlaneArgs{c->ring_grid.d, c->ring_grid.start.p, c->ring_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p,
+                       c->am_sel.p, c->am_plus.p, c->ring_c.p, c->ring_n.p, c->ring_sel.p, c->ring_plus.p,
+                       c->has_group_owner ? c->am_home.p : nullptr, c->has_group_owner ? c->am_gid.p : nullptr,
+                       c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
+                       b.u0.p, c->d_ctr + C_GP};
+    nb = nblocks(c->namide * 64, 256, 8192);
+    return ARP_OK;
+}
+
+int enqueue_atom_plane(arp_ctx* c, hipStream_t st) {
+    AtomPlaneArgs a{};
+    int nb = 0;
+    CHK(prepare_atom_plane(c, a, nb));
+    if (!nb) return ARP_OK;
     Prof p(c, SLOT_PLANES, st);
-    hipLaunchKernelGGL(k_group_plane, dim3(nblocks(c->namide * 64, 256, 8192)), dim3(256), 0, st, c->ring_grid.d, c->ring_grid.start.p,
-                       c->ring_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p, c->am_sel.p, c->am_plus.p, c->ring_c.p,
-                       c->ring_n.p, c->ring_sel.p, c->ring_plus.p, c->has_group_owner ? c->am_home.p : nullptr,
-                       c->has_group_owner ? c->am_gid.p : nullptr, c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap,
-                       b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p, b.u0.p, c->d_ctr + C_GP);
+    hipLaunchKernelGGL(k_atom_plane, dim3(nb), dim3(256), 0, st, a);
+    return check_launch(c, "k_atom_plane");
+}
+int enqueue_plane_plane(arp_ctx* c, hipStream_t st) {
+    PlanePlaneArgs a{};
+    int nb = 0;
+    CHK(prepare_plane_plane(c, a, nb));
+    if (!nb) return ARP_OK;
+    Prof p(c, SLOT_PLANES, st);
+    hipLaunchKernelGGL(k_plane_plane, dim3(nb), dim3(256), 0, st, a);
+    return check_launch(c, "k_plane_plane");
+}
+int enqueue_group_group(arp_ctx* c, hipStream_t st) {
+    GroupGroupArgs a{};
+    int nb = 0;
+    CHK(prepare_group_group(c, a, nb));
+    if (!nb) return ARP_OK;
+    Prof p(c, SLOT_PLANES, st);
+    hipLaunchKernelGGL(k_group_group, dim3(nb), dim3(256), 0, st, a);
+    return check_launch(c, "k_group_group");
+}
+int enqueue_group_plane(arp_ctx* c, hipStream_t st) {
+    GroupPlaneArgs a{};
+    int nb = 0;
+    CHK(prepare_group_plane(c, a, nb));
+    if (!nb) return ARP_OK;
+    Prof p(c, SLOT_PLANES, st);
+    hipLaunchKernelGGL(k_group_plane, dim3(nb), dim3(256), 0, st, a);
     return check_launch(c, "k_group_plane");
+}
+// I:346-347 (I:944-945, 1214-1215): all four in one launch
+int enqueue_planes(arp_ctx* c, hipStream_t st) {
+    AtomPlaneArgs ap{};
+    PlanePlaneArgs pp{};
+    GroupGroupArgs gg{};
+    GroupPlaneArgs gp{};
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    CHK(prepare_atom_plane(c, ap, n0));
+    CHK(prepare_plane_plane(c, pp, n1));
+    CHK(prepare_group_group(c, gg, n2));
+    CHK(prepare_group_plane(c, gp, n3));
+    if (n0 + n1 + n2 + n3 == 0) return ARP_OK;
+    Prof p(c, SLOT_PLANES, st);
+    hipLaunchKernelGGL(k_planes, dim3(n0 + n1 + n2 + n3), dim3(256), 0, st, ap, pp, gg, gp, n0, n0 + n1, n0 + n1 + n2);
+    return check_launch(c, "k_planes");
 }
 
 // After read_counters(): publish contact results; returns true when the pair buffer overflowed.
@@ -1302,10 +1358,7 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
         if (fork_early) CHK(enqueue_expansion(c, expand_radius, c->stream2));
         CHK(enqueue_selection_sets(c, c->stream2));                                 // I:1413-1437
-        CHK(enqueue_atom_plane(c, c->stream2));                                     // I:346 (I:945), reuses the 6 A grid
-        CHK(enqueue_plane_plane(c, c->stream2));                                    // I:346 (I:944)
-        CHK(enqueue_group_group(c, c->stream2));                                    // I:347 (I:1214)
-        CHK(enqueue_group_plane(c, c->stream2));                                    //       (I:1215)
+        CHK(enqueue_planes(c, c->stream2));                                         // I:346-347 (I:944-945, 1214-1215)
         HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));                  // join
         return enqueue_counter_copy(c, 1);
@@ -1464,10 +1517,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
         CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // critical path first (see arp_run_launch)
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
-        CHK(enqueue_atom_plane(c, c->stream2));
-        CHK(enqueue_plane_plane(c, c->stream2));
-        CHK(enqueue_group_group(c, c->stream2));
-        CHK(enqueue_group_plane(c, c->stream2));
+        CHK(enqueue_planes(c, c->stream2));
         HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
         CHK(enqueue_counter_copy(c));

@@ -90,7 +90,31 @@ __device__ __forceinline__ long long wave_slot(bool emit, u64* __restrict__ n_ou
 // NeighborSearch.search(center, 6.0) (I:960).  The grid is the all-atom 6 A grid of the
 // selection expansion; membership of the selection_plus tree (I:1442) and the hydrogen
 // filter (I:964) are applied per atom.
-__global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __restrict__ start,
+struct AtomPlaneArgs {
+    GridDesc g;
+    const int* start;
+    const float4* s_xyzm;
+    const int4* s_aux;
+    int nring;
+    const double* ring_c;
+    const double* ring_n;
+    const int* ring_res;
+    const uint8_t* ring_sel;
+    const uint8_t* ring_plus;
+    const uint8_t* plus;
+    const uint8_t* ring_home;
+    const int* ring_gid;
+    const int* gid;
+    long long cap;
+    int* out_atom;
+    int* out_ring;
+    double* out_dist;
+    double* out_theta;
+    uint8_t* out_mask;
+    uint8_t* out_ct;
+    u64* n_out;
+};
+__device__ __forceinline__ void atom_plane_body(GridDesc g, const int* __restrict__ start,
                                                     const float4* __restrict__ s_xyzm, const int4* __restrict__ s_aux,
                                                     int nring, const double* __restrict__ ring_c,
                                                     const double* __restrict__ ring_n, const int* __restrict__ ring_res,
@@ -100,10 +124,10 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
                                                     const int* __restrict__ gid, long long cap, int* __restrict__ out_atom,
                                                     int* __restrict__ out_ring, double* __restrict__ out_dist,
                                                     double* __restrict__ out_theta, uint8_t* __restrict__ out_mask,
-                                                    uint8_t* __restrict__ out_ct, u64* __restrict__ n_out) {
+                                                    uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (vgrid * blockDim.x) >> 6;
     for (int r = wave; r < nring; r += nwave) {
         if (!ring_plus[r]) continue;  // I:957
         if (ring_home && !ring_home[r]) continue;  // multi-GPU: the rank owning the ring emits
@@ -153,7 +177,31 @@ __global__ __launch_bounds__(256) void k_atom_plane(GridDesc g, const int* __res
 
 // One wavefront per ring a; lanes = partner rings b > a of the 27 cells around it.  Reproduces
 // both visits (a,b) and (b,a) of the reference's ordered double loop and its dedupe (I:1181-1194).
-__global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
+struct PlanePlaneArgs {
+    GridDesc g;
+    const int* start;
+    const int* perm;
+    int nring;
+    const double* ring_c;
+    const double* ring_n;
+    const int* ring_res;
+    const uint8_t* ring_sel;
+    const uint8_t* ring_plus;
+    const uint8_t* ring_home;
+    const int* ring_gid;
+    long long cap;
+    int* out_bgn;
+    int* out_end;
+    double* out_dist;
+    double* out_dih;
+    double* out_t1;
+    double* out_t2;
+    uint8_t* out_y1;
+    uint8_t* out_y2;
+    uint8_t* out_ct;
+    u64* n_out;
+};
+__device__ __forceinline__ void plane_plane_body(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
                                                      int nring, const double* __restrict__ ring_c,
                                                      const double* __restrict__ ring_n, const int* __restrict__ ring_res,
                                                      const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
@@ -162,10 +210,10 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_t1, double* __restrict__ out_t2,
                                                      uint8_t* __restrict__ out_y1, uint8_t* __restrict__ out_y2,
-                                                     uint8_t* __restrict__ out_ct, u64* __restrict__ n_out) {
+                                                     uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (vgrid * blockDim.x) >> 6;
     for (int a = wave; a < nring; a += nwave) {
         if (!ring_plus[a]) continue;  // I:1081
         if (ring_home && !ring_home[a]) continue;  // multi-GPU: owner of the lower ring id emits the pair
@@ -221,17 +269,37 @@ __global__ __launch_bounds__(256) void k_plane_plane(GridDesc g, const int* __re
 }
 
 // One wavefront per amide a; lanes = every other amide b of the 27 cells: ordered pairs, float32 (I:1217-1300).
-__global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
+struct GroupGroupArgs {
+    GridDesc g;
+    const int* start;
+    const int* perm;
+    int namide;
+    const float* am_c;
+    const float* am_n;
+    const uint8_t* am_sel;
+    const uint8_t* am_plus;
+    const uint8_t* am_home;
+    const int* am_gid;
+    long long cap;
+    int* out_bgn;
+    int* out_end;
+    float* out_dist;
+    float* out_dih;
+    float* out_theta;
+    uint8_t* out_ct;
+    u64* n_out;
+};
+__device__ __forceinline__ void group_group_body(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
                                                      int namide, const float* __restrict__ am_c, const float* __restrict__ am_n,
                                                      const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
                                                      const uint8_t* __restrict__ am_home, const int* __restrict__ am_gid,
                                                      long long cap, int* __restrict__ out_bgn, int* __restrict__ out_end,
                                                      float* __restrict__ out_dist, float* __restrict__ out_dih,
                                                      float* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     u64* __restrict__ n_out) {
+                                                     u64* __restrict__ n_out, int vblock, int vgrid) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (vgrid * blockDim.x) >> 6;
     for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
         if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the bgn amide emits
@@ -269,7 +337,32 @@ __global__ __launch_bounds__(256) void k_group_group(GridDesc g, const int* __re
 }
 
 // One wavefront per amide; lanes = rings of the 27 cells of the RING grid around the amide centre (I:1302-1382).
-__global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
+struct GroupPlaneArgs {
+    GridDesc g;
+    const int* start;
+    const int* perm;
+    int namide;
+    const float* am_c;
+    const float* am_n;
+    const uint8_t* am_sel;
+    const uint8_t* am_plus;
+    const double* ring_c;
+    const double* ring_n;
+    const uint8_t* ring_sel;
+    const uint8_t* ring_plus;
+    const uint8_t* am_home;
+    const int* am_gid;
+    const int* ring_gid;
+    long long cap;
+    int* out_amide;
+    int* out_ring;
+    double* out_dist;
+    double* out_dih;
+    double* out_theta;
+    uint8_t* out_ct;
+    u64* n_out;
+};
+__device__ __forceinline__ void group_plane_body(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
                                                      int namide, const float* __restrict__ am_c, const float* __restrict__ am_n,
                                                      const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
                                                      const double* __restrict__ ring_c, const double* __restrict__ ring_n,
@@ -279,10 +372,10 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
                                                      long long cap, int* __restrict__ out_amide, int* __restrict__ out_ring,
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     u64* __restrict__ n_out) {
+                                                     u64* __restrict__ n_out, int vblock, int vgrid) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (vgrid * blockDim.x) >> 6;
     for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
         if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the amide emits
@@ -317,5 +410,40 @@ __global__ __launch_bounds__(256) void k_group_plane(GridDesc g, const int* __re
                 out_ct[slot] = (uint8_t)ct;
             }
         }
+    }
+}
+
+// ---- launchable forms -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_atom_plane(AtomPlaneArgs a) {
+    atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void k_plane_plane(PlanePlaneArgs a) {
+    plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void k_group_group(GroupGroupArgs a) {
+    group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void k_group_plane(GroupPlaneArgs a) {
+    group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The four ring / amide kernels of a pass in ONE launch: blocks [0, nb0) work as k_atom_plane, [nb0, nb1) as
+// k_plane_plane, [nb1, nb2) as k_group_group, the rest as k_group_plane (a part with no blocks is skipped).  They are
+// independent of each other, so this saves three dependent-launch gaps and lets the small grids share the chip.
+__global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, int nb0,
+                                                int nb1, int nb2) {
+    const int b = (int)blockIdx.x, nb = (int)gridDim.x;
+    if (b < nb0) {
+        const AtomPlaneArgs& a = ap;
+        atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, b, nb0);
+    } else if (b < nb1) {
+        const PlanePlaneArgs& a = pp;
+        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - nb0, nb1 - nb0);
+    } else if (b < nb2) {
+        const GroupGroupArgs& a = gg;
+        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb1, nb2 - nb1);
+    } else {
+        const GroupPlaneArgs& a = gp;
+        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb2, nb - nb2);
     }
 }
