@@ -555,6 +555,46 @@ __device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) 
 #ifndef SIFT_MIN_WAVES
 #define SIFT_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for (sweep in profiles/README.md)
 #endif
+// The hydrogen geometry of one pair: the branches in `need` (bit k = branch k of the list in k_sift), run on a
+// lane of the task stage.  Returns the SIFt bits they add.
+__device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftRec& qe, unsigned need, const double* __restrict__ h_xyz,
+                                                  double comp, int ablate) {
+    const uint32_t mb = __float_as_uint(qb.xyzm.w), me = __float_as_uint(qe.xyzm.w);
+    const num::f3 xb = xyz_of(qb.xyzm), xe = xyz_of(qe.xyzm);
+    const float4 sbb = make_float4(qb.sbl.x, qb.sbl.y, qb.sbl.z, (mb & M_HAS_SB) ? 1.0f : 0.0f);
+    const float4 sbe = make_float4(qe.sbl.x, qe.sbl.y, qe.sbl.z, (me & M_HAS_SB) ? 1.0f : 0.0f);
+    const double vb = qb.rad.x, ve = qe.rad.x;
+    const int hb0 = qb.csr.x, hb1 = (ablate & 16) ? hb0 : qb.csr.x + qb.csr.y, he0 = qe.csr.x,
+              he1 = (ablate & 16) ? he0 : qe.csr.x + qe.csr.y;   // (ablate: profiling aid, ARP_ABLATE)
+    unsigned todo = need, res = 0;
+    while (todo) {                     // almost always one branch per pair
+        const int kind = __ffs(todo) - 1;
+        todo &= todo - 1;
+        bool r;
+        if (kind < 4) {
+            const bool donor_b = (kind == 0) || (kind == 3);
+            const double amin = (kind < 2) ? 1.57 : 2.27;
+            const double cmin = (kind < 2) ? ARP_COS_1_57 : ARP_COS_2_27;
+            r = hbond_like(donor_b ? xb : xe, h_xyz, donor_b ? hb0 : he0, donor_b ? hb1 : he1, donor_b ? xe : xb,
+                           donor_b ? ve : vb, comp, amin, cmin);
+        } else {
+            const bool hal_b = kind == 4;
+            r = halogen_weak(hal_b ? xb : xe, hal_b ? sbb : sbe, hal_b ? vb : ve, h_xyz, hal_b ? he0 : hb0,
+                             hal_b ? he1 : hb1, comp);
+        }
+        res |= (r ? 1u : 0u) << kind;
+    }
+    uint32_t s = 0;
+    if (res & 3u) s |= ARP_S_HBOND;
+    // the LAST applicable weak branch decides SIFt[6] (every branch overwrites it)
+    if (need & 60u) {
+        const int last = 31 - __clz((int)(need & 60u));
+        if ((res >> last) & 1u) s |= ARP_S_WEAK_HBOND;
+    }
+    return s;
+}
+
+#define SIFT_TASKQ 128
 __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
                                               const SiftRec* __restrict__ s_rec, const int* __restrict__ bond_idx,
                                               const double* __restrict__ h_xyz,
@@ -562,6 +602,22 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
                                               int* __restrict__ out_j, float* __restrict__ out_d,
                                               uint16_t* __restrict__ out_s, uint8_t* __restrict__ out_ct,
                                               int* __restrict__ err) {
+    // Two stages per wavefront.  Stage A, one lane per pair: everything of I:715-936 that needs no hydrogen — distance
+    // ladder, metal, type-pair flags, halogen bond — and the list of hydrogen-geometry branches the pair needs:
+    //   0 is_hbond(bgn, end)   1 is_hbond(end, bgn)          (if / elif, I:804-819)
+    //   2 is_weak_hbond(end, bgn)   3 is_weak_hbond(bgn, end)   4 / 5 is_halogen_weak_hbond  (I:857-886)
+    // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
+    // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
+    __shared__ uint4 tq[4][SIFT_TASKQ];   // {output index, bgn position, end position, sift | need << 16}
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int tn = 0;
+    auto run_tasks = [&](int first, int count) {   // stage B on tq[w][first .. first + count)
+        if (lane < count) {
+            const uint4 t = tq[w][first + lane];
+            const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, comp, ablate);
+            out_s[t.x] = (uint16_t)((t.w & 0xFFFFu) | add);
+        }
+    };
     // The segment fill counts are read on the device: no host round trip between search and sift.
     // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
     // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
@@ -573,14 +629,16 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
     const long long nseg = (long long)min(npairs_ptr[sgm], cap);
     const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
     const long long stride = (long long)(gridDim.x / PAIR_SEGS) * blockDim.x;
-    for (long long ps = (long long)(blockIdx.x / PAIR_SEGS) * blockDim.x + threadIdx.x; ps < nseg; ps += stride) {
+    for (long long base = (long long)(blockIdx.x / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane); base < nseg; base += stride) {
+        const long long ps = base + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
+        bool queued = false;
+        uint4 task = make_uint4(0u, 0u, 0u, 0u);
+        if (ps < nseg) {
         const long long p = out_base + ps;
         const int2 pr = seg_pairs[ps];
         const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // one 64-byte line per atom
         const float4 vb = qb.xyzm, ve = qe.xyzm;
         const int b = __float_as_int(qb.sbl.w), e = __float_as_int(qe.sbl.w);
-        const float4 sbb = make_float4(qb.sbl.x, qb.sbl.y, qb.sbl.z, (__float_as_uint(vb.w) & M_HAS_SB) ? 1.0f : 0.0f);
-        const float4 sbe = make_float4(qe.sbl.x, qe.sbl.y, qe.sbl.z, (__float_as_uint(ve.w) & M_HAS_SB) ? 1.0f : 0.0f);
         const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
         const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
         const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
@@ -590,6 +648,7 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
         const double sum_cov = rb.y + re.y, sum_vdw = rb.x + re.x;      // interactions.py:717-718
         const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
         uint32_t s = 0;
+        unsigned need = 0;
         // interactions.py:748-757: end among the bonded neighbours of bgn
         bool cov = false;
         for (int k = qb.csr.z, k1 = qb.csr.z + qb.csr.w; k < k1; ++k)
@@ -609,15 +668,8 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
         }
         // interactions.py:786: not clash (covalent pairs do get feature flags) and d <= 4.5
         if (!(s & ARP_S_CLASH) && d <= (float)4.5) {
-            const int hb0 = qb.csr.x, hb1 = (ablate & 16) ? hb0 : qb.csr.x + qb.csr.y, he0 = qe.csr.x,
-                      he1 = (ablate & 16) ? he0 : qe.csr.x + qe.csr.y;   // (ablate: profiling aid, ARP_ABLATE)
-            // interactions.py:791-819 (hbond / polar) and 857-886 (weak hbond / weak polar).  The flags that need no
-            // geometry are set here; the up-to-six hydrogen-geometry evaluations of a pair become a per-lane task list
-            // so that lanes needing DIFFERENT branches run side by side in one pass of the wave instead of one
-            // mostly-idle pass per branch:
-            //   0 is_hbond(bgn, end)   1 is_hbond(end, bgn)          (if / elif, I:804-819)
-            //   2 is_weak_hbond(end, bgn)   3 is_weak_hbond(bgn, end)   4 / 5 is_halogen_weak_hbond  (I:857-886)
-            unsigned need = 0;
+            // interactions.py:791-819 (hbond / polar) and 857-886 (weak hbond / weak polar): the flags that need no
+            // geometry are set here, the hydrogen-geometry branches go to the task list
             if (bw && d <= f_vdw_comp) {
                 if (te & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
             } else if (ew && d <= f_vdw_comp) {
@@ -636,35 +688,13 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
             if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) && (te & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 16u;
             if ((te & ARP_T_WEAK_HBOND_ACCEPTOR) && (me & M_HALOGEN) && (tb & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 32u;
             if ((need & 60u) && d <= (float)3.5) s |= ARP_S_WEAK_POLAR;   // each applicable weak branch sets it (I:861,869,877,885)
-            unsigned todo = need, res = 0;
-            while (todo) {                     // divergent trip counts: a lane leaves when its list is empty
-                const int kind = __ffs(todo) - 1;
-                todo &= todo - 1;
-                bool r;
-                if (kind < 4) {
-                    const bool donor_b = (kind == 0) || (kind == 3);
-                    const double amin = (kind < 2) ? 1.57 : 2.27;
-                    const double cmin = (kind < 2) ? ARP_COS_1_57 : ARP_COS_2_27;
-                    r = hbond_like(donor_b ? xb : xe, h_xyz, donor_b ? hb0 : he0, donor_b ? hb1 : he1, donor_b ? xe : xb,
-                                   donor_b ? re.x : rb.x, comp, amin, cmin);
-                } else {
-                    const bool hal_b = kind == 4;
-                    r = halogen_weak(hal_b ? xb : xe, hal_b ? sbb : sbe, hal_b ? rb.x : re.x, h_xyz, hal_b ? he0 : hb0,
-                                     hal_b ? he1 : hb1, comp);
-                }
-                res |= (r ? 1u : 0u) << kind;
-            }
-            if (res & 3u) s |= ARP_S_HBOND;
-            // the LAST applicable weak branch decides SIFt[6] (every branch overwrites it)
-            if (need & 60u) {
-                const int last = 31 - __clz((int)(need & 60u));
-                if ((res >> last) & 1u) s |= ARP_S_WEAK_HBOND;
-            }
             // interactions.py:889-895
             if (d <= f_vdw_comp) {
                 if ((tb & ARP_T_XBOND_DONOR) && (te & ARP_T_XBOND_ACCEPTOR)) {
+                    const float4 sbb = make_float4(qb.sbl.x, qb.sbl.y, qb.sbl.z, (mb & M_HAS_SB) ? 1.0f : 0.0f);
                     if (xbond(sbb, xb, xe, err)) s |= ARP_S_XBOND;
                 } else if ((te & ARP_T_XBOND_DONOR) && (tb & ARP_T_XBOND_ACCEPTOR)) {
+                    const float4 sbe = make_float4(qe.sbl.x, qe.sbl.y, qe.sbl.z, (me & M_HAS_SB) ? 1.0f : 0.0f);
                     if (xbond(sbe, xe, xb, err)) s |= ARP_S_XBOND;
                 }
             }
@@ -685,9 +715,26 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
         out_i[p] = gid ? gid[b] : b;
         out_j[p] = gid ? gid[e] : e;
         out_d[p] = d;
-        out_s[p] = (uint16_t)s;
         out_ct[p] = (uint8_t)ct;
+        if (need) {
+            queued = true;
+            task = make_uint4((unsigned)p, (unsigned)pr.x, (unsigned)pr.y, s | (need << 16));
+        } else {
+            out_s[p] = (uint16_t)s;
+        }
+        }
+        // stage B bookkeeping (whole wave)
+        const unsigned long long mq = __ballot(queued);
+        if (mq) {
+            if (queued) tq[w][tn + __popcll(mq & ((1ull << lane) - 1ull))] = task;
+            tn += __popcll(mq);
+            if (tn >= 64) {
+                tn -= 64;
+                run_tasks(tn, 64);
+            }
+        }
     }
+    if (tn > 0) run_tasks(0, tn);
 }
 
 // Per-atom accumulators of the contact loop (interactions.py:821-852, 923-934; utils.py:182-221) from the
