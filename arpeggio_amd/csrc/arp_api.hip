@@ -117,8 +117,9 @@ struct arp_ctx {
     DevBuf<float4> s_xyzm;
     DevBuf<int4> s_aux;
     DevBuf<SiftRec> s_rec;
-    DevBuf<int4> st_csr;          // selection-independent record columns, composed once per structure (k_prepare_static)
-    DevBuf<float4> st_sbl;
+    DevBuf<int4> st_q1;           // selection-independent record columns, composed once per structure (k_prepare_static)
+    DevBuf<uint16_t> rad_idx;     // per atom: index of its {vdw, cov} pair in rad_tab (RAD_NONE: not in the table)
+    DevBuf<double2> rad_tab;      // RAD_TABLE distinct radius pairs of the structure
     DevBuf<int4> st_aux;
     DevBuf<float4> st_xyzm;
     bool static_dirty = true;
@@ -340,8 +341,7 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
 int ensure_static(arp_ctx* c) {
     if (!c->static_dirty) return ARP_OK;
     const int n = (int)c->n;
-    HIPCHK(c, c->st_csr.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->st_sbl.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->st_q1.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->st_xyzm.reserve((size_t)std::max(n, 1)));
     RawAtoms r;
@@ -350,9 +350,9 @@ int ensure_static(arp_ctx* c) {
     r.res_prev = c->has_res ? c->res_prev.p : nullptr;
     r.res_next = c->has_res ? c->res_next.p : nullptr;
     r.home = c->has_home ? c->home.p : nullptr;
-    r.rad = c->rad.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.sb = c->sb.p;
+    r.rad = c->rad.p; r.rad_idx = c->rad_idx.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.sb = c->sb.p;
     if (n > 0) {
-        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_csr.p, c->st_sbl.p);
+        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p);
         CHK(check_launch(c, "k_prepare_static"));
     }
     c->static_dirty = false;
@@ -362,9 +362,7 @@ int ensure_static(arp_ctx* c) {
 StaticAtoms static_atoms(arp_ctx* c) {
     StaticAtoms r;
     r.xyzm = c->st_xyzm.p;
-    r.rad = c->rad.p;
-    r.csr = c->st_csr.p;
-    r.sbl = c->st_sbl.p;
+    r.q1 = c->st_q1.p;
     r.aux = c->st_aux.p;
     r.sel = c->sel_made ? c->sel.p : nullptr;
     r.plus = c->sel_made ? c->plus.p : nullptr;
@@ -597,7 +595,8 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             Prof p(c, SLOT_SIFT);
             static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 8));
             hipLaunchKernelGGL(k_sift, dim3(c->num_cu * sift_blocks_per_cu), dim3(256), 0, c->stream, c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap,
-                               c->s_rec.p, c->bond_idx.p, c->h_xyz_d.p, c->has_gid ? c->gid.p : nullptr, vdw_comp, env_int("ARP_ABLATE", 0),
+                               c->s_rec.p, SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p}, c->bond_idx.p, c->h_xyz_d.p,
+                               c->has_gid ? c->gid.p : nullptr, vdw_comp, env_int("ARP_ABLATE", 0),
                                c->out_i.p,
                                c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p, (int*)(c->d_ctr + C_ERR));
             CHK(check_launch(c, "k_sift"));
@@ -844,7 +843,7 @@ void arp_destroy(arp_ctx* c) {
     c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
-    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->st_csr.release(); c->st_sbl.release(); c->st_aux.release(); c->st_xyzm.release();
+    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
@@ -881,6 +880,31 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     }
     CHK(upload(c, c->xyz, x4.data(), (size_t)n));
     CHK(upload(c, c->rad, r2.data(), (size_t)n));
+    {   // dictionary of the distinct {vdw, cov} pairs (element values: a handful per structure), compared bit for bit
+        std::vector<double2> tab((size_t)RAD_TABLE, make_double2(0.0, 0.0));
+        std::vector<uint16_t> idx((size_t)std::max<int64_t>(n, 1), (uint16_t)RAD_NONE);
+        std::vector<std::pair<uint64_t, uint64_t>> keys;   // bit patterns, in table order
+        int last = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            uint64_t kv, kc;
+            memcpy(&kv, &vdw[i], 8);
+            memcpy(&kc, &cov[i], 8);
+            int hit = -1;
+            if (!keys.empty() && keys[(size_t)last].first == kv && keys[(size_t)last].second == kc) hit = last;
+            for (size_t k = 0; hit < 0 && k < keys.size(); ++k)
+                if (keys[k].first == kv && keys[k].second == kc) hit = (int)k;
+            if (hit < 0) {
+                if ((int)keys.size() >= RAD_TABLE) continue;   // stays RAD_NONE: k_sift fetches the uploaded radii
+                hit = (int)keys.size();
+                keys.emplace_back(kv, kc);
+                tab[(size_t)hit] = make_double2(vdw[i], cov[i]);
+            }
+            last = hit;
+            idx[(size_t)i] = (uint16_t)hit;
+        }
+        CHK(upload(c, c->rad_idx, idx.data(), (size_t)std::max<int64_t>(n, 1)));
+        CHK(upload(c, c->rad_tab, tab.data(), (size_t)RAD_TABLE));
+    }
     CHK(upload(c, c->tmask, type_mask, (size_t)n));
     CHK(upload(c, c->flags, flags, (size_t)n));
     CHK(upload(c, c->res_id, res_id, (size_t)n));

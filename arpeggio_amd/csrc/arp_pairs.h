@@ -67,17 +67,26 @@ struct RawAtoms {
     const int* res_next;
     const uint8_t* home;        // null: every atom owned by this rank
     const double2* rad;         // {vdw, cov}
+    const uint16_t* rad_idx;    // index of the atom's {vdw, cov} in the radius table, RAD_NONE: not in the table
     const int* h_off;
     const int* bond_off;
     const float4* sb;           // single-bond neighbour xyz, w = present
 };
 
-// 64-byte (one cache line) record read by k_sift for each atom of a pair
-struct __attribute__((aligned(64))) SiftRec {
-    float4 xyzm;      // x, y, z, meta
-    double2 rad;      // vdw, cov
-    int4 csr;         // h_off, h_count, bond_off, bond_count
-    float4 sbl;       // single-bond neighbour x, y, z; w = bit pattern of the local atom id
+// 32-byte record read by k_sift for each atom of a pair (two 16-byte gathers; the L1 tag rate is what bounds
+// that kernel, so everything it needs per atom sits in these two quads):
+//   xyzm = x, y, z, meta
+//   q1   = local atom id, bond_off, h_off, bond_cnt | h_cnt << 8 | rad_idx << 16
+// The {vdw, cov} float64 pair of an atom is one of a handful of element values: arp_set_atoms builds a table of the
+// distinct pairs (RAD_TABLE entries at most) and k_sift keeps it in LDS; an atom whose pair did not fit carries
+// RAD_NONE and its radii are fetched from the uploaded array.  Counts saturate at CNT_SAT (then the CSR offsets are
+// read).  The single-bond-neighbour coordinate (halogen / xbond branches only) stays in its uploaded array.
+#define RAD_TABLE 256
+#define RAD_NONE 0xFFFFu
+#define CNT_SAT 255
+struct __attribute__((aligned(32))) SiftRec {
+    float4 xyzm;
+    int4 q1;
 };
 
 // Everything of an atom record that does not depend on the selection, composed once per structure and
@@ -85,16 +94,14 @@ struct __attribute__((aligned(64))) SiftRec {
 struct StaticAtoms {
     const float4* xyzm;         // x, y, z, static meta
     const int4* aux;            // local id, residue, previous residue, next residue
-    const double2* rad;         // the uploaded radii, untouched
-    const int4* csr;            // h_off, h_count, bond_off, bond_count
-    const float4* sbl;          // single-bond neighbour xyz, w = bit pattern of the local id
+    const int4* q1;             // second quad of the sift record (see SiftRec)
     const uint8_t* sel;         // null: nothing selected
     const uint8_t* plus;        // null: everything in selection_plus
     int all;                    // the selection is the whole structure (then selection_plus is, too): sel / plus not read
 };
 
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
-                                                        int4* __restrict__ st_csr, float4* __restrict__ st_sbl) {
+                                                        int4* __restrict__ st_q1) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 v = r.xyz[i];
         const int res = r.res_id[i];
@@ -107,9 +114,9 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         if (sb.w != 0.0f) m |= M_HAS_SB;
         v.w = __uint_as_float(m);
         const int h0 = r.h_off[i], b0 = r.bond_off[i];
+        const int hc = min(r.h_off[i + 1] - h0, CNT_SAT), bc = min(r.bond_off[i + 1] - b0, CNT_SAT);
         st_xyzm[i] = v;
-        st_csr[i] = make_int4(h0, r.h_off[i + 1] - h0, b0, r.bond_off[i + 1] - b0);
-        st_sbl[i] = make_float4(sb.x, sb.y, sb.z, __int_as_float(i));
+        st_q1[i] = make_int4(i, b0, h0, bc | (hc << 8) | ((int)r.rad_idx[i] << 16));
         st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
     }
 }
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDes
 }
 
 // counting-sort scatter fused with the record build: every binned atom writes its cell-sorted
-// search record (xyzm + aux, 32 B) and, for the contact grid, its one-line sift record (64 B).
+// search record (xyzm + aux, 32 B) and, for the contact grid, its sift record (32 B).
 __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int* __restrict__ cell_of,
                                                        const int* __restrict__ start, int* __restrict__ cell_cnt,
                                                        float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
@@ -160,15 +167,11 @@ __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, con
         const float4 xyzm = compose_xyzm(r, i);
         const int4 aux = r.aux[i];
         SiftRec q;
-        if (s_rec) {
-            q.rad = r.rad[i];
-            q.csr = r.csr[i];
-            q.sbl = r.sbl[i];
-        }
+        if (s_rec) q.q1 = r.q1[i];
         const int pos = start[c] + atomicSub(&cell_cnt[c], 1) - 1;
         s_xyzm[pos] = xyzm;
         s_aux[pos] = aux;
-        if (s_rec) {   // the contact grid also carries the one-line sift record
+        if (s_rec) {   // the contact grid also carries the sift record
             q.xyzm = xyzm;
             s_rec[pos] = q;
         }
@@ -555,17 +558,35 @@ __device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) 
 #ifndef SIFT_MIN_WAVES
 #define SIFT_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for (sweep in profiles/README.md)
 #endif
+// Arrays k_sift reads beside the 32-byte records
+struct SiftSide {
+    const double2* rad_tab;   // RAD_TABLE distinct {vdw, cov} pairs (copied to LDS)
+    const double2* rad;       // uploaded radii by local atom id (atoms outside the table)
+    const int* h_off;         // uploaded CSR offsets by local atom id (saturated counts)
+    const int* bond_off;
+    const float4* sb;         // single-bond heavy neighbour by local atom id: x, y, z, present
+};
+__device__ __forceinline__ double2 rec_rad(int4 q1, const double2* s_tab, const SiftSide& sd) {
+    const unsigned ri = (unsigned)q1.w >> 16;
+    return (ri != RAD_NONE) ? s_tab[ri] : sd.rad[q1.x];
+}
+__device__ __forceinline__ int rec_bond_cnt(int4 q1, const SiftSide& sd) {
+    const int k = q1.w & 255;
+    return (k < CNT_SAT) ? k : sd.bond_off[q1.x + 1] - q1.y;
+}
+__device__ __forceinline__ int rec_h_cnt(int4 q1, const SiftSide& sd) {
+    const int k = (q1.w >> 8) & 255;
+    return (k < CNT_SAT) ? k : sd.h_off[q1.x + 1] - q1.z;
+}
+
 // The hydrogen geometry of one pair: the branches in `need` (bit k = branch k of the list in k_sift), run on a
 // lane of the task stage.  Returns the SIFt bits they add.
 __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftRec& qe, unsigned need, const double* __restrict__ h_xyz,
-                                                  double comp, int ablate) {
-    const uint32_t mb = __float_as_uint(qb.xyzm.w), me = __float_as_uint(qe.xyzm.w);
+                                                  const double2* s_tab, const SiftSide& sd, double comp, int ablate) {
     const num::f3 xb = xyz_of(qb.xyzm), xe = xyz_of(qe.xyzm);
-    const float4 sbb = make_float4(qb.sbl.x, qb.sbl.y, qb.sbl.z, (mb & M_HAS_SB) ? 1.0f : 0.0f);
-    const float4 sbe = make_float4(qe.sbl.x, qe.sbl.y, qe.sbl.z, (me & M_HAS_SB) ? 1.0f : 0.0f);
-    const double vb = qb.rad.x, ve = qe.rad.x;
-    const int hb0 = qb.csr.x, hb1 = (ablate & 16) ? hb0 : qb.csr.x + qb.csr.y, he0 = qe.csr.x,
-              he1 = (ablate & 16) ? he0 : qe.csr.x + qe.csr.y;   // (ablate: profiling aid, ARP_ABLATE)
+    const double vb = rec_rad(qb.q1, s_tab, sd).x, ve = rec_rad(qe.q1, s_tab, sd).x;
+    const int hb0 = qb.q1.z, hb1 = (ablate & 16) ? hb0 : hb0 + rec_h_cnt(qb.q1, sd), he0 = qe.q1.z,
+              he1 = (ablate & 16) ? he0 : he0 + rec_h_cnt(qe.q1, sd);   // (ablate: profiling aid, ARP_ABLATE)
     unsigned todo = need, res = 0;
     while (todo) {                     // almost always one branch per pair
         const int kind = __ffs(todo) - 1;
@@ -579,7 +600,8 @@ __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftR
                            donor_b ? ve : vb, comp, amin, cmin);
         } else {
             const bool hal_b = kind == 4;
-            r = halogen_weak(hal_b ? xb : xe, hal_b ? sbb : sbe, hal_b ? vb : ve, h_xyz, hal_b ? he0 : hb0,
+            const float4 sbh = sd.sb[hal_b ? qb.q1.x : qe.q1.x];   // w = 1 when the halogen has a single-bond neighbour
+            r = halogen_weak(hal_b ? xb : xe, sbh, hal_b ? vb : ve, h_xyz, hal_b ? he0 : hb0,
                              hal_b ? he1 : hb1, comp);
         }
         res |= (r ? 1u : 0u) << kind;
@@ -596,7 +618,7 @@ __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftR
 
 #define SIFT_TASKQ 128
 __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
-                                              const SiftRec* __restrict__ s_rec, const int* __restrict__ bond_idx,
+                                              const SiftRec* __restrict__ s_rec, SiftSide sd, const int* __restrict__ bond_idx,
                                               const double* __restrict__ h_xyz,
                                               const int* __restrict__ gid, double comp, int ablate, int* __restrict__ out_i,
                                               int* __restrict__ out_j, float* __restrict__ out_d,
@@ -609,12 +631,15 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
     // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
     // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
     __shared__ uint4 tq[4][SIFT_TASKQ];   // {output index, bgn position, end position, sift | need << 16}
+    __shared__ double2 s_tab[RAD_TABLE];   // the structure's distinct {vdw, cov} pairs
+    s_tab[threadIdx.x] = sd.rad_tab[threadIdx.x];   // (blockDim.x == RAD_TABLE)
+    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int tn = 0;
     auto run_tasks = [&](int first, int count) {   // stage B on tq[w][first .. first + count)
         if (lane < count) {
             const uint4 t = tq[w][first + lane];
-            const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, comp, ablate);
+            const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, s_tab, sd, comp, ablate);
             out_s[t.x] = (uint16_t)((t.w & 0xFFFFu) | add);
         }
     };
@@ -636,22 +661,22 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
         if (ps < nseg) {
         const long long p = out_base + ps;
         const int2 pr = seg_pairs[ps];
-        const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // one 64-byte line per atom
+        const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // two 16-byte quads per atom
         const float4 vb = qb.xyzm, ve = qe.xyzm;
-        const int b = __float_as_int(qb.sbl.w), e = __float_as_int(qe.sbl.w);
+        const int b = qb.q1.x, e = qe.q1.x;
         const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
         const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
         const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
         const bool bw = mb & M_WATER, ew = me & M_WATER;
         const int ct = contact_type(mb & M_SEL, me & M_SEL, bw, ew);  // interactions.py:715
-        const double2 rb = qb.rad, re = qe.rad;                         // {vdw, cov}
+        const double2 rb = rec_rad(qb.q1, s_tab, sd), re = rec_rad(qe.q1, s_tab, sd);   // {vdw, cov}
         const double sum_cov = rb.y + re.y, sum_vdw = rb.x + re.x;      // interactions.py:717-718
         const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
         uint32_t s = 0;
         unsigned need = 0;
         // interactions.py:748-757: end among the bonded neighbours of bgn
         bool cov = false;
-        for (int k = qb.csr.z, k1 = qb.csr.z + qb.csr.w; k < k1; ++k)
+        for (int k = qb.q1.y, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
             if (bond_idx[k] == e) { cov = true; break; }
         // interactions.py:756-773: float32 distance against Python floats -> float32 compare
         const double vdw_comp = sum_vdw + comp;
@@ -691,11 +716,9 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
             // interactions.py:889-895
             if (d <= f_vdw_comp) {
                 if ((tb & ARP_T_XBOND_DONOR) && (te & ARP_T_XBOND_ACCEPTOR)) {
-                    const float4 sbb = make_float4(qb.sbl.x, qb.sbl.y, qb.sbl.z, (mb & M_HAS_SB) ? 1.0f : 0.0f);
-                    if (xbond(sbb, xb, xe, err)) s |= ARP_S_XBOND;
+                    if (xbond(sd.sb[b], xb, xe, err)) s |= ARP_S_XBOND;
                 } else if ((te & ARP_T_XBOND_DONOR) && (tb & ARP_T_XBOND_ACCEPTOR)) {
-                    const float4 sbe = make_float4(qe.sbl.x, qe.sbl.y, qe.sbl.z, (me & M_HAS_SB) ? 1.0f : 0.0f);
-                    if (xbond(sbe, xe, xb, err)) s |= ARP_S_XBOND;
+                    if (xbond(sd.sb[e], xe, xb, err)) s |= ARP_S_XBOND;
                 }
             }
             // interactions.py:898-904

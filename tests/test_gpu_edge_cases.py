@@ -144,3 +144,35 @@ def test_selection_of_a_single_atom_and_of_nothing_nearby(ctx):
     sel = np.array([0, 0, 0, 0, 1], np.uint8)                      # isolated atom: selection_plus == selection, no contacts
     got = _check(ctx, pc, sel)
     assert len(got['i']) == 0
+
+
+def test_more_distinct_radii_than_the_table_holds(ctx):
+    """The sift record carries an index into a 256-entry {vdw, cov} table; atoms beyond it read the uploaded radii."""
+    from helpers import random_dense_pack
+    pc = random_dense_pack(33, n=900, box=16.0)
+    rng = np.random.default_rng(5)
+    pc.vdw = (np.asarray(pc.vdw) + rng.integers(0, 700, pc.n_atoms) * 1e-4).astype(np.float64)   # ~700 distinct pairs
+    pc.cov = (np.asarray(pc.cov) + rng.integers(0, 3, pc.n_atoms) * 1e-3).astype(np.float64)
+    assert len({(a, b) for a, b in zip(pc.vdw.tolist(), pc.cov.tolist())}) > 256
+    _check(ctx, pc)
+
+
+def test_atoms_with_hundreds_of_hydrogens_and_bonds(ctx):
+    """Counts are stored saturated at 255 in the record; beyond that the CSR offsets are read."""
+    from helpers import tiny_complex
+    from arpeggio_amd.core import config
+    rng = np.random.default_rng(9)
+    n = 320
+    xyz = (rng.random((n, 3)) * 9.0).astype(np.float32)
+    tm = np.zeros(n, np.uint16)
+    tm[0] = config.ATOM_TYPE_BIT['hbond donor'] | config.ATOM_TYPE_BIT['weak hbond donor']
+    tm[1:] = config.ATOM_TYPE_BIT['hbond acceptor']
+    v = rng.standard_normal((300, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    h = {0: (xyz[0].astype(np.float64) + v).tolist()}                       # 300 hydrogens on atom 0
+    bonds = [(0, j) for j in range(1, 301)]                                 # and 300 bonds
+    pc = tiny_complex(xyz, type_mask=tm, res_id=np.arange(n, dtype=np.int32), bonds=bonds, h=h)
+    got = _check(ctx, pc)
+    first = (got['i'] == 0)
+    cov_bit, hb_bit = 1 << config.SIFT_NAMES.index('covalent'), 1 << config.SIFT_NAMES.index('hbond')
+    assert first.any() and (got['sift'][first] & cov_bit).any() and (got['sift'][first] & hb_bit).any()
