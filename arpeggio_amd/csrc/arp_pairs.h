@@ -568,7 +568,13 @@ struct SiftSide {
 };
 __device__ __forceinline__ double2 rec_rad(int4 q1, const double2* s_tab, const SiftSide& sd) {
     const unsigned ri = (unsigned)q1.w >> 16;
-    return (ri != RAD_NONE) ? s_tab[ri] : sd.rad[q1.x];
+    double2 r = s_tab[ri & (RAD_TABLE - 1)];   // always an LDS read; the global fetch is a separate, rare branch
+    if (ri == RAD_NONE) {
+        int i = q1.x;
+        asm volatile("" : "+v"(i));   // opaque: keeps the compiler from folding both reads into one flat load
+        r = sd.rad[i];
+    }
+    return r;
 }
 __device__ __forceinline__ int rec_bond_cnt(int4 q1, const SiftSide& sd) {
     const int k = q1.w & 255;
