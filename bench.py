@@ -48,8 +48,8 @@ def algorithmic_bytes(kernel, n_binned, ncell, n_pairs):
         return 32 * n_binned + 4 * (ncell + 1) + 8 * n_pairs
     if kernel == 'mark_search':  # same reads, writes one byte per marked atom
         return 32 * n_binned + 4 * (ncell + 1) + n_binned
-    if kernel == 'sift':        # pair list + both records once per atom + radii + CSR offsets + 15-byte output record
-        return 8 * n_pairs + (32 + 16 + 8 + 16) * n_binned + 15 * n_pairs
+    if kernel == 'sift':        # pair list + each 32-byte atom record once + 15-byte output record
+        return 8 * n_pairs + 32 * n_binned + 15 * n_pairs
     raise KeyError(kernel)
 
 
@@ -230,7 +230,7 @@ def main():
         'kernel_launches_per_step': {k: v['launches'] / args.steps for k, v in ktimes.items() if v['launches']},
         'ms_per_step_profiled_pass': round(elapsed_profiled / args.steps * 1e3, 4),
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
-        'launch_mode': 'direct launches on two HIP streams, one host sync per step; kernel_ms from a second pass of the same steps with HIP events',
+        'launch_mode': 'direct launches on two HIP streams, one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'halo_exchange_ms': round(halo_ms, 3), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
