@@ -28,7 +28,7 @@ SYMBOLS = (
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
-    'arp_get_host_times',
+    'arp_get_host_times', 'arp_set_whole_structure',
 )
 
 _lib = None
@@ -85,6 +85,7 @@ def load():
     L.arp_set_profiling.argtypes = [vp, i32]
     L.arp_get_kernel_times.argtypes = [vp, vp, vp, i32]
     L.arp_get_host_times.argtypes = [vp, vp, vp, i32]
+    L.arp_set_whole_structure.argtypes = [vp, i32]
     L.arp_stream_handle.argtypes = [vp]
     L.arp_use_stream.argtypes = [vp, C.c_uint64]
     L.arp_stream_handle.restype = C.c_uint64
@@ -369,6 +370,10 @@ class Context:
         ms, ln = np.zeros(8, np.float64), np.zeros(8, np.int64)
         self._check(self._L.arp_get_kernel_times(self._h, _p(ms), _p(ln), int(reset)), 'arp_get_kernel_times')
         return {name: dict(ms=float(ms[k]), launches=int(ln[k])) for k, name in enumerate(KERNEL_SLOTS)}
+
+    def set_whole_structure(self, on=True):
+        """Sharded runs without a selection: assert that the selection is the whole global structure (no exchange needed)."""
+        self._check(self._L.arp_set_whole_structure(self._h, int(bool(on))), 'arp_set_whole_structure')
 
     def host_times(self, reset=False):
         """Per-pass host cost of run_launch: (enqueue_us, wait_us) averaged over the passes since the last reset."""

@@ -103,7 +103,9 @@ struct arp_ctx {
     DevBuf<uint8_t> home, sel, plus, res_sel, res_plus;
     bool has_res = false, has_gid = false, has_home = false;
     bool sel_made = false;
+    bool sel_uploaded = false;   // arp_set_selection / arp_set_selection_state since the last arp_set_atoms
     bool sel_all = false;        // the uploaded selection covers every atom: selection_plus = selection, no expansion search
+    bool whole_structure = false; // caller's assertion (arp_set_whole_structure): the selection is the whole GLOBAL structure
     DevBuf<double> ring_c, ring_n;
     DevBuf<int> ring_res;
     DevBuf<uint8_t> ring_sel, ring_plus;
@@ -540,8 +542,11 @@ int enqueue_selection_sets(arp_ctx* c, hipStream_t st) {
     HIPCHK(c, c->res_sel.reserve(2 * nres));   // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
     uint8_t* res_sel = c->res_sel.p;
     uint8_t* res_plus = c->res_sel.p + nres;
-    HIPCHK(c, hipMemsetAsync(res_sel, 0, 2 * nres, st));
-    if (n > 0)
+    // arp_set_whole_structure: every residue of the (global) table is selected — also those whose atoms live on
+    // another rank of a sharded run, which the local atoms could not tell
+    const bool all_res = c->whole_structure && c->sel_all;
+    HIPCHK(c, hipMemsetAsync(res_sel, all_res ? 1 : 0, 2 * nres, st));
+    if (n > 0 && !all_res)
         hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, st, n, c->res_id.p, c->sel.p, c->plus.p,
                            res_sel, res_plus);
     if (c->nring + c->namide > 0)
@@ -557,11 +562,14 @@ int enqueue_selection(arp_ctx* c, double radius) {   // the whole _make_selectio
 
 int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 with no selectors)
     if (c->sel_made) return ARP_OK;
-    const size_t n = (size_t)std::max<int64_t>(c->n, 1);
-    HIPCHK(c, c->sel.reserve(n));
-    HIPCHK(c, hipMemsetAsync(c->sel.p, 1, n, c->stream));
-    c->sel_all = true;
-    return enqueue_selection(c, 6.0);
+    if (!c->sel_uploaded) {
+        const size_t n = (size_t)std::max<int64_t>(c->n, 1);
+        HIPCHK(c, c->sel.reserve(n));
+        HIPCHK(c, hipMemsetAsync(c->sel.p, 1, n, c->stream));
+        c->sel_all = true;
+        c->sel_uploaded = true;
+    }
+    return enqueue_selection(c, 6.0);   // an uploaded selection that was not expanded yet is expanded here
 }
 
 // _calculate_atom_contacts (I:693-936): bin + sort + search + sift with the current capacities
@@ -918,6 +926,9 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     CHK(upload(c, c->sb, sb0.data(), (size_t)n));
     c->has_gid = c->has_home = false;
     c->sel_made = false;
+    c->sel_uploaded = false;   // a new structure starts with the default selection: everything (I:1395)
+    c->sel_all = false;
+    c->whole_structure = false;
     c->contacts_valid = false;
     c->atom_grid.valid = false;
     c->all_grid_current = false;
@@ -1085,6 +1096,7 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
     c->static_dirty = true;
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     CHK(upload(c, c->plus, in_plus, (size_t)c->n));
+    c->sel_uploaded = true;
     c->sel_all = false;   // the caller's masks are taken as they are
     CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));
     CHK(upload(c, c->am_sel, amide_sel, (size_t)c->namide)); CHK(upload(c, c->am_plus, amide_plus, (size_t)c->namide));
@@ -1100,6 +1112,7 @@ int arp_set_selection(arp_ctx* c, const uint8_t* in_selection) {
     if (!c || (c->n > 0 && !in_selection)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
+    c->sel_uploaded = true;
     c->sel_all = true;
     for (int64_t i = 0; i < c->n; ++i)
         if (!in_selection[i]) { c->sel_all = false; break; }
@@ -1149,10 +1162,11 @@ int arp_make_selection(arp_ctx* c, const uint8_t* in_selection, double expand_ra
     if (in_selection) CHK(arp_set_selection(c, in_selection));
     else {
         HIPCHK(c, hipSetDevice(c->device));
-        if (!c->sel.p || c->sel.cap < (size_t)c->n) {  // nothing uploaded yet: whole structure (I:1395)
+        if (!c->sel_uploaded) {  // nothing uploaded for this structure: whole structure (I:1395)
             HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
             HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
-        c->sel_all = true;
+            c->sel_all = true;
+            c->sel_uploaded = true;
         }
     }
     CHK(enqueue_selection(c, expand_radius));
@@ -1345,11 +1359,14 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
                    int64_t counts[5]) {
     if (!c || !(cutoff > 0) || !(expand_radius > 0)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->sel.p || c->sel.cap < (size_t)std::max<int64_t>(c->n, 1)) {  // no selection uploaded: whole structure
+    if (!c->sel_uploaded) {  // no selection uploaded for this structure: whole structure (I:1395)
         HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
         HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
         c->sel_all = true;
+        c->sel_uploaded = true;
     }
+    if (c->whole_structure && !c->sel_all)
+        FAIL(c, ARP_E_ARG, "arp_run_launch: arp_set_whole_structure is on but the uploaded selection is partial");
     // every stage enqueued back to back (no host synchronisation, no allocation once the buffers are sized)
     // the counter block must be zero when a pass starts; a pass leaves it zeroed (k_publish_counters)
     auto ensure_zero = [&]() -> int {
@@ -1495,10 +1512,11 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
     HIPCHK(c, hipSetDevice(c->device));
     if (stage == 0) {          // I:1384-1424 on the local atoms; exact for the atoms this rank owns
         if (!(expand_radius > 0)) return ARP_E_ARG;
-        if (!c->sel.p || c->sel.cap < (size_t)std::max<int64_t>(c->n, 1)) {
+        if (!c->sel_uploaded) {
             HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
             HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
-        c->sel_all = true;
+            c->sel_all = true;
+            c->sel_uploaded = true;
         }
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
         c->ctr_clean = true;
@@ -1582,6 +1600,15 @@ int arp_get_kernel_times(arp_ctx* c, double ms[8], int64_t launches[8], int rese
     if (!c || !ms || !launches) return ARP_E_ARG;
     for (int k = 0; k < NSLOT; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
     if (reset) for (int k = 0; k < NSLOT; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+    return ARP_OK;
+}
+
+int arp_set_whole_structure(arp_ctx* c, int enabled) {
+    if (!c) return ARP_E_ARG;
+    c->whole_structure = enabled != 0;
+    ++c->input_epoch;
+    c->contacts_valid = false;
+    c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
     return ARP_OK;
 }
 

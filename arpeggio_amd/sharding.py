@@ -320,12 +320,16 @@ def combine_selection(sh: Shard, local_plus: np.ndarray, dist=None, device=None)
 # ---------------------------------------------------------------------------------------------
 # GPU side
 # ---------------------------------------------------------------------------------------------
-def upload_shard(ctx, sh: Shard):
+def upload_shard(ctx, sh: Shard, whole_structure: bool = False):
+    """``whole_structure``: the shard was cut without a selection; the context is told so (no selection exchange)."""
+    if whole_structure and not bool(np.all(sh.sel)):
+        raise ValueError('whole_structure=True needs a shard whose selection mask is all ones')
     ctx.set_complex(sh.pc)
     ctx.set_single_bond_neighbour_coords(sh.sb_xyz, sh.sb_has)
     ctx.set_ownership(sh.is_home, sh.global_id)
     ctx.set_group_ownership(sh.ring_home, sh.ring_gid, sh.amide_home, sh.amide_gid)
     ctx.set_selection(sh.sel)
+    ctx.set_whole_structure(whole_structure)
 
 
 def run_shard(ctx, sh: Shard, dist=None, device=None, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
@@ -411,6 +415,14 @@ class DeviceExchange:
         with self._scope():
             dist.all_reduce(self.t_res, op=dist.ReduceOp.MAX)
         self._sync()
+
+
+def run_shard_whole_structure(ctx, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
+    """run_arpeggio on one shard when NO selection was given (whole structure, I:1395): selection_plus and the residue
+    sets are known without asking the neighbours (``Context.set_whole_structure``), so the pass is the single-GPU pass on
+    the shard — owned atoms, rings and amides emit — and the only traffic between the ranks is the halo of records that
+    built the shard.  ``upload_shard(ctx, sh, whole_structure=True)`` prepares the context."""
+    return ctx.run_launch(cutoff, vdw_comp, include_sequence_adjacent, 6.0)
 
 
 def run_shard_device(ctx, ex: DeviceExchange, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):

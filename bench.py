@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--cutoff', type=float, default=5.0)
     ap.add_argument('--vdw-comp', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--staged-exchange', action='store_true',
+                    help='N > 1: run the general three-stage protocol (selection_plus bits over P2P + residue-set all-reduce '
+                         'every step) although the whole-structure selection of the benchmark does not need it')
     ap.add_argument('--cpu-sample-atoms', type=int, default=100_000)
     return ap.parse_args()
 
@@ -99,7 +102,7 @@ def main():
         shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
         halo_ms = shard.halo_ms
         ctx = _capi.Context(local_rank)
-        sharding.upload_shard(ctx, shard)
+        sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
         n_local_home = int(shard.is_home.sum())
         pc = shard.pc
     gen_s = time.perf_counter() - t0
@@ -107,6 +110,11 @@ def main():
     if world == 1:
         def step():
             return ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+    elif not args.staged_exchange:
+        # no selection = whole structure (I:1395): selection_plus and the residue sets are known on every rank without
+        # asking the neighbours, so the pass needs no exchange; the halo of records was exchanged over RCCL above
+        def step():
+            return sharding.run_shard_whole_structure(ctx, args.cutoff, args.vdw_comp, False)
     elif comm_device is not None:
         # device-resident exchange: torch tensors alias the context's buffers, RCCL moves the halo bits and reduces
         # the residue sets between the three stages of the pass
@@ -231,6 +239,7 @@ def main():
         'ms_per_step_profiled_pass': round(elapsed_profiled / args.steps * 1e3, 4),
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
         'launch_mode': 'direct launches on two HIP streams, one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
+        'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
         'halo_exchange_ms': round(halo_ms, 3), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'roofline': roofline, 'cpu_baseline': cpu,
     }

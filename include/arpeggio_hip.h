@@ -307,6 +307,13 @@ int arp_get_stats(arp_ctx* ctx, int64_t stats[8]);
  * reset != 0 clears the accumulators after reading. */
 int arp_set_profiling(arp_ctx* ctx, int enabled);
 int arp_get_kernel_times(arp_ctx* ctx, double ms[8], int64_t launches[8], int reset);
+/* Sharded runs with NO selection (the reference's default, I:1395: every atom of the structure): the caller
+ * asserts that the selection is the whole global structure.  Then selection_plus = selection on every rank and every
+ * residue of the table is in both residue sets (I:1413-1437) — including residues whose atoms live on another rank,
+ * which the local atoms cannot tell — so arp_run_launch on each shard is exact without any exchange between the
+ * ranks.  arp_run_launch refuses (ARP_E_ARG) when the flag is on and the uploaded selection is partial.
+ * Precondition: every residue of the table has at least one atom somewhere. */
+int arp_set_whole_structure(arp_ctx* ctx, int enabled);
 /* Host side of arp_run_launch, accumulated over *passes calls: us[0] = time spent enqueueing the pass
  * (kernel launches, memsets, events), us[1] = time spent blocked in the one synchronisation. */
 int arp_get_host_times(arp_ctx* ctx, double us[2], int64_t* passes, int reset);

@@ -377,6 +377,47 @@ def test_sharded_union_on_one_gpu(ctx, capi, world):
                                             and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])), (k, f)
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_whole_structure_needs_no_exchange(ctx, capi, world):
+    """No selection = whole structure (I:1395): with Context.set_whole_structure every shard runs the plain single-GPU
+    pass (one launch sequence, no selection exchange) and the union of what the ranks own == the unsharded result."""
+    from arpeggio_amd import sharding, synth
+    full = synth.slab_config(6000, 3, seed=8)
+    ctx.set_complex(full)
+    n_ref = ctx.run_launch()
+    ref = ctx.atom_contacts_fetch(n_ref['atom_atom'])
+    names = ('plane_plane', 'atom_plane', 'group_group', 'group_plane')
+    ref_bags = {k: ctx.fetch_bag(k) for k in names}
+    assert n_ref['atom_atom'] > 10_000 and n_ref['plane_plane'] > 0 and n_ref['atom_plane'] > 0
+    c2 = capi.Context(0)
+    parts, bags = [], {k: [] for k in names}
+    for rank in range(world):
+        sh = sharding.make_shard_local(full, rank, world, None)
+        sharding.upload_shard(c2, sh, whole_structure=True)
+        n = sharding.run_shard_whole_structure(c2)
+        parts.append(c2.atom_contacts_fetch(n['atom_atom']))
+        for k in names:
+            bags[k].append(c2.fetch_bag(k))
+    # a partial selection under the assertion is refused
+    part = np.ones(sh.pc.n_atoms, np.uint8)
+    part[0] = 0
+    c2.set_selection(part)
+    with pytest.raises(Exception):
+        c2.run_launch()
+    c2.close()
+    got = {k: np.concatenate([p[k] for p in parts]) for k in ('i', 'j', 'dist', 'sift', 'ctype')}
+    o = np.lexsort((got['j'], got['i']))
+    _assert_contacts_equal({k: v[o] for k, v in got.items()}, ref)
+    order = {'plane_plane': ('bgn', 'end'), 'atom_plane': ('ring', 'atom'), 'group_group': ('bgn', 'end'), 'group_plane': ('amide', 'ring')}
+    for k, (k1, k2) in order.items():
+        g = {f: np.concatenate([b[f] for b in bags[k]]) for f in ref_bags[k]}
+        o = np.lexsort((g[k2], g[k1]))
+        for f in ref_bags[k]:
+            a, b = g[f][o], ref_bags[k][f]
+            assert np.array_equal(a, b) or (a.dtype.kind == 'f' and np.array_equal(np.isnan(a), np.isnan(b))
+                                            and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])), (k, f)
+
+
 def test_atom_accumulators(ctx):
     """per-atom sift masks and hbond/polar counters (I:821-852, 923-934; U:182-221)."""
     import oracle
