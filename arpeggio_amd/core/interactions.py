@@ -193,6 +193,57 @@ class InteractionComplex:
         """
         return residue_plane_sifts(self.pc, self._bags)
 
+    # ---- per-atom / per-residue SIFt accumulators ----
+    def atom_sifts(self):
+        """Per-atom OR-accumulated SIFts of the last run (I:923-934, U:182-221), computed on the GPU from the resident
+        contact list: dict of uint8 arrays [n_atoms, 15] ``sift``, ``sift_inter_only``, ``sift_intra_only``,
+        ``sift_water_only`` and the int32 [n_atoms, 8] ``counts`` = actual hbonds {all, intra, inter, water} and actual
+        polars {all, intra, inter, water} (I:821-852).  Rows of atoms outside ``selection_plus`` are zero."""
+        acc = self._ctx.atom_accumulators()
+        bits = (acc['sift'][:, :, None] >> np.arange(15, dtype=np.uint16)[None, None, :]) & 1
+        names = ('sift', 'sift_inter_only', 'sift_intra_only', 'sift_water_only')
+        out = {n: bits[:, k, :].astype(np.uint8) for k, n in enumerate(names)}
+        out['counts'] = acc['counts']
+        return out
+
+    def residue_sifts(self):
+        """Binary per-residue SIFts of `_calc_residue_sifts` (I:471-560): a bit is set when any atom of the residue (any
+        main-chain / side-chain atom for ``mc_*`` / ``sc_*``, polypeptide residues only, C:35) has it.  The reference
+        derives them by flattening its integer sifts, whose non-zero pattern is exactly this OR; the integer values
+        themselves depend on the KD-tree's pair order (U:233-242) and are not provided.  uint8 arrays [n_residues, 15]."""
+        pc = self.pc
+        a = self.atom_sifts()
+        poly = (np.asarray(pc.res_flags) & config.R_POLYPEPTIDE) != 0
+        mc = np.asarray([n in config.MAINCHAIN_ATOMS for n in pc.atom_name], bool)
+        rid = np.asarray(pc.res_id)
+        out = {}
+        for name in ('sift', 'sift_inter_only', 'sift_intra_only', 'sift_water_only'):
+            for prefix, rows in (('', np.ones(pc.n_atoms, bool)), ('mc_', mc & poly[rid]), ('sc_', ~mc & poly[rid])):
+                r = np.zeros((pc.n_residues, 15), np.uint8)
+                np.maximum.at(r, rid[rows], a[name][rows])
+                out[prefix + name] = r
+        return out
+
+    def write_atom_sifts(self, wd):
+        """I:349-366, 576-606: '<id>_sifts.csv' (atom, 15 flags) and '<id>_specific_sifts.csv' (atom, inter / intra /
+        water flags, 45 columns) for the atoms of selection_plus, in packed atom order (the reference iterates a set).
+        The header row is the reference's (17 names whatever the row width)."""
+        import csv
+        import os
+        a = self.atom_sifts()
+        header = ['atom'] + list(config.SIFT_NAMES) + ['interacting_entities']
+        rows_all, rows_spec = [], []
+        for i in self.selection_plus.tolist():
+            label = utils.make_pymol_string(self.pc, atom=i)
+            rows_all.append([label] + a['sift'][i].tolist())
+            rows_spec.append([label] + a['sift_inter_only'][i].tolist() + a['sift_intra_only'][i].tolist()
+                             + a['sift_water_only'][i].tolist())
+        for name, rows in ((self.id + '_sifts.csv', rows_all), (self.id + '_specific_sifts.csv', rows_spec)):
+            with open(os.path.join(wd, name), 'w') as f:
+                w = csv.writer(f, delimiter=',', quotechar='"', quoting=csv.QUOTE_MINIMAL)
+                w.writerow(header)
+                w.writerows(rows)
+
     def get_contacts(self):
         """I:172-212: JSON-able list, bags in the reference's order, canonical order inside a bag."""
         pc = self.pc

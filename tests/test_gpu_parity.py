@@ -326,6 +326,52 @@ def test_interaction_complex_drop_in(ctx):
         ic.run_arpeggio(['/A/999999/'], 5.0, 0.1, False)
 
 
+def test_atom_and_residue_sifts_and_csv(tmp_path):
+    """per-atom sifts (I:923-934), their per-residue flattening (I:471-560) and write_atom_sifts
+    (I:349-366) through the mirror class, against the oracle's accumulators."""
+    import csv
+    import oracle
+    from arpeggio_amd import synth
+    from arpeggio_amd.core import InteractionComplex, config, utils
+    pc = synth.proteinlike(n_res=120, seed=4, n_waters=60, id='plike')
+    ic = InteractionComplex(pc, 0.1, 5.0, 7.4)
+    ic.structure_checks()
+    ic.initialize()
+    ic.run_arpeggio(['/A/30/', '/A/31/', '/A/64/'], 5.0, 0.1, False)
+    sel = np.zeros(pc.n_atoms, np.uint8)
+    sel[utils.selection_parser(['/A/30/', '/A/31/', '/A/64/'], pc)] = 1
+    oc = oracle.OracleComplex(pc)
+    oc.make_selection(sel)
+    exp = oracle.atom_accumulators(pc.n_atoms, oc.atom_contacts())
+    got = ic.atom_sifts()
+    names = ('sift', 'sift_inter_only', 'sift_intra_only', 'sift_water_only')
+    for k, n in enumerate(names):
+        bits = ((exp['sift'][:, k, None] >> np.arange(15)[None, :]) & 1).astype(np.uint8)
+        assert np.array_equal(got[n], bits), n
+    assert np.array_equal(got['counts'], exp['counts'])
+    assert got['sift'].any() and got['sift_inter_only'].any() and got['sift_intra_only'].any()
+    # residues: OR over the atoms, main chain / side chain split for polypeptide residues
+    rs = ic.residue_sifts()
+    poly = (pc.res_flags & config.R_POLYPEPTIDE) != 0
+    for r in np.unique(pc.res_id[ic.selection_plus])[:40].tolist():
+        atoms = np.nonzero(pc.res_id == r)[0]
+        assert np.array_equal(rs['sift'][r], got['sift'][atoms].max(0))
+        mc = [a for a in atoms if pc.atom_name[a] in config.MAINCHAIN_ATOMS]
+        sc = [a for a in atoms if pc.atom_name[a] not in config.MAINCHAIN_ATOMS]
+        for pre, sub in (('mc_', mc), ('sc_', sc)):
+            want = got['sift_inter_only'][sub].max(0) if (poly[r] and sub) else np.zeros(15, np.uint8)
+            assert np.array_equal(rs[pre + 'sift_inter_only'][r], want)
+    assert rs['mc_sift'].any() and rs['sc_sift'].any()
+    # the two CSV files
+    ic.write_atom_sifts(str(tmp_path))
+    rows = list(csv.reader(open(tmp_path / 'plike_sifts.csv')))
+    assert rows[0] == ['atom'] + list(config.SIFT_NAMES) + ['interacting_entities'] and len(rows) == 1 + len(ic.selection_plus)
+    a0 = int(ic.selection_plus[0])
+    assert rows[1] == [utils.make_pymol_string(pc, atom=a0)] + [str(int(v)) for v in got['sift'][a0]]
+    spec = list(csv.reader(open(tmp_path / 'plike_specific_sifts.csv')))
+    assert len(spec) == len(rows) and len(spec[1]) == 46
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_sharded_union_on_one_gpu(ctx, capi, world):
     """The ownership / global-id logic of the kernels: shards run one after the other on one GPU,
