@@ -102,6 +102,7 @@ struct arp_ctx {
     DevBuf<int> gid;
     DevBuf<uint8_t> home, sel, plus, res_sel, res_plus;
     bool has_res = false, has_gid = false, has_home = false;
+    int64_t max_res_id = -1, max_ring_res = -1, max_amide_res = -1;   // host-side range checks of the uploaded indices
     bool sel_made = false;
     bool sel_uploaded = false;   // arp_set_selection / arp_set_selection_state since the last arp_set_atoms
     bool sel_all = false;        // the uploaded selection covers every atom: selection_plus = selection, no expansion search
@@ -478,6 +479,21 @@ void drop_graph(arp_ctx* c) {
     c->gkey.valid = false;
 }
 
+// CSR offsets: start at 0, never decrease (the kernels index with them unchecked)
+bool csr_ok(const int32_t* off, int64_t n) {
+    if (off[0] != 0) return false;
+    for (int64_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return false;
+    return true;
+}
+
+template <class T>
+bool all_finite(const T* v, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+        if (!std::isfinite((double)v[i])) return false;
+    return true;
+}
+
 void host_bbox(const float* xyz, int64_t n, double lo[3], double hi[3]) {
     for (int k = 0; k < 3; ++k) { lo[k] = 0; hi[k] = 0; }
     for (int64_t i = 0; i < n; ++i)
@@ -534,11 +550,18 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
     return ARP_OK;
 }
 
+int check_residue_ranges(arp_ctx* c) {   // the set kernels index the residue table with the uploaded ids, unchecked
+    if (std::max({c->max_res_id, c->max_ring_res, c->max_amide_res}) >= std::max<int64_t>(c->nres, 1))
+        FAIL(c, ARP_E_ARG, "selection sets: an atom, ring or amide refers to a residue beyond the residue table (arp_set_residues)");
+    return ARP_OK;
+}
+
 // I:1413-1437: residue, ring and amide sets of the selection and of selection_plus.  Only the ring / amide
 // kernels consume them, so arp_run_launch puts this stage on their stream.
 int enqueue_selection_sets(arp_ctx* c, hipStream_t st) {
     const int n = (int)c->n;
     const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+    CHK(check_residue_ranges(c));
     HIPCHK(c, c->res_sel.reserve(2 * nres));   // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
     uint8_t* res_sel = c->res_sel.p;
     uint8_t* res_plus = c->res_sel.p + nres;
@@ -874,6 +897,15 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     if (!c) return ARP_E_ARG;
     if (n < 0 || n > 0x7FFFFFF0LL) FAIL(c, ARP_E_ARG, "arp_set_atoms: n out of range");
     if (n > 0 && (!xyz || !vdw || !cov || !type_mask || !flags || !res_id)) FAIL(c, ARP_E_ARG, "arp_set_atoms: null input");
+    // the grids are sized from the bounding box: a NaN / inf coordinate has no cell
+    if (!all_finite(xyz, 3 * n)) FAIL(c, ARP_E_ARG, "arp_set_atoms: non-finite coordinate");
+    if (!all_finite(vdw, n) || !all_finite(cov, n)) FAIL(c, ARP_E_ARG, "arp_set_atoms: non-finite radius");
+    int64_t max_res = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        if (res_id[i] < 0) FAIL(c, ARP_E_ARG, "arp_set_atoms: negative residue index");
+        max_res = std::max<int64_t>(max_res, res_id[i]);
+    }
+    c->max_res_id = max_res;
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
@@ -938,6 +970,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
 int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const int32_t* prev, const int32_t* next) {
     if (!c) return ARP_E_ARG;
     if (nres < 0 || (nres > 0 && (!res_flags || !prev || !next))) FAIL(c, ARP_E_ARG, "arp_set_residues: bad input");
+    if (nres <= c->max_res_id) FAIL(c, ARP_E_ARG, "arp_set_residues: an atom refers to a residue beyond the table");
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
@@ -958,6 +991,7 @@ int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) 
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
+    if (!csr_ok(bond_off, c->n)) FAIL(c, ARP_E_ARG, "arp_set_bonds: offsets must start at 0 and never decrease");
     const int64_t m = bond_off[c->n];
     if (m < 0 || (m > 0 && !bond_idx)) FAIL(c, ARP_E_ARG, "arp_set_bonds: bad CSR");
     CHK(upload(c, c->bond_off, bond_off, (size_t)c->n + 1));
@@ -971,6 +1005,7 @@ int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
+    if (!csr_ok(h_off, c->n)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: offsets must start at 0 and never decrease");
     const int64_t m = h_off[c->n];
     if (m < 0 || (m > 0 && !h_xyz)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: bad CSR");
     CHK(upload(c, c->h_off, h_off, (size_t)c->n + 1));
@@ -999,6 +1034,12 @@ int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
 int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double* normal, const int32_t* ring_res) {
     if (!c) return ARP_E_ARG;
     if (nring < 0 || (nring > 0 && (!center || !normal || !ring_res))) FAIL(c, ARP_E_ARG, "arp_set_rings: bad input");
+    if (!all_finite(center, 3 * nring)) FAIL(c, ARP_E_ARG, "arp_set_rings: non-finite ring centre");   // (normals may be NaN: class '')
+    c->max_ring_res = -1;
+    for (int64_t i = 0; i < nring; ++i) {
+        if (ring_res[i] < -1) FAIL(c, ARP_E_ARG, "arp_set_rings: residue index below -1");
+        c->max_ring_res = std::max<int64_t>(c->max_ring_res, ring_res[i]);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
@@ -1018,6 +1059,12 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
 int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float* normal, const int32_t* amide_res) {
     if (!c) return ARP_E_ARG;
     if (namide < 0 || (namide > 0 && (!center || !normal || !amide_res))) FAIL(c, ARP_E_ARG, "arp_set_amides: bad input");
+    if (!all_finite(center, 3 * namide)) FAIL(c, ARP_E_ARG, "arp_set_amides: non-finite amide centre");
+    c->max_amide_res = -1;
+    for (int64_t i = 0; i < namide; ++i) {
+        if (amide_res[i] < -1) FAIL(c, ARP_E_ARG, "arp_set_amides: residue index below -1");
+        c->max_amide_res = std::max<int64_t>(c->max_amide_res, amide_res[i]);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
@@ -1530,6 +1577,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
     if (stage == 1) {          // I:1413, 1431 residue sets from the (now globally correct) selection_plus bits
         const int n = (int)c->n;
         const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+        CHK(check_residue_ranges(c));
         HIPCHK(c, c->res_sel.reserve(2 * nres));
         HIPCHK(c, hipMemsetAsync(c->res_sel.p, 0, 2 * nres, c->stream));
         if (n > 0)

@@ -176,3 +176,38 @@ def test_atoms_with_hundreds_of_hydrogens_and_bonds(ctx):
     first = (got['i'] == 0)
     cov_bit, hb_bit = 1 << config.SIFT_NAMES.index('covalent'), 1 << config.SIFT_NAMES.index('hbond')
     assert first.any() and (got['sift'][first] & cov_bit).any() and (got['sift'][first] & hb_bit).any()
+
+
+def test_malformed_inputs_are_refused_before_any_kernel_runs(capi):
+    """Non-finite coordinates (no grid cell), broken CSR offsets and out-of-range residue indices come back as
+    ARP_E_ARG from the setters instead of reaching a kernel that indexes with them."""
+    L = capi.load()
+    h = C.c_void_p()
+    assert L.arp_create(0, C.byref(h)) == 0
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = 4
+    xyz = np.zeros((n, 3), np.float32)
+    vdw, cov = np.full(n, 1.7), np.full(n, 0.76)
+    tm, fl, res = np.zeros(n, np.uint16), np.zeros(n, np.uint16), np.arange(n, dtype=np.int32)
+    bad = xyz.copy()
+    bad[2, 1] = np.nan
+    assert L.arp_set_atoms(h, n, p(bad), p(vdw), p(cov), p(tm), p(fl), p(res)) == -1
+    bad[2, 1] = np.inf
+    assert L.arp_set_atoms(h, n, p(bad), p(vdw), p(cov), p(tm), p(fl), p(res)) == -1
+    neg = res.copy()
+    neg[1] = -3
+    assert L.arp_set_atoms(h, n, p(xyz), p(vdw), p(cov), p(tm), p(fl), p(neg)) == -1
+    assert L.arp_set_atoms(h, n, p(xyz), p(vdw), p(cov), p(tm), p(fl), p(res)) == 0
+    rf, prv, nxt = np.zeros(2, np.uint8), np.full(2, -1, np.int32), np.full(2, -1, np.int32)
+    assert L.arp_set_residues(h, 2, p(rf), p(prv), p(nxt)) == -1            # atoms refer to residues 0..3
+    off = np.array([0, 2, 1, 3, 3], np.int32)                                # decreasing
+    assert L.arp_set_bonds(h, p(off), p(np.zeros(3, np.int32))) == -1
+    assert L.arp_set_hydrogens(h, p(off), p(np.zeros(9, np.float64))) == -1
+    ctr = np.zeros((1, 3), np.float64)
+    ctr[0, 0] = np.nan
+    assert L.arp_set_rings(h, 1, p(ctr), p(np.zeros((1, 3))), p(np.zeros(1, np.int32))) == -1
+    assert b'non-finite' in L.arp_last_error(h)
+    # without a residue table the selection sets cannot be built: clean error, not an out-of-bounds write
+    counts = np.zeros(5, np.int64)
+    assert L.arp_run_launch(h, C.c_double(5.0), C.c_double(0.1), 0, C.c_double(6.0), p(counts)) == -1
+    L.arp_destroy(h)
