@@ -645,6 +645,9 @@ int bag_reserve(arp_ctx* c, Bag& b, size_t cap, bool d, bool f) {
     return ARP_OK;
 }
 
+// One wavefront per ring / amide up to PLANE_BLOCKS blocks, several items per wave beyond: the waves queue their
+// records in LDS and a block pays ONE counter atomic when it ends.
+#define PLANE_BLOCKS 1024
 // The four ring / amide kernels: prepare_* sizes the bag, clears its counter and fills the kernel arguments
 // (nb = number of blocks, 0 when there is nothing to do); enqueue_* launches one of them, enqueue_planes all
 // four as ONE launch (k_planes).
@@ -660,7 +663,7 @@ int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb) {  // I:947-1062
                       c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                       c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
                       b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP};
-    nb = nblocks(c->nring * 64, 256, 8192);
+    nb = nblocks(c->nring * 64, 256, PLANE_BLOCKS);
     return ARP_OK;
 }
 int prepare_plane_plane(arp_ctx* c, PlanePlaneArgs& a, int& nb) {  // I:1064-1194
@@ -674,7 +677,7 @@ int prepare_plane_plane(arp_ctx* c, PlanePlaneArgs& a, int& nb) {  // I:1064-119
                        c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                        c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
                        b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP};
-    nb = nblocks(c->nring * 64, 256, 8192);
+    nb = nblocks(c->nring * 64, 256, PLANE_BLOCKS);
     return ARP_OK;
 }
 int prepare_group_group(arp_ctx* c, GroupGroupArgs& a, int& nb) {  // I:1217-1300
@@ -688,7 +691,7 @@ int prepare_group_group(arp_ctx* c, GroupGroupArgs& a, int& nb) {  // I:1217-130
                        c->am_sel.p, c->am_plus.p, c->has_group_owner ? c->am_home.p : nullptr,
                        c->has_group_owner ? c->am_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p,
                        b.u0.p, c->d_ctr + C_GG};
-    nb = nblocks(c->namide * 64, 256, 8192);
+    nb = nblocks(c->namide * 64, 256, PLANE_BLOCKS);
     return ARP_OK;
 }
 int prepare_group_plane(arp_ctx* c, GroupPlaneArgs& a, int& nb) {  // I:1302-1382
@@ -703,7 +706,7 @@ int prepare_group_plane(arp_ctx* c, GroupPlaneArgs& a, int& nb) {  // I:1302-138
                        c->has_group_owner ? c->am_home.p : nullptr, c->has_group_owner ? c->am_gid.p : nullptr,
                        c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
                        b.u0.p, c->d_ctr + C_GP};
-    nb = nblocks(c->namide * 64, 256, 8192);
+    nb = nblocks(c->namide * 64, 256, PLANE_BLOCKS);
     return ARP_OK;
 }
 

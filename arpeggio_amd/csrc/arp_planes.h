@@ -76,15 +76,61 @@ __device__ __forceinline__ int stencil_pos(const Stencil& st, int k) {
         if (k >= st.pre[r] && k < st.pre[r + 1]) pos = st.js[r] + (k - st.pre[r]);
     return pos;
 }
-// slot allocation for the lanes with emit == true: one atomicAdd per wavefront
-__device__ __forceinline__ long long wave_slot(bool emit, u64* __restrict__ n_out, int lane) {
-    const unsigned long long me = __ballot(emit);
-    if (!me) return -1;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(me));
-    base = __shfl(base, 0);
-    return (long long)(base + __popcll(me & ((1ull << lane) - 1ull)));
-}
+// Output records of the ring / amide kernels go through a per-wave LDS queue and leave with ONE atomicAdd on the
+// bag counter per flush (same-address atomics run at ~90 per microsecond on this chip: one per ring made the
+// 10 k-ring set of BASELINE configs[4] a 119 us kernel).  A record is two ids, up to four values and three bytes.
+struct __attribute__((aligned(16))) PlaneRec {
+    int i0, i1;
+    unsigned u;      // u0 | u1 << 8 | u2 << 16
+    unsigned pad;
+    double d0, d1, d2, d3;
+};
+#define PLANE_QCAP 128
+struct PlaneQueue {
+    PlaneRec* q;   // this wave's PLANE_QCAP records of LDS
+    int n;
+    __device__ __forceinline__ void push(bool emit, const PlaneRec& r, int lane) {
+        const unsigned long long me = __ballot(emit);
+        if (!me) return;
+        if (emit) q[n + __popcll(me & ((1ull << lane) - 1ull))] = r;
+        n += __popcll(me);
+    }
+    __device__ __forceinline__ bool nearly_full() const { return n > PLANE_QCAP - 64; }
+    template <class W>
+    __device__ __forceinline__ void flush(u64* __restrict__ n_out, long long cap, int lane, W write) {
+        if (n == 0) return;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)n);
+        base = __shfl(base, 0);
+        for (int k = lane; k < n; k += 64)
+            if ((long long)(base + k) < cap) write((long long)(base + k), q[k]);
+        __builtin_amdgcn_wave_barrier();
+        n = 0;
+    }
+    // end of the kernel: the four waves of the block leave with one atomicAdd (every wave of the block calls this)
+    template <class W>
+    __device__ __forceinline__ void flush_block(int* s_n, u64* s_base, u64* __restrict__ n_out, long long cap, int lane, W write) {
+        const int w = threadIdx.x >> 6;
+        if (lane == 0) s_n[w] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+            *s_base = tot ? atomicAdd(n_out, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long base = *s_base;
+        for (int k = 0; k < w; ++k) base += (unsigned long long)s_n[k];
+        for (int k = lane; k < n; k += 64)
+            if ((long long)(base + k) < cap) write((long long)(base + k), q[k]);
+        n = 0;
+    }
+};
+struct PlaneShared {   // LDS of one 256-thread block of a ring / amide kernel
+    PlaneRec q[4][PLANE_QCAP];
+    u64 base;
+    int n[4];
+};
 
 // One wavefront per ring; lanes sweep the atoms of the 27 cells around the ring centre =
 // NeighborSearch.search(center, 6.0) (I:960).  The grid is the all-atom 6 A grid of the
@@ -124,7 +170,13 @@ __device__ __forceinline__ void atom_plane_body(GridDesc g, const int* __restric
                                                     const int* __restrict__ gid, long long cap, int* __restrict__ out_atom,
                                                     int* __restrict__ out_ring, double* __restrict__ out_dist,
                                                     double* __restrict__ out_theta, uint8_t* __restrict__ out_mask,
-                                                    uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid) {
+                                                    uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    auto write = [&](long long slot, const PlaneRec& t) {
+        out_atom[slot] = t.i0; out_ring[slot] = t.i1;
+        out_dist[slot] = t.d0; out_theta[slot] = t.d1;
+        out_mask[slot] = (uint8_t)(t.u & 255u); out_ct[slot] = (uint8_t)((t.u >> 8) & 255u);
+    };
     const int lane = threadIdx.x & 63;
     const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (vgrid * blockDim.x) >> 6;
@@ -162,17 +214,18 @@ __device__ __forceinline__ void atom_plane_body(GridDesc g, const int* __restric
                     emit = mask != 0;                                           // I:1026
                 }
             }
-            const long long slot = wave_slot(emit, n_out, lane);
-            if (emit && slot < cap) {
-                out_atom[slot] = gid ? gid[lid] : lid;
-                out_ring[slot] = ring_gid ? ring_gid[r] : r;
-                out_dist[slot] = dist;
-                out_theta[slot] = theta;
-                out_mask[slot] = (uint8_t)mask;
-                out_ct[slot] = (uint8_t)ct;
+            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+            PlaneRec rec;
+            if (emit) {
+                rec.i0 = gid ? gid[lid] : lid;
+                rec.i1 = ring_gid ? ring_gid[r] : r;
+                rec.d0 = dist; rec.d1 = theta;
+                rec.u = mask | ((unsigned)ct << 8);
             }
+            Q.push(emit, rec, lane);
         }
     }
+    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
 // One wavefront per ring a; lanes = partner rings b > a of the 27 cells around it.  Reproduces
@@ -210,7 +263,14 @@ __device__ __forceinline__ void plane_plane_body(GridDesc g, const int* __restri
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_t1, double* __restrict__ out_t2,
                                                      uint8_t* __restrict__ out_y1, uint8_t* __restrict__ out_y2,
-                                                     uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid) {
+                                                     uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    auto write = [&](long long slot, const PlaneRec& t) {
+        out_bgn[slot] = t.i0; out_end[slot] = t.i1;
+        out_dist[slot] = t.d0; out_dih[slot] = t.d1; out_t1[slot] = t.d2; out_t2[slot] = t.d3;
+        out_y1[slot] = (uint8_t)(t.u & 255u); out_y2[slot] = (uint8_t)((t.u >> 8) & 255u);
+        out_ct[slot] = (uint8_t)((t.u >> 16) & 255u);
+    };
     const int lane = threadIdx.x & 63;
     const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (vgrid * blockDim.x) >> 6;
@@ -254,18 +314,19 @@ __device__ __forceinline__ void plane_plane_body(GridDesc g, const int* __restri
                     }
                 }
             }
-            const long long slot = wave_slot(emit, n_out, lane);
-            if (emit && slot < cap) {
+            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+            PlaneRec rec;
+            if (emit) {
                 const int ga = ring_gid ? ring_gid[a] : a, gb = ring_gid ? ring_gid[b] : b;
-                out_bgn[slot] = first ? ga : gb;
-                out_end[slot] = first ? gb : ga;
-                out_dist[slot] = dist; out_dih[slot] = dih;
-                out_t1[slot] = t1; out_t2[slot] = t2;
-                out_y1[slot] = (uint8_t)y1; out_y2[slot] = (uint8_t)y2;
-                out_ct[slot] = (uint8_t)ct;
+                rec.i0 = first ? ga : gb;
+                rec.i1 = first ? gb : ga;
+                rec.d0 = dist; rec.d1 = dih; rec.d2 = t1; rec.d3 = t2;
+                rec.u = (unsigned)y1 | ((unsigned)y2 << 8) | ((unsigned)ct << 16);
             }
+            Q.push(emit, rec, lane);
         }
     }
+    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
 // One wavefront per amide a; lanes = every other amide b of the 27 cells: ordered pairs, float32 (I:1217-1300).
@@ -296,7 +357,13 @@ __device__ __forceinline__ void group_group_body(GridDesc g, const int* __restri
                                                      long long cap, int* __restrict__ out_bgn, int* __restrict__ out_end,
                                                      float* __restrict__ out_dist, float* __restrict__ out_dih,
                                                      float* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     u64* __restrict__ n_out, int vblock, int vgrid) {
+                                                     u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    auto write = [&](long long slot, const PlaneRec& t) {   // float values travel as doubles (exact both ways)
+        out_bgn[slot] = t.i0; out_end[slot] = t.i1;
+        out_dist[slot] = (float)t.d0; out_dih[slot] = (float)t.d1; out_theta[slot] = (float)t.d2;
+        out_ct[slot] = (uint8_t)(t.u & 255u);
+    };
     const int lane = threadIdx.x & 63;
     const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (vgrid * blockDim.x) >> 6;
@@ -326,14 +393,17 @@ __device__ __forceinline__ void group_group_body(GridDesc g, const int* __restri
                     }
                 }
             }
-            const long long slot = wave_slot(emit, n_out, lane);
-            if (emit && slot < cap) {
-                out_bgn[slot] = am_gid ? am_gid[a] : a; out_end[slot] = am_gid ? am_gid[b] : b;
-                out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
-                out_ct[slot] = (uint8_t)ct;
+            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+            PlaneRec rec;
+            if (emit) {
+                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = am_gid ? am_gid[b] : b;
+                rec.d0 = (double)dist; rec.d1 = (double)dih; rec.d2 = (double)theta;
+                rec.u = (unsigned)ct;
             }
+            Q.push(emit, rec, lane);
         }
     }
+    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
 // One wavefront per amide; lanes = rings of the 27 cells of the RING grid around the amide centre (I:1302-1382).
@@ -372,7 +442,13 @@ __device__ __forceinline__ void group_plane_body(GridDesc g, const int* __restri
                                                      long long cap, int* __restrict__ out_amide, int* __restrict__ out_ring,
                                                      double* __restrict__ out_dist, double* __restrict__ out_dih,
                                                      double* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     u64* __restrict__ n_out, int vblock, int vgrid) {
+                                                     u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    auto write = [&](long long slot, const PlaneRec& t) {
+        out_amide[slot] = t.i0; out_ring[slot] = t.i1;
+        out_dist[slot] = t.d0; out_dih[slot] = t.d1; out_theta[slot] = t.d2;
+        out_ct[slot] = (uint8_t)(t.u & 255u);
+    };
     const int lane = threadIdx.x & 63;
     const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (vgrid * blockDim.x) >> 6;
@@ -403,28 +479,35 @@ __device__ __forceinline__ void group_plane_body(GridDesc g, const int* __restri
                     }
                 }
             }
-            const long long slot = wave_slot(emit, n_out, lane);
-            if (emit && slot < cap) {
-                out_amide[slot] = am_gid ? am_gid[a] : a; out_ring[slot] = ring_gid ? ring_gid[r] : r;
-                out_dist[slot] = dist; out_dih[slot] = dih; out_theta[slot] = theta;
-                out_ct[slot] = (uint8_t)ct;
+            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+            PlaneRec rec;
+            if (emit) {
+                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = ring_gid ? ring_gid[r] : r;
+                rec.d0 = dist; rec.d1 = dih; rec.d2 = theta;
+                rec.u = (unsigned)ct;
             }
+            Q.push(emit, rec, lane);
         }
     }
+    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
 // ---- launchable forms -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_atom_plane(AtomPlaneArgs a) {
-    atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+    __shared__ PlaneShared s_sh;
+    atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
 }
 __global__ __launch_bounds__(256) void k_plane_plane(PlanePlaneArgs a) {
-    plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+    __shared__ PlaneShared s_sh;
+    plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
 }
 __global__ __launch_bounds__(256) void k_group_group(GroupGroupArgs a) {
-    group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+    __shared__ PlaneShared s_sh;
+    group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
 }
 __global__ __launch_bounds__(256) void k_group_plane(GroupPlaneArgs a) {
-    group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x);
+    __shared__ PlaneShared s_sh;
+    group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
 }
 
 // The four ring / amide kernels of a pass in ONE launch: blocks [0, nb0) work as k_atom_plane, [nb0, nb1) as
@@ -432,18 +515,20 @@ __global__ __launch_bounds__(256) void k_group_plane(GroupPlaneArgs a) {
 // independent of each other, so this saves three dependent-launch gaps and lets the small grids share the chip.
 __global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, int nb0,
                                                 int nb1, int nb2) {
+    __shared__ PlaneShared s_sh;
+    PlaneShared* const qb = &s_sh;
     const int b = (int)blockIdx.x, nb = (int)gridDim.x;
     if (b < nb0) {
         const AtomPlaneArgs& a = ap;
-        atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, b, nb0);
+        atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, b, nb0, qb);
     } else if (b < nb1) {
         const PlanePlaneArgs& a = pp;
-        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - nb0, nb1 - nb0);
+        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - nb0, nb1 - nb0, qb);
     } else if (b < nb2) {
         const GroupGroupArgs& a = gg;
-        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb1, nb2 - nb1);
+        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb1, nb2 - nb1, qb);
     } else {
         const GroupPlaneArgs& a = gp;
-        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb2, nb - nb2);
+        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb2, nb - nb2, qb);
     }
 }
