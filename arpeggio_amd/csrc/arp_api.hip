@@ -269,7 +269,7 @@ void make_grid_desc(GridDesc& d, const double lo[3], const double hi[3], double 
     d.inv = 1.0 / edge;
 }
 
-// exclusive scan of the cell histogram: one launch for small grids, three-phase otherwise
+// exclusive scan of the cell histogram: one launch up to 32768 cells, two (tiles + fix-up) above
 int enqueue_scan(arp_ctx* c, Grid& G, u64* total_out = nullptr, hipStream_t st = nullptr) {
     if (!st) st = c->stream;
     const int ncell = G.d.ncell;
@@ -280,16 +280,18 @@ int enqueue_scan(arp_ctx* c, Grid& G, u64* total_out = nullptr, hipStream_t st =
         hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, total_out);
     } else if (ncell <= 32768) {
         hipLaunchKernelGGL((k_scan_small<32>), dim3(1), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, total_out);
-    } else if (ncell <= 65536) {
-        hipLaunchKernelGGL((k_scan_small<64>), dim3(1), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, total_out);
     } else {
-        const int nb_scan = (ncell + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(k_scan_local, dim3(nb_scan), dim3(SCAN_THREADS), 0, st, G.cnt.p, ncell, G.start.p, G.sums.p);
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, G.sums.p, nb_scan);
-        hipLaunchKernelGGL(k_scan_add, dim3((ncell + 1 + 255) / 256), dim3(256), 0, st, G.start.p, ncell, G.sums.p, nb_scan);
-        if (total_out) HIPCHK(c, hipMemcpyAsync(total_out, G.start.p + ncell, sizeof(int), hipMemcpyDeviceToDevice, st));
+        // tiles of 16384 counters, two launches (a 1 M-atom contact grid has 10 tiles)
+        const int ntiles = (ncell + TILE_CELLS - 1) / TILE_CELLS;
+        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, st, G.cnt.p, ncell, G.start.p, G.sums.p);
+        hipLaunchKernelGGL(k_scan_fix, dim3((ncell + 4095) / 4096), dim3(1024), 0, st, G.start.p, ncell, G.sums.p, ntiles, total_out);
     }
     return check_launch(c, "k_scan");
+}
+
+// the scans read / write whole int4s and whole tiles: histogram and start table are padded to a tile multiple
+size_t scan_padded(int ncell) {
+    return std::max<size_t>(((size_t)ncell / TILE_CELLS + 1) * TILE_CELLS + 8, 65536 + 8);
 }
 
 // grid buffers sized for the current descriptor; the histogram is zero on entry (see below)
@@ -300,11 +302,11 @@ int reserve_grid(arp_ctx* c, Grid& G, int n, hipStream_t st = nullptr) {
     HIPCHK(c, G.perm.reserve((size_t)std::max(n, 1)));
     {   // k_scatter's atomicSub takes every counter back to 0, so only a fresh allocation needs clearing
         bool fresh = false;
-        HIPCHK(c, G.cnt.reserve(std::max<size_t>((size_t)ncell + 1, 65536 + 8), &fresh));
+        HIPCHK(c, G.cnt.reserve(scan_padded(ncell), &fresh));
         if (fresh) HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), st));
     }
-    HIPCHK(c, G.start.reserve(std::max<size_t>((size_t)ncell + 2, 65536 + 8)));
-    HIPCHK(c, G.sums.reserve((size_t)(ncell + SCAN_TILE - 1) / SCAN_TILE + 2));
+    HIPCHK(c, G.start.reserve(scan_padded(ncell)));
+    HIPCHK(c, G.sums.reserve((size_t)(ncell + TILE_CELLS - 1) / TILE_CELLS + 2));
     return ARP_OK;
 }
 

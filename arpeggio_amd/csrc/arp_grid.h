@@ -59,16 +59,13 @@ __global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, int* __re
     }
 }
 
-#define SCAN_THREADS 256
-#define SCAN_ITEMS 8
-#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
 // Small grids (<= 65536 cells): the whole exclusive scan in ONE 1024-thread block (one launch
 // instead of three).  Thread t owns ITEMS consecutive counters (int4 loads, kept in registers);
 // out[n] = grand total.  Both arrays must be readable/writable up to ITEMS * 1024 elements.
 template <int ITEMS>
-__global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in, int n, int* __restrict__ out,
-                                                     unsigned long long* __restrict__ total_out) {
+__device__ __forceinline__ void scan_small_body(const int* __restrict__ in, int n, int* __restrict__ out,
+                                                int* __restrict__ total_slot, unsigned long long* __restrict__ total_out) {
     __shared__ int sh[32];
     const int base = threadIdx.x * ITEMS;
     int v[ITEMS];
@@ -115,71 +112,67 @@ __global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in,
         if (base + k < n) *reinterpret_cast<int4*>(out + base + k) = q;   // may spill past n inside the padded buffer
     }
     if (threadIdx.x == 1023) {
-        out[n] = sh[16 + 15];
+        *total_slot = sh[16 + 15];
         if (total_out) *total_out = (unsigned long long)sh[16 + 15];   // number of binned points, for the host statistics
     }
 }
-
-// Phase A: exclusive scan inside tiles of SCAN_TILE counters; tile totals to block_sums.
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_local(const int* __restrict__ in, int n, int* __restrict__ out,
-                                                              int* __restrict__ block_sums) {
-    __shared__ int sh[SCAN_THREADS];
-    int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    int v[SCAN_ITEMS];
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
-        sum += v[k];
-    }
-    sh[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-        int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    int run = sh[threadIdx.x] - sum;  // exclusive prefix of this thread
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) out[base + k] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == SCAN_THREADS - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in, int n, int* __restrict__ out,
+                                                     unsigned long long* __restrict__ total_out) {
+    scan_small_body<ITEMS>(in, n, out, out + n, total_out);
 }
 
-// Phase B: one block scans the tile totals in place (exclusive); total -> sums[nb].
-__global__ __launch_bounds__(1024) void k_scan_top(int* __restrict__ sums, int nb) {
-    __shared__ int sh[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
+// Larger histograms, two launches: every 1024-thread block scans one tile of TILE_ITEMS * 1024 counters with the
+// same register / shuffle scan (tile totals to tile_sums), then k_scan_fix adds to every tile the sum of the totals
+// before it (each block sums those few numbers itself: no third "scan of the totals" launch) and writes out[n].
+#define TILE_ITEMS 16
+#define TILE_CELLS (TILE_ITEMS * 1024)
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ in, int n, int* __restrict__ out,
+                                                     int* __restrict__ tile_sums) {
+    const int t0 = blockIdx.x * TILE_CELLS;
+    scan_small_body<TILE_ITEMS>(in + t0, min(n - t0, TILE_CELLS), out + t0, tile_sums + blockIdx.x, nullptr);
+}
+__global__ __launch_bounds__(1024) void k_scan_fix(int* __restrict__ out, int n, const int* __restrict__ tile_sums, int ntiles,
+                                                   unsigned long long* __restrict__ total_out) {
+    __shared__ int sh[16];
+    __shared__ int s_off;
+    const int first = blockIdx.x * 4096;                 // this block: 4096 counters of one tile
+    const int my_tile = first / TILE_CELLS;
+    const bool last = blockIdx.x == gridDim.x - 1;
+    const int upto = last ? ntiles : my_tile;            // the last block also needs the grand total
+    int part = 0, part_before = 0;
+    for (int k = threadIdx.x; k < upto; k += 1024) {
+        const int v = tile_sums[k];
+        part += v;
+        if (k < my_tile) part_before += v;
+    }
+    // block sums of both partials (wave shuffles, then 16 wave totals)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int a = part_before, b = part;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    __shared__ int sh2[16];
+    if (lane == 0) { sh[wv] = a; sh2[wv] = b; }
     __syncthreads();
-    for (int base = 0; base < nb; base += 1024) {
-        int i = base + threadIdx.x;
-        int v = (i < nb) ? sums[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
+    if (threadIdx.x == 0) {
+        int ta = 0, tb = 0;
+        for (int k = 0; k < 16; ++k) { ta += sh[k]; tb += sh2[k]; }
+        s_off = ta;
+        if (last) {
+            out[n] = tb;
+            if (total_out) *total_out = (unsigned long long)tb;
         }
-        int c = carry;
-        if (i < nb) sums[i] = c + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + sh[1023];
-        __syncthreads();
     }
-    if (threadIdx.x == 0) sums[nb] = carry;
-}
-
-// Phase C: add tile offsets; out[n] = grand total.
-__global__ __launch_bounds__(256) void k_scan_add(int* __restrict__ out, int n, const int* __restrict__ sums, int nb) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] += sums[i / SCAN_TILE];
-    if (i == n) out[n] = sums[nb];
+    __syncthreads();
+    const int off = s_off;
+    const int i = first + threadIdx.x * 4;
+    if (off != 0 && i < n) {   // (padded buffers: the int4 may run past n, where out[n] = the grand total must stay)
+        int4 q = *reinterpret_cast<int4*>(out + i);
+        q.x += off;
+        if (i + 1 < n) q.y += off;
+        if (i + 2 < n) q.z += off;
+        if (i + 3 < n) q.w += off;
+        *reinterpret_cast<int4*>(out + i) = q;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_scatter(int n, const int* __restrict__ cell_of, const int* __restrict__ start,

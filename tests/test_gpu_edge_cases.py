@@ -211,3 +211,19 @@ def test_malformed_inputs_are_refused_before_any_kernel_runs(capi):
     counts = np.zeros(5, np.int64)
     assert L.arp_run_launch(h, C.c_double(5.0), C.c_double(0.1), 0, C.c_double(6.0), p(counts)) == -1
     L.arp_destroy(h)
+
+
+@pytest.mark.parametrize('box', [165.0, 260.0, 402.0])
+def test_sparse_structures_whose_grids_need_the_tiled_scan(ctx, box):
+    """A few thousand atoms in a large box: tens of thousands of (mostly empty) cells, histogram scan in several
+    16384-cell tiles (3, 10 and ~33 tiles) with clusters so that there are contacts to compare."""
+    from helpers import random_dense_pack
+    pc = random_dense_pack(41, n=1500, box=14.0)
+    rng = np.random.default_rng(int(box))
+    shift = (rng.random((pc.n_atoms // 50 + 1, 3)) * (box - 14.0)).astype(np.float32)     # 50-atom clusters
+    pc.xyz = (np.asarray(pc.xyz) * 0.35 + shift[np.arange(pc.n_atoms) // 50]).astype(np.float32)
+    pc.h_xyz = np.asarray(pc.h_xyz).reshape(-1, 3)
+    par = np.repeat(np.arange(pc.n_atoms), np.diff(pc.h_off))
+    pc.h_xyz = ((pc.h_xyz * 0.35) + shift[par // 50]).reshape(pc.h_xyz.shape)
+    got = _check(ctx, pc, brute=False)
+    assert len(got['i']) > 1000
