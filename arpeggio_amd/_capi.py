@@ -28,7 +28,7 @@ SYMBOLS = (
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
-    'arp_get_host_times', 'arp_set_whole_structure',
+    'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
 )
 
 _lib = None
@@ -86,6 +86,9 @@ def load():
     L.arp_get_kernel_times.argtypes = [vp, vp, vp, i32]
     L.arp_get_host_times.argtypes = [vp, vp, vp, i32]
     L.arp_set_whole_structure.argtypes = [vp, i32]
+    L.arp_ring_geometry.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.arp_amide_geometry.argtypes = [vp, i64, vp, vp, vp]
+    L.arp_ring_residues.argtypes = [vp, i64, vp, vp, vp]
     L.arp_stream_handle.argtypes = [vp]
     L.arp_use_stream.argtypes = [vp, C.c_uint64]
     L.arp_stream_handle.restype = C.c_uint64
@@ -370,6 +373,33 @@ class Context:
         ms, ln = np.zeros(8, np.float64), np.zeros(8, np.int64)
         self._check(self._L.arp_get_kernel_times(self._h, _p(ms), _p(ln), int(reset)), 'arp_get_kernel_times')
         return {name: dict(ms=float(ms[k]), launches=int(ln[k])) for k, name in enumerate(KERNEL_SLOTS)}
+
+    # ---- geometric part of initialize() (needs the atoms: set_complex / arp_set_atoms first) ----
+    def ring_geometry(self, ring_atoms):
+        """I:1697-1733: (center f64 [R,3], normal f64 [R,3]) of rings given as lists of atom indices in ring order."""
+        nr = len(ring_atoms)
+        off = np.zeros(nr + 1, np.int32)
+        off[1:] = np.cumsum([len(a) for a in ring_atoms])
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(a, np.int32) for a in ring_atoms]) if nr else np.zeros(0, np.int32))
+        ctr, nrm = np.zeros((max(nr, 1), 3), np.float64), np.zeros((max(nr, 1), 3), np.float64)
+        self._check(self._L.arp_ring_geometry(self._h, nr, _p(off), _p(idx), _p(ctr), _p(nrm)), 'arp_ring_geometry')
+        return ctr[:nr], nrm[:nr]
+
+    def amide_geometry(self, amide_atoms):
+        """I:1531-1589: (center f32 [A,3], normal f32 [A,3]) of amide groups given as [N, C, O, CA] atom indices."""
+        at = np.ascontiguousarray(np.asarray(amide_atoms, np.int32).reshape(-1, 4))
+        na = at.shape[0]
+        ctr, nrm = np.zeros((max(na, 1), 3), np.float32), np.zeros((max(na, 1), 3), np.float32)
+        self._check(self._L.arp_amide_geometry(self._h, na, _p(at), _p(ctr), _p(nrm)), 'arp_amide_geometry')
+        return ctr[:na], nrm[:na]
+
+    def ring_residues(self, ring_center):
+        """I:1453-1492: (ring_res i32 [R], shortest distance f64 [R]) — residue of the nearest atom within 3.0 A, -1: none."""
+        ctr = np.ascontiguousarray(np.asarray(ring_center, np.float64).reshape(-1, 3))
+        nr = ctr.shape[0]
+        res, dist = np.full(max(nr, 1), -1, np.int32), np.zeros(max(nr, 1), np.float64)
+        self._check(self._L.arp_ring_residues(self._h, nr, _p(ctr), _p(res), _p(dist)), 'arp_ring_residues')
+        return res[:nr], dist[:nr]
 
     def set_whole_structure(self, on=True):
         """Sharded runs without a selection: assert that the selection is the whole global structure (no exchange needed)."""

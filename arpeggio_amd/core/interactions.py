@@ -87,6 +87,23 @@ class InteractionComplex:
         self._ctx.set_complex(self.pc)
         logging.debug('Uploaded packed structure to the GPU.')
 
+    def compute_plane_geometry(self, assign_ring_residues=True):
+        """The geometric part of the reference's initialize() on the GPU, for packs that carry the perceived rings /
+        amide groups only as atom lists (``ring_atoms``, ``amide_atoms``): ring centre + normal (I:1697-1733), amide
+        centre + normal (I:1531-1589) and, if asked, the ring -> residue assignment by nearest atom (I:1453-1492).
+        Overwrites ``ring_center / ring_normal / ring_res`` and ``amide_center / amide_normal`` of the pack and
+        uploads them."""
+        if self._ctx is None:
+            self.initialize()
+        pc, ctx = self.pc, self._ctx
+        if pc.n_rings and pc.ring_atoms:
+            pc.ring_center, pc.ring_normal = ctx.ring_geometry(pc.ring_atoms)
+            if assign_ring_residues:
+                pc.ring_res, self.ring_residue_shortest_distance = ctx.ring_residues(pc.ring_center)
+        if pc.n_amides and (pc.amide_atoms[:, :3] >= 0).all():
+            pc.amide_center, pc.amide_normal = ctx.amide_geometry(pc.amide_atoms)
+        ctx.set_complex(pc)
+
     def run_arpeggio(self, user_selections, interacting_cutoff, vdw_comp, include_sequence_adjacent):
         """I:329-347: selection + binding-site expansion, atom, ring and amide contacts (all on the GPU)."""
         if self._ctx is None:

@@ -19,6 +19,7 @@
 #include "arp_numerics.h"
 #include "arp_pairs.h"
 #include "arp_planes.h"
+#include "arp_prepare.h"
 
 namespace {
 
@@ -1654,6 +1655,89 @@ int arp_get_kernel_times(arp_ctx* c, double ms[8], int64_t launches[8], int rese
     for (int k = 0; k < NSLOT; ++k) { ms[k] = c->k_ms[k]; launches[k] = c->k_launches[k]; }
     if (reset) for (int k = 0; k < NSLOT; ++k) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
     return ARP_OK;
+}
+
+// ---- geometric part of initialize() --------------------------------------------------
+int arp_ring_geometry(arp_ctx* c, int64_t nring, const int32_t* ring_off, const int32_t* ring_idx, double* out_center,
+                      double* out_normal) {
+    if (!c || nring < 0 || (nring > 0 && (!ring_off || !out_center || !out_normal))) return ARP_E_ARG;
+    if (nring == 0) return ARP_OK;
+    if (!csr_ok(ring_off, nring)) FAIL(c, ARP_E_ARG, "arp_ring_geometry: offsets must start at 0 and never decrease");
+    const int64_t m = ring_off[nring];
+    if (m > 0 && !ring_idx) return ARP_E_ARG;
+    for (int64_t r = 0; r < nring; ++r)
+        if (ring_off[r + 1] - ring_off[r] < 3) FAIL(c, ARP_E_ARG, "arp_ring_geometry: a ring needs at least three atoms");
+    for (int64_t k = 0; k < m; ++k)
+        if (ring_idx[k] < 0 || ring_idx[k] >= c->n) FAIL(c, ARP_E_ARG, "arp_ring_geometry: atom index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf<int> d_off, d_idx;
+    DevBuf<double> d_c, d_n;
+    int rc = upload(c, d_off, ring_off, (size_t)nring + 1);
+    if (rc == ARP_OK) rc = upload(c, d_idx, ring_idx, (size_t)m);
+    hipError_t e = d_c.reserve((size_t)nring * 3);
+    if (e == hipSuccess) e = d_n.reserve((size_t)nring * 3);
+    if (rc == ARP_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_ring_geometry, dim3(nblocks(nring, 256)), dim3(256), 0, c->stream, (int)nring, d_off.p, d_idx.p,
+                           c->xyz.p, d_c.p, d_n.p);
+        rc = check_launch(c, "k_ring_geometry");
+        if (rc == ARP_OK) rc = download(c, out_center, d_c.p, (size_t)nring * 3);
+        if (rc == ARP_OK) rc = download(c, out_normal, d_n.p, (size_t)nring * 3);
+    }
+    d_off.release(); d_idx.release(); d_c.release(); d_n.release();
+    if (e != hipSuccess) FAIL(c, ARP_E_NOMEM, "arp_ring_geometry: out of device memory");
+    return rc;
+}
+
+int arp_amide_geometry(arp_ctx* c, int64_t namide, const int32_t* amide_atoms, float* out_center, float* out_normal) {
+    if (!c || namide < 0 || (namide > 0 && (!amide_atoms || !out_center || !out_normal))) return ARP_E_ARG;
+    if (namide == 0) return ARP_OK;
+    for (int64_t k = 0; k < 4 * namide; ++k)
+        if ((k & 3) != 3 && (amide_atoms[k] < 0 || amide_atoms[k] >= c->n))   // N, C, O are read; the fourth atom is not
+            FAIL(c, ARP_E_ARG, "arp_amide_geometry: atom index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf<int> d_at;
+    DevBuf<float> d_c, d_n;
+    int rc = upload(c, d_at, amide_atoms, (size_t)namide * 4);
+    hipError_t e = d_c.reserve((size_t)namide * 3);
+    if (e == hipSuccess) e = d_n.reserve((size_t)namide * 3);
+    if (rc == ARP_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_amide_geometry, dim3(nblocks(namide, 256)), dim3(256), 0, c->stream, (int)namide, d_at.p, c->xyz.p,
+                           d_c.p, d_n.p);
+        rc = check_launch(c, "k_amide_geometry");
+        if (rc == ARP_OK) rc = download(c, out_center, d_c.p, (size_t)namide * 3);
+        if (rc == ARP_OK) rc = download(c, out_normal, d_n.p, (size_t)namide * 3);
+    }
+    d_at.release(); d_c.release(); d_n.release();
+    if (e != hipSuccess) FAIL(c, ARP_E_NOMEM, "arp_amide_geometry: out of device memory");
+    return rc;
+}
+
+int arp_ring_residues(arp_ctx* c, int64_t nring, const double* center, int32_t* out_ring_res, double* out_shortest) {
+    if (!c || nring < 0 || (nring > 0 && (!center || !out_ring_res))) return ARP_E_ARG;
+    if (nring == 0) return ARP_OK;
+    if (!all_finite(center, 3 * nring)) FAIL(c, ARP_E_ARG, "arp_ring_residues: non-finite ring centre");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) {
+        for (int64_t r = 0; r < nring; ++r) { out_ring_res[r] = -1; if (out_shortest) out_shortest[r] = -1.0; }
+        return ARP_OK;
+    }
+    // the all-atom grid (hydrogens included, I:1455); its cells (>= 6 A) cover the 3 A query with the 27-cell stencil
+    if (!(c->all_grid_current && c->all_grid.valid && c->all_grid.radius == 6.0)) CHK(build_all_grid(c, 6.0));
+    DevBuf<double> d_c, d_d;
+    DevBuf<int> d_r;
+    int rc = upload(c, d_c, center, (size_t)nring * 3);
+    hipError_t e = d_r.reserve((size_t)nring);
+    if (e == hipSuccess) e = d_d.reserve((size_t)nring);
+    if (rc == ARP_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_ring_residue, dim3(nblocks(nring * 64, 256, 4096)), dim3(256), 0, c->stream, c->all_grid.d,
+                           c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, (int)nring, d_c.p, d_r.p, d_d.p);
+        rc = check_launch(c, "k_ring_residue");
+        if (rc == ARP_OK) rc = download(c, out_ring_res, d_r.p, (size_t)nring);
+        if (rc == ARP_OK && out_shortest) rc = download(c, out_shortest, d_d.p, (size_t)nring);
+    }
+    d_c.release(); d_r.release(); d_d.release();
+    if (e != hipSuccess) FAIL(c, ARP_E_NOMEM, "arp_ring_residues: out of device memory");
+    return rc;
 }
 
 int arp_set_whole_structure(arp_ctx* c, int enabled) {

@@ -307,6 +307,22 @@ int arp_get_stats(arp_ctx* ctx, int64_t stats[8]);
  * reset != 0 clears the accumulators after reading. */
 int arp_set_profiling(arp_ctx* ctx, int enabled);
 int arp_get_kernel_times(arp_ctx* ctx, double ms[8], int64_t launches[8], int reset);
+/* ---- geometric part of initialize() (I:288-327): from perceived rings / amide groups to what arp_set_rings /
+ * arp_set_amides take.  Perception itself (SSSR, aromaticity, the amide SMARTS) is OpenBabel's and not provided. ----
+ *
+ * _perceive_rings (I:1697-1733) -> OBRing::findCenterAndNormal: centre = mean of the ring atoms, normal = normalised
+ * mean of the cross products of consecutive centre->atom vectors, float64.  ring_off[nring+1] / ring_idx: CSR of the
+ * ring atoms in ring order (indices into the atoms of arp_set_atoms).  out_*: double[3 * nring]. */
+int arp_ring_geometry(arp_ctx* ctx, int64_t nring, const int32_t* ring_off, const int32_t* ring_idx, double* out_center,
+                      double* out_normal);
+/* _perceive_amide_groups (I:1531-1589): amide_atoms[4 * namide] = N, C, O, C-alpha of every match; centre = (C + N) / 2
+ * (float32, I:1569), normal = unit normal of the C, O, N plane (the reference takes the last right-singular vector
+ * of the centred coordinates: same direction, sign not reproduced).  out_*: float[3 * namide]. */
+int arp_amide_geometry(arp_ctx* ctx, int64_t namide, const int32_t* amide_atoms, float* out_center, float* out_normal);
+/* _assign_aromatic_rings_to_residues (I:1453-1492): residue of the atom nearest to each ring centre among ALL atoms
+ * within 3.0 A (float64, inclusive), -1 when there is none; out_shortest (may be NULL) = that distance
+ * ('residue_shortest_distance', I:1485), -1 when there is none.  Needs arp_set_atoms (and the residue ids given there). */
+int arp_ring_residues(arp_ctx* ctx, int64_t nring, const double* center, int32_t* out_ring_res, double* out_shortest);
 /* Sharded runs with NO selection (the reference's default, I:1395: every atom of the structure): the caller
  * asserts that the selection is the whole global structure.  Then selection_plus = selection on every rank and every
  * residue of the table is in both residue sets (I:1413-1437) — including residues whose atoms live on another rank,

@@ -197,3 +197,71 @@ class RefPy:
         return dict(i=np.array([t[0] for t in out], np.int32), j=np.array([t[1] for t in out], np.int32),
                     dist=np.array([t[2] for t in out], np.float32), sift=np.array([t[3] for t in out], np.uint16),
                     ctype=np.array([t[4] for t in out], np.uint8))
+
+
+# ---- geometric part of initialize() -----------------------------------------------------------
+def ring_geometry(xyz, ring_atoms):
+    """interactions.py:1697-1733 -> OBRing::findCenterAndNormal (OpenBabel ring.cpp, third party, restated from its
+    published source; PARITY UNPINNED — OpenBabel is not installed here): centre = sum of the atom vectors times
+    1/n, normal = sum of cross(v_j - centre, v_j+1 - centre) times 1/n, normalised unless its length is < 2e-6
+    (vector3::normalize / IsNearZero; operator/= multiplies by the reciprocal).  float64 on the float32 coordinates."""
+    x = np.asarray(xyz, np.float32).reshape(-1, 3).astype(np.float64)
+    ctr, nrm = np.zeros((len(ring_atoms), 3)), np.zeros((len(ring_atoms), 3))
+    for r, atoms in enumerate(ring_atoms):
+        na = len(atoms)
+        c = np.zeros(3)
+        for a in atoms:
+            c = c + x[a]
+        inv = 1.0 / float(na)
+        c = c * inv
+        n = np.zeros(3)
+        for j in range(na):
+            v1 = x[atoms[j]] - c
+            v2 = x[atoms[0 if j + 1 == na else j + 1]] - c
+            n = n + np.array([v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]])
+        n = n * inv
+        length = np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
+        if not abs(length) < 2e-6:
+            n = n * (1.0 / length)
+        ctr[r], nrm[r] = c, n
+    return ctr, nrm
+
+
+def amide_geometry(xyz, amide_atoms):
+    """interactions.py:1566-1580 with the reference's own NumPy calls: bond centroid of C-N (float32) and the plane
+    normal from np.linalg.svd of the centred C, O, N coordinates (float32; the sign is whatever LAPACK returns)."""
+    x = np.asarray(xyz, np.float32).reshape(-1, 3)
+    at = np.asarray(amide_atoms).reshape(-1, 4)
+    ctr, nrm = np.zeros((len(at), 3), np.float32), np.zeros((len(at), 3), np.float32)
+    for k, (n_, c_, o_, _) in enumerate(at):
+        con = np.array([x[c_], x[o_], x[n_]])                # C-O-N
+        cn = np.array([x[c_], x[n_]])                        # C-N
+        amide_centroid = con.sum(0) / float(len(con))
+        bond_centroid = cn.sum(0) / float(len(cn))
+        cog = con - amide_centroid
+        u, s_, vh = np.linalg.svd(cog)
+        v = vh.conj().transpose()
+        a, b, c = v[:, -1]
+        ctr[k], nrm[k] = bond_centroid, np.array([a, b, c])
+    return ctr, nrm
+
+
+def ring_residues(xyz, res_id, ring_center):
+    """interactions.py:1453-1492: atoms within 3.0 A of the ring centre (Bio.PDB.kdtrees: float64 sum of squares <= r*r),
+    nearest by np.linalg.norm(atom.coord - centre) with a strict '<' (first of equals wins; brute force in packed atom
+    order here, KD-tree order in the reference), its residue; -1 / -1.0 when no atom qualifies."""
+    x = np.asarray(xyz, np.float32).reshape(-1, 3)
+    ctr = np.asarray(ring_center, np.float64).reshape(-1, 3)
+    res, dist = np.full(len(ctr), -1, np.int32), np.full(len(ctr), -1.0)
+    xd = x.astype(np.float64)
+    for r, c in enumerate(ctr):
+        d = xd - c
+        near = np.nonzero(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2] <= 9.0)[0]
+        closest = (None, None)
+        for a in near:
+            distance = np.linalg.norm(x[a] - c)
+            if closest[1] is None or distance < closest[1]:
+                closest = (a, distance)
+        if closest[0] is not None:
+            res[r], dist[r] = res_id[closest[0]], closest[1]
+    return res, dist

@@ -326,6 +326,65 @@ def test_interaction_complex_drop_in(ctx):
         ic.run_arpeggio(['/A/999999/'], 5.0, 0.1, False)
 
 
+def test_initialize_geometry_rings_amides_and_ring_residues(ctx):
+    """ring centre / normal (I:1697-1733), amide centre / normal (I:1531-1589) and the ring ->
+    residue assignment (I:1453-1492) on the GPU against the NumPy restatement (oracle/ref_py.py)."""
+    from oracle import ref_py
+    from arpeggio_amd import synth
+    pc = synth.proteinlike(n_res=200, seed=6, n_waters=80)
+    ctx.set_complex(pc)
+    assert pc.n_rings > 10 and pc.n_amides > 100
+    rings = [np.asarray(a, np.int32) for a in pc.ring_atoms]
+    ctr, nrm = ctx.ring_geometry(rings)
+    ectr, enrm = ref_py.ring_geometry(pc.xyz, rings)
+    assert np.array_equal(ctr, ectr)                                        # bit-identical float64
+    assert np.array_equal(nrm, enrm)
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-12)
+    # the generator's own centres are the same points (it averages the same atoms)
+    assert np.allclose(ctr, pc.ring_center, atol=1e-5)
+    res, dist = ctx.ring_residues(ctr)
+    eres, edist = ref_py.ring_residues(pc.xyz, pc.res_id, ctr)
+    assert np.array_equal(res, eres) and np.array_equal(dist, edist)
+    assert (res >= 0).all() and (res == pc.ring_res).mean() > 0.8     # (the generator assigns rings by construction, not by distance)
+    far = ctr + 500.0                                                       # nothing within 3 A
+    res2, dist2 = ctx.ring_residues(far)
+    assert (res2 == -1).all() and (dist2 == -1.0).all()
+    # amides: centre bit-identical (float32 mean of C and N); normal = the SVD's plane normal up to sign and ~1e-6
+    am = pc.amide_atoms
+    actr, anrm = ctx.amide_geometry(am)
+    ectr, enrm = ref_py.amide_geometry(pc.xyz, am)
+    assert np.array_equal(actr, ectr)
+    sign = np.sign(np.sum(anrm * enrm, axis=1, keepdims=True))
+    assert np.abs(anrm * sign - enrm).max() < 5e-6
+    # through the mirror class: a pack whose ring / amide geometry is blank gets it from the GPU, results unchanged
+    from arpeggio_amd.core import InteractionComplex
+    import copy
+    blank = copy.deepcopy(pc)
+    blank.ring_center[:] = 0
+    blank.ring_normal[:] = 0
+    blank.amide_center[:] = 0
+    blank.amide_normal[:] = 0
+    ic = InteractionComplex(blank, 0.1, 5.0, 7.4)
+    ic.initialize()
+    ic.compute_plane_geometry(assign_ring_residues=False)
+    assert np.array_equal(blank.ring_center, ctr) and np.array_equal(blank.amide_center, actr)
+    ic.run_arpeggio([], 5.0, 0.1, False)
+    ref_ic = InteractionComplex(pc, 0.1, 5.0, 7.4)
+    ref_ic.initialize()
+    ref_ic.run_arpeggio([], 5.0, 0.1, False)
+    for bag in ('atom_plane', 'plane_plane', 'group_group', 'group_plane'):
+        a, b = ic._bags[bag], ref_ic._bags[bag]
+        assert len(a['dist']) == len(b['dist']) and np.allclose(a['dist'], b['dist'], atol=1e-5), bag
+    assert len(ic._bags['atom_plane']['dist']) > 0 and len(ic._bags['group_group']['dist']) > 0
+    # degenerate ring (all atoms on one point): the normal stays (0, 0, 0) as vector3::normalize leaves it
+    c0, n0 = ctx.ring_geometry([np.array([5, 5, 5], np.int32)])
+    assert np.array_equal(n0, np.zeros((1, 3))) and np.allclose(c0[0], pc.xyz[5], atol=1e-6)
+    with pytest.raises(Exception):
+        ctx.ring_geometry([np.array([0, 1], np.int32)])                     # fewer than three atoms
+    with pytest.raises(Exception):
+        ctx.ring_geometry([np.array([0, 1, pc.n_atoms], np.int32)])         # index out of range
+
+
 def test_atom_and_residue_sifts_and_csv(tmp_path):
     """per-atom sifts (I:923-934), their per-residue flattening (I:471-560) and write_atom_sifts
     (I:349-366) through the mirror class, against the oracle's accumulators."""

@@ -194,3 +194,31 @@ def test_plane_plane_classes_at_bin_edges():
     assert names[L.orc_pp_class(90.0, 90.0)] == 'EF'
     assert names[L.orc_pp_class(float('nan'), 10.0)] == ''
     assert names[L.orc_pp_class(10.0, float('nan'))] == ''
+
+
+def test_initialize_geometry_restatement_known_answers():
+    """oracle/ref_py.py ring / amide geometry and ring -> residue assignment on hand-made inputs (I:1697-1733,
+    1531-1589, 1453-1492)."""
+    import numpy as np
+    from oracle import ref_py
+    ang = np.arange(6) * np.pi / 3
+    hexagon = np.stack([1.39 * np.cos(ang) + 4.0, 1.39 * np.sin(ang) - 2.0, np.full(6, 7.5)], axis=1).astype(np.float32)
+    extra = np.array([[4.0, -2.0, 8.6], [4.0, -2.0, 10.4], [9.0, 9.0, 9.0]], np.float32)   # 1.1 A and 2.9 A above the centre, one far away
+    xyz = np.concatenate([hexagon, extra])
+    ctr, nrm = ref_py.ring_geometry(xyz, [list(range(6))])
+    assert np.allclose(ctr[0], [4.0, -2.0, 7.5], atol=1e-6)
+    assert np.allclose(nrm[0], [0, 0, 1], atol=1e-6)                         # counter-clockwise ring: +z
+    ctr2, nrm2 = ref_py.ring_geometry(xyz, [list(range(5, -1, -1))])
+    assert np.allclose(nrm2[0], [0, 0, -1], atol=1e-6)                       # same atoms the other way round: -z
+    res_id = np.array([3, 3, 3, 3, 3, 3, 8, 9, 1], np.int32)
+    res, dist = ref_py.ring_residues(xyz, res_id, ctr)
+    assert res.tolist() == [8] and abs(dist[0] - 1.1) < 1e-6                 # the atom 1.1 A above beats the ring atoms (1.39 A)
+    res, dist = ref_py.ring_residues(xyz[:6], res_id[:6], ctr)
+    assert res.tolist() == [3] and abs(dist[0] - 1.39) < 1e-6
+    res, dist = ref_py.ring_residues(xyz[8:], res_id[8:], ctr)
+    assert res.tolist() == [-1] and dist.tolist() == [-1.0]                  # nothing within 3 A (I:1476-1479)
+    # amide in the plane z = 2: centre = midpoint of C and N, normal = +-z
+    am = np.array([[1.3, 0.2, 2.0], [0.0, 0.0, 2.0], [-0.6, 1.05, 2.0], [-0.8, -1.2, 2.4]], np.float32)   # N, C, O, CA
+    c, n = ref_py.amide_geometry(am, [[0, 1, 2, 3]])
+    assert c.dtype == np.float32 and np.allclose(c[0], [0.65, 0.1, 2.0], atol=1e-6)
+    assert np.allclose(np.abs(n[0]), [0, 0, 1], atol=1e-5)
