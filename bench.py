@@ -201,6 +201,14 @@ def main():
                 'algorithmic_bytes_per_launch': int(b_alg), 'avg_launch_ms': round(dom_ms, 5),
                 'note': 'VALU-bound geometry kernel; HBM fraction is small by construction (SURVEY 8d)'}
 
+    # the same figure for every big kernel of the pass (informational; `roofline` above is the dominant one)
+    roofline_all = {}
+    for k, ms in candidates_for_dominant.items():
+        nb = st['binned'] if k != 'mark_search' else pc.n_atoms
+        b = algorithmic_bytes(k, nb, ncell, emitted)
+        roofline_all[f'k_{k}'] = {'avg_launch_ms': round(ms, 5), 'algorithmic_bytes_per_launch': int(b),
+                                  'achieved_GBps': round(b / (ms * 1e-3) / 1e9, 2), 'frac': round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+
     # ---------------- CPU baseline: the C oracle on one host core, bounded sample ----------------
     cpu = None
     if not args.no_cpu_baseline:
@@ -237,6 +245,7 @@ def main():
         'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()},
         'kernel_launches_per_step': {k: v['launches'] / args.steps for k, v in ktimes.items() if v['launches']},
         'ms_per_step_profiled_pass': round(elapsed_profiled / args.steps * 1e3, 4),
+        'roofline_all_kernels': roofline_all,
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
         'launch_mode': 'direct launches on two HIP streams, one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
