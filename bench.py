@@ -100,8 +100,14 @@ def main():
         full = synth.slab_config(args.atoms, world, seed=4)
         workload = (f'synthetic {args.atoms * world} atoms in {world} x-slabs of {args.atoms} '
                     f'(BASELINE configs[3] family), one-cell halo over RCCL')
-        shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
-        halo_ms = shard.halo_ms
+        halo_note = 'records of the one-cell halo exchanged with grouped isend/irecv (RCCL)'
+        try:
+            shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
+            halo_ms = shard.halo_ms
+        except Exception as exc:   # keep the scaling run alive: every rank holds the full synthetic structure anyway
+            shard = sharding.make_shard_local(full, rank, world)
+            halo_ms = -1.0
+            halo_note = f'halo exchange failed ({exc!r}); shards cut from the locally generated structure'
         ctx = _capi.Context(local_rank)
         sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
         n_local_home = int(shard.is_home.sum())
@@ -289,7 +295,7 @@ def main():
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
         'launch_mode': 'direct launches on two HIP streams, one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
-        'halo_exchange_ms': round(halo_ms, 3), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
+        'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange': (halo_note if world > 1 else None), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(line))
