@@ -89,6 +89,8 @@ def load():
     L.arp_ring_geometry.argtypes = [vp, i64, vp, vp, vp, vp]
     L.arp_amide_geometry.argtypes = [vp, i64, vp, vp, vp]
     L.arp_ring_residues.argtypes = [vp, i64, vp, vp, vp]
+    L.arp_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+    L.arp_host_free.argtypes = [vp]
     L.arp_stream_handle.argtypes = [vp]
     L.arp_use_stream.argtypes = [vp, C.c_uint64]
     L.arp_stream_handle.restype = C.c_uint64
@@ -102,6 +104,23 @@ def load():
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pinned_empty(n, dtype):
+    """NumPy array over page-locked memory from arp_host_alloc (freed when the array and its views are gone): the
+    fetch calls fill such arrays at PCIe speed.  Falls back to ordinary memory when the allocation fails."""
+    import weakref
+    dt = np.dtype(dtype)
+    nbytes = int(n) * dt.itemsize
+    if nbytes == 0:
+        return np.empty(int(n), dt)
+    L = load()
+    ptr = C.c_void_p()
+    if L.arp_host_alloc(nbytes, C.byref(ptr)) != 0 or not ptr.value:
+        return np.empty(int(n), dt)
+    buf = (C.c_char * nbytes).from_address(ptr.value)
+    weakref.finalize(buf, L.arp_host_free, C.c_void_p(ptr.value))
+    return np.frombuffer(buf, dtype=dt, count=int(n))
 
 
 KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')
@@ -254,10 +273,24 @@ class Context:
                                                      C.byref(cnt)), 'arp_atom_contacts_launch')
         return int(cnt.value)
 
-    def atom_contacts_fetch(self, count, sort=True):
+    @staticmethod
+    def pinned_contact_buffers(capacity):
+        """Page-locked result buffers for ``atom_contacts_fetch(..., out=...)``: allocate once, reuse for every structure
+        (the fetch then runs at PCIe speed; pinning memory costs more than one copy, so it is not done per call)."""
+        cap = max(int(capacity), 1)
+        return dict(i=pinned_empty(cap, np.int32), j=pinned_empty(cap, np.int32), dist=pinned_empty(cap, np.float32),
+                    sift=pinned_empty(cap, np.uint16), ctype=pinned_empty(cap, np.uint8))
+
+    def atom_contacts_fetch(self, count, sort=True, out=None):
+        """Download the resident contact list.  ``out``: buffers from ``pinned_contact_buffers`` (the returned arrays
+        are then views into them, valid until the next fetch into the same buffers)."""
         cap = max(int(count), 1)
-        oi, oj = np.empty(cap, np.int32), np.empty(cap, np.int32)
-        od, osf, oc = np.empty(cap, np.float32), np.empty(cap, np.uint16), np.empty(cap, np.uint8)
+        if out is not None and min(len(out[k]) for k in ('i', 'j', 'dist', 'sift', 'ctype')) >= cap:
+            oi, oj, od, osf, oc = out['i'], out['j'], out['dist'], out['sift'], out['ctype']
+            cap = min(len(a) for a in (oi, oj, od, osf, oc))
+        else:
+            oi, oj = np.empty(cap, np.int32), np.empty(cap, np.int32)
+            od, osf, oc = np.empty(cap, np.float32), np.empty(cap, np.uint16), np.empty(cap, np.uint8)
         cnt = C.c_int64(0)
         self._check(self._L.arp_atom_contacts_fetch(self._h, cap, _p(oi), _p(oj), _p(od), _p(osf), _p(oc), C.byref(cnt)),
                     'arp_atom_contacts_fetch')

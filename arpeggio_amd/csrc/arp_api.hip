@@ -121,6 +121,7 @@ struct arp_ctx {
     DevBuf<float4> s_xyzm;
     DevBuf<int4> s_aux;
     DevBuf<SiftRec> s_rec;
+    DevBuf<int> tmp_i32;          // scratch for index uploads
     DevBuf<int4> st_q1;           // selection-independent record columns, composed once per structure (k_prepare_static)
     DevBuf<uint16_t> rad_idx;     // per atom: index of its {vdw, cov} pair in rad_tab (RAD_NONE: not in the table)
     DevBuf<double2> rad_tab;      // RAD_TABLE distinct radius pairs of the structure
@@ -186,6 +187,17 @@ template <class T>
 int upload(arp_ctx* c, DevBuf<T>& buf, const T* src, size_t n) {
     HIPCHK(c, buf.reserve(n ? n : 1));
     if (n) HIPCHK(c, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ARP_OK;
+}
+// several uploads of one setter: enqueue them all, synchronise once (upload_done) before the sources go away
+template <class T>
+int upload_async(arp_ctx* c, DevBuf<T>& buf, const T* src, size_t n) {
+    HIPCHK(c, buf.reserve(n ? n : 1));
+    if (n) HIPCHK(c, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return ARP_OK;
+}
+int upload_done(arp_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
@@ -880,7 +892,7 @@ void arp_destroy(arp_ctx* c) {
     c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
-    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
+    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->tmp_i32.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
@@ -913,6 +925,8 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     }
     c->max_res_id = max_res;
     HIPCHK(c, hipSetDevice(c->device));
+    // uploads below are enqueued together; whatever the exit path, they are complete before the staging vectors die
+    struct SyncOnExit { arp_ctx* c; ~SyncOnExit() { (void)hipStreamSynchronize(c->stream); } } sync_on_exit{c};
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     c->n = n;
@@ -924,8 +938,8 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
         x4[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
         r2[i] = make_double2(vdw[i], cov[i]);
     }
-    CHK(upload(c, c->xyz, x4.data(), (size_t)n));
-    CHK(upload(c, c->rad, r2.data(), (size_t)n));
+    CHK(upload_async(c, c->xyz, x4.data(), (size_t)n));
+    CHK(upload_async(c, c->rad, r2.data(), (size_t)n));
     {   // dictionary of the distinct {vdw, cov} pairs (element values: a handful per structure), compared bit for bit
         std::vector<double2> tab((size_t)RAD_TABLE, make_double2(0.0, 0.0));
         std::vector<uint16_t> idx((size_t)std::max<int64_t>(n, 1), (uint16_t)RAD_NONE);
@@ -948,20 +962,22 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
             last = hit;
             idx[(size_t)i] = (uint16_t)hit;
         }
-        CHK(upload(c, c->rad_idx, idx.data(), (size_t)std::max<int64_t>(n, 1)));
-        CHK(upload(c, c->rad_tab, tab.data(), (size_t)RAD_TABLE));
+        CHK(upload_async(c, c->rad_idx, idx.data(), (size_t)std::max<int64_t>(n, 1)));
+        CHK(upload_async(c, c->rad_tab, tab.data(), (size_t)RAD_TABLE));
+        CHK(upload_done(c));   // tab / idx go out of scope here
     }
-    CHK(upload(c, c->tmask, type_mask, (size_t)n));
-    CHK(upload(c, c->flags, flags, (size_t)n));
-    CHK(upload(c, c->res_id, res_id, (size_t)n));
+    CHK(upload_async(c, c->tmask, type_mask, (size_t)n));
+    CHK(upload_async(c, c->flags, flags, (size_t)n));
+    CHK(upload_async(c, c->res_id, res_id, (size_t)n));
     // defaults for the optional per-atom inputs: no bonds, no hydrogens, no neighbours
     std::vector<int> zeros((size_t)n + 1, 0);
-    CHK(upload(c, c->bond_off, zeros.data(), (size_t)n + 1));
-    CHK(upload(c, c->h_off, zeros.data(), (size_t)n + 1));
+    CHK(upload_async(c, c->bond_off, zeros.data(), (size_t)n + 1));
+    CHK(upload_async(c, c->h_off, zeros.data(), (size_t)n + 1));
     HIPCHK(c, c->bond_idx.reserve(1));
     HIPCHK(c, c->h_xyz_d.reserve(3));
     std::vector<float4> sb0((size_t)n, make_float4(0, 0, 0, 0));
-    CHK(upload(c, c->sb, sb0.data(), (size_t)n));
+    CHK(upload_async(c, c->sb, sb0.data(), (size_t)n));
+    CHK(upload_done(c));   // (the staging vectors above live until here)
     c->has_gid = c->has_home = false;
     c->sel_made = false;
     c->sel_uploaded = false;   // a new structure starts with the default selection: everything (I:1395)
@@ -1025,14 +1041,16 @@ int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
     HIPCHK(c, hipSetDevice(c->device));
     ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
-    std::vector<float4> sb((size_t)c->n);
-    for (int64_t i = 0; i < c->n; ++i) {
-        int k = sb_nbr[i];
-        if (k < -1 || k >= c->n) FAIL(c, ARP_E_ARG, "arp_set_single_bond_neighbours: index out of range");
-        sb[i] = k < 0 ? make_float4(0, 0, 0, 0)
-                      : make_float4(c->h_xyz[3 * (size_t)k], c->h_xyz[3 * (size_t)k + 1], c->h_xyz[3 * (size_t)k + 2], 1.0f);
+    for (int64_t i = 0; i < c->n; ++i)
+        if (sb_nbr[i] < -1 || sb_nbr[i] >= c->n) FAIL(c, ARP_E_ARG, "arp_set_single_bond_neighbours: index out of range");
+    // the neighbour's coordinates are gathered on the device from the uploaded atoms (x, y, z, 1) / (0, 0, 0, 0)
+    CHK(upload(c, c->tmp_i32, sb_nbr, (size_t)c->n));
+    HIPCHK(c, c->sb.reserve((size_t)std::max<int64_t>(c->n, 1)));
+    if (c->n > 0) {
+        hipLaunchKernelGGL(k_gather_neighbours, dim3(nblocks(c->n, 256)), dim3(256), 0, c->stream, (int)c->n, c->tmp_i32.p, c->xyz.p, c->sb.p);
+        CHK(check_launch(c, "k_gather_neighbours"));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    CHK(upload(c, c->sb, sb.data(), (size_t)c->n));
     c->contacts_valid = false;
     return ARP_OK;
 }
@@ -1273,8 +1291,15 @@ int arp_atom_contacts_fetch(arp_ctx* c, int64_t cap, int32_t* out_i, int32_t* ou
     *count = c->n_contacts;
     if (c->n_contacts > cap) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_fetch: output buffer too small");
     const size_t k = (size_t)c->n_contacts;
-    CHK(download(c, out_i, c->out_i.p, k)); CHK(download(c, out_j, c->out_j.p, k)); CHK(download(c, out_dist, c->out_d.p, k));
-    CHK(download(c, out_sift, c->out_s.p, k)); CHK(download(c, out_ctype, c->out_ct.p, k));
+    // five copies in flight, one synchronisation (into buffers from arp_host_alloc they run at PCIe speed)
+    if (k) {
+        if (out_i) HIPCHK(c, hipMemcpyAsync(out_i, c->out_i.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_j) HIPCHK(c, hipMemcpyAsync(out_j, c->out_j.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, c->out_d.p, k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (out_sift) HIPCHK(c, hipMemcpyAsync(out_sift, c->out_s.p, k * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_ctype) HIPCHK(c, hipMemcpyAsync(out_ctype, c->out_ct.p, k * sizeof(uint8_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
 
@@ -1738,6 +1763,19 @@ int arp_ring_residues(arp_ctx* c, int64_t nring, const double* center, int32_t* 
     d_c.release(); d_r.release(); d_d.release();
     if (e != hipSuccess) FAIL(c, ARP_E_NOMEM, "arp_ring_residues: out of device memory");
     return rc;
+}
+
+// Page-locked host memory for result buffers (and inputs): copies to / from it are DMA transfers at PCIe speed,
+// pageable memory goes through the runtime's staging buffer at a fraction of that.
+int arp_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return ARP_E_ARG;
+    *out = nullptr;
+    if (bytes == 0) return ARP_OK;
+    return hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) == hipSuccess ? ARP_OK : ARP_E_NOMEM;
+}
+int arp_host_free(void* p) {
+    if (!p) return ARP_OK;
+    return hipHostFree(p) == hipSuccess ? ARP_OK : ARP_E_HIP;
 }
 
 int arp_set_whole_structure(arp_ctx* c, int enabled) {

@@ -89,6 +89,20 @@ struct __attribute__((aligned(32))) SiftRec {
     int4 q1;
 };
 
+// arp_set_single_bond_neighbours: coordinates of every atom's single-bond heavy neighbour (w = 1) or zeros (w = 0)
+__global__ __launch_bounds__(256) void k_gather_neighbours(int n, const int* __restrict__ nbr, const float4* __restrict__ xyz,
+                                                           float4* __restrict__ sb) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int k = nbr[i];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k >= 0) {
+            v = xyz[k];
+            v.w = 1.0f;
+        }
+        sb[i] = v;
+    }
+}
+
 // Everything of an atom record that does not depend on the selection, composed once per structure and
 // kept as 16-byte columns so that the per-pass grid builds read them coalesced.
 struct StaticAtoms {
