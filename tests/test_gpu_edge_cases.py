@@ -227,3 +227,39 @@ def test_sparse_structures_whose_grids_need_the_tiled_scan(ctx, box):
     pc.h_xyz = ((pc.h_xyz * 0.35) + shift[par // 50]).reshape(pc.h_xyz.shape)
     got = _check(ctx, pc, brute=False)
     assert len(got['i']) > 1000
+
+
+def test_many_random_small_structures(ctx):
+    """60 random soups of 1..500 atoms in boxes of 3..80 A (from one crowded cell to mostly empty grids), random
+    selections, every atom type / flag, bonds, hydrogens: selection_plus, contacts, SIFts and distances against the
+    brute-force oracle.  Exercises partial home blocks, grid borders, the start-table batches and the task queues."""
+    import oracle
+    from helpers import random_dense_pack
+    rng = np.random.default_rng(2024)
+    total = 0
+    for case in range(60):
+        n = int(rng.integers(1, 500))
+        box = float(rng.choice([3.0, 6.0, 9.5, 14.0, 22.0, 37.0, 80.0]))
+        pc = random_dense_pack(1000 + case, n=max(n, 4), box=box)
+        sel = None if case % 3 == 0 else (rng.random(pc.n_atoms) < rng.choice([0.02, 0.3, 0.9])).astype(np.uint8)
+        if sel is not None and sel.sum() == 0:
+            sel[int(rng.integers(0, pc.n_atoms))] = 1
+        ctx.set_complex(pc)
+        masks = ctx.make_selection(sel)
+        oc = oracle.OracleComplex(pc)
+        plus = oc.make_selection(sel, use_grid=False)
+        assert np.array_equal(masks['plus'], plus), case
+        got = ctx.atom_contacts()
+        exp = oc.atom_contacts(use_grid=False)
+        assert len(got['i']) == len(exp['i']), case
+        for k in ('i', 'j', 'sift', 'ctype'):
+            assert np.array_equal(got[k], exp[k]), (case, k)
+        assert np.array_equal(got['dist'].view(np.uint32), exp['dist'].view(np.uint32)), case
+        # the one-wait pass gives the same list
+        if sel is not None:
+            ctx.set_selection(sel)
+        counts = ctx.run_launch()
+        again = ctx.atom_contacts_fetch(counts['atom_atom'])
+        assert np.array_equal(again['i'], exp['i']) and np.array_equal(again['sift'], exp['sift']), case
+        total += len(exp['i'])
+    assert total > 100_000
