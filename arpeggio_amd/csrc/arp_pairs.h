@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, con
 }
 
 // ---- neighbour search ---------------------------------------------------------------
-#define SEARCH_WAVES 4
+#define SEARCH_WAVES 8
 #define QCAP 512
 #define HOME_BLOCK 32
 
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         }
       }
     }
-    // End of block: the four per-wave queues leave with ONE atomicAdd (single-address atomics
+    // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
     // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
     __shared__ int s_qn[SEARCH_WAVES];
     __shared__ u64 s_base, s_cand[SEARCH_WAVES], s_acc[SEARCH_WAVES];
