@@ -639,7 +639,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         }
         {
             Prof p(c, SLOT_SIFT);
-            static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 8));
+            static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
             hipLaunchKernelGGL(k_sift, dim3(c->num_cu * sift_blocks_per_cu), dim3(256), 0, c->stream, c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap,
                                c->s_rec.p, SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p}, c->bond_idx.p, c->h_xyz_d.p,
                                c->has_gid ? c->gid.p : nullptr, vdw_comp, env_int("ARP_ABLATE", 0),
