@@ -127,6 +127,30 @@ def test_local_shards_union_equals_unsharded(world):
     assert len(exp['aa']) > 1000 and len(exp['pp']) > 0 and len(exp['ap']) > 0
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_whole_structure_shards_need_no_selection_exchange(world):
+    """No selection (I:1395) = everything selected: each shard can fill its masks by itself — selection_plus is every
+    local atom and every ring / amide with a residue is in both sets (arp_set_whole_structure) — and the union of what
+    the ranks own is the unsharded whole-structure result.  This is the path bench.py --gpus N times by default."""
+    full, _ = _workload()
+    exp, oc = _reference(full, None)
+    assert oc.in_plus.all() and oc.ring_plus[full.ring_res >= 0].all()
+    got = {k: [] for k in exp}
+    for rank in range(world):
+        sh = sharding.make_shard_local(full, rank, world, None)
+        assert sh.sel.all()
+        ones = lambda n: np.ones(n, np.uint8)
+        masks = dict(sel=ones(sh.pc.n_atoms), plus=ones(sh.pc.n_atoms),
+                     ring_sel=(sh.pc.ring_res >= 0).astype(np.uint8), ring_plus=(sh.pc.ring_res >= 0).astype(np.uint8),
+                     amide_sel=(sh.pc.amide_res >= 0).astype(np.uint8), amide_plus=(sh.pc.amide_res >= 0).astype(np.uint8))
+        out = _eval_shard(sh, masks)
+        for k in got:
+            got[k].append(out[k])
+    for k in exp:
+        assert np.array_equal(_canon(np.concatenate(got[k], axis=0)), _canon(exp[k])), k
+    assert len(exp['aa']) > 10_000 and len(exp['pp']) > 0 and len(exp['ap']) > 0
+
+
 class _OracleStageContext:
     """Stand-in for the GPU context in the staged (run_stage) protocol: same three stages, NumPy buffers, the oracle
     as compute.  Exercises sharding.DeviceExchange / run_shard_device over gloo."""
