@@ -699,3 +699,53 @@ def test_proteinlike_stand_in_for_1tqn(ctx, selectors):
         hem = [c for c in contacts if c['type'] == 'atom-atom' and 'HEM' in (c['bgn']['label_comp_id'], c['end']['label_comp_id'])]
         assert hem and all(c['bgn']['auth_seq_id'] == 508 or c['end']['auth_seq_id'] == 508 for c in hem)
     ic._ctx = None     # the fixture owns the context
+
+
+def test_config4_two_million_atoms_sharded_equals_single_gpu(capi):
+    """BASELINE configs[3] at full size: 2 M atoms in 8 x-slabs.  Run once unsharded on one GPU and once as the 8 shards
+    the ranks of `bench.py --gpus 8` would hold (one after the other on this GPU, whole-structure path, no exchange):
+    the union of what the shards own is the single-GPU contact list — ids, SIFts, contact types, float32 distances —
+    plus the size-independent properties of the list."""
+    from arpeggio_amd import sharding, synth
+    full = synth.slab_config(250_000, 8, seed=4)
+    assert full.n_atoms == 2_000_000
+    c1 = capi.Context(0)
+    c1.set_complex(full)
+    counts = c1.run_launch()
+    ref = c1.atom_contacts_fetch(counts['atom_atom'])
+    ref_pp = c1.fetch_bag('plane_plane')
+    ref_ap = c1.fetch_bag('atom_plane')
+    again = c1.run_launch()
+    assert again == counts                                                    # idempotent
+    c1.close()
+    n = len(ref['i'])
+    assert n > 20_000_000 and np.all(ref['i'] < ref['j'])
+    key = ref['i'].astype(np.int64) * full.n_atoms + ref['j']
+    assert np.all(np.diff(key) > 0)                                           # sorted, no duplicate pair
+    ladder = ref['sift'] & 0x1F
+    assert np.all((ladder & (ladder - 1)) == 0) and np.all(ladder != 0)       # exactly one of clash .. proximal
+    assert np.all(full.res_id[ref['i']] != full.res_id[ref['j']])             # I:729
+    assert ref['dist'].max() <= np.float32(5.0) * np.float32(1.000001)
+    d = np.linalg.norm(full.xyz[ref['i'][::97]].astype(np.float64) - full.xyz[ref['j'][::97]].astype(np.float64), axis=1)
+    assert np.abs(d - ref['dist'][::97]).max() < 1e-5                         # the north star's distance bound
+    parts, pp_parts, ap_parts = [], [], []
+    c2 = capi.Context(0)
+    for rank in range(8):
+        sh = sharding.make_shard_local(full, rank, 8, None)
+        sharding.upload_shard(c2, sh, whole_structure=True)
+        k = sharding.run_shard_whole_structure(c2)
+        parts.append(c2.atom_contacts_fetch(k['atom_atom'], sort=False))
+        pp_parts.append(c2.fetch_bag('plane_plane'))
+        ap_parts.append(c2.fetch_bag('atom_plane'))
+    c2.close()
+    got = {f: np.concatenate([p[f] for p in parts]) for f in ('i', 'j', 'dist', 'sift', 'ctype')}
+    assert len(got['i']) == n
+    o = np.argsort(got['i'].astype(np.int64) * full.n_atoms + got['j'], kind='stable')
+    for f in ('i', 'j', 'sift', 'ctype'):
+        assert np.array_equal(got[f][o], ref[f]), f
+    assert np.array_equal(got['dist'][o].view(np.uint32), ref['dist'].view(np.uint32))
+    for bags, refbag, k1, k2 in ((pp_parts, ref_pp, 'bgn', 'end'), (ap_parts, ref_ap, 'ring', 'atom')):
+        g = {f: np.concatenate([b[f] for b in bags]) for f in refbag}
+        o = np.lexsort((g[k2], g[k1]))
+        assert np.array_equal(g[k1][o], refbag[k1]) and np.array_equal(g[k2][o], refbag[k2])
+        assert np.array_equal(g['dist'][o], refbag['dist'])
