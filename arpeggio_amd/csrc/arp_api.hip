@@ -455,12 +455,13 @@ int enqueue_counter_copy(arp_ctx* c, int zero = 0) {  // counter block -> pinned
     CHK(check_launch(c, "k_publish_counters"));
     return ARP_OK;
 }
-int collect_counters(arp_ctx* c) {  // the only stream sync of a pass
+int collect_counters(arp_ctx* c, bool replayed = false) {  // the only stream sync of a pass
     // The publish kernel is the last operation of the pass and ends by storing the pass number in pinned memory:
     // polling that word wakes the host ~10 us sooner than hipStreamSynchronize.  Bounded: after 2 ms (or with a
     // caller-owned stream, a captured graph or ARP_SPIN_WAIT=0) the runtime's own wait takes over.
     static const int spin = env_int("ARP_SPIN_WAIT", 1);
-    if (spin && !c->external_stream) {
+    // (a replayed graph stores the sequence number it was captured with: no polling there)
+    if (spin && !c->external_stream && !replayed) {
         volatile u64* flag = c->h_ctr_pinned + C_COUNT;
         const auto t0 = std::chrono::steady_clock::now();
         for (int it = 0; *flag != c->publish_seq; ++it) {
@@ -1505,7 +1506,7 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
             // replay: the launch-bound chain of ~25 small kernels costs one graph launch on the host
             CHK(ensure_zero());
             HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-            CHK(collect_counters(c));
+            CHK(collect_counters(c, true));
             c->ctr_zero_ok = true;
             const int ov = any_overflow(false);
             if (ov < 0) return ov;
@@ -1531,7 +1532,7 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
             } else {
                 CHK(ensure_zero());
                 HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-                CHK(collect_counters(c));
+                CHK(collect_counters(c, true));
                 c->ctr_zero_ok = true;
                 const int ov = any_overflow(false);
                 if (ov < 0) return ov;
