@@ -8,6 +8,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -23,8 +24,14 @@
 
 namespace {
 
-std::string g_create_error;
-uint64_t g_alloc_epoch = 0;   // bumped by every device (re)allocation: invalidates captured graphs
+std::string g_create_error;   // arp_create failures only (no context to hold the message); written under g_create_mutex
+std::mutex g_create_mutex;
+void set_create_error(const std::string& m) {
+    std::lock_guard<std::mutex> lk(g_create_mutex);
+    g_create_error = m;
+}
+std::atomic<uint64_t> g_alloc_epoch{0};   // bumped by every device (re)allocation: invalidates captured graphs
+                                          // (contexts may live on different host threads: one context per thread)
 
 template <class T>
 struct DevBuf {
@@ -849,15 +856,15 @@ int arp_create(int device, arp_ctx** out) {
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
-        g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        set_create_error(std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
         return ARP_E_HIP;
     }
     if (device < 0 || device >= ndev) {
-        g_create_error = "device ordinal out of range";
+        set_create_error("device ordinal out of range");
         return ARP_E_ARG;
     }
     e = hipSetDevice(device);
-    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return ARP_E_HIP; }
+    if (e != hipSuccess) { set_create_error(hipGetErrorString(e)); return ARP_E_HIP; }
     arp_ctx* c = new (std::nothrow) arp_ctx();
     if (!c) return ARP_E_NOMEM;
     c->device = device;
@@ -873,7 +880,7 @@ int arp_create(int device, arp_ctx** out) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_ctr_pinned, sizeof(u64) * (C_COUNT + 1), hipHostMallocDefault);
     if (e == hipSuccess) memset(c->h_ctr_pinned, 0, sizeof(u64) * (C_COUNT + 1));
     if (e != hipSuccess) {
-        g_create_error = hipGetErrorString(e);
+        set_create_error(hipGetErrorString(e));
         delete c;
         return ARP_E_HIP;
     }
@@ -1495,7 +1502,7 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
     // Graph replay of the pass is optional (ARP_GRAPH=1): on MI355X the direct launches already keep the GPU
     // busy back to back (measured 0.261 ms direct vs 0.273 ms replayed per 100k-atom pass), so it is off by default.
     static const int use_graph = env_int("ARP_GRAPH", 0);
-    const arp_ctx::GraphKey key{cutoff, vdw_comp, expand_radius, include_sequence_adjacent, g_alloc_epoch, c->input_epoch, true};
+    const arp_ctx::GraphKey key{cutoff, vdw_comp, expand_radius, include_sequence_adjacent, g_alloc_epoch.load(), c->input_epoch, true};
     auto same = [](const arp_ctx::GraphKey& a, const arp_ctx::GraphKey& b) {
         return a.valid && b.valid && a.cutoff == b.cutoff && a.comp == b.comp && a.expand == b.expand && a.seq_adj == b.seq_adj &&
                a.alloc_epoch == b.alloc_epoch && a.input_epoch == b.input_epoch;
@@ -1559,7 +1566,7 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_launch: result buffers could not be sized");
     }
     c->last_key = key;
-    c->last_key.alloc_epoch = g_alloc_epoch;
+    c->last_key.alloc_epoch = g_alloc_epoch.load();
     c->stats[5] = (int64_t)c->h_ctr[C_MARK_CAND];
     c->stats[6] = (int64_t)c->h_ctr[C_MARK_ACC];
     if (counts) {
