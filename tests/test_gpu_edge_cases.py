@@ -263,3 +263,42 @@ def test_many_random_small_structures(ctx):
         assert np.array_equal(again['i'], exp['i']) and np.array_equal(again['sift'], exp['sift']), case
         total += len(exp['i'])
     assert total > 100_000
+
+
+def test_two_contexts_on_two_host_threads(capi):
+    """One arp_ctx per host thread: two threads run different structures concurrently on one GPU and
+    each gets exactly what a lone run gives."""
+    import threading
+    from helpers import random_dense_pack
+    packs = [random_dense_pack(71, n=1800, box=28.0), random_dense_pack(72, n=2300, box=31.0)]
+    lone = []
+    for pc in packs:
+        c = capi.Context(0)
+        c.set_complex(pc)
+        k = c.run_launch()
+        lone.append((k, c.atom_contacts_fetch(k['atom_atom'])))
+        c.close()
+    results, errors = [None, None], []
+
+    def work(t):
+        try:
+            c = capi.Context(0)
+            c.set_complex(packs[t])
+            for _ in range(40):
+                k = c.run_launch()
+            results[t] = (k, c.atom_contacts_fetch(k['atom_atom']))
+            c.close()
+        except Exception as exc:      # surfaces in the main thread below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for t in range(2):
+        assert results[t][0] == lone[t][0]
+        for f in ('i', 'j', 'sift', 'ctype'):
+            assert np.array_equal(results[t][1][f], lone[t][1][f]), (t, f)
+        assert np.array_equal(results[t][1]['dist'].view(np.uint32), lone[t][1]['dist'].view(np.uint32))
