@@ -258,3 +258,24 @@ def search_point(xyz, center, radius, active=None):
     out = np.zeros(n if n else 1, np.int32)
     cnt = lib().orc_search_point(C.c_int64(n), _p(xyz), _p(act), _p(ctr), C.c_double(radius), C.c_int64(n), _p(out))
     return out[:int(cnt)]
+
+
+# ---- timing-only multi-core variant of one whole-structure pass (bench.py's extra CPU figure) -----------------------
+_omp_lib = None
+
+
+def pass_openmp(oc, cutoff=5.0, comp=0.1, include_sequence_adjacent=False, threads=0):
+    """One run_arpeggio pass of the C restatement with its cell loops spread over OpenMP threads (``threads`` = 0: all
+    cores): same searches, same per-pair evaluation, contacts kept in per-thread buffers.  Returns dict(candidates_6A,
+    pairs_6A, candidates, contacts, sift_checksum).  Not a checker: nothing is compared against it except its counts."""
+    global _omp_lib
+    if _omp_lib is None:
+        build()
+        _omp_lib = C.CDLL(os.path.join(_HERE, '_build', 'liborc_omp.so'))
+        _omp_lib.orc_pass_openmp.restype = C.c_int
+    st = np.zeros(5, np.int64)
+    rc = _omp_lib.orc_pass_openmp(C.byref(oc.s), C.c_double(cutoff), C.c_double(comp), C.c_int(int(include_sequence_adjacent)),
+                                  C.c_int(int(threads)), _p(st))
+    if rc != 0:
+        raise MemoryError('orc_pass_openmp failed')
+    return dict(candidates_6A=int(st[0]), pairs_6A=int(st[1]), candidates=int(st[2]), contacts=int(st[3]), sift_checksum=int(st[4]))

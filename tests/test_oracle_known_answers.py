@@ -222,3 +222,19 @@ def test_initialize_geometry_restatement_known_answers():
     c, n = ref_py.amide_geometry(am, [[0, 1, 2, 3]])
     assert c.dtype == np.float32 and np.allclose(c[0], [0.65, 0.1, 2.0], atol=1e-6)
     assert np.allclose(np.abs(n[0]), [0, 0, 1], atol=1e-5)
+
+
+def test_openmp_timing_variant_counts_what_the_oracle_counts():
+    """bench.py's multi-core CPU figure runs the same work: candidates, contacts and the SIFt checksum of
+    oracle.pass_openmp equal those of the single-thread restatement (whole-structure selection)."""
+    import numpy as np
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.config3(6000, seed=11)
+    oc = oracle.OracleComplex(pc)
+    oc.make_selection(None)
+    r = oc.atom_contacts()
+    for threads in (1, 3):
+        got = oracle.pass_openmp(oc, threads=threads)
+        assert got['candidates'] == int(r['stats'][0]) and got['contacts'] == len(r['i'])
+        assert got['sift_checksum'] == int(r['sift'].astype(np.int64).sum())
