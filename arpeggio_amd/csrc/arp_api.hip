@@ -114,6 +114,8 @@ struct arp_ctx {
     bool sel_made = false;
     bool sel_uploaded = false;   // arp_set_selection / arp_set_selection_state since the last arp_set_atoms
     bool sel_all = false;        // the uploaded selection covers every atom: selection_plus = selection, no expansion search
+    int64_t nsel = -1;            // selected atoms of the uploaded mask; their indices are in sel_list when nsel <= SMALL_SEL_MAX
+    DevBuf<int> sel_list;
     bool whole_structure = false; // caller's assertion (arp_set_whole_structure): the selection is the whole GLOBAL structure
     DevBuf<double> ring_c, ring_n;
     DevBuf<int> ring_res;
@@ -900,7 +902,7 @@ void arp_destroy(arp_ctx* c) {
     c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
-    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->tmp_i32.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
+    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
@@ -989,6 +991,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     c->has_gid = c->has_home = false;
     c->sel_made = false;
     c->sel_uploaded = false;   // a new structure starts with the default selection: everything (I:1395)
+    c->nsel = -1;
     c->sel_all = false;
     c->whole_structure = false;
     c->contacts_valid = false;
@@ -1176,6 +1179,7 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     CHK(upload(c, c->plus, in_plus, (size_t)c->n));
     c->sel_uploaded = true;
+    c->nsel = -1;
     c->sel_all = false;   // the caller's masks are taken as they are
     CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));
     CHK(upload(c, c->am_sel, amide_sel, (size_t)c->namide)); CHK(upload(c, c->am_plus, amide_plus, (size_t)c->namide));
@@ -1192,9 +1196,18 @@ int arp_set_selection(arp_ctx* c, const uint8_t* in_selection) {
     HIPCHK(c, hipSetDevice(c->device));
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     c->sel_uploaded = true;
-    c->sel_all = true;
+    // how many atoms are selected decides how selection_plus is computed (arp_run_launch): everything -> nothing to do,
+    // a handful -> direct test of every atom against the list (k_expand_small), otherwise the 6 A grid search
+    int64_t nsel = 0;
+    std::vector<int> list;
     for (int64_t i = 0; i < c->n; ++i)
-        if (!in_selection[i]) { c->sel_all = false; break; }
+        if (in_selection[i]) {
+            if (nsel < SMALL_SEL_MAX) list.push_back((int)i);
+            ++nsel;
+        }
+    c->nsel = nsel;
+    c->sel_all = (nsel == c->n);
+    if (nsel > 0 && nsel <= SMALL_SEL_MAX) CHK(upload(c, c->sel_list, list.data(), (size_t)nsel));
     c->sel_made = false;  // expansion pending
     c->all_grid_current = false;
     c->contacts_valid = false;
@@ -1467,8 +1480,20 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         // Whole-structure selection (the reference's default, I:1395 with no selectors): selection_plus is the
         // selection, so nothing on the contact path waits for _make_selection — the 6 A grid (still needed by the
         // atom-plane kernel) moves to stream2 with the rest of the ring / amide work.
-        const bool fork_early = c->sel_all;
+        // A small selection (ligand, binding site: nsel <= SMALL_SEL_MAX) gets selection_plus from a direct test of
+        // every atom against the selected ones — one short kernel — and then forks the same way.
+        // (worth it while the N x S direct tests stay below ~1.7e7: 160 selected atoms in a 100 k-atom structure)
+        const bool small_sel = !c->sel_all && c->nsel > 0 && c->nsel <= SMALL_SEL_MAX && c->n > 0 && !c->has_home &&
+                               c->n * c->nsel <= (int64_t)1 << 24;
+        const bool fork_early = c->sel_all || small_sel;
         if (!fork_early) CHK(enqueue_expansion(c, expand_radius));                  // I:342 (I:1384-1424)
+        if (small_sel) {
+            HIPCHK(c, c->plus.reserve((size_t)c->n));
+            Prof p(c, SLOT_MARK);
+            hipLaunchKernelGGL(k_expand_small, dim3(nblocks(c->n, 256, 1 << 22)), dim3(256), 0, c->stream, (int)c->n, c->xyz.p, c->sel_list.p,
+                               (int)c->nsel, c->sel.p, expand_radius * expand_radius, c->plus.p, c->d_ctr + C_STAT_MCAND);
+            CHK(check_launch(c, "k_expand_small"));
+        }
         // ring grids are built (once) on the main stream before the fork
         if (c->nring > 0) CHK(ensure_ring_grid(c));
         if (c->namide > 0) CHK(ensure_amide_grid(c));
@@ -1483,7 +1508,13 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         }
         CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
-        if (fork_early) CHK(enqueue_expansion(c, expand_radius, c->stream2));
+        if (c->sel_all) CHK(enqueue_expansion(c, expand_radius, c->stream2));
+        else if (small_sel) {
+            // selection_plus exists already: only the 6 A grid of the atom-plane kernel is still to be built
+            CHK(build_all_grid(c, expand_radius, nullptr, c->stream2));
+            c->contacts_valid = false;
+            c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
+        }
         CHK(enqueue_selection_sets(c, c->stream2));                                 // I:1413-1437
         CHK(enqueue_planes(c, c->stream2));                                         // I:346-347 (I:944-945, 1214-1215)
         HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));

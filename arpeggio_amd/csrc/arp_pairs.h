@@ -833,6 +833,49 @@ __global__ __launch_bounds__(256) void k_publish_counters(u64* __restrict__ ctr,
 }
 
 
+// _make_selection for SMALL selections (a ligand, a handful of residues: the reference's `-s /A/508/` use): selection_plus
+// = selection + every atom within `radius` of a selected atom (I:1420-1424; all atoms, hydrogens included) computed
+// directly — every atom against the list of selected atoms, staged through LDS — instead of a grid search over the
+// whole structure: no grid to build on the critical path and N x S exact float64 tests (Bio.PDB.kdtrees' inclusive
+// d^2 <= r^2) where S is a few dozen.  stats[0] += tests, stats[1] += atoms added.
+#define SMALL_SEL_MAX 1024
+__global__ __launch_bounds__(256) void k_expand_small(int n, const float4* __restrict__ xyz, const int* __restrict__ sel_list,
+                                                      int nsel, const uint8_t* __restrict__ sel, double r2,
+                                                      uint8_t* __restrict__ plus, u64* __restrict__ stats) {
+    __shared__ float4 s_sel[256];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const float4 v = live ? xyz[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
+    bool in = live && sel[i] != 0;
+    const bool was = in;
+    unsigned tests = 0;
+    for (int s0 = 0; s0 < nsel; s0 += 256) {
+        __syncthreads();
+        if (s0 + (int)threadIdx.x < nsel) s_sel[threadIdx.x] = xyz[sel_list[s0 + threadIdx.x]];
+        __syncthreads();
+        const int m = min(256, nsel - s0);
+        if (live && !in) {
+            for (int k = 0; k < m; ++k) {
+                const float4 q = s_sel[k];
+                ++tests;
+                if (num::dist2_kd(x, num::d3{(double)q.x, (double)q.y, (double)q.z}) <= r2) { in = true; break; }
+            }
+        }
+    }
+    if (live) plus[i] = in ? 1 : 0;
+    // statistics: one pair of atomics per block
+    __shared__ unsigned s_t[4], s_a[4];
+    unsigned t = tests, a = (in && !was) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); a += __shfl_xor(a, o); }
+    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = t; s_a[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0 && stats) {
+        atomicAdd(stats + (blockIdx.x & (STAT_SLOTS - 1)), (u64)(s_t[0] + s_t[1] + s_t[2] + s_t[3]));
+        atomicAdd(stats + STAT_SLOTS + (blockIdx.x & (STAT_SLOTS - 1)), (u64)(s_a[0] + s_a[1] + s_a[2] + s_a[3]));
+    }
+}
+
 // residue / ring / amide membership of _make_selection (interactions.py:1413-1437)
 __global__ __launch_bounds__(256) void k_res_mark(int n, const int* __restrict__ res_id, const uint8_t* __restrict__ sel,
                                                   const uint8_t* __restrict__ plus, uint8_t* __restrict__ res_sel,
