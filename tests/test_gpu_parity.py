@@ -749,3 +749,25 @@ def test_config4_two_million_atoms_sharded_equals_single_gpu(capi):
         o = np.lexsort((g[k2], g[k1]))
         assert np.array_equal(g[k1][o], refbag[k1]) and np.array_equal(g[k2][o], refbag[k2])
         assert np.array_equal(g['dist'][o], refbag['dist'])
+
+
+@pytest.mark.parametrize('n_sel_res', [1, 6, 100, 400])
+def test_run_launch_selection_plus_on_both_sides_of_the_small_selection_threshold(ctx, n_sel_res):
+    """arp_run_launch computes selection_plus three ways (whole structure: nothing; few atoms: k_expand_small; otherwise
+    the 6 A grid search): masks, ring / amide sets and contacts of each against the oracle."""
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.config3(30_000, seed=23)
+    sel = np.isin(pc.res_id, 37 + 11 * np.arange(n_sel_res)).astype(np.uint8)
+    ctx.set_complex(pc)
+    ctx.set_selection(sel)
+    counts = ctx.run_launch()
+    masks = ctx.make_selection_masks()
+    oc = oracle.OracleComplex(pc)
+    plus = oc.make_selection(sel)
+    assert np.array_equal(masks['plus'], plus)
+    assert np.array_equal(masks['ring_plus'], oc.ring_plus) and np.array_equal(masks['amide_plus'], oc.amide_plus)
+    assert np.array_equal(masks['ring_sel'], oc.ring_sel) and np.array_equal(masks['amide_sel'], oc.amide_sel)
+    _assert_contacts_equal(ctx.atom_contacts_fetch(counts['atom_atom']), oc.atom_contacts())
+    ap, eap = ctx.fetch_bag('atom_plane'), oc.atom_plane()
+    assert np.array_equal(ap['atom'], eap['atom']) and np.array_equal(ap['ring'], eap['ring']) and np.array_equal(ap['mask'], eap['mask'])
