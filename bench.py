@@ -321,6 +321,31 @@ def main():
         except Exception as exc:
             cpu_mc = {'error': repr(exc)}
 
+    # B1 of SURVEY 8d: the loop-structured Python / NumPy restatement (oracle/ref_py.py: interpreter-bound like the
+    # reference itself, which adds BioPython / OpenBabel object traffic on top) on a bounded 3000-atom sample
+    cpu_py = None
+    if cpu is not None and args.workload == 'config3':
+        try:
+            from oracle import ref_py
+            spy = synth.config3(3000, seed=3)
+            ocs = oracle.OracleComplex(spy)
+            ocs.make_selection(None)
+            cand_s = int(ocs.atom_contacts(args.cutoff, args.vdw_comp, False)['stats'][0])
+            rp = ref_py.RefPy(spy)
+            n_py, s_py, acc_py = 0, 0.0, 0
+            while s_py < 3.0 and n_py < 50:
+                t0 = time.perf_counter()
+                acc_py += len(rp.atom_contacts(args.cutoff, args.vdw_comp, False)['i'])
+                s_py += time.perf_counter() - t0
+                n_py += 1
+            cpu_py = {'value': round(cand_s * n_py / s_py, 1), 'unit': 'candidate atom-pairs/s', 'cores': 1, 'kind': 'port',
+                      'contacts_per_s': round(acc_py / s_py, 1),
+                      'sample': f'{n_py} passes of oracle/ref_py.py (Python loops + the reference\'s own NumPy calls per pair; vectorised '
+                                f'brute-force pair search) on a 3000-atom structure of the same density, {s_py:.1f} s; candidate pairs '
+                                f'counted as the grid search of the C restatement counts them'}
+        except Exception as exc:
+            cpu_py = {'error': repr(exc)}
+
     line = {
         'metric': 'evaluated atom-pairs/s', 'value': round(value, 1), 'unit': 'candidate atom-pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
@@ -338,6 +363,7 @@ def main():
         'roofline_all_kernels': roofline_all,
         'throughput_several_in_flight': in_flight,
         'cpu_baseline_all_cores': cpu_mc,
+        'cpu_baseline_python': cpu_py,
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
         'launch_mode': 'direct launches on two HIP streams, one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
