@@ -241,6 +241,11 @@ def test_many_random_small_structures(ctx):
         n = int(rng.integers(1, 500))
         box = float(rng.choice([3.0, 6.0, 9.5, 14.0, 22.0, 37.0, 80.0]))
         pc = random_dense_pack(1000 + case, n=max(n, 4), box=box)
+        if case % 5 == 2:      # duplicated coordinates
+            k = max(1, pc.n_atoms // 10)
+            pc.xyz[rng.integers(0, pc.n_atoms, k)] = pc.xyz[rng.integers(0, pc.n_atoms, k)]
+        elif case % 5 == 3:    # atoms on a 1.25 A lattice: many equal distances, pairs exactly at the cut-offs
+            pc.xyz = (np.round(pc.xyz / 1.25) * 1.25).astype(np.float32)
         sel = None if case % 3 == 0 else (rng.random(pc.n_atoms) < rng.choice([0.02, 0.3, 0.9])).astype(np.uint8)
         if sel is not None and sel.sum() == 0:
             sel[int(rng.integers(0, pc.n_atoms))] = 1
