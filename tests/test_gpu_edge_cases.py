@@ -307,3 +307,58 @@ def test_two_contexts_on_two_host_threads(capi):
         for f in ('i', 'j', 'sift', 'ctype'):
             assert np.array_equal(results[t][1][f], lone[t][1][f]), (t, f)
         assert np.array_equal(results[t][1]['dist'].view(np.uint32), lone[t][1]['dist'].view(np.uint32))
+
+
+def test_random_ring_and_amide_sets(ctx):
+    """40 random ring / amide sets on random soups — coincident centres, zero normals (NaN angles -> class ''), rings
+    without a residue, whole and partial selections — through arp_run_launch: ids, classes, masks and contact types
+    exactly, distances and angles within 2e-4 (acos differs by an ulp between the two libms)."""
+    import oracle
+    from helpers import random_dense_pack
+    rng = np.random.default_rng(99)
+
+    def close(a, b, tol=2e-4):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and (np.nan_to_num(np.abs(a - b)) <= tol).all()
+
+    bags = (('plane_plane', ('bgn', 'end'), ('bgn', 'end', 'type1', 'type2', 'ctype'), ('dist', 'dihedral', 'theta_bgn', 'theta_end')),
+            ('atom_plane', ('ring', 'atom'), ('atom', 'ring', 'mask', 'ctype'), ('dist', 'theta')),
+            ('group_group', ('bgn', 'end'), ('bgn', 'end', 'ctype'), ('dist', 'dihedral', 'theta')),
+            ('group_plane', ('amide', 'ring'), ('amide', 'ring', 'ctype'), ('dist', 'dihedral', 'theta')))
+    records = 0
+    for case in range(40):
+        nr, na = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        box = float(rng.choice([4.0, 9.0, 20.0, 45.0]))
+        pc = random_dense_pack(9000 + case, n=int(rng.integers(50, 600)), box=box)
+        rc, rn = rng.random((nr, 3)) * box, rng.standard_normal((nr, 3))
+        ac, an = (rng.random((na, 3)) * box).astype(np.float32), rng.standard_normal((na, 3)).astype(np.float32)
+        if case % 4 == 1:
+            rc[rng.integers(0, nr, max(1, nr // 5))] = rc[rng.integers(0, nr, max(1, nr // 5))]
+            rn[rng.integers(0, nr, max(1, nr // 8))] = 0.0
+        if case % 4 == 2:
+            an[rng.integers(0, na, max(1, na // 8))] = 0.0
+        pc.ring_center, pc.ring_normal = rc, rn
+        pc.ring_res = rng.integers(-1, pc.n_residues, nr).astype(np.int32)
+        pc.ring_atoms = []
+        pc.amide_center, pc.amide_normal = ac, an
+        pc.amide_res = rng.integers(-1, pc.n_residues, na).astype(np.int32)
+        pc.amide_atoms = np.full((na, 4), -1, np.int32)
+        sel = None if case % 3 == 0 else (rng.random(pc.n_atoms) < 0.3).astype(np.uint8)
+        if sel is not None and sel.sum() == 0:
+            sel[0] = 1
+        ctx.set_complex(pc)
+        if sel is not None:
+            ctx.set_selection(sel)
+        ctx.run_launch()
+        oc = oracle.OracleComplex(pc)
+        oc.make_selection(sel, use_grid=False)
+        for name, order, exact, tol in bags:
+            g, e = ctx.fetch_bag(name), getattr(oc, name)()
+            assert len(g[exact[0]]) == len(e[exact[0]]), (case, name)
+            o = np.lexsort((e[order[1]], e[order[0]]))
+            for k in exact:
+                assert np.array_equal(g[k], e[k][o]), (case, name, k)
+            for k in tol:
+                assert close(g[k], e[k][o]), (case, name, k)
+            records += len(o)
+    assert records > 20_000
