@@ -771,3 +771,82 @@ def test_run_launch_selection_plus_on_both_sides_of_the_small_selection_threshol
     _assert_contacts_equal(ctx.atom_contacts_fetch(counts['atom_atom']), oc.atom_contacts())
     ap, eap = ctx.fetch_bag('atom_plane'), oc.atom_plane()
     assert np.array_equal(ap['atom'], eap['atom']) and np.array_equal(ap['ring'], eap['ring']) and np.array_equal(ap['mask'], eap['mask'])
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_staged_protocol_between_contexts_on_one_gpu(capi, world):
+    """The general sharded protocol (partial selection) with real data flow on one GPU: one context per shard,
+    arp_run_stage 0 / 1 / 2, and between the stages exactly what DeviceExchange does over RCCL — every shard's halo atoms
+    take their selection_plus bit from the owner's buffer, the residue sets are OR-ed over the shards — here with torch
+    tensors aliasing the contexts' device buffers.  The union of what the shards own == the single-context result."""
+    import torch
+    from arpeggio_amd import sharding, synth
+    full = synth.slab_config(6000, 3, seed=8)
+    rng = np.random.default_rng(11)
+    sel = np.zeros(full.n_atoms, np.uint8)
+    sel[np.isin(full.res_id, rng.choice(full.n_residues, full.n_residues // 12, replace=False))] = 1
+    c0 = capi.Context(0)
+    c0.set_complex(full)
+    c0.set_selection(sel)
+    k0 = c0.run_launch()
+    ref = c0.atom_contacts_fetch(k0['atom_atom'])
+    names = ('plane_plane', 'atom_plane', 'group_group', 'group_plane')
+    ref_bags = {k: c0.fetch_bag(k) for k in names}
+    c0.close()
+
+    class Alias:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
+
+    def alias(c, which):
+        ptr, nb = c.device_buffer(which)
+        return torch.as_tensor(Alias(ptr, nb), device='cuda:0')
+
+    shards = [sharding.make_shard_local(full, r, world, sel) for r in range(world)]
+    ctxs = [capi.Context(0) for _ in range(world)]
+    for c, sh in zip(ctxs, shards):
+        sharding.upload_shard(c, sh)
+        c.run_stage(0)
+    torch.cuda.synchronize()
+    plus = [alias(c, c.BUF_PLUS) for c in ctxs]
+    moves = []
+    for r, sh in enumerate(shards):
+        for side in (-1, +1):
+            nb = r + side
+            if 0 <= nb < world:
+                ids = shards[nb].send_right if side == -1 else shards[nb].send_left      # what the neighbour sends towards r
+                src = torch.from_numpy(sharding._lookup(shards[nb].global_id, ids).astype(np.int64)).cuda()
+                dst = torch.from_numpy(np.nonzero(sh.origin == side)[0].astype(np.int64)).cuda()
+                assert len(src) == len(dst)
+                moves.append((r, dst, plus[nb][src].clone()))
+    for r, dst, bits in moves:
+        plus[r][dst] = bits
+    torch.cuda.synchronize()
+    for c in ctxs:
+        c.run_stage(1)
+    torch.cuda.synchronize()
+    res = [alias(c, c.BUF_RES_SETS) for c in ctxs]
+    merged = torch.stack(res).max(0).values
+    for t in res:
+        t.copy_(merged)
+    torch.cuda.synchronize()
+    parts, bags = [], {k: [] for k in names}
+    for c in ctxs:
+        k = c.run_stage(2)
+        parts.append(c.atom_contacts_fetch(k['atom_atom'], sort=False))
+        for b in names:
+            bags[b].append(c.fetch_bag(b))
+    for c in ctxs:
+        c.close()
+    got = {f: np.concatenate([p[f] for p in parts]) for f in ('i', 'j', 'dist', 'sift', 'ctype')}
+    o = np.lexsort((got['j'], got['i']))
+    _assert_contacts_equal({f: v[o] for f, v in got.items()}, ref)
+    order = {'plane_plane': ('bgn', 'end'), 'atom_plane': ('ring', 'atom'), 'group_group': ('bgn', 'end'), 'group_plane': ('amide', 'ring')}
+    for b, (k1, k2) in order.items():
+        g = {f: np.concatenate([x[f] for x in bags[b]]) for f in ref_bags[b]}
+        o = np.lexsort((g[k2], g[k1]))
+        for f in ref_bags[b]:
+            a, e = g[f][o], ref_bags[b][f]
+            assert np.array_equal(a, e) or (a.dtype.kind == 'f' and np.array_equal(np.isnan(a), np.isnan(e))
+                                            and np.array_equal(a[~np.isnan(a)], e[~np.isnan(e)])), (b, f)
+    assert len(ref['i']) > 5_000 and len(ref_bags['plane_plane']['bgn']) > 0
