@@ -270,7 +270,7 @@ def main():
 
     # ---------------- CPU baseline: the C oracle on one host core, bounded sample ----------------
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # (rank 0 at N = 1 only, as the bench contract says)
         import oracle
         ns = min(args.cpu_sample_atoms, args.atoms)
         spc = synth.config3(ns, seed=3) if (world > 1 or (ns != args.atoms and args.workload == 'config3')) else pc
