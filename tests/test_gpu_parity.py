@@ -777,9 +777,10 @@ def test_run_launch_selection_plus_on_both_sides_of_the_small_selection_threshol
 def test_staged_protocol_between_contexts_on_one_gpu(capi, world):
     """The general sharded protocol (partial selection) with real data flow on one GPU: one context per shard,
     arp_run_stage 0 / 1 / 2, and between the stages exactly what DeviceExchange does over RCCL — every shard's halo atoms
-    take their selection_plus bit from the owner's buffer, the residue sets are OR-ed over the shards — here with torch
-    tensors aliasing the contexts' device buffers.  The union of what the shards own == the single-context result."""
-    import torch
+    take their selection_plus bit from the owner's buffer, the residue sets are OR-ed over the shards — here with plain
+    hipMemcpy on the contexts' device buffers (arp_device_buffer; torch is not used: its bundled HIP runtime cannot be
+    initialised after the system one the library runs on).  The union of what the shards own == the single-context result."""
+    import ctypes
     from arpeggio_amd import sharding, synth
     full = synth.slab_config(6000, 3, seed=8)
     rng = np.random.default_rng(11)
@@ -794,42 +795,47 @@ def test_staged_protocol_between_contexts_on_one_gpu(capi, world):
     ref_bags = {k: c0.fetch_bag(k) for k in names}
     c0.close()
 
-    class Alias:
-        def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
+    hip = ctypes.CDLL('libamdhip64.so')
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipDeviceSynchronize.argtypes = []
 
-    def alias(c, which):
+    def read(c, which):
         ptr, nb = c.device_buffer(which)
-        return torch.as_tensor(Alias(ptr, nb), device='cuda:0')
+        out = np.empty(nb, np.uint8)
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), nb, 2) == 0      # device -> host
+        return out
+
+    def write(c, which, arr):
+        ptr, nb = c.device_buffer(which)
+        arr = np.ascontiguousarray(arr, np.uint8)
+        assert arr.size == nb
+        assert hip.hipMemcpy(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), nb, 1) == 0      # host -> device
 
     shards = [sharding.make_shard_local(full, r, world, sel) for r in range(world)]
     ctxs = [capi.Context(0) for _ in range(world)]
     for c, sh in zip(ctxs, shards):
         sharding.upload_shard(c, sh)
         c.run_stage(0)
-    torch.cuda.synchronize()
-    plus = [alias(c, c.BUF_PLUS) for c in ctxs]
-    moves = []
+    assert hip.hipDeviceSynchronize() == 0
+    plus = [read(c, c.BUF_PLUS) for c in ctxs]
+    new_plus = [p.copy() for p in plus]
     for r, sh in enumerate(shards):
         for side in (-1, +1):
             nb = r + side
             if 0 <= nb < world:
                 ids = shards[nb].send_right if side == -1 else shards[nb].send_left      # what the neighbour sends towards r
-                src = torch.from_numpy(sharding._lookup(shards[nb].global_id, ids).astype(np.int64)).cuda()
-                dst = torch.from_numpy(np.nonzero(sh.origin == side)[0].astype(np.int64)).cuda()
+                src = sharding._lookup(shards[nb].global_id, ids)
+                dst = np.nonzero(sh.origin == side)[0]
                 assert len(src) == len(dst)
-                moves.append((r, dst, plus[nb][src].clone()))
-    for r, dst, bits in moves:
-        plus[r][dst] = bits
-    torch.cuda.synchronize()
+                new_plus[r][dst] = plus[nb][src]
+    for c, p_ in zip(ctxs, new_plus):
+        write(c, c.BUF_PLUS, p_)
     for c in ctxs:
         c.run_stage(1)
-    torch.cuda.synchronize()
-    res = [alias(c, c.BUF_RES_SETS) for c in ctxs]
-    merged = torch.stack(res).max(0).values
-    for t in res:
-        t.copy_(merged)
-    torch.cuda.synchronize()
+    assert hip.hipDeviceSynchronize() == 0
+    merged = np.maximum.reduce([read(c, c.BUF_RES_SETS) for c in ctxs])
+    for c in ctxs:
+        write(c, c.BUF_RES_SETS, merged)
     parts, bags = [], {k: [] for k in names}
     for c in ctxs:
         k = c.run_stage(2)
