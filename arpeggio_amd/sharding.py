@@ -354,6 +354,15 @@ class DeviceExchange:
 
     def __init__(self, ctx, sh: Shard, dist, device, share_stream: bool = True):
         import torch
+        if device is not None and getattr(device, 'type', '') == 'cuda':
+            try:
+                torch.cuda.init()
+            except RuntimeError as exc:
+                # PyTorch-ROCm ships its own HIP runtime; it cannot start once the system runtime (which
+                # libarpeggio_hip.so binds to when it is loaded first) owns the process
+                raise RuntimeError('torch could not initialise the GPU in this process: import torch and touch the device '
+                                   '(torch.cuda.set_device) BEFORE the first arpeggio_amd Context is created, as bench.py '
+                                   'does') from exc
         self.torch, self.ctx, self.sh, self.dist, self.device = torch, ctx, sh, dist, device
         self.t_plus = self.t_res = None
         self._keep = []
