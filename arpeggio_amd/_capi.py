@@ -29,7 +29,7 @@ SYMBOLS = (
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
     'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
-    'arp_host_alloc', 'arp_host_free',
+    'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts',
 )
 
 _lib = None
@@ -72,6 +72,7 @@ def load():
     L.arp_set_ownership.argtypes = [vp, vp, vp]
     L.arp_set_selection.argtypes = [vp, vp]
     L.arp_atom_accumulators.argtypes = [vp, vp, vp]
+    L.arp_atom_integer_sifts.argtypes = [vp, vp]
     L.arp_device_buffer.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.arp_run_stage.argtypes = [vp, i32, dbl, dbl, i32, dbl, vp]
     L.arp_set_group_ownership.argtypes = [vp, vp, vp, vp, vp]
@@ -314,6 +315,13 @@ class Context:
         cnt = np.zeros((max(self.n, 1), 8), np.int32)
         self._check(self._L.arp_atom_accumulators(self._h, _p(sift), _p(cnt)), 'arp_atom_accumulators')
         return dict(sift=sift[:self.n], counts=cnt[:self.n])
+
+    def atom_integer_sifts(self):
+        """update_atom_integer_sift (U:224-242) under the canonical pair order: uint8 [n, 4, 15] =
+        integer_sift / _inter_only / _intra_only / _water_only of the last contact launch."""
+        out = np.zeros((max(self.n, 1), 4, 15), np.uint8)
+        self._check(self._L.arp_atom_integer_sifts(self._h, _p(out)), 'arp_atom_integer_sifts')
+        return out[:self.n]
 
     # ---- ring / amide contacts ----
     def fetch_bag(self, name):

@@ -1,37 +1,61 @@
 """Exception classes of the drop-in API.
 
-Same names and the same "log on construction" convention as the reference
-(arpeggio/core/exceptions.py:6-38).
+The reference's error convention (arpeggio/core/exceptions.py:6-38) is part of the boundary: five exception
+types, each of which writes one ``logging.error`` line when it is constructed and never calls
+``Exception.__init__`` (``e.args`` is what ``BaseException.__new__`` stored: the constructor arguments).  Here that
+convention lives in one base class; the subclasses only say what to log.
 """
 import logging
 
 
-class HydrogenError(Exception):
+class ArpeggioError(Exception):
+    """Logs ``describe(*args)`` on construction."""
+    message = ''
+
+    def __init__(self, *args):
+        logging.error(self.describe(*args))
+
+    def describe(self, *args):
+        return self.message
+
+
+class HydrogenError(ArpeggioError):
+    message = 'Please remove all hydrogens from the structure then re-run.'
+
     def __init__(self):
-        logging.error('Please remove all hydrogens from the structure then re-run.')
+        ArpeggioError.__init__(self)
 
 
-class OBBioMatchError(Exception):
+class AtomSerialError(ArpeggioError):
+    message = 'One or more atom serial numbers are duplicated.'
+
+    def __init__(self):
+        ArpeggioError.__init__(self)
+
+
+class SiftMatchError(ArpeggioError):
+    message = 'Seeing is not believing.'
+
+    def __init__(self):
+        ArpeggioError.__init__(self)
+
+
+class OBBioMatchError(ArpeggioError):
     def __init__(self, serial=''):
-        if not serial:
-            logging.error('An OpenBabel atom could not be matched to a BioPython counterpart.')
-        else:
-            logging.error(f'OpenBabel OBAtom with serial number {serial} could not be matched to a BioPython counterpart.')
+        ArpeggioError.__init__(self, serial)
+
+    def describe(self, serial):
+        if serial:
+            return f'OpenBabel OBAtom with serial number {serial} could not be matched to a BioPython counterpart.'
+        return 'An OpenBabel atom could not be matched to a BioPython counterpart.'
 
 
-class AtomSerialError(Exception):
-    def __init__(self):
-        logging.error('One or more atom serial numbers are duplicated.')
-
-
-class SiftMatchError(Exception):
-    def __init__(self):
-        logging.error('Seeing is not believing.')
-
-
-class SelectionError(Exception):
+class SelectionError(ArpeggioError):
     def __init__(self, selection):
-        logging.error(f'Invalid selector: {selection}')
+        ArpeggioError.__init__(self, selection)
+
+    def describe(self, selection):
+        return f'Invalid selector: {selection}'
 
 
 class NativeLibraryError(RuntimeError):

@@ -1,0 +1,277 @@
+"""Host-side export of the result bags: the JSON records of ``get_contacts`` and the legacy CSV tables.
+
+Everything here works on the struct-of-arrays bags the HIP library returns (one NumPy array per column) and on the
+string tables of the PackedComplex; no per-contact Python objects are built on the way.  The output is what the
+reference's ``get_contacts`` (interactions.py:172-212, 2063-2113) and ``write_*`` methods (interactions.py:135-170,
+349-366, 405-466 with ``_calc_residue_sifts`` 471-574) produce, and is pinned byte for byte against the text those
+methods wrote when executed on the same structure (tests/golden/core_exports.json.gz).
+
+Order of records inside a bag: atom-atom by (bgn, end) packed index with bgn = the lower one (the canonical order of
+this library; the reference's own order is its KD-tree's), the plane bags by (bgn id, end id) — the reference's creation
+order.  Tables that the reference writes by iterating a ``set`` (atom sifts, residue sifts, polar matching) come out in
+packed atom / residue order.
+"""
+from __future__ import annotations
+
+import csv
+import os
+
+import numpy as np
+
+from . import config
+
+_SIFT_FLAG_COLUMNS = ('clash', 'covalent', 'vdw_clash', 'vdw', 'proximal', 'hbond', 'weak_hbond', 'halogen_bond', 'ionic',
+                      'metal_complex', 'aromatic', 'hydrophobic', 'carbonyl', 'polar', 'weak_polar')
+_CLASS_PREFIX = ('', 'inter_only_', 'intra_only_', 'water_only_')
+_PI_COLUMNS = ('carbonpi', 'cationpi', 'donorpi', 'halogenpi', 'metsulphurpi')
+_BS_CONTACT_TYPES = ('INTER', 'INTRA_SELECTION', 'SELECTION_WATER', 'WATER_WATER')      # interactions.py:166
+
+
+def residue_sift_header():
+    """Column names of '<id>_residue_sifts.csv' (config.py:714-1141 of the reference: 426 names, regular)."""
+    h = ['residue', 'is_polypeptide']
+    for integer in ('', 'integer_'):
+        for part in ('', 'mc_', 'sc_'):
+            for cls in _CLASS_PREFIX:
+                h += [f'residue_{part}{integer}{cls}{flag}' for flag in _SIFT_FLAG_COLUMNS]
+    for integer in ('', 'integer_'):
+        h += [f'residue_ring_ring_inter_{integer}{t}' for t in config.PLANE_PLANE_NAMES[:9]]
+        for who in ('ring_atom', 'atom_ring', 'mc_atom_ring', 'sc_atom_ring'):
+            h += [f'residue_{who}_inter_{integer}{t}' for t in _PI_COLUMNS]
+    for integer in ('', '_integer'):
+        h += [f'residue_{who}_inter{integer}' for who in ('amide_ring', 'ring_amide', 'amide_amide')]
+    return h
+
+
+class Labels:
+    """Per-atom / per-residue strings of a PackedComplex, computed once per structure."""
+
+    def __init__(self, pc, component_types):
+        pc.ensure_labels()
+        self.pc = pc
+        nr = pc.n_residues
+        seq = [int(x) for x in pc.res_seq]
+        self.res_json = [(pc.res_name[r], seq[r], pc.res_chain[r], pc.res_icode[r]) for r in range(nr)]
+        self.res_comp_type = [component_types[pc.res_name[r]] for r in range(nr)] if nr else []   # KeyError like I:186
+        self.res_macro = ['{}/{}/'.format(pc.res_chain[r], seq[r] if pc.res_icode[r] == ' ' else str(seq[r]) + pc.res_icode[r])
+                          for r in range(nr)]
+        self.atom_res = pc.res_id.tolist()
+        self.atom_name = list(pc.atom_name)
+
+    def atom_macro(self, i):
+        return self.res_macro[self.atom_res[i]] + self.atom_name[i]
+
+    def atom_dict(self, i):
+        n, s, c, ic = self.res_json[self.atom_res[i]]
+        return {'label_comp_id': n, 'auth_seq_id': s, 'auth_asym_id': c, 'auth_atom_id': self.atom_name[i],
+                'pdbx_PDB_ins_code': ic, 'label_comp_type': self.res_comp_type[self.atom_res[i]]}
+
+    def plane_dict(self, r, atom_ids):
+        if r < 0:
+            raise TypeError('Cannot make a json object from non-Atom/Residue object.')   # ring without residue (I:1479; U:563)
+        n, s, c, ic = self.res_json[r]
+        return {'label_comp_id': n, 'auth_seq_id': s, 'auth_asym_id': c, 'pdbx_PDB_ins_code': ic,
+                'label_comp_type': self.res_comp_type[r], 'auth_atom_id': atom_ids}
+
+
+def ring_atom_ids(pc, r):
+    """Comma-joined sorted atom names of a ring (interactions.py:1059, 2078)."""
+    return ','.join(sorted(pc.atom_name[a] for a in pc.ring_atoms[r])) if pc.ring_atoms else ''
+
+
+def amide_atom_ids(pc, a):
+    return ','.join(sorted(pc.atom_name[i] for i in pc.amide_atoms[a] if i >= 0))
+
+
+def rounded(dist):
+    """``round(np.float64(d), 2)`` of every element (NumPy's rint(x * 100) / 100, as np.float64.__round__ does)."""
+    return np.round(np.asarray(dist, np.float64), 2).tolist()
+
+
+def contacts_json(pc, bags, component_types):
+    """The list ``get_contacts`` returns (interactions.py:172-212)."""
+    lab = Labels(pc, component_types)
+    out = []
+    b = bags.get('atom_atom')
+    if b is not None and len(b['i']):
+        used = np.unique(np.concatenate([b['i'], b['j']]))
+        adict = {int(a): lab.atom_dict(int(a)) for a in used.tolist()}
+        names = {int(s): [n for k, n in enumerate(config.SIFT_NAMES) if (int(s) >> k) & 1] for s in np.unique(b['sift']).tolist()}
+        ct = config.CONTACT_TYPE_NAMES
+        out += [{'bgn': dict(adict[i]), 'end': dict(adict[j]), 'type': 'atom-atom', 'distance': d, 'contact': list(names[s]),
+                 'interacting_entities': ct[c]}
+                for i, j, d, s, c in zip(b['i'].tolist(), b['j'].tolist(), rounded(b['dist']), b['sift'].tolist(), b['ctype'].tolist())]
+
+    ring_ids, amide_ids = {}, {}
+
+    def ring(r):
+        if r not in ring_ids:
+            ring_ids[r] = (int(pc.ring_res[r]), ring_atom_ids(pc, r))
+        return lab.plane_dict(*ring_ids[r])
+
+    def amide(a):
+        if a not in amide_ids:
+            amide_ids[a] = (int(pc.amide_res[a]), amide_atom_ids(pc, a))
+        return lab.plane_dict(*amide_ids[a])
+
+    ct = config.CONTACT_TYPE_NAMES
+    b = bags.get('plane_plane')
+    if b is not None and len(b['bgn']):
+        pp = config.PLANE_PLANE_NAMES
+        for r1, r2, d, t1, t2, c in zip(b['bgn'].tolist(), b['end'].tolist(), rounded(b['dist']), b['type1'].tolist(),
+                                        b['type2'].tolist(), b['ctype'].tolist()):
+            out.append({'bgn': ring(r1), 'end': ring(r2), 'type': 'plane-plane', 'distance': d,
+                        'contact': [pp[t1]] + ([pp[t2]] if t2 < config.PP_SAME else []), 'interacting_entities': ct[c]})
+    b = bags.get('atom_plane')
+    if b is not None and len(b['atom']):
+        ap = config.ATOM_PLANE_NAMES
+        for a, r, d, m, c in zip(b['atom'].tolist(), b['ring'].tolist(), rounded(b['dist']), b['mask'].tolist(), b['ctype'].tolist()):
+            out.append({'bgn': lab.atom_dict(a), 'end': ring(r), 'type': 'atom-plane', 'distance': d,
+                        'contact': [n for k, n in enumerate(ap) if (m >> k) & 1], 'interacting_entities': ct[c]})
+    b = bags.get('group_group')
+    if b is not None and len(b['bgn']):
+        for a1, a2, d, c in zip(b['bgn'].tolist(), b['end'].tolist(), rounded(b['dist']), b['ctype'].tolist()):
+            out.append({'bgn': amide(a1), 'end': amide(a2), 'type': 'group-group', 'distance': d, 'contact': ['AMIDEAMIDE'],
+                        'interacting_entities': ct[c]})
+    b = bags.get('group_plane')
+    if b is not None and len(b['amide']):
+        for a, r, d, c in zip(b['amide'].tolist(), b['ring'].tolist(), rounded(b['dist']), b['ctype'].tolist()):
+            out.append({'bgn': amide(a), 'end': ring(r), 'type': 'group-plane', 'distance': d, 'contact': ['AMIDERING'],
+                        'interacting_entities': ct[c]})
+    return out
+
+
+def _writer(path):
+    fh = open(path, 'w')
+    return fh, csv.writer(fh, delimiter=',', quotechar='"', quoting=csv.QUOTE_MINIMAL)
+
+
+_CONTACT_HEADER = ['atom_bgn', 'atom_end', 'distance'] + list(config.SIFT_NAMES) + ['interacting_entities']
+
+
+def write_contact_file(path, pc, lab, bag, rows=None):
+    """One '<id>_contacts.csv' style table (interactions.py:606-641); ``rows`` = optional index subset."""
+    bits = ((bag['sift'][:, None] >> np.arange(15, dtype=np.uint16)[None, :]) & 1).astype(np.uint8)
+    idx = range(len(bag['i'])) if rows is None else rows.tolist()
+    i, j, c = bag['i'].tolist(), bag['j'].tolist(), bag['ctype'].tolist()
+    dist = bag['dist']      # float32 scalars print with their shortest representation, as the reference's np.float32 does
+    fh, w = _writer(path)
+    with fh:
+        w.writerow(_CONTACT_HEADER)
+        w.writerows([lab.atom_macro(i[k]), lab.atom_macro(j[k]), dist[k]] + bits[k].tolist() + [config.CONTACT_TYPE_NAMES[c[k]]]
+                    for k in idx)
+
+
+def write_contacts(wd, sid, pc, bag, component_types, selection_given):
+    """interactions.py:151-170: '<id>_contacts.csv' and, when a selection was given, '<id>_bs_contacts.csv'."""
+    lab = Labels(pc, component_types)
+    write_contact_file(os.path.join(wd, sid + '_contacts.csv'), pc, lab, bag)
+    if not selection_given:
+        return
+    keep = np.isin(bag['ctype'], [config.CONTACT_TYPE_NAMES.index(t) for t in _BS_CONTACT_TYPES])
+    write_contact_file(os.path.join(wd, sid + '_bs_contacts.csv'), pc, lab, bag, np.nonzero(keep)[0])
+
+
+def write_atom_types(wd, sid, pc, component_types):
+    """interactions.py:135-149: every atom with the sorted list of its type names."""
+    lab = Labels(pc, component_types)
+    names = config.ATOM_TYPE_NAMES
+    cache = {}
+    fh, w = _writer(os.path.join(wd, sid + '_atomtypes.csv'))
+    with fh:
+        w.writerow(['atom', 'atom_types'])
+        for i, m in enumerate(pc.type_mask.tolist()):
+            if m not in cache:
+                cache[m] = sorted(n for b, n in enumerate(names) if (m >> b) & 1)
+            w.writerow([lab.atom_macro(i), cache[m]])
+
+
+def residue_sift_table(pc, atom_sift_bits, atom_isift, plane_sifts):
+    """`_calc_residue_sifts` (interactions.py:471-574) as arrays: dict name -> int array [n_residues, width]; the order of
+    the names is the column order of write_residue_sifts (interactions.py:448-464)."""
+    nr = pc.n_residues
+    rid = np.asarray(pc.res_id, np.int64)
+    poly = (np.asarray(pc.res_flags) & config.R_POLYPEPTIDE) != 0
+    mc = np.asarray([n in config.MAINCHAIN_ATOMS for n in pc.atom_name], bool) if pc.n_atoms else np.zeros(0, bool)
+    rows = {'': np.ones(pc.n_atoms, bool), 'mc_': mc & poly[rid], 'sc_': ~mc & poly[rid]}
+    isift = atom_isift.astype(np.int64)                     # [n, 4, 15]
+    integer = {}
+    for part, sel in rows.items():
+        acc = np.zeros((nr, 4, 15), np.int64)
+        np.add.at(acc, rid[sel], isift[sel])
+        for k, cls in enumerate(_CLASS_PREFIX):
+            integer[part + 'integer_sift' + ('_' + cls[:-1] if cls else '')] = acc[:, k, :]
+    out = {}
+    for part in ('', 'mc_', 'sc_'):                         # binary: flatten of the integer ones (I:493-496, 553-561)
+        for cls in ('', '_inter_only', '_intra_only', '_water_only'):
+            out[part + 'sift' + cls] = (integer[part + 'integer_sift' + cls] != 0).astype(np.int64)
+    for part in ('', 'mc_', 'sc_'):
+        for cls in ('', '_inter_only', '_intra_only', '_water_only'):
+            out[part + 'integer_sift' + cls] = integer[part + 'integer_sift' + cls]
+    ring_names = ('ring_ring_inter', 'ring_atom_inter', 'atom_ring_inter', 'mc_atom_ring_inter', 'sc_atom_ring_inter')
+    for nme in ring_names:
+        out[nme + '_sift'] = (plane_sifts[nme + '_integer_sift'] != 0).astype(np.int64)
+    for nme in ring_names:
+        out[nme + '_integer_sift'] = plane_sifts[nme + '_integer_sift']
+    amide_names = ('amide_ring_inter', 'ring_amide_inter', 'amide_amide_inter')
+    for nme in amide_names:
+        out[nme + '_sift'] = (plane_sifts[nme + '_integer_sift'] != 0).astype(np.int64)
+    for nme in amide_names:
+        out[nme + '_integer_sift'] = plane_sifts[nme + '_integer_sift']
+    return out
+
+
+def write_residue_sifts(wd, sid, pc, component_types, residues, table):
+    """interactions.py:435-466: one row per residue of selection_plus."""
+    lab = Labels(pc, component_types)
+    mat = np.concatenate([table[k] for k in table], axis=1)
+    poly = ((np.asarray(pc.res_flags) & config.R_POLYPEPTIDE) != 0).tolist()
+    fh, w = _writer(os.path.join(wd, sid + '_residue_sifts.csv'))
+    with fh:
+        w.writerow(residue_sift_header())
+        w.writerows([lab.res_macro[r], poly[r]] + mat[r].tolist() for r in np.asarray(residues).tolist())
+
+
+def potential_counts(pc):
+    """atom.potential_hbonds == atom.potential_polars as `_initialize_atom_sift` leaves them (interactions.py:1780-1816):
+    acceptors add their lone pairs (``lone_pair_electrons / 2`` — a float — unless the electron count is 0), donors their
+    bound hydrogens.  Python numbers, int or float exactly as the reference's arithmetic yields them."""
+    T = config.ATOM_TYPE_BIT
+    nh = np.diff(pc.h_off).tolist()
+    lone = pc.lone_pair_electrons.tolist()
+    out = []
+    for m, h, lp in zip(pc.type_mask.tolist(), nh, lone):
+        v = 0
+        if m & T['hbond acceptor']:
+            v = v + (lp / 2 if lp != 0 else lp)
+        if m & T['hbond donor']:
+            v = v + h
+        out.append(v)
+    return out
+
+
+def potential_fsift(pc):
+    """atom.potential_fsift (interactions.py:1795-1852) as 10-bit masks (bit k = FEATURE_SIFT[k])."""
+    T = config.ATOM_TYPE_BIT
+    m = pc.type_mask.astype(np.uint32)
+    hal = (pc.flags & config.F_HALOGEN) != 0
+    met = (pc.flags & config.F_METAL) != 0
+    has = lambda *names: (m & sum(T[n] for n in names)) != 0     # noqa: E731
+    hb = has('hbond acceptor', 'hbond donor')
+    weak = has('weak hbond acceptor', 'weak hbond donor', 'hbond donor', 'hbond acceptor') | hal
+    cols = (hb, weak, has('xbond acceptor', 'xbond donor'), has('pos ionisable', 'neg ionisable'), has('hbond acceptor') | met,
+            has('aromatic'), has('hydrophobe'), has('carbonyl oxygen', 'carbonyl carbon'), hb, weak)
+    return sum(c.astype(np.uint16) << k for k, c in enumerate(cols)).astype(np.uint16)
+
+
+def write_polar_matching(wd, sid, pc, component_types, atoms, counts):
+    """interactions.py:405-433: '<id>_polarmatch.csv' and '<id>_specific_polarmatch.csv' (no header rows)."""
+    lab = Labels(pc, component_types)
+    pot = potential_counts(pc)
+    c = counts.tolist()      # [hbonds, hbonds_intra, hbonds_inter, hbonds_water, polars, polars_intra, polars_inter, polars_water]
+    fa, wa = _writer(os.path.join(wd, sid + '_polarmatch.csv'))
+    fs, ws = _writer(os.path.join(wd, sid + '_specific_polarmatch.csv'))
+    with fa, fs:
+        for i in np.asarray(atoms).tolist():
+            wa.writerow([lab.atom_macro(i), pot[i], pot[i], c[i][0], c[i][4]])
+            ws.writerow([lab.atom_macro(i), pot[i], pot[i], c[i][2], c[i][1], c[i][3], c[i][6], c[i][5], c[i][7]])

@@ -17,11 +17,10 @@ from __future__ import annotations
 import collections
 import logging
 import os
-from functools import reduce
 
 import numpy as np
 
-from . import config, utils
+from . import config, export, utils
 from .exceptions import AtomSerialError, NativeLibraryError
 from .packed import PackedComplex
 
@@ -109,8 +108,11 @@ class InteractionComplex:
         if self._ctx is None:
             self.initialize()
         pc, ctx = self.pc, self._ctx
-        # I:1395: no selectors -> the whole structure
-        if user_selections:
+        # I:1395: no selectors -> the whole structure.  Extension: an integer array = the packed indices of the
+        # selected atoms (what the parser would have returned), for callers that select by their own means
+        if isinstance(user_selections, np.ndarray):
+            idx = np.unique(user_selections.astype(np.int64))
+        elif user_selections:
             idx = utils.selection_parser(user_selections, pc)
         else:
             idx = np.arange(pc.n_atoms, dtype=np.int64)
@@ -143,6 +145,10 @@ class InteractionComplex:
     # ---- result bags as lists of the reference's namedtuples (built on demand) ----
     def _ring_names(self, r):
         return sorted(self.pc.atom_name[a] for a in self.pc.ring_atoms[r]) if self.pc.ring_atoms else []
+
+    def _need_results(self):
+        if 'atom_atom' not in self._bags:
+            raise AttributeError('no results yet: call run_arpeggio() first')
 
     def _amide_names(self, a):
         return sorted(self.pc.atom_name[i] for i in self.pc.amide_atoms[a] if i >= 0)
@@ -223,35 +229,43 @@ class InteractionComplex:
         out['counts'] = acc['counts']
         return out
 
+    def atom_integer_sifts(self):
+        """``atom.integer_sift`` / ``_inter_only`` / ``_intra_only`` / ``_water_only`` (U:224-242, called at I:924-925) as
+        a uint8 array [n_atoms, 4, 15].  The reference's values are decided by the last pair its KD-tree delivers for each
+        atom; here the delivery order is the canonical one (contacts sorted by (bgn, end)), see include/arpeggio_hip.h."""
+        self._need_results()
+        return self._ctx.atom_integer_sifts()
+
     def residue_sifts(self):
-        """Binary per-residue SIFts of `_calc_residue_sifts` (I:471-560): a bit is set when any atom of the residue (any
-        main-chain / side-chain atom for ``mc_*`` / ``sc_*``, polypeptide residues only, C:35) has it.  The reference
-        derives them by flattening its integer sifts, whose non-zero pattern is exactly this OR; the integer values
-        themselves depend on the KD-tree's pair order (U:233-242) and are not provided.  uint8 arrays [n_residues, 15]."""
-        pc = self.pc
-        a = self.atom_sifts()
-        poly = (np.asarray(pc.res_flags) & config.R_POLYPEPTIDE) != 0
-        mc = np.asarray([n in config.MAINCHAIN_ATOMS for n in pc.atom_name], bool)
-        rid = np.asarray(pc.res_id)
-        out = {}
-        for name in ('sift', 'sift_inter_only', 'sift_intra_only', 'sift_water_only'):
-            for prefix, rows in (('', np.ones(pc.n_atoms, bool)), ('mc_', mc & poly[rid]), ('sc_', ~mc & poly[rid])):
-                r = np.zeros((pc.n_residues, 15), np.uint8)
-                np.maximum.at(r, rid[rows], a[name][rows])
-                out[prefix + name] = r
-        return out
+        """`_calc_residue_sifts` (I:471-574): dict name -> int array [n_residues, width] with the reference's attribute
+        names (``sift``, ``mc_sift_inter_only``, ``integer_sift``, ``ring_ring_inter_integer_sift`` ...), in the column
+        order of `write_residue_sifts`."""
+        self._need_results()
+        bits = self.atom_sifts()
+        return export.residue_sift_table(self.pc, bits, self.atom_integer_sifts(), self.residue_plane_sifts())
+
+    # ---- the legacy CSV tables (I:135-170, 349-366, 405-466) ----
+    def write_atom_types(self, wd):
+        """I:135-149: '<id>_atomtypes.csv'."""
+        export.write_atom_types(wd, self.id, self.pc, self.component_types)
+        logging.debug('Typed atoms.')
+
+    def write_contacts(self, selection, wd):
+        """I:151-170: '<id>_contacts.csv' (+ '<id>_bs_contacts.csv' when ``selection`` is not empty)."""
+        self._need_results()
+        export.write_contacts(wd, self.id, self.pc, self._bags['atom_atom'], self.component_types, len(selection) > 0)
 
     def write_atom_sifts(self, wd):
         """I:349-366, 576-606: '<id>_sifts.csv' (atom, 15 flags) and '<id>_specific_sifts.csv' (atom, inter / intra /
         water flags, 45 columns) for the atoms of selection_plus, in packed atom order (the reference iterates a set).
         The header row is the reference's (17 names whatever the row width)."""
         import csv
-        import os
         a = self.atom_sifts()
+        lab = export.Labels(self.pc, self.component_types)
         header = ['atom'] + list(config.SIFT_NAMES) + ['interacting_entities']
         rows_all, rows_spec = [], []
         for i in self.selection_plus.tolist():
-            label = utils.make_pymol_string(self.pc, atom=i)
+            label = lab.atom_macro(i)
             rows_all.append([label] + a['sift'][i].tolist())
             rows_spec.append([label] + a['sift_inter_only'][i].tolist() + a['sift_intra_only'][i].tolist()
                              + a['sift_water_only'][i].tolist())
@@ -261,64 +275,32 @@ class InteractionComplex:
                 w.writerow(header)
                 w.writerows(rows)
 
+    def write_residue_sifts(self, wd):
+        """I:435-466: '<id>_residue_sifts.csv', one row of 426 columns per residue of selection_plus."""
+        export.write_residue_sifts(wd, self.id, self.pc, self.component_types, self.selection_plus_residues, self.residue_sifts())
+
+    def write_polar_matching(self, wd):
+        """I:405-433: '<id>_polarmatch.csv' and '<id>_specific_polarmatch.csv' for the atoms of selection_plus."""
+        export.write_polar_matching(wd, self.id, self.pc, self.component_types, self.selection_plus, self.atom_sifts()['counts'])
+
+    def write_binding_site_sifts(self, wd):
+        """I:368-403 cannot complete in the reference itself: its row expression indexes a list with a list (I:401-402,
+        a missing ``+``) and ``utils.int3`` needs ``collections.Iterable`` (U:388, gone since Python 3.10), so there is no
+        output to reproduce.  ``potential_fsift()`` gives the per-atom potential feature SIFt it would match against."""
+        raise NotImplementedError('write_binding_site_sifts raises TypeError in the reference (interactions.py:401-402); '
+                                  'see potential_fsift() / atom_sifts() for its inputs')
+
+    def potential_fsift(self):
+        """``atom.potential_fsift`` (I:1795-1852) as uint8 [n_atoms, 10]."""
+        m = export.potential_fsift(self.pc)
+        return ((m[:, None] >> np.arange(10, dtype=np.uint16)[None, :]) & 1).astype(np.uint8)
+
     def get_contacts(self):
-        """I:172-212: JSON-able list, bags in the reference's order, canonical order inside a bag."""
-        pc = self.pc
-        contacts = config.SIFT_NAMES
-        result_bag = []
-        for contact in self.atom_contacts:
-            result_entry = {}
-            result_entry['bgn'] = utils.make_pymol_json(pc, atom=contact.bgn_atom)
-            result_entry['bgn']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, atom=contact.bgn_atom)]
-            result_entry['end'] = utils.make_pymol_json(pc, atom=contact.end_atom)
-            result_entry['end']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, atom=contact.end_atom)]
-            result_entry['type'] = 'atom-atom'
-            result_entry['distance'] = round(np.float64(contact.distance), 2)
-            result_entry['contact'] = [k for k, v in zip(contacts, contact.sifts) if v == 1]
-            result_entry['interacting_entities'] = contact.contact_type
-            result_bag.append(result_entry)
-        for contact in self.plane_plane_contacts:
-            result_bag.append(self._prepare_plane_plane_contact_for_export(contact, 'plane-plane'))
-        for contact in self.atom_plane_contacts:
-            result_bag.append(self._prepare_atom_plane_contact_for_export(contact, 'atom-plane'))
-        for contact in self.group_group_contacts:
-            result_bag.append(self._prepare_plane_plane_contact_for_export(contact, 'group-group'))
-        for contact in self.group_plane_contacts:
-            result_bag.append(self._prepare_plane_plane_contact_for_export(contact, 'group-plane'))
-        return result_bag
+        """I:172-212: the JSON-able list of contact records, bags in the reference's order (atom-atom, plane-plane,
+        atom-plane, group-group, group-plane), canonical order inside a bag ([] before run_arpeggio, like I:84-88)."""
+        return export.contacts_json(self.pc, self._bags, self.component_types)
 
     # endregion
-
-    def _prepare_plane_plane_contact_for_export(self, contact, contact_type):
-        """I:2063-2087."""
-        pc = self.pc
-        result_entry = {}
-        result_entry['bgn'] = utils.make_pymol_json(pc, residue=contact.bgn_res)
-        result_entry['bgn']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, residue=contact.bgn_res)]
-        result_entry['bgn']['auth_atom_id'] = reduce(lambda l, m: f'{l},{m}', contact.bgn_res_atoms)
-        result_entry['end'] = utils.make_pymol_json(pc, residue=contact.end_res)
-        result_entry['end']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, residue=contact.end_res)]
-        result_entry['end']['auth_atom_id'] = reduce(lambda l, m: f'{l},{m}', contact.end_res_atoms)
-        result_entry['type'] = contact_type
-        result_entry['distance'] = round(np.float64(contact.distance), 2)
-        result_entry['contact'] = contact.contact_type
-        result_entry['interacting_entities'] = contact.text
-        return result_entry
-
-    def _prepare_atom_plane_contact_for_export(self, contact, contact_type):
-        """I:2090-2113."""
-        pc = self.pc
-        result_entry = {}
-        result_entry['bgn'] = utils.make_pymol_json(pc, atom=contact.bgn_atom)
-        result_entry['bgn']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, atom=contact.bgn_atom)]
-        result_entry['end'] = utils.make_pymol_json(pc, residue=contact.end_res)
-        result_entry['end']['auth_atom_id'] = reduce(lambda l, m: f'{l},{m}', contact.end_res_atoms)
-        result_entry['end']['label_comp_type'] = self.component_types[utils.get_residue_name(pc, residue=contact.end_res)]
-        result_entry['type'] = contact_type
-        result_entry['distance'] = round(np.float64(contact.distance), 2)
-        result_entry['contact'] = contact.sifts
-        result_entry['interacting_entities'] = contact.text
-        return result_entry
 
 
 def residue_plane_sifts(pc, bags):

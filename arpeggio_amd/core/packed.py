@@ -25,6 +25,23 @@ def _arr(x, dtype, shape_tail=()):
     return a
 
 
+def single_bond_neighbours(bond_off, bond_idx, bond_order, bond_aromatic, is_hydrogen):
+    """utils.get_single_bond_neighbour (utils.py:612-635) for every atom: the first bond, in the bond graph's own
+    order, that has order 1, is not aromatic and leads to a non-hydrogen atom; -1 where there is none (the reference
+    returns None).  ``bond_order`` / ``bond_aromatic`` are aligned with ``bond_idx`` (CSR)."""
+    bond_off = np.asarray(bond_off, np.int64)
+    bond_idx = np.asarray(bond_idx, np.int64)
+    n = len(bond_off) - 1
+    ok = (np.asarray(bond_order) == 1) & (np.asarray(bond_aromatic) == 0) & ~np.asarray(is_hydrogen, bool)[bond_idx]
+    pos = np.nonzero(ok)[0]
+    owner = np.searchsorted(bond_off, pos, side='right') - 1
+    out = np.full(n, -1, np.int32)
+    first = np.ones(len(pos), bool)
+    first[1:] = owner[1:] != owner[:-1]
+    out[owner[first]] = bond_idx[pos[first]]
+    return out
+
+
 @dataclass
 class PackedComplex:
     # ---- atoms: self.s_atoms (interactions.py:54-60) ----
@@ -65,6 +82,9 @@ class PackedComplex:
     res_icode: Optional[List[str]] = None        # residue.id[2]
     res_chain: Optional[List[str]] = None        # chain.id
     component_types: Optional[Dict[str, str]] = None   # interactions.py:70
+    # ---- config.VALENCE[atomic_number] - atom.bond_order - atom.formal_charge (interactions.py:1804): what the
+    #      potential hbond / polar counts of acceptors are made of (write_polar_matching only) ----
+    lone_pair_electrons: Optional[np.ndarray] = None   # i32 [N]
     id: str = 'packed'
 
     def __post_init__(self):
@@ -160,6 +180,9 @@ class PackedComplex:
             self.serial = np.arange(1, n + 1, dtype=np.int32)
         if self.component_types is None:
             self.component_types = {}
+        if self.lone_pair_electrons is None:
+            self.lone_pair_electrons = np.zeros(n, np.int32)
+        self.lone_pair_electrons = _arr(self.lone_pair_electrons, np.int32)
         for rn in set(self.res_name):
             self.component_types.setdefault(rn, 'P')
         return self
@@ -171,32 +194,40 @@ class PackedComplex:
     # ---- persistence (a packed structure is the "file" this implementation reads) ----
     _ARRAYS = ('xyz', 'vdw', 'cov', 'type_mask', 'flags', 'res_id', 'res_flags', 'res_prev', 'res_next', 'bond_off',
                'bond_idx', 'h_off', 'h_xyz', 'sb_nbr', 'ring_center', 'ring_normal', 'ring_res', 'amide_center',
-               'amide_normal', 'amide_res', 'amide_atoms', 'serial', 'res_seq')
+               'amide_normal', 'amide_res', 'amide_atoms', 'serial', 'res_seq', 'lone_pair_electrons')
     _LISTS = ('atom_name', 'element', 'res_name', 'res_icode', 'res_chain')
+
+    def to_arrays(self, prefix=''):
+        """Every field as a NumPy array under ``prefix + name`` (what ``save`` writes)."""
+        self.ensure_labels()
+        d = {prefix + k: getattr(self, k) for k in self._ARRAYS}
+        for k in self._LISTS:
+            d[prefix + k] = np.array(getattr(self, k), dtype=np.str_)
+        ro = np.concatenate([[0], np.cumsum([len(a) for a in self.ring_atoms])]).astype(np.int32) if self.ring_atoms \
+            else np.zeros(self.n_rings + 1, np.int32)
+        d[prefix + 'ring_atoms_off'] = ro
+        d[prefix + 'ring_atoms_idx'] = (np.concatenate(self.ring_atoms).astype(np.int32) if self.ring_atoms and ro[-1]
+                                        else np.zeros(0, np.int32))
+        d[prefix + 'component_types_keys'] = np.array(list(self.component_types.keys()), dtype=np.str_)
+        d[prefix + 'component_types_vals'] = np.array(list(self.component_types.values()), dtype=np.str_)
+        d[prefix + 'id'] = np.array(self.id)
+        return d
+
+    @classmethod
+    def from_arrays(cls, z, prefix=''):
+        kw = {k: z[prefix + k] for k in cls._ARRAYS if (prefix + k) in z}
+        for k in cls._LISTS:
+            kw[k] = [str(x) for x in z[prefix + k]]
+        ro, ri = z[prefix + 'ring_atoms_off'], z[prefix + 'ring_atoms_idx']
+        kw['ring_atoms'] = [ri[ro[r]:ro[r + 1]] for r in range(len(ro) - 1)]
+        kw['component_types'] = {str(k): str(v) for k, v in zip(z[prefix + 'component_types_keys'], z[prefix + 'component_types_vals'])}
+        kw['id'] = str(z[prefix + 'id'])
+        return cls(**kw)
 
     def save(self, path):
         """Write the pack to a ``.npz`` file (numeric arrays + string tables)."""
-        self.ensure_labels()
-        d = {k: getattr(self, k) for k in self._ARRAYS}
-        for k in self._LISTS:
-            d[k] = np.array(getattr(self, k), dtype=np.str_)
-        ro = np.concatenate([[0], np.cumsum([len(a) for a in self.ring_atoms])]).astype(np.int32) if self.ring_atoms \
-            else np.zeros(self.n_rings + 1, np.int32)
-        d['ring_atoms_off'] = ro
-        d['ring_atoms_idx'] = (np.concatenate(self.ring_atoms).astype(np.int32) if self.ring_atoms and ro[-1] else np.zeros(0, np.int32))
-        d['component_types_keys'] = np.array(list(self.component_types.keys()), dtype=np.str_)
-        d['component_types_vals'] = np.array(list(self.component_types.values()), dtype=np.str_)
-        d['id'] = np.array(self.id)
-        np.savez_compressed(path, **d)
+        np.savez_compressed(path, **self.to_arrays())
 
     @classmethod
     def load(cls, path):
-        z = np.load(path, allow_pickle=False)
-        kw = {k: z[k] for k in cls._ARRAYS}
-        for k in cls._LISTS:
-            kw[k] = [str(x) for x in z[k]]
-        ro, ri = z['ring_atoms_off'], z['ring_atoms_idx']
-        kw['ring_atoms'] = [ri[ro[r]:ro[r + 1]] for r in range(len(ro) - 1)]
-        kw['component_types'] = {str(k): str(v) for k, v in zip(z['component_types_keys'], z['component_types_vals'])}
-        kw['id'] = str(z['id'])
-        return cls(**kw)
+        return cls.from_arrays(np.load(path, allow_pickle=False))

@@ -1365,6 +1365,41 @@ int arp_atom_accumulators(arp_ctx* c, uint16_t* out_sift4, int32_t* out_counts8)
     return ARP_OK;
 }
 
+int arp_atom_integer_sifts(arp_ctx* c, uint8_t* out_isift) {
+    if (!c || !out_isift) return ARP_E_ARG;
+    if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_atom_integer_sifts: no atom-contact results (call a launch first)");
+    if (c->has_gid) FAIL(c, ARP_E_ARG, "arp_atom_integer_sifts: not available on a shard (contacts carry global ids)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n4 = 4 * (size_t)std::max<int64_t>(c->n, 1);
+    DevBuf<u64> last_rank;
+    DevBuf<unsigned int> before, last_sift;
+    DevBuf<uint8_t> out;
+    HIPCHK(c, last_rank.reserve(n4));
+    HIPCHK(c, before.reserve(n4));
+    HIPCHK(c, last_sift.reserve(n4));
+    HIPCHK(c, out.reserve(15 * n4));
+    HIPCHK(c, hipMemsetAsync(last_rank.p, 0, n4 * sizeof(u64), c->stream));
+    HIPCHK(c, hipMemsetAsync(before.p, 0, n4 * sizeof(unsigned int), c->stream));
+    HIPCHK(c, hipMemsetAsync(last_sift.p, 0, n4 * sizeof(unsigned int), c->stream));
+    if (c->n_contacts > 0) {
+        const dim3 grid(nblocks(c->n_contacts, 256, 4096));
+        hipLaunchKernelGGL(k_isift_last, grid, dim3(256), 0, c->stream, (long long)c->n_contacts, c->out_i.p, c->out_j.p,
+                           c->out_ct.p, last_rank.p);
+        hipLaunchKernelGGL(k_isift_fill, grid, dim3(256), 0, c->stream, (long long)c->n_contacts, c->out_i.p, c->out_j.p,
+                           c->out_s.p, c->out_ct.p, last_rank.p, before.p, last_sift.p);
+        CHK(check_launch(c, "k_isift_fill"));
+    }
+    hipLaunchKernelGGL(k_isift_compose, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, (long long)n4, before.p,
+                       last_sift.p, out.p);
+    CHK(check_launch(c, "k_isift_compose"));
+    int rc = download(c, out_isift, out.p, 60 * (size_t)c->n);
+    last_rank.release();
+    before.release();
+    last_sift.release();
+    out.release();
+    return rc;
+}
+
 // ---- ring / amide contacts: launch (results stay in HBM) + fetch ----------------------------------
 int arp_atom_plane_launch(arp_ctx* c, int64_t* count) {
     if (!c) return ARP_E_ARG;

@@ -816,6 +816,57 @@ __global__ __launch_bounds__(256) void k_accumulate(long long np, const int* __r
     }
 }
 
+// utils.update_atom_integer_sift (U:224-242) under the canonical pair order (contacts sorted by (i, j), i < j): for an
+// atom a the last pair of a class is the one with the largest j among its pairs as bgn, or — if it is never bgn — the
+// largest i among its pairs as end.  rank = (a is bgn) << 32 | partner + 1.  Pass 1 takes the maximum rank per
+// (atom, class); pass 2 ORs every other pair's SIFt into `before` and stores the last pair's SIFt; pass 3 writes
+// before + last per bit.  Classes: 0 every pair, 1 type == 'INTER', 2 'INTRA' in type, 3 'WATER' in type.
+__device__ __forceinline__ unsigned int isift_classes(int ct) {
+    const bool inter = ct == ARP_CT_INTER;
+    const bool intra = ct == ARP_CT_INTRA_NON_SELECTION || ct == ARP_CT_INTRA_SELECTION;
+    const bool water = ct == ARP_CT_SELECTION_WATER || ct == ARP_CT_NON_SELECTION_WATER || ct == ARP_CT_WATER_WATER;
+    return 1u | (inter ? 2u : 0u) | (intra ? 4u : 0u) | (water ? 8u : 0u);
+}
+__global__ __launch_bounds__(256) void k_isift_last(long long np, const int* __restrict__ ci, const int* __restrict__ cj,
+                                                    const uint8_t* __restrict__ cct, u64* __restrict__ last_rank) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (long long)gridDim.x * blockDim.x) {
+        const unsigned int cls = isift_classes(cct[p]);
+        const int i = ci[p], j = cj[p];
+        const u64 rank_i = (1ull << 32) | (u64)(unsigned int)(j + 1), rank_j = (u64)(unsigned int)(i + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!((cls >> s) & 1u)) continue;
+            atomicMax(&last_rank[4 * (size_t)i + s], rank_i);
+            atomicMax(&last_rank[4 * (size_t)j + s], rank_j);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_isift_fill(long long np, const int* __restrict__ ci, const int* __restrict__ cj,
+                                                    const uint16_t* __restrict__ cs, const uint8_t* __restrict__ cct,
+                                                    const u64* __restrict__ last_rank, unsigned int* __restrict__ before,
+                                                    unsigned int* __restrict__ last_sift) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (long long)gridDim.x * blockDim.x) {
+        const unsigned int cls = isift_classes(cct[p]), sft = cs[p];
+        const int i = ci[p], j = cj[p];
+        const u64 rank_i = (1ull << 32) | (u64)(unsigned int)(j + 1), rank_j = (u64)(unsigned int)(i + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!((cls >> s) & 1u)) continue;
+            const size_t ki = 4 * (size_t)i + s, kj = 4 * (size_t)j + s;
+            if (last_rank[ki] == rank_i) last_sift[ki] = sft; else atomicOr(&before[ki], sft);
+            if (last_rank[kj] == rank_j) last_sift[kj] = sft; else atomicOr(&before[kj], sft);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_isift_compose(long long n4, const unsigned int* __restrict__ before,
+                                                       const unsigned int* __restrict__ last_sift, uint8_t* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const unsigned int b = before[t], l = last_sift[t];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) out[15 * t + k] = (uint8_t)(((b >> k) & 1u) + ((l >> k) & 1u));
+}
+
 // End of a pass: the counter block goes to the pinned host copy (a kernel store to mapped host memory costs one
 // launch; a D2H hipMemcpyAsync of 3 KB costs an SDMA round trip) and, when asked, returns to zero for the next pass.
 __global__ __launch_bounds__(256) void k_publish_counters(u64* __restrict__ ctr, u64* __restrict__ host, int n, int zero, u64 seq) {

@@ -210,9 +210,17 @@ int arp_atom_contacts(arp_ctx* ctx, double cutoff, double vdw_comp,
  *   out_sift4[4*a + {0,1,2,3}] = atom.sift / sift_inter_only / sift_intra_only / sift_water_only as
  *       15-bit masks (actual_fsift* = the same masks >> 5);
  *   out_counts8[8*a + k] = actual_hbonds, _intra_only, _inter_only, _water_only, actual_polars, ... (same order).
- * utils.update_atom_integer_sift (U:224-242) is NOT provided: its value depends on the order in which
- * the reference's KD-tree happens to deliver the pairs (it is "sift before the last pair + last pair"). */
+ * utils.update_atom_integer_sift (U:224-242): see arp_atom_integer_sifts. */
 int arp_atom_accumulators(arp_ctx* ctx, uint16_t* out_sift4, int32_t* out_counts8);
+
+/* utils.update_atom_integer_sift (U:224-242, called first at I:924-925) from the contact list of the last launch.
+ * The reference overwrites atom.integer_sift* at every pair with "binary sift before this pair + this pair", so what
+ * is left is decided by the LAST pair of each class that touched the atom, i.e. by the order in which its KD-tree
+ * delivered the pairs.  Here the order is the canonical one of this library (contacts sorted by (bgn, end), bgn = lower
+ * packed index — the same convention that fixes the bgn/end orientation):
+ *   out_isift[60*a + 15*slot + k], slot = {integer_sift, _inter_only, _intra_only, _water_only}, k = SIFt bit,
+ *   value = (bit set by an earlier pair of the class) + (bit set by the last pair of the class) in {0, 1, 2}. */
+int arp_atom_integer_sifts(arp_ctx* ctx, uint8_t* out_isift);
 
 /* ---- _calculate_ring_contacts (I:938-1206) ------------------------------- */
 /* __calculate_atom_plane_contacts (I:947-1062). mask = ARP_AP_* bits. */

@@ -223,6 +223,17 @@ def atom_accumulators(n, contacts):
     return dict(sift=sift[:n], counts=cnt[:n])
 
 
+def atom_integer_sifts(n, contacts):
+    """update_atom_integer_sift (U:224-242) walked over the contact list in the order given: uint8 [n, 4, 15]."""
+    ci = np.ascontiguousarray(contacts['i'], np.int32)
+    cj = np.ascontiguousarray(contacts['j'], np.int32)
+    cs = np.ascontiguousarray(contacts['sift'], np.uint16)
+    cc = np.ascontiguousarray(contacts['ctype'], np.uint8)
+    out = np.zeros((max(n, 1), 4, 15), np.uint8)
+    lib().orc_atom_integer_sifts(C.c_int64(n), C.c_int64(len(ci)), _p(ci), _p(cj), _p(cs), _p(cc), _p(out))
+    return out[:n]
+
+
 def sort_pairs(out, ki='i', kj='j'):
     """Canonical order: ascending (i, j)."""
     o = np.lexsort((out[kj], out[ki]))
