@@ -30,8 +30,6 @@ void set_create_error(const std::string& m) {
     std::lock_guard<std::mutex> lk(g_create_mutex);
     g_create_error = m;
 }
-std::atomic<uint64_t> g_alloc_epoch{0};   // bumped by every device (re)allocation: invalidates captured graphs
-                                          // (contexts may live on different host threads: one context per thread)
 
 template <class T>
 struct DevBuf {
@@ -44,7 +42,7 @@ struct DevBuf {
         release();
         size_t c = n + n / 4 + 64;
         hipError_t e = hipMalloc((void**)&p, c * sizeof(T));
-        if (e == hipSuccess) { cap = c; ++g_alloc_epoch; if (fresh) *fresh = true; }
+        if (e == hipSuccess) { cap = c; if (fresh) *fresh = true; }
         else p = nullptr;
         return e;
     }
@@ -58,11 +56,18 @@ struct DevBuf {
 struct Grid {
     GridDesc d{};
     DevBuf<int> cell_of, cnt, start, perm, sums;
+    // atom grids: {cell, rank in cell} per atom and a second histogram buffer (double-buffered: a build counts in
+    // hist[cur] and clears hist[1 - cur], the one the previous build used)
+    DevBuf<int2> cell_rank;
+    DevBuf<int> cnt2;
+    int cur = 0;
+    size_t used[2] = {0, 0};   // counters of hist[k] that may be non-zero
     int n_points = 0;   // points offered
     int n_binned = 0;   // points that passed the filter
     bool valid = false;
     double radius = 0;
-    void release() { cell_of.release(); cnt.release(); start.release(); perm.release(); sums.release(); valid = false; }
+    void release() { cell_of.release(); cnt.release(); start.release(); perm.release(); sums.release(); cell_rank.release();
+                     cnt2.release(); valid = false; }
 };
 
 struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
@@ -161,14 +166,13 @@ struct arp_ctx {
     bool ctr_clean = false;
     u64 publish_seq = 0;         // number of k_publish_counters launches; the kernel stores it in h_ctr_pinned[C_COUNT]
     bool ctr_zero_ok = false;    // the last arp_run_launch left the whole block zeroed (k_publish_counters) and nothing touched it since
-    // ---- hipGraph of the whole run_arpeggio pass (captured on the 2nd identical call, replayed afterwards)
-    u64* h_ctr_pinned = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_ok = true;          // set false if capture/instantiate ever fails: direct launches from then on
-    uint64_t input_epoch = 0;      // bumped by every call that changes sizes / pointers / flags baked into kernel args
-    struct GraphKey { double cutoff, comp, expand; int seq_adj; uint64_t alloc_epoch, input_epoch; bool valid; } gkey{0, 0, 0, 0, 0, 0, false},
-        last_key{0, 0, 0, 0, 0, 0, false};
+    u64* h_ctr_pinned = nullptr;   // pinned mirror of the counter block + completion word
+    PublishArgs pub{nullptr, nullptr, 0, 0};   // in-kernel end-of-pass publication (arp_run_launch sets it for one pass)
+    // residue sets of arp_run_launch, tagged with the pass number (never cleared between passes; wrap -> one memset)
+    DevBuf<uint8_t> res_tag;       // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
+    int res_tag_value = 0;
+    bool fuse_sets = false;        // the contact-grid build of the current pass also makes the residue / ring / amide sets
+    bool init_plus_in_bin = false; // ... and writes selection_plus = selection (whole-structure selection)
     // ---- device-resident result bags of the ring / amide kernels
     Bag bag_ap, bag_pp, bag_gg, bag_gp;
     // ---- profiling
@@ -402,41 +406,84 @@ StaticAtoms static_atoms(arp_ctx* c) {
 // sift records directly).
 int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, DevBuf<SiftRec>* srec, double radius,
                     uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr, uint8_t* plus_init = nullptr,
-                    hipStream_t st = nullptr) {
+                    hipStream_t st = nullptr, ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
     if (!st) st = c->stream;
     const int n = (int)c->n;
     make_grid_desc(G.d, c->lo, c->hi, radius);
     G.radius = radius;
     G.n_points = n;
-    CHK(reserve_grid(c, G, n, st));
+    const int ncell = G.d.ncell;
+    HIPCHK(c, G.cell_rank.reserve((size_t)std::max(n, 1)));
+    {   // both histograms: zero when freshly allocated; afterwards each build clears the other one
+        bool f0 = false, f1 = false;
+        HIPCHK(c, G.cnt.reserve(scan_padded(ncell), &f0));
+        HIPCHK(c, G.cnt2.reserve(scan_padded(ncell), &f1));
+        if (f0) { HIPCHK(c, hipMemsetAsync(G.cnt.p, 0, G.cnt.cap * sizeof(int), st)); G.used[0] = 0; }
+        if (f1) { HIPCHK(c, hipMemsetAsync(G.cnt2.p, 0, G.cnt2.cap * sizeof(int), st)); G.used[1] = 0; }
+    }
+    HIPCHK(c, G.start.reserve(scan_padded(ncell)));
+    HIPCHK(c, G.sums.reserve((size_t)(ncell + TILE_CELLS - 1) / TILE_CELLS + 2));
     HIPCHK(c, sx.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, sa.reserve((size_t)std::max(n, 1)));
     if (srec) HIPCHK(c, srec->reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c));
     const StaticAtoms r = static_atoms(c);
-    {
-        Prof p(c, SLOT_BIN, st);
-        if (n > 0) {
-            if (active) hipLaunchKernelGGL((k_bin_atoms<1>), dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.d, active, 0u, 0u, G.cell_of.p, G.cnt.p, plus_init);
-            else hipLaunchKernelGGL((k_bin_atoms<2>), dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.d, (const uint8_t*)nullptr, req, forb, G.cell_of.p, G.cnt.p, plus_init);
+    int* const hist = G.cur ? G.cnt2.p : G.cnt.p;
+    int* const other = G.cur ? G.cnt.p : G.cnt2.p;
+    if (n > 0) {
+        {
+            Prof p(c, SLOT_BIN, st);
+            const int nzero = (int)G.used[1 - G.cur];
+            if (active) hipLaunchKernelGGL((k_bin_atoms<1>), dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.d, active, 0u, 0u, G.cell_rank.p, hist, plus_init, other, nzero, rm);
+            else hipLaunchKernelGGL((k_bin_atoms<2>), dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.d, (const uint8_t*)nullptr, req, forb, G.cell_rank.p, hist, plus_init, other, nzero, rm);
             CHK(check_launch(c, "k_bin_atoms"));
+            G.used[1 - G.cur] = 0;
+            G.used[G.cur] = ((size_t)ncell + 3) & ~(size_t)3;
         }
-    }
-    CHK(enqueue_scan(c, G, total_out, st));
-    {
-        Prof p(c, SLOT_SCATTER, st);
-        if (n > 0) {
-            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_of.p, G.start.p, G.cnt.p,
-                               sx.p, sa.p, srec ? srec->p : (SiftRec*)nullptr);
+        SiftRec* const rec = srec ? srec->p : (SiftRec*)nullptr;
+        const int nb = (n + SCAT_ATOMS - 1) / SCAT_ATOMS;
+        if (ncell <= SCAN_LDS_CELLS) {   // start table in LDS: scan + scatter in one launch
+            Prof p(c, SLOT_SCATTER, st);
+            const int steps = (ncell + 16 * 256 - 1) / (16 * 256);
+#define LAUNCH_SS(S) hipLaunchKernelGGL((k_scan_scatter_atoms<S>), dim3(nb), dim3(1024), (S) * 16384, st, r, n, ncell, G.cell_rank.p, hist, \
+                                        G.start.p, total_out, sx.p, sa.p, rec, gm)
+            switch (steps) {
+                case 1: LAUNCH_SS(1); break;
+                case 2: LAUNCH_SS(2); break;
+                case 3: LAUNCH_SS(3); break;
+                case 4: LAUNCH_SS(4); break;
+                case 5: LAUNCH_SS(5); break;
+                case 6: LAUNCH_SS(6); break;
+                case 7: LAUNCH_SS(7); break;
+                case 8: LAUNCH_SS(8); break;
+                default: LAUNCH_SS(9); break;
+            }
+#undef LAUNCH_SS
+            CHK(check_launch(c, "k_scan_scatter_atoms"));
+        } else {
+            {
+                Prof p(c, SLOT_SCAN, st);
+                const int ntiles = (ncell + TILE_CELLS - 1) / TILE_CELLS;
+                hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.sums.p);
+                hipLaunchKernelGGL(k_scan_fix, dim3((ncell + 4095) / 4096), dim3(1024), 0, st, G.start.p, ncell, G.sums.p, ntiles, total_out);
+                CHK(check_launch(c, "k_scan"));
+            }
+            Prof p(c, SLOT_SCATTER, st);
+            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_rank.p, G.start.p, sx.p, sa.p, rec, gm);
             CHK(check_launch(c, "k_scatter_atoms"));
         }
+        G.cur = 1 - G.cur;
+    } else {
+        HIPCHK(c, hipMemsetAsync(G.start.p, 0, ((size_t)ncell + 1) * sizeof(int), st));
+        if (total_out) HIPCHK(c, hipMemsetAsync(total_out, 0, sizeof(u64), st));
     }
     G.valid = true;
     G.n_binned = -1;  // known on the device only (start[ncell])
     return ARP_OK;
 }
-int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr) {
-    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out);
+int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr,
+                       ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
+    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
 }
 // every atom (hydrogens included), used by the expansion and atom-plane; plus_init: also start selection_plus
 int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr, hipStream_t st = nullptr) {
@@ -464,13 +511,12 @@ int enqueue_counter_copy(arp_ctx* c, int zero = 0) {  // counter block -> pinned
     CHK(check_launch(c, "k_publish_counters"));
     return ARP_OK;
 }
-int collect_counters(arp_ctx* c, bool replayed = false) {  // the only stream sync of a pass
-    // The publish kernel is the last operation of the pass and ends by storing the pass number in pinned memory:
+int collect_counters(arp_ctx* c) {  // the only stream sync of a pass
+    // The pass ends by storing its number in pinned memory (pass_end in the last kernel, or k_publish_counters):
     // polling that word wakes the host ~10 us sooner than hipStreamSynchronize.  Bounded: after 2 ms (or with a
-    // caller-owned stream, a captured graph or ARP_SPIN_WAIT=0) the runtime's own wait takes over.
+    // caller-owned stream or ARP_SPIN_WAIT=0) the runtime's own wait takes over.
     static const int spin = env_int("ARP_SPIN_WAIT", 1);
-    // (a replayed graph stores the sequence number it was captured with: no polling there)
-    if (spin && !c->external_stream && !replayed) {
+    if (spin && !c->external_stream) {
         volatile u64* flag = c->h_ctr_pinned + C_COUNT;
         const auto t0 = std::chrono::steady_clock::now();
         for (int it = 0; *flag != c->publish_seq; ++it) {
@@ -478,7 +524,10 @@ int collect_counters(arp_ctx* c, bool replayed = false) {  // the only stream sy
             __builtin_ia32_pause();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (*flag != c->publish_seq) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*flag != c->publish_seq) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (*flag != c->publish_seq) FAIL(c, ARP_E_HIP, "the pass ended without publishing its counters");
+        }
         else if ((c->publish_seq & 15) == 0) (void)hipStreamQuery(c->stream);   // lets the runtime retire finished commands
     } else {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -495,13 +544,6 @@ int collect_counters(arp_ctx* c, bool replayed = false) {  // the only stream sy
 int read_counters(arp_ctx* c) {
     CHK(enqueue_counter_copy(c));
     return collect_counters(c);
-}
-void drop_graph(arp_ctx* c) {
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
-    c->graph_exec = nullptr;
-    c->graph = nullptr;
-    c->gkey.valid = false;
 }
 
 // CSR offsets: start at 0, never decrease (the kernels index with them unchecked)
@@ -565,7 +607,7 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
     if (n > 0 && !c->sel_all) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
-                           c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, env_int("ARP_ABLATE", 0), (int2*)nullptr,
+                           c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
                            0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
         CHK(check_launch(c, "k_search<MARK>"));
     }
@@ -620,48 +662,6 @@ int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 
     return enqueue_selection(c, 6.0);   // an uploaded selection that was not expanded yet is expanded here
 }
 
-// _calculate_atom_contacts (I:693-936): bin + sort + search + sift with the current capacities
-int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq_adj) {
-    // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
-    if (!c->ctr_clean) CHK(zero_counter(c, C_BINNED, 1));
-    CHK(build_contact_grid(c, cutoff, M_PLUS, M_HYDROGEN, nullptr, c->d_ctr + C_BINNED));
-    c->contact_cells = c->atom_grid.d.ncell;
-    if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 8192));
-    const size_t segcap = c->pairs.cap / PAIR_SEGS;   // the pair list is PAIR_SEGS segments of segcap entries
-    const size_t cap = segcap * PAIR_SEGS;
-    if (cap >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "contact list beyond 2^32 entries (k_sift's task queue holds 32-bit output indices)");
-    HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
-    HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
-    CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
-    CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
-    CHK(zero_counter(c, C_ERR, 1));
-    if (c->n > 0) {
-        {
-            Prof p(c, SLOT_SEARCH);
-            // the contact search ends with a block-level flush of its pair queues, which amortises better over
-            // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
-            static const int cpw = std::max(1, env_int("ARP_SEARCH_CPW", 3));
-            hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
-                               c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->has_home ? 1 : 0, env_int("ARP_ABLATE", 0), c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
-                               c->d_ctr + C_STAT_ACC,
-                               (uint8_t*)nullptr);
-            CHK(check_launch(c, "k_search<CONTACTS>"));
-        }
-        {
-            Prof p(c, SLOT_SIFT);
-            static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
-            hipLaunchKernelGGL(k_sift, dim3(c->num_cu * sift_blocks_per_cu), dim3(256), 0, c->stream, c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap,
-                               c->s_rec.p, SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p}, c->bond_idx.p, c->h_xyz_d.p,
-                               c->has_gid ? c->gid.p : nullptr, vdw_comp, env_int("ARP_ABLATE", 0),
-                               c->out_i.p,
-                               c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p, (int*)(c->d_ctr + C_ERR));
-            CHK(check_launch(c, "k_sift"));
-        }
-    }
-    return ARP_OK;
-}
-
 int bag_reserve(arp_ctx* c, Bag& b, size_t cap, bool d, bool f) {
     HIPCHK(c, b.a.reserve(cap)); HIPCHK(c, b.b.reserve(cap));
     if (d) { HIPCHK(c, b.d0.reserve(cap)); HIPCHK(c, b.d1.reserve(cap)); HIPCHK(c, b.d2.reserve(cap)); HIPCHK(c, b.d3.reserve(cap)); }
@@ -674,22 +674,37 @@ int bag_reserve(arp_ctx* c, Bag& b, size_t cap, bool d, bool f) {
 // One wavefront per ring / amide up to PLANE_BLOCKS blocks, several items per wave beyond: the waves queue their
 // records in LDS and a block pays ONE counter atomic when it ends.
 #define PLANE_BLOCKS 1024
+// items (rings / amides) per wavefront of the ring / amide kernels: their candidate pairs gather in the wave's LDS queue
+// until 64 are there for a full-lane evaluation, so a wave should see a few items; every item costs a few dependent
+// loads, so not too many (sweep in profiles/README.md)
+int plane_blocks(int64_t items) {
+    static const int ipw = std::max(1, env_int("ARP_PLANE_IPW", 4));
+    return nblocks((items + ipw - 1) / ipw * 64, 256, PLANE_BLOCKS);
+}
 // The four ring / amide kernels: prepare_* sizes the bag, clears its counter and fills the kernel arguments
 // (nb = number of blocks, 0 when there is nothing to do); enqueue_* launches one of them, enqueue_planes all
 // four as ONE launch (k_planes).
-int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb) {  // I:947-1062
+int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb, bool contact_grid = false) {  // I:947-1062
     Bag& b = c->bag_ap;
     nb = 0;
     if (!b.cap) CHK(bag_reserve(c, b, (size_t)c->nring * 8 + 256, true, false));
     CHK(zero_counter(c, C_AP, 1));
     if (c->nring == 0 || c->n == 0) return ARP_OK;
+    if (contact_grid) {   // the grid of the pass (selection_plus without hydrogens): atom_plane_cg_body
+        a = AtomPlaneArgs{c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
+                          c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
+                          c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
+                          b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP};
+        nb = plane_blocks(c->nring);
+        return ARP_OK;
+    }
     // all-atom 6 A grid (I:960 radius): the one the selection expansion has just built, if it is still current
     if (!(c->all_grid_current && c->all_grid.valid && c->all_grid.radius == 6.0)) CHK(build_all_grid(c, 6.0));
     a = AtomPlaneArgs{c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
                       c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                       c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
                       b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP};
-    nb = nblocks(c->nring * 64, 256, PLANE_BLOCKS);
+    nb = plane_blocks(c->nring);
     return ARP_OK;
 }
 int prepare_plane_plane(arp_ctx* c, PlanePlaneArgs& a, int& nb) {  // I:1064-1194
@@ -703,7 +718,7 @@ int prepare_plane_plane(arp_ctx* c, PlanePlaneArgs& a, int& nb) {  // I:1064-119
                        c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                        c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
                        b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP};
-    nb = nblocks(c->nring * 64, 256, PLANE_BLOCKS);
+    nb = plane_blocks(c->nring);
     return ARP_OK;
 }
 int prepare_group_group(arp_ctx* c, GroupGroupArgs& a, int& nb) {  // I:1217-1300
@@ -717,7 +732,7 @@ int prepare_group_group(arp_ctx* c, GroupGroupArgs& a, int& nb) {  // I:1217-130
                        c->am_sel.p, c->am_plus.p, c->has_group_owner ? c->am_home.p : nullptr,
                        c->has_group_owner ? c->am_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p,
                        b.u0.p, c->d_ctr + C_GG};
-    nb = nblocks(c->namide * 64, 256, PLANE_BLOCKS);
+    nb = plane_blocks(c->namide);
     return ARP_OK;
 }
 int prepare_group_plane(arp_ctx* c, GroupPlaneArgs& a, int& nb) {  // I:1302-1382
@@ -732,7 +747,7 @@ int prepare_group_plane(arp_ctx* c, GroupPlaneArgs& a, int& nb) {  // I:1302-138
                        c->has_group_owner ? c->am_home.p : nullptr, c->has_group_owner ? c->am_gid.p : nullptr,
                        c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
                        b.u0.p, c->d_ctr + C_GP};
-    nb = nblocks(c->namide * 64, 256, PLANE_BLOCKS);
+    nb = plane_blocks(c->namide);
     return ARP_OK;
 }
 
@@ -772,21 +787,110 @@ int enqueue_group_plane(arp_ctx* c, hipStream_t st) {
     hipLaunchKernelGGL(k_group_plane, dim3(nb), dim3(256), 0, st, a);
     return check_launch(c, "k_group_plane");
 }
-// I:346-347 (I:944-945, 1214-1215): all four in one launch
-int enqueue_planes(arp_ctx* c, hipStream_t st) {
+// The pass proper: _calculate_atom_contacts (I:693-936) = contact grid (bin + scan/scatter), neighbour search, fused
+// per-pair kernel; with_planes: the four ring / amide loops (I:938-1382) ride in the last launch (k_sift_planes).
+// fuse_sets (arp_run_launch): the grid build also produces the residue / ring / amide sets of I:1413-1437.
+int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq_adj, bool with_planes) {
+    // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
+    if (!c->ctr_clean) CHK(zero_counter(c, C_BINNED, 1));
+    ResMarks rm{nullptr, nullptr, 0};
+    GroupMasks gm{};
+    bool masks_after_bin = false;
+    if (c->fuse_sets) {
+        const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
+        CHK(check_residue_ranges(c));
+        bool fresh = false;
+        HIPCHK(c, c->res_tag.reserve(2 * nres, &fresh));
+        if (fresh || c->res_tag_value >= 255) {
+            HIPCHK(c, hipMemsetAsync(c->res_tag.p, 0, c->res_tag.cap, c->stream));
+            c->res_tag_value = 0;
+        }
+        const uint8_t tag = (uint8_t)++c->res_tag_value;
+        const bool all_res = c->whole_structure && c->sel_all;   // every residue of the (global) table is selected
+        if (!all_res) rm = ResMarks{c->res_tag.p, c->res_tag.p + nres, tag};
+        gm = GroupMasks{(int)c->nring, (int)c->namide, c->ring_res.p, c->am_res.p, c->res_tag.p, c->res_tag.p + nres, tag,
+                        all_res ? 1 : 0, c->ring_sel.p, c->ring_plus.p, c->am_sel.p, c->am_plus.p};
+        if (c->n == 0) masks_after_bin = true;   // no scatter launch to carry them
+    }
+    CHK(build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, cutoff, M_PLUS, M_HYDROGEN, nullptr, c->d_ctr + C_BINNED,
+                        c->init_plus_in_bin ? c->plus.p : nullptr, nullptr, rm, masks_after_bin ? GroupMasks{} : gm));
+    if (masks_after_bin && c->nring + c->namide > 0) {
+        hipLaunchKernelGGL(k_group_masks, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, c->stream, gm);
+        CHK(check_launch(c, "k_group_masks"));
+    }
+    c->contact_cells = c->atom_grid.d.ncell;
+    if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 8192));
+    const size_t segcap = c->pairs.cap / PAIR_SEGS;   // the pair list is PAIR_SEGS segments of segcap entries
+    const size_t cap = segcap * PAIR_SEGS;
+    if (cap >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "contact list beyond 2^32 entries (k_sift's task queue holds 32-bit output indices)");
+    HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
+    HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
+    CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
+    CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
+    CHK(zero_counter(c, C_ERR, 1));
+    // ---- ring / amide loops (I:938-1382): ONE launch on the second stream, released by the grid build.  It is
+    // enqueued after the search, whose 736 blocks take the whole chip first; the ~1500 short ring / amide blocks fill in
+    // as search blocks retire (the search has a long tail) and are gone before the sift kernel is.
     AtomPlaneArgs ap{};
     PlanePlaneArgs pp{};
     GroupGroupArgs gg{};
     GroupPlaneArgs gp{};
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    CHK(prepare_atom_plane(c, ap, n0));
-    CHK(prepare_plane_plane(c, pp, n1));
-    CHK(prepare_group_group(c, gg, n2));
-    CHK(prepare_group_plane(c, gp, n3));
-    if (n0 + n1 + n2 + n3 == 0) return ARP_OK;
-    Prof p(c, SLOT_PLANES, st);
-    hipLaunchKernelGGL(k_planes, dim3(n0 + n1 + n2 + n3), dim3(256), 0, st, ap, pp, gg, gp, n0, n0 + n1, n0 + n1 + n2);
-    return check_launch(c, "k_planes");
+    if (with_planes) {
+        CHK(prepare_atom_plane(c, ap, n0, /*contact_grid=*/true));
+        CHK(prepare_plane_plane(c, pp, n1));
+        CHK(prepare_group_group(c, gg, n2));
+        CHK(prepare_group_plane(c, gp, n3));
+    }
+    static const int planes_mode = env_int("ARP_PLANES_MODE", 0);   // 0: one grid with the sift kernel; 1: second stream
+    const bool merged = planes_mode == 0 && c->n > 0 && n0 + n1 + n2 + n3 > 0;
+    const bool planes_launched = !merged && n0 + n1 + n2 + n3 > 0;
+    hipStream_t st2 = c->external_stream ? c->stream : c->stream2;   // a caller-owned stream: everything in order on it
+    if (planes_launched) {
+        if (c->pub.expected) c->pub.expected = (c->n > 0) ? 2 : 1;
+        if (st2 != c->stream) HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));   // grid + masks are in place here
+    }
+    if (c->n > 0) {
+        Prof p(c, SLOT_SEARCH);
+        // the contact search ends with a block-level flush of its pair queues, which amortises better over
+        // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
+        static const int cpw = std::max(1, env_int("ARP_SEARCH_CPW", 3));
+        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
+                           c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
+                           include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
+                           c->d_ctr + C_STAT_ACC, (uint8_t*)nullptr);
+        CHK(check_launch(c, "k_search<CONTACTS>"));
+    }
+    if (planes_launched) {
+        const PlanesSplit ps{n0, n0 + n1, n0 + n1 + n2, n0 + n1 + n2 + n3};
+        if (st2 != c->stream) HIPCHK(c, hipStreamWaitEvent(st2, c->ev_sel, 0));
+        Prof p(c, SLOT_PLANES, st2);
+        hipLaunchKernelGGL(k_planes, dim3(ps.nb3), dim3(256), 0, st2, ap, pp, gg, gp, ps, c->pub);
+        CHK(check_launch(c, "k_planes"));
+    }
+    if (c->n > 0) {
+        Prof p(c, SLOT_SIFT);
+        static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
+        const SiftArgs sa{c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap, c->s_rec.p,
+                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p}, c->bond_idx.p, c->h_xyz_d.p,
+                          c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
+                          (int*)(c->d_ctr + C_ERR)};
+        if (merged) {
+            const PlanesSplit ps{n0, n0 + n1, n0 + n1 + n2, n0 + n1 + n2 + n3};
+            const int np = (ps.nb3 + 7) & ~7, nsift = c->num_cu * sift_blocks_per_cu;
+            hipLaunchKernelGGL(k_sift_planes, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, ps, np, c->pub);
+        } else {
+            hipLaunchKernelGGL(k_sift, dim3(c->num_cu * sift_blocks_per_cu), dim3(256), 0, c->stream, sa, c->pub);
+        }
+        CHK(check_launch(c, "k_sift"));
+    } else if (!planes_launched) {
+        c->pub.expected = 0;   // nothing was launched that could publish: the caller falls back to k_publish_counters
+    }
+    if (planes_launched && !c->external_stream) {   // join: whatever follows on the main stream sees the bags
+        HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
+    }
+    return ARP_OK;
 }
 
 // After read_counters(): publish contact results; returns true when the pair buffer overflowed.
@@ -815,6 +919,7 @@ bool finish_bag(arp_ctx* c, Bag& b, int slot) {
 }
 int grow_pairs(arp_ctx* c) {
     const size_t need = ((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 64) * PAIR_SEGS;
+    c->res_tag.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     HIPCHK(c, c->pairs.reserve(need));
     return ARP_OK;
@@ -871,11 +976,22 @@ int arp_create(int device, arp_ctx** out) {
     arp_ctx* c = new (std::nothrow) arp_ctx();
     if (!c) return ARP_E_NOMEM;
     c->device = device;
+    // the fused scan + scatter keeps the whole start table in LDS: up to 144 KB of the CU's 160 KB
+    (void)hipFuncSetAttribute((const void*)k_scan_scatter_atoms<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+    (void)hipFuncSetAttribute((const void*)k_scan_scatter_atoms<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
+    (void)hipFuncSetAttribute((const void*)k_scan_scatter_atoms<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
+    (void)hipFuncSetAttribute((const void*)k_scan_scatter_atoms<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 16384);
+    (void)hipFuncSetAttribute((const void*)k_scan_scatter_atoms<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+    (void)hipFuncSetAttribute((const void*)k_scan_scatter_atoms<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     c->stream = c->own_stream;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) {   // the second stream (ring / amide kernel) yields to the main one
+        int lo_prio = 0, hi_prio = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+        e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo_prio);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_COUNT);
@@ -908,7 +1024,6 @@ void arp_destroy(arp_ctx* c) {
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->ring_home.release(); c->am_home.release(); c->ring_gid.release(); c->am_gid.release();
-    drop_graph(c);
     if (c->h_ctr_pinned) (void)hipHostFree(c->h_ctr_pinned);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
@@ -938,7 +1053,6 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     HIPCHK(c, hipSetDevice(c->device));
     // uploads below are enqueued together; whatever the exit path, they are complete before the staging vectors die
     struct SyncOnExit { arp_ctx* c; ~SyncOnExit() { (void)hipStreamSynchronize(c->stream); } } sync_on_exit{c};
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     c->n = n;
     c->h_xyz.assign(xyz, xyz + 3 * n);
@@ -1006,7 +1120,6 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
     if (nres < 0 || (nres > 0 && (!res_flags || !prev || !next))) FAIL(c, ARP_E_ARG, "arp_set_residues: bad input");
     if (nres <= c->max_res_id) FAIL(c, ARP_E_ARG, "arp_set_residues: an atom refers to a residue beyond the table");
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     c->nres = nres;
     CHK(upload(c, c->res_flags, res_flags, (size_t)nres));
@@ -1023,7 +1136,6 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
 int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) {
     if (!c || !bond_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     if (!csr_ok(bond_off, c->n)) FAIL(c, ARP_E_ARG, "arp_set_bonds: offsets must start at 0 and never decrease");
     const int64_t m = bond_off[c->n];
@@ -1037,7 +1149,6 @@ int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) 
 int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
     if (!c || !h_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     if (!csr_ok(h_off, c->n)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: offsets must start at 0 and never decrease");
     const int64_t m = h_off[c->n];
@@ -1051,7 +1162,6 @@ int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
 int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
     if (!c || (c->n > 0 && !sb_nbr)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     for (int64_t i = 0; i < c->n; ++i)
         if (sb_nbr[i] < -1 || sb_nbr[i] >= c->n) FAIL(c, ARP_E_ARG, "arp_set_single_bond_neighbours: index out of range");
@@ -1077,7 +1187,6 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
         c->max_ring_res = std::max<int64_t>(c->max_ring_res, ring_res[i]);
     }
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     c->nring = nring;
     host_bbox_d(center, nring, c->ring_lo, c->ring_hi);
@@ -1102,7 +1211,6 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
         c->max_amide_res = std::max<int64_t>(c->max_amide_res, amide_res[i]);
     }
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     c->namide = namide;
     host_bbox(center, namide, c->am_lo, c->am_hi);
@@ -1120,7 +1228,6 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
 int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_id) {
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     if (is_home) { CHK(upload(c, c->home, is_home, (size_t)c->n)); c->has_home = true; }
     else c->has_home = false;
@@ -1140,7 +1247,6 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
                             const int32_t* amide_gid) {
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     if (!ring_home && !ring_gid && !amide_home && !amide_gid) { c->has_group_owner = false; return ARP_OK; }
     if ((c->nring > 0 && (!ring_home || !ring_gid)) || (c->namide > 0 && (!amide_home || !amide_gid)))
@@ -1158,7 +1264,6 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
 int arp_set_single_bond_neighbour_coords(arp_ctx* c, const float* sb_xyz, const uint8_t* sb_present) {
     if (!c || (c->n > 0 && (!sb_xyz || !sb_present))) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     std::vector<float4> sb((size_t)c->n);
     for (int64_t i = 0; i < c->n; ++i)
@@ -1175,7 +1280,6 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
         (c->namide > 0 && (!amide_sel || !amide_plus)))
         FAIL(c, ARP_E_ARG, "arp_set_selection_state: null input");
     HIPCHK(c, hipSetDevice(c->device));
-    ++c->input_epoch;   // invalidates a captured graph
     c->static_dirty = true;
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     CHK(upload(c, c->plus, in_plus, (size_t)c->n));
@@ -1232,7 +1336,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, 0, c->pairs.p,
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
                            (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, (uint8_t*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
@@ -1294,7 +1398,7 @@ int arp_atom_contacts_launch(arp_ctx* c, double cutoff, double vdw_comp, int inc
     HIPCHK(c, hipSetDevice(c->device));
     CHK(ensure_default_selection(c));
     for (int attempt = 0;; ++attempt) {
-        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent, false));
         CHK(read_counters(c));
         collect_events(c);
         if (!finish_contacts(c)) break;
@@ -1511,50 +1615,44 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
     };
     auto enqueue_all = [&]() -> int {
         c->ctr_clean = true;
-        struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
+        struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; c->pub.expected = 0; c->fuse_sets = false; c->init_plus_in_bin = false; } } unclean{c};
         CHK(ensure_static(c));
-        // Whole-structure selection (the reference's default, I:1395 with no selectors): selection_plus is the
-        // selection, so nothing on the contact path waits for _make_selection — the 6 A grid (still needed by the
-        // atom-plane kernel) moves to stream2 with the rest of the ring / amide work.
-        // A small selection (ligand, binding site: nsel <= SMALL_SEL_MAX) gets selection_plus from a direct test of
-        // every atom against the selected ones — one short kernel — and then forks the same way.
-        // (worth it while the N x S direct tests stay below ~1.7e7: 160 selected atoms in a 100 k-atom structure)
+        // The pass ends inside its last kernel (k_sift_planes): the last block to finish publishes the counters.
+        static const int inkernel_publish = env_int("ARP_INKERNEL_PUBLISH", 1);
+        c->pub = PublishArgs{c->d_ctr, c->h_ctr_pinned, 0, 0};
+        if (inkernel_publish && !c->external_stream) {
+            c->pub.expected = 1;
+            c->pub.seq = ++c->publish_seq;
+        }
+        // _make_selection (I:1384-1424).  Whole-structure selection (the reference's default, I:1395 with no
+        // selectors): selection_plus is the selection, nothing to search.  A small selection (ligand, binding site:
+        // nsel <= SMALL_SEL_MAX, worth it while the N x S direct tests stay below ~1.7e7) gets selection_plus from a
+        // direct test of every atom against the selected ones — one short kernel.  Anything else: the all-atom 6 A
+        // grid and the expansion search.
         const bool small_sel = !c->sel_all && c->nsel > 0 && c->nsel <= SMALL_SEL_MAX && c->n > 0 && !c->has_home &&
                                c->n * c->nsel <= (int64_t)1 << 24;
-        const bool fork_early = c->sel_all || small_sel;
-        if (!fork_early) CHK(enqueue_expansion(c, expand_radius));                  // I:342 (I:1384-1424)
+        if (c->sel_all || small_sel) {
+            c->sel_made = true;
+            HIPCHK(c, c->plus.reserve((size_t)std::max<int64_t>(c->n, 1)));
+            c->contacts_valid = false;
+            c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
+            c->init_plus_in_bin = c->sel_all;      // selection_plus = selection: written by the contact grid's binning kernel
+        } else {
+            CHK(enqueue_expansion(c, expand_radius));                                // I:342 (I:1384-1424)
+        }
         if (small_sel) {
-            HIPCHK(c, c->plus.reserve((size_t)c->n));
             Prof p(c, SLOT_MARK);
             hipLaunchKernelGGL(k_expand_small, dim3(nblocks(c->n, 256, 1 << 22)), dim3(256), 0, c->stream, (int)c->n, c->xyz.p, c->sel_list.p,
                                (int)c->nsel, c->sel.p, expand_radius * expand_radius, c->plus.p, c->d_ctr + C_STAT_MCAND);
             CHK(check_launch(c, "k_expand_small"));
         }
-        // ring grids are built (once) on the main stream before the fork
+        // ring / amide grids: built once per structure
         if (c->nring > 0) CHK(ensure_ring_grid(c));
         if (c->namide > 0) CHK(ensure_amide_grid(c));
-        // fork: the residue/ring/amide sets and the four small ring/amide kernels only need selection_plus and
-        // the 6 A grid; they run on stream2 underneath the contact pipeline (grid build + search + sift)
-        HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
-        // the host needs ~3 us per launch: the critical path (contact pipeline) is enqueued first, the small
-        // launches of stream2 afterwards — they have ~90 us of search + sift to hide under
-        if (fork_early) {
-            c->sel_made = true;
-            HIPCHK(c, c->plus.reserve((size_t)std::max<int64_t>(c->n, 1)));
-        }
-        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // I:345
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
-        if (c->sel_all) CHK(enqueue_expansion(c, expand_radius, c->stream2));
-        else if (small_sel) {
-            // selection_plus exists already: only the 6 A grid of the atom-plane kernel is still to be built
-            CHK(build_all_grid(c, expand_radius, nullptr, c->stream2));
-            c->contacts_valid = false;
-            c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
-        }
-        CHK(enqueue_selection_sets(c, c->stream2));                                 // I:1413-1437
-        CHK(enqueue_planes(c, c->stream2));                                         // I:346-347 (I:944-945, 1214-1215)
-        HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));                  // join
+        // I:1413-1437 (residue / ring / amide sets) ride on the contact grid build, I:345-347 in three launches
+        c->fuse_sets = true;
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent, true));
+        if (c->pub.expected) return ARP_OK;                                         // the last kernel publishes (pass_end)
         return enqueue_counter_copy(c, 1);
     };
     auto any_overflow = [&](bool grow) -> int {   // returns 1 when a buffer was too small (and regrows it if asked)
@@ -1566,55 +1664,7 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         if (finish_bag(c, c->bag_gp, C_GP)) { if (grow) CHK(grow_bag(c, c->bag_gp, C_GP, true, false)); again = 1; }
         return again;
     };
-    // Graph replay of the pass is optional (ARP_GRAPH=1): on MI355X the direct launches already keep the GPU
-    // busy back to back (measured 0.261 ms direct vs 0.273 ms replayed per 100k-atom pass), so it is off by default.
-    static const int use_graph = env_int("ARP_GRAPH", 0);
-    const arp_ctx::GraphKey key{cutoff, vdw_comp, expand_radius, include_sequence_adjacent, g_alloc_epoch.load(), c->input_epoch, true};
-    auto same = [](const arp_ctx::GraphKey& a, const arp_ctx::GraphKey& b) {
-        return a.valid && b.valid && a.cutoff == b.cutoff && a.comp == b.comp && a.expand == b.expand && a.seq_adj == b.seq_adj &&
-               a.alloc_epoch == b.alloc_epoch && a.input_epoch == b.input_epoch;
-    };
     bool done = false;
-    if (use_graph && c->graph_ok && !c->profiling) {
-        if (c->graph_exec && same(c->gkey, key)) {
-            // replay: the launch-bound chain of ~25 small kernels costs one graph launch on the host
-            CHK(ensure_zero());
-            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-            CHK(collect_counters(c, true));
-            c->ctr_zero_ok = true;
-            const int ov = any_overflow(false);
-            if (ov < 0) return ov;
-            if (ov == 0) done = true;        // (an overflow cannot happen with unchanged inputs; fall through if it does)
-            else drop_graph(c);
-        } else if (same(c->last_key, key)) {
-            // second identical call: everything is sized, capture the pass
-            drop_graph(c);
-            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            int rc = ARP_OK;
-            if (ok) {
-                rc = enqueue_all();
-                hipGraph_t g = nullptr;
-                ok = (hipStreamEndCapture(c->stream, &g) == hipSuccess) && g && rc == ARP_OK && g_alloc_epoch == key.alloc_epoch;
-                if (ok) ok = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
-                if (ok) { c->graph = g; c->gkey = key; }
-                else if (g) (void)hipGraphDestroy(g);
-            }
-            if (!ok) {
-                (void)hipGetLastError();
-                c->graph_ok = false;         // direct launches from now on
-                drop_graph(c);
-            } else {
-                CHK(ensure_zero());
-                HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-                CHK(collect_counters(c, true));
-                c->ctr_zero_ok = true;
-                const int ov = any_overflow(false);
-                if (ov < 0) return ov;
-                if (ov == 0) done = true;
-                else drop_graph(c);
-            }
-        }
-    }
     for (int attempt = 0; !done; ++attempt) {
         const auto t0 = std::chrono::steady_clock::now();
         CHK(ensure_zero());
@@ -1632,8 +1682,6 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         if (!again) break;
         if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_launch: result buffers could not be sized");
     }
-    c->last_key = key;
-    c->last_key.alloc_epoch = g_alloc_epoch.load();
     c->stats[5] = (int64_t)c->h_ctr[C_MARK_CAND];
     c->stats[6] = (int64_t)c->h_ctr[C_MARK_ACC];
     if (counts) {
@@ -1710,12 +1758,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         CHK(check_launch(c, "k_group_mask"));
         if (c->nring > 0) CHK(ensure_ring_grid(c));
         if (c->namide > 0) CHK(ensure_amide_grid(c));
-        HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
-        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent));     // critical path first (see arp_run_launch)
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
-        CHK(enqueue_planes(c, c->stream2));
-        HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
+        CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent, true));
         CHK(enqueue_counter_copy(c));
         CHK(collect_counters(c));
         collect_events(c);
@@ -1746,7 +1789,7 @@ int arp_get_stats(arp_ctx* c, int64_t stats[8]) {
 
 int arp_set_profiling(arp_ctx* c, int enabled) {
     if (!c) return ARP_E_ARG;
-    c->profiling = enabled != 0;   // profiled passes use direct launches bracketed by events (no graph replay)
+    c->profiling = enabled != 0;   // launches bracketed by HIP events on their own streams
     return ARP_OK;
 }
 
@@ -1856,7 +1899,6 @@ int arp_host_free(void* p) {
 int arp_set_whole_structure(arp_ctx* c, int enabled) {
     if (!c) return ARP_E_ARG;
     c->whole_structure = enabled != 0;
-    ++c->input_epoch;
     c->contacts_valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
     return ARP_OK;
@@ -1882,7 +1924,6 @@ int arp_use_stream(arp_ctx* c, uint64_t stream) {
         c->stream = (hipStream_t)(uintptr_t)stream;
         c->external_stream = true;
     }
-    ++c->input_epoch;
     return ARP_OK;
 }
 

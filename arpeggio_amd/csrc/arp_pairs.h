@@ -48,7 +48,10 @@ enum {
     // the pair list is written in PAIR_SEGS segments, one queue head per XCD (blockIdx % 8): the
     // per-block atomicAdd then runs on 8 different L2s instead of serialising on one address
     C_SEG_PAIRS = 16 + 256,
-    C_COUNT = 16 + 256 + 8
+    // end-of-pass tickets (pass_end): blocks of k_sift / k_planes that have finished, kernels that have finished
+    // (two sets of 8 group tickets + 1 kernel ticket: the sift kernel and the ring / amide kernel end a pass together)
+    C_TICKET_GROUP = 16 + 256 + 16, C_TICKET_KERNEL = 16 + 256 + 24, C_TICKET_SET = 16, C_KERNELS_DONE = 16 + 256 + 15,
+    C_COUNT = 16 + 256 + 48
 };
 #define STAT_SLOTS 64
 #define PAIR_SEGS 8
@@ -148,48 +151,202 @@ __device__ __forceinline__ float4 compose_xyzm(const StaticAtoms& r, int i) {
     return v;
 }
 
-// cell id + histogram of the atoms passing the filter:
-// FILTER 1: active[i] != 0;  FILTER 2: (meta & req) == req && !(meta & forb)
-template <int FILTER>
-__global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDesc g, const uint8_t* __restrict__ active,
-                                                   uint32_t req, uint32_t forb, int* __restrict__ cell_of,
-                                                   int* __restrict__ cell_cnt, uint8_t* __restrict__ plus_init) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 xyzm = compose_xyzm(r, i);
-        if (plus_init) plus_init[i] = r.all ? (uint8_t)1 : r.sel[i];   // I:1407: selection_plus starts as the selection
-        const uint32_t m = __float_as_uint(xyzm.w);
-        const bool on = (FILTER == 1) ? (active[i] != 0) : (((m & req) == req) && !(m & forb));
-        int c = -1;
-        if (on) {
-            c = cell_index(g, num::d3{(double)xyzm.x, (double)xyzm.y, (double)xyzm.z});
-            atomicAdd(&cell_cnt[c], 1);
-        }
-        cell_of[i] = c;
+// Residue / ring / amide sets of _make_selection (I:1413-1437) ride along with the contact grid build: the binning
+// kernel, which reads every atom's selection bits anyway, tags the residues (ResMarks; tag = pass number mod 255 + 1, so
+// the arrays never need clearing), and the scatter kernel — the next launch, i.e. after every tag is in place — turns
+// them into the ring / amide masks (GroupMasks).  Null pointers / zero counts switch either part off.
+struct ResMarks {
+    uint8_t* res_sel;
+    uint8_t* res_plus;
+    uint8_t tag;
+};
+struct GroupMasks {
+    int nring, namide;          // 0, 0: nothing to do
+    const int* ring_res;
+    const int* amide_res;
+    const uint8_t* res_sel;
+    const uint8_t* res_plus;
+    uint8_t tag;
+    int all;                    // every residue counts as selected (arp_set_whole_structure)
+    uint8_t* ring_sel;
+    uint8_t* ring_plus;
+    uint8_t* amide_sel;
+    uint8_t* amide_plus;
+};
+__device__ __forceinline__ void group_masks(const GroupMasks& gm, int first, int stride) {
+    for (int i = first; i < gm.nring + gm.namide; i += stride) {
+        const bool ring = i < gm.nring;
+        const int k = ring ? i : i - gm.nring;
+        const int r = ring ? gm.ring_res[k] : gm.amide_res[k];
+        const uint8_t s_ = (r >= 0 && (gm.all || gm.res_sel[r] == gm.tag)) ? 1 : 0;    // a ring whose residue is None never qualifies
+        const uint8_t p_ = (r >= 0 && (gm.all || gm.res_plus[r] == gm.tag)) ? 1 : 0;
+        if (ring) { gm.ring_sel[k] = s_; gm.ring_plus[k] = p_; }
+        else { gm.amide_sel[k] = s_; gm.amide_plus[k] = p_; }
     }
 }
 
-// counting-sort scatter fused with the record build: every binned atom writes its cell-sorted
-// search record (xyzm + aux, 32 B) and, for the contact grid, its sift record (32 B).
-__global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int* __restrict__ cell_of,
-                                                       const int* __restrict__ start, int* __restrict__ cell_cnt,
-                                                       float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
-                                                       SiftRec* __restrict__ s_rec) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int c = cell_of[i];
-        if (c < 0) continue;
-        // the record does not depend on the slot: its loads are in flight while the atomic returns
+__global__ __launch_bounds__(256) void k_group_masks(GroupMasks gm) {   // structures without atoms: no scatter launch to ride on
+    group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// cell id + histogram of the atoms passing the filter:
+// FILTER 1: active[i] != 0;  FILTER 2: (meta & req) == req && !(meta & forb)
+// The returning atomicAdd hands every atom its rank inside its cell, so the scatter needs no atomics of its own
+// (device-scope atomics execute at the memory side: ~10 k per microsecond whatever the kernel around them does, and a
+// second round of them was a third of the grid build).  The histogram is double-buffered: this build counts in `cell_cnt`
+// and clears the buffer of the previous build (`zero_other`), which nothing reads any more.
+template <int FILTER>
+__global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDesc g, const uint8_t* __restrict__ active,
+                                                   uint32_t req, uint32_t forb, int2* __restrict__ cell_rank,
+                                                   int* __restrict__ cell_cnt, uint8_t* __restrict__ plus_init,
+                                                   int* __restrict__ zero_other, int nzero, ResMarks rm) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < nzero; k += stride * 4)
+        *reinterpret_cast<int4*>(zero_other + k) = make_int4(0, 0, 0, 0);          // (buffers are padded to a multiple of 4)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float4 xyzm = compose_xyzm(r, i);
-        const int4 aux = r.aux[i];
-        SiftRec q;
-        if (s_rec) q.q1 = r.q1[i];
-        const int pos = start[c] + atomicSub(&cell_cnt[c], 1) - 1;
-        s_xyzm[pos] = xyzm;
-        s_aux[pos] = aux;
-        if (s_rec) {   // the contact grid also carries the sift record
-            q.xyzm = xyzm;
-            s_rec[pos] = q;
+        if (plus_init) plus_init[i] = r.all ? (uint8_t)1 : r.sel[i];   // I:1407: selection_plus starts as the selection
+        const uint32_t m = __float_as_uint(xyzm.w);
+        if (rm.res_sel) {   // I:1413, 1431: residues of the selection / of selection_plus (hydrogens included), tagged with the pass
+            const int res = r.aux[i].y;
+            if (m & M_SEL) rm.res_sel[res] = rm.tag;
+            if (m & M_PLUS) rm.res_plus[res] = rm.tag;
         }
+        const bool on = (FILTER == 1) ? (active[i] != 0) : (((m & req) == req) && !(m & forb));
+        int c = -1, rank = 0;
+        if (on) {
+            c = cell_index(g, num::d3{(double)xyzm.x, (double)xyzm.y, (double)xyzm.z});
+            rank = atomicAdd(&cell_cnt[c], 1);
+        }
+        cell_rank[i] = make_int2(c, rank);
     }
+}
+
+// one atom's cell-sorted records (search record 32 B; the contact grid adds the 32-byte sift record)
+__device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos, float4* __restrict__ s_xyzm,
+                                            int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec) {
+    const float4 xyzm = compose_xyzm(r, i);
+    s_xyzm[pos] = xyzm;
+    s_aux[pos] = r.aux[i];
+    if (s_rec) {
+        SiftRec q;
+        q.xyzm = xyzm;
+        q.q1 = r.q1[i];
+        s_rec[pos] = q;
+    }
+}
+
+// counting-sort scatter fused with the record build, start table from a separate scan (large grids)
+__global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int2* __restrict__ cell_rank,
+                                                       const int* __restrict__ start, float4* __restrict__ s_xyzm,
+                                                       int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec, GroupMasks gm) {
+    group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 cr = cell_rank[i];
+        if (cr.x < 0) continue;
+        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_rec);
+    }
+}
+
+// Grids whose start table fits in LDS (<= SCAN_LDS_CELLS cells: every structure below ~250 k atoms at 5 A): scan and
+// scatter in ONE launch.  Every 1024-thread block scans the whole histogram itself — 70 KB out of L2, all blocks at
+// once, against ~11 us for a single-block scan kernel that one CU's load bandwidth bounds, plus a launch — keeps the
+// exclusive prefix in LDS, writes its slice of the global start table (the search reads it) and scatters its
+// SCAT_ATOMS atoms.  Wave w scans cells [w * chunk, (w + 1) * chunk) in steps of 256 (one coalesced int4 load per
+// lane and step, all STEPS loads in flight together), shuffles inside the wave, no barrier until the 16 wave totals
+// meet; the LDS table holds prefixes relative to the wave's first cell, the wave offsets sit beside it.
+#define SCAT_ATOMS 1024
+#define SCAN_LDS_CELLS (16 * 9 * 256)
+template <int STEPS>
+__global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int n, int ncell, const int2* __restrict__ cell_rank,
+                                                             const int* __restrict__ cell_cnt, int* __restrict__ start,
+                                                             unsigned long long* __restrict__ total_out,
+                                                             float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
+                                                             SiftRec* __restrict__ s_rec, GroupMasks gm) {
+    extern __shared__ __attribute__((aligned(16))) int s_start[];   // 16 * STEPS * 256 ints
+    group_masks(gm, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024);
+    __shared__ int s_wtot[16], s_woff[17];
+    constexpr int CHUNK = STEPS * 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * SCAT_ATOMS + threadIdx.x;
+    const int2 cr = (i < n) ? cell_rank[i] : make_int2(-1, 0);      // in flight beside the histogram loads
+    int4 v[STEPS];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        const int c0 = wv * CHUNK + k * 256 + lane * 4;             // (the histogram is padded: reads past ncell are in bounds)
+        const int4 q = *reinterpret_cast<const int4*>(cell_cnt + c0);
+        v[k] = make_int4(c0 < ncell ? q.x : 0, c0 + 1 < ncell ? q.y : 0, c0 + 2 < ncell ? q.z : 0, c0 + 3 < ncell ? q.w : 0);
+    }
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        const int t = v[k].x + v[k].y + v[k].z + v[k].w;
+        int incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
+        }
+        const int e = run + incl - t;
+        *reinterpret_cast<int4*>(s_start + wv * CHUNK + k * 256 + lane * 4) = make_int4(e, e + v[k].x, e + v[k].x + v[k].y, e + v[k].x + v[k].y + v[k].z);
+        run += __shfl(incl, 63);
+    }
+    if (lane == 0) s_wtot[wv] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < 16; ++k) { s_woff[k] = acc; acc += s_wtot[k]; }
+        s_woff[16] = acc;
+    }
+    __syncthreads();
+    const int total = s_woff[16];
+    {   // global start table: block b writes slice b (start[ncell] = the grand total)
+        const int per = ((ncell + 1 + gridDim.x - 1) / gridDim.x + 3) & ~3;
+        const int lo = blockIdx.x * per, hi = min(lo + per, ncell + 1);
+        for (int k = lo + threadIdx.x; k < hi; k += 1024) start[k] = (k < ncell) ? s_start[k] + s_woff[k / CHUNK] : total;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = (unsigned long long)total;
+    }
+    if (cr.x >= 0) scatter_one(r, i, s_start[cr.x] + s_woff[cr.x / CHUNK] + cr.y, s_xyzm, s_aux, s_rec);
+}
+
+// ---- end of a pass, without a launch of its own ------------------------------------------------------------
+// The last kernels of a pass (k_sift on the main stream, k_planes beside it on the second one) call pass_end() as their
+// final statement: every block takes a ticket once its own atomics have been performed, the last block of a kernel
+// bumps the kernel count, and the last block of the last kernel publishes the counter block to the pinned host copy,
+// returns it to zero for the next pass and stores the pass number the host is polling — what k_publish_counters does
+// as a separate 5 us launch behind a cross-stream join.  expected = 0 switches it off (callers that publish themselves).
+struct PublishArgs {
+    u64* ctr;        // C_COUNT device counters
+    u64* host;       // pinned mirror, C_COUNT + 1 words (the last one = completion word)
+    int expected;    // kernels that end this pass (0: off)
+    u64 seq;         // value of the completion word for this pass
+};
+// Tickets are hierarchical — one counter per (blockIdx % 8), i.e. per XCD as the dispatcher places blocks, then one for
+// the eight groups — because same-address atomics run at ~90 per microsecond: 2500 blocks on one word were a 15 us tail.
+__device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
+    if (!pa.expected) return;
+    u64* const tickets = pa.ctr + set * C_TICKET_SET;
+    __shared__ int s_publisher;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's counter atomics have been performed (memory side)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int pub = 0;
+        const unsigned grp = blockIdx.x & 7u;
+        const u64 members = ((u64)gridDim.x + 7ull - grp) >> 3;                  // blocks b < gridDim.x with b % 8 == grp
+        if (atomicAdd(tickets + C_TICKET_GROUP + grp, 1ull) == members - 1ull) {
+            const u64 groups = gridDim.x < 8u ? (u64)gridDim.x : 8ull;
+            if (atomicAdd(tickets + C_TICKET_KERNEL, 1ull) == groups - 1ull)            // last block of this kernel
+                pub = atomicAdd(pa.ctr + C_KERNELS_DONE, 1ull) == (u64)pa.expected - 1ull;
+        }
+        s_publisher = pub;
+    }
+    __syncthreads();
+    if (!s_publisher) return;
+    // returning atomics read the memory-side value whatever this XCD's L2 holds, and leave the slot zero
+    for (int i = threadIdx.x; i < (int)C_COUNT; i += blockDim.x) pa.host[i] = atomicExch(pa.ctr + i, 0ull);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pa.host + C_COUNT, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- neighbour search ---------------------------------------------------------------
@@ -227,7 +384,7 @@ template <int MODE>
 __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
-                                                               int include_seq_adj, int count_owned, int ablate, int2* __restrict__ pairs,
+                                                               int include_seq_adj, int count_owned, int2* __restrict__ pairs,
                                                                unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus) {
@@ -307,10 +464,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
         const int o2 = o1 + __builtin_amdgcn_readlane(my_len, ci * 8 + 1);
         const int o3 = o2 + __builtin_amdgcn_readlane(my_len, ci * 8 + 2);
         const int o4 = o3 + __builtin_amdgcn_readlane(my_len, ci * 8 + 3);
-        const int total = (ablate & 8) ? 0 : o4 + __builtin_amdgcn_readlane(my_len, ci * 8 + 4);
+        const int total = o4 + __builtin_amdgcn_readlane(my_len, ci * 8 + 4);
 #pragma unroll 1
         for (int hb = hs; hb < he; hb += HOME_BLOCK) {  // home atoms, 32 at a time: one bit each in the per-lane hit masks
-            const int hcount = (ablate & 4) ? 0 : min(HOME_BLOCK, he - hb);
+            const int hcount = min(HOME_BLOCK, he - hb);
             const bool hvalid = lane < hcount;
             const int hpos = min(hb + lane, he - 1);   // (clamped: no branch around the loads; lanes >= hcount are never read)
             const float4 hreg = s_xyzm[hpos];
@@ -411,7 +568,6 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                     }
                 }
                 n_acc += __popc(lo0) + __popc(lo1);
-                if (ablate & 2) continue;
                 // ---- stage 2: every lane walks its own hits (residue filters, orientation, queueing)
                 while (__any((lo0 | lo1) != 0)) {
                     const bool has = (lo0 | lo1) != 0;
@@ -457,7 +613,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                         pb = min(ah.x, aj.x);
                         pe = max(ah.x, aj.x);
                     }
-                    const unsigned long long mp = (ablate & 1) ? 0ull : __ballot(pass);
+                    const unsigned long long mp = __ballot(pass);
                     if (mp) {
                         if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
                         qn += __popcll(mp);
@@ -602,11 +758,10 @@ __device__ __forceinline__ int rec_h_cnt(int4 q1, const SiftSide& sd) {
 // The hydrogen geometry of one pair: the branches in `need` (bit k = branch k of the list in k_sift), run on a
 // lane of the task stage.  Returns the SIFt bits they add.
 __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftRec& qe, unsigned need, const double* __restrict__ h_xyz,
-                                                  const double2* s_tab, const SiftSide& sd, double comp, int ablate) {
+                                                  const double2* s_tab, const SiftSide& sd, double comp) {
     const num::f3 xb = xyz_of(qb.xyzm), xe = xyz_of(qe.xyzm);
     const double vb = rec_rad(qb.q1, s_tab, sd).x, ve = rec_rad(qe.q1, s_tab, sd).x;
-    const int hb0 = qb.q1.z, hb1 = (ablate & 16) ? hb0 : hb0 + rec_h_cnt(qb.q1, sd), he0 = qe.q1.z,
-              he1 = (ablate & 16) ? he0 : he0 + rec_h_cnt(qe.q1, sd);   // (ablate: profiling aid, ARP_ABLATE)
+    const int hb0 = qb.q1.z, hb1 = hb0 + rec_h_cnt(qb.q1, sd), he0 = qe.q1.z, he1 = he0 + rec_h_cnt(qe.q1, sd);
     unsigned todo = need, res = 0;
     while (todo) {                     // almost always one branch per pair
         const int kind = __ffs(todo) - 1;
@@ -637,21 +792,53 @@ __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftR
 }
 
 #define SIFT_TASKQ 128
-__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __restrict__ pairs, const u64* __restrict__ npairs_ptr, u64 cap,
-                                              const SiftRec* __restrict__ s_rec, SiftSide sd, const int* __restrict__ bond_idx,
-                                              const double* __restrict__ h_xyz,
-                                              const int* __restrict__ gid, double comp, int ablate, int* __restrict__ out_i,
-                                              int* __restrict__ out_j, float* __restrict__ out_d,
-                                              uint16_t* __restrict__ out_s, uint8_t* __restrict__ out_ct,
-                                              int* __restrict__ err) {
+struct SiftArgs {
+    const int2* pairs;
+    const u64* npairs_ptr;
+    u64 cap;
+    const SiftRec* s_rec;
+    SiftSide sd;
+    const int* bond_idx;
+    const double* h_xyz;
+    const int* gid;
+    double comp;
+    int* out_i;
+    int* out_j;
+    float* out_d;
+    uint16_t* out_s;
+    uint8_t* out_ct;
+    int* err;
+};
+struct SiftShared {
+    uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
+    double2 tab[RAD_TABLE];      // the structure's distinct {vdw, cov} pairs
+};
+// vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
+// vblock % 8 is still the XCD the dispatcher put the block on)
+__device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgrid, SiftShared* sh) {
+    const int2* __restrict__ pairs = A.pairs;
+    const u64* __restrict__ npairs_ptr = A.npairs_ptr;
+    const u64 cap = A.cap;
+    const SiftRec* __restrict__ s_rec = A.s_rec;
+    const SiftSide sd = A.sd;
+    const int* __restrict__ bond_idx = A.bond_idx;
+    const double* __restrict__ h_xyz = A.h_xyz;
+    const int* __restrict__ gid = A.gid;
+    const double comp = A.comp;
+    int* __restrict__ out_i = A.out_i;
+    int* __restrict__ out_j = A.out_j;
+    float* __restrict__ out_d = A.out_d;
+    uint16_t* __restrict__ out_s = A.out_s;
+    uint8_t* __restrict__ out_ct = A.out_ct;
+    int* __restrict__ err = A.err;
+    uint4 (*tq)[SIFT_TASKQ] = sh->tq;
+    double2* s_tab = sh->tab;
     // Two stages per wavefront.  Stage A, one lane per pair: everything of I:715-936 that needs no hydrogen — distance
     // ladder, metal, type-pair flags, halogen bond — and the list of hydrogen-geometry branches the pair needs:
     //   0 is_hbond(bgn, end)   1 is_hbond(end, bgn)          (if / elif, I:804-819)
     //   2 is_weak_hbond(end, bgn)   3 is_weak_hbond(bgn, end)   4 / 5 is_halogen_weak_hbond  (I:857-886)
     // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
     // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
-    __shared__ uint4 tq[4][SIFT_TASKQ];   // {output index, bgn position, end position, sift | need << 16}
-    __shared__ double2 s_tab[RAD_TABLE];   // the structure's distinct {vdw, cov} pairs
     s_tab[threadIdx.x] = sd.rad_tab[threadIdx.x];   // (blockDim.x == RAD_TABLE)
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -659,22 +846,22 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(const int2* __rest
     auto run_tasks = [&](int first, int count) {   // stage B on tq[w][first .. first + count)
         if (lane < count) {
             const uint4 t = tq[w][first + lane];
-            const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, s_tab, sd, comp, ablate);
+            const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, s_tab, sd, comp);
             out_s[t.x] = (uint16_t)((t.w & 0xFFFFu) | add);
         }
     };
     // The segment fill counts are read on the device: no host round trip between search and sift.
     // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
     // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
-    const int sgm = blockIdx.x & (PAIR_SEGS - 1);
+    const int sgm = vblock & (PAIR_SEGS - 1);
     long long out_base = 0;
 #pragma unroll
     for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
         if (q_ < sgm) out_base += (long long)min(npairs_ptr[q_], cap);
     const long long nseg = (long long)min(npairs_ptr[sgm], cap);
     const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
-    const long long stride = (long long)(gridDim.x / PAIR_SEGS) * blockDim.x;
-    for (long long base = (long long)(blockIdx.x / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane); base < nseg; base += stride) {
+    const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
+    for (long long base = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane); base < nseg; base += stride) {
         const long long ps = base + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
         bool queued = false;
         uint4 task = make_uint4(0u, 0u, 0u, 0u);

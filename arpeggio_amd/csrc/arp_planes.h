@@ -126,10 +126,47 @@ struct PlaneQueue {
         n = 0;
     }
 };
+#define PAIR_QCAP 192
 struct PlaneShared {   // LDS of one 256-thread block of a ring / amide kernel
     PlaneRec q[4][PLANE_QCAP];
+    int2 pq[4][PAIR_QCAP];     // candidate pairs that passed the cheap distance pre-filter, waiting for a full wave
     u64 base;
     int n[4];
+};
+
+// Two-phase evaluation.  The geometry of a ring / amide pair is float64 acos / sqrt / division chains — hundreds of
+// instructions — while an item has only a handful of partners inside its stencil, so evaluating in place keeps a few
+// lanes of the wave busy.  Phase 1 therefore only enumerates: every lane tests one candidate with a cheap squared
+// distance (a superset of the reference's cut-off test) and the survivors are compacted into a per-wave LDS queue of
+// {home, partner} ids across items; phase 2 runs whenever 64 pairs have gathered (and once at the end) with one pair
+// per lane, full lanes, and applies the reference's exact sequence.
+struct PairQueue {
+    int2* q;
+    int n;
+    template <class Eval>
+    __device__ __forceinline__ void push(bool ok, int x, int y, int lane, Eval eval) {
+        const unsigned long long m = __ballot(ok);
+        if (!m) return;
+        if (ok) q[n + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(x, y);
+        n += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (n >= 64) {
+            n -= 64;
+            const int2 pr = q[n + lane];
+            __builtin_amdgcn_wave_barrier();
+            eval(true, pr.x, pr.y);
+        }
+    }
+    template <class Eval>
+    __device__ __forceinline__ void drain(int lane, Eval eval) {
+        __builtin_amdgcn_wave_barrier();
+        if (n > 0) {   // (wave-uniform)
+            const bool live = lane < n;
+            const int2 pr = live ? q[lane] : make_int2(0, 0);
+            eval(live, pr.x, pr.y);
+        }
+        n = 0;
+    }
 };
 
 // One wavefront per ring; lanes sweep the atoms of the 27 cells around the ring centre =
@@ -172,59 +209,67 @@ __device__ __forceinline__ void atom_plane_body(GridDesc g, const int* __restric
                                                     double* __restrict__ out_theta, uint8_t* __restrict__ out_mask,
                                                     uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
     PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
     auto write = [&](long long slot, const PlaneRec& t) {
         out_atom[slot] = t.i0; out_ring[slot] = t.i1;
         out_dist[slot] = t.d0; out_theta[slot] = t.d1;
         out_mask[slot] = (uint8_t)(t.u & 255u); out_ct[slot] = (uint8_t)((t.u >> 8) & 255u);
     };
     const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int r, int j) {   // ring r, atom at sorted position j (inside the tree radius, I:960)
+        bool emit = false;
+        PlaneRec rec;
+        if (live) {
+            const num::d3 ctr_ = ld3(ring_c, r), nrm = ld3(ring_n, r);
+            const float4 v = s_xyzm[j];
+            const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
+            const uint32_t m = __float_as_uint(v.w);
+            const int lid = s_aux[j].x;
+            const double dist = num::norm(num::sub(x, ctr_));                        // I:972
+            const int ct = plane_ctype(ring_sel[r], m & M_SEL, true, true);           // I:985-997
+            const double theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
+            uint32_t mask = 0;
+            if (dist <= 4.5 && theta <= 30.0) {                                      // I:1007
+                if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
+                if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
+                if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
+                if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
+            }
+            if (dist <= 6.0) {                                                       // I:1021
+                if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
+            }
+            emit = mask != 0;                                                        // I:1026
+            rec.i0 = gid ? gid[lid] : lid;
+            rec.i1 = ring_gid ? ring_gid[r] : r;
+            rec.d0 = dist; rec.d1 = theta;
+            rec.u = mask | ((unsigned)ct << 8);
+        }
+        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+        Q.push(emit, rec, lane);
+    };
     const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (vgrid * blockDim.x) >> 6;
     for (int r = wave; r < nring; r += nwave) {
         if (!ring_plus[r]) continue;  // I:957
         if (ring_home && !ring_home[r]) continue;  // multi-GPU: the rank owning the ring emits
-        const num::d3 ctr_ = ld3(ring_c, r), nrm = ld3(ring_n, r);
-        const bool rsel = ring_sel[r];
+        const num::d3 ctr_ = ld3(ring_c, r);
         const Stencil st = stencil_load(g, start, cell_box(g, ctr_), lane);
         for (int kb = 0; kb < st.pre[9]; kb += 64) {
             const int k = kb + lane;
-            bool emit = false;
-            double dist = 0, theta = 0;
-            uint32_t mask = 0;
-            int ct = 0, lid = 0;
+            bool ok = false;
+            int j = 0;
             if (k < st.pre[9]) {
-                const int j = stencil_pos(st, k);
+                j = stencil_pos(st, k);
                 const float4 v = s_xyzm[j];
-                const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
                 const uint32_t m = __float_as_uint(v.w);
-                // I:960 tree membership (float64, inclusive), I:964 hydrogens, I:975 aromatic atoms
-                if (num::dist2_kd(ctr_, x) <= 36.0 && !(m & (M_HYDROGEN | ARP_T_AROMATIC)) && plus[lid = s_aux[j].x]) {
-                    dist = num::norm(num::sub(x, ctr_));                        // I:972
-                    ct = plane_ctype(rsel, m & M_SEL, true, true);              // I:985-997
-                    theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
-                    if (dist <= 4.5 && theta <= 30.0) {                         // I:1007
-                        if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
-                        if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
-                        if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
-                        if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
-                    }
-                    if (dist <= 6.0) {                                          // I:1021
-                        if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
-                    }
-                    emit = mask != 0;                                           // I:1026
-                }
+                // I:960 tree membership (float64, inclusive), I:964 hydrogens, I:975 aromatic atoms, I:968 selection_plus
+                ok = num::dist2_kd(ctr_, num::d3{(double)v.x, (double)v.y, (double)v.z}) <= 36.0 &&
+                     !(m & (M_HYDROGEN | ARP_T_AROMATIC)) && plus[s_aux[j].x];
             }
-            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-            PlaneRec rec;
-            if (emit) {
-                rec.i0 = gid ? gid[lid] : lid;
-                rec.i1 = ring_gid ? ring_gid[r] : r;
-                rec.d0 = dist; rec.d1 = theta;
-                rec.u = mask | ((unsigned)ct << 8);
-            }
-            Q.push(emit, rec, lane);
+            P.push(ok, r, j, lane, eval);
         }
     }
+    P.drain(lane, eval);
     Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
@@ -265,6 +310,7 @@ __device__ __forceinline__ void plane_plane_body(GridDesc g, const int* __restri
                                                      uint8_t* __restrict__ out_y1, uint8_t* __restrict__ out_y2,
                                                      uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
     PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
     auto write = [&](long long slot, const PlaneRec& t) {
         out_bgn[slot] = t.i0; out_end[slot] = t.i1;
         out_dist[slot] = t.d0; out_dih[slot] = t.d1; out_t1[slot] = t.d2; out_t2[slot] = t.d3;
@@ -272,60 +318,64 @@ __device__ __forceinline__ void plane_plane_body(GridDesc g, const int* __restri
         out_ct[slot] = (uint8_t)((t.u >> 16) & 255u);
     };
     const int lane = threadIdx.x & 63;
-    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (vgrid * blockDim.x) >> 6;
-    for (int a = wave; a < nring; a += nwave) {
-        if (!ring_plus[a]) continue;  // I:1081
-        if (ring_home && !ring_home[a]) continue;  // multi-GPU: owner of the lower ring id emits the pair
-        const num::d3 ca = ld3(ring_c, a), na = ld3(ring_n, a);
-        const int ra = ring_res[a];
-        const bool asel = ring_sel[a];
-        const Stencil st = stencil_load(g, start, cell_box(g, ca), lane);
-        for (int kb = 0; kb < st.pre[9]; kb += 64) {
-            const int k = kb + lane;
-            bool emit = false, first = true;
-            int b = 0, y1 = 0, y2 = 0, ct = 0;
-            double dist = 0, dih = 0, t1 = 0, t2 = 0;
-            if (k < st.pre[9]) {
-                b = perm[stencil_pos(st, k)];
-                if (b > a && ring_plus[b]) {  // unordered pair once; I:1081, 1085
-                    const num::d3 cbv = ld3(ring_c, b), nb = ld3(ring_n, b);
-                    const num::d3 pab = num::sub(ca, cbv);
-                    dist = num::norm(pab);                 // I:1111 (same value for both visits)
-                    if (!(dist > 6.0)) {                   // I:1113
-                        const bool intra = ra == ring_res[b];  // I:1091
-                        ct = plane_ctype(asel, ring_sel[b], true, true);
-                        const double cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
-                        dih = num::fold_deg(acos(cosd));                              // I:1122
-                        const double t_ab = num::group_angle(na, pab);                // I:1123, visit (a,b)
-                        const double t_ba = num::group_angle(nb, num::sub(cbv, ca));  // visit (b,a)
-                        const int y_ab = num::pp_class(dih, t_ab), y_ba = num::pp_class(dih, t_ba);
-                        const bool skip_ab = intra && y_ab == ARP_PP_EE;  // I:1154
-                        const bool skip_ba = intra && y_ba == ARP_PP_EE;
-                        emit = !(skip_ab && skip_ba);
-                        first = !skip_ab;
-                        if (first) {  // record created by visit (a,b); visit (b,a) may append its class
-                            t1 = t_ab; t2 = skip_ba ? NAN : t_ba;
-                            y1 = y_ab; y2 = skip_ba ? ARP_PP_SKIPPED : (y_ba == y_ab ? ARP_PP_SAME : y_ba);
-                        } else {      // first visit skipped: the reverse visit creates the record
-                            t1 = t_ba; t2 = NAN;
-                            y1 = y_ba; y2 = ARP_PP_SKIPPED;
-                        }
-                    }
+    auto eval = [&](bool live, int a, int b) {   // rings a < b, both in selection_plus, centres within ~6 A
+        bool emit = false;
+        PlaneRec rec;
+        if (live) {
+            const num::d3 ca = ld3(ring_c, a), na = ld3(ring_n, a), cbv = ld3(ring_c, b), nb = ld3(ring_n, b);
+            const num::d3 pab = num::sub(ca, cbv);
+            const double dist = num::norm(pab);                 // I:1111 (same value for both visits)
+            if (!(dist > 6.0)) {                                // I:1113
+                const bool intra = ring_res[a] == ring_res[b];  // I:1091
+                const int ct = plane_ctype(ring_sel[a], ring_sel[b], true, true);
+                const double cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
+                const double dih = num::fold_deg(acos(cosd));                       // I:1122
+                const double t_ab = num::group_angle(na, pab);                      // I:1123, visit (a,b)
+                const double t_ba = num::group_angle(nb, num::sub(cbv, ca));        // visit (b,a)
+                const int y_ab = num::pp_class(dih, t_ab), y_ba = num::pp_class(dih, t_ba);
+                const bool skip_ab = intra && y_ab == ARP_PP_EE;  // I:1154
+                const bool skip_ba = intra && y_ba == ARP_PP_EE;
+                emit = !(skip_ab && skip_ba);
+                const bool first = !skip_ab;
+                double t1, t2;
+                int y1, y2;
+                if (first) {  // record created by visit (a,b); visit (b,a) may append its class
+                    t1 = t_ab; t2 = skip_ba ? NAN : t_ba;
+                    y1 = y_ab; y2 = skip_ba ? ARP_PP_SKIPPED : (y_ba == y_ab ? ARP_PP_SAME : y_ba);
+                } else {      // first visit skipped: the reverse visit creates the record
+                    t1 = t_ba; t2 = NAN;
+                    y1 = y_ba; y2 = ARP_PP_SKIPPED;
                 }
-            }
-            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-            PlaneRec rec;
-            if (emit) {
                 const int ga = ring_gid ? ring_gid[a] : a, gb = ring_gid ? ring_gid[b] : b;
                 rec.i0 = first ? ga : gb;
                 rec.i1 = first ? gb : ga;
                 rec.d0 = dist; rec.d1 = dih; rec.d2 = t1; rec.d3 = t2;
                 rec.u = (unsigned)y1 | ((unsigned)y2 << 8) | ((unsigned)ct << 16);
             }
-            Q.push(emit, rec, lane);
+        }
+        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+        Q.push(emit, rec, lane);
+    };
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (vgrid * blockDim.x) >> 6;
+    for (int a = wave; a < nring; a += nwave) {
+        if (!ring_plus[a]) continue;  // I:1081
+        if (ring_home && !ring_home[a]) continue;  // multi-GPU: owner of the lower ring id emits the pair
+        const num::d3 ca = ld3(ring_c, a);
+        const Stencil st = stencil_load(g, start, cell_box(g, ca), lane);
+        for (int kb = 0; kb < st.pre[9]; kb += 64) {
+            const int k = kb + lane;
+            bool ok = false;
+            int b = 0;
+            if (k < st.pre[9]) {
+                b = perm[stencil_pos(st, k)];
+                // unordered pair once (I:1081, 1085); squared-distance superset of I:1113, settled exactly in eval
+                ok = b > a && ring_plus[b] && num::dist2_kd(ca, ld3(ring_c, b)) <= 36.0 * (1.0 + 1e-9);
+            }
+            P.push(ok, a, b, lane, eval);
         }
     }
+    P.drain(lane, eval);
     Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
@@ -359,50 +409,53 @@ __device__ __forceinline__ void group_group_body(GridDesc g, const int* __restri
                                                      float* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
                                                      u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
     PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
     auto write = [&](long long slot, const PlaneRec& t) {   // float values travel as doubles (exact both ways)
         out_bgn[slot] = t.i0; out_end[slot] = t.i1;
         out_dist[slot] = (float)t.d0; out_dih[slot] = (float)t.d1; out_theta[slot] = (float)t.d2;
         out_ct[slot] = (uint8_t)(t.u & 255u);
     };
     const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int a, int b) {   // ordered pair of amides, float32 (I:1227-1300)
+        bool emit = false;
+        PlaneRec rec;
+        if (live) {
+            const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a), cbv = lf3(am_c, b), nb = lf3(am_n, b);
+            const num::f3 pab = num::sub(ca, cbv);
+            const float dist = num::norm(pab);                 // I:1268
+            if (!(dist > (float)6.0)) {                        // I:1270
+                const float cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
+                const float dih = num::fold_deg(acosf(cosd));  // I:1278
+                const float theta = num::group_angle(na, pab); // I:1279
+                emit = !(dih > 30.0f || theta > 30.0f);        // I:1282
+                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = am_gid ? am_gid[b] : b;
+                rec.d0 = (double)dist; rec.d1 = (double)dih; rec.d2 = (double)theta;
+                rec.u = (unsigned)plane_ctype(am_sel[a], am_sel[b], true, true);
+            }
+        }
+        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+        Q.push(emit, rec, lane);
+    };
     const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (vgrid * blockDim.x) >> 6;
     for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
         if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the bgn amide emits
-        const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
-        const bool asel = am_sel[a];
-        const Stencil st = stencil_load(g, start, cell_box(g, num::to_d3(ca)), lane);
+        const num::d3 cad = num::to_d3(lf3(am_c, a));
+        const Stencil st = stencil_load(g, start, cell_box(g, cad), lane);
         for (int kb = 0; kb < st.pre[9]; kb += 64) {
             const int k = kb + lane;
-            bool emit = false;
-            int b = 0, ct = 0;
-            float dist = 0, dih = 0, theta = 0;
+            bool ok = false;
+            int b = 0;
             if (k < st.pre[9]) {
                 b = perm[stencil_pos(st, k)];
-                if (b != a && am_plus[b]) {  // I:1233, 1237
-                    const num::f3 cbv = lf3(am_c, b), nb = lf3(am_n, b);
-                    const num::f3 pab = num::sub(ca, cbv);
-                    dist = num::norm(pab);                 // I:1268
-                    if (!(dist > (float)6.0)) {            // I:1270
-                        const float cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
-                        dih = num::fold_deg(acosf(cosd));  // I:1278
-                        theta = num::group_angle(na, pab); // I:1279
-                        emit = !(dih > 30.0f || theta > 30.0f);  // I:1282
-                        ct = plane_ctype(asel, am_sel[b], true, true);
-                    }
-                }
+                // I:1233, 1237; float64 squared-distance superset of the float32 test at I:1270 (settled exactly in eval)
+                ok = b != a && am_plus[b] && num::dist2_kd(cad, num::to_d3(lf3(am_c, b))) <= 36.0 * (1.0 + 1e-5);
             }
-            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-            PlaneRec rec;
-            if (emit) {
-                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = am_gid ? am_gid[b] : b;
-                rec.d0 = (double)dist; rec.d1 = (double)dih; rec.d2 = (double)theta;
-                rec.u = (unsigned)ct;
-            }
-            Q.push(emit, rec, lane);
+            P.push(ok, a, b, lane, eval);
         }
     }
+    P.drain(lane, eval);
     Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
@@ -444,51 +497,54 @@ __device__ __forceinline__ void group_plane_body(GridDesc g, const int* __restri
                                                      double* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
                                                      u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
     PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
     auto write = [&](long long slot, const PlaneRec& t) {
         out_amide[slot] = t.i0; out_ring[slot] = t.i1;
         out_dist[slot] = t.d0; out_dih[slot] = t.d1; out_theta[slot] = t.d2;
         out_ct[slot] = (uint8_t)(t.u & 255u);
     };
     const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int a, int r) {   // amide a, ring r (I:1312-1382)
+        bool emit = false;
+        PlaneRec rec;
+        if (live) {
+            const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
+            const num::d3 cad = num::to_d3(ca);
+            const num::d3 cr = ld3(ring_c, r), nr = ld3(ring_n, r);
+            const num::d3 par = num::sub(cad, cr);
+            const double dist = num::norm(par);         // I:1349
+            if (!(dist > 6.0)) {                        // I:1351
+                const double cosd = num::dot(num::to_d3(na), nr) / ((double)num::norm(na) * num::norm(nr));
+                const double dih = num::fold_deg(acos(cosd));    // I:1359
+                const double theta = num::group_angle(na, par);  // I:1360
+                emit = !(dih > 30.0 || theta > 30.0);            // I:1363
+                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = ring_gid ? ring_gid[r] : r;
+                rec.d0 = dist; rec.d1 = dih; rec.d2 = theta;
+                rec.u = (unsigned)plane_ctype(am_sel[a], ring_sel[r], true, true);
+            }
+        }
+        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
+        Q.push(emit, rec, lane);
+    };
     const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (vgrid * blockDim.x) >> 6;
     for (int a = wave; a < namide; a += nwave) {
         if (!am_plus[a]) continue;
         if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the amide emits
-        const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
-        const num::d3 cad = num::to_d3(ca);
-        const bool asel = am_sel[a];
+        const num::d3 cad = num::to_d3(lf3(am_c, a));
         const Stencil st = stencil_load(g, start, cell_box(g, cad), lane);
         for (int kb = 0; kb < st.pre[9]; kb += 64) {
             const int k = kb + lane;
-            bool emit = false;
-            int r = 0, ct = 0;
-            double dist = 0, dih = 0, theta = 0;
+            bool ok = false;
+            int r = 0;
             if (k < st.pre[9]) {
                 r = perm[stencil_pos(st, k)];
-                if (ring_plus[r]) {  // I:1318
-                    const num::d3 cr = ld3(ring_c, r), nr = ld3(ring_n, r);
-                    const num::d3 par = num::sub(cad, cr);
-                    dist = num::norm(par);         // I:1349
-                    if (!(dist > 6.0)) {           // I:1351
-                        const double cosd = num::dot(num::to_d3(na), nr) / ((double)num::norm(na) * num::norm(nr));
-                        dih = num::fold_deg(acos(cosd));    // I:1359
-                        theta = num::group_angle(na, par);  // I:1360
-                        emit = !(dih > 30.0 || theta > 30.0);  // I:1363
-                        ct = plane_ctype(asel, ring_sel[r], true, true);
-                    }
-                }
+                ok = ring_plus[r] && num::dist2_kd(cad, ld3(ring_c, r)) <= 36.0 * (1.0 + 1e-9);   // I:1318; superset of I:1351
             }
-            if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-            PlaneRec rec;
-            if (emit) {
-                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = ring_gid ? ring_gid[r] : r;
-                rec.d0 = dist; rec.d1 = dih; rec.d2 = theta;
-                rec.u = (unsigned)ct;
-            }
-            Q.push(emit, rec, lane);
+            P.push(ok, a, r, lane, eval);
         }
     }
+    P.drain(lane, eval);
     Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
 }
 
@@ -510,25 +566,149 @@ __global__ __launch_bounds__(256) void k_group_plane(GroupPlaneArgs a) {
     group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
 }
 
-// The four ring / amide kernels of a pass in ONE launch: blocks [0, nb0) work as k_atom_plane, [nb0, nb1) as
-// k_plane_plane, [nb1, nb2) as k_group_group, the rest as k_group_plane (a part with no blocks is skipped).  They are
-// independent of each other, so this saves three dependent-launch gaps and lets the small grids share the chip.
-__global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, int nb0,
-                                                int nb1, int nb2) {
-    __shared__ PlaneShared s_sh;
-    PlaneShared* const qb = &s_sh;
-    const int b = (int)blockIdx.x, nb = (int)gridDim.x;
-    if (b < nb0) {
-        const AtomPlaneArgs& a = ap;
-        atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, b, nb0, qb);
-    } else if (b < nb1) {
-        const PlanePlaneArgs& a = pp;
-        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - nb0, nb1 - nb0, qb);
-    } else if (b < nb2) {
-        const GroupGroupArgs& a = gg;
-        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb1, nb2 - nb1, qb);
-    } else {
-        const GroupPlaneArgs& a = gp;
-        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - nb2, nb - nb2, qb);
+// __calculate_atom_plane_contacts (I:947-1062) on the CONTACT grid of the pass (cell edge = the interacting cut-off,
+// atoms of selection_plus without hydrogens — exactly the atoms I:964-968 let through) instead of the all-atom 6 A
+// grid: with a 5 A edge the 6 A query reaches two cells, so the stencil is (2R + 1)^2 rows of 2R + 1 contiguous cells,
+// R = floor(6 / edge) + 1.  One wavefront per ring; lane r fetches the bounds of row r, the rows are then swept one
+// after the other, 64 atoms at a time.  Lets a pass do without the second grid build.
+__device__ __forceinline__ void atom_plane_cg_body(const AtomPlaneArgs& A, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
+    auto write = [&](long long slot, const PlaneRec& t) {
+        A.out_atom[slot] = t.i0; A.out_ring[slot] = t.i1;
+        A.out_dist[slot] = t.d0; A.out_theta[slot] = t.d1;
+        A.out_mask[slot] = (uint8_t)(t.u & 255u); A.out_ct[slot] = (uint8_t)((t.u >> 8) & 255u);
+    };
+    const GridDesc g = A.g;
+    const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int r, int j) {   // ring r, atom at sorted position j (inside the tree radius, I:960)
+        bool emit = false;
+        PlaneRec rec;
+        if (live) {
+            const num::d3 ctr_ = ld3(A.ring_c, r), nrm = ld3(A.ring_n, r);
+            const float4 v = A.s_xyzm[j];
+            const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
+            const uint32_t m = __float_as_uint(v.w);
+            const int lid = A.s_aux[j].x;
+            const double dist = num::norm(num::sub(x, ctr_));                        // I:972
+            const int ct = plane_ctype(A.ring_sel[r], m & M_SEL, true, true);         // I:985-997
+            const double theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
+            uint32_t mask = 0;
+            if (dist <= 4.5 && theta <= 30.0) {                                      // I:1007
+                if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
+                if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
+                if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
+                if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
+            }
+            if (dist <= 6.0) {                                                       // I:1021
+                if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
+            }
+            emit = mask != 0;                                                        // I:1026
+            rec.i0 = A.gid ? A.gid[lid] : lid;
+            rec.i1 = A.ring_gid ? A.ring_gid[r] : r;
+            rec.d0 = dist; rec.d1 = theta;
+            rec.u = mask | ((unsigned)ct << 8);
+        }
+        if (Q.nearly_full()) Q.flush(A.n_out, A.cap, lane, write);
+        Q.push(emit, rec, lane);
+    };
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (vgrid * blockDim.x) >> 6;
+    const int R = (int)floor(6.0 * g.inv) + 1, W = 2 * R + 1, nrows = W * W;
+    for (int r = wave; r < A.nring; r += nwave) {
+        if (!A.ring_plus[r]) continue;  // I:957
+        if (A.ring_home && !A.ring_home[r]) continue;  // multi-GPU: the rank owning the ring emits
+        const num::d3 ctr_ = ld3(A.ring_c, r);
+        const CellBox cb = cell_box(g, ctr_);
+        for (int row0 = 0; row0 < nrows; row0 += 64) {
+            int my_js = 0, my_len = 0;
+            const int row = row0 + lane;
+            if (row < nrows) {
+                const int y2 = cb.cy + (row % W) - R, z2 = cb.cz + (row / W) - R;
+                const int xlo = max(cb.cx - R, 0), xhi = min(cb.cx + R, g.nx - 1);
+                if (y2 >= 0 && y2 < g.ny && z2 >= 0 && z2 < g.nz && xlo <= xhi) {
+                    const int rowbase = (z2 * g.ny + y2) * g.nx;
+                    my_js = A.start[rowbase + xlo];
+                    my_len = A.start[rowbase + xhi + 1] - my_js;
+                }
+            }
+            const int rows_here = min(64, nrows - row0);
+            for (int rr = 0; rr < rows_here; ++rr) {
+                const int js = __builtin_amdgcn_readlane(my_js, rr), len = __builtin_amdgcn_readlane(my_len, rr);
+                for (int kb = 0; kb < len; kb += 64) {
+                    const int k = kb + lane;
+                    bool ok = false;
+                    if (k < len) {
+                        const float4 v = A.s_xyzm[js + k];
+                        // I:960 tree membership (float64, inclusive); hydrogens (I:964) and atoms outside selection_plus
+                        // (I:968) are not in this grid; I:975 aromatic atoms
+                        ok = num::dist2_kd(ctr_, num::d3{(double)v.x, (double)v.y, (double)v.z}) <= 36.0 &&
+                             !(__float_as_uint(v.w) & ARP_T_AROMATIC);
+                    }
+                    P.push(ok, r, js + k, lane, eval);
+                }
+            }
+        }
     }
+    P.drain(lane, eval);
+    Q.flush_block(sh->n, &sh->base, A.n_out, A.cap, lane, write);
+}
+
+// The four ring / amide loops of a pass in ONE launch: blocks [0, nb0) work as k_atom_plane (on the contact grid),
+// [nb0, nb1) as k_plane_plane, [nb1, nb2) as k_group_group, [nb2, nb3) as k_group_plane.  It is launched on the second
+// stream as soon as the contact grid and the ring / amide masks exist, i.e. together with the neighbour search, whose
+// long tail of retiring blocks leaves room for these ~1500 short blocks; it is over before the sift kernel is.
+struct PlanesSplit { int nb0, nb1, nb2, nb3; };   // cumulative block counts of the four parts
+__global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, PlanesSplit ps,
+                                                PublishArgs pub) {
+    __shared__ PlaneShared s_sh;
+    const int b = (int)blockIdx.x;
+    if (b < ps.nb0) {
+        atom_plane_cg_body(ap, b, ps.nb0, &s_sh);
+    } else if (b < ps.nb1) {
+        const PlanePlaneArgs& a = pp;
+        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - ps.nb0, ps.nb1 - ps.nb0, &s_sh);
+    } else if (b < ps.nb2) {
+        const GroupGroupArgs& a = gg;
+        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb1, ps.nb2 - ps.nb1, &s_sh);
+    } else if (b < ps.nb3) {
+        const GroupPlaneArgs& a = gp;
+        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb2, ps.nb3 - ps.nb2, &s_sh);
+    }
+    pass_end(pub, 1);
+}
+
+// interactions.py:715-936 for every pair of the list (sift_body); ends the pass on the main stream.
+__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(SiftArgs sa, PublishArgs pub) {
+    __shared__ SiftShared s_sh;
+    sift_body(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+    pass_end(pub, 0);
+}
+
+// The same two kernels as ONE grid: blocks [0, np) = the ring / amide loops (np a multiple of 8: idle padding blocks),
+// blocks [np, np + nsift) = the sift kernel.  One stream, no cross-stream events (those cost the host ~5 us each).
+union SiftPlanesShared {
+    PlaneShared planes;
+    SiftShared sift;
+};
+__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa, int nsift, AtomPlaneArgs ap, PlanePlaneArgs pp,
+                                                                     GroupGroupArgs gg, GroupPlaneArgs gp, PlanesSplit ps, int np,
+                                                                     PublishArgs pub) {
+    __shared__ SiftPlanesShared s_sh;
+    const int b = (int)blockIdx.x;
+    if (b >= np) {
+        sift_body(sa, b - np, nsift, &s_sh.sift);
+    } else if (b < ps.nb0) {
+        atom_plane_cg_body(ap, b, ps.nb0, &s_sh.planes);
+    } else if (b < ps.nb1) {
+        const PlanePlaneArgs& a = pp;
+        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - ps.nb0, ps.nb1 - ps.nb0, &s_sh.planes);
+    } else if (b < ps.nb2) {
+        const GroupGroupArgs& a = gg;
+        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb1, ps.nb2 - ps.nb1, &s_sh.planes);
+    } else if (b < ps.nb3) {
+        const GroupPlaneArgs& a = gp;
+        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb2, ps.nb3 - ps.nb2, &s_sh.planes);
+    }
+    pass_end(pub, 0);
 }
