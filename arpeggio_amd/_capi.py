@@ -29,7 +29,7 @@ SYMBOLS = (
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
     'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
-    'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts',
+    'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob',
 )
 
 _lib = None
@@ -73,6 +73,10 @@ def load():
     L.arp_set_selection.argtypes = [vp, vp]
     L.arp_atom_accumulators.argtypes = [vp, vp, vp]
     L.arp_atom_integer_sifts.argtypes = [vp, vp]
+    L.arp_blob_size.argtypes = [i64] * 6
+    L.arp_blob_size.restype = C.c_uint64
+    L.arp_blob_layout.argtypes = [vp, C.c_uint64] + [i64] * 6
+    L.arp_set_blob.argtypes = [vp, vp, C.c_uint64]
     L.arp_device_buffer.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.arp_run_stage.argtypes = [vp, i32, dbl, dbl, i32, dbl, vp]
     L.arp_set_group_ownership.argtypes = [vp, vp, vp, vp, vp]
@@ -98,7 +102,7 @@ def load():
     L.arp_stream_handle.restype = C.c_uint64
     for s in SYMBOLS:
         f = getattr(L, s)
-        if s not in ('arp_version', 'arp_last_error', 'arp_destroy', 'arp_stream_handle'):
+        if s not in ('arp_version', 'arp_last_error', 'arp_destroy', 'arp_stream_handle', 'arp_blob_size'):
             f.restype = C.c_int
     _lib = L
     return L
@@ -123,6 +127,78 @@ def pinned_empty(n, dtype):
     buf = (C.c_char * nbytes).from_address(ptr.value)
     weakref.finalize(buf, L.arp_host_free, C.c_void_p(ptr.value))
     return np.frombuffer(buf, dtype=dt, count=int(n))
+
+
+class BlobHeader(C.Structure):
+    """arp_blob_header of include/arpeggio_hip.h."""
+    _fields_ = [('magic', C.c_uint64), ('bytes', C.c_uint64), ('n', C.c_int64), ('nres', C.c_int64), ('nbond', C.c_int64),
+                ('nh', C.c_int64), ('nring', C.c_int64), ('namide', C.c_int64), ('n_rad', C.c_int64), ('off', C.c_uint64 * 21),
+                ('lo', C.c_double * 3), ('hi', C.c_double * 3), ('ring_lo', C.c_double * 3), ('ring_hi', C.c_double * 3),
+                ('amide_lo', C.c_double * 3), ('amide_hi', C.c_double * 3)]
+
+
+_BLOB_DTYPES = (np.float32, np.float64, np.uint16, np.uint16, np.int32, np.uint8, np.int32, np.int32, np.int32, np.int32, np.int32,
+                np.float64, np.int32, np.float64, np.float64, np.int32, np.float32, np.float32, np.int32, np.uint16, np.float64)
+
+
+def pack_blob(pc, pinned=True):
+    """The PackedComplex as ONE device-ready buffer (arp_blob_header + arrays, include/arpeggio_hip.h): a uint8 NumPy
+    array over page-locked memory (``pinned``), ready for ``Context.set_blob``.  This is the packing step a producer of
+    structures does once per structure; nothing is converted again on the way to the GPU."""
+    L = load()
+    n, nres, nring, namide = pc.n_atoms, pc.n_residues, pc.n_rings, pc.n_amides
+    nbond, nh = int(pc.bond_idx.shape[0]), int(pc.h_xyz.shape[0])
+    size = int(L.arp_blob_size(n, nres, nbond, nh, nring, namide))
+    if size == 0:
+        raise ValueError('pack_blob: counts out of range')
+    buf = pinned_empty(size, np.uint8) if pinned else np.empty(size, np.uint8)
+    if L.arp_blob_layout(_p(buf), size, n, nres, nbond, nh, nring, namide) != ARP_OK:
+        raise ValueError('arp_blob_layout failed')
+    hdr = BlobHeader.from_buffer(buf)
+    counts = (4 * n, 2 * n, n, n, n, nres, nres, nres, n + 1, nbond, n + 1, 3 * nh, n, 3 * nring, 3 * nring, nring, 3 * namide,
+              3 * namide, namide, n, 512)
+    v = [np.frombuffer(buf, dtype=dt, count=cnt, offset=int(hdr.off[k])) for k, (dt, cnt) in enumerate(zip(_BLOB_DTYPES, counts))]
+    x4 = v[0].reshape(-1, 4)
+    x4[:, :3] = pc.xyz
+    x4[:, 3] = 0.0
+    r2 = v[1].reshape(-1, 2)
+    r2[:, 0], r2[:, 1] = pc.vdw, pc.cov
+    v[2][:], v[3][:], v[4][:] = pc.type_mask, pc.flags, pc.res_id
+    v[5][:], v[6][:], v[7][:] = pc.res_flags, pc.res_prev, pc.res_next
+    v[8][:], v[9][:], v[10][:] = pc.bond_off, pc.bond_idx, pc.h_off
+    v[11][:] = pc.h_xyz.reshape(-1)
+    v[12][:] = pc.sb_nbr
+    v[13][:], v[14][:], v[15][:] = pc.ring_center.reshape(-1), pc.ring_normal.reshape(-1), pc.ring_res
+    v[16][:], v[17][:], v[18][:] = pc.amide_center.reshape(-1), pc.amide_normal.reshape(-1), pc.amide_res
+    # dictionary of the distinct {vdw, cov} pairs (a handful of element values), compared bit for bit
+    tab = v[20].reshape(256, 2)
+    tab[:] = 0.0
+    if n:
+        keys = r2.view(np.uint64).reshape(-1, 2)
+        uniq, inv = np.unique(keys, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        if len(uniq) <= 256:
+            tab[:len(uniq)] = uniq.view(np.float64)
+            v[19][:] = inv
+            hdr.n_rad = len(uniq)
+        else:   # keep the 256 most frequent pairs, the rest fetch their radii from the per-atom array
+            cnt = np.bincount(inv, minlength=len(uniq))
+            keep = np.argsort(-cnt, kind='stable')[:256]
+            slot = np.full(len(uniq), 0xFFFF, np.int64)
+            slot[keep] = np.arange(256)
+            tab[:] = uniq[keep].view(np.float64)
+            v[19][:] = slot[inv]
+            hdr.n_rad = 256
+    else:
+        hdr.n_rad = 0
+    for name, arr in (('', pc.xyz), ('ring_', pc.ring_center), ('amide_', pc.amide_center)):
+        lo = arr.min(axis=0).astype(np.float64) if len(arr) else np.zeros(3)
+        hi = arr.max(axis=0).astype(np.float64) if len(arr) else np.zeros(3)
+        for k in range(3):
+            getattr(hdr, name + 'lo')[k] = lo[k]
+            getattr(hdr, name + 'hi')[k] = hi[k]
+    del hdr
+    return buf
 
 
 KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')
@@ -178,6 +254,13 @@ class Context:
         self._check(L.arp_set_rings(h, pc.n_rings, _p(pc.ring_center), _p(pc.ring_normal), _p(pc.ring_res)), 'arp_set_rings')
         self._check(L.arp_set_amides(h, pc.n_amides, _p(pc.amide_center), _p(pc.amide_normal), _p(pc.amide_res)), 'arp_set_amides')
         self.n, self.n_rings, self.n_amides = pc.n_atoms, pc.n_rings, pc.n_amides
+
+    def set_blob(self, blob, counts=None):
+        """Upload a structure packed by ``pack_blob`` (one host-to-device copy); ``blob`` must stay alive during the call."""
+        self._keep = blob
+        self._check(self._L.arp_set_blob(self._h, _p(blob), int(blob.nbytes)), 'arp_set_blob')
+        hdr = BlobHeader.from_buffer_copy(blob[:C.sizeof(BlobHeader)].tobytes())
+        self.n, self.n_rings, self.n_amides = int(hdr.n), int(hdr.nring), int(hdr.namide)
 
     def set_ownership(self, is_home=None, global_id=None):
         home = None if is_home is None else np.ascontiguousarray(is_home, np.uint8)
@@ -324,14 +407,32 @@ class Context:
         return out[:self.n]
 
     # ---- ring / amide contacts ----
-    def fetch_bag(self, name):
-        """Fetch one of the ring/amide bags left in HBM by run_launch (no re-computation)."""
+    def pinned_bag_buffers(self, name, capacity):
+        """Page-locked result buffers for ``fetch_bag(name, out=...)`` (allocate once, reuse for every structure)."""
+        mk, keys, order = self._BAGS[name]
+        cap = max(int(capacity), 64)
+        return [pinned_empty(cap, a.dtype) for a in mk(1)]
+
+    def fetch_bag(self, name, sort=True, out=None):
+        """Fetch one of the ring/amide bags left in HBM by run_launch (no re-computation).  ``out``: buffers from
+        ``pinned_bag_buffers`` (the returned arrays are then views into them)."""
         fn = getattr(self._L, f'arp_{name}_fetch')
         mk, keys, order = self._BAGS[name]
-        arrs = self._grow(lambda cap, r, cnt: fn(self._h, cap, *[_p(x) for x in r], C.byref(cnt)), mk, f'arp_{name}_fetch', 64)
-        out = dict(zip(keys, arrs))
-        o = np.lexsort((out[order[1]], out[order[0]]))
-        return {k: v[o] for k, v in out.items()}
+        arrs = None
+        if out is not None:
+            cap, cnt = min(len(a) for a in out), C.c_int64(0)
+            rc = fn(self._h, cap, *[_p(x) for x in out], C.byref(cnt))
+            if rc == ARP_OK:
+                arrs = [a[:int(cnt.value)] for a in out]
+            elif rc != ARP_E_CAPACITY:
+                self._check(rc, f'arp_{name}_fetch')
+        if arrs is None:
+            arrs = self._grow(lambda cap, r, cnt: fn(self._h, cap, *[_p(x) for x in r], C.byref(cnt)), mk, f'arp_{name}_fetch', 64)
+        res = dict(zip(keys, arrs))
+        if sort:
+            o = np.lexsort((res[order[1]], res[order[0]]))
+            res = {k: v[o] for k, v in res.items()}
+        return res
 
     def _grow(self, call, arrays_factory, what, guess):
         cap = max(int(guess), 64)

@@ -35,6 +35,7 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;   // p points into memory owned by someone else (the device copy of an uploaded blob)
     // *fresh (optional) is set when new memory was allocated (contents undefined)
     hipError_t reserve(size_t n, bool* fresh = nullptr) {
         if (fresh) *fresh = false;
@@ -46,10 +47,17 @@ struct DevBuf {
         else p = nullptr;
         return e;
     }
+    void borrow(void* ptr, size_t n) {
+        release();
+        p = (T*)ptr;
+        cap = n;
+        borrowed = true;
+    }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        borrowed = false;
     }
 };
 
@@ -169,6 +177,10 @@ struct arp_ctx {
     u64* h_ctr_pinned = nullptr;   // pinned mirror of the counter block + completion word
     PublishArgs pub{nullptr, nullptr, 0, 0};   // in-kernel end-of-pass publication (arp_run_launch sets it for one pass)
     // residue sets of arp_run_launch, tagged with the pass number (never cleared between passes; wrap -> one memset)
+    DevBuf<uint8_t> blob_dev;      // device copy of the last arp_set_blob upload (the input arrays are views into it)
+    int64_t blob_nbond = 0, blob_nh = 0, blob_nrad = 0;
+    bool validate_on_device = false;   // blob uploads: k_prepare_static checks what the classic setters check on the host
+    DevBuf<int> blob_sb_nbr;
     DevBuf<uint8_t> res_tag;       // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
     int res_tag_value = 0;
     bool fuse_sets = false;        // the contact-grid build of the current pass also makes the residue / ring / amide sets
@@ -212,6 +224,11 @@ int upload_async(arp_ctx* c, DevBuf<T>& buf, const T* src, size_t n) {
 }
 int upload_done(arp_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ARP_OK;
+}
+template <class T>
+int download_async(arp_ctx* c, T* dst, const T* src, size_t n) {
+    if (n && dst) HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
     return ARP_OK;
 }
 template <class T>
@@ -919,7 +936,6 @@ bool finish_bag(arp_ctx* c, Bag& b, int slot) {
 }
 int grow_pairs(arp_ctx* c) {
     const size_t need = ((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 64) * PAIR_SEGS;
-    c->res_tag.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     HIPCHK(c, c->pairs.reserve(need));
     return ARP_OK;
@@ -1023,6 +1039,7 @@ void arp_destroy(arp_ctx* c) {
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
+    c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release();   // (views into the blob were released above: no-ops)
     c->ring_home.release(); c->am_home.release(); c->ring_gid.release(); c->am_gid.release();
     if (c->h_ctr_pinned) (void)hipHostFree(c->h_ctr_pinned);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
@@ -1222,6 +1239,147 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
     c->amide_grid.valid = false;
     c->sel_made = false;
     c->has_group_owner = false;
+    return ARP_OK;
+}
+
+// ---- one-blob upload -----------------------------------------------------------------------------------------------
+namespace {
+struct BlobSizes { uint64_t esize[ARP_BLOB_ARRAYS]; uint64_t count[ARP_BLOB_ARRAYS]; };
+bool blob_sizes(int64_t n, int64_t nres, int64_t nbond, int64_t nh, int64_t nring, int64_t namide, BlobSizes& z) {
+    if (n < 0 || nres < 0 || nbond < 0 || nh < 0 || nring < 0 || namide < 0) return false;
+    if (n > 0x7FFFFFF0LL || nres > 0x7FFFFFF0LL || nbond > 0x7FFFFFF0LL || nh > 0x7FFFFFF0LL / 3 || nring > 0x7FFFFFF0LL / 3 ||
+        namide > 0x7FFFFFF0LL / 3)
+        return false;
+    const uint64_t N = (uint64_t)n, NR = (uint64_t)nres, R = (uint64_t)nring, A = (uint64_t)namide;
+    const uint64_t es[ARP_BLOB_ARRAYS] = {4, 8, 2, 2, 4, 1, 4, 4, 4, 4, 4, 8, 4, 8, 8, 4, 4, 4, 4, 2, 8};
+    const uint64_t ct[ARP_BLOB_ARRAYS] = {4 * N, 2 * N, N, N, N, NR, NR, NR, N + 1, (uint64_t)nbond, N + 1, 3 * (uint64_t)nh, N, 3 * R, 3 * R,
+                                          R, 3 * A, 3 * A, A, N, 2 * RAD_TABLE};
+    for (int k = 0; k < ARP_BLOB_ARRAYS; ++k) { z.esize[k] = es[k]; z.count[k] = ct[k]; }
+    return true;
+}
+uint64_t align16(uint64_t v) { return (v + 15ull) & ~15ull; }
+}  // namespace
+
+uint64_t arp_blob_size(int64_t n, int64_t nres, int64_t nbond, int64_t nh, int64_t nring, int64_t namide) {
+    BlobSizes z;
+    if (!blob_sizes(n, nres, nbond, nh, nring, namide, z)) return 0;
+    uint64_t off = align16(sizeof(arp_blob_header));
+    for (int k = 0; k < ARP_BLOB_ARRAYS; ++k) off = align16(off + z.esize[k] * z.count[k]);
+    return off;
+}
+
+int arp_blob_layout(void* blob, uint64_t bytes, int64_t n, int64_t nres, int64_t nbond, int64_t nh, int64_t nring, int64_t namide) {
+    const uint64_t need = arp_blob_size(n, nres, nbond, nh, nring, namide);
+    if (!blob || need == 0 || bytes < need) return ARP_E_ARG;
+    BlobSizes z;
+    blob_sizes(n, nres, nbond, nh, nring, namide, z);
+    arp_blob_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = ARP_BLOB_MAGIC;
+    h.bytes = need;
+    h.n = n; h.nres = nres; h.nbond = nbond; h.nh = nh; h.nring = nring; h.namide = namide;
+    uint64_t off = align16(sizeof(arp_blob_header));
+    for (int k = 0; k < ARP_BLOB_ARRAYS; ++k) {
+        h.off[k] = off;
+        off = align16(off + z.esize[k] * z.count[k]);
+    }
+    memcpy(blob, &h, sizeof(h));
+    return ARP_OK;
+}
+
+int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
+    if (!c || !blob || bytes < sizeof(arp_blob_header)) return ARP_E_ARG;
+    arp_blob_header h;
+    memcpy(&h, blob, sizeof(h));
+    if (h.magic != ARP_BLOB_MAGIC) FAIL(c, ARP_E_ARG, "arp_set_blob: bad magic");
+    BlobSizes z;
+    if (!blob_sizes(h.n, h.nres, h.nbond, h.nh, h.nring, h.namide, z)) FAIL(c, ARP_E_ARG, "arp_set_blob: counts out of range");
+    if (h.bytes != arp_blob_size(h.n, h.nres, h.nbond, h.nh, h.nring, h.namide) || h.bytes > bytes)
+        FAIL(c, ARP_E_ARG, "arp_set_blob: size does not match the counts");
+    {   // the offsets must be the ones arp_blob_layout writes
+        uint64_t off = align16(sizeof(arp_blob_header));
+        for (int k = 0; k < ARP_BLOB_ARRAYS; ++k) {
+            if (h.off[k] != off) FAIL(c, ARP_E_ARG, "arp_set_blob: unexpected array offset");
+            off = align16(off + z.esize[k] * z.count[k]);
+        }
+    }
+    if (h.n_rad < 0 || h.n_rad > RAD_TABLE) FAIL(c, ARP_E_ARG, "arp_set_blob: n_rad out of range");
+    if (h.n > 0 && h.nres <= 0) FAIL(c, ARP_E_ARG, "arp_set_blob: atoms without a residue table");
+    for (int k = 0; k < 3; ++k) {
+        const bool ok = std::isfinite(h.lo[k]) && std::isfinite(h.hi[k]) && h.lo[k] <= h.hi[k] && std::isfinite(h.ring_lo[k]) &&
+                        std::isfinite(h.ring_hi[k]) && h.ring_lo[k] <= h.ring_hi[k] && std::isfinite(h.amide_lo[k]) &&
+                        std::isfinite(h.amide_hi[k]) && h.amide_lo[k] <= h.amide_hi[k];
+        if (!ok) FAIL(c, ARP_E_ARG, "arp_set_blob: bad bounding box");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->blob_dev.reserve((size_t)h.bytes));
+    HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, blob, (size_t)h.bytes, hipMemcpyHostToDevice, c->stream));
+    uint8_t* const d = c->blob_dev.p;
+    const size_t n1 = (size_t)std::max<int64_t>(h.n, 1);
+    c->xyz.borrow(d + h.off[0], n1); c->rad.borrow(d + h.off[1], n1); c->tmask.borrow(d + h.off[2], n1);
+    c->flags.borrow(d + h.off[3], n1); c->res_id.borrow(d + h.off[4], n1);
+    c->res_flags.borrow(d + h.off[5], (size_t)std::max<int64_t>(h.nres, 1)); c->res_prev.borrow(d + h.off[6], (size_t)std::max<int64_t>(h.nres, 1));
+    c->res_next.borrow(d + h.off[7], (size_t)std::max<int64_t>(h.nres, 1));
+    c->bond_off.borrow(d + h.off[8], (size_t)h.n + 1); c->bond_idx.borrow(d + h.off[9], (size_t)std::max<int64_t>(h.nbond, 1));
+    c->h_off.borrow(d + h.off[10], (size_t)h.n + 1); c->h_xyz_d.borrow(d + h.off[11], (size_t)std::max<int64_t>(3 * h.nh, 3));
+    c->blob_sb_nbr.borrow(d + h.off[12], n1);
+    c->ring_c.borrow(d + h.off[13], (size_t)std::max<int64_t>(3 * h.nring, 1)); c->ring_n.borrow(d + h.off[14], (size_t)std::max<int64_t>(3 * h.nring, 1));
+    c->ring_res.borrow(d + h.off[15], (size_t)std::max<int64_t>(h.nring, 1));
+    c->am_c.borrow(d + h.off[16], (size_t)std::max<int64_t>(3 * h.namide, 1)); c->am_n.borrow(d + h.off[17], (size_t)std::max<int64_t>(3 * h.namide, 1));
+    c->am_res.borrow(d + h.off[18], (size_t)std::max<int64_t>(h.namide, 1));
+    c->rad_idx.borrow(d + h.off[19], n1); c->rad_tab.borrow(d + h.off[20], (size_t)RAD_TABLE);
+    c->n = h.n; c->nres = h.nres; c->nring = h.nring; c->namide = h.namide;
+    c->has_res = true;
+    c->blob_nbond = h.nbond; c->blob_nh = h.nh; c->blob_nrad = h.n_rad;
+    c->max_res_id = h.nres - 1; c->max_ring_res = h.nres - 1; c->max_amide_res = h.nres - 1;   // (ranges verified on the device below)
+    for (int k = 0; k < 3; ++k) {
+        c->lo[k] = h.lo[k]; c->hi[k] = h.hi[k];
+        c->ring_lo[k] = h.ring_lo[k]; c->ring_hi[k] = h.ring_hi[k];
+        c->am_lo[k] = h.amide_lo[k]; c->am_hi[k] = h.amide_hi[k];
+    }
+    c->h_xyz.clear();
+    // device-side validation (what arp_set_atoms ... check on the host), result in the pinned completion area
+    int* const d_err = (int*)(c->d_ctr + C_ERR);
+    c->ctr_zero_ok = false;
+    HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(u64), c->stream));
+    BlobCheck bc;
+    bc.n = (int)h.n; bc.nres = (int)h.nres; bc.nbond = (int)h.nbond; bc.nh = (int)h.nh; bc.nring = (int)h.nring; bc.namide = (int)h.namide;
+    bc.nrad = (int)h.n_rad;
+    for (int k = 0; k < 3; ++k) {   // float32 coordinates against the double box: widen by one float ulp either way
+        bc.lo[k] = std::nextafter((float)h.lo[k], -INFINITY);
+        bc.hi[k] = std::nextafter((float)h.hi[k], INFINITY);
+    }
+    bc.xyz = c->xyz.p; bc.rad = c->rad.p; bc.rad_idx = c->rad_idx.p; bc.res_id = c->res_id.p; bc.res_prev = c->res_prev.p;
+    bc.res_next = c->res_next.p; bc.bond_off = c->bond_off.p; bc.bond_idx = c->bond_idx.p; bc.h_off = c->h_off.p;
+    bc.h_xyz = c->h_xyz_d.p; bc.sb_nbr = c->blob_sb_nbr.p; bc.ring_c = c->ring_c.p; bc.ring_res = c->ring_res.p;
+    bc.am_c = c->am_c.p; bc.am_res = c->am_res.p; bc.err = d_err;
+    const int64_t work = std::max({h.n, h.nbond, 3 * h.nh, h.nring, h.namide, h.nres, (int64_t)1});
+    hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256)), dim3(256), 0, c->stream, bc);
+    CHK(check_launch(c, "k_validate_blob"));
+    // the float32 box must really contain the float coordinates: the check above used it; the grids use the double one,
+    // which is at least as wide
+    int h_err = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // single-bond neighbour coordinates, ring / amide masks, bookkeeping: as the classic setters leave them
+    HIPCHK(c, c->sb.reserve(n1));
+    HIPCHK(c, c->ring_sel.reserve((size_t)std::max<int64_t>(h.nring, 1))); HIPCHK(c, c->ring_plus.reserve((size_t)std::max<int64_t>(h.nring, 1)));
+    HIPCHK(c, c->am_sel.reserve((size_t)std::max<int64_t>(h.namide, 1))); HIPCHK(c, c->am_plus.reserve((size_t)std::max<int64_t>(h.namide, 1)));
+    c->static_dirty = true;
+    c->has_gid = c->has_home = c->has_group_owner = false;
+    c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
+    c->contacts_valid = false;
+    c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
+    c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
+    if (h_err != 0) {
+        c->n = c->nres = c->nring = c->namide = 0;   // nothing usable is resident
+        FAIL(c, ARP_E_ARG, "arp_set_blob: the structure failed validation (non-finite value, point outside its box, index out of range or "
+                           "offsets that are not a CSR)");
+    }
+    if (h.n > 0) {
+        hipLaunchKernelGGL(k_gather_neighbours, dim3(nblocks(h.n, 256)), dim3(256), 0, c->stream, (int)h.n, c->blob_sb_nbr.p, c->xyz.p, c->sb.p);
+        CHK(check_launch(c, "k_gather_neighbours"));
+    }
     return ARP_OK;
 }
 
@@ -1534,8 +1692,8 @@ int arp_atom_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_atom, int32_t* ou
                          uint8_t* out_mask, uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_ap, "arp_atom_plane_fetch")
     Bag& b = c->bag_ap;
-    CHK(download(c, out_atom, b.a.p, m)); CHK(download(c, out_ring, b.b.p, m)); CHK(download(c, out_dist, b.d0.p, m));
-    CHK(download(c, out_theta, b.d1.p, m)); CHK(download(c, out_mask, b.u0.p, m)); CHK(download(c, out_ctype, b.u1.p, m));
+    CHK(download_async(c, out_atom, b.a.p, m)); CHK(download_async(c, out_ring, b.b.p, m)); CHK(download_async(c, out_dist, b.d0.p, m));
+    CHK(download_async(c, out_theta, b.d1.p, m)); CHK(download_async(c, out_mask, b.u0.p, m)); CHK(download(c, out_ctype, b.u1.p, m));
     return ARP_OK;
 }
 int arp_plane_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, double* out_dist, double* out_dihedral,
@@ -1543,25 +1701,25 @@ int arp_plane_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* ou
                           uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_pp, "arp_plane_plane_fetch")
     Bag& b = c->bag_pp;
-    CHK(download(c, out_bgn, b.a.p, m)); CHK(download(c, out_end, b.b.p, m)); CHK(download(c, out_dist, b.d0.p, m));
-    CHK(download(c, out_dihedral, b.d1.p, m)); CHK(download(c, out_theta_bgn, b.d2.p, m)); CHK(download(c, out_theta_end, b.d3.p, m));
-    CHK(download(c, out_type1, b.u0.p, m)); CHK(download(c, out_type2, b.u1.p, m)); CHK(download(c, out_ctype, b.u2.p, m));
+    CHK(download_async(c, out_bgn, b.a.p, m)); CHK(download_async(c, out_end, b.b.p, m)); CHK(download_async(c, out_dist, b.d0.p, m));
+    CHK(download_async(c, out_dihedral, b.d1.p, m)); CHK(download_async(c, out_theta_bgn, b.d2.p, m)); CHK(download_async(c, out_theta_end, b.d3.p, m));
+    CHK(download_async(c, out_type1, b.u0.p, m)); CHK(download_async(c, out_type2, b.u1.p, m)); CHK(download(c, out_ctype, b.u2.p, m));
     return ARP_OK;
 }
 int arp_group_group_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, float* out_dist, float* out_dihedral,
                           float* out_theta, uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_gg, "arp_group_group_fetch")
     Bag& b = c->bag_gg;
-    CHK(download(c, out_bgn, b.a.p, m)); CHK(download(c, out_end, b.b.p, m)); CHK(download(c, out_dist, b.f0.p, m));
-    CHK(download(c, out_dihedral, b.f1.p, m)); CHK(download(c, out_theta, b.f2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
+    CHK(download_async(c, out_bgn, b.a.p, m)); CHK(download_async(c, out_end, b.b.p, m)); CHK(download_async(c, out_dist, b.f0.p, m));
+    CHK(download_async(c, out_dihedral, b.f1.p, m)); CHK(download_async(c, out_theta, b.f2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
     return ARP_OK;
 }
 int arp_group_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_amide, int32_t* out_ring, double* out_dist, double* out_dihedral,
                           double* out_theta, uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_gp, "arp_group_plane_fetch")
     Bag& b = c->bag_gp;
-    CHK(download(c, out_amide, b.a.p, m)); CHK(download(c, out_ring, b.b.p, m)); CHK(download(c, out_dist, b.d0.p, m));
-    CHK(download(c, out_dihedral, b.d1.p, m)); CHK(download(c, out_theta, b.d2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
+    CHK(download_async(c, out_amide, b.a.p, m)); CHK(download_async(c, out_ring, b.b.p, m)); CHK(download_async(c, out_dist, b.d0.p, m));
+    CHK(download_async(c, out_dihedral, b.d1.p, m)); CHK(download_async(c, out_theta, b.d2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
     return ARP_OK;
 }
 

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_gather_neighbours(int n, const int* __r
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int k = nbr[i];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k >= 0) {
+        if (k >= 0 && k < n) {
             v = xyz[k];
             v.w = 1.0f;
         }
@@ -117,9 +117,63 @@ struct StaticAtoms {
     int all;                    // the selection is the whole structure (then selection_plus is, too): sel / plus not read
 };
 
+// What the classic setters check on the host (arp_set_atoms ...), for structures that arrive as one blob: done on the
+// device (the arrays are already there), result in *err (0 / ARP_E_ARG) which arp_set_blob waits for.
+struct BlobCheck {
+    int n, nres, nbond, nh, nring, namide, nrad;
+    float lo[3], hi[3];           // bounding box the grids are sized from
+    const float4* xyz;
+    const double2* rad;
+    const uint16_t* rad_idx;
+    const int* res_id;
+    const int* res_prev;
+    const int* res_next;
+    const int* bond_off;
+    const int* bond_idx;
+    const int* h_off;
+    const double* h_xyz;
+    const int* sb_nbr;
+    const double* ring_c;
+    const int* ring_res;
+    const float* am_c;
+    const int* am_res;
+    int* err;
+};
+__global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int k = gtid; k < bc.nbond; k += gstride) bad |= (unsigned)bc.bond_idx[k] >= (unsigned)bc.n;
+    for (int k = gtid; k < 3 * bc.nh; k += gstride) bad |= !isfinite(bc.h_xyz[k]);
+    for (int k = gtid; k < bc.nring; k += gstride) {
+        bad |= bc.ring_res[k] < -1 || bc.ring_res[k] >= bc.nres;
+        bad |= !(isfinite(bc.ring_c[3 * k]) && isfinite(bc.ring_c[3 * k + 1]) && isfinite(bc.ring_c[3 * k + 2]));
+    }
+    for (int k = gtid; k < bc.namide; k += gstride) {
+        bad |= bc.am_res[k] < -1 || bc.am_res[k] >= bc.nres;
+        bad |= !(isfinite(bc.am_c[3 * k]) && isfinite(bc.am_c[3 * k + 1]) && isfinite(bc.am_c[3 * k + 2]));
+    }
+    for (int k = gtid; k < bc.nres; k += gstride)
+        bad |= bc.res_prev[k] < -1 || bc.res_prev[k] >= bc.nres || bc.res_next[k] < -1 || bc.res_next[k] >= bc.nres;
+    for (int i = gtid; i < bc.n; i += gstride) {
+        const float4 v = bc.xyz[i];
+        bad |= !(v.x >= bc.lo[0] && v.x <= bc.hi[0] && v.y >= bc.lo[1] && v.y <= bc.hi[1] && v.z >= bc.lo[2] && v.z <= bc.hi[2]);   // (NaN fails)
+        bad |= (unsigned)bc.res_id[i] >= (unsigned)bc.nres;
+        const int h0 = bc.h_off[i], h1 = bc.h_off[i + 1], b0 = bc.bond_off[i], b1 = bc.bond_off[i + 1];
+        bad |= h0 < 0 || h1 < h0 || h1 > bc.nh || b0 < 0 || b1 < b0 || b1 > bc.nbond;
+        bad |= (i == 0 && (h0 != 0 || b0 != 0)) || (i == bc.n - 1 && (h1 != bc.nh || b1 != bc.nbond));
+        const double2 rd = bc.rad[i];
+        bad |= !(isfinite(rd.x) && isfinite(rd.y));
+        const unsigned ri = bc.rad_idx[i];
+        bad |= ri != RAD_NONE && ri >= (unsigned)bc.nrad;
+        bad |= bc.sb_nbr[i] < -1 || bc.sb_nbr[i] >= bc.n;
+    }
+    if (bad) atomicExch(bc.err, ARP_E_ARG);
+}
+
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
                                                         int4* __restrict__ st_q1) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    for (int i = gtid; i < n; i += gstride) {
         float4 v = r.xyz[i];
         const int res = r.res_id[i];
         uint32_t m = (uint32_t)(r.tmask[i] & M_TMASK) | ((uint32_t)(r.flags[i] & 0x7F) << M_FLAG_SHIFT);

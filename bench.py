@@ -34,7 +34,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--atoms', type=int, default=100_000, help='atoms per GPU (configs[2]: 100k; configs[3]: 250k x 8)')
+    ap.add_argument('--atoms', type=int, default=None,
+                    help='atoms per GPU; default: 100 000 at N = 1 (BASELINE configs[2]), 250 000 at N > 1 (configs[3]: 2 M atoms on 8 GPUs)')
+    ap.add_argument('--min-seconds', type=float, default=1.0,
+                    help='the K timed steps are repeated as a block until the timed region is at least this long')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the fresh-structure-per-step measurement')
     ap.add_argument('--cutoff', type=float, default=5.0)
     ap.add_argument('--vdw-comp', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -66,6 +70,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.atoms is None:
+        args.atoms = 100_000 if max(world, args.gpus) == 1 else 250_000
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
@@ -109,15 +115,11 @@ def main():
         from arpeggio_amd import sharding
         full = synth.slab_config(args.atoms, world, seed=4)
         workload = (f'synthetic {args.atoms * world} atoms in {world} x-slabs of {args.atoms} '
-                    f'(BASELINE configs[3] family), one-cell halo over RCCL')
+                    f'(BASELINE configs[3]{"" if args.atoms * world == 2_000_000 else " family"}), one-cell halo over RCCL')
         halo_note = 'records of the one-cell halo exchanged with grouped isend/irecv (RCCL)'
-        try:
-            shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
-            halo_ms = shard.halo_ms
-        except Exception as exc:   # keep the scaling run alive: every rank holds the full synthetic structure anyway
-            shard = sharding.make_shard_local(full, rank, world)
-            halo_ms = -1.0
-            halo_note = f'halo exchange failed ({exc!r}); shards cut from the locally generated structure'
+        # no fallback: if the exchange over RCCL fails, the run fails (a scaling figure must not be printed without it)
+        shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
+        halo_ms = shard.halo_ms
         ctx = _capi.Context(local_rank)
         sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
         n_local_home = int(shard.is_home.sum())
@@ -149,19 +151,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, not steps: the first passes size the result buffers (a pass is re-run when one was too small) and the
-    # GPU leaves its idle clocks; the W warm-up steps and the K timed steps below then run on a settled context
-    for _ in range(30):
+    # set-up, not steps: the first passes size the result buffers (a pass is re-run when one was too small); reported
+    # in the line as `setup_passes`.  Then the W warm-up steps and the timed region: the K steps, repeated as a block
+    # until the region is at least --min-seconds long (K x repeats steps are timed; `steps` stays K).
+    SETUP_PASSES = 5
+    for _ in range(SETUP_PASSES):
         counts = step()
     for _ in range(args.warmup):
         counts = step()
     sync_all()
     ctx.host_times(reset=True)
+    repeats = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts = step()          # blocks until the context stream has drained (one sync per step)
+    while True:
+        for _ in range(args.steps):
+            counts = step()          # blocks until the pass has published its counters (one host wait per step)
+        repeats += 1
+        go_on = (time.perf_counter() - t0) < args.min_seconds
+        if dist is not None:         # every rank must take the same number of blocks
+            flag = torch.tensor([1.0 if go_on else 0.0], device=('cpu' if comm_device is None else comm_device))
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            go_on = bool(flag.item() > 0)
+        if not go_on:
+            break
     sync_all()
     elapsed = time.perf_counter() - t0
+    timed_steps = args.steps * repeats
     host_times = ctx.host_times(reset=True)
     st = ctx.stats()
     # Per-kernel durations: the same K steps once more with every launch bracketed by HIP events on the
@@ -215,6 +230,106 @@ def main():
         except Exception as exc:   # never lose the main line over the extra measurement
             in_flight = {'error': repr(exc)}
 
+    # ---- wall clock per structure, end to end (world == 1; never `value`): a FRESH structure every step — one packed
+    # upload from page-locked memory (arp_set_blob: copy + device-side validation), the static record columns and the
+    # ring / amide grids rebuilt, the pass, and every result bag copied into page-locked host buffers.  The structures
+    # cycle through four different seeds of the same workload.  Measured with one context (latency of one structure)
+    # and with three contexts on three host threads (upload / pass / download of consecutive structures overlap).
+    end_to_end = None
+    if world == 1 and not args.no_end_to_end:
+        try:
+            import threading
+            if args.workload == 'standin':
+                fresh = [synth.proteinlike(seed=2 + k) for k in range(4)]
+            else:
+                fresh = [synth.config3(args.atoms, seed=3 + k) for k in range(4)]
+            t_pack = time.perf_counter()
+            blobs = [_capi.pack_blob(f) for f in fresh]
+            pack_ms = (time.perf_counter() - t_pack) / len(blobs) * 1e3
+
+            def make_buffers(cx):
+                cx.set_blob(blobs[0])
+                cnt = cx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+                cap = int(cnt['atom_atom'] * 1.2) + 1024
+                return cx.pinned_contact_buffers(cap), {k: cx.pinned_bag_buffers(k, 4 * max(cnt[k], 256)) for k in ('plane_plane', 'atom_plane', 'group_group', 'group_plane')}
+
+            def one_structure(cx, blob, bufs):
+                cx.set_blob(blob)
+                cnt = cx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+                res = cx.atom_contacts_fetch(cnt['atom_atom'], sort=False, out=bufs[0])
+                bags = {k: cx.fetch_bag(k, sort=False, out=bufs[1][k]) for k in bufs[1]}
+                return cnt, res, bags
+
+            bufs = make_buffers(ctx)
+            for k in range(8):
+                one_structure(ctx, blobs[k % 4], bufs)
+            n_e2e, t1 = 0, time.perf_counter()
+            while n_e2e < 40 or time.perf_counter() - t1 < 0.5:
+                cnt_e, res_e, bags_e = one_structure(ctx, blobs[n_e2e % 4], bufs)
+                n_e2e += 1
+            e2e_ms = (time.perf_counter() - t1) / n_e2e * 1e3
+            # breakdown of one structure (separately timed calls; their sum is a little above the loop figure)
+            br = {}
+            tt = time.perf_counter(); ctx.set_blob(blobs[1]); br['upload_validate_ms'] = (time.perf_counter() - tt) * 1e3
+            tt = time.perf_counter(); cnt_e = ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0); br['first_pass_ms'] = (time.perf_counter() - tt) * 1e3
+            tt = time.perf_counter(); res_e = ctx.atom_contacts_fetch(cnt_e['atom_atom'], sort=False, out=bufs[0]); br['download_contacts_ms'] = (time.perf_counter() - tt) * 1e3
+            tt = time.perf_counter(); bags_e = {k: ctx.fetch_bag(k, sort=False, out=bufs[1][k]) for k in bufs[1]}; br['download_bags_ms'] = (time.perf_counter() - tt) * 1e3
+            nbytes_up = int(blobs[1].nbytes)
+            nbytes_down = int(sum(v.nbytes for v in res_e.values()) + sum(v.nbytes for b in bags_e.values() for v in b.values()))
+            # the exporter of the drop-in class on this result (JSON records as the reference's get_contacts builds them)
+            from arpeggio_amd.core import export as _export
+            o = np.lexsort((res_e['j'], res_e['i']))
+            bag_sorted = {'atom_atom': {k: v[o] for k, v in res_e.items()}}
+            bag_sorted.update({k: ctx.fetch_bag(k) for k in bufs[1]})
+            fresh[1].ensure_labels()
+            tt = time.perf_counter()
+            recs = _export.contacts_json(fresh[1], bag_sorted, fresh[1].component_types)
+            get_contacts_ms = (time.perf_counter() - tt) * 1e3
+            n_recs = len(recs)
+            del recs
+            # pipelined: three contexts, three host threads
+            pipelined = None
+            if args.inflight > 1:
+                ctxs = [_capi.Context(local_rank) for _ in range(args.inflight)]
+                bb = [make_buffers(cx) for cx in ctxs]
+                per_thread = max(30, n_e2e // args.inflight)
+                gate = threading.Barrier(args.inflight + 1)
+
+                def worker(cx, bf, off):
+                    for k in range(4):
+                        one_structure(cx, blobs[(off + k) % 4], bf)
+                    gate.wait()
+                    for k in range(per_thread):
+                        one_structure(cx, blobs[(off + k) % 4], bf)
+
+                th = [threading.Thread(target=worker, args=(cx, bf, k)) for k, (cx, bf) in enumerate(zip(ctxs, bb))]
+                for t in th:
+                    t.start()
+                gate.wait()
+                t2 = time.perf_counter()
+                for t in th:
+                    t.join()
+                pipelined = round((time.perf_counter() - t2) / (per_thread * args.inflight) * 1e3, 4)
+                for cx in ctxs:
+                    cx.close()
+            end_to_end = {'ms_per_structure': round(e2e_ms, 4), 'structures': n_e2e,
+                          'ms_per_structure_3_contexts_in_flight': pipelined,
+                          'breakdown_ms': {k: round(v, 4) for k, v in br.items()},
+                          'upload_bytes': nbytes_up, 'download_bytes': nbytes_down,
+                          'candidate_pairs_per_s': round(st['candidates'] / (e2e_ms * 1e-3), 1),
+                          'pack_blob_ms_host': round(pack_ms, 3),
+                          'get_contacts_ms': round(get_contacts_ms, 2), 'get_contacts_records': n_recs,
+                          'note': 'fresh structure per step: arp_set_blob (one H2D copy from page-locked memory + device-side validation) + '
+                                  'static columns + ring / amide grids + pass + all five result bags into page-locked host buffers; '
+                                  'pack_blob_ms_host = NumPy packing of a PackedComplex into the blob (done by the producer of the '
+                                  'structure, outside the figure); get_contacts_ms = building the JSON records of the drop-in class '
+                                  'from the fetched arrays (host Python, outside the figure)'}
+            ctx.set_complex(pc)     # back to the resident benchmark structure
+            for _ in range(3):
+                step()
+        except Exception as exc:   # never lose the main line over the extra measurement
+            end_to_end = {'error': repr(exc)}
+
     # max over ranks of the elapsed time, sum over ranks of the work
     cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
     if dist is not None:
@@ -233,8 +348,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = cand_all * args.steps / elapsed
+    ms_per_step = elapsed / timed_steps * 1e3
+    value = cand_all * timed_steps / elapsed
 
     # ---------------- roofline of the dominant kernel (rank 0) ----------------
     per_kernel = {k: (v['ms'] / max(v['launches'], 1)) for k, v in ktimes.items() if v['launches']}
@@ -254,6 +369,18 @@ def main():
             traffic = pj['kernels'][f'k_{dom}']['hbm_bytes_per_launch']
             traffic_src = pj['source']
     except (OSError, KeyError, ValueError):
+        pass
+    # The number that actually bounds these kernels: VALU issue.  SQ_INSTS_VALU of the committed PMC run (per launch) /
+    # (launch duration x 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32)
+    roofline_valu = None
+    try:
+        pv = pj['kernels'][f'k_{dom}']
+        if args.atoms == 100_000 and world == 1 and 'valu_insts_per_launch' in pv:
+            peak = 1024 * 2.4e9 / 2.0
+            roofline_valu = {'kernel': f'k_{dom}', 'valu_wave_instructions_per_launch': pv['valu_insts_per_launch'],
+                             'issue_peak_per_s': peak, 'frac': round(pv['valu_insts_per_launch'] / (dom_ms * 1e-3) / peak, 4),
+                             'source': pj['source']}
+    except (OSError, KeyError, ValueError, NameError):
         pass
     roofline = {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
@@ -349,14 +476,15 @@ def main():
     line = {
         'metric': 'evaluated atom-pairs/s', 'value': round(value, 1), 'unit': 'candidate atom-pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'timed_steps': timed_steps, 'timed_region_s': round(elapsed, 3), 'setup_passes': SETUP_PASSES,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64 distance test / f32+f64 SIFt',
         'data': 'synthetic',
         'config': {'workload': workload, 'atoms_per_gpu': args.atoms, 'cutoff_A': args.cutoff, 'vdw_comp': args.vdw_comp,
                    'parallelism': f'slab{world}' if world > 1 else 'single'},
-        'wall_clock_per_structure_ms': round(ms_per_step, 4),
+        'wall_clock_per_structure_ms': round(ms_per_step, 4),   # RESIDENT structure re-evaluated; fresh structures: end_to_end
         'pairs': {'candidates': cand_all, 'accepted': acc_all, 'contacts_emitted': emitted_all,
                   'expansion_candidates_6A': exp_all, 'bags': counts},
-        'accepted_pairs_per_s': round(acc_all * args.steps / elapsed, 1),
+        'accepted_pairs_per_s': round(acc_all * timed_steps / elapsed, 1),
         'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()},
         'kernel_launches_per_step': {k: v['launches'] / args.steps for k, v in ktimes.items() if v['launches']},
         'ms_per_step_profiled_pass': round(elapsed_profiled / args.steps * 1e3, 4),
@@ -365,9 +493,13 @@ def main():
         'cpu_baseline_all_cores': cpu_mc,
         'cpu_baseline_python': cpu_py,
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
-        'launch_mode': 'direct launches on two HIP streams, one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
+        'launch_mode': 'four launches on one HIP stream (bin, scan+scatter, search, sift+ring/amide loops), the last one publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
         'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange': (halo_note if world > 1 else None), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
+        'end_to_end': end_to_end,
+        'end_to_end_ms_per_structure': (end_to_end or {}).get('ms_per_structure'),
+        'get_contacts_ms': (end_to_end or {}).get('get_contacts_ms'),
+        'roofline_valu': roofline_valu,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(line))

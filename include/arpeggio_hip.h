@@ -152,6 +152,43 @@ int arp_set_rings(arp_ctx* ctx, int64_t nring, const double* center,
 int arp_set_amides(arp_ctx* ctx, int64_t namide, const float* center,
                    const float* normal, const int32_t* amide_res);
 
+/* ---- the same inputs as ONE blob --------------------------------------------------------
+ * Everything arp_set_atoms ... arp_set_amides take, laid out device-ready in one contiguous host
+ * buffer (ideally page-locked: arp_host_alloc) and uploaded with a single asynchronous copy.
+ * The packer of a structure (what the reference's initialize(), I:288-327, leaves behind) writes
+ * straight into the views arp_blob_layout describes; nothing is converted or copied again on the
+ * way to the GPU.  Arrays, in the order of off[]:
+ *   0 xyz4      float[4n]   x, y, z, 0 per atom (P:327)            11 h_xyz     double[3 nh]   (I:1529)
+ *   1 rad       double[2n]  vdw, cov per atom (I:1501,1509)        12 sb_nbr    int32[n]       (U:612-635, -1 = None)
+ *   2 type_mask uint16[n]   ARP_T_*                                13 ring_c    double[3 nring]
+ *   3 flags     uint16[n]   ARP_F_*                                14 ring_n    double[3 nring]
+ *   4 res_id    int32[n]                                           15 ring_res  int32[nring]   (-1 = None)
+ *   5 res_flags uint8[nres] ARP_R_*                                16 amide_c   float[3 namide]
+ *   6 res_prev  int32[nres]                                        17 amide_n   float[3 namide]
+ *   7 res_next  int32[nres]                                        18 amide_res int32[namide]
+ *   8 bond_off  int32[n+1]  CSR (I:750)                            19 rad_idx   uint16[n]  index into rad_tab, 0xFFFF = not in it
+ *   9 bond_idx  int32[nbond]                                       20 rad_tab   double[2 * 256]  distinct {vdw, cov} pairs
+ *  10 h_off     int32[n+1]  CSR (I:1513-1529)
+ * lo/hi, ring_lo/hi, amide_lo/hi = bounding boxes of the atom coordinates / ring centres / amide centres (the grids are
+ * sized from them; arp_set_blob verifies that every point lies inside).  n_rad = entries of rad_tab in use. */
+#define ARP_BLOB_MAGIC 0x31424F4C42505241ull   /* "ARPBLOB1" */
+#define ARP_BLOB_ARRAYS 21
+typedef struct arp_blob_header {
+    uint64_t magic, bytes;
+    int64_t n, nres, nbond, nh, nring, namide, n_rad;
+    uint64_t off[ARP_BLOB_ARRAYS];      /* byte offsets from the start of the blob, 16-byte aligned */
+    double lo[3], hi[3], ring_lo[3], ring_hi[3], amide_lo[3], amide_hi[3];
+} arp_blob_header;
+/* bytes needed for a blob with these counts (header included); 0 on bad counts */
+uint64_t arp_blob_size(int64_t n, int64_t nres, int64_t nbond, int64_t nh, int64_t nring, int64_t namide);
+/* writes the header (magic, counts, offsets) at the start of `blob`; the caller then fills the arrays, the boxes and n_rad */
+int arp_blob_layout(void* blob, uint64_t bytes, int64_t n, int64_t nres, int64_t nbond, int64_t nh, int64_t nring, int64_t namide);
+/* Replaces every input of the context with the blob's.  One asynchronous host-to-device copy on the context's stream,
+ * then a device-side check of what the classic setters check on the host (finite coordinates inside the box, index
+ * ranges, CSR offsets) that the call waits for: ARP_E_ARG if the blob fails it.  The blob may be reused or freed when
+ * the call returns.  Selection and ownership are reset (whole structure, I:1395). */
+int arp_set_blob(arp_ctx* ctx, const void* blob, uint64_t bytes);
+
 /* ---- Bio.PDB.NeighborSearch equivalents (I:707,960,1394,1420,1442) -------- */
 /* NeighborSearch(atoms).search_all(radius): every unordered pair with
  * float64 d^2 <= radius^2, once, as (i<j).  active = optional u8[n] mask of the

@@ -362,3 +362,55 @@ def test_random_ring_and_amide_sets(ctx):
                 assert close(g[k], e[k][o]), (case, name, k)
             records += len(o)
     assert records > 20_000
+
+
+@pytest.mark.gpu
+def test_blob_upload_equals_classic_upload_and_rejects_bad_input():
+    """arp_set_blob (one packed copy + device-side validation) leaves the context exactly as the classic setters do; the
+    checks those setters make on the host are made on the device and turn into the same ValueError."""
+    from arpeggio_amd import _capi, synth
+    pc = synth.config3(20_000, seed=9)
+    a, b = _capi.Context(0), _capi.Context(0)
+    a.set_complex(pc)
+    blob = _capi.pack_blob(pc)
+    b.set_blob(blob)
+    sel = np.zeros(pc.n_atoms, np.uint8)
+    sel[pc.res_id % 7 == 0] = 1
+    for s in (None, sel):
+        if s is not None:
+            a.set_selection(s); b.set_selection(s)
+        ca, cb = a.run_launch(5.0, 0.1, False, 6.0), b.run_launch(5.0, 0.1, False, 6.0)
+        assert ca == cb
+        ra, rb = a.atom_contacts_fetch(ca['atom_atom']), b.atom_contacts_fetch(cb['atom_atom'])
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), k
+        for bag in ('plane_plane', 'atom_plane', 'group_group', 'group_plane'):
+            xa, xb = a.fetch_bag(bag), b.fetch_bag(bag)
+            for k in xa:
+                assert np.array_equal(xa[k], xb[k], equal_nan=(xa[k].dtype.kind == 'f')), (bag, k)
+    # a second structure into the same context, then back: views are re-pointed, nothing stale survives
+    pc2 = synth.proteinlike(n_res=60, n_waters=30)
+    b.set_blob(_capi.pack_blob(pc2))
+    a.set_complex(pc2)
+    assert a.run_launch(5.0, 0.1, False, 6.0) == b.run_launch(5.0, 0.1, False, 6.0)
+    # corrupted blobs
+    hdr_size = 512
+    def broken(mutate):
+        bad = _capi.pack_blob(pc2)
+        h = _capi.BlobHeader.from_buffer(bad)
+        mutate(bad, h)
+        del h
+        return bad
+    def nan_coord(bad, h): np.frombuffer(bad, np.float32, 4, int(h.off[0]))[1] = np.nan
+    def res_range(bad, h): np.frombuffer(bad, np.int32, 1, int(h.off[4]))[0] = int(h.nres)
+    def bond_range(bad, h): np.frombuffer(bad, np.int32, 1, int(h.off[9]))[0] = int(h.n)
+    def csr(bad, h): np.frombuffer(bad, np.int32, 3, int(h.off[10]))[1] = 10**6
+    def outside(bad, h): h.hi[0] = h.lo[0]
+    def magic(bad, h): h.magic = 1
+    def counts(bad, h): h.n = h.n + 1
+    for m in (nan_coord, res_range, bond_range, csr, outside, magic, counts):
+        with pytest.raises(ValueError):
+            b.set_blob(broken(m))
+    b.set_blob(_capi.pack_blob(pc2))                      # and the context is still usable
+    assert a.run_launch(5.0, 0.1, False, 6.0) == b.run_launch(5.0, 0.1, False, 6.0)
+    a.close(); b.close()

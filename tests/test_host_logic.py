@@ -150,3 +150,25 @@ def test_proteinlike_generator():
     assert len(sel) > 20 and {a.res_name[r] for r in a.res_id[sel]} == {'HEM'}
     # peptide-bonded neighbours are sequence neighbours
     assert a.res_next[0] == 1 and a.res_prev[1] == 0 and a.res_prev[0] == -1
+
+
+def test_blob_layout_without_a_gpu():
+    """arp_blob_size / arp_blob_layout are host-only: header, 16-byte aligned offsets, arrays where the header says."""
+    from arpeggio_amd import _capi
+    pc = synth.proteinlike(n_res=40, n_waters=12)
+    blob = _capi.pack_blob(pc, pinned=False)
+    h = _capi.BlobHeader.from_buffer_copy(blob[:ctypes.sizeof(_capi.BlobHeader)].tobytes())
+    assert h.magic == 0x31424F4C42505241 and h.bytes == blob.nbytes
+    assert (h.n, h.nres, h.nring, h.namide) == (pc.n_atoms, pc.n_residues, pc.n_rings, pc.n_amides)
+    offs = list(h.off)
+    assert all(o % 16 == 0 for o in offs) and offs == sorted(offs) and offs[0] >= ctypes.sizeof(_capi.BlobHeader)
+    x4 = np.frombuffer(blob, np.float32, 4 * pc.n_atoms, offs[0]).reshape(-1, 4)
+    assert np.array_equal(x4[:, :3], pc.xyz) and not x4[:, 3].any()
+    idx = np.frombuffer(blob, np.uint16, pc.n_atoms, offs[19])
+    tab = np.frombuffer(blob, np.float64, 512, offs[20]).reshape(256, 2)
+    assert np.array_equal(tab[idx, 0], pc.vdw) and np.array_equal(tab[idx, 1], pc.cov) and h.n_rad == len(np.unique(tab[:h.n_rad], axis=0))
+    assert np.array_equal(np.frombuffer(blob, np.float64, 3 * pc.h_xyz.shape[0], offs[11]).reshape(-1, 3), pc.h_xyz)
+    assert list(h.lo) == pc.xyz.min(axis=0).astype(np.float64).tolist()
+    L = _capi.load()
+    assert L.arp_blob_size(-1, 0, 0, 0, 0, 0) == 0
+    assert L.arp_blob_layout(None, 0, 1, 1, 0, 0, 0, 0) != 0

@@ -48,9 +48,10 @@ traffic = {}
 for k, v in out.items():
     if k.startswith('__amd') or 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
         continue
-    key = {'void k_search<0>': 'k_search', 'void k_search<2>': 'k_mark_search'}.get(k, k)
+    key = {'void k_search<0>': 'k_search', 'void k_search<2>': 'k_mark_search', 'k_sift_planes': 'k_sift'}.get(k, k)
     traffic[key] = {'hbm_bytes_per_launch': int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024),
                     'fetch_kib_raw': v['FETCH_SIZE'], 'write_kib_raw': v['WRITE_SIZE'],
+                    'valu_insts_per_launch': v.get('SQ_INSTS_VALU'),
                     'rocprof_avg_ns': avg_ns.get(k)}
 json.dump({'source': f'{tag} (tools/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes)',
            'correction': 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream)',
