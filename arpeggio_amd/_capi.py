@@ -30,6 +30,7 @@ SYMBOLS = (
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
     'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
     'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob',
+    'arp_write_contacts_json',
 )
 
 _lib = None
@@ -77,6 +78,7 @@ def load():
     L.arp_blob_size.restype = C.c_uint64
     L.arp_blob_layout.argtypes = [vp, C.c_uint64] + [i64] * 6
     L.arp_set_blob.argtypes = [vp, vp, C.c_uint64]
+    L.arp_write_contacts_json.argtypes = [C.c_char_p, i32, i32, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_char_p, i64]
     L.arp_device_buffer.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.arp_run_stage.argtypes = [vp, i32, dbl, dbl, i32, dbl, vp]
     L.arp_set_group_ownership.argtypes = [vp, vp, vp, vp, vp]

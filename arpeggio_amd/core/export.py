@@ -141,6 +141,46 @@ def contacts_json(pc, bags, component_types):
     return out
 
 
+def write_contacts_json(path, pc, bags, component_types, indent=4):
+    """``json.dump(get_contacts(), fh, indent=indent, sort_keys=True)`` (scripts/process_protein_cli.py:184-188) without
+    building the records in Python: the atom-atom bag — millions of records on a whole-structure run — is formatted by the
+    native library from the result arrays, the few ring / amide records by the json module.  Same bytes."""
+    import ctypes as C
+    import json
+
+    from .. import _capi
+    L = _capi.load()
+    pc.ensure_labels()
+    tail = contacts_json(pc, {k: v for k, v in bags.items() if k != 'atom_atom'}, component_types)
+    pad = ' ' * indent
+    tail_text = ',\n'.join('\n'.join(pad + line for line in json.dumps(r, indent=indent, sort_keys=True).split('\n')) for r in tail)
+    b = bags.get('atom_atom')
+    n = 0 if b is None else len(b['i'])
+    z = np.zeros(0, np.int32)
+    ci = np.ascontiguousarray(b['i'], np.int32) if n else z
+    cj = np.ascontiguousarray(b['j'], np.int32) if n else z
+    dist = np.round(np.asarray(b['dist'], np.float64), 2) if n else np.zeros(0)
+    sift = np.ascontiguousarray(b['sift'], np.uint16) if n else np.zeros(0, np.uint16)
+    ctype = np.ascontiguousarray(b['ctype'], np.uint8) if n else np.zeros(0, np.uint8)
+
+    def strings(items):
+        arr = (C.c_char_p * max(len(items), 1))()
+        for k, v in enumerate(items):
+            arr[k] = str(v).encode('utf-8')
+        return arr
+
+    nr = pc.n_residues
+    comp = [component_types[pc.res_name[r]] for r in range(nr)]       # KeyError like I:186
+    atom_res = np.ascontiguousarray(pc.res_id, np.int32)
+    res_seq = np.ascontiguousarray(pc.res_seq, np.int32)
+    rc = L.arp_write_contacts_json(os.fsencode(path), int(indent), 0, n, _capi._p(ci), _capi._p(cj), _capi._p(dist), _capi._p(sift),
+                                   _capi._p(ctype), pc.n_atoms, _capi._p(atom_res), strings(pc.atom_name), nr, strings(pc.res_name),
+                                   _capi._p(res_seq), strings(pc.res_chain), strings(pc.res_icode), strings(comp),
+                                   strings(config.SIFT_NAMES), strings(config.CONTACT_TYPE_NAMES), tail_text.encode('utf-8'), len(tail))
+    if rc != 0:
+        raise OSError(f'arp_write_contacts_json({path!r}) failed ({rc})')
+
+
 def _writer(path):
     fh = open(path, 'w')
     return fh, csv.writer(fh, delimiter=',', quotechar='"', quoting=csv.QUOTE_MINIMAL)

@@ -300,6 +300,12 @@ class InteractionComplex:
         atom-plane, group-group, group-plane), canonical order inside a bag ([] before run_arpeggio, like I:84-88)."""
         return export.contacts_json(self.pc, self._bags, self.component_types)
 
+    def write_json(self, path, indent=4):
+        """The file the reference's CLI writes (scripts/process_protein_cli.py:184-188):
+        ``json.dump(self.get_contacts(), fh, indent=4, sort_keys=True)``, byte for byte, without building the records in
+        Python (native formatter for the atom-atom bag)."""
+        export.write_contacts_json(path, self.pc, self._bags, self.component_types, indent)
+
     # endregion
 
 

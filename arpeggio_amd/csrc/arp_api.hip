@@ -21,6 +21,7 @@
 #include "arp_pairs.h"
 #include "arp_planes.h"
 #include "arp_prepare.h"
+#include "arp_json.h"
 
 namespace {
 

@@ -287,6 +287,12 @@ def main():
             get_contacts_ms = (time.perf_counter() - tt) * 1e3
             n_recs = len(recs)
             del recs
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:     # the CLI's output file, written by the native formatter
+                tt = time.perf_counter()
+                _export.write_contacts_json(os.path.join(td, 'out.json'), fresh[1], bag_sorted, fresh[1].component_types)
+                write_json_ms = (time.perf_counter() - tt) * 1e3
+                json_bytes = os.path.getsize(os.path.join(td, 'out.json'))
             # pipelined: three contexts, three host threads
             pipelined = None
             if args.inflight > 1:
@@ -319,6 +325,7 @@ def main():
                           'candidate_pairs_per_s': round(st['candidates'] / (e2e_ms * 1e-3), 1),
                           'pack_blob_ms_host': round(pack_ms, 3),
                           'get_contacts_ms': round(get_contacts_ms, 2), 'get_contacts_records': n_recs,
+                          'write_json_ms': round(write_json_ms, 2), 'write_json_bytes': json_bytes,
                           'note': 'fresh structure per step: arp_set_blob (one H2D copy from page-locked memory + device-side validation) + '
                                   'static columns + ring / amide grids + pass + all five result bags into page-locked host buffers; '
                                   'pack_blob_ms_host = NumPy packing of a PackedComplex into the blob (done by the producer of the '

@@ -391,6 +391,22 @@ uint64_t arp_stream_handle(arp_ctx* ctx);
  * blocks.  The stream must outlive the context or be reset with 0 first. */
 int arp_use_stream(arp_ctx* ctx, uint64_t stream);
 
+/* ---- JSON output (host only; no context, no GPU) ------------------------------------------
+ * The reference's CLI ends with json.dump(get_contacts(), fh, indent=4, sort_keys=True) (scripts/process_protein_cli.py:
+ * 184-188; records of I:172-212).  This writes the same bytes for the atom-atom records straight from the result arrays
+ * (sorted keys, indentation, float repr and string escaping of Python's json module) — a Python dict per record costs
+ * seconds on a whole-structure run — followed by `tail_records`: the n_tail records of the four ring / amide bags, already
+ * rendered at the same indentation and joined with ",\n" (they are few; the Python layer renders them).
+ * dist_rounded = round(float64(distance), 2) of every contact (I:190).  sift_names: 15 strings, ctype_names: 7 strings.
+ * Returns 0, or a negative number (-1 bad argument, -2 cannot open, -3 index out of range, -4 write error). */
+int arp_write_contacts_json(const char* path, int indent, int append_mode, int64_t n, const int32_t* ci, const int32_t* cj,
+                            const double* dist_rounded, const uint16_t* sift, const uint8_t* ctype, int64_t n_atoms,
+                            const int32_t* atom_res, const char* const* atom_name, int64_t n_res,
+                            const char* const* res_name, const int32_t* res_seq, const char* const* res_chain,
+                            const char* const* res_icode, const char* const* res_comp_type,
+                            const char* const* sift_names, const char* const* ctype_names, const char* tail_records,
+                            int64_t n_tail);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,6 +271,9 @@ def test_drop_in_exports_equal_executed_reference(core, tmp_path):
         assert json.dumps(ic.get_contacts(), sort_keys=True) == exp['get_contacts'], name
         wd = tmp_path / name.replace(':', '_')
         wd.mkdir()
+        ic.write_json(str(wd / 'out.json'))        # the CLI's file (CLI:184-188), written natively
+        assert open(wd / 'out.json').read() == json.dumps(json.loads(exp['get_contacts']), indent=4, sort_keys=True), name
+        os.remove(wd / 'out.json')
         ic.write_contacts(ic.selection if (c.get('selectors') or c.get('sel')) else [], str(wd))
         assert np.array_equal(export.potential_fsift(pc), z[name + '/atom_potential_fsift']), name
         ic.write_atom_types(str(wd))

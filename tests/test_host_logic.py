@@ -172,3 +172,32 @@ def test_blob_layout_without_a_gpu():
     L = _capi.load()
     assert L.arp_blob_size(-1, 0, 0, 0, 0, 0) == 0
     assert L.arp_blob_layout(None, 0, 1, 1, 0, 0, 0, 0) != 0
+
+
+def test_native_json_writer_equals_json_dump(tmp_path):
+    """arp_write_contacts_json (host-only) == json.dump(records, indent=4, sort_keys=True) of the Python exporter, on
+    made-up result bags with awkward strings and distances."""
+    from arpeggio_amd.core import export
+    pc = synth.proteinlike(n_res=30, n_waters=10).ensure_labels()
+    pc.atom_name[3] = 'O2\'"\\'
+    pc.atom_name[4] = 'Cα'            # non-ASCII -> \\uXXXX
+    pc.res_icode[1] = 'B'
+    rng = np.random.default_rng(5)
+    n = 400
+    i = rng.integers(0, pc.n_atoms - 1, n).astype(np.int32)
+    j = (i + 1 + rng.integers(0, 5, n)).clip(max=pc.n_atoms - 1).astype(np.int32)
+    dist = (rng.random(n) * 6).astype(np.float32)
+    dist[:6] = [0.0, 3.0, 4.999999, 2.675, 1e-5, 0.004999]
+    bags = {'atom_atom': dict(i=i, j=j, dist=dist, sift=rng.integers(0, 1 << 15, n).astype(np.uint16),
+                              ctype=rng.integers(0, 6, n).astype(np.uint8)),
+            'plane_plane': dict(bgn=np.array([0, 1], np.int32), end=np.array([1, 2], np.int32), dist=np.array([4.7234, 5.0]),
+                                type1=np.array([3, 9], np.uint8), type2=np.array([5, 255], np.uint8), ctype=np.array([2, 6], np.uint8)),
+            'group_group': dict(bgn=np.array([0], np.int32), end=np.array([2], np.int32), dist=np.array([4.29], np.float32),
+                                ctype=np.array([6], np.uint8))}
+    bags['atom_atom']['sift'][7] = 0
+    for case, b in (('full', bags), ('only_tail', {k: v for k, v in bags.items() if k != 'atom_atom'}), ('empty', {}),
+                    ('only_atoms', {'atom_atom': bags['atom_atom']})):
+        path = tmp_path / f'{case}.json'
+        export.write_contacts_json(str(path), pc, b, pc.component_types)
+        want = json.dumps(export.contacts_json(pc, b, pc.component_types), indent=4, sort_keys=True)
+        assert open(path, encoding='utf-8').read() == want, case
