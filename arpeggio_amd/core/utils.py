@@ -37,94 +37,90 @@ def is_digit(x):
         return False
 
 
+class _Tables:
+    """String columns of a PackedComplex as object arrays (built once per parser call)."""
+
+    def __init__(self, pc):
+        pc.ensure_labels()
+        self.pc = pc
+        self.res_of = pc.res_id
+        self.res_name = np.asarray(pc.res_name, dtype=object)
+        self.res_chain = np.asarray(pc.res_chain, dtype=object)
+        self.res_seq = np.asarray(pc.res_seq)
+        self.res_icode = np.asarray(pc.res_icode, dtype=object)
+        self.atom_name = np.asarray(pc.atom_name, dtype=object)
+
+
+def _select_resname(t, text, original):
+    name = text.replace('RESNAME:', '').strip()
+    if len(name) > 3:
+        raise SelectionError(original)
+    return (np.array([r.strip() for r in t.res_name], dtype=object) == name)[t.res_of]
+
+
+def _select_ligands(t):
+    pc, nres = t.pc, t.pc.n_residues
+    size = np.bincount(t.res_of, minlength=nres)
+    with_carbon = np.zeros(nres, bool)
+    with_carbon[t.res_of[np.asarray(pc.element, dtype=object) == 'C']] = True
+    names = [r.strip().upper() for r in t.res_name]
+    excluded = config.COMMON_SOLVENTS | config.STANDARD_NUCLEOTIDES
+    ligand = np.fromiter((not (pc.res_flags[r] & config.R_POLYPEPTIDE) and 5 <= size[r] <= 100 and with_carbon[r]
+                          and names[r] not in excluded and not t.res_name[r].startswith('+') for r in range(nres)), bool, nres)
+    return ligand[t.res_of]
+
+
+def _residue_field(text, original):
+    """'<number>[<insertion letter>]' -> (number, insertion code); anything else is a bad selector."""
+    if is_digit(text):
+        return int(text), ' '
+    if text.isalnum() and text[-1].isalpha() and is_digit(text[:-1]):
+        return int(text[:-1]), text[-1]
+    raise SelectionError(original)
+
+
+def _select_path(t, text, original):
+    fields = text.lstrip('/').split('/')
+    if len(fields) != 3:
+        raise SelectionError(original)
+    chain, residue, name = fields
+    mask = np.ones(t.pc.n_atoms, bool)
+    number, icode = _residue_field(residue, original) if residue else (None, ' ')
+    if name and not (name.isalnum() or "'" in name):
+        raise SelectionError(original)
+    if chain:
+        mask &= (t.res_chain == chain)[t.res_of]
+    if number:          # a residue number of 0 is falsy, hence silently ignored — as in the reference (utils.py:508)
+        mask &= ((t.res_seq == number) & (t.res_icode == icode))[t.res_of]
+    if name:
+        mask &= t.atom_name == name
+    return mask
+
+
 def selection_parser(selection_list, pc):
-    """Atoms selected by a list of selectors; returns a sorted int array of packed atom indices.
+    """Atoms selected by a list of selectors (their union); returns a sorted int array of packed atom indices.
 
-    Selector forms (additive): ``/<chain>/<resnum>[<inscode>]/<atom_name>`` with exactly
-    three fields (any may be empty), ``RESNAME:<up to 3 chars>`` and ``LIGANDS``.
-    Quirks kept from the reference: a residue number of 0 is ignored (utils.py:508), atom
-    names must be alphanumeric or contain an apostrophe (utils.py:499), an empty result
-    raises ``SelectionError('entity not found')`` (utils.py:522-524).
+    Behavioural counterpart of ``utils.selection_parser`` (arpeggio/core/utils.py:396-526), pinned against the executed
+    reference function by tests/golden/selection_parser.json.  Selector forms: ``/<chain>/<resnum>[<inscode>]/<atom_name>``
+    with exactly three fields (any may be empty), ``RESNAME:<up to 3 chars>`` and ``LIGANDS``; anything else, and an empty
+    result, raise ``SelectionError``.
     """
-    pc.ensure_labels()
-    n = pc.n_atoms
-    res_of = pc.res_id
-    res_name = np.asarray(pc.res_name, dtype=object)
-    res_chain = np.asarray(pc.res_chain, dtype=object)
-    res_seq = np.asarray(pc.res_seq)
-    res_icode = np.asarray(pc.res_icode, dtype=object)
-    atom_name = np.asarray(pc.atom_name, dtype=object)
-    final = np.zeros(n, bool)
-
-    for selection in selection_list:
-        residue_number = None
-        insertion_code = ' '
-        chain = None
-        name = None
-        original_selection = selection
-        selection = selection.strip()
-        current = np.ones(n, bool)
-
-        if selection.startswith('RESNAME:'):
-            selection = selection.replace('RESNAME:', '').strip()
-            if len(selection) > 3:  # RESNAMES ARE MAX LENGTH 3
-                raise SelectionError(original_selection)
-            stripped = np.array([r.strip() for r in res_name], dtype=object)
-            final |= (stripped == selection)[res_of]
-
-        elif selection.startswith('LIGANDS'):
-            nres = pc.n_residues
-            natoms = np.bincount(res_of, minlength=nres)
-            elem = np.asarray(pc.element, dtype=object)
-            has_c = np.zeros(nres, bool)
-            has_c[res_of[elem == 'C']] = True
-            upper = [r.strip().upper() for r in res_name]
-            ok = np.array([
-                not (pc.res_flags[r] & config.R_POLYPEPTIDE)             # MUST NOT BE POLYPEPTIDE
-                and 5 <= natoms[r] <= 100                                 # MIN / MAX NUMBER OF ATOMS
-                and has_c[r]                                              # MUST CONTAIN CARBON
-                and upper[r] not in config.COMMON_SOLVENTS                # MUST NOT BE COMMON SOLVENT
-                and upper[r] not in config.STANDARD_NUCLEOTIDES           # MUST NOT BE NUCLEOTIDE
-                and not res_name[r].startswith('+')                       # MUST NOT BE MODIFIED NUCLEOTIDE
-                for r in range(nres)], bool) if nres else np.zeros(0, bool)
-            final |= ok[res_of]
-
-        elif selection.startswith('/'):
-            fields = selection.lstrip('/').split('/')
-            if len(fields) != 3:
-                raise SelectionError(original_selection)
-            if fields[0]:
-                chain = fields[0]
-            if fields[1]:
-                if is_digit(fields[1]):
-                    residue_number = int(fields[1])
-                elif fields[1].isalnum():
-                    if fields[1][-1].isalpha() and is_digit(fields[1][:-1]):
-                        residue_number = int(fields[1][:-1])
-                        insertion_code = fields[1][-1]
-                    else:
-                        raise SelectionError(original_selection)
-                else:
-                    raise SelectionError(original_selection)
-            if fields[2]:
-                if not fields[2].isalnum() and "'" not in fields[2]:
-                    raise SelectionError(original_selection)
-                name = fields[2]
-            if chain:
-                current &= (res_chain == chain)[res_of]
-            if residue_number:   # 0 is falsy: residue number 0 is silently ignored (utils.py:508)
-                current &= ((res_seq == residue_number) & (res_icode == insertion_code))[res_of]
-            if name:
-                current &= (atom_name == name)
-            final |= current
-
+    t = _Tables(pc)
+    chosen = np.zeros(pc.n_atoms, bool)
+    for original in selection_list:
+        text = original.strip()
+        if text.startswith('RESNAME:'):
+            chosen |= _select_resname(t, text, original)
+        elif text.startswith('LIGANDS'):
+            chosen |= _select_ligands(t)
+        elif text.startswith('/'):
+            chosen |= _select_path(t, text, original)
         else:
-            raise SelectionError(original_selection)
-
-    if not final.any():
+            raise SelectionError(original)
+    if not chosen.any():
         logging.error('Selection was empty.')
         raise SelectionError('entity not found')
-    return np.nonzero(final)[0].astype(np.int64)
+    return np.nonzero(chosen)[0].astype(np.int64)
 
 
 def make_pymol_json(pc, atom=None, residue=None):

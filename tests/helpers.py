@@ -54,10 +54,17 @@ def tiny_complex(xyz, vdw=1.7, cov=0.76, type_mask=0, flags=0, res_id=None, res_
 
 
 def deg_close(a, b, tol=1e-4):
-    """Angles equal within tol degrees, NaN == NaN."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    """Angles equal within tol degrees (the north-star bound), NaN == NaN.  float32 angles (the amide-amide loop computes
+    in float32, I:1227-1300) get a tighter, derived bound: both sides run the same operation sequence on the same float32
+    cosine and differ only by acosf (device library vs glibc, <= 2 ulp of a value <= pi: 4.8e-7 rad = 2.7e-5 degrees)
+    carried through the degrees conversion rad * 180 / pi (two roundings of a value <= 180: 2 x 7.6e-6), i.e. 4.3e-5
+    degrees at most; 6e-5 is asserted."""
+    fa, fb = np.asarray(a), np.asarray(b)
+    if fa.dtype == np.float32 and fb.dtype == np.float32:
+        tol = min(tol, 6e-5)
+    a, b = fa.astype(np.float64), fb.astype(np.float64)
     both_nan = np.isnan(a) & np.isnan(b)
-    return np.all(both_nan | (np.abs(a - b) <= tol))
+    return bool(np.all(both_nan | (np.abs(a - b) <= tol)))
 
 
 def known_answer_packs():
@@ -166,3 +173,35 @@ def random_dense_pack(seed, n=400, box=14.0):
     lonely = xd & (pc.sb_nbr < 0)
     pc.sb_nbr[lonely] = (np.nonzero(lonely)[0] + 1) % n
     return pc
+
+
+def boundary_sensitive_pairs(pc, contacts, comp=0.1):
+    """how many emitted contacts sit within one float32 ulp of a threshold the per-pair code compares the
+    float32 distance with (sum of covalent radii, sum of vdW radii, vdW sum + comp, 2.8, 3.5, 3.6, 4.0, 4.5: I:760-920;
+    compared in float32, NEP 50).  These are the pairs on which a one-bit difference in the distance would flip a flag;
+    the parity tests compare them like every other pair (bit-identical), this only counts them."""
+    i, j, d = np.asarray(contacts['i']), np.asarray(contacts['j']), np.asarray(contacts['dist'], np.float32)
+    thr = [np.asarray(pc.cov[i] + pc.cov[j]).astype(np.float32), np.asarray(pc.vdw[i] + pc.vdw[j]).astype(np.float32),
+           np.asarray(pc.vdw[i] + pc.vdw[j] + comp).astype(np.float32)]
+    thr += [np.full(len(d), np.float32(t), np.float32) for t in (2.8, 3.5, 3.6, 4.0, 4.5)]
+    near = np.zeros(len(d), bool)
+    exact = np.zeros(len(d), bool)
+    for t in thr:
+        near |= (d >= np.nextafter(t, np.float32(-np.inf))) & (d <= np.nextafter(t, np.float32(np.inf)))
+        exact |= d == t
+    return dict(contacts=int(len(d)), within_1ulp=int(near.sum()), exactly_on_threshold=int(exact.sum()))
+
+
+def report_boundary_pairs(name, stats):
+    """Append to gpurun_out/boundary_pairs.json (copied into profiles/ for DESIGN.md)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, 'gpurun_out', 'boundary_pairs.json')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        data = json.load(open(path))
+    except (OSError, ValueError):
+        data = {}
+    data[name] = stats
+    json.dump(data, open(path, 'w'), indent=1, sort_keys=True)

@@ -249,3 +249,22 @@ def test_gloo_halo_exchange_and_selection_combine(world, worker):
     for k in exp:
         g = np.concatenate([x[1][k] for x in gathered], axis=0)
         assert np.array_equal(_canon(g), _canon(exp[k])), k
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """The real thing — two processes, two GPUs, backend nccl (= RCCL over xGMI): halo records exchanged with grouped
+    isend / irecv, the three-stage pass with the selection_plus bits and the residue sets exchanged on the device, and
+    the union of what the two ranks own equal to the single-GPU result.  Skipped on a one-GPU box."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(root, 'tests', 'rccl_two_ranks.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'RCCL_TWO_RANKS_OK' in out.stdout
