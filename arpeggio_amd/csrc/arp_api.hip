@@ -146,6 +146,7 @@ struct arp_ctx {
     DevBuf<SiftRec> s_rec;
     DevBuf<int> tmp_i32;          // scratch for index uploads
     DevBuf<int4> st_q1;           // selection-independent record columns, composed once per structure (k_prepare_static)
+    DevBuf<float> longest_bond;   // k_longest_bond, once per uploaded structure (ensure_static)
     DevBuf<uint16_t> rad_idx;     // per atom: index of its {vdw, cov} pair in rad_tab (RAD_NONE: not in the table)
     DevBuf<double2> rad_tab;      // RAD_TABLE distinct radius pairs of the structure
     DevBuf<int4> st_aux;
@@ -178,6 +179,11 @@ struct arp_ctx {
     u64* h_ctr_pinned = nullptr;   // pinned mirror of the counter block + completion word
     PublishArgs pub{nullptr, nullptr, 0, 0};   // in-kernel end-of-pass publication (arp_run_launch sets it for one pass)
     // residue sets of arp_run_launch, tagged with the pass number (never cleared between passes; wrap -> one memset)
+    // static candidate lists of the ring / amide loops (k_plane_lists), rebuilt when the structure changes
+    DevBuf<int2> plist[4];
+    DevBuf<u64> plist_count;       // [4]
+    bool lists_dirty = true;
+    long long plist_known[4] = {-1, -1, -1, -1};   // entries the lists held at the end of the last pass (-1: not known yet)
     DevBuf<uint8_t> blob_dev;      // device copy of the last arp_set_blob upload (the input arrays are views into it)
     int64_t blob_nbond = 0, blob_nh = 0, blob_nrad = 0;
     bool validate_on_device = false;   // blob uploads: k_prepare_static checks what the classic setters check on the host
@@ -274,9 +280,10 @@ struct Prof {  // brackets one launch with events when profiling is on
     }
 };
 
-void collect_events(arp_ctx* c) {  // call after a stream sync
+void collect_events(arp_ctx* c) {  // call after the pass has ended
     for (size_t k = 0; k < c->ev_used; ++k) {
         float ms = 0;
+        (void)hipEventSynchronize(c->ev_pool[k].b);   // the host may have seen the completion word before the last event landed
         if (hipEventElapsedTime(&ms, c->ev_pool[k].a, c->ev_pool[k].b) == hipSuccess) {
             c->k_ms[c->ev_pool[k].slot] += ms;
             c->k_launches[c->ev_pool[k].slot] += 1;
@@ -389,6 +396,7 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
 // selection-independent part of every atom record, rebuilt only when an input changed
 int ensure_static(arp_ctx* c) {
     if (!c->static_dirty) return ARP_OK;
+    c->lists_dirty = true;
     const int n = (int)c->n;
     HIPCHK(c, c->st_q1.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
@@ -400,8 +408,12 @@ int ensure_static(arp_ctx* c) {
     r.res_next = c->has_res ? c->res_next.p : nullptr;
     r.home = c->has_home ? c->home.p : nullptr;
     r.rad = c->rad.p; r.rad_idx = c->rad_idx.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.sb = c->sb.p;
+    HIPCHK(c, c->longest_bond.reserve(1));
+    HIPCHK(c, hipMemsetAsync(c->longest_bond.p, 0, sizeof(float), c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p);
+        hipLaunchKernelGGL(k_longest_bond, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->xyz.p, c->bond_off.p, c->bond_idx.p,
+                           (unsigned int*)c->longest_bond.p);
         CHK(check_launch(c, "k_prepare_static"));
     }
     c->static_dirty = false;
@@ -712,7 +724,8 @@ int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb, bool contact_grid 
         a = AtomPlaneArgs{c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
                           c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                           c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
-                          b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP};
+                          b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP,
+                          c->st_xyzm.p, c->sel_made ? c->sel.p : nullptr, (c->sel_made && c->sel_all) ? 1 : 0};
         nb = plane_blocks(c->nring);
         return ARP_OK;
     }
@@ -721,7 +734,8 @@ int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb, bool contact_grid 
     a = AtomPlaneArgs{c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
                       c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                       c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
-                      b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP};
+                      b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP,
+                      c->st_xyzm.p, c->sel_made ? c->sel.p : nullptr, (c->sel_made && c->sel_all) ? 1 : 0};
     nb = plane_blocks(c->nring);
     return ARP_OK;
 }
@@ -805,6 +819,37 @@ int enqueue_group_plane(arp_ctx* c, hipStream_t st) {
     hipLaunchKernelGGL(k_group_plane, dim3(nb), dim3(256), 0, st, a);
     return check_launch(c, "k_group_plane");
 }
+// Static candidate lists of the ring / amide loops (arp_planes.h): built on the stream when the structure changed.
+PlaneLists plane_lists(arp_ctx* c) {
+    PlaneLists L;
+    for (int k = 0; k < 4; ++k) { L.pairs[k] = c->plist[k].p; L.cap[k] = (long long)c->plist[k].cap; }
+    L.count = c->plist_count.p;
+    return L;
+}
+int ensure_plane_lists(arp_ctx* c) {
+    if (!c->lists_dirty && c->plist_count.p) return ARP_OK;
+    const size_t want[4] = {(size_t)c->nring * 96 + 256, (size_t)c->nring * 16 + 256, (size_t)c->namide * 16 + 256, (size_t)c->namide * 8 + 256};
+    for (int k = 0; k < 4; ++k) HIPCHK(c, c->plist[k].reserve(want[k]));
+    HIPCHK(c, c->plist_count.reserve(4));
+    HIPCHK(c, hipMemsetAsync(c->plist_count.p, 0, 4 * sizeof(u64), c->stream));
+    AtomPlaneArgs ap{};
+    PlanePlaneArgs pp{};
+    GroupGroupArgs gg{};
+    GroupPlaneArgs gp{};
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    CHK(prepare_atom_plane(c, ap, n0));      // all-atom 6 A grid (built here if need be), ring / amide grids
+    CHK(prepare_plane_plane(c, pp, n1));
+    CHK(prepare_group_group(c, gg, n2));
+    CHK(prepare_group_plane(c, gp, n3));
+    if (n0 + n1 + n2 + n3 > 0) {
+        hipLaunchKernelGGL(k_plane_lists, dim3(n0 + n1 + n2 + n3), dim3(256), 0, c->stream, ap, pp, gg, gp, plane_lists(c), n0, n0 + n1,
+                           n0 + n1 + n2, n0 + n1 + n2 + n3);
+        CHK(check_launch(c, "k_plane_lists"));
+    }
+    c->lists_dirty = false;
+    return ARP_OK;
+}
+
 // The pass proper: _calculate_atom_contacts (I:693-936) = contact grid (bin + scan/scatter), neighbour search, fused
 // per-pair kernel; with_planes: the four ring / amide loops (I:938-1382) ride in the last launch (k_sift_planes).
 // fuse_sets (arp_run_launch): the grid build also produces the residue / ring / amide sets of I:1413-1437.
@@ -846,27 +891,36 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
     CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
     CHK(zero_counter(c, C_ERR, 1));
-    // ---- ring / amide loops (I:938-1382): ONE launch on the second stream, released by the grid build.  It is
-    // enqueued after the search, whose 736 blocks take the whole chip first; the ~1500 short ring / amide blocks fill in
-    // as search blocks retire (the search has a long tail) and are gone before the sift kernel is.
+    // ---- ring / amide loops (I:938-1382): evaluated from the static candidate lists by the leading blocks of the
+    // last launch (ARP_PLANES_MODE=1: as a kernel of their own on the second stream, beside the search)
     AtomPlaneArgs ap{};
     PlanePlaneArgs pp{};
     GroupGroupArgs gg{};
     GroupPlaneArgs gp{};
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    if (with_planes) {
-        CHK(prepare_atom_plane(c, ap, n0, /*contact_grid=*/true));
+    if (with_planes && c->nring + c->namide > 0) {
+        CHK(ensure_plane_lists(c));
+        CHK(prepare_atom_plane(c, ap, n0, /*contact_grid=*/true));   // (argument blocks and bag buffers; no grid is walked)
         CHK(prepare_plane_plane(c, pp, n1));
         CHK(prepare_group_group(c, gg, n2));
         CHK(prepare_group_plane(c, gp, n3));
     }
+    const bool have_planes = n0 + n1 + n2 + n3 > 0;
+    // blocks for the list evaluation: one wave per 64 entries, from what the lists held last time (their capacity at first)
+    int np = 0;
+    if (have_planes) {
+        long long entries = 0;
+        for (int k = 0; k < 4; ++k) entries += std::min<long long>((long long)c->plist[k].cap, c->plist_known[k] >= 0 ? c->plist_known[k] + 64 : (long long)c->plist[k].cap / 4);
+        np = (int)std::min<long long>(std::max<long long>((entries + 255) / 256, 8), 1024);
+        np = (np + 7) & ~7;
+    }
     static const int planes_mode = env_int("ARP_PLANES_MODE", 0);   // 0: one grid with the sift kernel; 1: second stream
-    const bool merged = planes_mode == 0 && c->n > 0 && n0 + n1 + n2 + n3 > 0;
-    const bool planes_launched = !merged && n0 + n1 + n2 + n3 > 0;
+    const bool merged = have_planes && c->n > 0 && (planes_mode == 0 || c->external_stream);
+    const bool planes_alone = have_planes && !merged;
     hipStream_t st2 = c->external_stream ? c->stream : c->stream2;   // a caller-owned stream: everything in order on it
-    if (planes_launched) {
+    if (planes_alone) {
         if (c->pub.expected) c->pub.expected = (c->n > 0) ? 2 : 1;
-        if (st2 != c->stream) HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));   // grid + masks are in place here
+        if (st2 != c->stream) HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));   // masks (and lists) are in place here
     }
     if (c->n > 0) {
         Prof p(c, SLOT_SEARCH);
@@ -879,32 +933,30 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                            c->d_ctr + C_STAT_ACC, (uint8_t*)nullptr);
         CHK(check_launch(c, "k_search<CONTACTS>"));
     }
-    if (planes_launched) {
-        const PlanesSplit ps{n0, n0 + n1, n0 + n1 + n2, n0 + n1 + n2 + n3};
+    if (planes_alone) {
         if (st2 != c->stream) HIPCHK(c, hipStreamWaitEvent(st2, c->ev_sel, 0));
         Prof p(c, SLOT_PLANES, st2);
-        hipLaunchKernelGGL(k_planes, dim3(ps.nb3), dim3(256), 0, st2, ap, pp, gg, gp, ps, c->pub);
+        hipLaunchKernelGGL(k_planes, dim3(np), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + C_PLIST, c->pub);
         CHK(check_launch(c, "k_planes"));
     }
     if (c->n > 0) {
         Prof p(c, SLOT_SIFT);
         static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
         const SiftArgs sa{c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap, c->s_rec.p,
-                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p}, c->bond_idx.p, c->h_xyz_d.p,
+                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + C_ERR)};
-        if (merged) {
-            const PlanesSplit ps{n0, n0 + n1, n0 + n1 + n2, n0 + n1 + n2 + n3};
-            const int np = (ps.nb3 + 7) & ~7, nsift = c->num_cu * sift_blocks_per_cu;
-            hipLaunchKernelGGL(k_sift_planes, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, ps, np, c->pub);
-        } else {
-            hipLaunchKernelGGL(k_sift, dim3(c->num_cu * sift_blocks_per_cu), dim3(256), 0, c->stream, sa, c->pub);
-        }
+        const int nsift = c->num_cu * sift_blocks_per_cu;
+        if (merged)
+            hipLaunchKernelGGL(k_sift_planes, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
+                               c->d_ctr + C_PLIST, np, c->pub);
+        else
+            hipLaunchKernelGGL(k_sift, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         CHK(check_launch(c, "k_sift"));
-    } else if (!planes_launched) {
+    } else if (!planes_alone) {
         c->pub.expected = 0;   // nothing was launched that could publish: the caller falls back to k_publish_counters
     }
-    if (planes_launched && !c->external_stream) {   // join: whatever follows on the main stream sees the bags
+    if (planes_alone && st2 != c->stream) {   // join: whatever follows on the main stream sees the bags
         HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
     }
@@ -927,6 +979,25 @@ bool finish_contacts(arp_ctx* c) {
     c->stats[3] = (int64_t)(uint32_t)c->h_ctr[C_BINNED];
     c->stats[4] = c->contact_cells;
     return false;
+}
+// static candidate lists: entry counts travel with the counters of the pass; a list that was too small is re-sized and
+// rebuilt before the pass is repeated
+int finish_plane_lists(arp_ctx* c, bool grow) {
+    if (!c->plist_count.p || c->nring + c->namide == 0) return 0;
+    int again = 0;
+    for (int k = 0; k < 4; ++k) {
+        const u64 cnt = c->h_ctr[C_PLIST + k];
+        c->plist_known[k] = (long long)cnt;
+        if (cnt > (u64)c->plist[k].cap) {
+            again = 1;
+            if (grow) {
+                c->plist[k].release();
+                HIPCHK(c, c->plist[k].reserve((size_t)cnt + (size_t)cnt / 8 + 64));
+                c->lists_dirty = true;
+            }
+        }
+    }
+    return again;
 }
 bool finish_bag(arp_ctx* c, Bag& b, int slot) {
     const u64 k = c->h_ctr[slot];
@@ -1040,7 +1111,9 @@ void arp_destroy(arp_ctx* c) {
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
-    c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release();   // (views into the blob were released above: no-ops)
+    c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release(); c->longest_bond.release();
+    for (auto& l : c->plist) l.release();
+    c->plist_count.release();   // (views into the blob were released above: no-ops)
     c->ring_home.release(); c->am_home.release(); c->ring_gid.release(); c->am_gid.release();
     if (c->h_ctr_pinned) (void)hipHostFree(c->h_ctr_pinned);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
@@ -1821,7 +1894,9 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         if (finish_bag(c, c->bag_pp, C_PP)) { if (grow) CHK(grow_bag(c, c->bag_pp, C_PP, true, false)); again = 1; }
         if (finish_bag(c, c->bag_gg, C_GG)) { if (grow) CHK(grow_bag(c, c->bag_gg, C_GG, false, true)); again = 1; }
         if (finish_bag(c, c->bag_gp, C_GP)) { if (grow) CHK(grow_bag(c, c->bag_gp, C_GP, true, false)); again = 1; }
-        return again;
+        const int lists = finish_plane_lists(c, grow);
+        if (lists < 0) return lists;
+        return again | lists;
     };
     bool done = false;
     for (int attempt = 0; !done; ++attempt) {
@@ -1927,6 +2002,11 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         if (finish_bag(c, c->bag_pp, C_PP)) { CHK(grow_bag(c, c->bag_pp, C_PP, true, false)); again = 1; }
         if (finish_bag(c, c->bag_gg, C_GG)) { CHK(grow_bag(c, c->bag_gg, C_GG, false, true)); again = 1; }
         if (finish_bag(c, c->bag_gp, C_GP)) { CHK(grow_bag(c, c->bag_gp, C_GP, true, false)); again = 1; }
+        {
+            const int lists = finish_plane_lists(c, true);
+            if (lists < 0) return lists;
+            again |= lists;
+        }
         if (!again) break;
         if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_stage: result buffers could not be sized");
     }

@@ -51,6 +51,7 @@ enum {
     // end-of-pass tickets (pass_end): blocks of k_sift / k_planes that have finished, kernels that have finished
     // (two sets of 8 group tickets + 1 kernel ticket: the sift kernel and the ring / amide kernel end a pass together)
     C_TICKET_GROUP = 16 + 256 + 16, C_TICKET_KERNEL = 16 + 256 + 24, C_TICKET_SET = 16, C_KERNELS_DONE = 16 + 256 + 15,
+    C_PLIST = 16 + 256 + 8,   // 4 slots: entries of the static ring / amide candidate lists (copied from their own counters each pass)
     C_COUNT = 16 + 256 + 48
 };
 #define STAT_SLOTS 64
@@ -116,6 +117,25 @@ struct StaticAtoms {
     const uint8_t* plus;        // null: everything in selection_plus
     int all;                    // the selection is the whole structure (then selection_plus is, too): sel / plus not read
 };
+
+// Longest bond of the structure (float32 distance, rounded up a little), once per uploaded structure: k_sift runs its
+// covalent test — a walk over the bonded neighbours of bgn, dependent loads — only for pairs that are at most this far
+// apart (a pair further apart than every bond of the structure is not bonded).  out = float bits, atomicMax on unsigned
+// (positive floats order like their bit patterns).
+__global__ __launch_bounds__(256) void k_longest_bond(int n, const float4* __restrict__ xyz, const int* __restrict__ bond_off,
+                                                      const int* __restrict__ bond_idx, unsigned int* __restrict__ out) {
+    float m = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 a = xyz[i];
+        for (int k = bond_off[i], k1 = bond_off[i + 1]; k < k1; ++k) {
+            const float4 b = xyz[bond_idx[k]];
+            const double dx = (double)a.x - b.x, dy = (double)a.y - b.y, dz = (double)a.z - b.z;
+            m = fmaxf(m, (float)(sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-6)));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __float_as_uint(m));
+}
 
 // What the classic setters check on the host (arp_set_atoms ...), for structures that arrive as one blob: done on the
 // device (the arrays are already there), result in *err (0 / ARP_E_ARG) which arp_set_blob waits for.
@@ -789,6 +809,7 @@ struct SiftSide {
     const int* h_off;         // uploaded CSR offsets by local atom id (saturated counts)
     const int* bond_off;
     const float4* sb;         // single-bond heavy neighbour by local atom id: x, y, z, present
+    const float* longest_bond;   // k_longest_bond
 };
 __device__ __forceinline__ double2 rec_rad(int4 q1, const double2* s_tab, const SiftSide& sd) {
     const unsigned ri = (unsigned)q1.w >> 16;
@@ -907,6 +928,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     // The segment fill counts are read on the device: no host round trip between search and sift.
     // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
     // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
+    const float longest_bond = *sd.longest_bond;
     const int sgm = vblock & (PAIR_SEGS - 1);
     long long out_base = 0;
 #pragma unroll
@@ -935,10 +957,11 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
         uint32_t s = 0;
         unsigned need = 0;
-        // interactions.py:748-757: end among the bonded neighbours of bgn
+        // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
         bool cov = false;
-        for (int k = qb.q1.y, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
-            if (bond_idx[k] == e) { cov = true; break; }
+        if (d <= longest_bond)
+            for (int k = qb.q1.y, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
+                if (bond_idx[k] == e) { cov = true; break; }
         // interactions.py:756-773: float32 distance against Python floats -> float32 compare
         const double vdw_comp = sum_vdw + comp;
         const float f_vdw_comp = (float)vdw_comp;

@@ -169,12 +169,11 @@ struct PairQueue {
     }
 };
 
-// One wavefront per ring; lanes sweep the atoms of the 27 cells around the ring centre =
-// NeighborSearch.search(center, 6.0) (I:960).  The grid is the all-atom 6 A grid of the
-// selection expansion; membership of the selection_plus tree (I:1442) and the hydrogen
-// filter (I:964) are applied per atom.
-struct AtomPlaneArgs {
-    GridDesc g;
+// =====================================================================================================================
+// Argument blocks of the four loops
+// =====================================================================================================================
+struct AtomPlaneArgs {          // __calculate_atom_plane_contacts, I:947-1062
+    GridDesc g;                 // atom grid the candidates come from (all-atom 6 A grid, or the contact grid of the pass)
     const int* start;
     const float4* s_xyzm;
     const int4* s_aux;
@@ -196,86 +195,12 @@ struct AtomPlaneArgs {
     uint8_t* out_mask;
     uint8_t* out_ct;
     u64* n_out;
+    // list mode (atoms addressed by local id through the static columns instead of a sorted position)
+    const float4* st_xyzm;
+    const uint8_t* sel;
+    int sel_all;
 };
-__device__ __forceinline__ void atom_plane_body(GridDesc g, const int* __restrict__ start,
-                                                    const float4* __restrict__ s_xyzm, const int4* __restrict__ s_aux,
-                                                    int nring, const double* __restrict__ ring_c,
-                                                    const double* __restrict__ ring_n, const int* __restrict__ ring_res,
-                                                    const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
-                                                    const uint8_t* __restrict__ plus, const uint8_t* __restrict__ ring_home,
-                                                    const int* __restrict__ ring_gid,
-                                                    const int* __restrict__ gid, long long cap, int* __restrict__ out_atom,
-                                                    int* __restrict__ out_ring, double* __restrict__ out_dist,
-                                                    double* __restrict__ out_theta, uint8_t* __restrict__ out_mask,
-                                                    uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
-    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
-    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
-    auto write = [&](long long slot, const PlaneRec& t) {
-        out_atom[slot] = t.i0; out_ring[slot] = t.i1;
-        out_dist[slot] = t.d0; out_theta[slot] = t.d1;
-        out_mask[slot] = (uint8_t)(t.u & 255u); out_ct[slot] = (uint8_t)((t.u >> 8) & 255u);
-    };
-    const int lane = threadIdx.x & 63;
-    auto eval = [&](bool live, int r, int j) {   // ring r, atom at sorted position j (inside the tree radius, I:960)
-        bool emit = false;
-        PlaneRec rec;
-        if (live) {
-            const num::d3 ctr_ = ld3(ring_c, r), nrm = ld3(ring_n, r);
-            const float4 v = s_xyzm[j];
-            const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
-            const uint32_t m = __float_as_uint(v.w);
-            const int lid = s_aux[j].x;
-            const double dist = num::norm(num::sub(x, ctr_));                        // I:972
-            const int ct = plane_ctype(ring_sel[r], m & M_SEL, true, true);           // I:985-997
-            const double theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
-            uint32_t mask = 0;
-            if (dist <= 4.5 && theta <= 30.0) {                                      // I:1007
-                if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
-                if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
-                if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
-                if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
-            }
-            if (dist <= 6.0) {                                                       // I:1021
-                if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
-            }
-            emit = mask != 0;                                                        // I:1026
-            rec.i0 = gid ? gid[lid] : lid;
-            rec.i1 = ring_gid ? ring_gid[r] : r;
-            rec.d0 = dist; rec.d1 = theta;
-            rec.u = mask | ((unsigned)ct << 8);
-        }
-        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-        Q.push(emit, rec, lane);
-    };
-    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (vgrid * blockDim.x) >> 6;
-    for (int r = wave; r < nring; r += nwave) {
-        if (!ring_plus[r]) continue;  // I:957
-        if (ring_home && !ring_home[r]) continue;  // multi-GPU: the rank owning the ring emits
-        const num::d3 ctr_ = ld3(ring_c, r);
-        const Stencil st = stencil_load(g, start, cell_box(g, ctr_), lane);
-        for (int kb = 0; kb < st.pre[9]; kb += 64) {
-            const int k = kb + lane;
-            bool ok = false;
-            int j = 0;
-            if (k < st.pre[9]) {
-                j = stencil_pos(st, k);
-                const float4 v = s_xyzm[j];
-                const uint32_t m = __float_as_uint(v.w);
-                // I:960 tree membership (float64, inclusive), I:964 hydrogens, I:975 aromatic atoms, I:968 selection_plus
-                ok = num::dist2_kd(ctr_, num::d3{(double)v.x, (double)v.y, (double)v.z}) <= 36.0 &&
-                     !(m & (M_HYDROGEN | ARP_T_AROMATIC)) && plus[s_aux[j].x];
-            }
-            P.push(ok, r, j, lane, eval);
-        }
-    }
-    P.drain(lane, eval);
-    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
-}
-
-// One wavefront per ring a; lanes = partner rings b > a of the 27 cells around it.  Reproduces
-// both visits (a,b) and (b,a) of the reference's ordered double loop and its dedupe (I:1181-1194).
-struct PlanePlaneArgs {
+struct PlanePlaneArgs {         // __calculate_plane_plane_contacts, I:1064-1194
     GridDesc g;
     const int* start;
     const int* perm;
@@ -299,88 +224,7 @@ struct PlanePlaneArgs {
     uint8_t* out_ct;
     u64* n_out;
 };
-__device__ __forceinline__ void plane_plane_body(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
-                                                     int nring, const double* __restrict__ ring_c,
-                                                     const double* __restrict__ ring_n, const int* __restrict__ ring_res,
-                                                     const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
-                                                     const uint8_t* __restrict__ ring_home, const int* __restrict__ ring_gid,
-                                                     long long cap, int* __restrict__ out_bgn, int* __restrict__ out_end,
-                                                     double* __restrict__ out_dist, double* __restrict__ out_dih,
-                                                     double* __restrict__ out_t1, double* __restrict__ out_t2,
-                                                     uint8_t* __restrict__ out_y1, uint8_t* __restrict__ out_y2,
-                                                     uint8_t* __restrict__ out_ct, u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
-    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
-    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
-    auto write = [&](long long slot, const PlaneRec& t) {
-        out_bgn[slot] = t.i0; out_end[slot] = t.i1;
-        out_dist[slot] = t.d0; out_dih[slot] = t.d1; out_t1[slot] = t.d2; out_t2[slot] = t.d3;
-        out_y1[slot] = (uint8_t)(t.u & 255u); out_y2[slot] = (uint8_t)((t.u >> 8) & 255u);
-        out_ct[slot] = (uint8_t)((t.u >> 16) & 255u);
-    };
-    const int lane = threadIdx.x & 63;
-    auto eval = [&](bool live, int a, int b) {   // rings a < b, both in selection_plus, centres within ~6 A
-        bool emit = false;
-        PlaneRec rec;
-        if (live) {
-            const num::d3 ca = ld3(ring_c, a), na = ld3(ring_n, a), cbv = ld3(ring_c, b), nb = ld3(ring_n, b);
-            const num::d3 pab = num::sub(ca, cbv);
-            const double dist = num::norm(pab);                 // I:1111 (same value for both visits)
-            if (!(dist > 6.0)) {                                // I:1113
-                const bool intra = ring_res[a] == ring_res[b];  // I:1091
-                const int ct = plane_ctype(ring_sel[a], ring_sel[b], true, true);
-                const double cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
-                const double dih = num::fold_deg(acos(cosd));                       // I:1122
-                const double t_ab = num::group_angle(na, pab);                      // I:1123, visit (a,b)
-                const double t_ba = num::group_angle(nb, num::sub(cbv, ca));        // visit (b,a)
-                const int y_ab = num::pp_class(dih, t_ab), y_ba = num::pp_class(dih, t_ba);
-                const bool skip_ab = intra && y_ab == ARP_PP_EE;  // I:1154
-                const bool skip_ba = intra && y_ba == ARP_PP_EE;
-                emit = !(skip_ab && skip_ba);
-                const bool first = !skip_ab;
-                double t1, t2;
-                int y1, y2;
-                if (first) {  // record created by visit (a,b); visit (b,a) may append its class
-                    t1 = t_ab; t2 = skip_ba ? NAN : t_ba;
-                    y1 = y_ab; y2 = skip_ba ? ARP_PP_SKIPPED : (y_ba == y_ab ? ARP_PP_SAME : y_ba);
-                } else {      // first visit skipped: the reverse visit creates the record
-                    t1 = t_ba; t2 = NAN;
-                    y1 = y_ba; y2 = ARP_PP_SKIPPED;
-                }
-                const int ga = ring_gid ? ring_gid[a] : a, gb = ring_gid ? ring_gid[b] : b;
-                rec.i0 = first ? ga : gb;
-                rec.i1 = first ? gb : ga;
-                rec.d0 = dist; rec.d1 = dih; rec.d2 = t1; rec.d3 = t2;
-                rec.u = (unsigned)y1 | ((unsigned)y2 << 8) | ((unsigned)ct << 16);
-            }
-        }
-        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-        Q.push(emit, rec, lane);
-    };
-    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (vgrid * blockDim.x) >> 6;
-    for (int a = wave; a < nring; a += nwave) {
-        if (!ring_plus[a]) continue;  // I:1081
-        if (ring_home && !ring_home[a]) continue;  // multi-GPU: owner of the lower ring id emits the pair
-        const num::d3 ca = ld3(ring_c, a);
-        const Stencil st = stencil_load(g, start, cell_box(g, ca), lane);
-        for (int kb = 0; kb < st.pre[9]; kb += 64) {
-            const int k = kb + lane;
-            bool ok = false;
-            int b = 0;
-            if (k < st.pre[9]) {
-                b = perm[stencil_pos(st, k)];
-                // unordered pair once (I:1081, 1085); squared-distance superset of I:1113, settled exactly in eval
-                ok = b > a && ring_plus[b] && num::dist2_kd(ca, ld3(ring_c, b)) <= 36.0 * (1.0 + 1e-9);
-            }
-            P.push(ok, a, b, lane, eval);
-        }
-    }
-    P.drain(lane, eval);
-    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
-}
-
-// One wavefront per amide a; lanes = every other amide b of the 27 cells: ordered pairs, float32 (I:1217-1300).
-struct GroupGroupArgs {
+struct GroupGroupArgs {         // __calculate_group_group_contacts, I:1217-1300
     GridDesc g;
     const int* start;
     const int* perm;
@@ -400,68 +244,8 @@ struct GroupGroupArgs {
     uint8_t* out_ct;
     u64* n_out;
 };
-__device__ __forceinline__ void group_group_body(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
-                                                     int namide, const float* __restrict__ am_c, const float* __restrict__ am_n,
-                                                     const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
-                                                     const uint8_t* __restrict__ am_home, const int* __restrict__ am_gid,
-                                                     long long cap, int* __restrict__ out_bgn, int* __restrict__ out_end,
-                                                     float* __restrict__ out_dist, float* __restrict__ out_dih,
-                                                     float* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
-    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
-    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
-    auto write = [&](long long slot, const PlaneRec& t) {   // float values travel as doubles (exact both ways)
-        out_bgn[slot] = t.i0; out_end[slot] = t.i1;
-        out_dist[slot] = (float)t.d0; out_dih[slot] = (float)t.d1; out_theta[slot] = (float)t.d2;
-        out_ct[slot] = (uint8_t)(t.u & 255u);
-    };
-    const int lane = threadIdx.x & 63;
-    auto eval = [&](bool live, int a, int b) {   // ordered pair of amides, float32 (I:1227-1300)
-        bool emit = false;
-        PlaneRec rec;
-        if (live) {
-            const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a), cbv = lf3(am_c, b), nb = lf3(am_n, b);
-            const num::f3 pab = num::sub(ca, cbv);
-            const float dist = num::norm(pab);                 // I:1268
-            if (!(dist > (float)6.0)) {                        // I:1270
-                const float cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
-                const float dih = num::fold_deg(acosf(cosd));  // I:1278
-                const float theta = num::group_angle(na, pab); // I:1279
-                emit = !(dih > 30.0f || theta > 30.0f);        // I:1282
-                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = am_gid ? am_gid[b] : b;
-                rec.d0 = (double)dist; rec.d1 = (double)dih; rec.d2 = (double)theta;
-                rec.u = (unsigned)plane_ctype(am_sel[a], am_sel[b], true, true);
-            }
-        }
-        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-        Q.push(emit, rec, lane);
-    };
-    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (vgrid * blockDim.x) >> 6;
-    for (int a = wave; a < namide; a += nwave) {
-        if (!am_plus[a]) continue;
-        if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the bgn amide emits
-        const num::d3 cad = num::to_d3(lf3(am_c, a));
-        const Stencil st = stencil_load(g, start, cell_box(g, cad), lane);
-        for (int kb = 0; kb < st.pre[9]; kb += 64) {
-            const int k = kb + lane;
-            bool ok = false;
-            int b = 0;
-            if (k < st.pre[9]) {
-                b = perm[stencil_pos(st, k)];
-                // I:1233, 1237; float64 squared-distance superset of the float32 test at I:1270 (settled exactly in eval)
-                ok = b != a && am_plus[b] && num::dist2_kd(cad, num::to_d3(lf3(am_c, b))) <= 36.0 * (1.0 + 1e-5);
-            }
-            P.push(ok, a, b, lane, eval);
-        }
-    }
-    P.drain(lane, eval);
-    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
-}
-
-// One wavefront per amide; lanes = rings of the 27 cells of the RING grid around the amide centre (I:1302-1382).
-struct GroupPlaneArgs {
-    GridDesc g;
+struct GroupPlaneArgs {         // __calculate_group_plane_contacts, I:1302-1382
+    GridDesc g;                 // RING grid
     const int* start;
     const int* perm;
     int namide;
@@ -485,230 +269,477 @@ struct GroupPlaneArgs {
     uint8_t* out_ct;
     u64* n_out;
 };
-__device__ __forceinline__ void group_plane_body(GridDesc g, const int* __restrict__ start, const int* __restrict__ perm,
-                                                     int namide, const float* __restrict__ am_c, const float* __restrict__ am_n,
-                                                     const uint8_t* __restrict__ am_sel, const uint8_t* __restrict__ am_plus,
-                                                     const double* __restrict__ ring_c, const double* __restrict__ ring_n,
-                                                     const uint8_t* __restrict__ ring_sel, const uint8_t* __restrict__ ring_plus,
-                                                     const uint8_t* __restrict__ am_home, const int* __restrict__ am_gid,
-                                                     const int* __restrict__ ring_gid,
-                                                     long long cap, int* __restrict__ out_amide, int* __restrict__ out_ring,
-                                                     double* __restrict__ out_dist, double* __restrict__ out_dih,
-                                                     double* __restrict__ out_theta, uint8_t* __restrict__ out_ct,
-                                                     u64* __restrict__ n_out, int vblock, int vgrid, PlaneShared* sh) {
-    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
-    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
-    auto write = [&](long long slot, const PlaneRec& t) {
-        out_amide[slot] = t.i0; out_ring[slot] = t.i1;
-        out_dist[slot] = t.d0; out_dih[slot] = t.d1; out_theta[slot] = t.d2;
-        out_ct[slot] = (uint8_t)(t.u & 255u);
-    };
-    const int lane = threadIdx.x & 63;
-    auto eval = [&](bool live, int a, int r) {   // amide a, ring r (I:1312-1382)
-        bool emit = false;
-        PlaneRec rec;
-        if (live) {
-            const num::f3 ca = lf3(am_c, a), na = lf3(am_n, a);
-            const num::d3 cad = num::to_d3(ca);
-            const num::d3 cr = ld3(ring_c, r), nr = ld3(ring_n, r);
-            const num::d3 par = num::sub(cad, cr);
-            const double dist = num::norm(par);         // I:1349
-            if (!(dist > 6.0)) {                        // I:1351
-                const double cosd = num::dot(num::to_d3(na), nr) / ((double)num::norm(na) * num::norm(nr));
-                const double dih = num::fold_deg(acos(cosd));    // I:1359
-                const double theta = num::group_angle(na, par);  // I:1360
-                emit = !(dih > 30.0 || theta > 30.0);            // I:1363
-                rec.i0 = am_gid ? am_gid[a] : a; rec.i1 = ring_gid ? ring_gid[r] : r;
-                rec.d0 = dist; rec.d1 = dih; rec.d2 = theta;
-                rec.u = (unsigned)plane_ctype(am_sel[a], ring_sel[r], true, true);
-            }
-        }
-        if (Q.nearly_full()) Q.flush(n_out, cap, lane, write);
-        Q.push(emit, rec, lane);
-    };
-    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (vgrid * blockDim.x) >> 6;
-    for (int a = wave; a < namide; a += nwave) {
-        if (!am_plus[a]) continue;
-        if (am_home && !am_home[a]) continue;  // multi-GPU: owner of the amide emits
-        const num::d3 cad = num::to_d3(lf3(am_c, a));
-        const Stencil st = stencil_load(g, start, cell_box(g, cad), lane);
-        for (int kb = 0; kb < st.pre[9]; kb += 64) {
-            const int k = kb + lane;
-            bool ok = false;
-            int r = 0;
-            if (k < st.pre[9]) {
-                r = perm[stencil_pos(st, k)];
-                ok = ring_plus[r] && num::dist2_kd(cad, ld3(ring_c, r)) <= 36.0 * (1.0 + 1e-9);   // I:1318; superset of I:1351
-            }
-            P.push(ok, a, r, lane, eval);
-        }
-    }
-    P.drain(lane, eval);
-    Q.flush_block(sh->n, &sh->base, n_out, cap, lane, write);
-}
 
-// ---- launchable forms -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_atom_plane(AtomPlaneArgs a) {
-    __shared__ PlaneShared s_sh;
-    atom_plane_body(a.g, a.start, a.s_xyzm, a.s_aux, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.plus, a.ring_home, a.ring_gid, a.gid, a.cap, a.out_atom, a.out_ring, a.out_dist, a.out_theta, a.out_mask, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
-}
-__global__ __launch_bounds__(256) void k_plane_plane(PlanePlaneArgs a) {
-    __shared__ PlaneShared s_sh;
-    plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
-}
-__global__ __launch_bounds__(256) void k_group_group(GroupGroupArgs a) {
-    __shared__ PlaneShared s_sh;
-    group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
-}
-__global__ __launch_bounds__(256) void k_group_plane(GroupPlaneArgs a) {
-    __shared__ PlaneShared s_sh;
-    group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, (int)blockIdx.x, (int)gridDim.x, &s_sh);
-}
-
-// __calculate_atom_plane_contacts (I:947-1062) on the CONTACT grid of the pass (cell edge = the interacting cut-off,
-// atoms of selection_plus without hydrogens — exactly the atoms I:964-968 let through) instead of the all-atom 6 A
-// grid: with a 5 A edge the 6 A query reaches two cells, so the stencil is (2R + 1)^2 rows of 2R + 1 contiguous cells,
-// R = floor(6 / edge) + 1.  One wavefront per ring; lane r fetches the bounds of row r, the rows are then swept one
-// after the other, 64 atoms at a time.  Lets a pass do without the second grid build.
-__device__ __forceinline__ void atom_plane_cg_body(const AtomPlaneArgs& A, int vblock, int vgrid, PlaneShared* sh) {
-    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
-    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
-    auto write = [&](long long slot, const PlaneRec& t) {
+// =====================================================================================================================
+// Phase 2 of every loop: the reference's exact operation sequence for ONE candidate pair per lane, record into the
+// wave's output queue.  `live` = this lane holds a pair that passed the per-pass filters.
+// =====================================================================================================================
+struct ApWrite {
+    const AtomPlaneArgs& A;
+    __device__ __forceinline__ void operator()(long long slot, const PlaneRec& t) const {
         A.out_atom[slot] = t.i0; A.out_ring[slot] = t.i1;
         A.out_dist[slot] = t.d0; A.out_theta[slot] = t.d1;
         A.out_mask[slot] = (uint8_t)(t.u & 255u); A.out_ct[slot] = (uint8_t)((t.u >> 8) & 255u);
-    };
-    const GridDesc g = A.g;
-    const int lane = threadIdx.x & 63;
-    auto eval = [&](bool live, int r, int j) {   // ring r, atom at sorted position j (inside the tree radius, I:960)
-        bool emit = false;
-        PlaneRec rec;
-        if (live) {
-            const num::d3 ctr_ = ld3(A.ring_c, r), nrm = ld3(A.ring_n, r);
+    }
+};
+// ring r against the atom (x, y, z, meta) with local id lid, already inside the tree radius (I:960)
+__device__ __forceinline__ void ap_eval(const AtomPlaneArgs& A, bool live, int r, float4 v, int lid, PlaneQueue& Q, int lane) {
+    bool emit = false;
+    PlaneRec rec;
+    if (live) {
+        const num::d3 ctr_ = ld3(A.ring_c, r), nrm = ld3(A.ring_n, r);
+        const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
+        const uint32_t m = __float_as_uint(v.w);
+        const double dist = num::norm(num::sub(x, ctr_));                        // I:972
+        const int ct = plane_ctype(A.ring_sel[r], m & M_SEL, true, true);         // I:985-997
+        const double theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
+        uint32_t mask = 0;
+        if (dist <= 4.5 && theta <= 30.0) {                                      // I:1007
+            if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
+            if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
+            if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
+            if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
+        }
+        if (dist <= 6.0) {                                                       // I:1021
+            if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
+        }
+        emit = mask != 0;                                                        // I:1026
+        rec.i0 = A.gid ? A.gid[lid] : lid;
+        rec.i1 = A.ring_gid ? A.ring_gid[r] : r;
+        rec.d0 = dist; rec.d1 = theta;
+        rec.u = mask | ((unsigned)ct << 8);
+    }
+    if (Q.nearly_full()) Q.flush(A.n_out, A.cap, lane, ApWrite{A});
+    Q.push(emit, rec, lane);
+}
+
+struct PpWrite {
+    const PlanePlaneArgs& A;
+    __device__ __forceinline__ void operator()(long long slot, const PlaneRec& t) const {
+        A.out_bgn[slot] = t.i0; A.out_end[slot] = t.i1;
+        A.out_dist[slot] = t.d0; A.out_dih[slot] = t.d1; A.out_t1[slot] = t.d2; A.out_t2[slot] = t.d3;
+        A.out_y1[slot] = (uint8_t)(t.u & 255u); A.out_y2[slot] = (uint8_t)((t.u >> 8) & 255u);
+        A.out_ct[slot] = (uint8_t)((t.u >> 16) & 255u);
+    }
+};
+// rings a < b: reproduces both visits (a,b) and (b,a) of the reference's ordered double loop and its dedupe (I:1181-1194)
+__device__ __forceinline__ void pp_eval(const PlanePlaneArgs& A, bool live, int a, int b, PlaneQueue& Q, int lane) {
+    bool emit = false;
+    PlaneRec rec;
+    if (live) {
+        const num::d3 ca = ld3(A.ring_c, a), na = ld3(A.ring_n, a), cbv = ld3(A.ring_c, b), nb = ld3(A.ring_n, b);
+        const num::d3 pab = num::sub(ca, cbv);
+        const double dist = num::norm(pab);                 // I:1111 (same value for both visits)
+        if (!(dist > 6.0)) {                                // I:1113
+            const bool intra = A.ring_res[a] == A.ring_res[b];  // I:1091
+            const int ct = plane_ctype(A.ring_sel[a], A.ring_sel[b], true, true);
+            const double cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
+            const double dih = num::fold_deg(acos(cosd));                       // I:1122
+            const double t_ab = num::group_angle(na, pab);                      // I:1123, visit (a,b)
+            const double t_ba = num::group_angle(nb, num::sub(cbv, ca));        // visit (b,a)
+            const int y_ab = num::pp_class(dih, t_ab), y_ba = num::pp_class(dih, t_ba);
+            const bool skip_ab = intra && y_ab == ARP_PP_EE;  // I:1154
+            const bool skip_ba = intra && y_ba == ARP_PP_EE;
+            emit = !(skip_ab && skip_ba);
+            const bool first = !skip_ab;
+            double t1, t2;
+            int y1, y2;
+            if (first) {  // record created by visit (a,b); visit (b,a) may append its class
+                t1 = t_ab; t2 = skip_ba ? NAN : t_ba;
+                y1 = y_ab; y2 = skip_ba ? ARP_PP_SKIPPED : (y_ba == y_ab ? ARP_PP_SAME : y_ba);
+            } else {      // first visit skipped: the reverse visit creates the record
+                t1 = t_ba; t2 = NAN;
+                y1 = y_ba; y2 = ARP_PP_SKIPPED;
+            }
+            const int ga = A.ring_gid ? A.ring_gid[a] : a, gb = A.ring_gid ? A.ring_gid[b] : b;
+            rec.i0 = first ? ga : gb;
+            rec.i1 = first ? gb : ga;
+            rec.d0 = dist; rec.d1 = dih; rec.d2 = t1; rec.d3 = t2;
+            rec.u = (unsigned)y1 | ((unsigned)y2 << 8) | ((unsigned)ct << 16);
+        }
+    }
+    if (Q.nearly_full()) Q.flush(A.n_out, A.cap, lane, PpWrite{A});
+    Q.push(emit, rec, lane);
+}
+
+struct GgWrite {
+    const GroupGroupArgs& A;
+    __device__ __forceinline__ void operator()(long long slot, const PlaneRec& t) const {   // float values travel as doubles (exact both ways)
+        A.out_bgn[slot] = t.i0; A.out_end[slot] = t.i1;
+        A.out_dist[slot] = (float)t.d0; A.out_dih[slot] = (float)t.d1; A.out_theta[slot] = (float)t.d2;
+        A.out_ct[slot] = (uint8_t)(t.u & 255u);
+    }
+};
+// ordered pair of amides, float32 (I:1227-1300)
+__device__ __forceinline__ void gg_eval(const GroupGroupArgs& A, bool live, int a, int b, PlaneQueue& Q, int lane) {
+    bool emit = false;
+    PlaneRec rec;
+    if (live) {
+        const num::f3 ca = lf3(A.am_c, a), na = lf3(A.am_n, a), cbv = lf3(A.am_c, b), nb = lf3(A.am_n, b);
+        const num::f3 pab = num::sub(ca, cbv);
+        const float dist = num::norm(pab);                 // I:1268
+        if (!(dist > (float)6.0)) {                        // I:1270
+            const float cosd = num::dot(na, nb) / (num::norm(na) * num::norm(nb));
+            const float dih = num::fold_deg(acosf(cosd));  // I:1278
+            const float theta = num::group_angle(na, pab); // I:1279
+            emit = !(dih > 30.0f || theta > 30.0f);        // I:1282
+            rec.i0 = A.am_gid ? A.am_gid[a] : a; rec.i1 = A.am_gid ? A.am_gid[b] : b;
+            rec.d0 = (double)dist; rec.d1 = (double)dih; rec.d2 = (double)theta;
+            rec.u = (unsigned)plane_ctype(A.am_sel[a], A.am_sel[b], true, true);
+        }
+    }
+    if (Q.nearly_full()) Q.flush(A.n_out, A.cap, lane, GgWrite{A});
+    Q.push(emit, rec, lane);
+}
+
+struct GpWrite {
+    const GroupPlaneArgs& A;
+    __device__ __forceinline__ void operator()(long long slot, const PlaneRec& t) const {
+        A.out_amide[slot] = t.i0; A.out_ring[slot] = t.i1;
+        A.out_dist[slot] = t.d0; A.out_dih[slot] = t.d1; A.out_theta[slot] = t.d2;
+        A.out_ct[slot] = (uint8_t)(t.u & 255u);
+    }
+};
+// amide a, ring r (I:1312-1382)
+__device__ __forceinline__ void gp_eval(const GroupPlaneArgs& A, bool live, int a, int r, PlaneQueue& Q, int lane) {
+    bool emit = false;
+    PlaneRec rec;
+    if (live) {
+        const num::f3 ca = lf3(A.am_c, a), na = lf3(A.am_n, a);
+        const num::d3 cad = num::to_d3(ca);
+        const num::d3 cr = ld3(A.ring_c, r), nr = ld3(A.ring_n, r);
+        const num::d3 par = num::sub(cad, cr);
+        const double dist = num::norm(par);         // I:1349
+        if (!(dist > 6.0)) {                        // I:1351
+            const double cosd = num::dot(num::to_d3(na), nr) / ((double)num::norm(na) * num::norm(nr));
+            const double dih = num::fold_deg(acos(cosd));    // I:1359
+            const double theta = num::group_angle(na, par);  // I:1360
+            emit = !(dih > 30.0 || theta > 30.0);            // I:1363
+            rec.i0 = A.am_gid ? A.am_gid[a] : a; rec.i1 = A.ring_gid ? A.ring_gid[r] : r;
+            rec.d0 = dist; rec.d1 = dih; rec.d2 = theta;
+            rec.u = (unsigned)plane_ctype(A.am_sel[a], A.ring_sel[r], true, true);
+        }
+    }
+    if (Q.nearly_full()) Q.flush(A.n_out, A.cap, lane, GpWrite{A});
+    Q.push(emit, rec, lane);
+}
+
+// =====================================================================================================================
+// Phase 1: enumeration of the candidates of one home item (a wavefront per item, lanes over the stencil).  `Sink` receives
+// (ok, x, y) for every lane; DYNAMIC = also apply the per-pass filters (selection_plus membership, ownership), which the
+// static candidate lists leave to the pass.
+// =====================================================================================================================
+template <bool DYNAMIC, class Sink>
+__device__ __forceinline__ void ap_enumerate(const AtomPlaneArgs& A, int r, int lane, Sink sink) {   // 27-cell stencil of a >= 6 A atom grid
+    if (DYNAMIC && (!A.ring_plus[r] || (A.ring_home && !A.ring_home[r]))) return;   // I:957; multi-GPU: the ring's owner emits
+    const num::d3 ctr_ = ld3(A.ring_c, r);
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, ctr_), lane);
+    for (int kb = 0; kb < st.pre[9]; kb += 64) {
+        const int k = kb + lane;
+        bool ok = false;
+        int j = 0;
+        if (k < st.pre[9]) {
+            j = stencil_pos(st, k);
             const float4 v = A.s_xyzm[j];
-            const num::d3 x = {(double)v.x, (double)v.y, (double)v.z};
             const uint32_t m = __float_as_uint(v.w);
-            const int lid = A.s_aux[j].x;
-            const double dist = num::norm(num::sub(x, ctr_));                        // I:972
-            const int ct = plane_ctype(A.ring_sel[r], m & M_SEL, true, true);         // I:985-997
-            const double theta = num::group_angle(nrm, num::sub(ctr_, x));           // I:1005
-            uint32_t mask = 0;
-            if (dist <= 4.5 && theta <= 30.0) {                                      // I:1007
-                if ((m & M_ELEM_C) && (m & ARP_T_WEAK_HBOND_DONOR)) mask |= ARP_AP_CARBONPI;
-                if (m & ARP_T_POS_IONISABLE) mask |= ARP_AP_CATIONPI;
-                if (m & ARP_T_HBOND_DONOR) mask |= ARP_AP_DONORPI;
-                if (m & ARP_T_XBOND_DONOR) mask |= ARP_AP_HALOGENPI;
-            }
-            if (dist <= 6.0) {                                                       // I:1021
-                if ((m & M_RES_MET) && (m & M_ELEM_S)) mask |= ARP_AP_METSULPHURPI;
-            }
-            emit = mask != 0;                                                        // I:1026
-            rec.i0 = A.gid ? A.gid[lid] : lid;
-            rec.i1 = A.ring_gid ? A.ring_gid[r] : r;
-            rec.d0 = dist; rec.d1 = theta;
-            rec.u = mask | ((unsigned)ct << 8);
+            // I:960 tree membership (float64, inclusive), I:964 hydrogens, I:975 aromatic atoms, I:968 selection_plus
+            ok = num::dist2_kd(ctr_, num::d3{(double)v.x, (double)v.y, (double)v.z}) <= 36.0 && !(m & (M_HYDROGEN | ARP_T_AROMATIC));
+            if (DYNAMIC) ok = ok && A.plus[A.s_aux[j].x];
         }
-        if (Q.nearly_full()) Q.flush(A.n_out, A.cap, lane, write);
-        Q.push(emit, rec, lane);
-    };
-    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6;
-    const int nwave = (vgrid * blockDim.x) >> 6;
+        sink(ok, r, j);
+    }
+}
+// the same on the CONTACT grid of the pass (cell edge = the interacting cut-off, atoms of selection_plus without
+// hydrogens — exactly the atoms I:964-968 let through): with a 5 A edge the 6 A query reaches two cells, so the stencil is
+// (2R + 1)^2 rows of 2R + 1 contiguous cells, R = floor(6 / edge) + 1; lane r fetches the bounds of row r, the rows are
+// swept one after the other
+template <class Sink>
+__device__ __forceinline__ void ap_enumerate_cg(const AtomPlaneArgs& A, int r, int lane, Sink sink) {
+    if (!A.ring_plus[r] || (A.ring_home && !A.ring_home[r])) return;
+    const GridDesc g = A.g;
     const int R = (int)floor(6.0 * g.inv) + 1, W = 2 * R + 1, nrows = W * W;
-    for (int r = wave; r < A.nring; r += nwave) {
-        if (!A.ring_plus[r]) continue;  // I:957
-        if (A.ring_home && !A.ring_home[r]) continue;  // multi-GPU: the rank owning the ring emits
-        const num::d3 ctr_ = ld3(A.ring_c, r);
-        const CellBox cb = cell_box(g, ctr_);
-        for (int row0 = 0; row0 < nrows; row0 += 64) {
-            int my_js = 0, my_len = 0;
-            const int row = row0 + lane;
-            if (row < nrows) {
-                const int y2 = cb.cy + (row % W) - R, z2 = cb.cz + (row / W) - R;
-                const int xlo = max(cb.cx - R, 0), xhi = min(cb.cx + R, g.nx - 1);
-                if (y2 >= 0 && y2 < g.ny && z2 >= 0 && z2 < g.nz && xlo <= xhi) {
-                    const int rowbase = (z2 * g.ny + y2) * g.nx;
-                    my_js = A.start[rowbase + xlo];
-                    my_len = A.start[rowbase + xhi + 1] - my_js;
-                }
-            }
-            const int rows_here = min(64, nrows - row0);
-            for (int rr = 0; rr < rows_here; ++rr) {
-                const int js = __builtin_amdgcn_readlane(my_js, rr), len = __builtin_amdgcn_readlane(my_len, rr);
-                for (int kb = 0; kb < len; kb += 64) {
-                    const int k = kb + lane;
-                    bool ok = false;
-                    if (k < len) {
-                        const float4 v = A.s_xyzm[js + k];
-                        // I:960 tree membership (float64, inclusive); hydrogens (I:964) and atoms outside selection_plus
-                        // (I:968) are not in this grid; I:975 aromatic atoms
-                        ok = num::dist2_kd(ctr_, num::d3{(double)v.x, (double)v.y, (double)v.z}) <= 36.0 &&
-                             !(__float_as_uint(v.w) & ARP_T_AROMATIC);
-                    }
-                    P.push(ok, r, js + k, lane, eval);
-                }
+    const num::d3 ctr_ = ld3(A.ring_c, r);
+    const CellBox cb = cell_box(g, ctr_);
+    for (int row0 = 0; row0 < nrows; row0 += 64) {
+        int my_js = 0, my_len = 0;
+        const int row = row0 + lane;
+        if (row < nrows) {
+            const int y2 = cb.cy + (row % W) - R, z2 = cb.cz + (row / W) - R;
+            const int xlo = max(cb.cx - R, 0), xhi = min(cb.cx + R, g.nx - 1);
+            if (y2 >= 0 && y2 < g.ny && z2 >= 0 && z2 < g.nz && xlo <= xhi) {
+                const int rowbase = (z2 * g.ny + y2) * g.nx;
+                my_js = A.start[rowbase + xlo];
+                my_len = A.start[rowbase + xhi + 1] - my_js;
             }
         }
+        const int rows_here = min(64, nrows - row0);
+        for (int rr = 0; rr < rows_here; ++rr) {
+            const int js = __builtin_amdgcn_readlane(my_js, rr), len = __builtin_amdgcn_readlane(my_len, rr);
+            for (int kb = 0; kb < len; kb += 64) {
+                const int k = kb + lane;
+                bool ok = false;
+                if (k < len) {
+                    const float4 v = A.s_xyzm[js + k];
+                    ok = num::dist2_kd(ctr_, num::d3{(double)v.x, (double)v.y, (double)v.z}) <= 36.0 &&
+                         !(__float_as_uint(v.w) & ARP_T_AROMATIC);
+                }
+                sink(ok, r, js + k);
+            }
+        }
+    }
+}
+template <bool DYNAMIC, class Sink>
+__device__ __forceinline__ void pp_enumerate(const PlanePlaneArgs& A, int a, int lane, Sink sink) {
+    if (DYNAMIC && (!A.ring_plus[a] || (A.ring_home && !A.ring_home[a]))) return;   // I:1081; multi-GPU: owner of the lower ring id emits
+    const num::d3 ca = ld3(A.ring_c, a);
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, ca), lane);
+    for (int kb = 0; kb < st.pre[9]; kb += 64) {
+        const int k = kb + lane;
+        bool ok = false;
+        int b = 0;
+        if (k < st.pre[9]) {
+            b = A.perm[stencil_pos(st, k)];
+            // unordered pair once (I:1081, 1085); squared-distance superset of I:1113, settled exactly in pp_eval
+            ok = b > a && num::dist2_kd(ca, ld3(A.ring_c, b)) <= 36.0 * (1.0 + 1e-9);
+            if (DYNAMIC) ok = ok && A.ring_plus[b];
+        }
+        sink(ok, a, b);
+    }
+}
+template <bool DYNAMIC, class Sink>
+__device__ __forceinline__ void gg_enumerate(const GroupGroupArgs& A, int a, int lane, Sink sink) {
+    if (DYNAMIC && (!A.am_plus[a] || (A.am_home && !A.am_home[a]))) return;   // multi-GPU: owner of the bgn amide emits
+    const num::d3 cad = num::to_d3(lf3(A.am_c, a));
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, cad), lane);
+    for (int kb = 0; kb < st.pre[9]; kb += 64) {
+        const int k = kb + lane;
+        bool ok = false;
+        int b = 0;
+        if (k < st.pre[9]) {
+            b = A.perm[stencil_pos(st, k)];
+            // I:1233, 1237; float64 squared-distance superset of the float32 test at I:1270 (settled exactly in gg_eval)
+            ok = b != a && num::dist2_kd(cad, num::to_d3(lf3(A.am_c, b))) <= 36.0 * (1.0 + 1e-5);
+            if (DYNAMIC) ok = ok && A.am_plus[b];
+        }
+        sink(ok, a, b);
+    }
+}
+template <bool DYNAMIC, class Sink>
+__device__ __forceinline__ void gp_enumerate(const GroupPlaneArgs& A, int a, int lane, Sink sink) {
+    if (DYNAMIC && (!A.am_plus[a] || (A.am_home && !A.am_home[a]))) return;   // multi-GPU: owner of the amide emits
+    const num::d3 cad = num::to_d3(lf3(A.am_c, a));
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, cad), lane);
+    for (int kb = 0; kb < st.pre[9]; kb += 64) {
+        const int k = kb + lane;
+        bool ok = false;
+        int r = 0;
+        if (k < st.pre[9]) {
+            r = A.perm[stencil_pos(st, k)];
+            ok = num::dist2_kd(cad, ld3(A.ring_c, r)) <= 36.0 * (1.0 + 1e-9);   // superset of I:1351
+            if (DYNAMIC) ok = ok && A.ring_plus[r];                              // I:1318
+        }
+        sink(ok, a, r);
+    }
+}
+
+// =====================================================================================================================
+// Direct form: enumerate and evaluate in one kernel (standalone entry points, sharded stage path)
+// =====================================================================================================================
+__device__ __forceinline__ void atom_plane_body(const AtomPlaneArgs& A, int vblock, int vgrid, PlaneShared* sh, bool contact_grid) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
+    const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int r, int j) {
+        const float4 v = live ? A.s_xyzm[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ap_eval(A, live, r, v, live ? A.s_aux[j].x : 0, Q, lane);
+    };
+    auto sink = [&](bool ok, int r, int j) { P.push(ok, r, j, lane, eval); };
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6, nwave = (vgrid * blockDim.x) >> 6;
+    for (int r = wave; r < A.nring; r += nwave) {
+        if (contact_grid) ap_enumerate_cg(A, r, lane, sink);
+        else ap_enumerate<true>(A, r, lane, sink);
     }
     P.drain(lane, eval);
-    Q.flush_block(sh->n, &sh->base, A.n_out, A.cap, lane, write);
+    Q.flush_block(sh->n, &sh->base, A.n_out, A.cap, lane, ApWrite{A});
+}
+__device__ __forceinline__ void plane_plane_body(const PlanePlaneArgs& A, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
+    const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int a, int b) { pp_eval(A, live, a, b, Q, lane); };
+    auto sink = [&](bool ok, int a, int b) { P.push(ok, a, b, lane, eval); };
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6, nwave = (vgrid * blockDim.x) >> 6;
+    for (int a = wave; a < A.nring; a += nwave) pp_enumerate<true>(A, a, lane, sink);
+    P.drain(lane, eval);
+    Q.flush_block(sh->n, &sh->base, A.n_out, A.cap, lane, PpWrite{A});
+}
+__device__ __forceinline__ void group_group_body(const GroupGroupArgs& A, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
+    const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int a, int b) { gg_eval(A, live, a, b, Q, lane); };
+    auto sink = [&](bool ok, int a, int b) { P.push(ok, a, b, lane, eval); };
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6, nwave = (vgrid * blockDim.x) >> 6;
+    for (int a = wave; a < A.namide; a += nwave) gg_enumerate<true>(A, a, lane, sink);
+    P.drain(lane, eval);
+    Q.flush_block(sh->n, &sh->base, A.n_out, A.cap, lane, GgWrite{A});
+}
+__device__ __forceinline__ void group_plane_body(const GroupPlaneArgs& A, int vblock, int vgrid, PlaneShared* sh) {
+    PlaneQueue Q{sh->q[threadIdx.x >> 6], 0};
+    PairQueue P{sh->pq[threadIdx.x >> 6], 0};
+    const int lane = threadIdx.x & 63;
+    auto eval = [&](bool live, int a, int r) { gp_eval(A, live, a, r, Q, lane); };
+    auto sink = [&](bool ok, int a, int r) { P.push(ok, a, r, lane, eval); };
+    const int wave = (vblock * blockDim.x + threadIdx.x) >> 6, nwave = (vgrid * blockDim.x) >> 6;
+    for (int a = wave; a < A.namide; a += nwave) gp_enumerate<true>(A, a, lane, sink);
+    P.drain(lane, eval);
+    Q.flush_block(sh->n, &sh->base, A.n_out, A.cap, lane, GpWrite{A});
 }
 
-// The four ring / amide loops of a pass in ONE launch: blocks [0, nb0) work as k_atom_plane (on the contact grid),
-// [nb0, nb1) as k_plane_plane, [nb1, nb2) as k_group_group, [nb2, nb3) as k_group_plane.  It is launched on the second
-// stream as soon as the contact grid and the ring / amide masks exist, i.e. together with the neighbour search, whose
-// long tail of retiring blocks leaves room for these ~1500 short blocks; it is over before the sift kernel is.
-struct PlanesSplit { int nb0, nb1, nb2, nb3; };   // cumulative block counts of the four parts
-__global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, PlanesSplit ps,
-                                                PublishArgs pub) {
+__global__ __launch_bounds__(256) void k_atom_plane(AtomPlaneArgs a) {
     __shared__ PlaneShared s_sh;
-    const int b = (int)blockIdx.x;
-    if (b < ps.nb0) {
-        atom_plane_cg_body(ap, b, ps.nb0, &s_sh);
-    } else if (b < ps.nb1) {
-        const PlanePlaneArgs& a = pp;
-        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - ps.nb0, ps.nb1 - ps.nb0, &s_sh);
-    } else if (b < ps.nb2) {
-        const GroupGroupArgs& a = gg;
-        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb1, ps.nb2 - ps.nb1, &s_sh);
-    } else if (b < ps.nb3) {
-        const GroupPlaneArgs& a = gp;
-        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb2, ps.nb3 - ps.nb2, &s_sh);
+    atom_plane_body(a, (int)blockIdx.x, (int)gridDim.x, &s_sh, false);
+}
+__global__ __launch_bounds__(256) void k_plane_plane(PlanePlaneArgs a) {
+    __shared__ PlaneShared s_sh;
+    plane_plane_body(a, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+}
+__global__ __launch_bounds__(256) void k_group_group(GroupGroupArgs a) {
+    __shared__ PlaneShared s_sh;
+    group_group_body(a, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+}
+__global__ __launch_bounds__(256) void k_group_plane(GroupPlaneArgs a) {
+    __shared__ PlaneShared s_sh;
+    group_plane_body(a, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+}
+
+// =====================================================================================================================
+// Static candidate lists.  Which ring / amide / atom pairs lie within 6 A of each other depends on the coordinates only;
+// it is established ONCE per uploaded structure (k_plane_lists: the four enumerations above without the per-pass filters,
+// appended to four {x, y} lists in HBM) — a spatial index like the ring grid it is built from.  A pass then spends no
+// time walking stencils: it reads the lists, 64 pairs per wavefront, applies the filters of the pass (selection_plus
+// membership of both partners, ownership) and evaluates the geometry with full lanes (planes_from_lists).
+// =====================================================================================================================
+struct PlaneLists {
+    int2* pairs[4];            // 0 atom-plane {ring, atom local id}, 1 plane-plane {a, b}, 2 group-group {a, b}, 3 group-plane {amide, ring}
+    long long cap[4];
+    u64* count;                // [4], device; may exceed cap (overflow: the host re-sizes and rebuilds)
+};
+struct ListSink {              // appends the lanes with ok to list k, one atomicAdd per wave
+    const PlaneLists& L;
+    int k, lane;
+    __device__ __forceinline__ void operator()(bool ok, int x, int y) const {
+        const unsigned long long m = __ballot(ok);
+        if (!m) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(L.count + k, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0);
+        const long long slot = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && slot < L.cap[k]) L.pairs[k][slot] = make_int2(x, y);
     }
-    pass_end(pub, 1);
+};
+// blocks [0, nb0) rings -> atom-plane list, [nb0, nb1) rings -> plane-plane, [nb1, nb2) amides -> group-group, rest -> group-plane
+__global__ __launch_bounds__(256) void k_plane_lists(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp,
+                                                     PlaneLists L, int nb0, int nb1, int nb2, int nb3) {
+    const int b = (int)blockIdx.x, lane = threadIdx.x & 63;
+    if (b < nb0) {
+        const int wave = (b * 256 + (int)threadIdx.x) >> 6, nwave = nb0 * 4;
+        // the list holds local atom ids: translate the sorted position
+        auto sink = [&](bool ok, int r, int j) { ListSink{L, 0, lane}(ok, r, ok ? ap.s_aux[j].x : 0); };
+        for (int r = wave; r < ap.nring; r += nwave) ap_enumerate<false>(ap, r, lane, sink);
+    } else if (b < nb1) {
+        const int wave = ((b - nb0) * 256 + (int)threadIdx.x) >> 6, nwave = (nb1 - nb0) * 4;
+        for (int a = wave; a < pp.nring; a += nwave) pp_enumerate<false>(pp, a, lane, ListSink{L, 1, lane});
+    } else if (b < nb2) {
+        const int wave = ((b - nb1) * 256 + (int)threadIdx.x) >> 6, nwave = (nb2 - nb1) * 4;
+        for (int a = wave; a < gg.namide; a += nwave) gg_enumerate<false>(gg, a, lane, ListSink{L, 2, lane});
+    } else if (b < nb3) {
+        const int wave = ((b - nb2) * 256 + (int)threadIdx.x) >> 6, nwave = (nb3 - nb2) * 4;
+        for (int a = wave; a < gp.namide; a += nwave) gp_enumerate<false>(gp, a, lane, ListSink{L, 3, lane});
+    }
 }
 
-// interactions.py:715-936 for every pair of the list (sift_body); ends the pass on the main stream.
-__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(SiftArgs sa, PublishArgs pub) {
-    __shared__ SiftShared s_sh;
-    sift_body(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
-    pass_end(pub, 0);
+// The ring / amide loops of a pass from the lists: waves take chunks of 64 list entries (a chunk never straddles two
+// lists), filter, evaluate.  vblock / vgrid: position among the blocks doing this work.
+__device__ __forceinline__ void planes_from_lists(const AtomPlaneArgs& ap, const PlanePlaneArgs& pp, const GroupGroupArgs& gg,
+                                                  const GroupPlaneArgs& gp, const PlaneLists& L, u64* __restrict__ publish_counts,
+                                                  int vblock, int vgrid, PlaneShared* sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long cnt[4], chunks[5];
+    chunks[0] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u64 c = L.count[k];
+        cnt[k] = (long long)(c < (u64)L.cap[k] ? c : (u64)L.cap[k]);
+        chunks[k + 1] = chunks[k] + (cnt[k] + 63) / 64;
+        if (vblock == 0 && threadIdx.x == 0) publish_counts[k] = c;   // the host checks them against the capacities at the end of the pass
+    }
+    const long long wave = (long long)vblock * 4 + w, nwave = (long long)vgrid * 4;
+    PlaneQueue Q{sh->q[w], 0};
+    int kind_done = -1;     // output queue holds records of one kind at a time
+    auto flush_kind = [&](int kind) {
+        if (kind == 0) Q.flush(ap.n_out, ap.cap, lane, ApWrite{ap});
+        else if (kind == 1) Q.flush(pp.n_out, pp.cap, lane, PpWrite{pp});
+        else if (kind == 2) Q.flush(gg.n_out, gg.cap, lane, GgWrite{gg});
+        else if (kind == 3) Q.flush(gp.n_out, gp.cap, lane, GpWrite{gp});
+    };
+    for (long long ch = wave; ch < chunks[4]; ch += nwave) {
+        const int kind = ch < chunks[1] ? 0 : ch < chunks[2] ? 1 : ch < chunks[3] ? 2 : 3;
+        if (kind != kind_done) { flush_kind(kind_done); kind_done = kind; }
+        const long long e = (ch - chunks[kind]) * 64 + lane;
+        const bool have = e < cnt[kind];
+        const int2 pr = have ? L.pairs[kind][e] : make_int2(0, 0);
+        if (kind == 0) {
+            const int r = pr.x, lid = pr.y;
+            bool live = have && ap.ring_plus[r] && !(ap.ring_home && !ap.ring_home[r]) && (ap.sel_all || ap.plus[lid]);   // I:957, 968
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                v = ap.st_xyzm[lid];
+                uint32_t m = __float_as_uint(v.w);
+                if (ap.sel_all || (ap.sel && ap.sel[lid])) m |= M_SEL;
+                v.w = __uint_as_float(m);
+            }
+            ap_eval(ap, live, r, v, lid, Q, lane);
+        } else if (kind == 1) {
+            const bool live = have && pp.ring_plus[pr.x] && pp.ring_plus[pr.y] && !(pp.ring_home && !pp.ring_home[pr.x]);
+            pp_eval(pp, live, pr.x, pr.y, Q, lane);
+        } else if (kind == 2) {
+            const bool live = have && gg.am_plus[pr.x] && gg.am_plus[pr.y] && !(gg.am_home && !gg.am_home[pr.x]);
+            gg_eval(gg, live, pr.x, pr.y, Q, lane);
+        } else {
+            const bool live = have && gp.am_plus[pr.x] && gp.ring_plus[pr.y] && !(gp.am_home && !gp.am_home[pr.x]);
+            gp_eval(gp, live, pr.x, pr.y, Q, lane);
+        }
+    }
+    flush_kind(kind_done);
 }
 
-// The same two kernels as ONE grid: blocks [0, np) = the ring / amide loops (np a multiple of 8: idle padding blocks),
-// blocks [np, np + nsift) = the sift kernel.  One stream, no cross-stream events (those cost the host ~5 us each).
+// ---- the last launch of a pass: ring / amide loops (from the lists) and the per-pair SIFt kernel in ONE grid ------------
+// Blocks [0, np) evaluate the candidate lists (np a multiple of 8, so that vblock % 8 of the sift blocks is still the XCD
+// the dispatcher puts them on), blocks [np, np + nsift) are the sift kernel.  One stream, no cross-stream events (those
+// cost the host ~5 us each); pass_end() publishes the counters of the pass.
 union SiftPlanesShared {
     PlaneShared planes;
     SiftShared sift;
 };
 __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa, int nsift, AtomPlaneArgs ap, PlanePlaneArgs pp,
-                                                                     GroupGroupArgs gg, GroupPlaneArgs gp, PlanesSplit ps, int np,
-                                                                     PublishArgs pub) {
+                                                                     GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
+                                                                     u64* publish_counts, int np, PublishArgs pub) {
     __shared__ SiftPlanesShared s_sh;
     const int b = (int)blockIdx.x;
-    if (b >= np) {
-        sift_body(sa, b - np, nsift, &s_sh.sift);
-    } else if (b < ps.nb0) {
-        atom_plane_cg_body(ap, b, ps.nb0, &s_sh.planes);
-    } else if (b < ps.nb1) {
-        const PlanePlaneArgs& a = pp;
-        plane_plane_body(a.g, a.start, a.perm, a.nring, a.ring_c, a.ring_n, a.ring_res, a.ring_sel, a.ring_plus, a.ring_home, a.ring_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_t1, a.out_t2, a.out_y1, a.out_y2, a.out_ct, a.n_out, b - ps.nb0, ps.nb1 - ps.nb0, &s_sh.planes);
-    } else if (b < ps.nb2) {
-        const GroupGroupArgs& a = gg;
-        group_group_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.am_home, a.am_gid, a.cap, a.out_bgn, a.out_end, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb1, ps.nb2 - ps.nb1, &s_sh.planes);
-    } else if (b < ps.nb3) {
-        const GroupPlaneArgs& a = gp;
-        group_plane_body(a.g, a.start, a.perm, a.namide, a.am_c, a.am_n, a.am_sel, a.am_plus, a.ring_c, a.ring_n, a.ring_sel, a.ring_plus, a.am_home, a.am_gid, a.ring_gid, a.cap, a.out_amide, a.out_ring, a.out_dist, a.out_dih, a.out_theta, a.out_ct, a.n_out, b - ps.nb2, ps.nb3 - ps.nb2, &s_sh.planes);
-    }
+    if (b >= np) sift_body(sa, b - np, nsift, &s_sh.sift);
+    else planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
+    pass_end(pub, 0);
+}
+// the two halves as separate kernels (sharded stage path with a caller-owned stream, structures without atoms / planes)
+__global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
+                                                u64* publish_counts, PublishArgs pub) {
+    __shared__ PlaneShared s_sh;
+    planes_from_lists(ap, pp, gg, gp, L, publish_counts, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+    pass_end(pub, 1);
+}
+__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(SiftArgs sa, PublishArgs pub) {
+    __shared__ SiftShared s_sh;
+    sift_body(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
     pass_end(pub, 0);
 }
