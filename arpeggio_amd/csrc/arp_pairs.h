@@ -344,6 +344,11 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * SCAT_ATOMS + threadIdx.x;
     const int2 cr = (i < n) ? cell_rank[i] : make_int2(-1, 0);      // in flight beside the histogram loads
+    // ... and so are the atom's record columns (they do not depend on where the atom goes)
+    const int ii = (i < n) ? i : 0;
+    const float4 my_xyzm = compose_xyzm(r, ii);
+    const int4 my_aux = r.aux[ii];
+    const int4 my_q1 = s_rec ? r.q1[ii] : make_int4(0, 0, 0, 0);
     int4 v[STEPS];
 #pragma unroll
     for (int k = 0; k < STEPS; ++k) {
@@ -380,7 +385,17 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
         for (int k = lo + threadIdx.x; k < hi; k += 1024) start[k] = (k < ncell) ? s_start[k] + s_woff[k / CHUNK] : total;
         if (blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = (unsigned long long)total;
     }
-    if (cr.x >= 0) scatter_one(r, i, s_start[cr.x] + s_woff[cr.x / CHUNK] + cr.y, s_xyzm, s_aux, s_rec);
+    if (cr.x >= 0) {
+        const int pos = s_start[cr.x] + s_woff[cr.x / CHUNK] + cr.y;
+        s_xyzm[pos] = my_xyzm;
+        s_aux[pos] = my_aux;
+        if (s_rec) {
+            SiftRec q;
+            q.xyzm = my_xyzm;
+            q.q1 = my_q1;
+            s_rec[pos] = q;
+        }
+    }
 }
 
 // ---- end of a pass, without a launch of its own ------------------------------------------------------------
@@ -587,11 +602,18 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                     const unsigned long long ms0 = __ballot(valid0 && selj0), ms1 = __ballot(valid1 && selj1);
                     if ((m_selh == m_hvalid && ms0 == mv0 && ms1 == mv1) || (m_selh == 0 && ms0 == 0 && ms1 == 0)) continue;
                 }
+                const int t0 = hb - hs;
+                if (MODE != MODE_MARK && !count_owned) {
+                    // tests of this chunk, in closed form (candidate k of the home pencil meets home atom t iff k > t; every other
+                    // candidate meets every home atom): the loop below need not count
+                    const int c0 = kk0 < 0 ? 0 : (kk0 == INT_MAX ? hcount : min(max(kk0 - t0, 0), hcount));
+                    const int c1 = kk1 < 0 ? 0 : (kk1 == INT_MAX ? hcount : min(max(kk1 - t0, 0), hcount));
+                    n_cand += (unsigned)(c0 + c1);
+                }
                 // ---- stage 1: distance tests only.  Bit hh of lo/hi = candidate within r2_lo / r2_hi of home atom hh.
                 // float32 pre-filter: |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded squares, two
                 // rounded sums), so outside the +-1e-5 band the float32 answer IS the float64 answer.
                 uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
-                const int t0 = hb - hs;
 #pragma unroll 1
                 for (int hh = hcount - 1; hh >= 0; --hh) {
                     // broadcast the home atom from lane hh (v_readlane, no memory traffic)
@@ -619,7 +641,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                         const uint32_t mh0 = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
                         n_cand += (unsigned)(te0 && (((lh < a0.x) ? mh0 : mj0) & M_HOME));
                         n_cand += (unsigned)(te1 && (((lh < a1.x) ? mh0 : mj1) & M_HOME));
-                    } else {
+                    } else if (MODE == MODE_MARK) {
                         n_cand += (unsigned)te0 + (unsigned)te1;
                     }
                 }

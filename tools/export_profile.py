@@ -31,12 +31,17 @@ def agg(path):
 
 
 out = collections.defaultdict(dict)
-for f in ('fetch/f_counter_collection.csv', 'write/w_counter_collection.csv', 'sq/s_counter_collection.csv'):
+import os
+for f in ('fetch/f_counter_collection.csv', 'write/w_counter_collection.csv', 'sq/s_counter_collection.csv', 'sq2/s_counter_collection.csv', 'tc/c_counter_collection.csv'):
+    if not os.path.exists(f'{base}/{f}'):
+        continue
     for k, v in agg(f'{base}/{f}').items():
         for c, x in v.items():
             out[k][c] = round(sum(x) / len(x), 1)
 cols = ['FETCH_SIZE', 'WRITE_SIZE', 'SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU',
-        'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES']
+        'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR',
+        'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_VMEM', 'SQ_ACTIVE_INST_SCA', 'SQ_INST_LEVEL_VMEM', 'TCP_TOTAL_CACHE_ACCESSES_sum',
+        'TCP_TCC_READ_REQ_sum', 'TCC_HIT_sum', 'TCC_MISS_sum']
 with open(f'profiles/{tag}_pmc_per_launch.csv', 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow(['Kernel'] + cols)
