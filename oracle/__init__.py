@@ -3,8 +3,9 @@
 Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of bench.py may
 import this package, and only as the checker.  The product (arpeggio_amd/) never does.
 
-Parity status: PARTIALLY PINNED against executed reference code — see the header of
-ref_c.c and tests/golden/README.md for exactly which functions are pinned.
+Parity status: pinned against executed reference code for the whole path (run_arpeggio and everything below it;
+tests/golden/make_golden_core.py) — see the header of ref_c.c and tests/golden/README.md; third-party semantics the
+reference calls but does not contain (KD-tree membership test and delivery order) are restated as recalled.
 
 ``ref_c.c`` is the restatement (plain C, gcc); this module is its ctypes binding.
 """

@@ -5,15 +5,20 @@
  * import, link or call this file; only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, and only as the checker.
  *
- * Parity status: PARTIALLY PINNED.  The reference cannot be executed end to end
- * in this environment (BioPython / OpenBabel / gemmi are absent and the reference
- * ships no tests or fixtures).  What is pinned against *executed reference code*
- * (tests/golden/, generated by tests/golden/make_golden.py from the reference's own
- * function bodies): get_angle, group_angle, group_group_angle, is_hbond,
- * is_weak_hbond, __get_contact_type, the three update_atom_* accumulators and
- * the plane-plane / group-group / group-plane loops.  The per-pair ladder of
- * _calculate_atom_contacts, the atom-plane loop and _make_selection are restated
- * from the cited lines and are NOT pinned against an executed reference.
+ * Parity status: PINNED against executed reference code for everything the reference itself computes on the
+ * path.  The reference cannot be imported as a package here (BioPython / OpenBabel / gemmi are absent; it ships no
+ * tests or fixtures), so tests/golden/make_golden.py and make_golden_core.py compile its own function and method
+ * bodies with `ast` from the files where they lie under /root/reference and run them on data holders (stored
+ * attributes, neighbour lists, bond orders — no arithmetic of the path): run_arpeggio, _make_selection,
+ * _calculate_atom_contacts, __get_contact_type, the atom-plane / plane-plane / group-group / group-plane loops,
+ * is_hbond, is_weak_hbond, is_halogen_weak_hbond, is_xbond, get_single_bond_neighbour, get_angle, group_angle,
+ * group_group_angle and the three update_atom_* accumulators; 136 structures in three delivery orders, 240 k
+ * atom-atom records, all compared bit for bit with this file (tests/test_golden_core.py, tests/test_oracle_golden.py)
+ * and — directly, without this file in between — with the HIP kernels.
+ * What stays "recalled" is third-party semantics the reference calls but does not contain: the KD-tree's
+ * membership test (Bio.PDB.kdtrees: float64 dx*dx + dy*dy + dz*dz <= r*r, inclusive) and its delivery order / pair
+ * orientation (results are defined on the canonical one, bgn = lower packed index), OpenBabel's iteration order
+ * of bonds.
  *
  * Citations: I: = arpeggio/core/interactions.py, U: = arpeggio/core/utils.py,
  * C: = arpeggio/core/config.py of the reference tree.
