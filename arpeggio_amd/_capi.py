@@ -30,7 +30,8 @@ SYMBOLS = (
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
     'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
     'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob',
-    'arp_write_contacts_json',
+    'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_shard_set_home', 'arp_shard_pack_face',
+    'arp_shard_assemble', 'arp_shard_layout', 'arp_get_blob',
 )
 
 _lib = None
@@ -78,6 +79,14 @@ def load():
     L.arp_blob_size.restype = C.c_uint64
     L.arp_blob_layout.argtypes = [vp, C.c_uint64] + [i64] * 6
     L.arp_set_blob.argtypes = [vp, vp, C.c_uint64]
+    L.arp_records_size.argtypes = [i64] * 5
+    L.arp_records_size.restype = C.c_uint64
+    L.arp_records_layout.argtypes = [vp, C.c_uint64] + [i64] * 5
+    L.arp_shard_set_home.argtypes = [vp, vp, C.c_uint64]
+    L.arp_shard_pack_face.argtypes = [vp, i32, dbl, dbl, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.arp_shard_assemble.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, i64, vp]
+    L.arp_shard_layout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.arp_get_blob.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.arp_write_contacts_json.argtypes = [C.c_char_p, i32, i32, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_char_p, i64]
     L.arp_device_buffer.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.arp_run_stage.argtypes = [vp, i32, dbl, dbl, i32, dbl, vp]
@@ -104,7 +113,7 @@ def load():
     L.arp_stream_handle.restype = C.c_uint64
     for s in SYMBOLS:
         f = getattr(L, s)
-        if s not in ('arp_version', 'arp_last_error', 'arp_destroy', 'arp_stream_handle', 'arp_blob_size'):
+        if s not in ('arp_version', 'arp_last_error', 'arp_destroy', 'arp_stream_handle', 'arp_blob_size', 'arp_records_size'):
             f.restype = C.c_int
     _lib = L
     return L
@@ -203,6 +212,106 @@ def pack_blob(pc, pinned=True):
     return buf
 
 
+def unpack_blob(buf):
+    """The arrays of a blob (as written by ``pack_blob`` or read back with ``Context.get_blob``) as a dict of NumPy views,
+    radii decoded through the dictionary; for tests and tools."""
+    hdr = BlobHeader.from_buffer_copy(buf[:C.sizeof(BlobHeader)].tobytes())
+    n, nres, nring, namide, nbond, nh = int(hdr.n), int(hdr.nres), int(hdr.nring), int(hdr.namide), int(hdr.nbond), int(hdr.nh)
+    counts = (4 * n, 2 * n, n, n, n, nres, nres, nres, n + 1, nbond, n + 1, 3 * nh, n, 3 * nring, 3 * nring, nring, 3 * namide,
+              3 * namide, namide, n, 512)
+    v = [np.frombuffer(buf, dtype=dt, count=cnt, offset=int(hdr.off[k])) for k, (dt, cnt) in enumerate(zip(_BLOB_DTYPES, counts))]
+    names = ('xyz4', 'rad', 'type_mask', 'flags', 'res_id', 'res_flags', 'res_prev', 'res_next', 'bond_off', 'bond_idx', 'h_off',
+             'h_xyz', 'sb_nbr', 'ring_center', 'ring_normal', 'ring_res', 'amide_center', 'amide_normal', 'amide_res', 'rad_idx',
+             'rad_tab')
+    d = dict(zip(names, v))
+    d['xyz'] = d['xyz4'].reshape(-1, 4)[:, :3]
+    d['rad'] = d['rad'].reshape(-1, 2)
+    d['rad_tab'] = d['rad_tab'].reshape(256, 2)
+    for k in ('h_xyz', 'ring_center', 'ring_normal', 'amide_center', 'amide_normal'):
+        d[k] = d[k].reshape(-1, 3)
+    d['header'] = hdr
+    return d
+
+
+# ---- record buffers of the device-side shard assembly (arp_rec_header / arp_rec_atom / ... of the header file) ----------
+class RecHeader(C.Structure):
+    _fields_ = [('magic', C.c_uint64), ('bytes', C.c_uint64), ('na', C.c_int64), ('nh', C.c_int64), ('nb', C.c_int64),
+                ('nring', C.c_int64), ('namide', C.c_int64), ('n_rad', C.c_int64), ('off', C.c_uint64 * 5),
+                ('lo', C.c_double * 3), ('hi', C.c_double * 3), ('ring_lo', C.c_double * 3), ('ring_hi', C.c_double * 3),
+                ('amide_lo', C.c_double * 3), ('amide_hi', C.c_double * 3), ('rad_tab', C.c_double * 512)]
+
+
+REC_ATOM = np.dtype([('xyz', '<f4', 3), ('gid', '<i4'), ('vdw', '<f8'), ('cov', '<f8'), ('sb_xyz', '<f4', 3), ('sb_has', '<i4'),
+                     ('res_gid', '<i4'), ('res_prev', '<i4'), ('res_next', '<i4'), ('tmask', '<u2'), ('flags', '<u2'),
+                     ('h_start', '<i4'), ('h_cnt', '<i4'), ('bond_start', '<i4'), ('bond_cnt', '<i4'),
+                     ('res_flags', 'u1'), ('sel', 'u1'), ('pad', 'u1', 14)])
+REC_RING = np.dtype([('c', '<f8', 3), ('n', '<f8', 3), ('gid', '<i4'), ('res', '<i4'), ('pad', '<i4', 2)])
+REC_AMIDE = np.dtype([('c', '<f4', 3), ('n', '<f4', 3), ('gid', '<i4'), ('res', '<i4')])
+assert REC_ATOM.itemsize == 96 and REC_RING.itemsize == 64 and REC_AMIDE.itemsize == 32
+
+
+def _rec_views(buf, hdr):
+    return (np.frombuffer(buf, REC_ATOM, int(hdr.na), int(hdr.off[0])), np.frombuffer(buf, np.float64, 3 * int(hdr.nh), int(hdr.off[1])).reshape(-1, 3),
+            np.frombuffer(buf, np.int32, int(hdr.nb), int(hdr.off[2])), np.frombuffer(buf, REC_RING, int(hdr.nring), int(hdr.off[3])),
+            np.frombuffer(buf, REC_AMIDE, int(hdr.namide), int(hdr.off[4])))
+
+
+def pack_records_buffer(rec, pinned=True):
+    """``sharding.pack_records`` output (dict of arrays, ascending ids) as ONE record buffer for ``Context.shard_set_home``."""
+    L = load()
+    na, nh, nb = int(rec['gid'].size), int(rec['h_xyz'].shape[0]), int(rec['bond_gid'].size)
+    nr, nm = int(rec['ring_gid'].size), int(rec['amide_gid'].size)
+    size = int(L.arp_records_size(na, nh, nb, nr, nm))
+    if size == 0:
+        raise ValueError('pack_records_buffer: counts out of range')
+    buf = pinned_empty(size, np.uint8) if pinned else np.empty(size, np.uint8)
+    buf[:] = 0
+    if L.arp_records_layout(_p(buf), size, na, nh, nb, nr, nm) != ARP_OK:
+        raise ValueError('arp_records_layout failed')
+    hdr = RecHeader.from_buffer(buf)
+    a, h, b, r, m = _rec_views(buf, hdr)
+    a['xyz'], a['gid'], a['vdw'], a['cov'] = rec['xyz'], rec['gid'], rec['vdw'], rec['cov']
+    a['sb_xyz'], a['sb_has'] = rec['sb_xyz'], rec['sb_has']
+    a['res_gid'], a['res_prev'], a['res_next'], a['res_flags'] = rec['res_gid'], rec['res_prev'], rec['res_next'], rec['res_flags']
+    a['tmask'], a['flags'], a['sel'] = rec['tmask'], rec['flags'], rec['sel']
+    a['h_cnt'], a['bond_cnt'] = rec['h_cnt'], rec['bond_cnt']
+    a['h_start'] = np.concatenate([[0], np.cumsum(rec['h_cnt'])])[:-1] if na else 0
+    a['bond_start'] = np.concatenate([[0], np.cumsum(rec['bond_cnt'])])[:-1] if na else 0
+    h[:], b[:] = rec['h_xyz'], rec['bond_gid']
+    r['c'], r['n'], r['gid'], r['res'] = rec['ring_center'], rec['ring_normal'], rec['ring_gid'], rec['ring_res']
+    m['c'], m['n'], m['gid'], m['res'] = rec['amide_center'], rec['amide_normal'], rec['amide_gid'], rec['amide_res']
+    tab = np.zeros((256, 2))
+    if na:
+        keys = np.stack([rec['vdw'], rec['cov']], axis=1).astype(np.float64).view(np.uint64)
+        uniq = np.unique(keys, axis=0)[:256]
+        tab[:len(uniq)] = uniq.view(np.float64)
+        hdr.n_rad = len(uniq)
+    for k, val in enumerate(tab.reshape(-1)):
+        hdr.rad_tab[k] = val
+    for name, arr in (('', rec['xyz']), ('ring_', rec['ring_center']), ('amide_', rec['amide_center'])):
+        lo = arr.min(axis=0).astype(np.float64) if len(arr) else np.zeros(3)
+        hi = arr.max(axis=0).astype(np.float64) if len(arr) else np.zeros(3)
+        for k in range(3):
+            getattr(hdr, name + 'lo')[k] = lo[k]
+            getattr(hdr, name + 'hi')[k] = hi[k]
+    del hdr
+    return buf
+
+
+def unpack_records_buffer(buf):
+    """Inverse of ``pack_records_buffer`` (the dict ``sharding.pack_records`` makes); for tests."""
+    hdr = RecHeader.from_buffer_copy(buf[:C.sizeof(RecHeader)].tobytes())
+    a, h, b, r, m = _rec_views(buf, hdr)
+    return {'gid': a['gid'].copy(), 'xyz': a['xyz'].copy(), 'vdw': a['vdw'].copy(), 'cov': a['cov'].copy(), 'tmask': a['tmask'].copy(),
+            'flags': a['flags'].copy(), 'res_gid': a['res_gid'].copy(), 'res_flags': a['res_flags'].copy(), 'res_prev': a['res_prev'].copy(),
+            'res_next': a['res_next'].copy(), 'sel': a['sel'].copy(), 'sb_xyz': a['sb_xyz'].copy(), 'sb_has': a['sb_has'].astype(np.uint8),
+            'h_cnt': a['h_cnt'].copy(), 'h_xyz': h.copy(), 'bond_cnt': a['bond_cnt'].copy(), 'bond_gid': b.copy(),
+            'h_start': a['h_start'].copy(), 'bond_start': a['bond_start'].copy(),
+            'ring_gid': r['gid'].copy(), 'ring_center': r['c'].copy(), 'ring_normal': r['n'].copy(), 'ring_res': r['res'].copy(),
+            'amide_gid': m['gid'].copy(), 'amide_center': m['c'].copy(), 'amide_normal': m['n'].copy(), 'amide_res': m['res'].copy(),
+            'header': hdr}
+
+
 KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')
 
 
@@ -263,6 +372,41 @@ class Context:
         self._check(self._L.arp_set_blob(self._h, _p(blob), int(blob.nbytes)), 'arp_set_blob')
         hdr = BlobHeader.from_buffer_copy(blob[:C.sizeof(BlobHeader)].tobytes())
         self.n, self.n_rings, self.n_amides = int(hdr.n), int(hdr.nring), int(hdr.namide)
+
+    def get_blob(self):
+        """The resident structure read back in blob form (uint8 array; ``unpack_blob`` gives the arrays)."""
+        nb = C.c_uint64()
+        self._check(self._L.arp_get_blob(self._h, None, 0, C.byref(nb)), 'arp_get_blob')
+        buf = np.empty(int(nb.value), np.uint8)
+        self._check(self._L.arp_get_blob(self._h, _p(buf), int(buf.nbytes), C.byref(nb)), 'arp_get_blob')
+        return buf
+
+    # ---- shard assembled on the device (sharding.make_shard_device)
+    def shard_set_home(self, records):
+        self._check(self._L.arp_shard_set_home(self._h, _p(records), int(records.nbytes)), 'arp_shard_set_home')
+
+    def shard_pack_face(self, slot, x_lo, x_hi):
+        """(device pointer, bytes) of the record buffer with the home items whose x lies in [x_lo, x_hi]."""
+        ptr, nb = C.c_uint64(), C.c_uint64()
+        self._check(self._L.arp_shard_pack_face(self._h, int(slot), float(x_lo), float(x_hi), C.byref(ptr), C.byref(nb)), 'arp_shard_pack_face')
+        return int(ptr.value), int(nb.value)
+
+    def shard_assemble(self, left, right, n_res_global):
+        """``left`` / ``right``: (device pointer, bytes) of the halo buffers received from the neighbours, or None."""
+        lp, lb = left[:2] if left else (0, 0)       # (a third element — the owner of the memory — is the caller's business)
+        rp, rb = right[:2] if right else (0, 0)
+        counts = np.zeros(3, np.int64)
+        self._check(self._L.arp_shard_assemble(self._h, int(lp), int(lb), int(rp), int(rb), int(n_res_global), _p(counts)), 'arp_shard_assemble')
+        self.n, self.n_rings, self.n_amides = int(counts[0]), int(counts[1]), int(counts[2])
+        return counts
+
+    def shard_layout(self):
+        out = dict(global_id=np.empty(self.n, np.int32), origin=np.empty(self.n, np.int8), sel=np.empty(self.n, np.uint8),
+                   ring_gid=np.empty(self.n_rings, np.int32), ring_origin=np.empty(self.n_rings, np.int8),
+                   amide_gid=np.empty(self.n_amides, np.int32), amide_origin=np.empty(self.n_amides, np.int8))
+        self._check(self._L.arp_shard_layout(self._h, *[_p(out[k]) for k in ('global_id', 'origin', 'sel', 'ring_gid', 'ring_origin',
+                                                                              'amide_gid', 'amide_origin')]), 'arp_shard_layout')
+        return out
 
     def set_ownership(self, is_home=None, global_id=None):
         home = None if is_home is None else np.ascontiguousarray(is_home, np.uint8)

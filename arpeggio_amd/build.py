@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libarpeggio_hip.so')
 SOURCES = ['arp_api.hip']
-HEADERS = ['arp_numerics.h', 'arp_grid.h', 'arp_pairs.h', 'arp_planes.h']
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h'))
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
          '-Wall', '-Wno-unused-function']
 

@@ -22,6 +22,7 @@
 #include "arp_planes.h"
 #include "arp_prepare.h"
 #include "arp_json.h"
+#include "arp_shard.h"
 
 namespace {
 
@@ -188,6 +189,16 @@ struct arp_ctx {
     int64_t blob_nbond = 0, blob_nh = 0, blob_nrad = 0;
     bool validate_on_device = false;   // blob uploads: k_prepare_static checks what the classic setters check on the host
     DevBuf<int> blob_sb_nbr;
+    uint64_t blob_bytes = 0;       // size of the resident blob (0: the structure came through the classic setters)
+    // ---- sharded structures assembled on the device (arp_shard_*)
+    DevBuf<uint8_t> rec_home, rec_face[2];
+    arp_rec_header rec_home_hdr;
+    bool has_rec_home = false;
+    DevBuf<int> sh_scan;           // flags / counts and their exclusive scans
+    DevBuf<int2> sh_src;
+    DevBuf<int8_t> origin, ring_origin, am_origin;
+    DevBuf<uint8_t> sh_sel;
+    bool shard_resident = false;
     DevBuf<uint8_t> res_tag;       // [0, nres) = selection residues, [nres, 2 nres) = selection_plus residues
     int res_tag_value = 0;
     bool fuse_sets = false;        // the contact-grid build of the current pass also makes the residue / ring / amide sets
@@ -1112,6 +1123,8 @@ void arp_destroy(arp_ctx* c) {
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release(); c->longest_bond.release();
+    c->rec_home.release(); c->rec_face[0].release(); c->rec_face[1].release(); c->sh_scan.release(); c->sh_src.release();
+    c->origin.release(); c->ring_origin.release(); c->am_origin.release(); c->sh_sel.release();
     for (auto& l : c->plist) l.release();
     c->plist_count.release();   // (views into the blob were released above: no-ops)
     c->ring_home.release(); c->am_home.release(); c->ring_gid.release(); c->am_gid.release();
@@ -1134,6 +1147,8 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     if (n > 0 && (!xyz || !vdw || !cov || !type_mask || !flags || !res_id)) FAIL(c, ARP_E_ARG, "arp_set_atoms: null input");
     // the grids are sized from the bounding box: a NaN / inf coordinate has no cell
     if (!all_finite(xyz, 3 * n)) FAIL(c, ARP_E_ARG, "arp_set_atoms: non-finite coordinate");
+    c->blob_bytes = 0;           // the resident structure no longer is the blob that was uploaded / assembled
+    c->shard_resident = false;
     if (!all_finite(vdw, n) || !all_finite(cov, n)) FAIL(c, ARP_E_ARG, "arp_set_atoms: non-finite radius");
     int64_t max_res = -1;
     for (int64_t i = 0; i < n; ++i) {
@@ -1361,10 +1376,9 @@ int arp_blob_layout(void* blob, uint64_t bytes, int64_t n, int64_t nres, int64_t
     return ARP_OK;
 }
 
-int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
-    if (!c || !blob || bytes < sizeof(arp_blob_header)) return ARP_E_ARG;
-    arp_blob_header h;
-    memcpy(&h, blob, sizeof(h));
+namespace {
+// header of a blob: counts, size and offsets as arp_blob_layout writes them, finite boxes
+int check_blob_header(arp_ctx* c, const arp_blob_header& h, uint64_t bytes) {
     if (h.magic != ARP_BLOB_MAGIC) FAIL(c, ARP_E_ARG, "arp_set_blob: bad magic");
     BlobSizes z;
     if (!blob_sizes(h.n, h.nres, h.nbond, h.nh, h.nring, h.namide, z)) FAIL(c, ARP_E_ARG, "arp_set_blob: counts out of range");
@@ -1385,9 +1399,11 @@ int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
                         std::isfinite(h.amide_hi[k]) && h.amide_lo[k] <= h.amide_hi[k];
         if (!ok) FAIL(c, ARP_E_ARG, "arp_set_blob: bad bounding box");
     }
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, c->blob_dev.reserve((size_t)h.bytes));
-    HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, blob, (size_t)h.bytes, hipMemcpyHostToDevice, c->stream));
+    return ARP_OK;
+}
+
+// the input arrays of the context become views into c->blob_dev (which holds, or is about to hold, a blob with header h)
+void borrow_blob_views(arp_ctx* c, const arp_blob_header& h) {
     uint8_t* const d = c->blob_dev.p;
     const size_t n1 = (size_t)std::max<int64_t>(h.n, 1);
     c->xyz.borrow(d + h.off[0], n1); c->rad.borrow(d + h.off[1], n1); c->tmask.borrow(d + h.off[2], n1);
@@ -1405,14 +1421,19 @@ int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
     c->n = h.n; c->nres = h.nres; c->nring = h.nring; c->namide = h.namide;
     c->has_res = true;
     c->blob_nbond = h.nbond; c->blob_nh = h.nh; c->blob_nrad = h.n_rad;
-    c->max_res_id = h.nres - 1; c->max_ring_res = h.nres - 1; c->max_amide_res = h.nres - 1;   // (ranges verified on the device below)
+    c->blob_bytes = h.bytes;
+    c->max_res_id = h.nres - 1; c->max_ring_res = h.nres - 1; c->max_amide_res = h.nres - 1;   // (ranges verified on the device)
     for (int k = 0; k < 3; ++k) {
         c->lo[k] = h.lo[k]; c->hi[k] = h.hi[k];
         c->ring_lo[k] = h.ring_lo[k]; c->ring_hi[k] = h.ring_hi[k];
         c->am_lo[k] = h.amide_lo[k]; c->am_hi[k] = h.amide_hi[k];
     }
     c->h_xyz.clear();
-    // device-side validation (what arp_set_atoms ... check on the host), result in the pinned completion area
+}
+
+// Device-side validation of the resident blob (what arp_set_atoms ... check on the host) + the bookkeeping of a new
+// structure.  Waits for the stream.  `also` = further device error words OR-ed in (shard assembly), may be null.
+int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr) {
     int* const d_err = (int*)(c->d_ctr + C_ERR);
     c->ctr_zero_ok = false;
     HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(u64), c->stream));
@@ -1430,30 +1451,328 @@ int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
     const int64_t work = std::max({h.n, h.nbond, 3 * h.nh, h.nring, h.namide, h.nres, (int64_t)1});
     hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256)), dim3(256), 0, c->stream, bc);
     CHK(check_launch(c, "k_validate_blob"));
-    // the float32 box must really contain the float coordinates: the check above used it; the grids use the double one,
-    // which is at least as wide
-    int h_err = 0;
-    HIPCHK(c, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int h_err[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(&h_err[0], d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (also) HIPCHK(c, hipMemcpyAsync(&h_err[1], also, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // single-bond neighbour coordinates, ring / amide masks, bookkeeping: as the classic setters leave them
+    const size_t n1 = (size_t)std::max<int64_t>(h.n, 1);
     HIPCHK(c, c->sb.reserve(n1));
     HIPCHK(c, c->ring_sel.reserve((size_t)std::max<int64_t>(h.nring, 1))); HIPCHK(c, c->ring_plus.reserve((size_t)std::max<int64_t>(h.nring, 1)));
     HIPCHK(c, c->am_sel.reserve((size_t)std::max<int64_t>(h.namide, 1))); HIPCHK(c, c->am_plus.reserve((size_t)std::max<int64_t>(h.namide, 1)));
     c->static_dirty = true;
+    c->lists_dirty = true;
     c->has_gid = c->has_home = c->has_group_owner = false;
+    c->shard_resident = false;
     c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
     c->contacts_valid = false;
     c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
-    if (h_err != 0) {
+    if (h_err[0] != 0 || h_err[1] != 0) {
         c->n = c->nres = c->nring = c->namide = 0;   // nothing usable is resident
-        FAIL(c, ARP_E_ARG, "arp_set_blob: the structure failed validation (non-finite value, point outside its box, index out of range or "
-                           "offsets that are not a CSR)");
+        c->blob_bytes = 0;
+        c->err = std::string(who) + ": the structure failed validation (non-finite value, point outside its box, index out of range, "
+                                    "offsets that are not a CSR, or an item that occurs twice)";
+        return ARP_E_ARG;
     }
+    return ARP_OK;
+}
+}  // namespace
+
+int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
+    if (!c || !blob || bytes < sizeof(arp_blob_header)) return ARP_E_ARG;
+    arp_blob_header h;
+    memcpy(&h, blob, sizeof(h));
+    CHK(check_blob_header(c, h, bytes));
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->blob_dev.reserve((size_t)h.bytes));
+    HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, blob, (size_t)h.bytes, hipMemcpyHostToDevice, c->stream));
+    borrow_blob_views(c, h);
+    CHK(validate_resident_blob(c, h, "arp_set_blob"));
     if (h.n > 0) {
         hipLaunchKernelGGL(k_gather_neighbours, dim3(nblocks(h.n, 256)), dim3(256), 0, c->stream, (int)h.n, c->blob_sb_nbr.p, c->xyz.p, c->sb.p);
         CHK(check_launch(c, "k_gather_neighbours"));
     }
+    return ARP_OK;
+}
+
+int arp_get_blob(arp_ctx* c, void* host, uint64_t cap, uint64_t* bytes) {
+    if (!c || !bytes) return ARP_E_ARG;
+    if (c->blob_bytes == 0 || !c->blob_dev.p) FAIL(c, ARP_E_ARG, "arp_get_blob: the resident structure did not come from a blob");
+    *bytes = c->blob_bytes;
+    if (!host) return ARP_OK;
+    if (cap < c->blob_bytes) FAIL(c, ARP_E_CAPACITY, "arp_get_blob: buffer too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(host, c->blob_dev.p, (size_t)c->blob_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ARP_OK;
+}
+
+// ---- sharded structures assembled on the device ---------------------------------------------------------
+namespace {
+const uint64_t REC_ESIZE[5] = {sizeof(arp_rec_atom), 3 * sizeof(double), sizeof(int32_t), sizeof(arp_rec_ring), sizeof(arp_rec_amide)};
+bool rec_counts_ok(int64_t na, int64_t nh, int64_t nb, int64_t nring, int64_t namide) {
+    const int64_t lim = 0x7FFFFFF0LL / 3;
+    return na >= 0 && nh >= 0 && nb >= 0 && nring >= 0 && namide >= 0 && na <= lim && nh <= lim && nb <= 0x7FFFFFF0LL && nring <= lim &&
+           namide <= lim;
+}
+int check_rec_header(arp_ctx* c, const arp_rec_header& h, uint64_t bytes, const char* who) {
+    const std::string w(who);
+    if (h.magic != ARP_REC_MAGIC) FAIL(c, ARP_E_ARG, w + ": bad magic");
+    if (!rec_counts_ok(h.na, h.nh, h.nb, h.nring, h.namide)) FAIL(c, ARP_E_ARG, w + ": counts out of range");
+    if (h.bytes != arp_records_size(h.na, h.nh, h.nb, h.nring, h.namide) || h.bytes > bytes) FAIL(c, ARP_E_ARG, w + ": size does not match the counts");
+    const int64_t cnt[5] = {h.na, h.nh, h.nb, h.nring, h.namide};
+    uint64_t off = align16(sizeof(arp_rec_header));
+    for (int k = 0; k < 5; ++k) {
+        if (h.off[k] != off) FAIL(c, ARP_E_ARG, w + ": unexpected section offset");
+        off = align16(off + REC_ESIZE[k] * (uint64_t)cnt[k]);
+    }
+    if (h.n_rad < 0 || h.n_rad > RAD_TABLE) FAIL(c, ARP_E_ARG, w + ": n_rad out of range");
+    return ARP_OK;
+}
+RecList rec_list(const uint8_t* base, const arp_rec_header& h) {
+    RecList l;
+    l.a = (const arp_rec_atom*)(base + h.off[0]); l.h = (const double*)(base + h.off[1]); l.b = (const int*)(base + h.off[2]);
+    l.r = (const arp_rec_ring*)(base + h.off[3]); l.m = (const arp_rec_amide*)(base + h.off[4]);
+    l.na = (int)h.na; l.nh = (int)h.nh; l.nb = (int)h.nb; l.nr = (int)h.nring; l.nm = (int)h.namide;
+    return l;
+}
+RecList empty_rec_list() {
+    RecList l;
+    l.a = nullptr; l.h = nullptr; l.b = nullptr; l.r = nullptr; l.m = nullptr;
+    l.na = l.nh = l.nb = l.nr = l.nm = 0;
+    return l;
+}
+}  // namespace
+
+uint64_t arp_records_size(int64_t na, int64_t nh, int64_t nb, int64_t nring, int64_t namide) {
+    if (!rec_counts_ok(na, nh, nb, nring, namide)) return 0;
+    const int64_t cnt[5] = {na, nh, nb, nring, namide};
+    uint64_t off = align16(sizeof(arp_rec_header));
+    for (int k = 0; k < 5; ++k) off = align16(off + REC_ESIZE[k] * (uint64_t)cnt[k]);
+    return off;
+}
+
+int arp_records_layout(void* buf, uint64_t bytes, int64_t na, int64_t nh, int64_t nb, int64_t nring, int64_t namide) {
+    const uint64_t need = arp_records_size(na, nh, nb, nring, namide);
+    if (!buf || need == 0 || bytes < need) return ARP_E_ARG;
+    arp_rec_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = ARP_REC_MAGIC;
+    h.bytes = need;
+    h.na = na; h.nh = nh; h.nb = nb; h.nring = nring; h.namide = namide;
+    const int64_t cnt[5] = {na, nh, nb, nring, namide};
+    uint64_t off = align16(sizeof(arp_rec_header));
+    for (int k = 0; k < 5; ++k) {
+        h.off[k] = off;
+        off = align16(off + REC_ESIZE[k] * (uint64_t)cnt[k]);
+    }
+    memcpy(buf, &h, sizeof(h));
+    return ARP_OK;
+}
+
+int arp_shard_set_home(arp_ctx* c, const void* records, uint64_t bytes) {
+    if (!c || !records || bytes < sizeof(arp_rec_header)) return ARP_E_ARG;
+    arp_rec_header h;
+    memcpy(&h, records, sizeof(h));
+    CHK(check_rec_header(c, h, bytes, "arp_shard_set_home"));
+    {   // the CSR runs of the home records are read by the face kernels: check them here (the merge checks received buffers)
+        const arp_rec_atom* a = (const arp_rec_atom*)((const uint8_t*)records + h.off[0]);
+        for (int64_t i = 0; i < h.na; ++i) {
+            const bool ok = a[i].h_cnt >= 0 && a[i].bond_cnt >= 0 && a[i].h_start >= 0 && a[i].bond_start >= 0 &&
+                            (int64_t)a[i].h_start + a[i].h_cnt <= h.nh && (int64_t)a[i].bond_start + a[i].bond_cnt <= h.nb &&
+                            (i == 0 || a[i - 1].gid < a[i].gid);
+            if (!ok) FAIL(c, ARP_E_ARG, "arp_shard_set_home: atom records must ascend by gid and their runs must lie inside the sections");
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->rec_home.reserve((size_t)h.bytes));
+    HIPCHK(c, hipMemcpyAsync(c->rec_home.p, records, (size_t)h.bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rec_home_hdr = h;
+    c->has_rec_home = true;
+    return ARP_OK;
+}
+
+int arp_shard_pack_face(arp_ctx* c, int slot, double x_lo, double x_hi, uint64_t* device_ptr, uint64_t* out_bytes) {
+    if (!c || slot < 0 || slot > 1 || !device_ptr || !out_bytes || std::isnan(x_lo) || std::isnan(x_hi)) return ARP_E_ARG;
+    if (!c->has_rec_home) FAIL(c, ARP_E_ARG, "arp_shard_pack_face: call arp_shard_set_home first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const arp_rec_header& H = c->rec_home_hdr;
+    const RecList home = rec_list(c->rec_home.p, H);
+    // five flag / count arrays, each one longer than its set (the scans leave the totals there)
+    const size_t na = (size_t)H.na, nr = (size_t)H.nring, nm = (size_t)H.namide;
+    HIPCHK(c, c->sh_scan.reserve(3 * (na + 1) + (nr + 1) + (nm + 1)));
+    int* fa = c->sh_scan.p; int* fh = fa + na + 1; int* fb = fh + na + 1; int* fr = fb + na + 1; int* fm = fr + nr + 1;
+    hipLaunchKernelGGL(k_face_flags, dim3(nblocks((int64_t)std::max({na, nr, nm, (size_t)1}), 256)), dim3(256), 0, c->stream, home, x_lo, x_hi,
+                       fa, fh, fb, fr, fm);
+    ScanSegs S;
+    S.p[0] = fa; S.p[1] = fh; S.p[2] = fb; S.p[3] = fr; S.p[4] = fm;
+    S.n[0] = S.n[1] = S.n[2] = (int)na; S.n[3] = (int)nr; S.n[4] = (int)nm;
+    hipLaunchKernelGGL(k_scan_segments, dim3(5), dim3(1024), 0, c->stream, S);
+    CHK(check_launch(c, "k_face_flags / k_scan_segments"));
+    int tot[5];
+    const int* last[5] = {fa + na, fh + na, fb + na, fr + nr, fm + nm};
+    for (int k = 0; k < 5; ++k) HIPCHK(c, hipMemcpyAsync(&tot[k], last[k], sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t bytes = arp_records_size(tot[0], tot[1], tot[2], tot[3], tot[4]);
+    if (bytes == 0) FAIL(c, ARP_E_ARG, "arp_shard_pack_face: counts out of range");
+    std::vector<uint8_t> hb(sizeof(arp_rec_header));
+    arp_records_layout(hb.data(), bytes, tot[0], tot[1], tot[2], tot[3], tot[4]);
+    arp_rec_header F;
+    memcpy(&F, hb.data(), sizeof(F));
+    // any box that contains the points will do: the home boxes, clipped to the x range that was asked for
+    for (int k = 0; k < 3; ++k) {
+        F.lo[k] = H.lo[k]; F.hi[k] = H.hi[k]; F.ring_lo[k] = H.ring_lo[k]; F.ring_hi[k] = H.ring_hi[k];
+        F.amide_lo[k] = H.amide_lo[k]; F.amide_hi[k] = H.amide_hi[k];
+    }
+    auto clip = [&](double& lo, double& hi) {
+        const double l = std::max(lo, x_lo), u = std::min(hi, x_hi);
+        if (l <= u) { lo = l; hi = u; }    // (an empty face keeps the home box; its points are none)
+    };
+    clip(F.lo[0], F.hi[0]); clip(F.ring_lo[0], F.ring_hi[0]); clip(F.amide_lo[0], F.amide_hi[0]);
+    F.n_rad = H.n_rad;
+    memcpy(F.rad_tab, H.rad_tab, sizeof(F.rad_tab));
+    DevBuf<uint8_t>& out = c->rec_face[slot];
+    HIPCHK(c, out.reserve((size_t)bytes));
+    HIPCHK(c, hipMemsetAsync(out.p, 0, (size_t)bytes, c->stream));         // alignment gaps travel too: keep them defined
+    HIPCHK(c, hipMemcpyAsync(out.p, &F, sizeof(F), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_face_write, dim3(nblocks((int64_t)std::max({na, nr, nm, (size_t)1}), 256)), dim3(256), 0, c->stream, home, fa, fh, fb, fr,
+                       fm, (arp_rec_atom*)(out.p + F.off[0]), (double*)(out.p + F.off[1]), (int*)(out.p + F.off[2]),
+                       (arp_rec_ring*)(out.p + F.off[3]), (arp_rec_amide*)(out.p + F.off[4]));
+    CHK(check_launch(c, "k_face_write"));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // the caller hands the buffer to another stream (RCCL)
+    *device_ptr = (uint64_t)(uintptr_t)out.p;
+    *out_bytes = bytes;
+    return ARP_OK;
+}
+
+int arp_shard_assemble(arp_ctx* c, uint64_t dev_left, uint64_t bytes_left, uint64_t dev_right, uint64_t bytes_right, int64_t nres_global,
+                       int64_t counts[3]) {
+    if (!c || nres_global < 0) return ARP_E_ARG;
+    if (!c->has_rec_home) FAIL(c, ARP_E_ARG, "arp_shard_assemble: call arp_shard_set_home first");
+    HIPCHK(c, hipSetDevice(c->device));
+    arp_rec_header hd[3];
+    hd[0] = c->rec_home_hdr;
+    const uint8_t* base[3] = {c->rec_home.p, (const uint8_t*)(uintptr_t)dev_left, (const uint8_t*)(uintptr_t)dev_right};
+    const uint64_t given[3] = {hd[0].bytes, bytes_left, bytes_right};
+    RecLists L;
+    L.l[0] = rec_list(base[0], hd[0]);
+    for (int s = 1; s < 3; ++s) {
+        if (!base[s]) { L.l[s] = empty_rec_list(); memset(&hd[s], 0, sizeof(hd[s])); continue; }
+        if (given[s] < sizeof(arp_rec_header)) FAIL(c, ARP_E_ARG, "arp_shard_assemble: halo buffer shorter than its header");
+        HIPCHK(c, hipMemcpyAsync(&hd[s], base[s], sizeof(arp_rec_header), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 1; s < 3; ++s)
+        if (base[s]) {
+            CHK(check_rec_header(c, hd[s], given[s], "arp_shard_assemble"));
+            L.l[s] = rec_list(base[s], hd[s]);
+        }
+    const int64_t n = hd[0].na + hd[1].na + hd[2].na, nh = hd[0].nh + hd[1].nh + hd[2].nh;
+    const int64_t nring = hd[0].nring + hd[1].nring + hd[2].nring, namide = hd[0].namide + hd[1].namide + hd[2].namide;
+    if (!rec_counts_ok(n, nh, 0, nring, namide)) FAIL(c, ARP_E_ARG, "arp_shard_assemble: merged counts out of range");
+    if (n > 0 && nres_global <= 0) FAIL(c, ARP_E_ARG, "arp_shard_assemble: atoms without a residue table");
+    // positions, hydrogen and local-bond counts, their scans
+    HIPCHK(c, c->sh_scan.reserve(2 * ((size_t)n + 1) + 4));
+    HIPCHK(c, c->sh_src.reserve((size_t)std::max<int64_t>(n, 1)));
+    int* hoff = c->sh_scan.p; int* boff = hoff + n + 1; int* d_err = boff + n + 1;
+    HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_merge_positions, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, L, c->sh_src.p, hoff, boff, d_err);
+        CHK(check_launch(c, "k_merge_positions"));
+    }
+    ScanSegs S;
+    memset(&S, 0, sizeof(S));
+    S.p[0] = hoff; S.p[1] = boff; S.n[0] = S.n[1] = (int)n;
+    hipLaunchKernelGGL(k_scan_segments, dim3(2), dim3(1024), 0, c->stream, S);
+    CHK(check_launch(c, "k_scan_segments"));
+    int tot[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(&tot[0], hoff + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&tot[1], boff + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&tot[2], d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (tot[2] != 0 || tot[0] != nh)
+        FAIL(c, ARP_E_ARG, "arp_shard_assemble: an atom occurs twice in home + halos, a list is not ascending, or a record's runs leave its sections");
+    const int64_t nbond = tot[1];
+    // the blob the merged structure lives in
+    const uint64_t bytes = arp_blob_size(n, nres_global, nbond, nh, nring, namide);
+    if (bytes == 0) FAIL(c, ARP_E_ARG, "arp_shard_assemble: merged counts out of range");
+    std::vector<uint8_t> hb(sizeof(arp_blob_header));
+    arp_blob_layout(hb.data(), bytes, n, nres_global, nbond, nh, nring, namide);
+    arp_blob_header B;
+    memcpy(&B, hb.data(), sizeof(B));
+    auto merge_box = [&](double* lo, double* hi, int which) {
+        bool any = false;
+        for (int s = 0; s < 3; ++s) {
+            const int64_t cnt = which == 0 ? hd[s].na : (which == 1 ? hd[s].nring : hd[s].namide);
+            if (cnt == 0) continue;
+            const double* l = which == 0 ? hd[s].lo : (which == 1 ? hd[s].ring_lo : hd[s].amide_lo);
+            const double* u = which == 0 ? hd[s].hi : (which == 1 ? hd[s].ring_hi : hd[s].amide_hi);
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = any ? std::min(lo[k], l[k]) : l[k];
+                hi[k] = any ? std::max(hi[k], u[k]) : u[k];
+            }
+            any = true;
+        }
+        if (!any) for (int k = 0; k < 3; ++k) lo[k] = hi[k] = 0.0;
+    };
+    merge_box(B.lo, B.hi, 0); merge_box(B.ring_lo, B.ring_hi, 1); merge_box(B.amide_lo, B.amide_hi, 2);
+    B.n_rad = hd[0].n_rad;
+    CHK(check_blob_header(c, B, bytes));
+    HIPCHK(c, c->blob_dev.reserve((size_t)bytes));
+    HIPCHK(c, hipMemsetAsync(c->blob_dev.p, 0, (size_t)bytes, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, &B, sizeof(B), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->blob_dev.p + B.off[20], hd[0].rad_tab, sizeof(double) * 2 * RAD_TABLE, hipMemcpyHostToDevice, c->stream));
+    borrow_blob_views(c, B);
+    const size_t n1 = (size_t)std::max<int64_t>(n, 1), r1 = (size_t)std::max<int64_t>(nring, 1), m1 = (size_t)std::max<int64_t>(namide, 1);
+    HIPCHK(c, c->sb.reserve(n1)); HIPCHK(c, c->gid.reserve(n1)); HIPCHK(c, c->home.reserve(n1)); HIPCHK(c, c->origin.reserve(n1));
+    HIPCHK(c, c->sh_sel.reserve(n1));
+    HIPCHK(c, c->ring_gid.reserve(r1)); HIPCHK(c, c->ring_home.reserve(r1)); HIPCHK(c, c->ring_origin.reserve(r1));
+    HIPCHK(c, c->am_gid.reserve(m1)); HIPCHK(c, c->am_home.reserve(m1)); HIPCHK(c, c->am_origin.reserve(m1));
+    if (nres_global > 0) {
+        hipLaunchKernelGGL(k_init_residues, dim3(nblocks(nres_global, 256)), dim3(256), 0, c->stream, (int)nres_global, c->res_flags.p,
+                           c->res_prev.p, c->res_next.p);
+        CHK(check_launch(c, "k_init_residues"));
+    }
+    MergeOut O;
+    O.n = (int)n; O.nres = (int)nres_global; O.n_rad = (int)B.n_rad;
+    O.xyz = c->xyz.p; O.rad = c->rad.p; O.tmask = c->tmask.p; O.flags = c->flags.p; O.res_id = c->res_id.p;
+    O.res_flags = c->res_flags.p; O.res_prev = c->res_prev.p; O.res_next = c->res_next.p;
+    O.bond_off = c->bond_off.p; O.bond_idx = c->bond_idx.p; O.h_off = c->h_off.p; O.h_xyz = c->h_xyz_d.p; O.sb_nbr = c->blob_sb_nbr.p;
+    O.rad_idx = c->rad_idx.p; O.rad_tab = c->rad_tab.p;
+    O.sb = c->sb.p; O.gid = c->gid.p; O.home = c->home.p; O.origin = c->origin.p; O.sel = c->sh_sel.p;
+    hipLaunchKernelGGL(k_merge_fill, dim3(nblocks(std::max<int64_t>(n, 1), 256)), dim3(256), 0, c->stream, L, O, c->sh_src.p, hoff, boff, d_err);
+    CHK(check_launch(c, "k_merge_fill"));
+    GroupOut G;
+    G.ring_c = c->ring_c.p; G.ring_n = c->ring_n.p; G.ring_res = c->ring_res.p; G.ring_gid = c->ring_gid.p; G.ring_home = c->ring_home.p;
+    G.ring_origin = c->ring_origin.p;
+    G.am_c = c->am_c.p; G.am_n = c->am_n.p; G.am_res = c->am_res.p; G.am_gid = c->am_gid.p; G.am_home = c->am_home.p; G.am_origin = c->am_origin.p;
+    if (nring + namide > 0) {
+        hipLaunchKernelGGL(k_merge_groups, dim3(nblocks(std::max(nring, namide), 256)), dim3(256), 0, c->stream, L, G, d_err);
+        CHK(check_launch(c, "k_merge_groups"));
+    }
+    CHK(validate_resident_blob(c, B, "arp_shard_assemble", d_err));     // waits; resets selection and ownership state
+    c->has_gid = c->has_home = true;
+    c->has_group_owner = true;
+    c->shard_resident = true;
+    if (counts) { counts[0] = n; counts[1] = nring; counts[2] = namide; }
+    return ARP_OK;
+}
+
+int arp_shard_layout(arp_ctx* c, int32_t* global_id, int8_t* origin, uint8_t* sel, int32_t* ring_gid, int8_t* ring_origin,
+                     int32_t* amide_gid, int8_t* amide_origin) {
+    if (!c) return ARP_E_ARG;
+    if (!c->shard_resident) FAIL(c, ARP_E_ARG, "arp_shard_layout: no structure assembled by arp_shard_assemble is resident");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(download_async(c, global_id, c->gid.p, (size_t)c->n));
+    CHK(download_async(c, origin, c->origin.p, (size_t)c->n));
+    CHK(download_async(c, sel, c->sh_sel.p, (size_t)c->n));
+    CHK(download_async(c, ring_gid, c->ring_gid.p, (size_t)c->nring));
+    CHK(download_async(c, ring_origin, c->ring_origin.p, (size_t)c->nring));
+    CHK(download_async(c, amide_gid, c->am_gid.p, (size_t)c->namide));
+    CHK(download_async(c, amide_origin, c->am_origin.p, (size_t)c->namide));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
 

@@ -49,6 +49,17 @@ def _single_bond_coords(pc: PackedComplex):
     return xyz, has.astype(np.uint8)
 
 
+def _runs(starts, counts) -> np.ndarray:
+    """Indices of the concatenated runs [starts[k], starts[k] + counts[k]) — the rows of a CSR section that belong to a
+    list of atoms, in the order of the list."""
+    counts = np.asarray(counts, np.int64)
+    total = int(counts.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    return np.repeat(np.asarray(starts, np.int64) - first, counts) + np.arange(total, dtype=np.int64)
+
+
 def pack_records(pc: PackedComplex, atom_ids, ring_ids, amide_ids, sel=None) -> Dict[str, np.ndarray]:
     """Self-contained records of the given atoms / rings / amides (ids = packed indices = global ids)."""
     a = np.asarray(atom_ids, np.int64)
@@ -58,8 +69,7 @@ def pack_records(pc: PackedComplex, atom_ids, ring_ids, amide_ids, sel=None) -> 
     res = pc.res_id[a]
     hc = (pc.h_off[a + 1] - pc.h_off[a]).astype(np.int32)
     bc = (pc.bond_off[a + 1] - pc.bond_off[a]).astype(np.int32)
-    h_idx = np.concatenate([np.arange(pc.h_off[i], pc.h_off[i + 1]) for i in a]) if a.size and hc.sum() else np.zeros(0, np.int64)
-    b_idx = np.concatenate([np.arange(pc.bond_off[i], pc.bond_off[i + 1]) for i in a]) if a.size and bc.sum() else np.zeros(0, np.int64)
+    h_idx, b_idx = _runs(pc.h_off[a], hc), _runs(pc.bond_off[a], bc)
     return {
         'gid': a.astype(np.int32), 'xyz': pc.xyz[a], 'vdw': pc.vdw[a], 'cov': pc.cov[a], 'tmask': pc.type_mask[a],
         'flags': pc.flags[a], 'res_gid': res.astype(np.int32), 'res_flags': pc.res_flags[res],
@@ -111,6 +121,14 @@ class Shard:
     send_right: Optional[np.ndarray] = None
     halo_ms: float = 0.0
     halo_bytes: int = 0
+    halo: float = 0.0                         # width the faces were cut with: no search radius of a run may exceed it
+
+
+def _check_radius(sh, cutoff, expand=6.0):
+    """A shard holds its neighbours' atoms up to ``halo`` beyond its faces: a run whose search radius is larger would
+    silently miss pairs across the faces."""
+    if sh is not None and getattr(sh, 'world', 1) > 1 and getattr(sh, 'halo', 0.0) > 0.0 and max(cutoff, expand) > sh.halo:
+        raise ValueError(f'search radius {max(cutoff, expand)} exceeds the halo width {sh.halo:.4f} this shard was cut with')
 
 
 def _lookup(sorted_keys: np.ndarray, q: np.ndarray) -> np.ndarray:
@@ -142,8 +160,7 @@ def assemble_shard(home: Dict[str, np.ndarray], halos: Dict[int, Dict[str, np.nd
     h_start = np.concatenate([[0], np.cumsum(rec['h_cnt'])])[:-1]
     b_start = np.concatenate([[0], np.cumsum(rec['bond_cnt'])])[:-1]
     h_cnt, b_cnt = rec['h_cnt'][order], rec['bond_cnt'][order]
-    h_sel = np.concatenate([np.arange(s, s + c) for s, c in zip(h_start[order], h_cnt)]) if h_cnt.sum() else np.zeros(0, np.int64)
-    b_sel = np.concatenate([np.arange(s, s + c) for s, c in zip(b_start[order], b_cnt)]) if b_cnt.sum() else np.zeros(0, np.int64)
+    h_sel, b_sel = _runs(h_start[order], h_cnt), _runs(b_start[order], b_cnt)
     h_xyz = rec['h_xyz'][h_sel.astype(np.int64)]
     bond_gid = rec['bond_gid'][b_sel.astype(np.int64)]
     # bonds: global partner id -> local index, partners that are not local cannot form a local pair
@@ -227,6 +244,7 @@ def make_shard_local(full: PackedComplex, rank: int, world: int, sel=None, cutof
             sends[side] = _face_sets(full, edges, a_own, r_own, m_own, rank, side, halo)[0]
     sh = assemble_shard(home, halos, full.n_residues, rank, world)
     sh.send_left, sh.send_right = sends.get(-1), sends.get(+1)
+    sh.halo = halo
     return sh
 
 
@@ -274,6 +292,116 @@ def make_shard_distributed(full: PackedComplex, rank: int, world: int, dist, dev
     sh.send_left, sh.send_right = sends.get(-1), sends.get(+1)
     sh.halo_ms = ms
     sh.halo_bytes = int(sum(v.size for v in payload.values()))
+    sh.halo = halo
+    return sh
+
+
+# ---------------------------------------------------------------------------------------------
+# the same on the device: the host only packs its HOME records; cutting the faces out, moving them (RCCL on device
+# pointers) and merging home + halos into the resident structure happen in HBM (arp_shard_* of the C ABI)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class DeviceShard:
+    """What the host keeps of a shard assembled on the device: the id maps (to translate results and to drive the
+    selection exchange); the structure itself is resident in the context."""
+    n_atoms: int
+    is_home: np.ndarray
+    global_id: np.ndarray
+    origin: np.ndarray
+    sel: np.ndarray
+    ring_home: np.ndarray
+    ring_gid: np.ndarray
+    amide_home: np.ndarray
+    amide_gid: np.ndarray
+    n_res_global: int
+    rank: int = 0
+    world: int = 1
+    send_left: Optional[np.ndarray] = None
+    send_right: Optional[np.ndarray] = None
+    halo: float = 0.0                 # width the faces were cut with: no search radius of a run may exceed it
+    halo_ms: float = 0.0
+    halo_bytes: int = 0
+
+
+class _DevAlias:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
+
+
+def exchange_device_buffers(dist, device, rank, world, payload):
+    """payload: side -> (device pointer, bytes) of the buffer for rank + side.  Returns side -> (pointer, bytes, tensor)
+    of what the neighbours sent; the tensor owns the memory.  Sizes first (one int64 each way), then the buffers, both
+    with grouped isend / irecv on device memory — RCCL over xGMI under the nccl backend."""
+    import torch
+    sides = [s for s in (-1, +1) if 0 <= rank + s < world]
+    lens_out = {s: torch.tensor([payload[s][1]], dtype=torch.int64, device=device) for s in sides}
+    lens_in = {s: torch.zeros(1, dtype=torch.int64, device=device) for s in sides}
+    ops = []
+    for s in sides:
+        ops.append(dist.P2POp(dist.isend, lens_out[s], rank + s))
+        ops.append(dist.P2POp(dist.irecv, lens_in[s], rank + s))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    out_t = {s: torch.as_tensor(_DevAlias(payload[s][0], payload[s][1]), device=device) for s in sides}
+    in_t = {s: torch.empty(int(lens_in[s].item()), dtype=torch.uint8, device=device) for s in sides}
+    ops = []
+    for s in sides:
+        ops.append(dist.P2POp(dist.isend, out_t[s], rank + s))
+        ops.append(dist.P2POp(dist.irecv, in_t[s], rank + s))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    torch.cuda.synchronize(device)
+    return {s: (int(in_t[s].data_ptr()), int(in_t[s].numel()), in_t[s]) for s in sides}
+
+
+def shard_home_to_device(ctx, full: PackedComplex, rank: int, world: int, sel=None, cutoff=5.0):
+    """Step 1 of the device assembly: this rank's home records to its GPU, the two face buffers cut out there.
+    Returns (faces: side -> (pointer, bytes), bookkeeping for ``finish_shard_on_device``)."""
+    halo = halo_width(cutoff)
+    edges, a_own, r_own, m_own = _partition(full, world, halo)
+    from . import _capi
+    home_ids = np.nonzero(a_own == rank)[0]
+    home = pack_records(full, home_ids, np.nonzero(r_own == rank)[0], np.nonzero(m_own == rank)[0], sel)
+    ctx.shard_set_home(_capi.pack_records_buffer(home))
+    faces, sends = {}, {}
+    hx = full.xyz[home_ids, 0].astype(np.float64)
+    for side in (-1, +1):
+        if 0 <= rank + side < world:
+            lo, hi = (-np.inf, edges[rank] + halo) if side < 0 else (edges[rank + 1] - halo, np.inf)
+            faces[side] = ctx.shard_pack_face(0 if side < 0 else 1, lo, hi)
+            sends[side] = home_ids[(hx >= lo) & (hx <= hi)]           # the same comparison the kernel makes
+    return faces, dict(sends=sends, halo=halo, n_res_global=full.n_residues, rank=rank, world=world)
+
+
+def finish_shard_on_device(ctx, received, book, whole_structure=False) -> DeviceShard:
+    """Step 3: merge home + received halos in HBM; ``received``: side -> (pointer, bytes[, owner])."""
+    ctx.shard_assemble(received.get(-1), received.get(+1), book['n_res_global'])
+    lay = ctx.shard_layout()
+    sel = lay['sel']
+    if whole_structure:
+        if not bool(np.all(sel)):
+            raise ValueError('whole_structure=True needs a shard whose selection mask is all ones')
+    else:
+        ctx.set_selection(sel)
+    ctx.set_whole_structure(whole_structure)
+    return DeviceShard(n_atoms=ctx.n, is_home=(lay['origin'] == 0).astype(np.uint8), global_id=lay['global_id'], origin=lay['origin'],
+                       sel=sel, ring_home=(lay['ring_origin'] == 0).astype(np.uint8), ring_gid=lay['ring_gid'],
+                       amide_home=(lay['amide_origin'] == 0).astype(np.uint8), amide_gid=lay['amide_gid'],
+                       n_res_global=book['n_res_global'], rank=book['rank'], world=book['world'],
+                       send_left=book['sends'].get(-1), send_right=book['sends'].get(+1), halo=book['halo'])
+
+
+def make_shard_device(ctx, full: PackedComplex, rank: int, world: int, dist, device, sel=None, cutoff=5.0,
+                      whole_structure=False) -> DeviceShard:
+    """``make_shard_distributed`` + ``upload_shard`` without the host in the data path: the halo records are cut out,
+    exchanged (RCCL) and merged on the GPUs."""
+    faces, book = shard_home_to_device(ctx, full, rank, world, sel, cutoff)
+    t0 = time.perf_counter()
+    received = exchange_device_buffers(dist, device, rank, world, faces) if world > 1 else {}
+    ms = (time.perf_counter() - t0) * 1e3
+    sh = finish_shard_on_device(ctx, received, book, whole_structure)
+    sh.halo_ms = ms
+    sh.halo_bytes = int(sum(v[1] for v in faces.values()))
     return sh
 
 
@@ -334,6 +462,7 @@ def upload_shard(ctx, sh: Shard, whole_structure: bool = False):
 
 def run_shard(ctx, sh: Shard, dist=None, device=None, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
     """run_arpeggio on one shard: local expansion, selection exchange, then the five bags (results stay in HBM)."""
+    _check_radius(sh, cutoff)
     local = ctx.make_selection(sh.sel)
     st = combine_selection(sh, local['plus'], dist, device)
     ctx.set_selection_state(st['sel'], st['plus'], st['ring_sel'], st['ring_plus'], st['amide_sel'], st['amide_plus'])
@@ -426,16 +555,19 @@ class DeviceExchange:
         self._sync()
 
 
-def run_shard_whole_structure(ctx, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
+def run_shard_whole_structure(ctx, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, sh=None):
     """run_arpeggio on one shard when NO selection was given (whole structure, I:1395): selection_plus and the residue
     sets are known without asking the neighbours (``Context.set_whole_structure``), so the pass is the single-GPU pass on
     the shard — owned atoms, rings and amides emit — and the only traffic between the ranks is the halo of records that
-    built the shard.  ``upload_shard(ctx, sh, whole_structure=True)`` prepares the context."""
+    built the shard.  ``upload_shard(ctx, sh, whole_structure=True)`` prepares the context; ``sh`` (optional) lets the
+    call refuse a cutoff wider than the halo."""
+    _check_radius(sh, cutoff)
     return ctx.run_launch(cutoff, vdw_comp, include_sequence_adjacent, 6.0)
 
 
 def run_shard_device(ctx, ex: DeviceExchange, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
     """run_arpeggio on one shard with the selection state combined on the device (three stages, two exchanges)."""
+    _check_radius(ex.sh, cutoff)
     ctx.run_stage(0, cutoff, vdw_comp, include_sequence_adjacent)
     ex.exchange_plus()
     ctx.run_stage(1, cutoff, vdw_comp, include_sequence_adjacent)

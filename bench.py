@@ -46,6 +46,7 @@ def parse():
                     help="config3: BASELINE configs[2] (the headline); standin: the 1tqn_h stand-in of configs[1] (5.9 k atoms incl. "
                          "explicit hydrogens, whole structure) on one GPU beside the CPU restatement")
     ap.add_argument('--inflight', type=int, default=3, help='contexts (host threads) of the extra several-structures-in-flight measurement; 1 = skip')
+    ap.add_argument('--host-halo', action='store_true', help='N > 1: pack / merge the halo records on the host (the round-1 path) instead of on the device')
     ap.add_argument('--staged-exchange', action='store_true',
                     help='N > 1: run the general three-stage protocol (selection_plus bits over P2P + residue-set all-reduce '
                          'every step) although the whole-structure selection of the benchmark does not need it')
@@ -98,7 +99,7 @@ def main():
 
     # ---------------- workload ----------------
     t0 = time.perf_counter()
-    halo_ms = 0.0
+    halo_ms, halo_bytes, shard_setup_ms = 0.0, 0, 0.0
     if world == 1:
         if args.workload == 'standin':
             pc = synth.proteinlike()
@@ -116,14 +117,24 @@ def main():
         full = synth.slab_config(args.atoms, world, seed=4)
         workload = (f'synthetic {args.atoms * world} atoms in {world} x-slabs of {args.atoms} '
                     f'(BASELINE configs[3]{"" if args.atoms * world == 2_000_000 else " family"}), one-cell halo over RCCL')
-        halo_note = 'records of the one-cell halo exchanged with grouped isend/irecv (RCCL)'
         # no fallback: if the exchange over RCCL fails, the run fails (a scaling figure must not be printed without it)
-        shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
-        halo_ms = shard.halo_ms
         ctx = _capi.Context(local_rank)
-        sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
+        t_sh = time.perf_counter()
+        if args.host_halo:
+            halo_note = 'records of the one-cell halo packed on the host, exchanged with grouped isend/irecv (RCCL), merged on the host'
+            shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
+            sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
+            n_local = shard.pc.n_atoms
+        else:
+            halo_note = ('home records uploaded once; the one-cell halo cut out on the device, exchanged with grouped isend/irecv on the '
+                         'device buffers (RCCL), merged into the resident structure on the device (arp_shard_*)')
+            shard = sharding.make_shard_device(ctx, full, rank, world, dist, comm_device, whole_structure=not args.staged_exchange)
+            n_local = shard.n_atoms
+        shard_setup_ms = (time.perf_counter() - t_sh) * 1e3
+        halo_ms, halo_bytes = shard.halo_ms, shard.halo_bytes
         n_local_home = int(shard.is_home.sum())
-        pc = shard.pc
+        import types
+        pc = types.SimpleNamespace(n_atoms=n_local)      # the rest of the script needs the atom count of the local structure only
     gen_s = time.perf_counter() - t0
 
     if world == 1:
@@ -502,7 +513,8 @@ def main():
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
         'launch_mode': 'four launches on one HIP stream (bin, scan+scatter, search, sift+ring/amide loops), the last one publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
-        'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange': (halo_note if world > 1 else None), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
+        'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2),
+        'halo_exchange': (halo_note if world > 1 else None), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'end_to_end': end_to_end,
         'end_to_end_ms_per_structure': (end_to_end or {}).get('ms_per_structure'),
         'get_contacts_ms': (end_to_end or {}).get('get_contacts_ms'),

@@ -391,6 +391,60 @@ uint64_t arp_stream_handle(arp_ctx* ctx);
  * blocks.  The stream must outlive the context or be reset with 0 first. */
 int arp_use_stream(arp_ctx* ctx, uint64_t stream);
 
+/* ---- sharded structures assembled on the device (no counterpart in the reference) ---------------
+ * One rank = one context.  The rank uploads the records of its HOME atoms / rings / amides once, the device cuts out
+ * the records its two neighbours need (the atoms within one halo width of the slab faces), the caller moves those
+ * buffers between the GPUs (RCCL isend / irecv on the device pointers), and the device merges home + received halos
+ * into the resident structure: sorted by global id, CSR sections rebuilt, bonded global ids turned into local indices
+ * (partners that are not local are dropped), residue table filled, ownership (arp_set_ownership /
+ * arp_set_group_ownership) and single-bond-neighbour coordinates set.  Nothing of this goes through host memory; the
+ * host sees five counters per buffer.
+ *
+ * A record buffer = arp_rec_header, then the sections at header.off[] (16-byte aligned): atoms (arp_rec_atom, ascending
+ * gid), hydrogen coordinates (double[3] each; an atom's run starts at h_start), bonded GLOBAL ids (int32; bond_start),
+ * rings (arp_rec_ring, ascending gid), amides (arp_rec_amide, ascending gid).  Residue ids are global. */
+#define ARP_REC_MAGIC 0x3143455250524141ull   /* "AARPREC1" */
+typedef struct arp_rec_header {
+    uint64_t magic, bytes;
+    int64_t na, nh, nb, nring, namide, n_rad;
+    uint64_t off[5];
+    double lo[3], hi[3], ring_lo[3], ring_hi[3], amide_lo[3], amide_hi[3];   /* boxes that contain the points (any such box) */
+    double rad_tab[512];            /* n_rad distinct {vdw, cov} pairs of the sender's home atoms */
+} arp_rec_header;
+typedef struct arp_rec_atom {       /* 96 bytes */
+    float x, y, z; int32_t gid;
+    double vdw, cov;
+    float sb_x, sb_y, sb_z; int32_t sb_has;      /* coordinates of the single-bond heavy neighbour (U:340-359) */
+    int32_t res_gid, res_prev, res_next; uint16_t tmask, flags;
+    int32_t h_start, h_cnt, bond_start, bond_cnt;
+    uint8_t res_flags, sel, pad[14];
+} arp_rec_atom;
+typedef struct arp_rec_ring { double c[3], n[3]; int32_t gid, res, pad[2]; } arp_rec_ring;      /* 64 bytes */
+typedef struct arp_rec_amide { float c[3], n[3]; int32_t gid, res; } arp_rec_amide;            /* 32 bytes */
+/* host-only helpers: size of a record buffer, and header (magic, counts, offsets) written at its start */
+uint64_t arp_records_size(int64_t na, int64_t nh, int64_t nb, int64_t nring, int64_t namide);
+int arp_records_layout(void* buf, uint64_t bytes, int64_t na, int64_t nh, int64_t nb, int64_t nring, int64_t namide);
+/* Upload the home records (one asynchronous copy; the buffer may be reused when the call returns). */
+int arp_shard_set_home(arp_ctx* ctx, const void* records, uint64_t bytes);
+/* Records of the home atoms with x_lo <= x <= x_hi (float64 comparison; rings and amides by their centre), packed on
+ * the device into a buffer the context owns until the next call with the same `slot` (0 or 1).  The order of the home
+ * records is kept.  *device_ptr / *out_bytes: what to send. */
+int arp_shard_pack_face(arp_ctx* ctx, int slot, double x_lo, double x_hi, uint64_t* device_ptr, uint64_t* out_bytes);
+/* Merge the home records with the record buffers received from the left / right neighbour (DEVICE pointers, 0 = no
+ * neighbour on that side) and make the result the resident structure of the context (as arp_set_blob would: selection
+ * reset to the whole structure).  nres_global = rows of the global residue table.  counts: atoms, rings, amides.
+ * ARP_E_ARG when an atom, ring or amide occurs twice. */
+int arp_shard_assemble(arp_ctx* ctx, uint64_t dev_left, uint64_t bytes_left, uint64_t dev_right, uint64_t bytes_right,
+                       int64_t nres_global, int64_t counts[3]);
+/* What the caller needs to map results back and to exchange selection bits: global id, origin (0 home, -1 / +1 received
+ * from the left / right) and selection bit of every local atom; global id and origin of every ring and amide.  Any
+ * pointer may be NULL. */
+int arp_shard_layout(arp_ctx* ctx, int32_t* global_id, int8_t* origin, uint8_t* sel, int32_t* ring_gid, int8_t* ring_origin,
+                     int32_t* amide_gid, int8_t* amide_origin);
+/* Read back the resident structure in blob form (arp_blob_header + arrays) when it came from arp_set_blob or
+ * arp_shard_assemble: *bytes = size; copies when cap suffices (host may be NULL to ask for the size). */
+int arp_get_blob(arp_ctx* ctx, void* host, uint64_t cap, uint64_t* bytes);
+
 /* ---- JSON output (host only; no context, no GPU) ------------------------------------------
  * The reference's CLI ends with json.dump(get_contacts(), fh, indent=4, sort_keys=True) (scripts/process_protein_cli.py:
  * 184-188; records of I:172-212).  This writes the same bytes for the atom-atom records straight from the result arrays

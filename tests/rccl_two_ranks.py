@@ -21,10 +21,14 @@ def main():
     from arpeggio_amd import _capi, sharding, synth
     full = synth.slab_config(30_000, world, seed=4)
     sel = (full.res_id % 9 == 2).astype(np.uint8)
-    for mode in ('whole', 'staged'):
-        shard = sharding.make_shard_distributed(full, rank, world, dist, device=dev, sel=None if mode == 'whole' else sel)
+    for mode, assembly in (('whole', 'device'), ('staged', 'device'), ('whole', 'host'), ('staged', 'host')):
         ctx = _capi.Context(local)
-        sharding.upload_shard(ctx, shard, whole_structure=(mode == 'whole'))
+        if assembly == 'device':    # halo records cut out, exchanged (RCCL on device pointers) and merged in HBM
+            shard = sharding.make_shard_device(ctx, full, rank, world, dist, dev, sel=None if mode == 'whole' else sel,
+                                               whole_structure=(mode == 'whole'))
+        else:                       # the same through host buffers
+            shard = sharding.make_shard_distributed(full, rank, world, dist, device=dev, sel=None if mode == 'whole' else sel)
+            sharding.upload_shard(ctx, shard, whole_structure=(mode == 'whole'))
         if mode == 'whole':
             counts = sharding.run_shard_whole_structure(ctx)
         else:
@@ -49,7 +53,7 @@ def main():
             c1 = one.run_launch()
             ref = one.atom_contacts_fetch(c1['atom_atom'])
             want = ref['i'].astype(np.int64) * full.n_atoms + ref['j']
-            assert np.array_equal(union, want), (mode, len(union), len(want))
+            assert np.array_equal(union, want), (mode, assembly, len(union), len(want))
             one.close()
         ctx.close()
         dist.barrier()

@@ -1,0 +1,175 @@
+"""Shards assembled on the device (arp_shard_set_home / _pack_face / _assemble) against the host-side assembly.
+
+One GPU, one context per rank: the face buffers a rank cuts out are handed to its neighbours' contexts as device
+pointers — exactly what RCCL delivers in ``sharding.make_shard_device`` — so the whole data path of the multi-GPU set-up
+runs here except the transport."""
+import numpy as np
+import pytest
+
+from arpeggio_amd import sharding, synth
+
+pytestmark = pytest.mark.gpu
+
+@pytest.fixture(scope='module')
+def capi():
+    from arpeggio_amd import _capi
+    return _capi
+
+
+NAMES = ('plane_plane', 'atom_plane', 'group_group', 'group_plane')
+
+
+def _structures():
+    rng = np.random.default_rng(11)
+    slab = synth.slab_config(5000, 3, seed=8)                       # rings, amides, bonds, single-bond neighbours
+    sel = np.zeros(slab.n_atoms, np.uint8)
+    sel[np.isin(slab.res_id, rng.choice(slab.n_residues, slab.n_residues // 12, replace=False))] = 1
+    prot = synth.proteinlike(n_res=400, n_waters=150, seed=5)       # explicit hydrogens (h_xyz runs), real bond graph
+    return [('slabs', slab, None), ('slabs_sel', slab, sel), ('proteinlike', prot, None)]
+
+
+def _assemble_all(capi, full, world, sel, whole):
+    ctxs = [capi.Context(0) for _ in range(world)]
+    step1 = [sharding.shard_home_to_device(c, full, r, world, sel) for r, c in enumerate(ctxs)]
+    shards = []
+    for r, c in enumerate(ctxs):
+        received = {}
+        if r > 0:
+            received[-1] = step1[r - 1][0][+1]          # what the left neighbour cut out for its right side
+        if r + 1 < world:
+            received[+1] = step1[r + 1][0][-1]
+        shards.append(sharding.finish_shard_on_device(c, received, step1[r][1], whole_structure=whole))
+    return ctxs, shards
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_device_assembled_shard_equals_host_assembled(capi, world):
+    for name, full, sel in _structures():
+        if name == 'proteinlike' and world == 3:
+            continue                                     # slabs thinner than the halo
+        try:
+            sharding._partition(full, world, sharding.halo_width())
+        except ValueError:
+            continue
+        ctxs, shards = _assemble_all(capi, full, world, sel, whole=sel is None)
+        ref = capi.Context(0)
+        for r, (c, ds) in enumerate(zip(ctxs, shards)):
+            hs = sharding.make_shard_local(full, r, world, sel)
+            # id maps
+            assert np.array_equal(ds.global_id, hs.global_id) and np.array_equal(ds.origin, hs.origin), (name, r)
+            assert np.array_equal(ds.is_home, hs.is_home) and np.array_equal(ds.sel, hs.sel)
+            assert np.array_equal(ds.ring_gid, hs.ring_gid) and np.array_equal(ds.ring_home, hs.ring_home)
+            assert np.array_equal(ds.amide_gid, hs.amide_gid) and np.array_equal(ds.amide_home, hs.amide_home)
+            assert np.array_equal(ds.send_left if ds.send_left is not None else [], hs.send_left if hs.send_left is not None else [])
+            assert np.array_equal(ds.send_right if ds.send_right is not None else [], hs.send_right if hs.send_right is not None else [])
+            assert (ds.origin != 0).sum() > 0
+            # the resident arrays, read back
+            got = capi.unpack_blob(c.get_blob())
+            pc = hs.pc
+            assert np.array_equal(got['xyz'], pc.xyz) and np.array_equal(got['rad'][:, 0], pc.vdw) and np.array_equal(got['rad'][:, 1], pc.cov)
+            for k, want in (('type_mask', pc.type_mask), ('flags', pc.flags), ('res_id', pc.res_id), ('res_flags', pc.res_flags),
+                            ('res_prev', pc.res_prev), ('res_next', pc.res_next), ('bond_off', pc.bond_off), ('bond_idx', pc.bond_idx),
+                            ('h_off', pc.h_off), ('h_xyz', pc.h_xyz), ('ring_center', pc.ring_center), ('ring_normal', pc.ring_normal),
+                            ('ring_res', pc.ring_res), ('amide_center', pc.amide_center), ('amide_normal', pc.amide_normal),
+                            ('amide_res', pc.amide_res)):
+                assert np.array_equal(got[k], want), (name, r, k)
+            assert np.all(got['sb_nbr'] == -1)
+            idx = got['rad_idx']
+            known = idx != 0xFFFF
+            assert known.mean() > 0.99 and np.array_equal(got['rad_tab'][idx[known]], got['rad'][known])
+            hdr = got['header']
+            assert all(hdr.lo[k] <= pc.xyz[:, k].min() and hdr.hi[k] >= pc.xyz[:, k].max() for k in range(3))
+            # and what the pass makes of it
+            sharding.upload_shard(ref, hs, whole_structure=sel is None)
+            if sel is None:
+                n_dev, n_host = sharding.run_shard_whole_structure(c, sh=ds), sharding.run_shard_whole_structure(ref, sh=hs)
+            else:
+                n_dev, n_host = c.run_launch(), ref.run_launch()          # local expansion of the shard's selection bits
+            assert n_dev == n_host and n_dev['atom_atom'] > 100, (name, r, n_dev, n_host)
+            a, b = c.atom_contacts_fetch(n_dev['atom_atom']), ref.atom_contacts_fetch(n_host['atom_atom'])
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (name, r, k)
+            for bag in NAMES:
+                x, y = c.fetch_bag(bag), ref.fetch_bag(bag)
+                for k in x:
+                    assert np.array_equal(x[k], y[k], equal_nan=x[k].dtype.kind == 'f'), (name, r, bag, k)
+        for c in ctxs + [ref]:
+            c.close()
+
+
+def test_device_assembly_rejects_bad_buffers(capi):
+    full = synth.slab_config(2000, 2, seed=3)
+    c0, c1 = capi.Context(0), capi.Context(0)
+    f0, b0 = sharding.shard_home_to_device(c0, full, 0, 2)
+    f1, b1 = sharding.shard_home_to_device(c1, full, 1, 2)
+    with pytest.raises(Exception, match='twice|ascending'):
+        c0.shard_assemble(f1[-1], f1[-1], full.n_residues)            # the same halo on both sides: every atom twice
+    with pytest.raises(Exception):
+        c0.shard_assemble((f1[-1][0], 100), None, full.n_residues)    # truncated buffer
+    with pytest.raises(Exception):
+        c0.shard_assemble(f1[-1], None, 3)                            # residue ids beyond the table
+    with pytest.raises(Exception):
+        capi.Context(0).shard_pack_face(0, 0.0, 1.0)                  # no home records
+    ds = sharding.finish_shard_on_device(c0, {+1: f1[-1]}, b0, whole_structure=True)     # and the good call still works
+    assert ds.n_atoms > 2000 and sharding.run_shard_whole_structure(c0, sh=ds)['atom_atom'] > 0
+    with pytest.raises(ValueError, match='halo'):
+        sharding.run_shard_whole_structure(c0, cutoff=7.5, sh=ds)
+    c0.close(); c1.close()
+
+
+_TORCH_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+torch.cuda.set_device(0); torch.cuda.init()            # torch touches the device first (INTEGRATION.md)
+import torch.distributed as dist
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from arpeggio_amd import _capi, sharding, synth
+dev = torch.device('cuda', 0)
+full = synth.slab_config(4000, 2, seed=6)
+c = [_capi.Context(0), _capi.Context(0)]
+step1 = [sharding.shard_home_to_device(c[r], full, r, 2) for r in range(2)]
+
+def through_torch(pb):      # both ends of exchange_device_buffers without the wire: alias the face buffer, copy into a torch tensor
+    t = torch.as_tensor(sharding._DevAlias(pb[0], pb[1]), device=dev)
+    r = torch.empty(pb[1], dtype=torch.uint8, device=dev)
+    r.copy_(t)
+    torch.cuda.synchronize(dev)
+    return (int(r.data_ptr()), int(r.numel()), r)
+
+got = []
+for r in range(2):
+    recv = {+1: through_torch(step1[1][0][-1])} if r == 0 else {-1: through_torch(step1[0][0][+1])}
+    ds = sharding.finish_shard_on_device(c[r], recv, step1[r][1], whole_structure=True)
+    n = sharding.run_shard_whole_structure(c[r], sh=ds)
+    got.append(c[r].atom_contacts_fetch(n['atom_atom']))
+one = _capi.Context(0)
+one.set_complex(full)
+n1 = one.run_launch()
+ref = one.atom_contacts_fetch(n1['atom_atom'])
+key = lambda d: d['i'].astype(np.int64) * full.n_atoms + d['j']
+union = np.sort(np.concatenate([key(g) for g in got]))
+assert np.array_equal(union, key(ref)), (len(union), len(ref['i']))
+# world 1 through the whole driver: no neighbours, no faces, the shard is the structure
+c1 = _capi.Context(0)
+ds = sharding.make_shard_device(c1, full, 0, 1, dist, dev, whole_structure=True)
+assert ds.n_atoms == full.n_atoms and sharding.run_shard_whole_structure(c1, sh=ds) == n1
+dist.destroy_process_group()
+print('TORCH_ALIAS_OK')
+"""
+
+
+def test_face_buffers_through_torch_tensors(capi):
+    """The torch side of ``exchange_device_buffers``: face buffers aliased as torch tensors (``__cuda_array_interface__``),
+    received into torch-owned memory, handed to arp_shard_assemble by pointer.  Own process: torch must start first."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, '-c', _TORCH_SCRIPT % port], cwd=root, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert out.returncode == 0 and 'TORCH_ALIAS_OK' in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

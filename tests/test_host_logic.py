@@ -201,3 +201,25 @@ def test_native_json_writer_equals_json_dump(tmp_path):
         export.write_contacts_json(str(path), pc, b, pc.component_types)
         want = json.dumps(export.contacts_json(pc, b, pc.component_types), indent=4, sort_keys=True)
         assert open(path, encoding='utf-8').read() == want, case
+
+
+def test_record_buffer_layout_without_a_gpu():
+    """arp_records_size / arp_records_layout are host-only; the packer's structured dtypes are the C structs."""
+    from arpeggio_amd import _capi, sharding
+    pc = synth.proteinlike(n_res=40, n_waters=12)
+    ids = np.arange(5, pc.n_atoms, 3)
+    rec = sharding.pack_records(pc, ids, np.arange(pc.n_rings), np.arange(0, pc.n_amides, 2))
+    buf = _capi.pack_records_buffer(rec, pinned=False)
+    h = _capi.RecHeader.from_buffer_copy(buf[:ctypes.sizeof(_capi.RecHeader)].tobytes())
+    assert h.magic == 0x3143455250524141 and h.bytes == buf.nbytes and ctypes.sizeof(_capi.RecHeader) == 4344
+    assert (h.na, h.nh, h.nb, h.nring, h.namide) == (ids.size, rec['h_xyz'].shape[0], rec['bond_gid'].size, pc.n_rings, (pc.n_amides + 1) // 2)
+    offs = list(h.off)
+    assert all(o % 16 == 0 for o in offs) and offs == sorted(offs) and offs[0] >= ctypes.sizeof(_capi.RecHeader)
+    back = _capi.unpack_records_buffer(buf)
+    for k, v in rec.items():
+        assert np.array_equal(back[k], v), k
+    assert np.array_equal(back['h_start'][1:], np.cumsum(rec['h_cnt'])[:-1]) and back['h_start'][0] == 0
+    tab = np.array(h.rad_tab[:2 * h.n_rad]).reshape(-1, 2)
+    assert {(a, b) for a, b in zip(rec['vdw'], rec['cov'])} == {tuple(t) for t in tab}
+    L = _capi.load()
+    assert L.arp_records_size(-1, 0, 0, 0, 0) == 0 and L.arp_records_layout(None, 0, 1, 0, 0, 0, 0) != 0
