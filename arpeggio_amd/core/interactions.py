@@ -96,6 +96,12 @@ class InteractionComplex:
             self.initialize()
         pc, ctx = self.pc, self._ctx
         if pc.n_rings and pc.ring_atoms:
+            # the normal is a sum of cross products of CONSECUTIVE centre->atom vectors (OBRing::findCenterAndNormal walks
+            # the ring path): atoms listed in another order (e.g. file order CG, CD1, CD2, CE1, CE2, CZ) cancel to noise
+            bad = pc.rings_not_in_path_order()
+            if bad:
+                raise ValueError(f'ring_atoms of ring(s) {bad[:8]} are not in ring-path order (consecutive atoms are not bonded): '
+                                 'store the OpenBabel ring path, or keep the ring_center / ring_normal of the pack')
             pc.ring_center, pc.ring_normal = ctx.ring_geometry(pc.ring_atoms)
             if assign_ring_residues:
                 pc.ring_res, self.ring_residue_shortest_distance = ctx.ring_residues(pc.ring_center)

@@ -161,6 +161,26 @@ class PackedComplex:
                 raise ValueError(f'{what} out of range')
 
     # ---- string tables with defaults (synthetic packs carry none) ----
+    def rings_not_in_path_order(self):
+        """Indices of the rings whose ``ring_atoms`` form a cycle of the bond graph (every atom has two bonded partners in
+        the ring) but are not LISTED along it (some consecutive pair, the last and the first included, is not bonded).
+        Rings whose atoms are not bonded among themselves (packs without that part of the bond graph) cannot be judged and
+        are not reported."""
+        if not self.ring_atoms or self.bond_idx.shape[0] == 0:
+            return []
+        bad = []
+        for r, atoms in enumerate(self.ring_atoms):
+            a = [int(x) for x in atoms]
+            if len(a) < 3:
+                continue
+            members = set(a)
+            nbrs = {i: members.intersection(self.bond_idx[self.bond_off[i]:self.bond_off[i + 1]].tolist()) for i in a}
+            if any(len(v) < 2 for v in nbrs.values()):
+                continue
+            if any(a[(k + 1) % len(a)] not in nbrs[a[k]] for k in range(len(a))):
+                bad.append(r)
+        return bad
+
     def ensure_labels(self):
         n, nr = self.n_atoms, self.n_residues
         if self.res_name is None:

@@ -223,3 +223,16 @@ def test_record_buffer_layout_without_a_gpu():
     assert {(a, b) for a, b in zip(rec['vdw'], rec['cov'])} == {tuple(t) for t in tab}
     L = _capi.load()
     assert L.arp_records_size(-1, 0, 0, 0, 0) == 0 and L.arp_records_layout(None, 0, 1, 0, 0, 0, 0) != 0
+
+
+def test_rings_listed_off_their_path_are_reported():
+    """compute_plane_geometry sums cross products of consecutive ring atoms: a ring listed in another order must not be
+    accepted silently (PackedComplex.rings_not_in_path_order)."""
+    import copy
+    pc = synth.proteinlike(n_res=60, n_waters=10)
+    assert pc.n_rings > 0 and pc.rings_not_in_path_order() == []
+    q = copy.deepcopy(pc)
+    r = [int(x) for x in q.ring_atoms[0]]
+    q.ring_atoms[0] = np.array([r[0], r[2], r[1]] + r[3:], np.int32)
+    assert q.rings_not_in_path_order() == [0]
+    assert synth.config3(3000).rings_not_in_path_order() == []      # ring atoms without bonds among them: not judged
