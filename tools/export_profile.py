@@ -8,6 +8,13 @@ Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports 1/2 
 (16 B per lane) coalesced stream, so it is doubled; WRITE_SIZE is used as printed — it was calibrated here
 on k_sift, whose output is exactly 15 B per contact (18.76 MB expected, 18.9 MB counted).
 Both counters are printed by rocprofv3 in KiB.
+
+Gathers are different (tools/calibrate_pmc_gather.py, profiles/README.md): every 128-byte row of a 256 MiB table read
+once in random order shows FETCH_SIZE = 1.000 x the table, every 32-byte row 3.99 x — i.e. line fills are counted in
+full, only merged streaming requests are halved.  k_sift reads its atom records by gather (counted in full) and one
+coalesced stream, the pair list (8 B per pair, of which the counter shows half): its traffic is
+FETCH_SIZE + WRITE_SIZE + 4 B x pairs.  The figure of the guide's rule for everything, 2 x FETCH + WRITE, is kept
+beside it as `hbm_bytes_all_streams`.
 """
 import collections
 import csv
@@ -50,16 +57,29 @@ with open(f'profiles/{tag}_pmc_per_launch.csv', 'w', newline='') as f:
             w.writerow([k] + [v.get(c, '') for c in cols])
 avg_ns = {r['Name'].split('(')[0]: float(r['AverageNs']) for r in rows}
 traffic = {}
+n_pairs = None
+try:   # the bench line of the kernel-trace pass tells how many pairs one launch handled
+    line = [l for l in open(f'{base}/trace.log') if l.startswith('{')][-1]
+    n_pairs = int(json.loads(line)['pairs']['contacts_emitted'])
+except (OSError, IndexError, KeyError, ValueError):
+    pass
 for k, v in out.items():
     if k.startswith('__amd') or 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
         continue
     key = {'void k_search<0>': 'k_search', 'void k_search<2>': 'k_mark_search', 'k_sift_planes': 'k_sift'}.get(k, k)
-    traffic[key] = {'hbm_bytes_per_launch': int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024),
+    all_streams = int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024)
+    if key == 'k_sift' and n_pairs is not None:
+        hbm = int((v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 + 4 * n_pairs)
+        model = 'gathers counted in full + half of the 8 B/pair list stream added back'
+    else:
+        hbm, model = all_streams, 'coalesced streams: 2 x FETCH_SIZE + WRITE_SIZE'
+    traffic[key] = {'hbm_bytes_per_launch': hbm, 'hbm_bytes_all_streams': all_streams, 'model': model,
                     'fetch_kib_raw': v['FETCH_SIZE'], 'write_kib_raw': v['WRITE_SIZE'],
                     'valu_insts_per_launch': v.get('SQ_INSTS_VALU'),
                     'rocprof_avg_ns': avg_ns.get(k)}
 json.dump({'source': f'{tag} (tools/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes)',
-           'correction': 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream)',
+           'correction': 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream); k_sift: '
+                         'FETCH_SIZE + WRITE_SIZE + 4 B x pairs (line fills of gathers are counted in full: tools/calibrate_pmc_gather.py)',
            'kernels': traffic}, open('profiles/pmc_traffic.json', 'w'), indent=1)
 for k in ('k_search', 'k_sift', 'k_mark_search', 'k_scatter_atoms'):
     if k in traffic:
