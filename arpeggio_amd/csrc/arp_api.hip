@@ -152,6 +152,10 @@ struct arp_ctx {
     DevBuf<double2> rad_tab;      // RAD_TABLE distinct radius pairs of the structure
     DevBuf<int4> st_aux;
     DevBuf<float4> st_xyzm;
+    DevBuf<float4> sp_xyzm;       // the same columns in the spatial order of the structure (what the per-pass grid builds read)
+    DevBuf<int4> sp_aux, sp_q1;
+    DevBuf<int> sp_cnt;
+    DevBuf<int2> sp_cr;
     bool static_dirty = true;
     double host_enqueue_us = 0, host_wait_us = 0;   // arp_run_launch: time spent enqueueing / waiting (arp_get_host_times)
     int64_t host_passes = 0;
@@ -426,6 +430,21 @@ int ensure_static(arp_ctx* c) {
         hipLaunchKernelGGL(k_longest_bond, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->xyz.p, c->bond_off.p, c->bond_idx.p,
                            (unsigned int*)c->longest_bond.p);
         CHK(check_launch(c, "k_prepare_static"));
+        // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure
+        GridDesc d;
+        make_grid_desc(d, c->lo, c->hi, 6.0);
+        HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_q1.reserve((size_t)n));
+        HIPCHK(c, c->sp_cr.reserve((size_t)n));
+        HIPCHK(c, c->sp_cnt.reserve((size_t)d.ncell + 1));
+        HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, ((size_t)d.ncell + 1) * sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_static_bin, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->st_xyzm.p, d, c->sp_cnt.p, c->sp_cr.p);
+        ScanSegs S;
+        memset(&S, 0, sizeof(S));
+        S.p[0] = c->sp_cnt.p; S.n[0] = d.ncell;
+        hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, c->stream, S);
+        hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, c->sp_cnt.p, c->st_xyzm.p,
+                           c->st_aux.p, c->st_q1.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p);
+        CHK(check_launch(c, "k_static_permute"));
     }
     c->static_dirty = false;
     return ARP_OK;
@@ -433,9 +452,9 @@ int ensure_static(arp_ctx* c) {
 
 StaticAtoms static_atoms(arp_ctx* c) {
     StaticAtoms r;
-    r.xyzm = c->st_xyzm.p;
-    r.q1 = c->st_q1.p;
-    r.aux = c->st_aux.p;
+    r.xyzm = c->sp_xyzm.p;
+    r.q1 = c->sp_q1.p;
+    r.aux = c->sp_aux.p;
     r.sel = c->sel_made ? c->sel.p : nullptr;
     r.plus = c->sel_made ? c->plus.p : nullptr;
     r.all = (c->sel_made && c->sel_all) ? 1 : 0;
@@ -1119,6 +1138,7 @@ void arp_destroy(arp_ctx* c) {
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
     c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
+    c->sp_xyzm.release(); c->sp_aux.release(); c->sp_q1.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();

@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void k_gather_neighbours(int n, const int* __r
 }
 
 // Everything of an atom record that does not depend on the selection, composed once per structure and
-// kept as 16-byte columns so that the per-pass grid builds read them coalesced.
+// kept as 16-byte columns so that the per-pass grid builds read them coalesced.  The columns are held in a SPATIAL order
+// fixed once per structure (6 A cells, x fastest; k_static_bin / k_static_permute): row k is some atom whose local id is
+// aux[k].x, and the atoms of one wavefront lie in a handful of neighbouring cells whatever the cell size of the pass —
+// so the binning kernel can combine the histogram atomics of a wave (one per distinct cell instead of one per atom: the
+// memory-side atomic rate was its bound) and the scatter writes land next to each other.  sel / plus are by local id.
 struct StaticAtoms {
     const float4* xyzm;         // x, y, z, static meta
     const int4* aux;            // local id, residue, previous residue, next residue
@@ -212,17 +216,39 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
     }
 }
 
-// search record of atom i: static part + the selection bits of the moment
-__device__ __forceinline__ float4 compose_xyzm(const StaticAtoms& r, int i) {
+// search record of row i (local id lid): static part + the selection bits of the moment
+__device__ __forceinline__ float4 compose_xyzm(const StaticAtoms& r, int i, int lid) {
     float4 v = r.xyzm[i];
     uint32_t m = __float_as_uint(v.w);
     if (r.all) m |= M_SEL | M_PLUS;
     else {
-        if (r.sel && r.sel[i]) m |= M_SEL;
-        if (!r.plus || r.plus[i]) m |= M_PLUS;
+        if (r.sel && r.sel[lid]) m |= M_SEL;
+        if (!r.plus || r.plus[lid]) m |= M_PLUS;
     }
     v.w = __uint_as_float(m);
     return v;
+}
+
+// ---- the spatial order of the static columns (once per structure) ----
+__global__ __launch_bounds__(256) void k_static_bin(int n, const float4* __restrict__ st_xyzm, GridDesc g, int* __restrict__ cnt,
+                                                    int2* __restrict__ cr) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 v = st_xyzm[i];
+        const int c = cell_index(g, num::d3{(double)v.x, (double)v.y, (double)v.z});
+        cr[i] = make_int2(c, atomicAdd(&cnt[c], 1));
+    }
+}
+__global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __restrict__ cr, const int* __restrict__ start,
+                                                        const float4* __restrict__ st_xyzm, const int4* __restrict__ st_aux,
+                                                        const int4* __restrict__ st_q1, float4* __restrict__ sp_xyzm,
+                                                        int4* __restrict__ sp_aux, int4* __restrict__ sp_q1) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int2 c = cr[i];
+        const int pos = start[c.x] + c.y;
+        sp_xyzm[pos] = st_xyzm[i];
+        sp_aux[pos] = st_aux[i];
+        sp_q1[pos] = st_q1[i];
+    }
 }
 
 // Residue / ring / amide sets of _make_selection (I:1413-1437) ride along with the contact grid build: the binning
@@ -277,31 +303,49 @@ __global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDes
     const int stride = gridDim.x * blockDim.x;
     for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < nzero; k += stride * 4)
         *reinterpret_cast<int4*>(zero_other + k) = make_int4(0, 0, 0, 0);          // (buffers are padded to a multiple of 4)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float4 xyzm = compose_xyzm(r, i);
-        if (plus_init) plus_init[i] = r.all ? (uint8_t)1 : r.sel[i];   // I:1407: selection_plus starts as the selection
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const bool need_aux = !r.all || rm.res_sel || plus_init || FILTER == 1;
+    for (int base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < n; base += stride) {   // (wave-uniform trip count)
+        const int i = base + lane;
+        const bool valid = i < n;
+        const int ii = valid ? i : n - 1;
+        const int4 aux = need_aux ? r.aux[ii] : make_int4(0, 0, 0, 0);
+        const float4 xyzm = compose_xyzm(r, ii, aux.x);
         const uint32_t m = __float_as_uint(xyzm.w);
-        if (rm.res_sel) {   // I:1413, 1431: residues of the selection / of selection_plus (hydrogens included), tagged with the pass
-            const int res = r.aux[i].y;
-            if (m & M_SEL) rm.res_sel[res] = rm.tag;
-            if (m & M_PLUS) rm.res_plus[res] = rm.tag;
+        if (valid) {
+            if (plus_init) plus_init[aux.x] = r.all ? (uint8_t)1 : r.sel[aux.x];   // I:1407: selection_plus starts as the selection
+            if (rm.res_sel) {   // I:1413, 1431: residues of the selection / of selection_plus (hydrogens included), tagged with the pass
+                if (m & M_SEL) rm.res_sel[aux.y] = rm.tag;
+                if (m & M_PLUS) rm.res_plus[aux.y] = rm.tag;
+            }
         }
-        const bool on = (FILTER == 1) ? (active[i] != 0) : (((m & req) == req) && !(m & forb));
-        int c = -1, rank = 0;
-        if (on) {
-            c = cell_index(g, num::d3{(double)xyzm.x, (double)xyzm.y, (double)xyzm.z});
-            rank = atomicAdd(&cell_cnt[c], 1);
+        const bool on = valid && ((FILTER == 1) ? (active[aux.x] != 0) : (((m & req) == req) && !(m & forb)));
+        const int c = on ? cell_index(g, num::d3{(double)xyzm.x, (double)xyzm.y, (double)xyzm.z}) : -1;
+        // one atomic per distinct cell of the wave: the lanes of a cell elect the lowest one, which asks for the whole group
+        int leader = 0, before = 0, group = 0;
+        unsigned long long todo = __ballot(on);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            const int cl = __shfl(c, l);
+            const unsigned long long same = __ballot(on && c == cl);
+            if (on && c == cl) { leader = l; before = __popcll(same & below); group = __popcll(same); }
+            todo &= ~same;
         }
-        cell_rank[i] = make_int2(c, rank);
+        int first = 0;
+        if (on && lane == leader) first = atomicAdd(&cell_cnt[c], group);
+        first = __shfl(first, leader);
+        if (valid) cell_rank[i] = make_int2(c, first + before);
     }
 }
 
 // one atom's cell-sorted records (search record 32 B; the contact grid adds the 32-byte sift record)
 __device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos, float4* __restrict__ s_xyzm,
                                             int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec) {
-    const float4 xyzm = compose_xyzm(r, i);
+    const int4 aux = r.aux[i];
+    const float4 xyzm = compose_xyzm(r, i, aux.x);
     s_xyzm[pos] = xyzm;
-    s_aux[pos] = r.aux[i];
+    s_aux[pos] = aux;
     if (s_rec) {
         SiftRec q;
         q.xyzm = xyzm;
@@ -346,8 +390,8 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     const int2 cr = (i < n) ? cell_rank[i] : make_int2(-1, 0);      // in flight beside the histogram loads
     // ... and so are the atom's record columns (they do not depend on where the atom goes)
     const int ii = (i < n) ? i : 0;
-    const float4 my_xyzm = compose_xyzm(r, ii);
     const int4 my_aux = r.aux[ii];
+    const float4 my_xyzm = compose_xyzm(r, ii, my_aux.x);
     const int4 my_q1 = s_rec ? r.q1[ii] : make_int4(0, 0, 0, 0);
     int4 v[STEPS];
 #pragma unroll
