@@ -1003,13 +1003,16 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     const long long nseg = (long long)min(npairs_ptr[sgm], cap);
     const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
     const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
-    for (long long base = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane); base < nseg; base += stride) {
+    const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
+    int2 pr_next = (first + lane < nseg) ? seg_pairs[first + lane] : make_int2(0, 0);
+    for (long long base = first; base < nseg; base += stride) {
         const long long ps = base + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
         bool queued = false;
         uint4 task = make_uint4(0u, 0u, 0u, 0u);
+        const int2 pr = pr_next;
+        if (ps + stride < nseg) pr_next = seg_pairs[ps + stride];     // the next batch's pairs travel while this one is evaluated
         if (ps < nseg) {
         const long long p = out_base + ps;
-        const int2 pr = seg_pairs[ps];
         const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // two 16-byte quads per atom
         const float4 vb = qb.xyzm, ve = qe.xyzm;
         const int b = qb.q1.x, e = qe.q1.x;
