@@ -31,7 +31,8 @@ SYMBOLS = (
     'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
     'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob',
     'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_shard_set_home', 'arp_shard_pack_face',
-    'arp_shard_assemble', 'arp_shard_layout', 'arp_get_blob',
+    'arp_shard_assemble', 'arp_shard_layout', 'arp_get_blob', 'arp_cif_open', 'arp_cif_close', 'arp_cif_rows', 'arp_cif_cols',
+    'arp_cif_blocks', 'arp_cif_tag', 'arp_cif_text', 'arp_cif_column', 'arp_cif_column_f64', 'arp_cif_column_i64',
 )
 
 _lib = None
@@ -87,6 +88,20 @@ def load():
     L.arp_shard_assemble.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, i64, vp]
     L.arp_shard_layout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.arp_get_blob.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.arp_cif_open.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_uint64]
+    L.arp_cif_close.argtypes = [vp]
+    L.arp_cif_close.restype = None
+    L.arp_cif_rows.argtypes = [vp]
+    L.arp_cif_rows.restype = C.c_int64
+    L.arp_cif_cols.argtypes = [vp]
+    L.arp_cif_blocks.argtypes = [vp]
+    L.arp_cif_tag.argtypes = [vp, i32]
+    L.arp_cif_tag.restype = C.c_char_p
+    L.arp_cif_text.argtypes = [vp]
+    L.arp_cif_text.restype = vp
+    L.arp_cif_column.argtypes = [vp, i32, vp, vp, vp]
+    L.arp_cif_column_f64.argtypes = [vp, i32, dbl, vp, C.POINTER(i64)]
+    L.arp_cif_column_i64.argtypes = [vp, i32, i64, vp, C.POINTER(i64)]
     L.arp_write_contacts_json.argtypes = [C.c_char_p, i32, i32, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_char_p, i64]
     L.arp_device_buffer.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.arp_run_stage.argtypes = [vp, i32, dbl, dbl, i32, dbl, vp]
@@ -113,7 +128,8 @@ def load():
     L.arp_stream_handle.restype = C.c_uint64
     for s in SYMBOLS:
         f = getattr(L, s)
-        if s not in ('arp_version', 'arp_last_error', 'arp_destroy', 'arp_stream_handle', 'arp_blob_size', 'arp_records_size'):
+        if s not in ('arp_version', 'arp_last_error', 'arp_destroy', 'arp_stream_handle', 'arp_blob_size', 'arp_records_size',
+                     'arp_cif_close', 'arp_cif_rows', 'arp_cif_tag', 'arp_cif_text'):
             f.restype = C.c_int
     _lib = L
     return L
@@ -310,6 +326,64 @@ def unpack_records_buffer(buf):
             'ring_gid': r['gid'].copy(), 'ring_center': r['c'].copy(), 'ring_normal': r['n'].copy(), 'ring_res': r['res'].copy(),
             'amide_gid': m['gid'].copy(), 'amide_center': m['c'].copy(), 'amide_normal': m['n'].copy(), 'amide_res': m['res'].copy(),
             'header': hdr}
+
+
+class CifCategory:
+    """One category of an mmCIF text (``arp_cif_open``): what gemmi's ``cif_block.get_mmcif_category(name)`` gives the
+    reference — ``columns()[item]`` is a list with ``None`` for '?', ``False`` for '.', the unquoted string otherwise —
+    plus bulk numeric access for the big ``_atom_site`` table."""
+
+    def __init__(self, text, category):
+        self._L = load()
+        raw = text.encode('utf-8') if isinstance(text, str) else bytes(text)
+        h, err = C.c_void_p(), C.create_string_buffer(256)
+        rc = self._L.arp_cif_open(raw, len(raw), category.encode(), C.byref(h), err, 256)
+        if rc != ARP_OK:
+            raise ValueError(err.value.decode() or f'arp_cif_open failed ({rc})')
+        self._h = h
+        self.category = category
+        self.rows, self.n_blocks = int(self._L.arp_cif_rows(h)), int(self._L.arp_cif_blocks(h))
+        self.tags = [self._L.arp_cif_tag(h, k).decode() for k in range(int(self._L.arp_cif_cols(h)))]
+        self._raw = raw
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.arp_cif_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __contains__(self, item):
+        return item in self.tags
+
+    def _cells(self, item):
+        col = self.tags.index(item)
+        b, ln, kd = np.empty(self.rows, np.uint64), np.empty(self.rows, np.uint32), np.empty(self.rows, np.uint8)
+        if self._L.arp_cif_column(self._h, col, _p(b), _p(ln), _p(kd)) != ARP_OK:
+            raise ValueError(f'arp_cif_column({item})')
+        return b, ln, kd
+
+    def column(self, item):
+        """The column as gemmi delivers it: str / None ('?') / False ('.')."""
+        b, ln, kd = self._cells(item)
+        raw = self._raw
+        return [raw[s:s + n].decode('utf-8') if k == 0 else (None if k == 1 else False)
+                for s, n, k in zip(b.tolist(), ln.tolist(), kd.tolist())]
+
+    def columns(self):
+        return {t: self.column(t) for t in self.tags}
+
+    def floats(self, item, missing=np.nan):
+        out, bad = np.empty(self.rows, np.float64), C.c_int64(-1)
+        if self._L.arp_cif_column_f64(self._h, self.tags.index(item), float(missing), _p(out), C.byref(bad)) != ARP_OK:
+            raise ValueError(f'{self.category}{item}: row {bad.value} is not a number')
+        return out
+
+    def ints(self, item, missing=0):
+        out, bad = np.empty(self.rows, np.int64), C.c_int64(-1)
+        if self._L.arp_cif_column_i64(self._h, self.tags.index(item), int(missing), _p(out), C.byref(bad)) != ARP_OK:
+            raise ValueError(f'{self.category}{item}: row {bad.value} is not an integer')
+        return out
 
 
 KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')

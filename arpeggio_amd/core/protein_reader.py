@@ -1,0 +1,325 @@
+"""mmCIF -> the atom / residue part of a PackedComplex without gemmi or BioPython.
+
+Mirrors ``arpeggio/core/protein_reader.py`` of the reference where the reference's own code decides, and restates the
+third-party behaviour it relies on where it does not:
+
+====================================  ==========================================================================
+reference                             here
+====================================  ==========================================================================
+gemmi ``get_mmcif_category``          ``_capi.CifCategory`` (native CIF tokenizer, ``csrc/arp_cif.h``): '?' -> None,
+                                      '.' -> False, quoted values unquoted — recalled gemmi semantics
+``_parse_atom_site_biopython``        ``structure_events``: the same calls, in the same order, with the same arguments,
+(P:366-411), ``_init_biopython_atom`` as the reference makes on ``StructureBuilder`` — pinned by executing the
+(P:309-363), ``_get_hetero_flag``     reference's functions on a recording builder (tests/golden/reader.json)
+``Bio.PDB.StructureBuilder``          ``build_structure``: chains by id, residues by (het flag, seq, icode), alternative
+                                      locations collapsed to the highest-occupancy child as ``DisorderedAtom`` does —
+                                      recalled; point mutations (two residue names under one id) are refused
+``get_component_types`` (P:415-441)   ``get_component_types`` — pinned by executing the reference's function
+``Bio.PDB.PPBuilder`` (I:1598-1599)   ``build_peptides``: C–N < 1.8 A between consecutive accepted residues of a chain —
+                                      recalled; a residue is accepted if it is a standard amino acid or has a CA atom
+                                      (BioPython also accepts the modified residues of its extended table that lack CA)
+``_handle_chains_residues_and_breaks``  ``polypeptide_bookkeeping`` — pinned by executing the reference's method on the
+(I:1591-1693)                         polypeptides ``build_peptides`` returns
+====================================  ==========================================================================
+
+What a file alone does NOT give: the OpenBabel bond graph, hydrogens added by OpenBabel, SMARTS types of ligand atoms,
+aromatic rings and amide groups.  ``read_mmcif`` therefore returns a pack whose atoms of standard residues are typed by
+table (``core/typing.py``), whose other atoms carry no type, and whose bond / ring / amide sections are empty;
+``pc.incomplete`` lists what is missing.  The reference also passes the file through gemmi's ``read_structure`` +
+``make_mmcif_block`` (first model only, merged chain parts, coordinates re-formatted to three decimals) before reading
+the table; this reader takes the first model of the file's own ``_atom_site`` table.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from . import config, typing
+from .packed import PackedComplex
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_COMP = None
+
+
+def _read_text(path):
+    if not os.path.isfile(path):
+        raise IOError('File {} not found'.format(path))            # P:58-59, 269-270, 417-418
+    with open(path, 'rb') as fh:
+        return fh.read()
+
+
+def _category(text, name):
+    from .. import _capi
+    return _capi.CifCategory(text, name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# _chem_comp -> component types
+# ---------------------------------------------------------------------------------------------------------------------
+def _comp_table():
+    global _COMP
+    if _COMP is None:
+        _COMP = json.load(open(os.path.join(_HERE, 'data', 'chem_comp_types.json')))
+    return _COMP
+
+
+def component_types_from_columns(chem_comp):
+    """P:421-437 on the columns of the ``_chem_comp`` category (item -> list, gemmi conventions)."""
+    t = _comp_table()
+    letter = {v: k for k, v in t['letters'].items()}
+    out = {}
+    for i in range(len(chem_comp['id'])):
+        ctype = chem_comp['type'][i]
+        if ctype:
+            comp = t['chem_comp_type'][ctype.upper()]               # KeyError for a type the table does not hold, as the reference
+            if comp != letter[5]:
+                out[chem_comp['id'][i]] = comp
+            elif chem_comp['name'][i].upper() == 'WATER':
+                out[chem_comp['id'][i]] = letter[8]
+            else:
+                out[chem_comp['id'][i]] = letter[7]
+        else:
+            out[chem_comp['id'][i]] = letter[9]
+    return out
+
+
+def get_component_types(path):
+    """``protein_reader.get_component_types`` (P:415-441): residue name -> one-letter component type."""
+    text = _read_text(path)
+    cat = _category(text, '_chem_comp.')
+    if cat.n_blocks != 1:
+        raise RuntimeError('single data block expected, got: %d' % cat.n_blocks)      # gemmi's sole_block()
+    if cat.rows == 0 and not cat.tags:
+        raise ValueError('Missing _chem_comp. category in mmcif')                      # P:440-441
+    return component_types_from_columns(cat.columns())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# _atom_site -> the calls the reference makes on StructureBuilder
+# ---------------------------------------------------------------------------------------------------------------------
+def _get_hetero_flag(field, resn):
+    """P:292-306."""
+    if field == 'HETATM':
+        if resn in ('HOH', 'WAT'):
+            return 'W'
+        return 'H'
+    return ' '
+
+
+def structure_events(atom_sites):
+    """The builder calls of ``_parse_atom_site_biopython`` (P:366-411) for an ``_atom_site`` dict of columns, as a list of
+    tuples ('model', n) / ('seg', id) / ('chain', id) / ('residue', name, het flag, seq, icode) / ('atom', name, (x, y,
+    z), b, occupancy, altloc, fullname, serial, element).  The reference's quirks are kept: a chain change alone does not
+    open a residue (``last_chain_id`` is updated before it is compared, P:390-399)."""
+    ev = []
+    has_label = 'pdbe_label_seq_id' in atom_sites
+    has_b = 'B_iso_or_equiv' in atom_sites
+    last_model = last_ins = last_chain = last_name = last_id = None
+    n = len(atom_sites['id'])
+    for i in range(n):
+        res_id = int(atom_sites['pdbe_label_seq_id'][i] if has_label else atom_sites['auth_seq_id'][i])       # P:16-21
+        name = atom_sites['label_comp_id'][i]
+        het = _get_hetero_flag(atom_sites['group_PDB'][i], name)
+        ins = ' ' if not atom_sites['pdbx_PDB_ins_code'][i] else atom_sites['pdbx_PDB_ins_code'][i]          # P:30-35
+        if last_model != atom_sites['pdbx_PDB_model_num'][i]:
+            last_model = atom_sites['pdbx_PDB_model_num'][i]
+            ev.append(('model', int(last_model) - 1))
+        if i == 0:
+            ev.append(('seg', '    '))
+        if last_chain != atom_sites['auth_asym_id'][i]:
+            last_chain = atom_sites['auth_asym_id'][i]
+            ev.append(('chain', last_chain))
+        if last_id != res_id or last_name != name or last_ins != ins:
+            last_id, last_name, last_ins = res_id, name, ins
+            ev.append(('residue', name, het, res_id, ins))
+        x, y, z = float(atom_sites['Cartn_x'][i]), float(atom_sites['Cartn_y'][i]), float(atom_sites['Cartn_z'][i])
+        b = float(atom_sites['B_iso_or_equiv'][i]) if has_b else 20.0                                         # P:24-27
+        alt = ' ' if not atom_sites['label_alt_id'][i] else atom_sites['label_alt_id'][i]
+        ev.append(('atom', atom_sites['label_atom_id'][i], (x, y, z), b, float(atom_sites['occupancy'][i]), alt,
+                   atom_sites['label_atom_id'][i], int(atom_sites['id'][i]), atom_sites['type_symbol'][i].upper()))
+    return ev
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# StructureBuilder (BioPython; recalled): chains, residues, disordered atoms
+# ---------------------------------------------------------------------------------------------------------------------
+class _Atom:
+    __slots__ = ('name', 'children', 'selected', 'last_occ', 'residue')
+
+    def __init__(self, name, residue):
+        self.name, self.children, self.selected, self.last_occ, self.residue = name, [], 0, -1e300, residue
+
+    def add(self, coord, b, occ, alt, serial, element):
+        self.children.append(dict(coord=np.array(coord, 'f'), b=b, occ=occ, alt=alt, serial=serial, element=element))
+        if occ > self.last_occ:              # DisorderedAtom.disordered_add: the child with the highest occupancy is selected
+            self.last_occ, self.selected = occ, len(self.children) - 1
+
+    def __getattr__(self, k):
+        return self.children[self.selected][k]
+
+
+class _Residue:
+    def __init__(self, name, het, seq, icode, chain):
+        self.name, self.het, self.seq, self.icode, self.chain = name, het, seq, icode, chain
+        self.atoms, self.by_name = [], {}
+
+
+def build_structure(events, first_model_only=True):
+    """Chains (by id, in order of first appearance), residues and atoms as ``Bio.PDB.StructureBuilder`` would arrange them
+    for the events of ``structure_events`` (first model).  Returns the list of chains, each a list of residues."""
+    chains, by_id = [], {}
+    chain = residue = None
+    models = 0
+    for e in events:
+        kind = e[0]
+        if kind == 'model':
+            models += 1
+            if models > 1 and first_model_only:          # the reference drops the other models before it reads the table
+                break
+        elif kind == 'chain':
+            if e[1] not in by_id:
+                by_id[e[1]] = (e[1], [], {})
+                chains.append(by_id[e[1]])
+            chain = by_id[e[1]]                          # (a chain seen before: BioPython warns "discontinuous" and goes on)
+        elif kind == 'residue':
+            _, name, het, seq, icode = e
+            key = (het if het != 'H' else 'H_' + name, seq, icode)
+            old = chain[2].get(key)
+            if old is not None:
+                if old.name != name or het != ' ':
+                    raise ValueError(f'residue id {key} of chain {chain[0]} is used twice (point mutation / duplicated hetero '
+                                     f'residue): not supported by this reader')
+                residue = old                            # "Residue redefined": BioPython continues with the existing one
+            else:
+                residue = _Residue(name, het, seq, icode, chain[0])
+                chain[1].append(residue)
+                chain[2][key] = residue
+        elif kind == 'atom':
+            _, name, coord, b, occ, alt, fullname, serial, element = e
+            a = residue.by_name.get(name)
+            if a is None:
+                a = _Atom(name, residue)
+                residue.by_name[name] = a
+                residue.atoms.append(a)
+            elif alt == ' ' or any(c['alt'] == alt for c in a.children):
+                raise ValueError(f'atom {name} defined twice in residue {residue.name} {residue.seq} of chain {chain[0]}: '
+                                 f'not supported by this reader')
+            a.add(coord, b, occ, alt, serial, element)
+    return [(cid, res) for cid, res, _ in chains]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PPBuilder (BioPython; recalled) and the reference's bookkeeping on top of it
+# ---------------------------------------------------------------------------------------------------------------------
+def _accept(res):
+    return res.name in typing.table()['std_res'] or 'CA' in res.by_name
+
+
+def _is_connected(prev, nxt, radius=1.8):
+    c, n = prev.by_name.get('C'), nxt.by_name.get('N')
+    if c is None or n is None:
+        return False
+    for ni, nn in enumerate(n.children):                 # every pair of compatible alternative locations; the pair that is
+        for ci, cc in enumerate(c.children):             # bonded becomes the selected one (PPBuilder._is_connected)
+            if nn['alt'] == cc['alt'] or nn['alt'] == ' ' or cc['alt'] == ' ':
+                d = nn['coord'] - cc['coord']
+                if np.sqrt(np.dot(d, d)) < radius:       # Atom.__sub__: float32 difference, np.sqrt(np.dot(diff, diff))
+                    if len(c.children) > 1:
+                        c.selected = ci
+                    if len(n.children) > 1:
+                        n.selected = ni
+                    return True
+    return False
+
+
+def build_peptides(chains):
+    """``PPBuilder().build_peptides(structure, aa_only=False)``: lists of consecutive connected residues."""
+    pps = []
+    for _, residues in chains:
+        it = iter(residues)
+        prev = next((r for r in it if _accept(r)), None)
+        if prev is None:
+            continue
+        pp = None
+        for nxt in it:
+            if _accept(prev) and _accept(nxt) and _is_connected(prev, nxt):
+                if pp is None:
+                    pp = [prev]
+                    pps.append(pp)
+                pp.append(nxt)
+            else:
+                pp = None
+            prev = nxt
+    return pps
+
+
+def polypeptide_bookkeeping(polypeptides):
+    """I:1656-1693: residues of a polypeptide are flagged and linked to their neighbours inside it.  Returns
+    {id(residue): (prev residue or None, next residue or None)} for the residues that are part of a polypeptide."""
+    links = {}
+    for pp in polypeptides:
+        last = None
+        for r in pp:
+            links[id(r)] = [last, None]
+            if last is not None:
+                links[id(last)][1] = r
+            last = r
+    return links
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# file -> PackedComplex
+# ---------------------------------------------------------------------------------------------------------------------
+def read_mmcif(path, use_ambiguities=False):
+    """The atom / residue part of ``initialize()``'s result for an mmCIF file: see the module docstring for what is and
+    what is not there (``pc.incomplete``)."""
+    text = _read_text(path)
+    cat = _category(text, '_atom_site.')
+    if cat.rows == 0:
+        raise ValueError('The cif file does not contain _atom_site record')           # P:285-287
+    chains = build_structure(structure_events(cat.columns()))
+    links = polypeptide_bookkeeping(build_peptides(chains))
+    residues = [r for _, rs in chains for r in rs]
+    res_index = {id(r): k for k, r in enumerate(residues)}
+    atoms = [a for r in residues for a in r.atoms]
+    n, nres = len(atoms), len(residues)
+    res_flags = np.zeros(nres, np.uint8)
+    res_prev, res_next = np.full(nres, -1, np.int32), np.full(nres, -1, np.int32)
+    for k, r in enumerate(residues):
+        if id(r) in links:
+            res_flags[k] |= config.R_POLYPEPTIDE | config.R_HAS_SEQ
+            p, q = links[id(r)]
+            res_prev[k] = -1 if p is None else res_index[id(p)]
+            res_next[k] = -1 if q is None else res_index[id(q)]
+    element = [a.element for a in atoms]
+    res_id = np.array([res_index[id(a.residue)] for a in atoms], np.int32)
+    res_name = [r.name for r in residues]
+    flags = typing.element_flags(element, res_name, res_id)
+    water = np.array([r.het == 'W' for r in residues], bool)[res_id] if n else np.zeros(0, bool)
+    flags[water] |= config.F_WATER
+    vdw, cov = typing.element_radii(element)
+    try:
+        comp = component_types_from_columns(_category(text, '_chem_comp.').columns())
+    except (KeyError, ValueError):
+        comp = {}
+    pc = PackedComplex(
+        xyz=np.array([a.coord for a in atoms], np.float32).reshape(-1, 3), vdw=vdw, cov=cov, type_mask=np.zeros(n, np.uint16), flags=flags,
+        res_id=res_id, res_flags=res_flags, res_prev=res_prev, res_next=res_next, bond_off=np.zeros(n + 1, np.int32),
+        bond_idx=np.zeros(0, np.int32), h_off=np.zeros(n + 1, np.int32), h_xyz=np.zeros((0, 3)), sb_nbr=np.full(n, -1, np.int32),
+        ring_center=np.zeros((0, 3)), ring_normal=np.zeros((0, 3)), ring_res=np.zeros(0, np.int32),
+        amide_center=np.zeros((0, 3), np.float32), amide_normal=np.zeros((0, 3), np.float32), amide_res=np.zeros(0, np.int32),
+        id=os.path.basename(path).split('.')[0])
+    pc.atom_name = [a.name for a in atoms]
+    pc.element = element
+    pc.serial = np.array([a.serial for a in atoms], np.int64)
+    pc.res_name = res_name
+    pc.res_chain = [r.chain for r in residues]
+    pc.res_seq = np.array([r.seq for r in residues], np.int32)
+    pc.res_icode = [r.icode for r in residues]
+    pc.res_het = [r.het for r in residues]
+    pc.component_types = comp
+    pc.type_mask = typing.apply_protein_typing(pc, use_ambiguities=use_ambiguities)
+    pc.incomplete = ('bonds', 'hydrogen coordinates', 'ligand atom types', 'rings', 'amides')
+    return pc

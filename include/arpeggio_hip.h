@@ -445,6 +445,27 @@ int arp_shard_layout(arp_ctx* ctx, int32_t* global_id, int8_t* origin, uint8_t* 
  * arp_shard_assemble: *bytes = size; copies when cap suffices (host may be NULL to ask for the size). */
 int arp_get_blob(arp_ctx* ctx, void* host, uint64_t cap, uint64_t* bytes);
 
+/* ---- mmCIF category reader (host only; no context, no GPU) — SURVEY.md 8 row f3 ---------------------------------
+ * What the reference asks gemmi for (protein_reader.py:258-289, 415-441): one category of the file as columns
+ * (cif_block.get_mmcif_category('_atom_site.') / ('_chem_comp.')).  arp_cif_open parses `text` (CIF 1.1 syntax: loops,
+ * pair items, quoted strings, text fields, comments) and keeps the items of the FIRST data block whose tags start with
+ * `category` (e.g. "_atom_site.", case-insensitive).  A cell is a slice of the text plus a kind: 0 value, 1 bare '?'
+ * (gemmi: None), 2 bare '.' (gemmi: False).  Errors: negative return, message in err (if given). */
+typedef struct arp_cif arp_cif;
+int arp_cif_open(const char* text, uint64_t len, const char* category, arp_cif** out, char* err, uint64_t err_cap);
+void arp_cif_close(arp_cif* t);
+int64_t arp_cif_rows(const arp_cif* t);
+int arp_cif_cols(const arp_cif* t);
+int arp_cif_blocks(const arp_cif* t);                 /* data_ blocks in the file (gemmi's sole_block() wants exactly one) */
+const char* arp_cif_tag(const arp_cif* t, int col);   /* item name after the category prefix */
+const char* arp_cif_text(const arp_cif* t);           /* the text the cells point into */
+/* cells of one column: begin / len / kind arrays of arp_cif_rows() entries, filled by the call */
+int arp_cif_column(const arp_cif* t, int col, uint64_t* begin, uint32_t* len, uint8_t* kind);
+/* float(value) / int(value) of every cell (C strtod / strtoll over the whole cell); '?' and '.' give `missing`;
+ * a cell that is not a number: returns -1 and its row in *bad_row */
+int arp_cif_column_f64(const arp_cif* t, int col, double missing, double* out, int64_t* bad_row);
+int arp_cif_column_i64(const arp_cif* t, int col, int64_t missing, int64_t* out, int64_t* bad_row);
+
 /* ---- JSON output (host only; no context, no GPU) ------------------------------------------
  * The reference's CLI ends with json.dump(get_contacts(), fh, indent=4, sort_keys=True) (scripts/process_protein_cli.py:
  * 184-188; records of I:172-212).  This writes the same bytes for the atom-atom records straight from the result arrays

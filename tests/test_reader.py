@@ -1,0 +1,145 @@
+"""mmCIF reader against the executed reference functions of tests/golden/reader.json.  Host only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from arpeggio_amd import _capi
+from arpeggio_amd.core import config, protein_reader
+
+
+@pytest.fixture(scope='module')
+def golden(golden_dir):
+    return json.load(open(os.path.join(golden_dir, 'reader.json')))
+
+
+def test_category_columns_are_what_gemmi_would_deliver(golden):
+    """The text of each case was written from the column dicts the reference functions were run on: parsing it gives the
+    dicts back (quoted atom names like O5' and "C"2", values with blanks, '?' -> None, '.' -> False)."""
+    for case in golden['cases']:
+        for cat in ('atom_site', 'chem_comp'):
+            c = _capi.CifCategory(case['text'], f'_{cat}.')
+            assert c.n_blocks == 1 and c.rows == len(next(iter(case[cat].values())))
+            assert c.columns() == case[cat], (case['name'], cat)
+        assert _capi.CifCategory(case['text'], '_entry.').columns() == {'id': [case['name'].replace('peptide', 'CASE')]}
+        a = _capi.CifCategory(case['text'], '_atom_site.')
+        assert np.array_equal(a.floats('Cartn_x'), np.array([float(v) for v in case['atom_site']['Cartn_x']]))
+        assert a.ints('id').tolist() == [int(v) for v in case['atom_site']['id']]
+        if 'pdbx_formal_charge' in a:
+            assert a.ints('pdbx_formal_charge', missing=0).tolist() == [int(v) if v else 0 for v in case['atom_site']['pdbx_formal_charge']]
+
+
+def test_cif_syntax_corners():
+    text = ("#c\ndata_x # trailing comment\n_a.one 'it's'   # quote inside: only quote + blank closes\n_a.two ;notatext\n"
+            "_a.three\n;line 1\n line 2 ; not the end\n;\n_a.four \"a b\"\n_A.Five ?\n_a.six '?'\nloop_\n_b.k\n_b.v\n1 .\n2 'x y'\n")
+    a = _capi.CifCategory(text, '_a.').columns()
+    assert a == {'one': ["it's"], 'two': [';notatext'], 'three': ['line 1\n line 2 ; not the end'], 'four': ['a b'], 'Five': [None], 'six': ['?']}
+    assert _capi.CifCategory(text, '_b.').columns() == {'k': ['1', '2'], 'v': [False, 'x y']}
+    assert _capi.CifCategory(text, '_missing.').rows == 0
+    two = _capi.CifCategory('data_a\n_x.y 1\ndata_b\n_x.y 2\n', '_x.')
+    assert two.n_blocks == 2 and two.columns() == {'y': ['1']}                 # first block only
+    for bad in ("data_a\nloop_\n_x.a\n_x.b\n1 2 3\n", "data_a\n_x.a 'open\n", "data_a\n_x.a\n;never closed\n", "_x.a 1\n", "data_a\n_x.a\n"):
+        with pytest.raises(ValueError):
+            _capi.CifCategory(bad, '_x.')
+    with pytest.raises(ValueError, match='not a number'):
+        _capi.CifCategory("data_a\nloop_\n_x.a\n1.0\n2.5(3)\n", '_x.').floats('a')
+
+
+def test_builder_calls_equal_the_executed_reference(golden):
+    """structure_events == what _parse_atom_site_biopython / _init_biopython_atom called on StructureBuilder."""
+    for case in golden['cases']:
+        got = protein_reader.structure_events(case['atom_site'])
+        want = case['builder_calls']
+        assert len(got) == len(want), case['name']
+        for g, w in zip(got, want):
+            g = list(g)
+            if g[0] == 'atom':
+                g[2] = [float(x) for x in np.array(g[2], 'f')]         # numpy.array((x, y, z), 'f') (P:324-327)
+            assert g == w, (case['name'], g, w)
+        assert sum(1 for g in got if g[0] == 'model') == (2 if case['name'] == 'peptide1' else 1)
+    for field, resn, want in golden['hetero_flag']:
+        assert protein_reader._get_hetero_flag(field, resn) == want
+
+
+def test_component_types_equal_the_executed_reference(golden, tmp_path):
+    for case in golden['cases']:
+        p = tmp_path / (case['name'] + '.cif')
+        p.write_text(case['text'])
+        assert protein_reader.get_component_types(str(p)) == case['component_types']
+        assert set(case['component_types'].values()) >= {'P', 'W', 'B', 'D', 'R', 'S', 'O', 'M'}
+    p = tmp_path / 'nochem.cif'
+    p.write_text('data_x\n_entry.id x\n')
+    with pytest.raises(ValueError) as ei:
+        protein_reader.get_component_types(str(p))
+    assert str(ei.value) == golden['missing_chem_comp']
+    with pytest.raises(IOError):
+        protein_reader.get_component_types(str(tmp_path / 'absent.cif'))
+
+
+def test_polypeptide_bookkeeping_equals_the_executed_reference(golden):
+    for b in golden['bookkeeping']:
+        residues = [object() for _ in b['residues']]
+        links = protein_reader.polypeptide_bookkeeping([[residues[k] for k in pp] for pp in b['polypeptides']])
+        for k, want in enumerate(b['residues']):
+            mine = links.get(id(residues[k]))
+            assert (mine is not None) == want['is_polypeptide'] == want['has_links'], k
+            if mine is not None:
+                idx = {id(r): i for i, r in enumerate(residues)}
+                assert (idx[id(mine[0])] if mine[0] is not None else -1) == want['prev']
+                assert (idx[id(mine[1])] if mine[1] is not None else -1) == want['next']
+        assert sorted(k for k, r in enumerate(residues) if id(r) in links) == b['polypeptide_residues']
+
+
+def test_read_mmcif_end_to_end(golden, tmp_path):
+    case = golden['cases'][1]                   # the one with a second model
+    p = tmp_path / '1abc_h.cif'
+    p.write_text(case['text'])
+    pc = protein_reader.read_mmcif(str(p))
+    pc.validate()
+    cols = case['atom_site']
+    first_model = [k for k, m in enumerate(cols['pdbx_PDB_model_num']) if m == '1']
+    n_alt = sum(1 for k in first_model if cols['label_alt_id'][k] == 'B')        # one child of every A / B pair is kept
+    assert pc.n_atoms == len(first_model) - n_alt and pc.id == '1abc_h'
+    # alternative locations: the child with the higher occupancy (B, 0.6) is the atom
+    k = [i for i in first_model if cols['label_alt_id'][i] == 'B'][0]
+    i = pc.serial.tolist().index(int(cols['id'][k]))
+    assert pc.atom_name[i] == 'CA' and np.array_equal(pc.xyz[i], np.array([cols['Cartn_x'][k], cols['Cartn_y'][k], cols['Cartn_z'][k]], 'f'))
+    assert int(cols['id'][k]) - 1 not in pc.serial.tolist()
+    # residues: chain A peptide (6 + MSE + 17A + 17B | break | LEU VAL), chain B peptide, ligand, ions, waters
+    names = list(zip(pc.res_chain, pc.res_name, pc.res_seq.tolist(), pc.res_icode))
+    assert ('A', 'MSE', 16, ' ') in names and ('A', names[7][1], 17, 'A') == names[7] and names[8][2:] == (17, 'B')
+    poly = (pc.res_flags & config.R_POLYPEPTIDE) != 0
+    a_chain = [k for k, nm in enumerate(names) if nm[0] == 'A' and nm[2] < 300]
+    assert poly[a_chain].all() and pc.res_next[a_chain[8]] == -1 and pc.res_prev[a_chain[9]] == -1      # the break
+    assert pc.res_next[a_chain[5]] == a_chain[6] and pc.res_prev[a_chain[7]] == a_chain[6]              # through MSE
+    assert not poly[[k for k, nm in enumerate(names) if nm[1] in ('LIG', 'ZN', 'CA', 'HOH', 'WAT')]].any()
+    water = (pc.flags & config.F_WATER) != 0
+    assert water.sum() == 5 and {pc.res_name[r] for r in pc.res_id[water]} == {'HOH', 'WAT'}
+    assert ((pc.flags & config.F_METAL) != 0).sum() == 3                                               # FE, ZN, CA
+    # typing by table for the standard residues, nothing for the ligand
+    lig = np.array([pc.res_name[r] == 'LIG' for r in pc.res_id])
+    assert not pc.type_mask[lig].any()
+    o = [i for i in range(pc.n_atoms) if pc.atom_name[i] == 'O' and pc.res_name[pc.res_id[i]] == 'GLY']
+    assert o and all(pc.type_mask[i] & config.ATOM_TYPE_BIT['hbond acceptor'] for i in o)
+    assert {k: pc.component_types[k] for k in case['component_types']} == case['component_types'] and 'bonds' in pc.incomplete
+    with pytest.raises(ValueError, match='_atom_site'):
+        q = tmp_path / 'empty.cif'
+        q.write_text('data_x\n_entry.id x\n')
+        protein_reader.read_mmcif(str(q))
+
+
+@pytest.mark.gpu
+def test_read_mmcif_structure_runs_on_the_gpu(golden, tmp_path):
+    """The pack a file gives is incomplete (no bonds, rings, hydrogens) but well-formed: the pass runs on it and the drop-in
+    class exports its contacts."""
+    from arpeggio_amd.core import InteractionComplex
+    p = tmp_path / 'case0.cif'
+    p.write_text(golden['cases'][0]['text'])
+    ic = InteractionComplex(protein_reader.read_mmcif(str(p)), 0.1, 5.0, 7.4)
+    ic.structure_checks()
+    ic.initialize()
+    ic.run_arpeggio([], 5.0, 0.1, False)
+    recs = ic.get_contacts()
+    assert len(recs) > 50 and all(r['type'] == 'atom-atom' for r in recs)
+    assert any(r['bgn']['auth_atom_id'] == "O5'" or r['end']['auth_atom_id'] == "O5'" for r in recs)

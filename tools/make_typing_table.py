@@ -39,3 +39,22 @@ out = {
 path = os.path.join(HERE, '..', 'arpeggio_amd', 'core', 'data', 'prot_atom_types.json')
 json.dump(out, open(path, 'w'), indent=0, sort_keys=True)
 print(len(out['keys']), 'keys,', len(out['std_res']), 'residues ->', os.path.normpath(path))
+
+# _chem_comp.type -> one-letter component type (config.py:1143-1200, used by protein_reader.get_component_types): the same
+# kind of contract data.  The method builds its dictionary in its body, so it is asked for every key found in its source.
+import ast
+import inspect
+src = inspect.getsource(cfg.ComponentType.from_chem_comp_type)
+keys = [n.value for n in ast.walk(ast.parse('class _:\n' + src if src.startswith('    ') else src)) if isinstance(n, ast.Constant) and isinstance(n.value, str)
+        and n.value.upper() == n.value and len(n.value) > 4 and 'Maps' not in n.value]
+table = {}
+for k in keys:
+    try:
+        table[k] = cfg.ComponentType.from_chem_comp_type(k)
+    except KeyError:
+        pass
+out2 = {'source': 'arpeggio/core/config.py:1143-1200 (ComponentType.from_chem_comp_type), pdbe-arpeggio 1.4.4',
+        'letters': {m.name: int(m.value) for m in cfg.ComponentType}, 'chem_comp_type': {k: table[k] for k in sorted(table)}}
+path2 = os.path.join(HERE, '..', 'arpeggio_amd', 'core', 'data', 'chem_comp_types.json')
+json.dump(out2, open(path2, 'w'), indent=0, sort_keys=True)
+print(len(table), 'chem_comp types ->', os.path.normpath(path2))
