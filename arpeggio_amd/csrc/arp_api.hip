@@ -82,16 +82,35 @@ struct Grid {
 };
 
 struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
+    // the arrays are sub-ranges of ONE allocation (slab), so that a small bag reaches the host with one copy
+    DevBuf<uint8_t> slab;
     DevBuf<int> a, b;
     DevBuf<double> d0, d1, d2, d3;
     DevBuf<float> f0, f1, f2;
     DevBuf<uint8_t> u0, u1, u2;
     size_t cap = 0;
+    size_t slab_bytes = 0;
     int64_t count = 0;
     bool valid = false;
+    uint64_t version = 0;        // bumped whenever a launch refills the bag
+    uint64_t staged_version = 0; // version whose records are in the context's page-locked staging area, at stage_off[]
+    uint32_t stage_off[12] = {0};
     void release() { a.release(); b.release(); d0.release(); d1.release(); d2.release(); d3.release(); f0.release();
-                     f1.release(); f2.release(); u0.release(); u1.release(); u2.release(); cap = 0; valid = false; }
+                     f1.release(); f2.release(); u0.release(); u1.release(); u2.release(); slab.release(); cap = 0; slab_bytes = 0;
+                     valid = false; staged_version = 0; }
 };
+
+// the used prefixes of every array of every bag, gathered into one device buffer for one copy to the host
+struct PackSeg { const uint8_t* src; uint32_t dst, bytes; };
+struct PackTable { PackSeg s[48]; int n; };
+__global__ __launch_bounds__(256) void k_pack_segments(PackTable t, uint8_t* __restrict__ out) {
+    const PackSeg g = t.s[blockIdx.x];
+    const uint32_t words = g.bytes >> 2;
+    const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(g.src);      // (arrays of a slab start on 256-byte boundaries,
+    uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(out + g.dst);            //  destinations on 16-byte ones)
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < (g.bytes & 3u)) out[g.dst + (words << 2) + threadIdx.x] = g.src[(words << 2) + threadIdx.x];
+}
 
 enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_UNUSED = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
 
@@ -210,6 +229,9 @@ struct arp_ctx {
     bool init_plus_in_bin = false; // ... and writes selection_plus = selection (whole-structure selection)
     // ---- device-resident result bags of the ring / amide kernels
     Bag bag_ap, bag_pp, bag_gg, bag_gp;
+    DevBuf<uint8_t> bag_pack;      // staging of small bags: device side ...
+    uint8_t* bag_stage = nullptr;  // ... and its page-locked host copy
+    size_t bag_stage_cap = 0;
     // ---- profiling
     bool profiling = false;
     std::vector<EventPair> ev_pool;
@@ -724,12 +746,35 @@ int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 
 }
 
 int bag_reserve(arp_ctx* c, Bag& b, size_t cap, bool d, bool f) {
-    HIPCHK(c, b.a.reserve(cap)); HIPCHK(c, b.b.reserve(cap));
-    if (d) { HIPCHK(c, b.d0.reserve(cap)); HIPCHK(c, b.d1.reserve(cap)); HIPCHK(c, b.d2.reserve(cap)); HIPCHK(c, b.d3.reserve(cap)); }
-    if (f) { HIPCHK(c, b.f0.reserve(cap)); HIPCHK(c, b.f1.reserve(cap)); HIPCHK(c, b.f2.reserve(cap)); }
-    HIPCHK(c, b.u0.reserve(cap)); HIPCHK(c, b.u1.reserve(cap)); HIPCHK(c, b.u2.reserve(cap));
-    b.cap = std::min({b.a.cap, b.b.cap, b.u0.cap});
+    cap = cap + cap / 4 + 64;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t bi = al(cap * sizeof(int)), bd = al(cap * sizeof(double)), bf = al(cap * sizeof(float)), bu = al(cap);
+    const size_t total = 2 * bi + (d ? 4 * bd : 0) + (f ? 3 * bf : 0) + 3 * bu;
+    b.release();
+    HIPCHK(c, b.slab.reserve(total));
+    uint8_t* p = b.slab.p;
+    b.a.borrow(p, cap); p += bi; b.b.borrow(p, cap); p += bi;
+    if (d) { b.d0.borrow(p, cap); p += bd; b.d1.borrow(p, cap); p += bd; b.d2.borrow(p, cap); p += bd; b.d3.borrow(p, cap); p += bd; }
+    if (f) { b.f0.borrow(p, cap); p += bf; b.f1.borrow(p, cap); p += bf; b.f2.borrow(p, cap); p += bf; }
+    b.u0.borrow(p, cap); p += bu; b.u1.borrow(p, cap); p += bu; b.u2.borrow(p, cap); p += bu;
+    b.cap = cap;
+    b.slab_bytes = total;
     return ARP_OK;
+}
+
+// Small bags travel to the host in one piece: the first *_fetch after a pass gathers the used prefix of every array of
+// EVERY valid bag into one device buffer (k_pack_segments), copies it to page-locked memory and synchronises once; the
+// fetch calls hand the arrays out from there — instead of six to nine small copies and a synchronisation per bag.
+#define BAG_STAGE_MAX ((size_t)4 << 20)
+int stage_bags(arp_ctx* c);
+inline bool bag_is_staged(const arp_ctx* c, const Bag& b) { return c->bag_stage && b.staged_version == b.version && b.version != 0; }
+template <class T>
+int bag_download(arp_ctx* c, const Bag& b, T* dst, const DevBuf<T>& src, int idx, size_t m) {
+    if (bag_is_staged(c, b)) {
+        if (m && dst) memcpy(dst, c->bag_stage + b.stage_off[idx], m * sizeof(T));
+        return ARP_OK;
+    }
+    return download_async(c, dst, src.p, m);
 }
 
 // One wavefront per ring / amide up to PLANE_BLOCKS blocks, several items per wave beyond: the waves queue their
@@ -1035,6 +1080,7 @@ bool finish_bag(arp_ctx* c, Bag& b, int slot) {
     if (k > b.cap) return true;
     b.count = (int64_t)k;
     b.valid = true;
+    ++b.version;
     return false;
 }
 int grow_pairs(arp_ctx* c) {
@@ -1143,6 +1189,8 @@ void arp_destroy(arp_ctx* c) {
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
+    c->bag_pack.release();
+    if (c->bag_stage) (void)hipHostFree(c->bag_stage);
     c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release(); c->longest_bond.release();
     c->rec_home.release(); c->rec_face[0].release(); c->rec_face[1].release(); c->sh_scan.release(); c->sh_src.release();
     c->origin.release(); c->ring_origin.release(); c->am_origin.release(); c->sh_sel.release();
@@ -2102,12 +2150,65 @@ int arp_group_plane_launch(arp_ctx* c, int64_t* count) {
     if ((bag).count > cap) FAIL(c, ARP_E_CAPACITY, what ": output buffer too small");             \
     const size_t m = (size_t)(bag).count;
 
+namespace {
+int stage_bags(arp_ctx* c) {
+    Bag* bags[4] = {&c->bag_ap, &c->bag_pp, &c->bag_gg, &c->bag_gp};
+    bool stale = false;
+    for (Bag* b : bags) stale = stale || (b->valid && b->staged_version != b->version);
+    if (!stale) return ARP_OK;
+    PackTable t;
+    t.n = 0;
+    size_t total = 0;
+    for (Bag* b : bags) {
+        if (!b->valid) continue;
+        const uint8_t* ptr[12] = {(const uint8_t*)b->a.p, (const uint8_t*)b->b.p, (const uint8_t*)b->d0.p, (const uint8_t*)b->d1.p,
+                                  (const uint8_t*)b->d2.p, (const uint8_t*)b->d3.p, (const uint8_t*)b->f0.p, (const uint8_t*)b->f1.p,
+                                  (const uint8_t*)b->f2.p, b->u0.p, b->u1.p, b->u2.p};
+        const size_t es[12] = {4, 4, 8, 8, 8, 8, 4, 4, 4, 1, 1, 1};
+        for (int k = 0; k < 12; ++k) {
+            b->stage_off[k] = (uint32_t)total;
+            if (!ptr[k] || b->count == 0) continue;
+            const size_t bytes = (size_t)b->count * es[k];
+            t.s[t.n++] = PackSeg{ptr[k], (uint32_t)total, (uint32_t)bytes};
+            total = (total + bytes + 15) & ~(size_t)15;
+        }
+    }
+    if (total > BAG_STAGE_MAX) {   // big bags (configs[4]): array by array, as before
+        for (Bag* b : bags) b->staged_version = 0;
+        return ARP_OK;
+    }
+    if (total > 0) {
+        if (c->bag_stage_cap < total) {
+            if (c->bag_stage) (void)hipHostFree(c->bag_stage);
+            c->bag_stage = nullptr;
+            c->bag_stage_cap = 0;
+            const size_t want = total + total / 2 + 4096;
+            if (hipHostMalloc((void**)&c->bag_stage, want, hipHostMallocDefault) != hipSuccess) { c->bag_stage = nullptr; return ARP_OK; }
+            c->bag_stage_cap = want;
+        }
+        HIPCHK(c, c->bag_pack.reserve(total));
+        hipLaunchKernelGGL(k_pack_segments, dim3(t.n), dim3(256), 0, c->stream, t, c->bag_pack.p);
+        CHK(check_launch(c, "k_pack_segments"));
+        HIPCHK(c, hipMemcpyAsync(c->bag_stage, c->bag_pack.p, total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else if (!c->bag_stage) {    // nothing to copy, but "staged" needs a buffer to point into
+        if (hipHostMalloc((void**)&c->bag_stage, 4096, hipHostMallocDefault) != hipSuccess) { c->bag_stage = nullptr; return ARP_OK; }
+        c->bag_stage_cap = 4096;
+    }
+    for (Bag* b : bags)
+        if (b->valid) b->staged_version = b->version;
+    return ARP_OK;
+}
+}  // namespace
+
 int arp_atom_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_atom, int32_t* out_ring, double* out_dist, double* out_theta,
                          uint8_t* out_mask, uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_ap, "arp_atom_plane_fetch")
     Bag& b = c->bag_ap;
-    CHK(download_async(c, out_atom, b.a.p, m)); CHK(download_async(c, out_ring, b.b.p, m)); CHK(download_async(c, out_dist, b.d0.p, m));
-    CHK(download_async(c, out_theta, b.d1.p, m)); CHK(download_async(c, out_mask, b.u0.p, m)); CHK(download(c, out_ctype, b.u1.p, m));
+    CHK(stage_bags(c));
+    CHK(bag_download(c, b, out_atom, b.a, 0, m)); CHK(bag_download(c, b, out_ring, b.b, 1, m)); CHK(bag_download(c, b, out_dist, b.d0, 2, m));
+    CHK(bag_download(c, b, out_theta, b.d1, 3, m)); CHK(bag_download(c, b, out_mask, b.u0, 9, m)); CHK(bag_download(c, b, out_ctype, b.u1, 10, m));
+    if (!bag_is_staged(c, b)) HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
 int arp_plane_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, double* out_dist, double* out_dihedral,
@@ -2115,25 +2216,31 @@ int arp_plane_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* ou
                           uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_pp, "arp_plane_plane_fetch")
     Bag& b = c->bag_pp;
-    CHK(download_async(c, out_bgn, b.a.p, m)); CHK(download_async(c, out_end, b.b.p, m)); CHK(download_async(c, out_dist, b.d0.p, m));
-    CHK(download_async(c, out_dihedral, b.d1.p, m)); CHK(download_async(c, out_theta_bgn, b.d2.p, m)); CHK(download_async(c, out_theta_end, b.d3.p, m));
-    CHK(download_async(c, out_type1, b.u0.p, m)); CHK(download_async(c, out_type2, b.u1.p, m)); CHK(download(c, out_ctype, b.u2.p, m));
+    CHK(stage_bags(c));
+    CHK(bag_download(c, b, out_bgn, b.a, 0, m)); CHK(bag_download(c, b, out_end, b.b, 1, m)); CHK(bag_download(c, b, out_dist, b.d0, 2, m));
+    CHK(bag_download(c, b, out_dihedral, b.d1, 3, m)); CHK(bag_download(c, b, out_theta_bgn, b.d2, 4, m)); CHK(bag_download(c, b, out_theta_end, b.d3, 5, m));
+    CHK(bag_download(c, b, out_type1, b.u0, 9, m)); CHK(bag_download(c, b, out_type2, b.u1, 10, m)); CHK(bag_download(c, b, out_ctype, b.u2, 11, m));
+    if (!bag_is_staged(c, b)) HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
 int arp_group_group_fetch(arp_ctx* c, int64_t cap, int32_t* out_bgn, int32_t* out_end, float* out_dist, float* out_dihedral,
                           float* out_theta, uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_gg, "arp_group_group_fetch")
     Bag& b = c->bag_gg;
-    CHK(download_async(c, out_bgn, b.a.p, m)); CHK(download_async(c, out_end, b.b.p, m)); CHK(download_async(c, out_dist, b.f0.p, m));
-    CHK(download_async(c, out_dihedral, b.f1.p, m)); CHK(download_async(c, out_theta, b.f2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
+    CHK(stage_bags(c));
+    CHK(bag_download(c, b, out_bgn, b.a, 0, m)); CHK(bag_download(c, b, out_end, b.b, 1, m)); CHK(bag_download(c, b, out_dist, b.f0, 6, m));
+    CHK(bag_download(c, b, out_dihedral, b.f1, 7, m)); CHK(bag_download(c, b, out_theta, b.f2, 8, m)); CHK(bag_download(c, b, out_ctype, b.u0, 9, m));
+    if (!bag_is_staged(c, b)) HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
 int arp_group_plane_fetch(arp_ctx* c, int64_t cap, int32_t* out_amide, int32_t* out_ring, double* out_dist, double* out_dihedral,
                           double* out_theta, uint8_t* out_ctype, int64_t* count) {
     FETCH_PROLOGUE(c->bag_gp, "arp_group_plane_fetch")
     Bag& b = c->bag_gp;
-    CHK(download_async(c, out_amide, b.a.p, m)); CHK(download_async(c, out_ring, b.b.p, m)); CHK(download_async(c, out_dist, b.d0.p, m));
-    CHK(download_async(c, out_dihedral, b.d1.p, m)); CHK(download_async(c, out_theta, b.d2.p, m)); CHK(download(c, out_ctype, b.u0.p, m));
+    CHK(stage_bags(c));
+    CHK(bag_download(c, b, out_amide, b.a, 0, m)); CHK(bag_download(c, b, out_ring, b.b, 1, m)); CHK(bag_download(c, b, out_dist, b.d0, 2, m));
+    CHK(bag_download(c, b, out_dihedral, b.d1, 3, m)); CHK(bag_download(c, b, out_theta, b.d2, 4, m)); CHK(bag_download(c, b, out_ctype, b.u0, 9, m));
+    if (!bag_is_staged(c, b)) HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
 
