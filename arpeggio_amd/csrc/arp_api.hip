@@ -450,7 +450,7 @@ int ensure_static(arp_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->longest_bond.p, 0, sizeof(float), c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p);
-        hipLaunchKernelGGL(k_longest_bond, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->xyz.p, c->bond_off.p, c->bond_idx.p,
+        hipLaunchKernelGGL(k_longest_bond, dim3(nblocks(n, 256, 512)), dim3(256), 0, c->stream, n, c->xyz.p, c->bond_off.p, c->bond_idx.p,
                            (unsigned int*)c->longest_bond.p);
         CHK(check_launch(c, "k_prepare_static"));
         // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure
@@ -917,6 +917,11 @@ int ensure_plane_lists(arp_ctx* c) {
     CHK(prepare_plane_plane(c, pp, n1));
     CHK(prepare_group_group(c, gg, n2));
     CHK(prepare_group_plane(c, gp, n3));
+    // one wavefront per ring / amide: a stencil walk is a chain of dependent loads, and this kernel runs alone
+    if (n0) n0 = nblocks(c->nring * 64, 256, 4096);
+    if (n1) n1 = nblocks(c->nring * 64, 256, 4096);
+    if (n2) n2 = nblocks(c->namide * 64, 256, 4096);
+    if (n3) n3 = nblocks(c->namide * 64, 256, 4096);
     if (n0 + n1 + n2 + n3 > 0) {
         hipLaunchKernelGGL(k_plane_lists, dim3(n0 + n1 + n2 + n3), dim3(256), 0, c->stream, ap, pp, gg, gp, plane_lists(c), n0, n0 + n1,
                            n0 + n1 + n2, n0 + n1 + n2 + n3);

@@ -625,38 +625,78 @@ struct PlaneLists {
     long long cap[4];
     u64* count;                // [4], device; may exceed cap (overflow: the host re-sizes and rebuilds)
 };
-struct ListSink {              // appends the lanes with ok to list k, one atomicAdd per wave
+// Appends the lanes with ok to list k.  The entries of a block gather in LDS (slots from an LDS counter) and leave with
+// ONE global atomicAdd when the block ends (flush_list): all the waves of the launch adding to the same four counters
+// were bound by the same-address atomic rate (~90 per microsecond), 74 us for config 3.  A block that overflows its LDS
+// queue appends the rest directly (one global atomicAdd per wave and call).
+#define LIST_QCAP 1024
+struct ListQueue { int2 q[LIST_QCAP]; int n, cut; unsigned long long base; };   // cut: first slot that was NOT written to LDS
+struct ListSink {
     const PlaneLists& L;
     int k, lane;
+    ListQueue* Q;
     __device__ __forceinline__ void operator()(bool ok, int x, int y) const {
         const unsigned long long m = __ballot(ok);
         if (!m) return;
+        int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&Q->n, __popcll(m));
+        slot0 = __shfl(slot0, 0);
+        const int slot = slot0 + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot0 + __popcll(m) <= LIST_QCAP) {
+            if (ok) Q->q[slot] = make_int2(x, y);
+            return;
+        }
+        // overflow: this call's LDS slots stay unwritten (the queue is cut at the first such slot), its entries go to the list directly
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(L.count + k, (unsigned long long)__popcll(m));
+        if (lane == 0) {
+            atomicMin(&Q->cut, slot0);
+            base = atomicAdd(L.count + k, (unsigned long long)__popcll(m));
+        }
         base = __shfl(base, 0);
-        const long long slot = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
-        if (ok && slot < L.cap[k]) L.pairs[k][slot] = make_int2(x, y);
+        const long long g = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && g < L.cap[k]) L.pairs[k][g] = make_int2(x, y);
     }
 };
+// (every thread of the block, after its enumeration)
+__device__ __forceinline__ void flush_list(const PlaneLists& L, int k, ListQueue* Q) {
+    __syncthreads();
+    // slots are handed out in order, so everything below the first slot of the first overflowing call was written
+    const int n = min(Q->n, Q->cut);
+    if (threadIdx.x == 0) Q->base = n > 0 ? atomicAdd(L.count + k, (unsigned long long)n) : 0ull;
+    __syncthreads();
+    const unsigned long long base = Q->base;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const long long g = (long long)base + i;
+        if (g < L.cap[k]) L.pairs[k][g] = Q->q[i];
+    }
+}
 // blocks [0, nb0) rings -> atom-plane list, [nb0, nb1) rings -> plane-plane, [nb1, nb2) amides -> group-group, rest -> group-plane
 __global__ __launch_bounds__(256) void k_plane_lists(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp,
                                                      PlaneLists L, int nb0, int nb1, int nb2, int nb3) {
+    __shared__ ListQueue s_lq;
+    if (threadIdx.x == 0) { s_lq.n = 0; s_lq.cut = LIST_QCAP; }
+    __syncthreads();
     const int b = (int)blockIdx.x, lane = threadIdx.x & 63;
+    int kind = 3;
     if (b < nb0) {
+        kind = 0;
         const int wave = (b * 256 + (int)threadIdx.x) >> 6, nwave = nb0 * 4;
         // the list holds local atom ids: translate the sorted position
-        auto sink = [&](bool ok, int r, int j) { ListSink{L, 0, lane}(ok, r, ok ? ap.s_aux[j].x : 0); };
+        auto sink = [&](bool ok, int r, int j) { ListSink{L, 0, lane, &s_lq}(ok, r, ok ? ap.s_aux[j].x : 0); };
         for (int r = wave; r < ap.nring; r += nwave) ap_enumerate<false>(ap, r, lane, sink);
     } else if (b < nb1) {
+        kind = 1;
         const int wave = ((b - nb0) * 256 + (int)threadIdx.x) >> 6, nwave = (nb1 - nb0) * 4;
-        for (int a = wave; a < pp.nring; a += nwave) pp_enumerate<false>(pp, a, lane, ListSink{L, 1, lane});
+        for (int a = wave; a < pp.nring; a += nwave) pp_enumerate<false>(pp, a, lane, ListSink{L, 1, lane, &s_lq});
     } else if (b < nb2) {
+        kind = 2;
         const int wave = ((b - nb1) * 256 + (int)threadIdx.x) >> 6, nwave = (nb2 - nb1) * 4;
-        for (int a = wave; a < gg.namide; a += nwave) gg_enumerate<false>(gg, a, lane, ListSink{L, 2, lane});
+        for (int a = wave; a < gg.namide; a += nwave) gg_enumerate<false>(gg, a, lane, ListSink{L, 2, lane, &s_lq});
     } else if (b < nb3) {
         const int wave = ((b - nb2) * 256 + (int)threadIdx.x) >> 6, nwave = (nb3 - nb2) * 4;
-        for (int a = wave; a < gp.namide; a += nwave) gp_enumerate<false>(gp, a, lane, ListSink{L, 3, lane});
+        for (int a = wave; a < gp.namide; a += nwave) gp_enumerate<false>(gp, a, lane, ListSink{L, 3, lane, &s_lq});
     }
+    flush_list(L, kind, &s_lq);
 }
 
 // The ring / amide loops of a pass from the lists: waves take chunks of 64 list entries (a chunk never straddles two

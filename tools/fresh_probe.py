@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""A new structure every step (blob upload + first pass), for a kernel trace of the per-structure work:
+    rocprofv3 --kernel-trace --output-format csv -d out -o t -- python tools/fresh_probe.py
+    python tools/fresh_timeline.py out/t_kernel_trace.csv"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from arpeggio_amd import _capi, synth  # noqa: E402
+
+blobs = [_capi.pack_blob(synth.config3(100_000, seed=3 + k)) for k in range(3)]
+ctx = _capi.Context(0)
+for rep in range(4):
+    for b in blobs:
+        ctx.set_blob(b)
+        ctx.run_launch(5.0, 0.1, False, 6.0)
