@@ -513,6 +513,15 @@ __device__ __forceinline__ int cand_pos(int k, int o1, int o2, int o3, int o4, i
     d = (k >= o4) ? d4 : d;
     return d + k;
 }
+// (v << 1) | (d <= thr) in TWO instructions: the compare writes its lane mask to an SGPR pair, which is the carry-in of
+// v + v + carry — the select / shift / or the compiler makes of the C expression were a third of the distance loop's VALU work
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t shl1_or_le(uint32_t v, float d, float thr) {   // (v << 1) | (d <= thr)
+    uint32_t r;
+    unsigned long long m;
+    asm("v_cmp_le_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %4, %4, %1" : "=v"(r), "=&s"(m) : "v"(d), "v"(thr), "v"(v));
+    return r;
+}
 __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
     unsigned long long s = v;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -664,36 +673,44 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                 // float32 pre-filter: |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded squares, two
                 // rounded sums), so outside the +-1e-5 band the float32 answer IS the float64 answer.
                 uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+                const v2f cx = {x0.x, x1.x}, cy = {x0.y, x1.y}, cz = {x0.z, x1.z};
 #pragma unroll 1
                 for (int hh = hcount - 1; hh >= 0; --hh) {
                     // broadcast the home atom from lane hh (v_readlane, no memory traffic)
                     const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh));
                     const float hy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh));
                     const float hz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.z), hh));
-                    const int t = t0 + hh;
-                    bool te0 = kk0 > t, te1 = kk1 > t;
-                    if (MODE == MODE_MARK) {
-                        const bool sh = (m_selh >> hh) & 1u;
-                        te0 = te0 && (selj0 != sh);
-                        te1 = te1 && (selj1 != sh);
-                    }
-                    const float dx0 = hx - x0.x, dy0 = hy - x0.y, dz0 = hz - x0.z;
-                    const float dx1 = hx - x1.x, dy1 = hy - x1.y, dz1 = hz - x1.z;
-                    const float d0 = fmaf(dz0, dz0, fmaf(dy0, dy0, dx0 * dx0));   // any rounding order fits the 4e-7 bound
-                    const float d1 = fmaf(dz1, dz1, fmaf(dy1, dy1, dx1 * dx1));
-                    lo0 = (lo0 << 1) | (uint32_t)(te0 && d0 <= r2_lo);
-                    hi0 = (hi0 << 1) | (uint32_t)(te0 && d0 <= r2_hi);
-                    lo1 = (lo1 << 1) | (uint32_t)(te1 && d1 <= r2_lo);
-                    hi1 = (hi1 << 1) | (uint32_t)(te1 && d1 <= r2_hi);
+                    const v2f dx = hx - cx, dy = hy - cy, dz = hz - cz;          // both candidates of the lane at once (v_pk_*)
+                    const v2f dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));   // any rounding order fits the 4e-7 bound
+                    const float d0 = dd.x, d1 = dd.y;
+                    // bit hh of the masks (the loop runs downwards and shifts left); which pairs are to be tested at all does
+                    // not depend on the distance and is applied to the finished masks below
+                    lo0 = shl1_or_le(lo0, d0, r2_lo);
+                    hi0 = shl1_or_le(hi0, d0, r2_hi);
+                    lo1 = shl1_or_le(lo1, d1, r2_lo);
+                    hi1 = shl1_or_le(hi1, d1, r2_hi);
                     if (count_owned) {
                         // sharded run: a boundary pair is tested on two ranks; count it for the owner of its bgn atom only
+                        const int t = t0 + hh;
+                        const bool te0 = kk0 > t, te1 = kk1 > t;
                         const int lh = __builtin_amdgcn_readlane(hauxreg.x, hh);
                         const uint32_t mh0 = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
                         n_cand += (unsigned)(te0 && (((lh < a0.x) ? mh0 : mj0) & M_HOME));
                         n_cand += (unsigned)(te1 && (((lh < a1.x) ? mh0 : mj1) & M_HOME));
-                    } else if (MODE == MODE_MARK) {
-                        n_cand += (unsigned)te0 + (unsigned)te1;
                     }
+                }
+                {   // pairs that are tested: candidate k of the home pencil meets home atom t iff k > t (bit hh <-> t = t0 + hh)
+                    auto tested = [&](int kk) -> uint32_t {
+                        const int c = kk - t0;
+                        return kk < 0 ? 0u : (c >= 32 ? 0xFFFFFFFFu : (c <= 0 ? 0u : ((1u << c) - 1u)));
+                    };
+                    uint32_t te0 = tested(kk0), te1 = tested(kk1);
+                    if (MODE == MODE_MARK) {   // ... and, for the expansion, only pairs with exactly one selected atom
+                        te0 &= selj0 ? ~m_selh : m_selh;
+                        te1 &= selj1 ? ~m_selh : m_selh;
+                        n_cand += __popc(te0 & m_hvalid) + __popc(te1 & m_hvalid);
+                    }
+                    lo0 &= te0; hi0 &= te0; lo1 &= te1; hi1 &= te1;
                 }
                 // inside the band (rare) the exact Bio.PDB.kdtrees float64 test decides
                 uint32_t band0 = hi0 & ~lo0, band1 = hi1 & ~lo1;
