@@ -992,7 +992,12 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     if (have_planes) {
         long long entries = 0;
         for (int k = 0; k < 4; ++k) entries += std::min<long long>((long long)c->plist[k].cap, c->plist_known[k] >= 0 ? c->plist_known[k] + 64 : (long long)c->plist[k].cap / 4);
-        np = (int)std::min<long long>(std::max<long long>((entries + 255) / 256, 8), 1024);
+        // Few, fat blocks: they and the sift blocks of the same launch must ALL be resident from the start (the sift
+        // blocks split their work statically: one that had to wait for a slot would finish that much later than the rest),
+        // so the sift part gets num_cu * blocks-per-CU minus these.  Sixteen list chunks (of 64 entries) per wave are still
+        // inside the time the sift blocks need (sweep in profiles/README.md); ring-heavy structures get more blocks, up to half the slots.
+        static const int chunks_per_wave = std::max(1, env_int("ARP_PLANE_CPW", 16));
+        np = (int)std::min<long long>(std::max<long long>((entries + 256 * chunks_per_wave - 1) / (256 * chunks_per_wave), 8), 2 * c->num_cu);
         np = (np + 7) & ~7;
     }
     static const int planes_mode = env_int("ARP_PLANES_MODE", 0);   // 0: one grid with the sift kernel; 1: second stream
@@ -1027,7 +1032,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                           SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + C_ERR)};
-        const int nsift = c->num_cu * sift_blocks_per_cu;
+        const int nsift = merged ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1) : c->num_cu * sift_blocks_per_cu;
         if (merged)
             hipLaunchKernelGGL(k_sift_planes, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
                                c->d_ctr + C_PLIST, np, c->pub);
