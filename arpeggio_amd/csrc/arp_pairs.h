@@ -976,6 +976,7 @@ struct SiftArgs {
 struct SiftShared {
     uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
     double2 tab[RAD_TABLE];      // the structure's distinct {vdw, cov} pairs
+    float4 thr[256];             // for the first 16 of them, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), -}
 };
 // vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
 // vblock % 8 is still the XCD the dispatcher put the block on)
@@ -1004,6 +1005,12 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
     // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
     s_tab[threadIdx.x] = sd.rad_tab[threadIdx.x];   // (blockDim.x == RAD_TABLE)
+    {   // the three float32 thresholds of the ladder (I:717-718, 756-773: float64 sums, compared as float32) depend on the two
+        // radius pairs only: for the common case — both atoms among the first 16 table entries — they are looked up, not computed
+        const double2 ra = sd.rad_tab[threadIdx.x >> 4], rb_ = sd.rad_tab[threadIdx.x & 15];
+        const double sv = ra.x + rb_.x;
+        sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), 0.0f);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int tn = 0;
@@ -1044,8 +1051,18 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
         const bool bw = mb & M_WATER, ew = me & M_WATER;
         const int ct = contact_type(mb & M_SEL, me & M_SEL, bw, ew);  // interactions.py:715
-        const double2 rb = rec_rad(qb.q1, s_tab, sd), re = rec_rad(qe.q1, s_tab, sd);   // {vdw, cov}
-        const double sum_cov = rb.y + re.y, sum_vdw = rb.x + re.x;      // interactions.py:717-718
+        float f_sum_cov, f_sum_vdw, f_vdw_comp;                         // interactions.py:717-718 and the casts of 756-773
+        {
+            const unsigned rib = (unsigned)qb.q1.w >> 16, rie = (unsigned)qe.q1.w >> 16;
+            if ((rib | rie) < 16u) {
+                const float4 t = sh->thr[rib * 16u + rie];
+                f_sum_cov = t.x; f_sum_vdw = t.y; f_vdw_comp = t.z;
+            } else {
+                const double2 rb = rec_rad(qb.q1, s_tab, sd), re = rec_rad(qe.q1, s_tab, sd);   // {vdw, cov}
+                const double sum_vdw = rb.x + re.x;
+                f_sum_cov = (float)(rb.y + re.y); f_sum_vdw = (float)sum_vdw; f_vdw_comp = (float)(sum_vdw + comp);
+            }
+        }
         const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
         uint32_t s = 0;
         unsigned need = 0;
@@ -1055,11 +1072,9 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             for (int k = qb.q1.y, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
                 if (bond_idx[k] == e) { cov = true; break; }
         // interactions.py:756-773: float32 distance against Python floats -> float32 compare
-        const double vdw_comp = sum_vdw + comp;
-        const float f_vdw_comp = (float)vdw_comp;
         if (cov) s |= ARP_S_COVALENT;
-        else if (d < (float)sum_cov) s |= ARP_S_CLASH;
-        else if (d < (float)sum_vdw) s |= ARP_S_VDW_CLASH;
+        else if (d < f_sum_cov) s |= ARP_S_CLASH;
+        else if (d < f_sum_vdw) s |= ARP_S_VDW_CLASH;
         else if (d <= f_vdw_comp) s |= ARP_S_VDW;
         else s |= ARP_S_PROXIMAL;
         // interactions.py:777-783
