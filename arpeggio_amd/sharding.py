@@ -331,26 +331,33 @@ class _DevAlias:
 def exchange_device_buffers(dist, device, rank, world, payload):
     """payload: side -> (device pointer, bytes) of the buffer for rank + side.  Returns side -> (pointer, bytes, tensor)
     of what the neighbours sent; the tensor owns the memory.  Sizes first (one int64 each way), then the buffers, both
-    with grouped isend / irecv on device memory — RCCL over xGMI under the nccl backend."""
+    with grouped isend / irecv on device memory — RCCL over xGMI under the nccl backend.  ``device=None`` (gloo, the
+    one-GPU debug mode of bench.py): the buffers make a detour through host tensors, everything else is the same."""
     import torch
     sides = [s for s in (-1, +1) if 0 <= rank + s < world]
-    lens_out = {s: torch.tensor([payload[s][1]], dtype=torch.int64, device=device) for s in sides}
-    lens_in = {s: torch.zeros(1, dtype=torch.int64, device=device) for s in sides}
+    gpu = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    wire = device if device is not None else torch.device('cpu')
+    lens_out = {s: torch.tensor([payload[s][1]], dtype=torch.int64, device=wire) for s in sides}
+    lens_in = {s: torch.zeros(1, dtype=torch.int64, device=wire) for s in sides}
     ops = []
     for s in sides:
         ops.append(dist.P2POp(dist.isend, lens_out[s], rank + s))
         ops.append(dist.P2POp(dist.irecv, lens_in[s], rank + s))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
-    out_t = {s: torch.as_tensor(_DevAlias(payload[s][0], payload[s][1]), device=device) for s in sides}
-    in_t = {s: torch.empty(int(lens_in[s].item()), dtype=torch.uint8, device=device) for s in sides}
+    out_t = {s: torch.as_tensor(_DevAlias(payload[s][0], payload[s][1]), device=gpu) for s in sides}
+    if device is None:
+        out_t = {s: t.cpu() for s, t in out_t.items()}
+    in_t = {s: torch.empty(int(lens_in[s].item()), dtype=torch.uint8, device=wire) for s in sides}
     ops = []
     for s in sides:
         ops.append(dist.P2POp(dist.isend, out_t[s], rank + s))
         ops.append(dist.P2POp(dist.irecv, in_t[s], rank + s))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
-    torch.cuda.synchronize(device)
+    if device is None:
+        in_t = {s: t.to(gpu) for s, t in in_t.items()}
+    torch.cuda.synchronize(gpu)
     return {s: (int(in_t[s].data_ptr()), int(in_t[s].numel()), in_t[s]) for s in sides}
 
 

@@ -120,6 +120,8 @@ def main():
         # no fallback: if the exchange over RCCL fails, the run fails (a scaling figure must not be printed without it)
         ctx = _capi.Context(local_rank)
         t_sh = time.perf_counter()
+        if args.staged_exchange and comm_device is None:
+            args.host_halo = True      # (one-GPU debug mode over gloo: the per-step exchange then goes through host buffers, which needs the host-side shard)
         if args.host_halo:
             halo_note = 'records of the one-cell halo packed on the host, exchanged with grouped isend/irecv (RCCL), merged on the host'
             shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)

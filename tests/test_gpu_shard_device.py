@@ -154,6 +154,13 @@ assert np.array_equal(union, key(ref)), (len(union), len(ref['i']))
 c1 = _capi.Context(0)
 ds = sharding.make_shard_device(c1, full, 0, 1, dist, dev, whole_structure=True)
 assert ds.n_atoms == full.n_atoms and sharding.run_shard_whole_structure(c1, sh=ds) == n1
+# ... and the three-stage pass with the exchange objects built from a device-assembled shard
+sel = (full.res_id %% 7 == 3).astype(np.uint8)
+c2 = _capi.Context(0)
+ds2 = sharding.make_shard_device(c2, full, 0, 1, dist, dev, sel=sel)
+ex = sharding.DeviceExchange(c2, ds2, dist, dev)
+one.set_selection(sel)
+assert sharding.run_shard_device(c2, ex) == one.run_launch()
 dist.destroy_process_group()
 print('TORCH_ALIAS_OK')
 """
