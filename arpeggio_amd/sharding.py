@@ -321,6 +321,7 @@ class DeviceShard:
     halo: float = 0.0                 # width the faces were cut with: no search radius of a run may exceed it
     halo_ms: float = 0.0
     halo_bytes: int = 0
+    timings_ms: Optional[dict] = None # where the set-up time went: host packing of the home records / device work / exchange
 
 
 class _DevAlias:
@@ -367,9 +368,12 @@ def shard_home_to_device(ctx, full: PackedComplex, rank: int, world: int, sel=No
     halo = halo_width(cutoff)
     edges, a_own, r_own, m_own = _partition(full, world, halo)
     from . import _capi
+    t0 = time.perf_counter()
     home_ids = np.nonzero(a_own == rank)[0]
     home = pack_records(full, home_ids, np.nonzero(r_own == rank)[0], np.nonzero(m_own == rank)[0], sel)
-    ctx.shard_set_home(_capi.pack_records_buffer(home))
+    buf = _capi.pack_records_buffer(home)
+    t1 = time.perf_counter()
+    ctx.shard_set_home(buf)
     faces, sends = {}, {}
     hx = full.xyz[home_ids, 0].astype(np.float64)
     for side in (-1, +1):
@@ -377,12 +381,16 @@ def shard_home_to_device(ctx, full: PackedComplex, rank: int, world: int, sel=No
             lo, hi = (-np.inf, edges[rank] + halo) if side < 0 else (edges[rank + 1] - halo, np.inf)
             faces[side] = ctx.shard_pack_face(0 if side < 0 else 1, lo, hi)
             sends[side] = home_ids[(hx >= lo) & (hx <= hi)]           # the same comparison the kernel makes
-    return faces, dict(sends=sends, halo=halo, n_res_global=full.n_residues, rank=rank, world=world)
+    t2 = time.perf_counter()
+    return faces, dict(sends=sends, halo=halo, n_res_global=full.n_residues, rank=rank, world=world,
+                       timings={'host_pack_home_records': (t1 - t0) * 1e3, 'upload_home_and_cut_faces': (t2 - t1) * 1e3})
 
 
 def finish_shard_on_device(ctx, received, book, whole_structure=False) -> DeviceShard:
     """Step 3: merge home + received halos in HBM; ``received``: side -> (pointer, bytes[, owner])."""
+    t0 = time.perf_counter()
     ctx.shard_assemble(received.get(-1), received.get(+1), book['n_res_global'])
+    t1 = time.perf_counter()
     lay = ctx.shard_layout()
     sel = lay['sel']
     if whole_structure:
@@ -391,7 +399,8 @@ def finish_shard_on_device(ctx, received, book, whole_structure=False) -> Device
     else:
         ctx.set_selection(sel)
     ctx.set_whole_structure(whole_structure)
-    return DeviceShard(n_atoms=ctx.n, is_home=(lay['origin'] == 0).astype(np.uint8), global_id=lay['global_id'], origin=lay['origin'],
+    timings = dict(book.get('timings', {}), merge_on_device=(t1 - t0) * 1e3, id_maps_and_selection=(time.perf_counter() - t1) * 1e3)
+    return DeviceShard(timings_ms={k: round(v, 3) for k, v in timings.items()}, n_atoms=ctx.n, is_home=(lay['origin'] == 0).astype(np.uint8), global_id=lay['global_id'], origin=lay['origin'],
                        sel=sel, ring_home=(lay['ring_origin'] == 0).astype(np.uint8), ring_gid=lay['ring_gid'],
                        amide_home=(lay['amide_origin'] == 0).astype(np.uint8), amide_gid=lay['amide_gid'],
                        n_res_global=book['n_res_global'], rank=book['rank'], world=book['world'],
@@ -409,6 +418,7 @@ def make_shard_device(ctx, full: PackedComplex, rank: int, world: int, dist, dev
     sh = finish_shard_on_device(ctx, received, book, whole_structure)
     sh.halo_ms = ms
     sh.halo_bytes = int(sum(v[1] for v in faces.values()))
+    sh.timings_ms['exchange'] = round(ms, 3)
     return sh
 
 

@@ -99,7 +99,7 @@ def main():
 
     # ---------------- workload ----------------
     t0 = time.perf_counter()
-    halo_ms, halo_bytes, shard_setup_ms = 0.0, 0, 0.0
+    halo_ms, halo_bytes, shard_setup_ms, shard_timings = 0.0, 0, 0.0, None
     if world == 1:
         if args.workload == 'standin':
             pc = synth.proteinlike()
@@ -132,6 +132,7 @@ def main():
                          'device buffers (RCCL), merged into the resident structure on the device (arp_shard_*)')
             shard = sharding.make_shard_device(ctx, full, rank, world, dist, comm_device, whole_structure=not args.staged_exchange)
             n_local = shard.n_atoms
+            shard_timings = shard.timings_ms
         shard_setup_ms = (time.perf_counter() - t_sh) * 1e3
         halo_ms, halo_bytes = shard.halo_ms, shard.halo_bytes
         n_local_home = int(shard.is_home.sum())
@@ -518,7 +519,7 @@ def main():
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
         'launch_mode': 'four launches on one HIP stream (bin, scan+scatter, search, sift+ring/amide loops), the last one publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
-        'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2),
+        'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2), 'shard_setup_breakdown_ms': shard_timings,
         'halo_exchange': (halo_note if world > 1 else None), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'end_to_end': end_to_end,
         'end_to_end_ms_per_structure': (end_to_end or {}).get('ms_per_structure'),
