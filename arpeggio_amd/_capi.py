@@ -29,8 +29,8 @@ SYMBOLS = (
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
     'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
-    'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob',
-    'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_shard_set_home', 'arp_shard_pack_face',
+    'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob', 'arp_blob_fill',
+    'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_records_fill', 'arp_shard_set_home', 'arp_shard_pack_face',
     'arp_shard_assemble', 'arp_shard_layout', 'arp_get_blob', 'arp_cif_open', 'arp_cif_close', 'arp_cif_rows', 'arp_cif_cols',
     'arp_cif_blocks', 'arp_cif_tag', 'arp_cif_text', 'arp_cif_column', 'arp_cif_column_f64', 'arp_cif_column_i64',
 )
@@ -80,9 +80,11 @@ def load():
     L.arp_blob_size.restype = C.c_uint64
     L.arp_blob_layout.argtypes = [vp, C.c_uint64] + [i64] * 6
     L.arp_set_blob.argtypes = [vp, vp, C.c_uint64]
+    L.arp_blob_fill.argtypes = [vp, C.c_uint64] + [vp] * 20
     L.arp_records_size.argtypes = [i64] * 5
     L.arp_records_size.restype = C.c_uint64
     L.arp_records_layout.argtypes = [vp, C.c_uint64] + [i64] * 5
+    L.arp_records_fill.argtypes = [vp, C.c_uint64, i64] + [vp] * 24
     L.arp_shard_set_home.argtypes = [vp, vp, C.c_uint64]
     L.arp_shard_pack_face.argtypes = [vp, i32, dbl, dbl, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.arp_shard_assemble.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, i64, vp]
@@ -181,50 +183,14 @@ def pack_blob(pc, pinned=True):
     buf = pinned_empty(size, np.uint8) if pinned else np.empty(size, np.uint8)
     if L.arp_blob_layout(_p(buf), size, n, nres, nbond, nh, nring, namide) != ARP_OK:
         raise ValueError('arp_blob_layout failed')
-    hdr = BlobHeader.from_buffer(buf)
-    counts = (4 * n, 2 * n, n, n, n, nres, nres, nres, n + 1, nbond, n + 1, 3 * nh, n, 3 * nring, 3 * nring, nring, 3 * namide,
-              3 * namide, namide, n, 512)
-    v = [np.frombuffer(buf, dtype=dt, count=cnt, offset=int(hdr.off[k])) for k, (dt, cnt) in enumerate(zip(_BLOB_DTYPES, counts))]
-    x4 = v[0].reshape(-1, 4)
-    x4[:, :3] = pc.xyz
-    x4[:, 3] = 0.0
-    r2 = v[1].reshape(-1, 2)
-    r2[:, 0], r2[:, 1] = pc.vdw, pc.cov
-    v[2][:], v[3][:], v[4][:] = pc.type_mask, pc.flags, pc.res_id
-    v[5][:], v[6][:], v[7][:] = pc.res_flags, pc.res_prev, pc.res_next
-    v[8][:], v[9][:], v[10][:] = pc.bond_off, pc.bond_idx, pc.h_off
-    v[11][:] = pc.h_xyz.reshape(-1)
-    v[12][:] = pc.sb_nbr
-    v[13][:], v[14][:], v[15][:] = pc.ring_center.reshape(-1), pc.ring_normal.reshape(-1), pc.ring_res
-    v[16][:], v[17][:], v[18][:] = pc.amide_center.reshape(-1), pc.amide_normal.reshape(-1), pc.amide_res
-    # dictionary of the distinct {vdw, cov} pairs (a handful of element values), compared bit for bit
-    tab = v[20].reshape(256, 2)
-    tab[:] = 0.0
-    if n:
-        keys = r2.view(np.uint64).reshape(-1, 2)
-        uniq, inv = np.unique(keys, axis=0, return_inverse=True)
-        inv = inv.reshape(-1)
-        if len(uniq) <= 256:
-            tab[:len(uniq)] = uniq.view(np.float64)
-            v[19][:] = inv
-            hdr.n_rad = len(uniq)
-        else:   # keep the 256 most frequent pairs, the rest fetch their radii from the per-atom array
-            cnt = np.bincount(inv, minlength=len(uniq))
-            keep = np.argsort(-cnt, kind='stable')[:256]
-            slot = np.full(len(uniq), 0xFFFF, np.int64)
-            slot[keep] = np.arange(256)
-            tab[:] = uniq[keep].view(np.float64)
-            v[19][:] = slot[inv]
-            hdr.n_rad = 256
-    else:
-        hdr.n_rad = 0
-    for name, arr in (('', pc.xyz), ('ring_', pc.ring_center), ('amide_', pc.amide_center)):
-        lo = arr.min(axis=0).astype(np.float64) if len(arr) else np.zeros(3)
-        hi = arr.max(axis=0).astype(np.float64) if len(arr) else np.zeros(3)
-        for k in range(3):
-            getattr(hdr, name + 'lo')[k] = lo[k]
-            getattr(hdr, name + 'hi')[k] = hi[k]
-    del hdr
+    c = lambda a, dt: np.ascontiguousarray(a, dt)
+    arrays = [c(pc.xyz, np.float32), c(pc.vdw, np.float64), c(pc.cov, np.float64), c(pc.type_mask, np.uint16), c(pc.flags, np.uint16),
+              c(pc.res_id, np.int32), c(pc.res_flags, np.uint8), c(pc.res_prev, np.int32), c(pc.res_next, np.int32),
+              c(pc.bond_off, np.int32), c(pc.bond_idx, np.int32), c(pc.h_off, np.int32), c(pc.h_xyz, np.float64), c(pc.sb_nbr, np.int32),
+              c(pc.ring_center, np.float64), c(pc.ring_normal, np.float64), c(pc.ring_res, np.int32), c(pc.amide_center, np.float32),
+              c(pc.amide_normal, np.float32), c(pc.amide_res, np.int32)]
+    if L.arp_blob_fill(_p(buf), size, *[_p(a) for a in arrays]) != ARP_OK:
+        raise ValueError('arp_blob_fill failed')
     return buf
 
 
@@ -311,6 +277,33 @@ def pack_records_buffer(rec, pinned=True):
             getattr(hdr, name + 'lo')[k] = lo[k]
             getattr(hdr, name + 'hi')[k] = hi[k]
     del hdr
+    return buf
+
+
+def pack_records_native(pc, atom_ids, ring_ids, amide_ids, sel=None, pinned=True):
+    """The record buffer of the given atoms / rings / amides of ``pc`` (ascending packed indices = global ids), packed by the
+    library (``arp_records_fill``): the same bytes as ``pack_records_buffer(sharding.pack_records(...))``, ~50x sooner."""
+    L = load()
+    a = np.ascontiguousarray(atom_ids, np.int64)
+    r = np.ascontiguousarray(ring_ids, np.int64)
+    m = np.ascontiguousarray(amide_ids, np.int64)
+    h_off, b_off = np.ascontiguousarray(pc.h_off, np.int32), np.ascontiguousarray(pc.bond_off, np.int32)
+    nh = int((h_off[a + 1] - h_off[a]).sum()) if a.size else 0
+    nb = int((b_off[a + 1] - b_off[a]).sum()) if a.size else 0
+    size = int(L.arp_records_size(a.size, nh, nb, r.size, m.size))
+    if size == 0:
+        raise ValueError('pack_records_native: counts out of range')
+    buf = pinned_empty(size, np.uint8) if pinned else np.empty(size, np.uint8)
+    if L.arp_records_layout(_p(buf), size, a.size, nh, nb, r.size, m.size) != ARP_OK:
+        raise ValueError('arp_records_layout failed')
+    c = lambda x, dt: np.ascontiguousarray(x, dt)
+    arrays = [c(pc.xyz, np.float32), c(pc.vdw, np.float64), c(pc.cov, np.float64), c(pc.type_mask, np.uint16), c(pc.flags, np.uint16),
+              c(pc.res_id, np.int32), c(pc.res_flags, np.uint8), c(pc.res_prev, np.int32), c(pc.res_next, np.int32), b_off,
+              c(pc.bond_idx, np.int32), h_off, c(pc.h_xyz, np.float64), c(pc.sb_nbr, np.int32), c(pc.ring_center, np.float64),
+              c(pc.ring_normal, np.float64), c(pc.ring_res, np.int32), c(pc.amide_center, np.float32), c(pc.amide_normal, np.float32),
+              c(pc.amide_res, np.int32), (None if sel is None else c(sel, np.uint8)), a, r, m]
+    if L.arp_records_fill(_p(buf), size, pc.n_atoms, *[_p(x) for x in arrays]) != ARP_OK:
+        raise ValueError('arp_records_fill failed (ids must ascend and lie inside the structure)')
     return buf
 
 

@@ -1455,6 +1455,109 @@ int arp_blob_layout(void* blob, uint64_t bytes, int64_t n, int64_t nres, int64_t
     return ARP_OK;
 }
 
+int arp_blob_fill(void* blob, uint64_t bytes, const float* xyz, const double* vdw, const double* cov, const uint16_t* type_mask,
+                  const uint16_t* flags, const int32_t* res_id, const uint8_t* res_flags, const int32_t* res_prev,
+                  const int32_t* res_next, const int32_t* bond_off, const int32_t* bond_idx, const int32_t* h_off,
+                  const double* h_xyz, const int32_t* sb_nbr, const double* ring_center, const double* ring_normal,
+                  const int32_t* ring_res, const float* amide_center, const float* amide_normal, const int32_t* amide_res) {
+    if (!blob || bytes < sizeof(arp_blob_header)) return ARP_E_ARG;
+    arp_blob_header h;
+    memcpy(&h, blob, sizeof(h));
+    if (h.magic != ARP_BLOB_MAGIC || h.bytes > bytes || h.bytes != arp_blob_size(h.n, h.nres, h.nbond, h.nh, h.nring, h.namide)) return ARP_E_ARG;
+    const int64_t n = h.n;
+    if ((n > 0 && (!xyz || !vdw || !cov || !type_mask || !flags || !res_id || !bond_off || !h_off || !sb_nbr)) ||
+        (h.nres > 0 && (!res_flags || !res_prev || !res_next)) || (h.nbond > 0 && !bond_idx) || (h.nh > 0 && !h_xyz) ||
+        (h.nring > 0 && (!ring_center || !ring_normal || !ring_res)) || (h.namide > 0 && (!amide_center || !amide_normal || !amide_res)))
+        return ARP_E_ARG;
+    uint8_t* const b = (uint8_t*)blob;
+    auto at = [&](int k) { return b + h.off[k]; };
+    float* x4 = (float*)at(0);
+    double* r2 = (double*)at(1);
+    for (int64_t i = 0; i < n; ++i) {
+        x4[4 * i] = xyz[3 * i]; x4[4 * i + 1] = xyz[3 * i + 1]; x4[4 * i + 2] = xyz[3 * i + 2]; x4[4 * i + 3] = 0.0f;
+        r2[2 * i] = vdw[i]; r2[2 * i + 1] = cov[i];
+    }
+    auto copy = [&](int k, const void* src, size_t nbytes) { if (nbytes) memcpy(at(k), src, nbytes); };
+    copy(2, type_mask, (size_t)n * 2); copy(3, flags, (size_t)n * 2); copy(4, res_id, (size_t)n * 4);
+    copy(5, res_flags, (size_t)h.nres); copy(6, res_prev, (size_t)h.nres * 4); copy(7, res_next, (size_t)h.nres * 4);
+    if (n > 0) { copy(8, bond_off, ((size_t)n + 1) * 4); copy(10, h_off, ((size_t)n + 1) * 4); }
+    else { const int32_t z = 0; copy(8, &z, 4); copy(10, &z, 4); }
+    copy(9, bond_idx, (size_t)h.nbond * 4); copy(11, h_xyz, (size_t)h.nh * 24); copy(12, sb_nbr, (size_t)n * 4);
+    copy(13, ring_center, (size_t)h.nring * 24); copy(14, ring_normal, (size_t)h.nring * 24); copy(15, ring_res, (size_t)h.nring * 4);
+    copy(16, amide_center, (size_t)h.namide * 12); copy(17, amide_normal, (size_t)h.namide * 12); copy(18, amide_res, (size_t)h.namide * 4);
+    // dictionary of the distinct {vdw, cov} pairs, compared bit for bit: a handful of element values in practice, so a
+    // small open-addressing table keyed by the 128 bits; entries are numbered in ascending (vdw bits, cov bits) order
+    uint16_t* ridx = (uint16_t*)at(19);
+    double* tab = (double*)at(20);
+    memset(tab, 0, sizeof(double) * 2 * RAD_TABLE);
+    struct Key { uint64_t a, b; int64_t count; int slot; };
+    std::vector<Key> keys;
+    std::vector<int> hash(4096, -1);
+    std::vector<int> key_of((size_t)n);
+    auto bits = [](double d) { uint64_t u; memcpy(&u, &d, 8); return u; };
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t ka = bits(vdw[i]), kb = bits(cov[i]);
+        size_t hpos = (size_t)((ka * 0x9E3779B97F4A7C15ull) ^ (kb * 0xC2B2AE3D27D4EB4Full)) >> 20;
+        int found = -1;
+        for (;;) {
+            hpos &= hash.size() - 1;
+            const int k = hash[hpos];
+            if (k < 0) break;
+            if (keys[(size_t)k].a == ka && keys[(size_t)k].b == kb) { found = k; break; }
+            ++hpos;
+        }
+        if (found < 0) {
+            if (keys.size() * 2 >= hash.size()) {   // grow and re-insert
+                std::vector<int> bigger(hash.size() * 4, -1);
+                for (size_t k = 0; k < keys.size(); ++k) {
+                    size_t p = (size_t)((keys[k].a * 0x9E3779B97F4A7C15ull) ^ (keys[k].b * 0xC2B2AE3D27D4EB4Full)) >> 20;
+                    for (;; ++p) { p &= bigger.size() - 1; if (bigger[p] < 0) { bigger[p] = (int)k; break; } }
+                }
+                hash.swap(bigger);
+                hpos = (size_t)((ka * 0x9E3779B97F4A7C15ull) ^ (kb * 0xC2B2AE3D27D4EB4Full)) >> 20;
+                for (;; ++hpos) { hpos &= hash.size() - 1; if (hash[hpos] < 0) break; }
+            }
+            found = (int)keys.size();
+            keys.push_back(Key{ka, kb, 0, -1});
+            hash[hpos] = found;
+        }
+        ++keys[(size_t)found].count;
+        key_of[(size_t)i] = found;
+    }
+    std::vector<int> order(keys.size());
+    for (size_t k = 0; k < keys.size(); ++k) order[k] = (int)k;
+    std::sort(order.begin(), order.end(), [&](int p, int q) { return keys[(size_t)p].a != keys[(size_t)q].a ? keys[(size_t)p].a < keys[(size_t)q].a : keys[(size_t)p].b < keys[(size_t)q].b; });
+    if (keys.size() <= (size_t)RAD_TABLE) {
+        for (size_t r = 0; r < order.size(); ++r) keys[(size_t)order[r]].slot = (int)r;
+        h.n_rad = (int64_t)keys.size();
+    } else {   // the 256 most frequent pairs (ties: the smaller pair first), numbered by descending frequency
+        std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return keys[(size_t)p].count > keys[(size_t)q].count; });
+        for (size_t r = 0; r < (size_t)RAD_TABLE; ++r) keys[(size_t)order[r]].slot = (int)r;
+        h.n_rad = RAD_TABLE;
+    }
+    for (const Key& k : keys)
+        if (k.slot >= 0) { memcpy(&tab[2 * k.slot], &k.a, 8); memcpy(&tab[2 * k.slot + 1], &k.b, 8); }
+    for (int64_t i = 0; i < n; ++i) {
+        const int slot = keys[(size_t)key_of[(size_t)i]].slot;
+        ridx[i] = slot >= 0 ? (uint16_t)slot : (uint16_t)RAD_NONE;
+    }
+    // bounding boxes (0 for an empty set)
+    auto box = [](auto* pts, int64_t cnt, double* lo, double* hi) {
+        for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = cnt > 0 ? (double)pts[k] : 0.0; }
+        for (int64_t i = 1; i < cnt; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const double v = (double)pts[3 * i + k];
+                lo[k] = std::min(lo[k], v);
+                hi[k] = std::max(hi[k], v);
+            }
+    };
+    box(xyz, n, h.lo, h.hi);
+    box(ring_center, h.nring, h.ring_lo, h.ring_hi);
+    box(amide_center, h.namide, h.amide_lo, h.amide_hi);
+    memcpy(blob, &h, sizeof(h));
+    return ARP_OK;
+}
+
 namespace {
 // header of a blob: counts, size and offsets as arp_blob_layout writes them, finite boxes
 int check_blob_header(arp_ctx* c, const arp_blob_header& h, uint64_t bytes) {
@@ -1646,6 +1749,83 @@ int arp_records_layout(void* buf, uint64_t bytes, int64_t na, int64_t nh, int64_
         h.off[k] = off;
         off = align16(off + REC_ESIZE[k] * (uint64_t)cnt[k]);
     }
+    memcpy(buf, &h, sizeof(h));
+    return ARP_OK;
+}
+
+int arp_records_fill(void* buf, uint64_t bytes, int64_t n_total, const float* xyz, const double* vdw, const double* cov,
+                     const uint16_t* type_mask, const uint16_t* flags, const int32_t* res_id, const uint8_t* res_flags,
+                     const int32_t* res_prev, const int32_t* res_next, const int32_t* bond_off, const int32_t* bond_idx,
+                     const int32_t* h_off, const double* h_xyz, const int32_t* sb_nbr, const double* ring_center,
+                     const double* ring_normal, const int32_t* ring_res, const float* amide_center, const float* amide_normal,
+                     const int32_t* amide_res, const uint8_t* sel, const int64_t* atom_ids, const int64_t* ring_ids,
+                     const int64_t* amide_ids) {
+    if (!buf || bytes < sizeof(arp_rec_header)) return ARP_E_ARG;
+    arp_rec_header h;
+    memcpy(&h, buf, sizeof(h));
+    if (h.magic != ARP_REC_MAGIC || h.bytes > bytes || h.bytes != arp_records_size(h.na, h.nh, h.nb, h.nring, h.namide)) return ARP_E_ARG;
+    if ((h.na > 0 && (!atom_ids || !xyz || !vdw || !cov || !type_mask || !flags || !res_id || !res_flags || !res_prev || !res_next || !bond_off ||
+                      !h_off || !sb_nbr)) ||
+        (h.nring > 0 && (!ring_ids || !ring_center || !ring_normal || !ring_res)) ||
+        (h.namide > 0 && (!amide_ids || !amide_center || !amide_normal || !amide_res)))
+        return ARP_E_ARG;
+    uint8_t* const b = (uint8_t*)buf;
+    memset(b + sizeof(h), 0, (size_t)h.bytes - sizeof(h));
+    arp_rec_atom* A = (arp_rec_atom*)(b + h.off[0]);
+    double* H = (double*)(b + h.off[1]);
+    int32_t* B = (int32_t*)(b + h.off[2]);
+    arp_rec_ring* R = (arp_rec_ring*)(b + h.off[3]);
+    arp_rec_amide* M = (arp_rec_amide*)(b + h.off[4]);
+    int64_t hs = 0, bs = 0;
+    struct Pair { uint64_t a, b; };
+    std::vector<Pair> uniq;
+    auto bits = [](double d) { uint64_t u; memcpy(&u, &d, 8); return u; };
+    for (int64_t k = 0; k < h.na; ++k) {
+        const int64_t i = atom_ids[k];
+        if (i < 0 || i >= n_total || (k > 0 && atom_ids[k - 1] >= i)) return ARP_E_ARG;
+        arp_rec_atom& r = A[k];
+        r.x = xyz[3 * i]; r.y = xyz[3 * i + 1]; r.z = xyz[3 * i + 2]; r.gid = (int32_t)i;
+        r.vdw = vdw[i]; r.cov = cov[i];
+        const int32_t nb = sb_nbr[i];
+        if (nb >= 0) { r.sb_x = xyz[3 * (int64_t)nb]; r.sb_y = xyz[3 * (int64_t)nb + 1]; r.sb_z = xyz[3 * (int64_t)nb + 2]; r.sb_has = 1; }
+        const int32_t res = res_id[i];
+        r.res_gid = res; r.res_prev = res_prev[res]; r.res_next = res_next[res]; r.res_flags = res_flags[res];
+        r.tmask = type_mask[i]; r.flags = flags[i];
+        r.sel = sel ? sel[i] : (uint8_t)1;
+        r.h_start = (int32_t)hs; r.h_cnt = h_off[i + 1] - h_off[i];
+        r.bond_start = (int32_t)bs; r.bond_cnt = bond_off[i + 1] - bond_off[i];
+        if (r.h_cnt < 0 || r.bond_cnt < 0 || hs + r.h_cnt > h.nh || bs + r.bond_cnt > h.nb) return ARP_E_ARG;
+        if (r.h_cnt) memcpy(H + 3 * hs, h_xyz + 3 * (int64_t)h_off[i], (size_t)r.h_cnt * 24);
+        if (r.bond_cnt) memcpy(B + bs, bond_idx + bond_off[i], (size_t)r.bond_cnt * 4);
+        hs += r.h_cnt; bs += r.bond_cnt;
+        const Pair key{bits(r.vdw), bits(r.cov)};
+        bool seen = false;
+        for (const Pair& u : uniq) if (u.a == key.a && u.b == key.b) { seen = true; break; }
+        if (!seen && uniq.size() < 4096) uniq.push_back(key);     // (a handful of element values in practice)
+    }
+    if (hs != h.nh || bs != h.nb) return ARP_E_ARG;
+    for (int64_t k = 0; k < h.nring; ++k) {
+        const int64_t i = ring_ids[k];
+        for (int q = 0; q < 3; ++q) { R[k].c[q] = ring_center[3 * i + q]; R[k].n[q] = ring_normal[3 * i + q]; }
+        R[k].gid = (int32_t)i; R[k].res = ring_res[i];
+    }
+    for (int64_t k = 0; k < h.namide; ++k) {
+        const int64_t i = amide_ids[k];
+        for (int q = 0; q < 3; ++q) { M[k].c[q] = amide_center[3 * i + q]; M[k].n[q] = amide_normal[3 * i + q]; }
+        M[k].gid = (int32_t)i; M[k].res = amide_res[i];
+    }
+    std::sort(uniq.begin(), uniq.end(), [](const Pair& p, const Pair& q) { return p.a != q.a ? p.a < q.a : p.b < q.b; });
+    h.n_rad = (int64_t)std::min<size_t>(uniq.size(), RAD_TABLE);
+    memset(h.rad_tab, 0, sizeof(h.rad_tab));
+    for (int64_t k = 0; k < h.n_rad; ++k) { memcpy(&h.rad_tab[2 * k], &uniq[(size_t)k].a, 8); memcpy(&h.rad_tab[2 * k + 1], &uniq[(size_t)k].b, 8); }
+    auto box = [](double* lo, double* hi, int64_t cnt, auto coord) {
+        for (int q = 0; q < 3; ++q) lo[q] = hi[q] = cnt > 0 ? coord(0, q) : 0.0;
+        for (int64_t k = 1; k < cnt; ++k)
+            for (int q = 0; q < 3; ++q) { const double v = coord(k, q); lo[q] = std::min(lo[q], v); hi[q] = std::max(hi[q], v); }
+    };
+    box(h.lo, h.hi, h.na, [&](int64_t k, int q) { return (double)(&A[k].x)[q]; });
+    box(h.ring_lo, h.ring_hi, h.nring, [&](int64_t k, int q) { return R[k].c[q]; });
+    box(h.amide_lo, h.amide_hi, h.namide, [&](int64_t k, int q) { return (double)M[k].c[q]; });
     memcpy(buf, &h, sizeof(h));
     return ARP_OK;
 }

@@ -370,8 +370,7 @@ def shard_home_to_device(ctx, full: PackedComplex, rank: int, world: int, sel=No
     from . import _capi
     t0 = time.perf_counter()
     home_ids = np.nonzero(a_own == rank)[0]
-    home = pack_records(full, home_ids, np.nonzero(r_own == rank)[0], np.nonzero(m_own == rank)[0], sel)
-    buf = _capi.pack_records_buffer(home)
+    buf = _capi.pack_records_native(full, home_ids, np.nonzero(r_own == rank)[0], np.nonzero(m_own == rank)[0], sel)
     t1 = time.perf_counter()
     ctx.shard_set_home(buf)
     faces, sends = {}, {}

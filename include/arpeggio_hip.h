@@ -188,6 +188,15 @@ int arp_blob_layout(void* blob, uint64_t bytes, int64_t n, int64_t nres, int64_t
  * ranges, CSR offsets) that the call waits for: ARP_E_ARG if the blob fails it.  The blob may be reused or freed when
  * the call returns.  Selection and ownership are reset (whole structure, I:1395). */
 int arp_set_blob(arp_ctx* ctx, const void* blob, uint64_t bytes);
+/* Host-only packer: fills every array of a blob whose header arp_blob_layout has written from the arrays the classic
+ * setters take (same types and meanings; xyz is float[3 * n], hydrogen coordinates double[3 * nh], ...), builds the
+ * dictionary of distinct {vdw, cov} pairs (compared bit for bit; the 256 most frequent if there are more) and the
+ * three bounding boxes.  Any pointer whose count is zero may be NULL. */
+int arp_blob_fill(void* blob, uint64_t bytes, const float* xyz, const double* vdw, const double* cov, const uint16_t* type_mask,
+                  const uint16_t* flags, const int32_t* res_id, const uint8_t* res_flags, const int32_t* res_prev,
+                  const int32_t* res_next, const int32_t* bond_off, const int32_t* bond_idx, const int32_t* h_off,
+                  const double* h_xyz, const int32_t* sb_nbr, const double* ring_center, const double* ring_normal,
+                  const int32_t* ring_res, const float* amide_center, const float* amide_normal, const int32_t* amide_res);
 
 /* ---- Bio.PDB.NeighborSearch equivalents (I:707,960,1394,1420,1442) -------- */
 /* NeighborSearch(atoms).search_all(radius): every unordered pair with
@@ -424,6 +433,17 @@ typedef struct arp_rec_amide { float c[3], n[3]; int32_t gid, res; } arp_rec_ami
 /* host-only helpers: size of a record buffer, and header (magic, counts, offsets) written at its start */
 uint64_t arp_records_size(int64_t na, int64_t nh, int64_t nb, int64_t nring, int64_t namide);
 int arp_records_layout(void* buf, uint64_t bytes, int64_t na, int64_t nh, int64_t nb, int64_t nring, int64_t namide);
+/* Host-only packer: the records of the given atoms / rings / amides (ascending ids = global ids) of a structure held as
+ * the arrays of the classic setters, written into a buffer whose header arp_records_layout has prepared (na, nring,
+ * namide = the list lengths; nh, nb = the hydrogens / bonds of the listed atoms).  sel = selection mask over ALL atoms
+ * (NULL: everything selected).  Fills the sections, the radius dictionary of the listed atoms and the boxes. */
+int arp_records_fill(void* buf, uint64_t bytes, int64_t n_atoms_total, const float* xyz, const double* vdw, const double* cov,
+                     const uint16_t* type_mask, const uint16_t* flags, const int32_t* res_id, const uint8_t* res_flags,
+                     const int32_t* res_prev, const int32_t* res_next, const int32_t* bond_off, const int32_t* bond_idx,
+                     const int32_t* h_off, const double* h_xyz, const int32_t* sb_nbr, const double* ring_center,
+                     const double* ring_normal, const int32_t* ring_res, const float* amide_center, const float* amide_normal,
+                     const int32_t* amide_res, const uint8_t* sel, const int64_t* atom_ids, const int64_t* ring_ids,
+                     const int64_t* amide_ids);
 /* Upload the home records (one asynchronous copy; the buffer may be reused when the call returns). */
 int arp_shard_set_home(arp_ctx* ctx, const void* records, uint64_t bytes);
 /* Records of the home atoms with x_lo <= x <= x_hi (float64 comparison; rings and amides by their centre), packed on

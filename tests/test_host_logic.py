@@ -236,3 +236,20 @@ def test_rings_listed_off_their_path_are_reported():
     q.ring_atoms[0] = np.array([r[0], r[2], r[1]] + r[3:], np.int32)
     assert q.rings_not_in_path_order() == [0]
     assert synth.config3(3000).rings_not_in_path_order() == []      # ring atoms without bonds among them: not judged
+
+
+def test_native_record_packer_equals_the_numpy_one():
+    """arp_records_fill (host only) writes the bytes pack_records_buffer(pack_records(...)) writes."""
+    from arpeggio_amd import _capi, sharding
+    for pc in (synth.proteinlike(n_res=120, n_waters=40), synth.config3(4000, seed=2)):
+        rng = np.random.default_rng(1)
+        ids = np.sort(rng.choice(pc.n_atoms, pc.n_atoms // 2, replace=False))
+        rid, mid = np.arange(0, pc.n_rings, 2), np.arange(1, pc.n_amides, 2)
+        for sel in (None, (np.arange(pc.n_atoms) % 3 == 0).astype(np.uint8)):
+            a = _capi.pack_records_buffer(sharding.pack_records(pc, ids, rid, mid, sel), pinned=False)
+            b = _capi.pack_records_native(pc, ids, rid, mid, sel, pinned=False)
+            assert np.array_equal(a, b)
+    empty = _capi.pack_records_native(pc, [], [], [], None, pinned=False)
+    assert _capi.unpack_records_buffer(empty)['gid'].size == 0
+    with pytest.raises(ValueError):
+        _capi.pack_records_native(pc, [5, 3], [], [], None, pinned=False)          # ids must ascend
