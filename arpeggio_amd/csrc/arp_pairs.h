@@ -764,14 +764,13 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const 
                         const uint32_t m_end = h_first ? mj : mh;
                         pb = h_first ? h : j;
                         pe = h_first ? j : h;
-                        // interactions.py:729 same residue
-                        if (ah.y == aj.y) pass = false;
-                        // interactions.py:733-741 sequence-adjacent residues
-                        if (!include_seq_adj && (m_end & M_RES_POLY) && (mh & mj & M_RES_HASSEQ)) {
-                            if (ah.w == aj.y || ah.z == aj.y || aj.w == ah.y || aj.z == ah.y) pass = false;
-                        }
-                        // multi-GPU ownership: the rank owning the bgn atom emits the pair
-                        if (!(m_bgn & M_HOME)) pass = false;
+                        // Straight-line filters (a branch costs this loop more than the handful of integer operations it skips):
+                        // interactions.py:729 same residue; 733-741 sequence-adjacent residues — one of the four links equal
+                        // <=> the smallest of the four XORs is zero —; ownership: the rank owning the bgn atom emits the pair
+                        const unsigned adj = min(min((unsigned)(ah.w ^ aj.y), (unsigned)(ah.z ^ aj.y)), min((unsigned)(aj.w ^ ah.y), (unsigned)(aj.z ^ ah.y)));
+                        const unsigned gate = (include_seq_adj ? 0u : 1u) & ((m_end & M_RES_POLY) ? 1u : 0u) & ((mh & mj & M_RES_HASSEQ) ? 1u : 0u);
+                        const unsigned drop = (ah.y == aj.y ? 1u : 0u) | (gate & (adj == 0u ? 1u : 0u)) | ((m_bgn & M_HOME) ? 0u : 1u);
+                        pass = has & (drop == 0u);
                     } else {  // MODE_PAIRS: raw search_all, report packed ids (i < j)
                         pb = min(ah.x, aj.x);
                         pe = max(ah.x, aj.x);
