@@ -253,3 +253,33 @@ def test_native_record_packer_equals_the_numpy_one():
     assert _capi.unpack_records_buffer(empty)['gid'].size == 0
     with pytest.raises(ValueError):
         _capi.pack_records_native(pc, [5, 3], [], [], None, pinned=False)          # ids must ascend
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+    if not shutil.which('gcc'):
+        pytest.skip('gcc not available')
+    exe = str(tmp_path / 'c_abi_smoke')
+    lib_dir = os.path.join(ROOT, 'arpeggio_amd', 'csrc')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'c_abi_smoke.c'),
+                    '-o', exe, '-L', lib_dir, '-larpeggio_hip', f'-Wl,-rpath,{lib_dir}', '-lm'], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_the_c_example_links_and_runs(tmp_path):
+    """include/arpeggio_hip.h is C99 (the boundary is a C ABI, not a C++ one) and examples/c_abi_smoke.c — no Python, no
+    C++ — links against the library; without a GPU it runs the host-only entry points and stops at arp_create."""
+    import subprocess
+    import torch
+    subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c', os.path.join(ROOT, 'include', 'arpeggio_hip.h')], check=True)
+    out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert ('GPU_OK' if torch.cuda.is_available() else 'NO_GPU') in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_example_on_the_gpu(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'GPU_OK' in out.stdout, out.stdout + out.stderr
