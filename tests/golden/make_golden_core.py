@@ -588,6 +588,14 @@ def main():
         for mode in ('canonical', 'reversed'):
             out, _ = run_case(IC, config, pc, mode=mode)
             add(f'ka_{nm}:{mode}', pc, out, pack='ka_' + nm, selectors=None, sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode=mode)
+    # ---- A2. pairs ON every distance threshold and one float32 ulp to either side (tests/helpers.threshold_edge_pack)
+    from helpers import threshold_edge_pack
+    edge = threshold_edge_pack()
+    edge.id = 'edge'
+    edge.ensure_labels()
+    for mode in ('canonical', 'reversed'):
+        out, _ = run_case(IC, config, edge, mode=mode)
+        add(f'edge:{mode}', edge, out, pack='edge', selectors=None, sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode=mode)
     T = pconfig.ATOM_TYPE_BIT
     from helpers import tiny_complex
     crash = tiny_complex([[0, 0, 0], [3.0, 0, 0]], type_mask=[T['xbond donor'], T['xbond acceptor']], sb_nbr=[-1, -1])

@@ -205,3 +205,36 @@ def report_boundary_pairs(name, stats):
         data = {}
     data[name] = stats
     json.dump(data, open(path, 'w'), indent=1, sort_keys=True)
+
+
+def threshold_edge_pack(comp=0.1):
+    """Isolated pairs placed ON every distance threshold of I:745-921 and one float32 ulp to either side of it: atom A at
+    (0, 20 k, 20 m), atom B at (d, 20 k, 20 m), so that the float32 difference is d itself and nothing else is within reach.
+    Each atom is its own residue.  The thresholds: sum of covalent radii, sum of van-der-Waals radii, that + vdw_comp
+    (compared as float32, I:756-773), 2.8 (metal), 3.5 (polar / weak polar), 3.6 (carbonyl), 4.0 (ionic, aromatic), 4.5
+    (feature gate, hydrophobic), and the search radius 5.0 (float64 d^2 <= 25 on the float32 coordinates)."""
+    from arpeggio_amd.core import config
+    T = config.ATOM_TYPE_BIT
+    vdw, cov = 1.7, 0.76
+    thresholds = [np.float32(cov + cov), np.float32(vdw + vdw), np.float32(vdw + vdw + comp), np.float32(2.8), np.float32(3.5),
+                  np.float32(3.6), np.float32(4.0), np.float32(4.5), np.float32(5.0)]
+    both = 0
+    for k in ('hbond acceptor', 'hbond donor', 'weak hbond acceptor', 'weak hbond donor', 'pos ionisable', 'neg ionisable',
+              'hydrophobe', 'carbonyl oxygen', 'carbonyl carbon', 'aromatic', 'xbond acceptor'):
+        both |= T[k]
+    combos = [(both, 0, both, 0),                                           # every type on both sides (no hydrogens: hbond by geometry stays 0)
+              (T['hbond acceptor'], 0, 0, config.F_METAL),                  # metal complex at 2.8
+              (T['hbond acceptor'] | T['hbond donor'], config.F_WATER, T['hbond acceptor'], 0),     # water branch of the hbond block
+              (T['carbonyl oxygen'] | T['neg ionisable'], 0, T['carbonyl carbon'] | T['pos ionisable'], 0)]
+    xyz, tm, fl = [], [], []
+    slot = 0
+    for t in thresholds:
+        for d in (np.nextafter(t, np.float32(0)), t, np.nextafter(t, np.float32(10))):
+            for tb, fb, te, fe in combos:
+                y, z = 20.0 * (slot % 12), 20.0 * (slot // 12)
+                slot += 1
+                xyz += [[0.0, y, z], [float(d), y, z]]
+                tm += [tb, te]
+                fl += [fb, fe]
+    pc = tiny_complex(np.array(xyz, np.float32), vdw=vdw, cov=cov, type_mask=tm, flags=fl)
+    return pc
