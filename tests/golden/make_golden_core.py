@@ -596,6 +596,11 @@ def main():
     for mode in ('canonical', 'reversed'):
         out, _ = run_case(IC, config, edge, mode=mode)
         add(f'edge:{mode}', edge, out, pack='edge', selectors=None, sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode=mode)
+    sel6 = edge.expansion_probe[0::2]           # the A atoms of the pairs at 6.0 A -/0/+ one ulp: which B atoms join selection_plus
+    arrays['edge/sel_idx'] = sel6.astype(np.int32)
+    out, _ = run_case(IC, config, edge, sel_idx=sel6)
+    assert sorted(out['selection_plus'].tolist()) == sorted(edge.expansion_probe[[0, 1, 2, 3, 4]].tolist()), out['selection_plus']
+    add('edge:sel6', edge, out, pack='edge', selectors=None, sel='edge/sel_idx', cutoff=5.0, comp=0.1, seq_adj=False, mode='canonical')
     T = pconfig.ATOM_TYPE_BIT
     from helpers import tiny_complex
     crash = tiny_complex([[0, 0, 0], [3.0, 0, 0]], type_mask=[T['xbond donor'], T['xbond acceptor']], sb_nbr=[-1, -1])

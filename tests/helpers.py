@@ -236,5 +236,16 @@ def threshold_edge_pack(comp=0.1):
                 xyz += [[0.0, y, z], [float(d), y, z]]
                 tm += [tb, te]
                 fl += [fb, fe]
+    # three more pairs around the 6.0 A expansion radius of _make_selection (I:1420: float64 d^2 <= 36 on float32 coordinates);
+    # pc.expansion_probe = the six atoms (A, B per pair): selecting the A atoms decides which B atoms join selection_plus
+    probe = []
+    for d in (np.nextafter(np.float32(6.0), np.float32(0)), np.float32(6.0), np.nextafter(np.float32(6.0), np.float32(10))):
+        y, z = 20.0 * (slot % 12), 20.0 * (slot // 12)
+        slot += 1
+        probe += [len(xyz), len(xyz) + 1]
+        xyz += [[0.0, y, z], [float(d), y, z]]
+        tm += [0, 0]
+        fl += [0, 0]
     pc = tiny_complex(np.array(xyz, np.float32), vdw=vdw, cov=cov, type_mask=tm, flags=fl)
+    pc.expansion_probe = np.array(probe, np.int32)
     return pc
