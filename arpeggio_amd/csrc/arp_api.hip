@@ -193,6 +193,7 @@ struct arp_ctx {
     DevBuf<uint16_t> out_s;
     DevBuf<uint8_t> out_ct;
     int64_t n_contacts = 0;
+    int64_t contacts_expected = 0;   // contacts the previous pass over this structure found (0: none yet): sizes the sift launch
     bool contacts_valid = false;
     u64* d_ctr = nullptr;        // C_COUNT device counters
     u64 h_ctr[C_COUNT] = {0};
@@ -435,6 +436,7 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
 int ensure_static(arp_ctx* c) {
     if (!c->static_dirty) return ARP_OK;
     c->lists_dirty = true;
+    c->contacts_expected = 0;
     const int n = (int)c->n;
     HIPCHK(c, c->st_q1.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
@@ -996,7 +998,12 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // blocks split their work statically: one that had to wait for a slot would finish that much later than the rest),
         // so the sift part gets num_cu * blocks-per-CU minus these.  Sixteen list chunks (of 64 entries) per wave are still
         // inside the time the sift blocks need (sweep in profiles/README.md); ring-heavy structures get more blocks, up to half the slots.
-        static const int chunks_per_wave = std::max(1, env_int("ARP_PLANE_CPW", 16));
+        // ... and fewer when the sift part itself is short: about three list chunks take as long as one batch of 64 pairs, and a
+        // sift wave of a small structure has only a batch or two.
+        static const int cpw_max = std::max(1, env_int("ARP_PLANE_CPW", 16));
+        const int64_t expect_pairs = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
+        const double batches_per_wave = (double)expect_pairs / (64.0 * 4.0 * std::min<double>(c->num_cu * 4.0, std::max(1.0, expect_pairs / 256.0)));
+        const int chunks_per_wave = std::max(2, std::min(cpw_max, (int)(3.0 * batches_per_wave + 0.5)));
         np = (int)std::min<long long>(std::max<long long>((entries + 256 * chunks_per_wave - 1) / (256 * chunks_per_wave), 8), 2 * c->num_cu);
         np = (np + 7) & ~7;
     }
@@ -1012,7 +1019,10 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         Prof p(c, SLOT_SEARCH);
         // the contact search ends with a block-level flush of its pair queues, which amortises better over
         // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
-        static const int cpw = std::max(1, env_int("ARP_SEARCH_CPW", 3));
+        // Small grids (a protein of a few thousand atoms has ~1000 cells) get fewer cells per wave: the chip is far from full
+        // and a wave's cells are a serial chain (1tqn_h stand-in: 22 -> 16 us).
+        static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 3));
+        const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
         hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
                            c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
                            include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
@@ -1032,7 +1042,14 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                           SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + C_ERR)};
-        const int nsift = merged ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1) : c->num_cu * sift_blocks_per_cu;
+        // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
+        // this structure found, or ~13 per heavy atom for the first one.  A protein-sized structure then runs 70-odd blocks
+        // instead of 1024, whose start-up and end-of-pass tickets were most of the kernel (stand-in: 25 -> 16 us).
+        static const int pairs_per_block = std::max(64, env_int("ARP_SIFT_PPB", 256));
+        const int64_t expect = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
+        const int by_work = (int)std::min<int64_t>((expect + pairs_per_block - 1) / pairs_per_block + PAIR_SEGS, 1 << 20);
+        const int slots = merged ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * sift_blocks_per_cu;
+        const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
         if (merged)
             hipLaunchKernelGGL(k_sift_planes, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
                                c->d_ctr + C_PLIST, np, c->pub);
@@ -1058,6 +1075,7 @@ bool finish_contacts(arp_ctx* c) {
     c->h_ctr[C_SCRATCH0] = worst;
     if (worst > segcap) return true;
     c->n_contacts = (int64_t)np;
+    c->contacts_expected = (int64_t)np;
     c->contacts_valid = true;
     c->stats[0] = (int64_t)c->h_ctr[C_CAND];
     c->stats[1] = (int64_t)c->h_ctr[C_ACC];
