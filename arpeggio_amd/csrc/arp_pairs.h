@@ -31,6 +31,7 @@
 #define M_HOME (1u << 24)
 
 // device counters (one u64 each); kernels receive pointers to the slots they update
+#define STAT_SLOTS 16
 enum {
     C_PAIRS = 0,      // contact pairs enqueued (after the residue filters)
     C_CAND = 1,       // distance tests of the contact search
@@ -44,17 +45,19 @@ enum {
     C_ERR = 15,       // ARP_E_* raised on the device (low 32 bits)
     // statistics counters are spread over STAT_SLOTS addresses (hashed by block) so that the
     // end-of-block atomics of thousands of blocks do not serialise on one L2 line
-    C_STAT_CAND = 16, C_STAT_ACC = 16 + 64, C_STAT_MCAND = 16 + 128, C_STAT_MACC = 16 + 192,
+    C_STAT_CAND = 16, C_STAT_ACC = 16 + STAT_SLOTS, C_STAT_MCAND = 16 + 2 * STAT_SLOTS, C_STAT_MACC = 16 + 3 * STAT_SLOTS,
+    C_TAIL = 16 + 4 * STAT_SLOTS,
     // the pair list is written in PAIR_SEGS segments, one queue head per XCD (blockIdx % 8): the
     // per-block atomicAdd then runs on 8 different L2s instead of serialising on one address
-    C_SEG_PAIRS = 16 + 256,
+    C_SEG_PAIRS = C_TAIL,
     // end-of-pass tickets (pass_end): blocks of k_sift / k_planes that have finished, kernels that have finished
     // (two sets of 8 group tickets + 1 kernel ticket: the sift kernel and the ring / amide kernel end a pass together)
-    C_TICKET_GROUP = 16 + 256 + 16, C_TICKET_KERNEL = 16 + 256 + 24, C_TICKET_SET = 16, C_KERNELS_DONE = 16 + 256 + 15,
-    C_PLIST = 16 + 256 + 8,   // 4 slots: entries of the static ring / amide candidate lists (copied from their own counters each pass)
-    C_COUNT = 16 + 256 + 48
+    C_TICKET_GROUP = C_TAIL + 16, C_TICKET_KERNEL = C_TAIL + 24, C_TICKET_SET = 16, C_KERNELS_DONE = C_TAIL + 15,
+    C_PLIST = C_TAIL + 8,   // 4 slots: entries of the static ring / amide candidate lists (copied from their own counters each pass)
+    // 128 words in all: the last block of a pass hands the whole block to the host with ONE round of returning atomics per
+    // thread (pass_end); with 64 statistics slots it took two
+    C_COUNT = C_TAIL + 48
 };
-#define STAT_SLOTS 64
 #define PAIR_SEGS 8
 typedef unsigned long long u64;
 
