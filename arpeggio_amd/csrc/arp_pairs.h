@@ -493,7 +493,12 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
 
 // ---- neighbour search ---------------------------------------------------------------
 #define SEARCH_WAVES 8
+#ifndef QCAP
 #define QCAP 512
+#endif
+#ifndef SEARCH_MIN_WAVES
+#define SEARCH_MIN_WAVES 1
+#endif
 #define HOME_BLOCK 32
 
 enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
@@ -532,7 +537,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64 * SEARCH_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
+__global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
                                                                int include_seq_adj, int count_owned, int2* __restrict__ pairs,
