@@ -1011,6 +1011,23 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     //   2 is_weak_hbond(end, bgn)   3 is_weak_hbond(bgn, end)   4 / 5 is_halogen_weak_hbond  (I:857-886)
     // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
     // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
+    // (everything the first batch needs is asked for before the barrier: the queue heads, the first pairs and the radius table
+    // travel together instead of one dependent round trip after the other)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // The segment fill counts are read on the device: no host round trip between search and sift.
+    // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
+    // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
+    const int sgm = vblock & (PAIR_SEGS - 1);
+    u64 heads[PAIR_SEGS];
+#pragma unroll
+    for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_];
+    const float longest_bond = *sd.longest_bond;
+    const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
+    const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
+    const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
+    // (a pair beyond the end of the segment is read and ignored: the list is padded — see enqueue_contacts — and the count
+    // that says so is still on its way)
+    int2 pr_next = (first + lane < (long long)cap) ? seg_pairs[first + lane] : make_int2(0, 0);
     s_tab[threadIdx.x] = sd.rad_tab[threadIdx.x];   // (blockDim.x == RAD_TABLE)
     {   // the three float32 thresholds of the ladder (I:717-718, 756-773: float64 sums, compared as float32) depend on the two
         // radius pairs only: for the common case — both atoms among the first 16 table entries — they are looked up, not computed
@@ -1019,29 +1036,19 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), 0.0f);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int tn = 0;
-    auto run_tasks = [&](int first, int count) {   // stage B on tq[w][first .. first + count)
+    auto run_tasks = [&](int first_, int count) {   // stage B on tq[w][first_ .. first_ + count)
         if (lane < count) {
-            const uint4 t = tq[w][first + lane];
+            const uint4 t = tq[w][first_ + lane];
             const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, s_tab, sd, comp);
             out_s[t.x] = (uint16_t)((t.w & 0xFFFFu) | add);
         }
     };
-    // The segment fill counts are read on the device: no host round trip between search and sift.
-    // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
-    // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
-    const float longest_bond = *sd.longest_bond;
-    const int sgm = vblock & (PAIR_SEGS - 1);
     long long out_base = 0;
 #pragma unroll
     for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
-        if (q_ < sgm) out_base += (long long)min(npairs_ptr[q_], cap);
-    const long long nseg = (long long)min(npairs_ptr[sgm], cap);
-    const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
-    const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
-    const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
-    int2 pr_next = (first + lane < nseg) ? seg_pairs[first + lane] : make_int2(0, 0);
+        if (q_ < sgm) out_base += (long long)min(heads[q_], cap);
+    const long long nseg = (long long)min(heads[sgm], cap);
     for (long long base = first; base < nseg; base += stride) {
         const long long ps = base + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
         bool queued = false;
