@@ -869,3 +869,51 @@ def test_staged_protocol_between_contexts_on_one_gpu(capi, world):
             assert np.array_equal(a, e) or (a.dtype.kind == 'f' and np.array_equal(np.isnan(a), np.isnan(e))
                                             and np.array_equal(a[~np.isnan(a)], e[~np.isnan(e)])), (b, f)
     assert len(ref['i']) > 5_000 and len(ref_bags['plane_plane']['bgn']) > 0
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_random_parameters_and_selections(ctx, seed):
+    """run_arpeggio with parameters off the defaults — cutoff 3 .. 8 A (incl. beyond the 6 A expansion radius), vdw_comp 0 .. 0.4,
+    sequence-adjacent pairs on / off, selections from one residue to nearly everything — on structures of different kinds and
+    sizes, every result bag against the oracle."""
+    import oracle
+    from arpeggio_amd import synth
+    from helpers import random_dense_pack
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 3
+    if kind == 0:
+        pc = synth.config3(int(rng.integers(1500, 30000)), seed=int(rng.integers(1, 1000)))
+    elif kind == 1:
+        pc = synth.proteinlike(n_res=int(rng.integers(40, 400)), n_waters=int(rng.integers(0, 120)), seed=int(rng.integers(1, 50)))
+    else:
+        pc = random_dense_pack(int(rng.integers(1, 1000)), n=int(rng.integers(200, 900)))
+    cutoff = float(rng.choice([3.0, 4.0, 4.5, 5.0, 5.5, 6.5, 8.0]))
+    comp = float(rng.choice([0.0, 0.1, 0.25, 0.4]))
+    seq_adj = bool(rng.integers(0, 2))
+    frac = float(rng.choice([0.0, 0.02, 0.3, 0.95, 1.0]))
+    sel_res = rng.random(pc.n_residues) < frac
+    if frac == 0.0:
+        sel_res[int(rng.integers(0, pc.n_residues))] = True
+    sel = sel_res[pc.res_id].astype(np.uint8)
+    ctx.set_complex(pc)
+    ctx.set_selection(sel)
+    counts = ctx.run_launch(cutoff, comp, seq_adj, 6.0)
+    oc = oracle.OracleComplex(pc)
+    plus = oc.make_selection(sel)
+    masks = ctx.make_selection_masks()
+    assert np.array_equal(masks['plus'], plus) and np.array_equal(masks['ring_plus'], oc.ring_plus) and np.array_equal(masks['amide_plus'], oc.amide_plus)
+    tag = (seed, kind, pc.n_atoms, cutoff, comp, seq_adj, frac)
+    try:
+        exp = oc.atom_contacts(cutoff, comp, seq_adj)
+    except Exception:
+        exp = None
+    if exp is not None and exp.get('err', 0) == 0:
+        _assert_contacts_equal(ctx.atom_contacts_fetch(counts['atom_atom']), exp)
+    epp = oc.plane_plane()
+    o = np.lexsort((epp['end'], epp['bgn']))
+    epp = {k: v[o] for k, v in epp.items()}
+    _assert_planes_equal(ctx.fetch_bag('plane_plane'), epp, ('bgn', 'end', 'type1', 'type2', 'ctype', 'dist'), ('dihedral', 'theta_bgn', 'theta_end'))
+    _assert_planes_equal(ctx.fetch_bag('atom_plane'), oc.atom_plane(), ('atom', 'ring', 'mask', 'ctype', 'dist'), ('theta',))
+    _assert_planes_equal(ctx.fetch_bag('group_group'), oc.group_group(), ('bgn', 'end', 'ctype', 'dist'), ('dihedral', 'theta'))
+    _assert_planes_equal(ctx.fetch_bag('group_plane'), oc.group_plane(), ('amide', 'ring', 'ctype', 'dist'), ('dihedral', 'theta'))
+    assert counts['atom_atom'] >= 0, tag
