@@ -46,7 +46,9 @@ class InteractionComplex:
         else:
             raise NotImplementedError(
                 'Reading mmCIF/PDB needs the reference\'s BioPython/OpenBabel/gemmi preparation (I:53-105, 288-327), '
-                'which is outside the accelerated path: pass a PackedComplex (see pack_from_reference_objects).')
+                'which is outside the accelerated path: pass a PackedComplex (see pack_from_reference_objects).  '
+                'core.protein_reader.read_mmcif(path) gives the part of a pack a file alone determines (atoms, residues, '
+                'polypeptide links, table types of standard residues; no bonds, hydrogens, ligand types, rings or amides).')
         self.pc.ensure_labels()
         self.device = device
         self._ctx = None
