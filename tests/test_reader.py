@@ -44,6 +44,19 @@ def test_cif_syntax_corners():
             _capi.CifCategory(bad, '_x.')
     with pytest.raises(ValueError, match='not a number'):
         _capi.CifCategory("data_a\nloop_\n_x.a\n1.0\n2.5(3)\n", '_x.').floats('a')
+    more = {
+        'CRLF line ends': ("data_x\r\nloop_\r\n_a.b\r\n_a.c\r\n1 'x y'\r\n2 ?\r\n", {'b': ['1', '2'], 'c': ['x y', None]}),
+        'reserved words and tags are case-insensitive': ("DATA_X\nLOOP_\n_A.B\n_a.C\n1 2\n", {'B': ['1'], 'C': ['2']}),
+        'tab inside quotes': ('data_x\n_a.b\t"q\tr"\n', {'b': ['q\tr']}),
+        'text field with CRLF': ("data_x\r\n_a.b\r\n;line1\r\nline2\r\n;\r\n", {'b': ['line1\r\nline2']}),
+        'save frame': ("data_x\nsave_frame\n_a.b 1\nsave_\n_a.c 2\n", {'b': ['1'], 'c': ['2']}),
+        'comments between tokens': ("data_x\nloop_\n_a.b # tag comment\n# full line\n1 # value comment\n2\n", {'b': ['1', '2']}),
+        'hash inside a word': ("data_x\n_a.b x#y\n", {'b': ['x#y']}),
+        'semicolon not at the line start': ("data_x\nloop_\n_a.b\n_a.c\n1 ;2\n", {'b': ['1'], 'c': [';2']}),
+        'empty quoted string': ("data_x\n_a.b ''\n", {'b': ['']}),
+    }
+    for what, (txt, want) in more.items():
+        assert _capi.CifCategory(txt, '_a.').columns() == want, what
 
 
 def test_builder_calls_equal_the_executed_reference(golden):
