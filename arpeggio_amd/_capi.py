@@ -21,7 +21,7 @@ ARP_OK, ARP_E_ARG, ARP_E_HIP, ARP_E_CAPACITY, ARP_E_XBOND_NBR, ARP_E_NOMEM = 0, 
 SYMBOLS = (
     'arp_version', 'arp_create', 'arp_destroy', 'arp_last_error', 'arp_set_atoms', 'arp_set_residues',
     'arp_set_bonds', 'arp_set_hydrogens', 'arp_set_single_bond_neighbours', 'arp_set_rings', 'arp_set_amides',
-    'arp_search_all', 'arp_make_selection', 'arp_atom_contacts_launch', 'arp_atom_contacts_fetch',
+    'arp_search_all', 'arp_search', 'arp_make_selection', 'arp_atom_contacts_launch', 'arp_atom_contacts_fetch',
     'arp_atom_contacts', 'arp_atom_plane', 'arp_plane_plane', 'arp_group_group', 'arp_group_plane',
     'arp_set_ownership', 'arp_get_stats', 'arp_set_profiling', 'arp_get_kernel_times', 'arp_stream_handle',
     'arp_set_selection', 'arp_run_launch', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
@@ -64,6 +64,7 @@ def load():
     L.arp_set_rings.argtypes = [vp, i64, vp, vp, vp]
     L.arp_set_amides.argtypes = [vp, i64, vp, vp, vp]
     L.arp_search_all.argtypes = [vp, dbl, vp, i64, vp, vp, C.POINTER(i64)]
+    L.arp_search.argtypes = [vp, dbl, i64, vp, i64, vp, vp, C.POINTER(i64)]
     L.arp_make_selection.argtypes = [vp, vp, dbl, vp, vp, vp, vp, vp]
     L.arp_atom_contacts_launch.argtypes = [vp, dbl, dbl, i32, C.POINTER(i64)]
     L.arp_atom_contacts_fetch.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
@@ -529,6 +530,22 @@ class Context:
             k = int(cnt.value)
             o = np.lexsort((oj[:k], oi[:k]))
             return oi[:k][o], oj[:k][o]
+
+    def search(self, centers, radius):
+        """``NeighborSearch.search(center, radius)`` for many centres: (centre index, atom index) of every atom within
+        ``radius`` of a centre (all atoms, hydrogens included), sorted by centre then atom."""
+        ctr = np.ascontiguousarray(centers, np.float64).reshape(-1, 3)
+        cap = max(64 * len(ctr), 1024)
+        while True:
+            oc, oa = np.empty(cap, np.int32), np.empty(cap, np.int32)
+            cnt = C.c_int64(0)
+            rc = self._L.arp_search(self._h, float(radius), len(ctr), _p(ctr), cap, _p(oc), _p(oa), C.byref(cnt))
+            if rc == ARP_E_CAPACITY:
+                cap = int(cnt.value)
+                continue
+            self._check(rc, 'arp_search')
+            k = int(cnt.value)
+            return oc[:k].copy(), oa[:k].copy()
 
     def set_selection(self, in_selection):
         sel = np.ascontiguousarray(in_selection, np.uint8)

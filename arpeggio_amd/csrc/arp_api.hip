@@ -2777,6 +2777,47 @@ int arp_ring_residues(arp_ctx* c, int64_t nring, const double* center, int32_t* 
     return rc;
 }
 
+int arp_search(arp_ctx* c, double radius, int64_t ncenters, const double* centers, int64_t cap, int32_t* out_center, int32_t* out_atom,
+               int64_t* count) {
+    if (!c || !count || ncenters < 0 || cap < 0 || !(radius > 0) || (ncenters > 0 && !centers)) return ARP_E_ARG;
+    *count = 0;
+    if (ncenters == 0 || c->n == 0) return ARP_OK;
+    if (ncenters > 0x7FFFFFF0LL) FAIL(c, ARP_E_ARG, "arp_search: too many centres");
+    if (!all_finite(centers, 3 * ncenters)) FAIL(c, ARP_E_ARG, "arp_search: non-finite centre");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!(c->all_grid_current && c->all_grid.valid && c->all_grid.radius >= radius)) CHK(build_all_grid(c, std::max(radius, 6.0)));
+    DevBuf<double> d_c;
+    DevBuf<int2> d_out;
+    DevBuf<u64> d_n;
+    int rc = upload(c, d_c, centers, (size_t)ncenters * 3);
+    hipError_t e = d_out.reserve((size_t)std::max<int64_t>(cap, 1));
+    if (e == hipSuccess) e = d_n.reserve(1);
+    u64 found = 0;
+    std::vector<int2> tmp;
+    if (rc == ARP_OK && e == hipSuccess) {
+        e = hipMemsetAsync(d_n.p, 0, sizeof(u64), c->stream);
+        hipLaunchKernelGGL(k_center_search, dim3(nblocks(ncenters * 64, 256, 4096)), dim3(256), 0, c->stream, c->all_grid.d, c->all_grid.start.p,
+                           c->a_xyzm.p, c->a_aux.p, (int)ncenters, d_c.p, radius * radius, d_out.p, (u64)cap, d_n.p);
+        rc = check_launch(c, "k_center_search");
+        if (rc == ARP_OK) rc = download(c, &found, d_n.p, 1);
+        if (rc == ARP_OK && found <= (u64)cap && found > 0) {
+            tmp.resize((size_t)found);
+            rc = download(c, tmp.data(), d_out.p, (size_t)found);
+        }
+    }
+    d_c.release(); d_out.release(); d_n.release();
+    if (e != hipSuccess) FAIL(c, ARP_E_NOMEM, "arp_search: out of device memory");
+    if (rc != ARP_OK) return rc;
+    *count = (int64_t)found;
+    if (found > (u64)cap) FAIL(c, ARP_E_CAPACITY, "arp_search: output buffer too small");
+    std::sort(tmp.begin(), tmp.end(), [](const int2& a, const int2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    for (size_t k = 0; k < tmp.size(); ++k) {
+        if (out_center) out_center[k] = tmp[k].x;
+        if (out_atom) out_atom[k] = tmp[k].y;
+    }
+    return ARP_OK;
+}
+
 // Page-locked host memory for result buffers (and inputs): copies to / from it are DMA transfers at PCIe speed,
 // pageable memory goes through the runtime's staging buffer at a fraction of that.
 int arp_host_alloc(uint64_t bytes, void** out) {

@@ -205,6 +205,13 @@ int arp_blob_fill(void* blob, uint64_t bytes, const float* xyz, const double* vd
 int arp_search_all(arp_ctx* ctx, double radius, const uint8_t* active,
                    int64_t cap, int32_t* out_i, int32_t* out_j, int64_t* count);
 
+/* NeighborSearch(atoms).search(center, radius) (I:960, 1463) for ncenters centres at once: every (centre, atom) with
+ * float64 d^2 <= radius^2 over ALL atoms of the structure (hydrogens included, as the tree of I:1394 / 1455 holds them).
+ * centers = double[3 * ncenters].  Output sorted by (centre, atom index).  ARP_E_CAPACITY with the required count in
+ * *count when cap is too small. */
+int arp_search(arp_ctx* ctx, double radius, int64_t ncenters, const double* centers, int64_t cap, int32_t* out_center,
+               int32_t* out_atom, int64_t* count);
+
 /* ---- _make_selection (I:1384-1451) --------------------------------------- */
 /* in_selection: u8[n] = utils.selection_parser result (NULL = keep the mask already uploaded,
  * or the whole structure if none was).

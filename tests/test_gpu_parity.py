@@ -917,3 +917,31 @@ def test_random_parameters_and_selections(ctx, seed):
     _assert_planes_equal(ctx.fetch_bag('group_group'), oc.group_group(), ('bgn', 'end', 'ctype', 'dist'), ('dihedral', 'theta'))
     _assert_planes_equal(ctx.fetch_bag('group_plane'), oc.group_plane(), ('amide', 'ring', 'ctype', 'dist'), ('dihedral', 'theta'))
     assert counts['atom_atom'] >= 0, tag
+
+
+def test_search_around_centres_equals_brute_force(ctx):
+    """arp_search = NeighborSearch.search(center, radius) (I:960, 1463) for many centres: inclusive float64 test on the float32
+    coordinates widened to float64, all atoms (hydrogens too), centres inside, on the border of and far outside the box."""
+    from arpeggio_amd import synth
+    pc = synth.proteinlike(n_res=200, n_waters=80, seed=4)
+    ctx.set_complex(pc)
+    rng = np.random.default_rng(3)
+    x = pc.xyz.astype(np.float64)
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    centers = np.concatenate([lo + rng.random((300, 3)) * (hi - lo), x[rng.choice(len(x), 50)], [lo - 2.0, hi + 3.9, hi + 500.0],
+                              x[:5] + [3.0, 0.0, 0.0]])
+    for radius in (3.0, 4.0, 6.0, 9.5):
+        oc, oa = ctx.search(centers, radius)
+        d = x[None, :, :] - centers[:, None, :]
+        d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+        ec, ea = np.nonzero(d2 <= radius * radius)
+        assert np.array_equal(oc, ec) and np.array_equal(oa, ea), radius
+        assert len(oc) > 1000
+    oc, oa = ctx.search(np.zeros((0, 3)), 4.0)
+    assert len(oc) == 0
+    with pytest.raises(Exception):
+        ctx.search([[np.nan, 0, 0]], 4.0)
+    # the resident pass is not disturbed by the query's grid
+    n1 = ctx.run_launch()
+    ctx.search(centers[:10], 7.0)
+    assert ctx.run_launch() == n1
