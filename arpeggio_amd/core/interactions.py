@@ -76,9 +76,14 @@ class InteractionComplex:
             raise AtomSerialError
 
     def address_ambiguities(self):
-        """I:120-133 edits the typing tables *before* typing; here typing is part of the packed
-        input, so the ambiguity choice has to be made by whoever builds the PackedComplex."""
-        logging.warning('address_ambiguities(): atom typing is part of the packed input; no effect on a PackedComplex.')
+        """I:120-133 strikes the ASN / GLN / HIS side-chain keys from four lists of the typing dictionary BEFORE initialize()
+        types the atoms of standard residues from it (I:1966-1983).  Here the types are part of the packed input: the atoms of
+        standard residues are re-typed from the same dictionary with those keys struck (``typing.apply_protein_typing``, pinned
+        against the executed reference); every other atom keeps the types it was packed with."""
+        from . import typing
+        self.pc.type_mask = typing.apply_protein_typing(self.pc, use_ambiguities=True)
+        if self._ctx is not None:
+            self._ctx.set_complex(self.pc)
 
     def initialize(self):
         """I:288-327 prepares per-atom state; here: create the GPU context and upload the pack."""
