@@ -24,7 +24,7 @@ SYMBOLS = (
     'arp_search_all', 'arp_search', 'arp_make_selection', 'arp_atom_contacts_launch', 'arp_atom_contacts_fetch',
     'arp_atom_contacts', 'arp_atom_plane', 'arp_plane_plane', 'arp_group_group', 'arp_group_plane',
     'arp_set_ownership', 'arp_get_stats', 'arp_set_profiling', 'arp_get_kernel_times', 'arp_stream_handle',
-    'arp_set_selection', 'arp_run_launch', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
+    'arp_set_selection', 'arp_run_launch', 'arp_run_enqueue', 'arp_run_wait', 'arp_atom_plane_launch', 'arp_plane_plane_launch', 'arp_group_group_launch',
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
@@ -113,6 +113,8 @@ def load():
     L.arp_set_selection_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.arp_get_selection.argtypes = [vp, vp, vp, vp, vp, vp]
     L.arp_run_launch.argtypes = [vp, dbl, dbl, i32, dbl, vp]
+    L.arp_run_enqueue.argtypes = [vp, dbl, dbl, i32, dbl]
+    L.arp_run_wait.argtypes = [vp, vp]
     for nm in ('atom_plane', 'plane_plane', 'group_group', 'group_plane'):
         getattr(L, f'arp_{nm}_launch').argtypes = [vp, C.POINTER(i64)]
         getattr(L, f'arp_{nm}_fetch').argtypes = getattr(L, f'arp_{nm}').argtypes
@@ -552,6 +554,17 @@ class Context:
         if sel.shape != (self.n,):
             raise ValueError('in_selection must have one entry per atom')
         self._check(self._L.arp_set_selection(self._h, _p(sel)), 'arp_set_selection')
+
+    def run_enqueue(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, expand_radius=6.0):
+        """First half of ``run_launch``: the pass is enqueued, the call returns.  Pair with ``run_wait``."""
+        self._check(self._L.arp_run_enqueue(self._h, float(cutoff), float(vdw_comp), int(bool(include_sequence_adjacent)),
+                                            float(expand_radius)), 'arp_run_enqueue')
+
+    def run_wait(self):
+        """Second half of ``run_launch``: waits for the enqueued pass, returns the five bag sizes."""
+        counts = np.zeros(5, np.int64)
+        self._check(self._L.arp_run_wait(self._h, _p(counts)), 'arp_run_wait')
+        return dict(zip(('atom_atom', 'plane_plane', 'atom_plane', 'group_group', 'group_plane'), [int(x) for x in counts]))
 
     def run_launch(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, expand_radius=6.0):
         """run_arpeggio on the resident structure; results stay in HBM.  Returns the five bag sizes."""

@@ -193,6 +193,9 @@ struct arp_ctx {
     DevBuf<uint16_t> out_s;
     DevBuf<uint8_t> out_ct;
     int64_t n_contacts = 0;
+    bool pass_pending = false;      // arp_run_enqueue without its arp_run_wait yet
+    double pending_cutoff = 5.0, pending_comp = 0.1, pending_expand = 6.0;
+    int pending_seq_adj = 0;
     int64_t contacts_expected = 0;   // contacts the previous pass over this structure found (0: none yet): sizes the sift launch
     bool contacts_valid = false;
     u64* d_ctr = nullptr;        // C_COUNT device counters
@@ -2481,9 +2484,11 @@ int arp_group_plane(arp_ctx* c, int64_t cap, int32_t* out_amide, int32_t* out_ri
 }
 
 // ---- run_arpeggio (I:329-347): every stage enqueued back to back, ONE host synchronisation ---------
-int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius,
-                   int64_t counts[5]) {
-    if (!c || !(cutoff > 0) || !(expand_radius > 0)) return ARP_E_ARG;
+namespace {
+// One pass = enqueue (everything back to back on the context's stream, no host synchronisation) + wait (the one host wait,
+// capacity checks, a re-run if a buffer was too small).  arp_run_launch is the two in a row; arp_run_enqueue / arp_run_wait
+// give them to the caller separately, so that ONE host thread keeps several contexts busy.
+int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->sel_uploaded) {  // no selection uploaded for this structure: whole structure (I:1395)
         HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
@@ -2542,6 +2547,15 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         if (c->pub.expected) return ARP_OK;                                         // the last kernel publishes (pass_end)
         return enqueue_counter_copy(c, 1);
     };
+    const auto t0 = std::chrono::steady_clock::now();
+    CHK(ensure_zero());
+    CHK(enqueue_all());
+    c->host_enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return ARP_OK;
+}
+
+int run_pass_wait(arp_ctx* c, int64_t counts[5]) {
+    HIPCHK(c, hipSetDevice(c->device));
     auto any_overflow = [&](bool grow) -> int {   // returns 1 when a buffer was too small (and regrows it if asked)
         int again = 0;
         if (finish_contacts(c)) { if (grow) CHK(grow_pairs(c)); again = 1; }
@@ -2553,23 +2567,18 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         if (lists < 0) return lists;
         return again | lists;
     };
-    bool done = false;
-    for (int attempt = 0; !done; ++attempt) {
-        const auto t0 = std::chrono::steady_clock::now();
-        CHK(ensure_zero());
-        CHK(enqueue_all());
+    for (int attempt = 0;; ++attempt) {
         const auto t1 = std::chrono::steady_clock::now();
         CHK(collect_counters(c));
         c->ctr_zero_ok = true;
-        const auto t2 = std::chrono::steady_clock::now();
-        c->host_enqueue_us += std::chrono::duration<double, std::micro>(t1 - t0).count();
-        c->host_wait_us += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        c->host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         ++c->host_passes;
         collect_events(c);
         const int again = any_overflow(true);
         if (again < 0) return again;
         if (!again) break;
         if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_launch: result buffers could not be sized");
+        CHK(run_pass_enqueue(c, c->pending_cutoff, c->pending_comp, c->pending_seq_adj, c->pending_expand));   // a buffer was too small: once more
     }
     c->stats[5] = (int64_t)c->h_ctr[C_MARK_CAND];
     c->stats[6] = (int64_t)c->h_ctr[C_MARK_ACC];
@@ -2578,6 +2587,29 @@ int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_seque
         counts[3] = c->bag_gg.count; counts[4] = c->bag_gp.count;
     }
     return device_error(c);
+}
+}  // namespace
+
+int arp_run_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius) {
+    if (!c || !(cutoff > 0) || !(expand_radius > 0)) return ARP_E_ARG;
+    if (c->pass_pending) FAIL(c, ARP_E_ARG, "arp_run_enqueue: the previous pass has not been waited for (arp_run_wait)");
+    c->pending_cutoff = cutoff; c->pending_comp = vdw_comp; c->pending_seq_adj = include_sequence_adjacent; c->pending_expand = expand_radius;
+    CHK(run_pass_enqueue(c, cutoff, vdw_comp, include_sequence_adjacent, expand_radius));
+    c->pass_pending = true;
+    return ARP_OK;
+}
+
+int arp_run_wait(arp_ctx* c, int64_t counts[5]) {
+    if (!c) return ARP_E_ARG;
+    if (!c->pass_pending) FAIL(c, ARP_E_ARG, "arp_run_wait: no pass was enqueued (arp_run_enqueue)");
+    c->pass_pending = false;
+    return run_pass_wait(c, counts);
+}
+
+int arp_run_launch(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius,
+                   int64_t counts[5]) {
+    CHK(arp_run_enqueue(c, cutoff, vdw_comp, include_sequence_adjacent, expand_radius));
+    return arp_run_wait(c, counts);
 }
 
 // ---- staged run_arpeggio for sharded runs ------------------------------------------------------------

@@ -239,6 +239,19 @@ def main():
                          'ms_per_step': round(el2 / (per_thread * args.inflight) * 1e3, 4),
                          'value': round(st['candidates'] * per_thread * args.inflight / el2, 1),
                          'note': 'one arp_ctx per host thread, same structure resident in each; not the headline value'}
+            # the same contexts driven by ONE host thread: enqueue the pass of each (arp_run_enqueue), then wait for each
+            rounds = max(per_thread, 1)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(rounds):
+                for cx in ctxs:
+                    cx.run_enqueue(args.cutoff, args.vdw_comp, False, 6.0)
+                for cx in ctxs:
+                    cx.run_wait()
+            el3 = time.perf_counter() - t3
+            in_flight['one_thread_enqueue_wait'] = {'contexts': args.inflight, 'steps': rounds * args.inflight,
+                                                     'ms_per_step': round(el3 / (rounds * args.inflight) * 1e3, 4),
+                                                     'value': round(st['candidates'] * rounds * args.inflight / el3, 1)}
             for c2 in ctxs[1:]:
                 c2.close()
         except Exception as exc:   # never lose the main line over the extra measurement

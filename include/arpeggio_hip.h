@@ -239,6 +239,12 @@ int arp_set_selection(arp_ctx* ctx, const uint8_t* in_selection);
  * get_contacts (I:183-210): atom-atom, plane-plane, atom-plane, group-group, group-plane. */
 int arp_run_launch(arp_ctx* ctx, double cutoff, double vdw_comp, int include_sequence_adjacent,
                    double expand_radius, int64_t counts[5]);
+/* The same pass in two calls, so that ONE host thread can keep several contexts (structures) busy: arp_run_enqueue returns
+ * as soon as the launches are enqueued (~15 us of host time), arp_run_wait blocks for the pass, checks the capacities
+ * (re-running the pass itself if a buffer was too small) and reports the counts.  Between the two calls only other contexts
+ * may be used; every enqueue needs its wait before the next one on the same context. */
+int arp_run_enqueue(arp_ctx* ctx, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius);
+int arp_run_wait(arp_ctx* ctx, int64_t counts[5]);
 
 /* ---- _calculate_atom_contacts (I:693-936) -------------------------------- */
 /* Enqueue bin + sort + neighbour search + fused per-pair SIFt kernels on the

@@ -414,3 +414,38 @@ def test_blob_upload_equals_classic_upload_and_rejects_bad_input():
     b.set_blob(_capi.pack_blob(pc2))                      # and the context is still usable
     assert a.run_launch(5.0, 0.1, False, 6.0) == b.run_launch(5.0, 0.1, False, 6.0)
     a.close(); b.close()
+
+
+def test_enqueue_and_wait_keep_several_contexts_busy_from_one_thread():
+    """arp_run_enqueue / arp_run_wait: the pass of run_launch in two calls; three contexts driven round-robin by one thread give
+    what three run_launch calls give, an enqueue without its wait (or a wait without an enqueue) is refused."""
+    from arpeggio_amd import _capi, synth
+    pcs = [synth.config3(6000 + 3000 * k, seed=5 + k) for k in range(3)]
+    ctxs = [_capi.Context(0) for _ in pcs]
+    want = []
+    for c, pc in zip(ctxs, pcs):
+        c.set_complex(pc)
+        n = c.run_launch(5.0, 0.1, False, 6.0)
+        want.append((n, c.atom_contacts_fetch(n['atom_atom'])))
+    for rep in range(4):
+        for c in ctxs:
+            c.run_enqueue(5.0, 0.1, False, 6.0)
+        for c, (n, contacts) in zip(ctxs, want):
+            got = c.run_wait()
+            assert got == n
+            if rep == 3:
+                g = c.atom_contacts_fetch(got['atom_atom'])
+                assert all(np.array_equal(g[k], contacts[k]) for k in contacts)
+    ctxs[0].run_enqueue()
+    with pytest.raises(Exception, match='waited'):
+        ctxs[0].run_enqueue()
+    assert ctxs[0].run_wait() == want[0][0]
+    with pytest.raises(Exception, match='enqueued'):
+        ctxs[0].run_wait()
+    # a pass whose buffers are too small is repeated inside the wait: a fresh context, first pass through enqueue / wait
+    fresh = _capi.Context(0)
+    fresh.set_complex(pcs[2])
+    fresh.run_enqueue()
+    assert fresh.run_wait() == want[2][0]
+    for c in ctxs + [fresh]:
+        c.close()
