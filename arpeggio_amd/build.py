@@ -35,13 +35,33 @@ def is_stale():
 
 def build(force=False, verbose=False):
     if not force and not is_stale():
+        build_pyexport()
         return LIB
     cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
+    build_pyexport(force)
     return LIB
 
 
+PYEXPORT = os.path.join(HERE, '_pyexport.so')
+
+
+def build_pyexport(force=False):
+    """The optional CPython helper of core/export.py (host code, gcc): get_contacts() records built in C."""
+    import sysconfig
+    src = os.path.join(CSRC, 'arp_pyexport.c')
+    if not force and os.path.exists(PYEXPORT) and os.path.getmtime(PYEXPORT) >= os.path.getmtime(src):
+        return PYEXPORT
+    inc = sysconfig.get_paths()['include']
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if not cc or not os.path.exists(os.path.join(inc, 'Python.h')):
+        return None          # no compiler / no headers: export.py keeps its Python loop
+    subprocess.run([cc, '-O2', '-shared', '-fPIC', '-I', inc, src, '-o', PYEXPORT], check=True)
+    return PYEXPORT
+
+
 if __name__ == '__main__':
+    print(build_pyexport(force=True))
     print(build(force=True, verbose=True))

@@ -283,3 +283,26 @@ def test_c_example_on_the_gpu(tmp_path):
     import subprocess
     out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and 'GPU_OK' in out.stdout, out.stdout + out.stderr
+
+
+def test_c_record_builder_equals_the_python_loop():
+    """csrc/arp_pyexport.c (optional CPython helper of get_contacts) builds the records the Python comprehension builds."""
+    from arpeggio_amd.core import export
+    if export._pyexport() is None:
+        pytest.skip('helper not built')
+    pc = synth.proteinlike(n_res=40, n_waters=12).ensure_labels()
+    rng = np.random.default_rng(9)
+    n = 3000
+    i = rng.integers(0, pc.n_atoms - 1, n).astype(np.int32)
+    bags = {'atom_atom': dict(i=i, j=(i + 1).astype(np.int32), dist=(rng.random(n) * 6).astype(np.float32),
+                              sift=rng.integers(0, 1 << 15, n).astype(np.uint16), ctype=rng.integers(0, 6, n).astype(np.uint8))}
+    fast = export.contacts_json(pc, bags, pc.component_types)
+    saved, export._PYEXPORT = export._PYEXPORT, None
+    try:
+        slow = export.contacts_json(pc, bags, pc.component_types)
+    finally:
+        export._PYEXPORT = saved
+    assert fast == slow and [list(r) for r in fast] == [list(r) for r in slow]          # same records, same key order
+    assert fast[0]['bgn'] is not fast[1]['bgn'] and fast[0]['contact'] is not slow[0]['contact']
+    fast[0]['bgn']['auth_atom_id'] = 'changed'                                          # records own their dicts
+    assert export.contacts_json(pc, bags, pc.component_types)[0]['bgn']['auth_atom_id'] != 'changed'
