@@ -88,6 +88,23 @@ def rounded(dist):
     return np.round(np.asarray(dist, np.float64), 2).tolist()
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def paused_gc():
+    """Pause the cyclic garbage collector while a large list of small containers is built (none of them is garbage, and the
+    collector would re-scan them every few hundred allocations)."""
+    import gc
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 _PYEXPORT = False
 
 
@@ -108,14 +125,8 @@ def _pyexport():
 def contacts_json(pc, bags, component_types):
     """The list ``get_contacts`` returns (interactions.py:172-212).  Millions of small containers are created and none of
     them is garbage: the cyclic collector, which would re-scan them every few hundred allocations, is paused meanwhile."""
-    import gc
-    was_enabled = gc.isenabled()
-    gc.disable()
-    try:
+    with paused_gc():
         return _contacts_json(pc, bags, component_types)
-    finally:
-        if was_enabled:
-            gc.enable()
 
 
 def _contacts_json(pc, bags, component_types):

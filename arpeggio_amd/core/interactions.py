@@ -171,8 +171,10 @@ class InteractionComplex:
         b = self._bags.get('atom_atom')
         if b is None:
             return []
-        return [AtomAtomContact(int(i), int(j), [(int(s) >> k) & 1 for k in range(15)], config.CONTACT_TYPE_NAMES[c], d)
-                for i, j, s, c, d in zip(b['i'], b['j'], b['sift'], b['ctype'], b['dist'])]
+        bits = {int(s): [(int(s) >> k) & 1 for k in range(15)] for s in np.unique(b['sift']).tolist()}
+        with export.paused_gc():
+            return [AtomAtomContact(i, j, list(bits[s]), config.CONTACT_TYPE_NAMES[c], d)
+                    for i, j, s, c, d in zip(b['i'].tolist(), b['j'].tolist(), b['sift'].tolist(), b['ctype'].tolist(), b['dist'])]
 
     @property
     def plane_plane_contacts(self):
