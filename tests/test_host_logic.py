@@ -306,3 +306,25 @@ def test_c_record_builder_equals_the_python_loop():
     assert fast[0]['bgn'] is not fast[1]['bgn'] and fast[0]['contact'] is not slow[0]['contact']
     fast[0]['bgn']['auth_atom_id'] = 'changed'                                          # records own their dicts
     assert export.contacts_json(pc, bags, pc.component_types)[0]['bgn']['auth_atom_id'] != 'changed'
+
+
+def test_contact_table_writer_equals_the_csv_module(tmp_path):
+    """write_contact_file assembles '<id>_contacts.csv' from text fragments; the bytes are what csv.writer (QUOTE_MINIMAL,
+    '\\r\\n' line ends) writes row by row — atom names that need quoting and awkward float32 distances included."""
+    from arpeggio_amd.core import export
+    pc = synth.proteinlike(n_res=60, n_waters=20).ensure_labels()
+    pc.atom_name[5], pc.atom_name[6], pc.atom_name[7] = 'C,1', 'O"2', "N'3"
+    rng = np.random.default_rng(1)
+    n = 5000
+    i = rng.integers(0, pc.n_atoms - 1, n).astype(np.int32)
+    i[:60] = rng.integers(4, 8, 60)
+    dist = (rng.random(n) * 5).astype(np.float32)
+    dist[:8] = [0.0, 1e-5, 3.0, 4.9999995, 1.5e-7, 2.5, 1e-4, 123456.79]
+    bag = dict(i=i, j=(i + 1).astype(np.int32), dist=dist, sift=rng.integers(0, 1 << 15, n).astype(np.uint16),
+               ctype=rng.integers(0, 6, n).astype(np.uint8))
+    lab = export.Labels(pc, pc.component_types)
+    for tag, rows in (('all', None), ('subset', np.nonzero(bag['ctype'] == 2)[0]), ('none', np.zeros(0, np.int64))):
+        a, b = str(tmp_path / f'{tag}_a.csv'), str(tmp_path / f'{tag}_b.csv')
+        export.write_contact_file(a, pc, lab, bag, rows)
+        export.write_contact_file_csv_module(b, pc, lab, bag, rows)
+        assert open(a, 'rb').read() == open(b, 'rb').read(), tag
