@@ -16,6 +16,7 @@ oracle timed on one host core on a bounded sample of the same workload).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -175,19 +176,23 @@ def main():
         counts = step()
     sync_all()
     ctx.host_times(reset=True)
-    repeats = 0
+    # How many blocks of K steps fill --min-seconds is settled ONCE, before the timed region, from an untimed trial block (all
+    # ranks take the largest answer): the timed region itself holds steps only — at N > 1 no collective that N = 1 would not have.
+    t_trial = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    trial_s = max(time.perf_counter() - t_trial, 1e-6)
+    repeats = max(1, int(math.ceil(args.min_seconds / trial_s)))
+    if dist is not None:
+        flag = torch.tensor([float(repeats)], device=('cpu' if comm_device is None else comm_device))
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        repeats = int(flag.item())
+    sync_all()
+    ctx.host_times(reset=True)
     t0 = time.perf_counter()
-    while True:
+    for _ in range(repeats):
         for _ in range(args.steps):
             counts = step()          # blocks until the pass has published its counters (one host wait per step)
-        repeats += 1
-        go_on = (time.perf_counter() - t0) < args.min_seconds
-        if dist is not None:         # every rank must take the same number of blocks
-            flag = torch.tensor([1.0 if go_on else 0.0], device=('cpu' if comm_device is None else comm_device))
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            go_on = bool(flag.item() > 0)
-        if not go_on:
-            break
     sync_all()
     elapsed = time.perf_counter() - t0
     timed_steps = args.steps * repeats
@@ -513,7 +518,7 @@ def main():
     line = {
         'metric': 'evaluated atom-pairs/s', 'value': round(value, 1), 'unit': 'candidate atom-pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-        'timed_steps': timed_steps, 'timed_region_s': round(elapsed, 3), 'setup_passes': SETUP_PASSES,
+        'timed_steps': timed_steps, 'timed_region_s': round(elapsed, 3), 'setup_passes': SETUP_PASSES, 'untimed_trial_steps': args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64 distance test / f32+f64 SIFt',
         'data': 'synthetic',
         'config': {'workload': workload, 'atoms_per_gpu': args.atoms, 'cutoff_A': args.cutoff, 'vdw_comp': args.vdw_comp,
