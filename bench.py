@@ -538,7 +538,9 @@ def main():
         'launch_mode': 'four launches on one HIP stream (bin, scan+scatter, search, sift+ring/amide loops), the last one publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
         'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2), 'shard_setup_breakdown_ms': shard_timings,
-        'halo_exchange': (halo_note if world > 1 else None), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
+        'halo_exchange': (halo_note if world > 1 else None),
+        'scaling_note': (None if world == 1 else f'per-GPU work is {args.atoms} atoms (+ halo); the default N = 1 line is the 100 000-atom headline workload, '
+                                                 f'so the single-GPU figure to compare with is `bench.py --gpus 1 --atoms {args.atoms}` (profiles/README.md: 1.18e11 pairs/s at 250 000 atoms)'), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'end_to_end': end_to_end,
         'end_to_end_ms_per_structure': (end_to_end or {}).get('ms_per_structure'),
         'get_contacts_ms': (end_to_end or {}).get('get_contacts_ms'),
