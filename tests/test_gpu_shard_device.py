@@ -180,3 +180,39 @@ def test_face_buffers_through_torch_tensors(capi):
     out = subprocess.run([sys.executable, '-c', _TORCH_SCRIPT % port], cwd=root, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert out.returncode == 0 and 'TORCH_ALIAS_OK' in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_shards_device_vs_host(capi, seed):
+    """Random structure sizes, rank counts and selections: every device-assembled shard gives the results of the host-assembled
+    one, and the union over the ranks is the single-context result."""
+    rng = np.random.default_rng(500 + seed)
+    world = int(rng.integers(2, 5))
+    full = synth.slab_config(int(rng.integers(1500, 6000)), world, seed=int(rng.integers(1, 100)))
+    whole = bool(rng.integers(0, 2))
+    sel = None
+    if not whole:
+        sel = (rng.random(full.n_residues) < rng.choice([0.05, 0.4, 0.9]))[full.res_id].astype(np.uint8)
+        sel[0] = 1
+    ctxs, shards = _assemble_all(capi, full, world, sel, whole=whole)
+    ref = capi.Context(0)
+    one = capi.Context(0)
+    one.set_complex(full)
+    if sel is not None:
+        one.set_selection(sel)
+    n_one = one.run_launch()
+    keys = []
+    for r, (c, ds) in enumerate(zip(ctxs, shards)):
+        hs = sharding.make_shard_local(full, r, world, sel)
+        assert np.array_equal(ds.global_id, hs.global_id) and np.array_equal(ds.origin, hs.origin)
+        sharding.upload_shard(ref, hs, whole_structure=whole)
+        n_dev, n_host = c.run_launch(), ref.run_launch()
+        assert n_dev == n_host, (seed, r, n_dev, n_host)
+        a, b = c.atom_contacts_fetch(n_dev['atom_atom']), ref.atom_contacts_fetch(n_host['atom_atom'])
+        assert all(np.array_equal(a[k], b[k]) for k in a)
+        keys.append(a['i'].astype(np.int64) * full.n_atoms + a['j'])
+    if whole:      # (with a partial selection the shards would first have to exchange selection_plus: covered elsewhere)
+        want = one.atom_contacts_fetch(n_one['atom_atom'])
+        assert np.array_equal(np.sort(np.concatenate(keys)), want['i'].astype(np.int64) * full.n_atoms + want['j'])
+    for c in ctxs + [ref, one]:
+        c.close()
