@@ -249,3 +249,35 @@ def threshold_edge_pack(comp=0.1):
     pc = tiny_complex(np.array(xyz, np.float32), vdw=vdw, cov=cov, type_mask=tm, flags=fl)
     pc.expansion_probe = np.array(probe, np.int32)
     return pc
+
+
+def concat_packs(p, q, shift=(0.0, 0.0, 0.0)):
+    """Two packed structures side by side as one (q moved by `shift`); labels are dropped.  For shard tests that need a
+    gap in the structure (an empty slab between two bodies)."""
+    n, r = p.n_atoms, p.n_residues
+    d = np.asarray(shift, np.float64)
+
+    def link(v, base):
+        return np.where(v >= 0, v + base, -1).astype(np.int32)
+
+    def moved(c):
+        return (c + d.astype(c.dtype)) if len(c) else c
+
+    return PackedComplex(
+        xyz=np.concatenate([p.xyz, moved(q.xyz)]), vdw=np.concatenate([p.vdw, q.vdw]), cov=np.concatenate([p.cov, q.cov]),
+        type_mask=np.concatenate([p.type_mask, q.type_mask]), flags=np.concatenate([p.flags, q.flags]),
+        res_id=np.concatenate([p.res_id, q.res_id + r]).astype(np.int32),
+        res_flags=np.concatenate([p.res_flags, q.res_flags]),
+        res_prev=np.concatenate([p.res_prev, link(q.res_prev, r)]).astype(np.int32),
+        res_next=np.concatenate([p.res_next, link(q.res_next, r)]).astype(np.int32),
+        bond_off=np.concatenate([p.bond_off, q.bond_off[1:] + p.bond_off[-1]]).astype(np.int32),
+        bond_idx=np.concatenate([p.bond_idx, q.bond_idx + n]).astype(np.int32),
+        h_off=np.concatenate([p.h_off, q.h_off[1:] + p.h_off[-1]]).astype(np.int32),
+        h_xyz=np.concatenate([p.h_xyz, moved(q.h_xyz)]),
+        sb_nbr=np.concatenate([p.sb_nbr, link(q.sb_nbr, n)]).astype(np.int32),
+        ring_center=np.concatenate([p.ring_center, moved(q.ring_center)]),
+        ring_normal=np.concatenate([p.ring_normal, q.ring_normal]),
+        ring_res=np.concatenate([p.ring_res, link(q.ring_res, r)]).astype(np.int32),
+        amide_center=np.concatenate([p.amide_center, moved(q.amide_center)]),
+        amide_normal=np.concatenate([p.amide_normal, q.amide_normal]),
+        amide_res=np.concatenate([p.amide_res, link(q.amide_res, r)]).astype(np.int32))

@@ -216,3 +216,29 @@ def test_random_shards_device_vs_host(capi, seed):
         assert np.array_equal(np.sort(np.concatenate(keys)), want['i'].astype(np.int64) * full.n_atoms + want['j'])
     for c in ctxs + [ref, one]:
         c.close()
+
+
+def test_rank_with_an_empty_slab(capi):
+    """Two bodies 200 A apart cut into three slabs: the middle rank owns nothing and receives nothing.  Its assembled shard
+    is an empty structure (zero atoms, zero contacts) on both the device and the host path, and the other two ranks give the
+    single-context result between them."""
+    from helpers import concat_packs
+    full = concat_packs(synth.config3(3000, seed=1), synth.config3(3000, seed=2), shift=(200.0, 0.0, 0.0))
+    full.validate()
+    ctxs, shards = _assemble_all(capi, full, 3, None, whole=True)
+    assert shards[1].n_atoms == 0 and sharding.make_shard_local(full, 1, 3, None).pc.n_atoms == 0
+    one = capi.Context(0)
+    one.set_complex(full)
+    n_one = one.run_launch()
+    want = one.atom_contacts_fetch(n_one['atom_atom'])
+    keys, planes = [], 0
+    for c in ctxs:
+        n = c.run_launch()
+        g = c.atom_contacts_fetch(n['atom_atom'])
+        keys.append(g['i'].astype(np.int64) * full.n_atoms + g['j'])
+        planes += sum(n[k] for k in NAMES)
+    assert len(keys[1]) == 0
+    assert np.array_equal(np.sort(np.concatenate(keys)), want['i'].astype(np.int64) * full.n_atoms + want['j'])
+    assert planes == sum(n_one[k] for k in NAMES) > 0
+    for c in ctxs + [one]:
+        c.close()
