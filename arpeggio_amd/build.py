@@ -37,7 +37,8 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         build_pyexport()
         return LIB
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    # ARP_EXTRA_HIPCC_FLAGS: developer builds only (e.g. -DARP_SEARCH_TRACE, -DHOME_CELLS=1)
+    cmd = [hipcc()] + FLAGS + os.environ.get('ARP_EXTRA_HIPCC_FLAGS', '').split() + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

@@ -125,6 +125,7 @@ struct arp_ctx {
     bool external_stream = false;
     std::string err;
     int num_cu = 256;
+    int search_resident = 768;          // blocks of k_search<MODE_CONTACTS> the chip holds at once (occupancy x CUs)
 
     // ---- sizes
     int64_t n = 0, nres = 0, nring = 0, namide = 0;
@@ -580,11 +581,62 @@ int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr, hipS
     return ARP_OK;
 }
 
+#ifdef ARP_SEARCH_TRACE
+static unsigned long long* trace_buf() {   // stamps of 12 blocks x 2 waves x 10 words (arp_pairs.h, ARP_SEARCH_TRACE)
+    static unsigned long long* p = nullptr;
+    if (!p && hipMalloc(&p, 400 * 8) == hipSuccess) (void)hipMemset(p, 0, 400 * 8);
+    return p;
+}
+static void trace_dump(hipStream_t st) {
+    static int passes = 0;
+    if (!getenv("ARP_TRACE_DUMP") || ++passes != 30) return;
+    (void)hipStreamSynchronize(st);
+    unsigned long long h[400];
+    if (hipMemcpy(h, trace_buf(), sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int k = 0; k < 24; ++k) {
+        const unsigned long long* o = h + k * 10;
+        if (!o[0]) continue;
+        fprintf(stderr, "TRACE block %4llu qn %3llu :", o[8], o[9]);
+        for (int j = 1; j < 8; ++j) fprintf(stderr, " %6.2f", o[j] ? (double)(o[j] - o[0]) * 0.01 : -1.0);
+        fprintf(stderr, "  start %.2f us\n", (double)(long long)(o[0] - h[0]) * 0.01);
+    }
+}
+#define SEARCH_TRACE_ARG ((uint8_t*)trace_buf())
+#else
+#define SEARCH_TRACE_ARG ((uint8_t*)nullptr)
+#endif
+#ifdef ARP_SIFT_TRACE
+static void sift_trace_dump(hipStream_t st, int np) {
+    static int passes = 0;
+    if (!getenv("ARP_TRACE_DUMP") || ++passes != 30) return;
+    (void)hipStreamSynchronize(st);
+    unsigned long long h[32 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sift_trace), sizeof(h)) != hipSuccess) return;
+    for (int k = 0; k < 32; ++k) {
+        const unsigned long long* o = h + k * 8;
+        if (!o[0]) continue;
+        const int blk = k < 24 ? k * 32 : (k - 24) * 8;
+        fprintf(stderr, "SIFT TRACE block %4d (%s):", blk, blk < np ? "lists" : "sift");
+        for (int j = 1; j < 6; ++j) fprintf(stderr, " %6.2f", o[j] >= o[0] ? (double)(o[j] - o[0]) * 0.01 : -1.0);
+        fprintf(stderr, "  start %.2f us\n", (double)(long long)(o[0] - h[24 * 8]) * 0.01);
+    }
+}
+#endif
 // Blocks of the neighbour search: ~ARP_SEARCH_CPW cells per wave, a multiple of 8 (one per XCD).
 int search_blocks(const GridDesc& d, int cpw = 1) {
     int nb = (d.ncell + SEARCH_WAVES * cpw - 1) / (SEARCH_WAVES * cpw);
     nb = std::max(8, std::min(nb, 8192));
     return (nb + 7) & ~7;
+}
+// ... rounded to whole rounds of resident blocks once the launch comes near one: with 656 blocks on a chip that holds 768,
+// the CUs given three blocks have half as much work again as those given two, and the kernel lasts as long as the former
+// (100 k atoms: 38.3 -> 35.3 us with 768)
+int search_blocks_balanced(const arp_ctx* c, const GridDesc& d, int cpw) {
+    static const int forced = env_int("ARP_SEARCH_BLOCKS", 0);
+    if (forced > 0) return (forced + 7) & ~7;
+    const int nb = search_blocks(d, cpw), R = c->search_resident;
+    if (R < 8 || 2 * nb < R) return nb;
+    return std::min(std::max(1, (nb + R / 2) / R) * R, 8192) & ~7;
 }
 
 int zero_counter(arp_ctx* c, int first, int count) {
@@ -1001,12 +1053,13 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // blocks split their work statically: one that had to wait for a slot would finish that much later than the rest),
         // so the sift part gets num_cu * blocks-per-CU minus these.  Sixteen list chunks (of 64 entries) per wave are still
         // inside the time the sift blocks need (sweep in profiles/README.md); ring-heavy structures get more blocks, up to half the slots.
-        // ... and fewer when the sift part itself is short: about three list chunks take as long as one batch of 64 pairs, and a
-        // sift wave of a small structure has only a batch or two.
+        // ... and fewer when the sift part itself is short: a list chunk takes about as long as a batch of 64 pairs (2.3 vs 2.5-3 us
+        // in the block traces, -DARP_SIFT_TRACE), and a sift wave of a small structure has only a batch or two.
         static const int cpw_max = std::max(1, env_int("ARP_PLANE_CPW", 16));
         const int64_t expect_pairs = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
         const double batches_per_wave = (double)expect_pairs / (64.0 * 4.0 * std::min<double>(c->num_cu * 4.0, std::max(1.0, expect_pairs / 256.0)));
-        const int chunks_per_wave = std::max(2, std::min(cpw_max, (int)(3.0 * batches_per_wave + 0.5)));
+        static const double chunk_factor = env_int("ARP_PLANE_CHUNK_FACTOR_X10", 10) / 10.0;
+        const int chunks_per_wave = std::max(2, std::min(cpw_max, (int)(chunk_factor * batches_per_wave + 0.5)));
         np = (int)std::min<long long>(std::max<long long>((entries + 256 * chunks_per_wave - 1) / (256 * chunks_per_wave), 8), 2 * c->num_cu);
         np = (np + 7) & ~7;
     }
@@ -1026,11 +1079,14 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // and a wave's cells are a serial chain (1tqn_h stand-in: 22 -> 16 us).
         static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 3));
         const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
-        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks(c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
+        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
                            c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
                            include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
-                           c->d_ctr + C_STAT_ACC, (uint8_t*)nullptr);
+                           c->d_ctr + C_STAT_ACC, SEARCH_TRACE_ARG);
         CHK(check_launch(c, "k_search<CONTACTS>"));
+#ifdef ARP_SEARCH_TRACE
+        trace_dump(c->stream);
+#endif
     }
     if (planes_alone) {
         if (st2 != c->stream) HIPCHK(c, hipStreamWaitEvent(st2, c->ev_sel, 0));
@@ -1059,6 +1115,9 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         else
             hipLaunchKernelGGL(k_sift, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         CHK(check_launch(c, "k_sift"));
+#ifdef ARP_SIFT_TRACE
+        sift_trace_dump(c->stream, np);
+#endif
     } else if (!planes_alone) {
         c->pub.expected = 0;   // nothing was launched that could publish: the caller falls back to k_publish_counters
     }
@@ -1181,6 +1240,11 @@ int arp_create(int device, arp_ctx** out) {
     (void)hipFuncSetAttribute((const void*)k_scan_scatter_atoms<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16384);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_search<MODE_CONTACTS>, 64 * SEARCH_WAVES, 0) == hipSuccess && per_cu > 0)
+            c->search_resident = per_cu * c->num_cu;
+    }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     c->stream = c->own_stream;
     if (e == hipSuccess) {   // the second stream (ring / amide kernel) yields to the main one

@@ -503,6 +503,38 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
 
 enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
 
+// Build with -DARP_SEARCH_TRACE to see where a wave of k_search<MODE_CONTACTS> spends its time: lane 0 of the first and the last
+// wave of every 97th block stamp the 100 MHz clock after the start table has arrived (1), after the atoms of the first chunk have (2),
+// after its distance loop (3), after its hits are queued (4), when the wave's home blocks are done (5), after the block's
+// reservation (6) and after the final write (7); the stamps leave through the `plus` argument (unused in this mode) and
+// ARP_TRACE_DUMP=1 prints them at the 30th pass (arp_api.hip).  The stamps of (1) and (2) wait for the loads — they perturb
+// what they measure a little.
+#ifdef ARP_SEARCH_TRACE
+// (the stamps live in LDS, not in registers: the trace build keeps the occupancy of the production build)
+#define TRACE_DECL __shared__ unsigned long long s_tr[SEARCH_WAVES][8]; int tr_on = 1; \
+    if (lane < 8) s_tr[w][lane] = 0
+#define TRACE_PUT(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) s_tr[w][k] = t_; } while (0)
+#define TRACE_STAMP(k) do { if (tr_on) TRACE_PUT(k); } while (0)
+#define TRACE_STAMP_LOADED(k) do { if (tr_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE_PUT(k); } } while (0)
+#define TRACE_FIRST_ONLY tr_on = 0
+#define TRACE_ALWAYS(k) TRACE_PUT(k)
+#define TRACE_DUMP do { \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        TRACE_PUT(7); \
+        if (MODE == MODE_CONTACTS && plus && lane == 0 && (w == 0 || w == SEARCH_WAVES - 1) && (blockIdx.x % 97 == 0)) { \
+            unsigned long long* o = (unsigned long long*)plus + ((blockIdx.x / 97) * 2 + (w ? 1 : 0)) * 10; \
+            for (int k = 0; k < 8; ++k) o[k] = s_tr[w][k]; \
+            o[8] = blockIdx.x; o[9] = (unsigned long long)qn; \
+        } } while (0)
+#else
+#define TRACE_DECL
+#define TRACE_STAMP(k)
+#define TRACE_STAMP_LOADED(k)
+#define TRACE_FIRST_ONLY
+#define TRACE_ALWAYS(k)
+#define TRACE_DUMP
+#endif
+
 // One wavefront per home cell.  Half stencil: own cell (later entries) + 13 forward cells,
 // expressed as 5 contiguous ranges of the cell-sorted array (cells are x-fastest, so 3
 // x-neighbours are contiguous).  The ~87 candidate atoms of the 5 ranges are flattened over
@@ -562,6 +594,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
 
     int qn = 0;
     unsigned int n_cand = 0, n_acc = 0;   // per lane; reduced over the wave at the end
+    TRACE_DECL;
+    TRACE_STAMP(0);
     const float r2_lo = (float)(r2 * (1.0 - 1e-5)), r2_hi = (float)(r2 * (1.0 + 1e-5));
 
     // output segment of this block (cap = capacity of ONE segment)
@@ -606,6 +640,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
             }
         }
       }
+      TRACE_STAMP_LOADED(1);
 #pragma unroll 1
       for (int ci = 0; ci < 8; ++ci) {
         const int cell = cg + ci * SEARCH_WAVES;
@@ -681,6 +716,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                 // float32 pre-filter: |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded squares, two
                 // rounded sums), so outside the +-1e-5 band the float32 answer IS the float64 answer.
                 uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+                TRACE_STAMP_LOADED(2);
                 const v2f cx = {x0.x, x1.x}, cy = {x0.y, x1.y}, cz = {x0.z, x1.z};
 #pragma unroll 1
                 for (int hh = hcount - 1; hh >= 0; --hh) {
@@ -720,6 +756,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                     }
                     lo0 &= te0; hi0 &= te0; lo1 &= te1; hi1 &= te1;
                 }
+                TRACE_STAMP(3);
                 // inside the band (rare) the exact Bio.PDB.kdtrees float64 test decides
                 uint32_t band0 = hi0 & ~lo0, band1 = hi1 & ~lo1;
                 if (__any((band0 | band1) != 0)) {
@@ -790,10 +827,13 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                         if (qn > QCAP - 64) flush();
                     }
                 }
+                TRACE_STAMP(4);
+                TRACE_FIRST_ONLY;
             }
         }
       }
     }
+    TRACE_ALWAYS(5);
     // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
     // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
     __shared__ int s_qn[SEARCH_WAVES];
@@ -811,15 +851,30 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         atomicAdd(ctr_acc + slot, ta);
     }
     __syncthreads();
+    TRACE_ALWAYS(6);
     if (MODE != MODE_MARK && qn > 0) {
         u64 base = s_base;
         for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
         for (int k = lane; k < qn; k += 64)
             if (base + k < cap) seg_pairs[base + k] = q[w][k];
     }
+    TRACE_DUMP;
 }
 
 // ---- per-pair SIFt --------------------------------------------------------------------
+// -DARP_SIFT_TRACE: thread 0 of every 32nd block of k_sift_planes stamps the 100 MHz clock at entry (0), after the prologue's
+// barrier (1), after its first batch (2), after its last batch (3), after the remaining hydrogen tasks (4) and after pass_end (5);
+// ARP_TRACE_DUMP=1 prints them at the 30th pass (arp_api.hip)
+#ifdef ARP_SIFT_TRACE
+__device__ unsigned long long g_sift_trace[32 * 8];
+// slots 0-23: every 32nd block; slots 24-31: blocks 0, 8, .. 56 (the list blocks come first)
+#define SIFT_TRACE(k) do { if (threadIdx.x == 0) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+        if ((blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 24 && blockIdx.x > 0) g_sift_trace[(blockIdx.x >> 5) * 8 + (k)] = t_; \
+        if ((blockIdx.x & 7) == 0 && blockIdx.x < 64) g_sift_trace[(24 + (blockIdx.x >> 3)) * 8 + (k)] = t_; } } while (0)
+#else
+#define SIFT_TRACE(k)
+#endif
 __device__ __forceinline__ num::f3 xyz_of(float4 v) { return {v.x, v.y, v.z}; }
 
 // utils.is_hbond (utils.py:73-93, angle_min 1.57) / is_weak_hbond (utils.py:96-116, 2.27).
@@ -1036,12 +1091,13 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), 0.0f);
     }
     __syncthreads();
+    SIFT_TRACE(1);
     int tn = 0;
     auto run_tasks = [&](int first_, int count) {   // stage B on tq[w][first_ .. first_ + count)
         if (lane < count) {
             const uint4 t = tq[w][first_ + lane];
             const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, s_tab, sd, comp);
-            out_s[t.x] = (uint16_t)((t.w & 0xFFFFu) | add);
+            __builtin_nontemporal_store((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
         }
     };
     long long out_base = 0;
@@ -1140,15 +1196,17 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             if ((tb & te & ARP_T_AROMATIC) && d <= (float)4.0) s |= ARP_S_AROMATIC;
             if ((tb & te & ARP_T_HYDROPHOBE) && d <= (float)4.5) s |= ARP_S_HYDROPHOBIC;
         }
-        out_i[p] = gid ? gid[b] : b;
-        out_j[p] = gid ? gid[e] : e;
-        out_d[p] = d;
-        out_ct[p] = (uint8_t)ct;
+        // (the records are not read again on the device in this pass: streaming stores, so that they leave L2 while the kernel
+        // runs instead of in the write-back at its end)
+        __builtin_nontemporal_store(gid ? gid[b] : b, out_i + p);
+        __builtin_nontemporal_store(gid ? gid[e] : e, out_j + p);
+        __builtin_nontemporal_store(d, out_d + p);
+        __builtin_nontemporal_store((uint8_t)ct, out_ct + p);
         if (need) {
             queued = true;
             task = make_uint4((unsigned)p, (unsigned)pr.x, (unsigned)pr.y, s | (need << 16));
         } else {
-            out_s[p] = (uint16_t)s;
+            __builtin_nontemporal_store((uint16_t)s, out_s + p);
         }
         }
         // stage B bookkeeping (whole wave)
@@ -1161,8 +1219,11 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
                 run_tasks(tn, 64);
             }
         }
+        if (base == first) SIFT_TRACE(2);
     }
+    SIFT_TRACE(3);
     if (tn > 0) run_tasks(0, tn);
+    SIFT_TRACE(4);
 }
 
 // Per-atom accumulators of the contact loop (interactions.py:821-852, 923-934; utils.py:182-221) from the

@@ -766,10 +766,15 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa
                                                                      GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
                                                                      u64* publish_counts, int np, PublishArgs pub) {
     __shared__ SiftPlanesShared s_sh;
+    SIFT_TRACE(0);
     const int b = (int)blockIdx.x;
     if (b >= np) sift_body(sa, b - np, nsift, &s_sh.sift);
-    else planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
+    else {
+        planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
+        SIFT_TRACE(4);
+    }
     pass_end(pub, 0);
+    SIFT_TRACE(5);
 }
 // the two halves as separate kernels (sharded stage path with a caller-owned stream, structures without atoms / planes)
 __global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
