@@ -593,6 +593,34 @@ static void trace_dump(hipStream_t st) {
     (void)hipStreamSynchronize(st);
     unsigned long long h[400];
     if (hipMemcpy(h, trace_buf(), sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    {
+        static unsigned long long e[8192 * 2];
+        if (hipMemcpyFromSymbol(e, HIP_SYMBOL(g_search_ends), sizeof(e)) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            int nblk = 0;
+            for (int k = 0; k < 8192; ++k) if (e[2 * k]) { t0 = std::min(t0, e[2 * k]); nblk = k + 1; }
+            std::vector<double> ends, starts;
+            for (int k = 0; k < nblk; ++k) { ends.push_back((double)(e[2 * k + 1] - t0) * 0.01); starts.push_back((double)(e[2 * k] - t0) * 0.01); }
+            std::sort(ends.begin(), ends.end());
+            std::sort(starts.begin(), starts.end());
+            if (nblk > 0)
+                fprintf(stderr, "SEARCH BLOCK ENDS (%d blocks; starts: median %.2f, max %.2f us): 10%% %.2f, median %.2f, 90%% %.2f, 99%% %.2f, max %.2f us\n", nblk,
+                        starts[nblk / 2], starts[nblk - 1], ends[nblk / 10], ends[nblk / 2], ends[nblk * 9 / 10], ends[nblk * 99 / 100], ends[nblk - 1]);
+            for (int g8 = 0; g8 < 8 && nblk >= 8; ++g8) {
+                double sum = 0, mx = 0, mn = 1e9; int cnt = 0;
+                for (int k = g8; k < nblk; k += 8) { const double v = (double)(e[2 * k + 1] - t0) * 0.01; sum += v; mx = std::max(mx, v); mn = std::min(mn, v); ++cnt; }
+                fprintf(stderr, "  blocks %% 8 == %d: mean end %.2f, min %.2f, max %.2f us;", g8, sum / cnt, mn, mx);
+                // by position inside the XCD's run of cells: first, middle and last third
+                const int per = nblk / 8;
+                for (int third = 0; third < 3; ++third) {
+                    double s3 = 0; int c3 = 0;
+                    for (int k = g8; k < nblk; k += 8) { const int pos = k >> 3; if (pos * 3 / per == third) { s3 += (double)(e[2 * k + 1] - t0) * 0.01; ++c3; } }
+                    fprintf(stderr, " third %d: %.2f", third, s3 / std::max(c3, 1));
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+    }
     for (int k = 0; k < 24; ++k) {
         const unsigned long long* o = h + k * 10;
         if (!o[0]) continue;
@@ -612,10 +640,32 @@ static void sift_trace_dump(hipStream_t st, int np) {
     (void)hipStreamSynchronize(st);
     unsigned long long h[32 * 8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sift_trace), sizeof(h)) != hipSuccess) return;
+    {
+        static unsigned long long e[2048 * 2];
+        if (hipMemcpyFromSymbol(e, HIP_SYMBOL(g_sift_ends), sizeof(e)) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            int nblk = 0;
+            for (int k = 0; k < 2048; ++k) if (e[2 * k]) { t0 = std::min(t0, e[2 * k]); nblk = k + 1; }
+            std::vector<std::pair<double, int>> ends;
+            double latest_start = 0;
+            for (int k = 0; k < nblk; ++k) { ends.push_back({(double)(e[2 * k + 1] - t0) * 0.01, k}); latest_start = std::max(latest_start, (double)(e[2 * k] - t0) * 0.01); }
+            std::sort(ends.begin(), ends.end());
+            fprintf(stderr, "BLOCK ENDS (%d blocks, %d list blocks; latest start %.2f us): median %.2f, 90%% %.2f, 99%% %.2f; last ten:", nblk, np, latest_start,
+                    ends[nblk / 2].first, ends[nblk * 9 / 10].first, ends[nblk * 99 / 100].first);
+            for (int k = std::max(0, nblk - 10); k < nblk; ++k) fprintf(stderr, " %d@%.2f(start %.2f)", ends[k].second, ends[k].first, (double)(e[2 * ends[k].second] - t0) * 0.01);
+            fprintf(stderr, "\n");
+            for (int g8 = 0; g8 < 8; ++g8) {
+                double sum = 0, mx = 0; int cnt = 0;
+                for (int k = np + ((g8 - np) & 7); k < nblk; k += 8) { const double v = (double)(e[2 * k + 1] - t0) * 0.01; sum += v; mx = std::max(mx, v); ++cnt; }
+                fprintf(stderr, "  blocks %% 8 == %d: %d sift blocks, mean end %.2f, max %.2f us\n", g8, cnt, sum / std::max(cnt, 1), mx);
+            }
+        }
+    }
     for (int k = 0; k < 32; ++k) {
         const unsigned long long* o = h + k * 8;
         if (!o[0]) continue;
         const int blk = k < 24 ? k * 32 : (k - 24) * 8;
+        if (k == 23) fprintf(stderr, "PUBLISHER (ticket in, tickets done, counters fetched, fence, flag):"); else
         fprintf(stderr, "SIFT TRACE block %4d (%s):", blk, blk < np ? "lists" : "sift");
         for (int j = 1; j < 6; ++j) fprintf(stderr, " %6.2f", o[j] >= o[0] ? (double)(o[j] - o[0]) * 0.01 : -1.0);
         fprintf(stderr, "  start %.2f us\n", (double)(long long)(o[0] - h[24 * 8]) * 0.01);

@@ -451,6 +451,25 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     }
 }
 
+// -DARP_SIFT_TRACE: thread 0 of every 32nd block of k_sift_planes stamps the 100 MHz clock at entry (0), after the prologue's
+// barrier (1), after its first batch (2), after its last batch (3), after the remaining hydrogen tasks (4) and after pass_end (5);
+// ARP_TRACE_DUMP=1 prints them at the 30th pass (arp_api.hip)
+#ifdef ARP_SIFT_TRACE
+__device__ unsigned long long g_sift_trace[32 * 8];
+__device__ unsigned long long g_sift_ends[2048 * 2];   // start / end of every block (thread 0)
+// slots 0-23: every 32nd block; slots 24-31: blocks 0, 8, .. 56 (the list blocks come first)
+#define SIFT_TRACE(k) do { if (threadIdx.x == 0) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+        if ((blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 23 && blockIdx.x > 0) g_sift_trace[(blockIdx.x >> 5) * 8 + (k)] = t_; \
+        if ((blockIdx.x & 7) == 0 && blockIdx.x < 64) g_sift_trace[(24 + (blockIdx.x >> 3)) * 8 + (k)] = t_; } } while (0)
+#else
+#define SIFT_TRACE(k)
+#endif
+#ifdef ARP_SIFT_TRACE
+#define PUB_TRACE(k) do { if (threadIdx.x == 0) g_sift_trace[23 * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PUB_TRACE(k)
+#endif
 // ---- end of a pass, without a launch of its own ------------------------------------------------------------
 // The last kernels of a pass (k_sift on the main stream, k_planes beside it on the second one) call pass_end() as their
 // final statement: every block takes a ticket once its own atomics have been performed, the last block of a kernel
@@ -471,6 +490,9 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     __shared__ int s_publisher;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's counter atomics have been performed (memory side)
     __syncthreads();
+#ifdef ARP_SIFT_TRACE
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) {
         int pub = 0;
         const unsigned grp = blockIdx.x & 7u;
@@ -484,11 +506,18 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     }
     __syncthreads();
     if (!s_publisher) return;
+#ifdef ARP_SIFT_TRACE
+    if (threadIdx.x == 0) g_sift_trace[23 * 8 + 0] = t_in;
+#endif
+    PUB_TRACE(1);
     // returning atomics read the memory-side value whatever this XCD's L2 holds, and leave the slot zero
     for (int i = threadIdx.x; i < (int)C_COUNT; i += blockDim.x) pa.host[i] = atomicExch(pa.ctr + i, 0ull);
+    PUB_TRACE(2);
     __threadfence_system();
+    PUB_TRACE(3);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(pa.host + C_COUNT, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    PUB_TRACE(4);
 }
 
 // ---- neighbour search ---------------------------------------------------------------
@@ -510,9 +539,11 @@ enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
 // ARP_TRACE_DUMP=1 prints them at the 30th pass (arp_api.hip).  The stamps of (1) and (2) wait for the loads — they perturb
 // what they measure a little.
 #ifdef ARP_SEARCH_TRACE
+__device__ unsigned long long g_search_ends[8192 * 2];   // start / end of every block (wave 0)
 // (the stamps live in LDS, not in registers: the trace build keeps the occupancy of the production build)
 #define TRACE_DECL __shared__ unsigned long long s_tr[SEARCH_WAVES][8]; int tr_on = 1; \
-    if (lane < 8) s_tr[w][lane] = 0
+    if (lane < 8) s_tr[w][lane] = 0; \
+    if (MODE == MODE_CONTACTS && threadIdx.x == 0 && blockIdx.x < 8192) g_search_ends[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime()
 #define TRACE_PUT(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) s_tr[w][k] = t_; } while (0)
 #define TRACE_STAMP(k) do { if (tr_on) TRACE_PUT(k); } while (0)
 #define TRACE_STAMP_LOADED(k) do { if (tr_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE_PUT(k); } } while (0)
@@ -521,6 +552,7 @@ enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
 #define TRACE_DUMP do { \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         TRACE_PUT(7); \
+        if (MODE == MODE_CONTACTS && threadIdx.x == 0 && blockIdx.x < 8192) g_search_ends[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); \
         if (MODE == MODE_CONTACTS && plus && lane == 0 && (w == 0 || w == SEARCH_WAVES - 1) && (blockIdx.x % 97 == 0)) { \
             unsigned long long* o = (unsigned long long*)plus + ((blockIdx.x / 97) * 2 + (w ? 1 : 0)) * 10; \
             for (int k = 0; k < 8; ++k) o[k] = s_tr[w][k]; \
@@ -674,7 +706,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
             const uint32_t m_selh = (MODE == MODE_MARK) ? (uint32_t)__ballot(hvalid && (__float_as_uint(hreg.w) & M_SEL)) : 0u;
 #pragma unroll 1
             for (int kb = 0; kb < total; kb += 128) {  // the ~87 candidates of this cell, two per lane
-                const int k0 = kb + lane, k1 = kb + 64 + lane;
+                // second candidate of the lane in REVERSE order: the candidates most likely to hit come first in the list (home
+                // pencil, then the pencils of the same layer), and a lane holding two of those walks twice as many hits in
+                // stage 2 as the rest — whose iteration count is the fullest lane's.  Lane l pairs candidate l with 127 - l.
+                const int k0 = kb + lane, k1 = kb + 127 - lane;
                 const bool valid0 = k0 < total, valid1 = k1 < total;
                 // invalid lanes read the first home atom instead of branching around the loads: the four loads of a
                 // chunk leave back to back (their lanes never test, kk = -1 below)
@@ -719,7 +754,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                 TRACE_STAMP_LOADED(2);
                 const v2f cx = {x0.x, x1.x}, cy = {x0.y, x1.y}, cz = {x0.z, x1.z};
 #pragma unroll 1
+#ifdef ARP_EXP_SKIP_STAGE1
+                for (int hh = (x0.x == 12345.0f ? hcount - 1 : -1); hh >= 0; --hh) {
+#else
                 for (int hh = hcount - 1; hh >= 0; --hh) {
+#endif
                     // broadcast the home atom from lane hh (v_readlane, no memory traffic)
                     const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh));
                     const float hy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh));
@@ -776,6 +815,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                     }
                 }
                 n_acc += __popc(lo0) + __popc(lo1);
+#ifdef ARP_EXP_SKIP_STAGE2
+                if (lo0 | lo1) { q[w][0] = make_int2((int)lo0, (int)lo1); }
+                lo0 = lo1 = 0;
+#endif
                 // ---- stage 2: every lane walks its own hits (residue filters, orientation, queueing)
                 while (__any((lo0 | lo1) != 0)) {
                     const bool has = (lo0 | lo1) != 0;
@@ -862,19 +905,6 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
 }
 
 // ---- per-pair SIFt --------------------------------------------------------------------
-// -DARP_SIFT_TRACE: thread 0 of every 32nd block of k_sift_planes stamps the 100 MHz clock at entry (0), after the prologue's
-// barrier (1), after its first batch (2), after its last batch (3), after the remaining hydrogen tasks (4) and after pass_end (5);
-// ARP_TRACE_DUMP=1 prints them at the 30th pass (arp_api.hip)
-#ifdef ARP_SIFT_TRACE
-__device__ unsigned long long g_sift_trace[32 * 8];
-// slots 0-23: every 32nd block; slots 24-31: blocks 0, 8, .. 56 (the list blocks come first)
-#define SIFT_TRACE(k) do { if (threadIdx.x == 0) { \
-        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
-        if ((blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 24 && blockIdx.x > 0) g_sift_trace[(blockIdx.x >> 5) * 8 + (k)] = t_; \
-        if ((blockIdx.x & 7) == 0 && blockIdx.x < 64) g_sift_trace[(24 + (blockIdx.x >> 3)) * 8 + (k)] = t_; } } while (0)
-#else
-#define SIFT_TRACE(k)
-#endif
 __device__ __forceinline__ num::f3 xyz_of(float4 v) { return {v.x, v.y, v.z}; }
 
 // utils.is_hbond (utils.py:73-93, angle_min 1.57) / is_weak_hbond (utils.py:96-116, 2.27).
