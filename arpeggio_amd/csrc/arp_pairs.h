@@ -888,7 +888,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         int tot = 0;
         u64 tc = 0, ta = 0;
         for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
+#ifdef ARP_EXP_SKIP_OUTPUT
+        s_base = 0;
+#else
         s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot) : 0;
+#endif
         const int slot = blockIdx.x & (STAT_SLOTS - 1);
         atomicAdd(ctr_cand + slot, tc);
         atomicAdd(ctr_acc + slot, ta);
@@ -898,8 +902,12 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     if (MODE != MODE_MARK && qn > 0) {
         u64 base = s_base;
         for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
+#ifndef ARP_EXP_SKIP_OUTPUT
         for (int k = lane; k < qn; k += 64)
             if (base + k < cap) seg_pairs[base + k] = q[w][k];
+#else
+        if (base == 12345 && cap == 77) seg_pairs[lane] = q[w][lane];
+#endif
     }
     TRACE_DUMP;
 }
