@@ -1156,14 +1156,21 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // instead of 1024, whose start-up and end-of-pass tickets were most of the kernel (stand-in: 25 -> 16 us).
         static const int pairs_per_block = std::max(64, env_int("ARP_SIFT_PPB", 256));
         const int64_t expect = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
+        static const int64_t stream_bytes = (int64_t)env_int("ARP_STREAM_OUT_MB", 96) << 20;
+        const bool stream_out = expect * 15 > stream_bytes;     // (15 B per record)
         const int by_work = (int)std::min<int64_t>((expect + pairs_per_block - 1) / pairs_per_block + PAIR_SEGS, 1 << 20);
         const int slots = merged ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * sift_blocks_per_cu;
         const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
-        if (merged)
-            hipLaunchKernelGGL(k_sift_planes, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
+        if (merged && stream_out)
+            hipLaunchKernelGGL(k_sift_planes<1>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
                                c->d_ctr + C_PLIST, np, c->pub);
+        else if (merged)
+            hipLaunchKernelGGL(k_sift_planes<0>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
+                               c->d_ctr + C_PLIST, np, c->pub);
+        else if (stream_out)
+            hipLaunchKernelGGL(k_sift<1>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         else
-            hipLaunchKernelGGL(k_sift, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
+            hipLaunchKernelGGL(k_sift<0>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         CHK(check_launch(c, "k_sift"));
 #ifdef ARP_SIFT_TRACE
         sift_trace_dump(c->stream, np);

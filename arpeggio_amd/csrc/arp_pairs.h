@@ -1073,6 +1073,16 @@ struct SiftArgs {
     uint8_t* out_ct;
     int* err;
 };
+// Contact records are not read again on the device in the pass that writes them.  When there are more of them than L2 and the
+// Infinity Cache keep (1 M atoms: 190 MB), streaming stores let them leave while the kernel runs instead of in the write-back at
+// its end (sift 303 -> 254 us); for a structure whose records fit (100 k atoms: 19 MB) they only cost write transactions
+// (WRITE_SIZE 20.8 -> 26.7 MB: partial lines are not merged), so the host picks the variant by size.  (A template parameter:
+// behind a run-time flag the compiler merges the two stores into a plain one.)
+template <int STREAM, typename T>
+__device__ __forceinline__ void put_record(T v, T* p) {
+    if (STREAM) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 struct SiftShared {
     uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
     double2 tab[RAD_TABLE];      // the structure's distinct {vdw, cov} pairs
@@ -1080,6 +1090,7 @@ struct SiftShared {
 };
 // vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
 // vblock % 8 is still the XCD the dispatcher put the block on)
+template <int STREAM>
 __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgrid, SiftShared* sh) {
     const int2* __restrict__ pairs = A.pairs;
     const u64* __restrict__ npairs_ptr = A.npairs_ptr;
@@ -1135,7 +1146,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         if (lane < count) {
             const uint4 t = tq[w][first_ + lane];
             const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, s_tab, sd, comp);
-            __builtin_nontemporal_store((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
+            put_record<STREAM>((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
         }
     };
     long long out_base = 0;
@@ -1234,17 +1245,15 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             if ((tb & te & ARP_T_AROMATIC) && d <= (float)4.0) s |= ARP_S_AROMATIC;
             if ((tb & te & ARP_T_HYDROPHOBE) && d <= (float)4.5) s |= ARP_S_HYDROPHOBIC;
         }
-        // (the records are not read again on the device in this pass: streaming stores, so that they leave L2 while the kernel
-        // runs instead of in the write-back at its end)
-        __builtin_nontemporal_store(gid ? gid[b] : b, out_i + p);
-        __builtin_nontemporal_store(gid ? gid[e] : e, out_j + p);
-        __builtin_nontemporal_store(d, out_d + p);
-        __builtin_nontemporal_store((uint8_t)ct, out_ct + p);
+        put_record<STREAM>(gid ? gid[b] : b, out_i + p);
+        put_record<STREAM>(gid ? gid[e] : e, out_j + p);
+        put_record<STREAM>(d, out_d + p);
+        put_record<STREAM>((uint8_t)ct, out_ct + p);
         if (need) {
             queued = true;
             task = make_uint4((unsigned)p, (unsigned)pr.x, (unsigned)pr.y, s | (need << 16));
         } else {
-            __builtin_nontemporal_store((uint16_t)s, out_s + p);
+            put_record<STREAM>((uint16_t)s, out_s + p);
         }
         }
         // stage B bookkeeping (whole wave)

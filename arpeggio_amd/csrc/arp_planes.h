@@ -762,6 +762,7 @@ union SiftPlanesShared {
     PlaneShared planes;
     SiftShared sift;
 };
+template <int STREAM>
 __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa, int nsift, AtomPlaneArgs ap, PlanePlaneArgs pp,
                                                                      GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
                                                                      u64* publish_counts, int np, PublishArgs pub) {
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_sift_ends[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int b = (int)blockIdx.x;
-    if (b >= np) sift_body(sa, b - np, nsift, &s_sh.sift);
+    if (b >= np) sift_body<STREAM>(sa, b - np, nsift, &s_sh.sift);
     else {
         planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
         SIFT_TRACE(4);
@@ -790,8 +791,9 @@ __global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs
     planes_from_lists(ap, pp, gg, gp, L, publish_counts, (int)blockIdx.x, (int)gridDim.x, &s_sh);
     pass_end(pub, 1);
 }
+template <int STREAM>
 __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(SiftArgs sa, PublishArgs pub) {
     __shared__ SiftShared s_sh;
-    sift_body(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+    sift_body<STREAM>(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
     pass_end(pub, 0);
 }
