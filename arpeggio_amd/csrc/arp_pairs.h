@@ -500,7 +500,7 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
         if (atomicAdd(tickets + C_TICKET_GROUP + grp, 1ull) == members - 1ull) {
             const u64 groups = gridDim.x < 8u ? (u64)gridDim.x : 8ull;
             if (atomicAdd(tickets + C_TICKET_KERNEL, 1ull) == groups - 1ull)            // last block of this kernel
-                pub = atomicAdd(pa.ctr + C_KERNELS_DONE, 1ull) == (u64)pa.expected - 1ull;
+                pub = pa.expected == 1 || atomicAdd(pa.ctr + C_KERNELS_DONE, 1ull) == (u64)pa.expected - 1ull;
         }
         s_publisher = pub;
     }
@@ -820,13 +820,16 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                 lo0 = lo1 = 0;
 #endif
                 // ---- stage 2: every lane walks its own hits (residue filters, orientation, queueing)
-                while (__any((lo0 | lo1) != 0)) {
-                    const bool has = (lo0 | lo1) != 0;
-                    const bool use1 = lo0 == 0;
-                    const uint32_t bits = use1 ? lo1 : lo0;
-                    const int hh = has ? __ffs(bits) - 1 : 0;
-                    if (use1) lo1 &= lo1 - 1; else lo0 &= lo0 - 1;
-                    const int4 aj = use1 ? a1 : a0;
+                // (both masks of the lane as one 64-bit word: the walk needs no branch to tell the two candidates apart — the
+                // compiler turned `use1 ? a1 : a0` plus the two ways of clearing a bit into two arms of register moves)
+                unsigned long long lo = (unsigned long long)lo0 | ((unsigned long long)lo1 << 32);
+                while (__any(lo != 0)) {
+                    const bool has = lo != 0;
+                    const int bit = __ffsll((long long)lo) - 1;     // (-1 for a lane without hits: it reads home atom 31 and is masked by `has`)
+                    lo &= lo - 1ull;
+                    const int hh = bit & 31;
+                    const bool use1 = bit >= 32;
+                    const int4 aj = make_int4(use1 ? a1.x : a0.x, use1 ? a1.y : a0.y, use1 ? a1.z : a0.z, use1 ? a1.w : a0.w);
                     const uint32_t mj = use1 ? mj1 : mj0;
                     const int j = use1 ? j1 : j0;
                     const int h = hb + hh;
