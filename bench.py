@@ -424,7 +424,7 @@ def main():
     roofline = {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': int(b_alg), 'avg_launch_ms': round(dom_ms, 5),
-                'note': {'search': 'VALU / LDS issue-bound geometry kernel (12 M wave-instructions per launch, profiles/round2_j_pmc_per_launch.csv); ',
+                'note': {'search': 'VALU / LDS issue-bound geometry kernel (12 M wave-instructions per launch, profiles/round2_k_pmc_per_launch.csv); ',
                          'sift': 'gather-latency-bound at 4 waves per SIMD (125 VGPRs): 72 % of the wave cycles are waits (SQ_WAIT_ANY); ',
                          'mark_search': 'VALU / LDS issue-bound geometry kernel; '}.get(dom, '') +
                         'the HBM fraction is small by construction: register-tiled pair tests move ~35 MB per 100 k-atom pass (SURVEY 8d)'}
