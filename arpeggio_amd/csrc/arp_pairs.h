@@ -521,7 +521,9 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
 }
 
 // ---- neighbour search ---------------------------------------------------------------
+#ifndef SEARCH_WAVES
 #define SEARCH_WAVES 8
+#endif
 #ifndef QCAP
 #define QCAP 512
 #endif
