@@ -451,13 +451,13 @@ int ensure_static(arp_ctx* c) {
     r.res_prev = c->has_res ? c->res_prev.p : nullptr;
     r.res_next = c->has_res ? c->res_next.p : nullptr;
     r.home = c->has_home ? c->home.p : nullptr;
-    r.rad = c->rad.p; r.rad_idx = c->rad_idx.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.sb = c->sb.p;
-    HIPCHK(c, c->longest_bond.reserve(1));
-    HIPCHK(c, hipMemsetAsync(c->longest_bond.p, 0, sizeof(float), c->stream));
+    r.rad = c->rad.p; r.rad_idx = c->rad_idx.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.bond_idx = c->bond_idx.p; r.sb = c->sb.p;
+    HIPCHK(c, c->longest_bond.reserve(2));
+    HIPCHK(c, hipMemsetAsync(c->longest_bond.p, 0, 2 * sizeof(float), c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p);
         hipLaunchKernelGGL(k_longest_bond, dim3(nblocks(n, 256, 512)), dim3(256), 0, c->stream, n, c->xyz.p, c->bond_off.p, c->bond_idx.p,
-                           (unsigned int*)c->longest_bond.p);
+                           c->h_off.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
         CHK(check_launch(c, "k_prepare_static"));
         // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure
         GridDesc d;

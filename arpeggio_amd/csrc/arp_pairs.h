@@ -29,6 +29,11 @@
 #define M_RES_POLY (1u << 21)
 #define M_RES_HASSEQ (1u << 22)
 #define M_HOME (1u << 24)
+// bits 25-31: how far, in local atom ids, the atom's bonded neighbours are (max |id - neighbour id|, saturated at 127 = "any").
+// k_sift walks the bond list of bgn only for partners inside that reach: bonded atoms sit next to each other in every real
+// structure, and a pair's ids are at hand, so almost no pair walks (a necessary condition: the walk itself is unchanged).
+#define M_REACH_SHIFT 25
+#define M_REACH_ANY 127u
 
 // device counters (one u64 each); kernels receive pointers to the slots they update
 #define STAT_SLOTS 16
@@ -77,6 +82,7 @@ struct RawAtoms {
     const uint16_t* rad_idx;    // index of the atom's {vdw, cov} in the radius table, RAD_NONE: not in the table
     const int* h_off;
     const int* bond_off;
+    const int* bond_idx;
     const float4* sb;           // single-bond neighbour xyz, w = present
 };
 
@@ -129,9 +135,12 @@ struct StaticAtoms {
 // covalent test — a walk over the bonded neighbours of bgn, dependent loads — only for pairs that are at most this far
 // apart (a pair further apart than every bond of the structure is not bonded).  out = float bits, atomicMax on unsigned
 // (positive floats order like their bit patterns).
+// out[1] = the longest distance between an atom and one of its hydrogens (same rounding up): a hydrogen of D is no nearer to A
+// than |D - A| minus this, which lets k_sift leave the hydrogen loops of far pairs alone.
 __global__ __launch_bounds__(256) void k_longest_bond(int n, const float4* __restrict__ xyz, const int* __restrict__ bond_off,
-                                                      const int* __restrict__ bond_idx, unsigned int* __restrict__ out) {
-    float m = 0.0f;
+                                                      const int* __restrict__ bond_idx, const int* __restrict__ h_off,
+                                                      const double* __restrict__ h_xyz, unsigned int* __restrict__ out) {
+    float m = 0.0f, mh = 0.0f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 a = xyz[i];
         for (int k = bond_off[i], k1 = bond_off[i + 1]; k < k1; ++k) {
@@ -139,14 +148,20 @@ __global__ __launch_bounds__(256) void k_longest_bond(int n, const float4* __res
             const double dx = (double)a.x - b.x, dy = (double)a.y - b.y, dz = (double)a.z - b.z;
             m = fmaxf(m, (float)(sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-6)));
         }
+        for (int k = h_off[i], k1 = h_off[i + 1]; k < k1; ++k) {
+            const double dx = (double)a.x - h_xyz[3 * (size_t)k], dy = (double)a.y - h_xyz[3 * (size_t)k + 1], dz = (double)a.z - h_xyz[3 * (size_t)k + 2];
+            mh = fmaxf(mh, (float)(sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-6)));
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __shared__ float s_m[4];            // one atomic per block: same-address atomics run at ~90 per microsecond
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); mh = fmaxf(mh, __shfl_xor(mh, o)); }
+    __shared__ float s_m[4], s_mh[4];   // one atomic per block: same-address atomics run at ~90 per microsecond
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_mh[threadIdx.x >> 6] = mh; }
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        mh = fmaxf(fmaxf(s_mh[0], s_mh[1]), fmaxf(s_mh[2], s_mh[3]));
         if (m > 0.0f) atomicMax(out, __float_as_uint(m));
+        if (mh > 0.0f) atomicMax(out + 1, __float_as_uint(mh));
     }
 }
 
@@ -217,8 +232,12 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         const float4 sb = r.sb[i];
         if (sb.w != 0.0f) m |= M_HAS_SB;
         v.w = __uint_as_float(m);
-        const int h0 = r.h_off[i], b0 = r.bond_off[i];
-        const int hc = min(r.h_off[i + 1] - h0, CNT_SAT), bc = min(r.bond_off[i + 1] - b0, CNT_SAT);
+        const int h0 = r.h_off[i], b0 = r.bond_off[i], b1 = r.bond_off[i + 1];
+        const int hc = min(r.h_off[i + 1] - h0, CNT_SAT), bc = min(b1 - b0, CNT_SAT);
+        unsigned reach = 0;
+        for (int k = b0; k < b1; ++k) reach = max(reach, (unsigned)abs(r.bond_idx[k] - i));
+        m |= min(reach, M_REACH_ANY) << M_REACH_SHIFT;
+        v.w = __uint_as_float(m);
         st_xyzm[i] = v;
         st_q1[i] = make_int4(i, b0, h0, bc | (hc << 8) | ((int)r.rad_idx[i] << 16));
         st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
@@ -1003,7 +1022,7 @@ struct SiftSide {
     const int* h_off;         // uploaded CSR offsets by local atom id (saturated counts)
     const int* bond_off;
     const float4* sb;         // single-bond heavy neighbour by local atom id: x, y, z, present
-    const float* longest_bond;   // k_longest_bond
+    const float* longest_bond;   // k_longest_bond: [0] longest bond, [1] longest atom - hydrogen distance
 };
 __device__ __forceinline__ double2 rec_rad(int4 q1, const double2* s_tab, const SiftSide& sd) {
     const unsigned ri = (unsigned)q1.w >> 16;
@@ -1085,6 +1104,9 @@ struct SiftArgs {
 // behind a run-time flag the compiler merges the two stores into a plain one.)
 template <int STREAM, typename T>
 __device__ __forceinline__ void put_record(T v, T* p) {
+#ifdef ARP_EXP_SIFT_NO_STORE
+    if ((size_t)p != 0x1234567) return;
+#endif
     if (STREAM) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
@@ -1130,7 +1152,8 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     u64 heads[PAIR_SEGS];
 #pragma unroll
     for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_];
-    const float longest_bond = *sd.longest_bond;
+    const float longest_bond = sd.longest_bond[0];
+    const double h_slack = (double)sd.longest_bond[1] + 1e-4;   // |H - A| >= |D - A| - h_slack for every hydrogen H of D (margin: float32 distance, roundings)
     const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
     const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
     const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
@@ -1192,7 +1215,11 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         unsigned need = 0;
         // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
         bool cov = false;
-        if (d <= longest_bond)
+#ifndef ARP_EXP_SIFT_NO_COVALENT
+        if (d <= longest_bond && ((mb >> M_REACH_SHIFT) == M_REACH_ANY || (unsigned)abs(b - e) <= (mb >> M_REACH_SHIFT)))
+#else
+        if (d < -1.0f)
+#endif
             for (int k = qb.q1.y, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
                 if (bond_idx[k] == e) { cov = true; break; }
         // interactions.py:756-773: float32 distance against Python floats -> float32 compare
@@ -1228,6 +1255,24 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) && (te & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 16u;
             if ((te & ARP_T_WEAK_HBOND_ACCEPTOR) && (me & M_HALOGEN) && (tb & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 32u;
             if ((need & 60u) && d <= (float)3.5) s |= ARP_S_WEAK_POLAR;   // each applicable weak branch sets it (I:861,869,877,885)
+            if (need) {
+                // Branches that cannot succeed need no hydrogen loop: the donor has no hydrogen, the halogen no single-bond
+                // neighbour (U:139-141), or the partner is further from the donor than the test's reach 1.2 + vdw + comp
+                // (U:86, 109, 145) plus the longest atom - hydrogen distance of the structure.  If EVERY applicable branch is
+                // such a one the pair gets no hbond / weak hbond bit — what the loops would find — and is not queued; if one
+                // is left the task runs with the full set (the last applicable weak branch decides, I:857-886).
+                const double dd = (double)d;
+                const bool far_e = dd > 1.2 + rec_rad(qe.q1, s_tab, sd).x + comp + h_slack;   // target = end (acceptor / halogen)
+                const bool far_b = dd > 1.2 + rec_rad(qb.q1, s_tab, sd).x + comp + h_slack;   // target = bgn
+                unsigned dead = 0;
+                if (((qb.q1.w >> 8) & 255) == 0 || far_e) dead |= 1u | 8u | 32u;               // hydrogens of bgn
+                if (((qe.q1.w >> 8) & 255) == 0 || far_b) dead |= 2u | 4u | 16u;               // hydrogens of end
+                if (!(mb & M_HAS_SB)) dead |= 16u;
+                if (!(me & M_HAS_SB)) dead |= 32u;
+#ifndef ARP_EXP_NO_HPRUNE
+                if ((need & ~dead) == 0) need = 0;
+#endif
+            }
             // interactions.py:889-895
             if (d <= f_vdw_comp) {
                 if ((tb & ARP_T_XBOND_DONOR) && (te & ARP_T_XBOND_ACCEPTOR)) {
@@ -1262,6 +1307,9 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         }
         }
         // stage B bookkeeping (whole wave)
+#ifdef ARP_EXP_SIFT_NO_TASKS
+        if (queued) { put_record<STREAM>((uint16_t)(task.w & 0xFFFFu), out_s + task.x); queued = false; }
+#endif
         const unsigned long long mq = __ballot(queued);
         if (mq) {
             if (queued) tq[w][tn + __popcll(mq & ((1ull << lane) - 1ull))] = task;
