@@ -167,6 +167,7 @@ struct arp_ctx {
     DevBuf<int4> s_aux;
     DevBuf<SiftRec> s_rec;
     DevBuf<int> tmp_i32;          // scratch for index uploads
+    DevBuf<int4> st_b4, sp_b4, s_b4;   // first bonded neighbours: static, in the spatial order, cell-sorted beside s_rec
     DevBuf<int4> st_q1;           // selection-independent record columns, composed once per structure (k_prepare_static)
     DevBuf<float> longest_bond;   // k_longest_bond, once per uploaded structure (ensure_static)
     DevBuf<uint16_t> rad_idx;     // per atom: index of its {vdw, cov} pair in rad_tab (RAD_NONE: not in the table)
@@ -443,6 +444,7 @@ int ensure_static(arp_ctx* c) {
     c->contacts_expected = 0;
     const int n = (int)c->n;
     HIPCHK(c, c->st_q1.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->st_b4.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->st_xyzm.reserve((size_t)std::max(n, 1)));
     RawAtoms r;
@@ -455,14 +457,14 @@ int ensure_static(arp_ctx* c) {
     HIPCHK(c, c->longest_bond.reserve(2));
     HIPCHK(c, hipMemsetAsync(c->longest_bond.p, 0, 2 * sizeof(float), c->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p);
+        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p, c->st_b4.p);
         hipLaunchKernelGGL(k_longest_bond, dim3(nblocks(n, 256, 512)), dim3(256), 0, c->stream, n, c->xyz.p, c->bond_off.p, c->bond_idx.p,
                            c->h_off.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
         CHK(check_launch(c, "k_prepare_static"));
         // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure
         GridDesc d;
         make_grid_desc(d, c->lo, c->hi, 6.0);
-        HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_q1.reserve((size_t)n));
+        HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_q1.reserve((size_t)n)); HIPCHK(c, c->sp_b4.reserve((size_t)n));
         HIPCHK(c, c->sp_cr.reserve((size_t)n));
         HIPCHK(c, c->sp_cnt.reserve((size_t)d.ncell + 1));
         HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, ((size_t)d.ncell + 1) * sizeof(int), c->stream));
@@ -472,7 +474,7 @@ int ensure_static(arp_ctx* c) {
         S.p[0] = c->sp_cnt.p; S.n[0] = d.ncell;
         hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, c->stream, S);
         hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, c->sp_cnt.p, c->st_xyzm.p,
-                           c->st_aux.p, c->st_q1.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p);
+                           c->st_aux.p, c->st_q1.p, c->st_b4.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p, c->sp_b4.p);
         CHK(check_launch(c, "k_static_permute"));
     }
     c->static_dirty = false;
@@ -483,6 +485,7 @@ StaticAtoms static_atoms(arp_ctx* c) {
     StaticAtoms r;
     r.xyzm = c->sp_xyzm.p;
     r.q1 = c->sp_q1.p;
+    r.b4 = c->sp_b4.p;
     r.aux = c->sp_aux.p;
     r.sel = c->sel_made ? c->sel.p : nullptr;
     r.plus = c->sel_made ? c->plus.p : nullptr;
@@ -515,6 +518,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
     HIPCHK(c, sx.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, sa.reserve((size_t)std::max(n, 1)));
     if (srec) HIPCHK(c, srec->reserve((size_t)std::max(n, 1)));
+    if (srec) HIPCHK(c, c->s_b4.reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c));
     const StaticAtoms r = static_atoms(c);
     int* const hist = G.cur ? G.cnt2.p : G.cnt.p;
@@ -530,12 +534,13 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
             G.used[G.cur] = ((size_t)ncell + 3) & ~(size_t)3;
         }
         SiftRec* const rec = srec ? srec->p : (SiftRec*)nullptr;
+        int4* const b4 = srec ? c->s_b4.p : (int4*)nullptr;
         const int nb = (n + SCAT_ATOMS - 1) / SCAT_ATOMS;
         if (ncell <= SCAN_LDS_CELLS) {   // start table in LDS: scan + scatter in one launch
             Prof p(c, SLOT_SCATTER, st);
             const int steps = (ncell + 16 * 256 - 1) / (16 * 256);
 #define LAUNCH_SS(S) hipLaunchKernelGGL((k_scan_scatter_atoms<S>), dim3(nb), dim3(1024), (S) * 16384, st, r, n, ncell, G.cell_rank.p, hist, \
-                                        G.start.p, total_out, sx.p, sa.p, rec, gm)
+                                        G.start.p, total_out, sx.p, sa.p, rec, b4, gm)
             switch (steps) {
                 case 1: LAUNCH_SS(1); break;
                 case 2: LAUNCH_SS(2); break;
@@ -558,7 +563,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
                 CHK(check_launch(c, "k_scan"));
             }
             Prof p(c, SLOT_SCATTER, st);
-            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_rank.p, G.start.p, sx.p, sa.p, rec, gm);
+            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_rank.p, G.start.p, sx.p, sa.p, rec, b4, gm);
             CHK(check_launch(c, "k_scatter_atoms"));
         }
         G.cur = 1 - G.cur;
@@ -1147,7 +1152,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     if (c->n > 0) {
         Prof p(c, SLOT_SIFT);
         static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
-        const SiftArgs sa{c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap, c->s_rec.p,
+        const SiftArgs sa{c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap, c->s_rec.p, c->s_b4.p,
                           SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + C_ERR)};
@@ -1337,7 +1342,7 @@ void arp_destroy(arp_ctx* c) {
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
     c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
-    c->sp_xyzm.release(); c->sp_aux.release(); c->sp_q1.release(); c->sp_cnt.release(); c->sp_cr.release();
+    c->sp_xyzm.release(); c->sp_aux.release(); c->sp_q1.release(); c->st_b4.release(); c->sp_b4.release(); c->s_b4.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();

@@ -29,11 +29,6 @@
 #define M_RES_POLY (1u << 21)
 #define M_RES_HASSEQ (1u << 22)
 #define M_HOME (1u << 24)
-// bits 25-31: how far, in local atom ids, the atom's bonded neighbours are (max |id - neighbour id|, saturated at 127 = "any").
-// k_sift walks the bond list of bgn only for partners inside that reach: bonded atoms sit next to each other in every real
-// structure, and a pair's ids are at hand, so almost no pair walks (a necessary condition: the walk itself is unchanged).
-#define M_REACH_SHIFT 25
-#define M_REACH_ANY 127u
 
 // device counters (one u64 each); kernels receive pointers to the slots they update
 #define STAT_SLOTS 16
@@ -126,6 +121,7 @@ struct StaticAtoms {
     const float4* xyzm;         // x, y, z, static meta
     const int4* aux;            // local id, residue, previous residue, next residue
     const int4* q1;             // second quad of the sift record (see SiftRec)
+    const int4* b4;             // first bonded neighbours (local ids), see k_prepare_static
     const uint8_t* sel;         // null: nothing selected
     const uint8_t* plus;        // null: everything in selection_plus
     int all;                    // the selection is the whole structure (then selection_plus is, too): sel / plus not read
@@ -219,7 +215,7 @@ __global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc) {
 }
 
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
-                                                        int4* __restrict__ st_q1) {
+                                                        int4* __restrict__ st_q1, int4* __restrict__ st_b4) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
     for (int i = gtid; i < n; i += gstride) {
         float4 v = r.xyz[i];
@@ -234,10 +230,13 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         v.w = __uint_as_float(m);
         const int h0 = r.h_off[i], b0 = r.bond_off[i], b1 = r.bond_off[i + 1];
         const int hc = min(r.h_off[i + 1] - h0, CNT_SAT), bc = min(b1 - b0, CNT_SAT);
-        unsigned reach = 0;
-        for (int k = b0; k < b1; ++k) reach = max(reach, (unsigned)abs(r.bond_idx[k] - i));
-        m |= min(reach, M_REACH_ANY) << M_REACH_SHIFT;
-        v.w = __uint_as_float(m);
+        // the first bonded neighbours beside the record (-1: none; w = -2: more than four, the fourth and later ones are in the CSR list)
+        int4 b4 = make_int4(-1, -1, -1, -1);
+        if (b1 > b0) b4.x = r.bond_idx[b0];
+        if (b1 > b0 + 1) b4.y = r.bond_idx[b0 + 1];
+        if (b1 > b0 + 2) b4.z = r.bond_idx[b0 + 2];
+        if (b1 > b0 + 3) b4.w = (b1 > b0 + 4) ? -2 : r.bond_idx[b0 + 3];
+        st_b4[i] = b4;
         st_xyzm[i] = v;
         st_q1[i] = make_int4(i, b0, h0, bc | (hc << 8) | ((int)r.rad_idx[i] << 16));
         st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
@@ -268,14 +267,16 @@ __global__ __launch_bounds__(256) void k_static_bin(int n, const float4* __restr
 }
 __global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __restrict__ cr, const int* __restrict__ start,
                                                         const float4* __restrict__ st_xyzm, const int4* __restrict__ st_aux,
-                                                        const int4* __restrict__ st_q1, float4* __restrict__ sp_xyzm,
-                                                        int4* __restrict__ sp_aux, int4* __restrict__ sp_q1) {
+                                                        const int4* __restrict__ st_q1, const int4* __restrict__ st_b4,
+                                                        float4* __restrict__ sp_xyzm, int4* __restrict__ sp_aux, int4* __restrict__ sp_q1,
+                                                        int4* __restrict__ sp_b4) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 c = cr[i];
         const int pos = start[c.x] + c.y;
         sp_xyzm[pos] = st_xyzm[i];
         sp_aux[pos] = st_aux[i];
         sp_q1[pos] = st_q1[i];
+        sp_b4[pos] = st_b4[i];
     }
 }
 
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDes
 
 // one atom's cell-sorted records (search record 32 B; the contact grid adds the 32-byte sift record)
 __device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos, float4* __restrict__ s_xyzm,
-                                            int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec) {
+                                            int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec, int4* __restrict__ s_b4) {
     const int4 aux = r.aux[i];
     const float4 xyzm = compose_xyzm(r, i, aux.x);
     s_xyzm[pos] = xyzm;
@@ -379,18 +380,19 @@ __device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos
         q.xyzm = xyzm;
         q.q1 = r.q1[i];
         s_rec[pos] = q;
+        s_b4[pos] = r.b4[i];
     }
 }
 
 // counting-sort scatter fused with the record build, start table from a separate scan (large grids)
 __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int2* __restrict__ cell_rank,
                                                        const int* __restrict__ start, float4* __restrict__ s_xyzm,
-                                                       int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec, GroupMasks gm) {
+                                                       int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec, int4* __restrict__ s_b4, GroupMasks gm) {
     group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 cr = cell_rank[i];
         if (cr.x < 0) continue;
-        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_rec);
+        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_rec, s_b4);
     }
 }
 
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
                                                              const int* __restrict__ cell_cnt, int* __restrict__ start,
                                                              unsigned long long* __restrict__ total_out,
                                                              float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
-                                                             SiftRec* __restrict__ s_rec, GroupMasks gm) {
+                                                             SiftRec* __restrict__ s_rec, int4* __restrict__ s_b4, GroupMasks gm) {
     extern __shared__ __attribute__((aligned(16))) int s_start[];   // 16 * STEPS * 256 ints
     group_masks(gm, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024);
     __shared__ int s_wtot[16], s_woff[17];
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     const int4 my_aux = r.aux[ii];
     const float4 my_xyzm = compose_xyzm(r, ii, my_aux.x);
     const int4 my_q1 = s_rec ? r.q1[ii] : make_int4(0, 0, 0, 0);
+    const int4 my_b4 = s_rec ? r.b4[ii] : make_int4(0, 0, 0, 0);
     int4 v[STEPS];
 #pragma unroll
     for (int k = 0; k < STEPS; ++k) {
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
             q.xyzm = my_xyzm;
             q.q1 = my_q1;
             s_rec[pos] = q;
+            s_b4[pos] = my_b4;
         }
     }
 }
@@ -1085,6 +1089,7 @@ struct SiftArgs {
     const u64* npairs_ptr;
     u64 cap;
     const SiftRec* s_rec;
+    const int4* s_b4;       // first bonded neighbours of the atom at each sorted position (k_prepare_static)
     SiftSide sd;
     const int* bond_idx;
     const double* h_xyz;
@@ -1191,6 +1196,8 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         if (ps < nseg) {
         const long long p = out_base + ps;
         const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // two 16-byte quads per atom
+        const int4 nbr = A.s_b4[pr.x];                     // bgn's first bonded neighbours: travels WITH the records (addressed by position),
+                                                           // not after them as the walk over the CSR list did
         const float4 vb = qb.xyzm, ve = qe.xyzm;
         const int b = qb.q1.x, e = qe.q1.x;
         const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
@@ -1216,12 +1223,13 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
         bool cov = false;
 #ifndef ARP_EXP_SIFT_NO_COVALENT
-        if (d <= longest_bond && ((mb >> M_REACH_SHIFT) == M_REACH_ANY || (unsigned)abs(b - e) <= (mb >> M_REACH_SHIFT)))
-#else
-        if (d < -1.0f)
+        if (d <= longest_bond) {
+            cov = nbr.x == e || nbr.y == e || nbr.z == e || nbr.w == e;       // (-1 / -2 never equal a local id)
+            if (!cov && nbr.w == -2)                                          // more than four neighbours: the rest of the list
+                for (int k = qb.q1.y + 3, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
+                    if (bond_idx[k] == e) { cov = true; break; }
+        }
 #endif
-            for (int k = qb.q1.y, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
-                if (bond_idx[k] == e) { cov = true; break; }
         // interactions.py:756-773: float32 distance against Python floats -> float32 compare
         if (cov) s |= ARP_S_COVALENT;
         else if (d < f_sum_cov) s |= ARP_S_CLASH;

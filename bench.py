@@ -61,8 +61,8 @@ def algorithmic_bytes(kernel, n_binned, ncell, n_pairs):
         return 32 * n_binned + 4 * (ncell + 1) + 8 * n_pairs
     if kernel == 'mark_search':  # same reads, writes one byte per marked atom
         return 32 * n_binned + 4 * (ncell + 1) + n_binned
-    if kernel == 'sift':        # pair list + each 32-byte atom record once + 15-byte output record
-        return 8 * n_pairs + 32 * n_binned + 15 * n_pairs
+    if kernel == 'sift':        # pair list + each atom's 32-byte record and 16-byte bonded-neighbour quad once + 15-byte output record
+        return 8 * n_pairs + 48 * n_binned + 15 * n_pairs
     raise KeyError(kernel)
 
 
