@@ -449,3 +449,31 @@ def test_enqueue_and_wait_keep_several_contexts_busy_from_one_thread():
     assert fresh.run_wait() == want[2][0]
     for c in ctxs + [fresh]:
         c.close()
+
+
+def test_covalent_flag_for_every_bond_count(ctx):
+    """The covalent test reads the first four bonded neighbours of bgn from a quad beside the record and walks the CSR list only
+    for the fifth and later ones: centres with 0 .. 9 partners, as the lower and as the higher index of the pair, partners
+    listed before and after unbonded atoms at the same distance."""
+    from helpers import tiny_complex
+    from arpeggio_amd.core import config
+    rng = np.random.default_rng(21)
+    xyz, bonds = [], []
+    for k in range(10):                       # centre with k bonded and 3 unbonded atoms 1.5 A away, clusters 30 A apart
+        for centre_first in (True, False):
+            base = len(xyz)
+            c = np.array([30.0 * k, 40.0 * centre_first, 0.0])
+            v = rng.standard_normal((k + 3, 3))
+            v = 1.5 * v / np.linalg.norm(v, axis=1, keepdims=True)
+            pts = [c] + list(c + v) if centre_first else list(c + v) + [c]
+            xyz += pts
+            centre = base if centre_first else base + k + 3
+            others = [base + 1 + t for t in range(k + 3)] if centre_first else [base + t for t in range(k + 3)]
+            order = rng.permutation(k + 3)
+            bonds += [(centre, others[t]) for t in order[:k]]
+    xyz = np.array(xyz, np.float32)
+    pc = tiny_complex(xyz, res_id=np.arange(len(xyz), dtype=np.int32), bonds=bonds)
+    got = _check(ctx, pc)
+    cov = 1 << config.SIFT_NAMES.index('covalent')
+    pairs = {(int(a), int(b)) for a, b, s in zip(got['i'], got['j'], got['sift']) if s & cov}
+    assert pairs == {(min(a, b), max(a, b)) for a, b in bonds}
