@@ -55,14 +55,15 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(kernel, n_binned, ncell, n_pairs):
-    """Compulsory HBM bytes of one launch (DESIGN.md 'Kernels and rooflines')."""
+def algorithmic_bytes(kernel, n_binned, ncell, n_pairs, n_h=0):
+    """Compulsory HBM bytes of one launch (DESIGN.md 'Kernels and rooflines').  n_h = explicit hydrogens of the structure
+    (24-byte float64 coordinates, read by the hydrogen-geometry tests of k_sift; 0 when the caller does not know the count)."""
     if kernel == 'search':      # read each sorted record once (xyzm 16 B + aux 16 B), the cell table, write the pair list
         return 32 * n_binned + 4 * (ncell + 1) + 8 * n_pairs
     if kernel == 'mark_search':  # same reads, writes one byte per marked atom
         return 32 * n_binned + 4 * (ncell + 1) + n_binned
-    if kernel == 'sift':        # pair list + each atom's 32-byte record and 16-byte bonded-neighbour quad once + 15-byte output record
-        return 8 * n_pairs + 48 * n_binned + 15 * n_pairs
+    if kernel == 'sift':        # pair list + each atom's 32-byte record and 16-byte bonded-neighbour quad once + its hydrogens + 15-byte output record
+        return 8 * n_pairs + 48 * n_binned + 24 * n_h + 15 * n_pairs
     raise KeyError(kernel)
 
 
@@ -397,7 +398,8 @@ def main():
     dom_ms = candidates_for_dominant[dom]
     n_binned = st['binned'] if dom != 'mark_search' else pc.n_atoms
     ncell = st['cells']
-    b_alg = algorithmic_bytes(dom, n_binned, ncell, emitted)
+    n_h = int(pc.h_xyz.shape[0]) if getattr(pc, 'h_xyz', None) is not None else 0
+    b_alg = algorithmic_bytes(dom, n_binned, ncell, emitted, n_h)
     achieved = b_alg / (dom_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters of the last committed rocprofv3 run (profiles/pmc_traffic.json,
     # written by tools/export_profile.py; separate --pmc passes, gfx950 FETCH_SIZE correction applied)
@@ -423,7 +425,8 @@ def main():
         pass
     roofline = {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
-                'algorithmic_bytes_per_launch': int(b_alg), 'avg_launch_ms': round(dom_ms, 5),
+                'algorithmic_bytes_per_launch': int(b_alg), 'algorithmic_bytes_without_hydrogen_coordinates': int(b_alg - (24 * n_h if dom == 'sift' else 0)),
+                'avg_launch_ms': round(dom_ms, 5),
                 'note': {'search': 'VALU / LDS issue-bound geometry kernel (12 M wave-instructions per launch, profiles/round2_k_pmc_per_launch.csv); ',
                          'sift': 'gather-latency-bound at 4 waves per SIMD (125 VGPRs): 72 % of the wave cycles are waits (SQ_WAIT_ANY); ',
                          'mark_search': 'VALU / LDS issue-bound geometry kernel; '}.get(dom, '') +
@@ -433,7 +436,7 @@ def main():
     roofline_all = {}
     for k, ms in candidates_for_dominant.items():
         nb = st['binned'] if k != 'mark_search' else pc.n_atoms
-        b = algorithmic_bytes(k, nb, ncell, emitted)
+        b = algorithmic_bytes(k, nb, ncell, emitted, n_h)
         roofline_all[f'k_{k}'] = {'avg_launch_ms': round(ms, 5), 'algorithmic_bytes_per_launch': int(b),
                                   'achieved_GBps': round(b / (ms * 1e-3) / 1e9, 2), 'frac': round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
 
