@@ -398,6 +398,10 @@ class Context:
         self._h = h
         self.device = device
         self.n = self.n_rings = self.n_amides = 0
+        # the five bag sizes of a pass land here (one context per host thread: no sharing); a ctypes array made once costs the
+        # call nothing, a NumPy array + pointer per call cost ~2 us of a ~90 us pass
+        self._counts = (C.c_int64 * 5)()
+        self._counts_p = C.cast(self._counts, C.c_void_p)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -562,17 +566,19 @@ class Context:
 
     def run_wait(self):
         """Second half of ``run_launch``: waits for the enqueued pass, returns the five bag sizes."""
-        counts = np.zeros(5, np.int64)
-        self._check(self._L.arp_run_wait(self._h, _p(counts)), 'arp_run_wait')
-        return dict(zip(('atom_atom', 'plane_plane', 'atom_plane', 'group_group', 'group_plane'), [int(x) for x in counts]))
+        rc = self._L.arp_run_wait(self._h, self._counts_p)
+        if rc != ARP_OK:
+            self._check(rc, 'arp_run_wait')
+        c = self._counts
+        return {'atom_atom': c[0], 'plane_plane': c[1], 'atom_plane': c[2], 'group_group': c[3], 'group_plane': c[4]}
 
     def run_launch(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, expand_radius=6.0):
         """run_arpeggio on the resident structure; results stay in HBM.  Returns the five bag sizes."""
-        counts = np.zeros(5, np.int64)
-        self._check(self._L.arp_run_launch(self._h, float(cutoff), float(vdw_comp), int(bool(include_sequence_adjacent)),
-                                           float(expand_radius), _p(counts)), 'arp_run_launch')
-        return dict(atom_atom=int(counts[0]), plane_plane=int(counts[1]), atom_plane=int(counts[2]),
-                    group_group=int(counts[3]), group_plane=int(counts[4]))
+        rc = self._L.arp_run_launch(self._h, cutoff, vdw_comp, 1 if include_sequence_adjacent else 0, expand_radius, self._counts_p)
+        if rc != ARP_OK:
+            self._check(rc, 'arp_run_launch')
+        c = self._counts
+        return {'atom_atom': c[0], 'plane_plane': c[1], 'atom_plane': c[2], 'group_group': c[3], 'group_plane': c[4]}
 
     def make_selection_masks(self):
         """Masks computed by the last selection expansion (downloads only; no recomputation)."""
