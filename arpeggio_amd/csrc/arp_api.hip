@@ -71,6 +71,8 @@ struct Grid {
     // hist[cur] and clears hist[1 - cur], the one the previous build used)
     DevBuf<int2> cell_rank;
     DevBuf<int> cnt2;
+    DevBuf<unsigned long long> chain;   // k_scan_tiles_chained: {launch number, tile total} per tile
+    unsigned int chain_epoch = 0;
     int cur = 0;
     size_t used[2] = {0, 0};   // counters of hist[k] that may be non-zero
     int n_points = 0;   // points offered
@@ -78,7 +80,7 @@ struct Grid {
     bool valid = false;
     double radius = 0;
     void release() { cell_of.release(); cnt.release(); start.release(); perm.release(); sums.release(); cell_rank.release();
-                     cnt2.release(); valid = false; }
+                     cnt2.release(); chain.release(); valid = false; }
 };
 
 struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
@@ -558,8 +560,17 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
             {
                 Prof p(c, SLOT_SCAN, st);
                 const int ntiles = (ncell + TILE_CELLS - 1) / TILE_CELLS;
-                hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.sums.p);
-                hipLaunchKernelGGL(k_scan_fix, dim3((ncell + 4095) / 4096), dim3(1024), 0, st, G.start.p, ncell, G.sums.p, ntiles, total_out);
+                static const int chained = env_int("ARP_CHAINED_SCAN", 1);
+                if (chained && ntiles <= CHAIN_TILES) {   // one launch: the tiles hand their totals on themselves
+                    bool fresh = false;
+                    HIPCHK(c, G.chain.reserve(CHAIN_TILES, &fresh));
+                    if (fresh) { HIPCHK(c, hipMemsetAsync(G.chain.p, 0, G.chain.cap * sizeof(unsigned long long), st)); G.chain_epoch = 0; }
+                    if (++G.chain_epoch == 0) ++G.chain_epoch;
+                    hipLaunchKernelGGL(k_scan_tiles_chained, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.chain.p, G.chain_epoch, total_out);
+                } else {
+                    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.sums.p);
+                    hipLaunchKernelGGL(k_scan_fix, dim3((ncell + 4095) / 4096), dim3(1024), 0, st, G.start.p, ncell, G.sums.p, ntiles, total_out);
+                }
                 CHK(check_launch(c, "k_scan"));
             }
             Prof p(c, SLOT_SCATTER, st);

@@ -132,6 +132,93 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ in,
     const int t0 = blockIdx.x * TILE_CELLS;
     scan_small_body<TILE_ITEMS>(in + t0, min(n - t0, TILE_CELLS), out + t0, tile_sums + blockIdx.x, nullptr);
 }
+// The same in ONE launch for up to CHAIN_TILES tiles (every block of the launch is resident at once: two 1024-thread blocks
+// per CU): a tile publishes its total as soon as it has it — one 64-bit word {launch number, total}, so nothing needs
+// clearing between launches — and waits for the totals of the tiles before it (they are a handful of words), adds their
+// sum to its prefixes before it writes them.  The wait is bounded: a tile that is not served traps (the launch fails
+// loudly) instead of hanging the queue.
+#define CHAIN_TILES 128
+__global__ __launch_bounds__(1024) void k_scan_tiles_chained(const int* __restrict__ in, int n, int* __restrict__ out,
+                                                             unsigned long long* __restrict__ chain, unsigned int epoch,
+                                                             unsigned long long* __restrict__ total_out) {
+    __shared__ int sh[32];
+    __shared__ int s_off;
+    constexpr int ITEMS = TILE_ITEMS;
+    const int tile = blockIdx.x, t0 = tile * TILE_CELLS, nt = min(n - t0, TILE_CELLS);
+    const int base = threadIdx.x * ITEMS;
+    int v[ITEMS];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 4) {
+        const int4 q = *reinterpret_cast<const int4*>(in + t0 + base + k);
+        v[k] = (base + k < nt) ? q.x : 0;
+        v[k + 1] = (base + k + 1 < nt) ? q.y : 0;
+        v[k + 2] = (base + k + 2 < nt) ? q.z : 0;
+        v[k + 3] = (base + k + 3 < nt) ? q.w : 0;
+        sum += v[k] + v[k + 1] + v[k + 2] + v[k + 3];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        int w_incl = (lane < 16) ? sh[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int t = __shfl_up(w_incl, off);
+            if (lane >= off) w_incl += t;
+        }
+        if (lane < 16) sh[16 + lane] = w_incl;   // inclusive totals of waves 0..lane
+        const int total = __shfl(w_incl, 15);
+        if (lane == 0)
+            __hip_atomic_store(chain + tile, ((unsigned long long)epoch << 32) | (unsigned int)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // the totals of the tiles before this one (lane l takes tiles l, l + 64)
+        int before = 0;
+        for (int k = lane; k < tile; k += 64) {
+            unsigned long long w = 0;
+            int spins = 0;
+            for (;;) {
+                w = __hip_atomic_load(chain + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(w >> 32) == epoch) break;
+                if (++spins > (1 << 22)) __builtin_trap();
+                __builtin_amdgcn_s_sleep(2);
+            }
+            before += (int)(unsigned int)w;
+        }
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+        if (lane == 0) {
+            s_off = before;
+            if (tile == (int)gridDim.x - 1) {
+                out[n] = before + total;
+                if (total_out) *total_out = (unsigned long long)(before + total);
+            }
+        }
+    }
+    __syncthreads();
+    const int wave_base = (wv == 0) ? 0 : sh[16 + wv - 1];
+    int run = s_off + wave_base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k += 4) {
+        int4 q;
+        q.x = run; run += v[k];
+        q.y = run; run += v[k + 1];
+        q.z = run; run += v[k + 2];
+        q.w = run; run += v[k + 3];
+        // (padded buffers: the int4 may run past the tile's last cell — into the next tile's first prefixes, which that tile
+        // writes itself, or past n, where out[n] must stay: write only the cells that are this tile's)
+        if (base + k + 3 < nt) *reinterpret_cast<int4*>(out + t0 + base + k) = q;
+        else {
+            if (base + k < nt) out[t0 + base + k] = q.x;
+            if (base + k + 1 < nt) out[t0 + base + k + 1] = q.y;
+            if (base + k + 2 < nt) out[t0 + base + k + 2] = q.z;
+        }
+    }
+}
 __global__ __launch_bounds__(1024) void k_scan_fix(int* __restrict__ out, int n, const int* __restrict__ tile_sums, int ntiles,
                                                    unsigned long long* __restrict__ total_out) {
     __shared__ int sh[16];
