@@ -20,7 +20,6 @@
 #include "arp_numerics.h"
 #include "arp_pairs.h"
 #include "arp_planes.h"
-#include "arp_contacts.h"
 #include "arp_prepare.h"
 #include "arp_json.h"
 #include "arp_shard.h"
@@ -129,7 +128,6 @@ struct arp_ctx {
     std::string err;
     int num_cu = 256;
     int search_resident = 768;          // blocks of k_search<MODE_CONTACTS> the chip holds at once (occupancy x CUs)
-    int contact_resident = 512;         // ... of k_contacts
 
     // ---- sizes
     int64_t n = 0, nres = 0, nring = 0, namide = 0;
@@ -194,14 +192,6 @@ struct arp_ctx {
     DevBuf<uint8_t> tmp_u8;
     // ---- pair list and outputs of the atom-contact pass
     DevBuf<int2> pairs;
-    // k_contacts (the fused search + per-pair kernel): chunked record list, hydrogen-geometry tasks, their fill tables
-    DevBuf<int4> recs;
-    DevBuf<uint4> tasks;
-    DevBuf<unsigned int> rec_fill, task_fill, pack_offsets;
-    int64_t tasks_expected = 0;      // tasks the previous pass over this structure left (0: none yet)
-    bool fused_pass = false;         // the resident contact list is the chunked one (recs) and has not been packed yet
-    bool packed_valid = false;       // out_i .. out_ct hold the dense columns of the resident list
-    u64 rec_heads[PAIR_SEGS] = {0};
     DevBuf<int> out_i, out_j;
     DevBuf<float> out_d;
     DevBuf<uint16_t> out_s;
@@ -715,15 +705,6 @@ int search_blocks_balanced(const arp_ctx* c, const GridDesc& d, int cpw) {
     return std::min(std::max(1, (nb + R / 2) / R) * R, 8192) & ~7;
 }
 
-// k_contacts holds fewer blocks per CU than k_search (its LDS ring): whole rounds of ITS resident blocks
-int contact_blocks_balanced(const arp_ctx* c, const GridDesc& d, int cpw) {
-    static const int forced = env_int("ARP_SEARCH_BLOCKS", 0);
-    if (forced > 0) return (forced + 7) & ~7;
-    const int nb = search_blocks(d, cpw), R = c->contact_resident;
-    if (R < 8 || 2 * nb < R) return nb;
-    return std::min(std::max(1, (nb + R / 2) / R) * R, 8192) & ~7;
-}
-
 int zero_counter(arp_ctx* c, int first, int count) {
     if (c->ctr_clean) return ARP_OK;  // arp_run_launch cleared the whole block with one memset
     c->ctr_zero_ok = false;
@@ -1098,35 +1079,19 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                         all_res ? 1 : 0, c->ring_sel.p, c->ring_plus.p, c->am_sel.p, c->am_plus.p};
         if (c->n == 0) masks_after_bin = true;   // no scatter launch to carry them
     }
-    static const int fused = env_int("ARP_FUSED", 1);   // 1: k_contacts + k_tasks_planes; 0: k_search -> pair list -> k_sift_planes
-    CHK(build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, fused ? nullptr : &c->s_rec, cutoff, M_PLUS, M_HYDROGEN, nullptr, c->d_ctr + C_BINNED,
+    CHK(build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, cutoff, M_PLUS, M_HYDROGEN, nullptr, c->d_ctr + C_BINNED,
                         c->init_plus_in_bin ? c->plus.p : nullptr, nullptr, rm, masks_after_bin ? GroupMasks{} : gm));
     if (masks_after_bin && c->nring + c->namide > 0) {
         hipLaunchKernelGGL(k_group_masks, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, c->stream, gm);
         CHK(check_launch(c, "k_group_masks"));
     }
     c->contact_cells = c->atom_grid.d.ncell;
-    c->fused_pass = fused != 0;
-    c->packed_valid = false;
-    size_t segcap = 0, tsegcap = 0;
-    if (fused) {
-        // chunked record list: PAIR_SEGS segments of whole chunks; ~13 contacts per heavy atom + the chunks blocks leave half full
-        if (!c->recs.p) HIPCHK(c, c->recs.reserve((size_t)c->n * 20 + (size_t)PAIR_SEGS * 2048 * REC_CHUNK / 4));
-        segcap = c->recs.cap / PAIR_SEGS / REC_CHUNK * REC_CHUNK;
-        if (segcap * PAIR_SEGS >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "contact list beyond 2^32 entries (tasks hold 32-bit record indices)");
-        if (!c->tasks.p) HIPCHK(c, c->tasks.reserve((size_t)c->n * 4 + (size_t)PAIR_SEGS * 2048 * TASK_CHUNK / 4));
-        tsegcap = c->tasks.cap / PAIR_SEGS / TASK_CHUNK * TASK_CHUNK;
-        HIPCHK(c, c->rec_fill.reserve((segcap / REC_CHUNK + 1) * PAIR_SEGS));
-        HIPCHK(c, c->task_fill.reserve((tsegcap / TASK_CHUNK + 1) * PAIR_SEGS));
-        CHK(zero_counter(c, C_SEG_TASKS, PAIR_SEGS + STAT_SLOTS));
-    } else {
     if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 8192));
-    segcap = c->pairs.cap / PAIR_SEGS;   // the pair list is PAIR_SEGS segments of segcap entries
+    const size_t segcap = c->pairs.cap / PAIR_SEGS;   // the pair list is PAIR_SEGS segments of segcap entries
     const size_t cap = segcap * PAIR_SEGS;
     if (cap >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "contact list beyond 2^32 entries (k_sift's task queue holds 32-bit output indices)");
     HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
-    }
     CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
     CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
     CHK(zero_counter(c, C_ERR, 1));
@@ -1172,20 +1137,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         if (c->pub.expected) c->pub.expected = (c->n > 0) ? 2 : 1;
         if (st2 != c->stream) HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));   // masks (and lists) are in place here
     }
-    const SiftSide side{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p};
-    if (c->n > 0 && fused) {
-        Prof p(c, SLOT_SEARCH);
-        static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 3));
-        const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
-        const ContactArgs ca{c->recs.p, c->rec_fill.p, (u64)segcap, (unsigned int)(segcap / REC_CHUNK + 1), c->d_ctr + C_SEG_PAIRS,
-                             c->tasks.p, c->task_fill.p, (u64)tsegcap, (unsigned int)(tsegcap / TASK_CHUNK + 1), c->d_ctr + C_SEG_TASKS,
-                             c->d_ctr + C_STAT_EMIT, c->d_ctr + C_STAT_CAND, c->d_ctr + C_STAT_ACC, side, c->rad_idx.p, c->st_b4.p,
-                             c->bond_idx.p, c->has_gid ? c->gid.p : nullptr, vdw_comp, (int*)(c->d_ctr + C_ERR)};
-        hipLaunchKernelGGL(k_contacts, dim3(contact_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff, include_seq_adj,
-                           c->has_home ? 1 : 0, ca);
-        CHK(check_launch(c, "k_contacts"));
-    } else if (c->n > 0) {
+    if (c->n > 0) {
         Prof p(c, SLOT_SEARCH);
         // the contact search ends with a block-level flush of its pair queues, which amortises better over
         // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
@@ -1208,25 +1160,11 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         hipLaunchKernelGGL(k_planes, dim3(np), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + C_PLIST, c->pub);
         CHK(check_launch(c, "k_planes"));
     }
-    if (c->n > 0 && fused) {
-        Prof p(c, SLOT_SIFT);
-        const TaskArgs ta{c->tasks.p, c->task_fill.p, (u64)tsegcap, (unsigned int)(tsegcap / TASK_CHUNK + 1), c->d_ctr + C_SEG_TASKS, c->recs.p,
-                          c->st_xyzm.p, c->st_q1.p, side, c->h_xyz_d.p, vdw_comp};
-        // one task wave per 64 tasks the previous pass over this structure left (~1.5 per heavy atom for the first)
-        const int64_t expect = (c->tasks_expected > 0) ? c->tasks_expected : (int64_t)c->n * 3 / 2;
-        static const int task_blocks_per_cu = std::max(1, env_int("ARP_TASK_BPC", 4));
-        const int by_work = (int)std::min<int64_t>((expect + 255) / 256 + PAIR_SEGS, 1 << 20);
-        const int slots = merged ? std::max(c->num_cu * task_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * task_blocks_per_cu;
-        const int ntask = std::max(std::min(slots, by_work), PAIR_SEGS) & ~(PAIR_SEGS - 1);
-        const int npl = merged ? np : 0;
-        hipLaunchKernelGGL(k_tasks_planes, dim3(npl + ntask), dim3(256), 0, c->stream, ta, ntask, ap, pp, gg, gp, plane_lists(c),
-                           c->d_ctr + C_PLIST, npl, c->pub);
-        CHK(check_launch(c, "k_tasks_planes"));
-    } else if (c->n > 0) {
+    if (c->n > 0) {
         Prof p(c, SLOT_SIFT);
         static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
         const SiftArgs sa{c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap, c->s_rec.p, c->s_b4.p,
-                          side, c->bond_idx.p, c->h_xyz_d.p,
+                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + C_ERR)};
         // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
@@ -1265,30 +1203,12 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
 
 // After read_counters(): publish contact results; returns true when the pair buffer overflowed.
 bool finish_contacts(arp_ctx* c) {
+    const u64 segcap = c->pairs.cap / PAIR_SEGS;
     u64 np = 0, worst = 0;
-    bool overflow = false;
-    if (c->fused_pass) {
-        const u64 segcap = c->recs.cap / PAIR_SEGS / REC_CHUNK * REC_CHUNK, tsegcap = c->tasks.cap / PAIR_SEGS / TASK_CHUNK * TASK_CHUNK;
-        u64 tworst = 0, ttotal = 0;
-        for (int k = 0; k < PAIR_SEGS; ++k) {
-            c->rec_heads[k] = c->h_ctr[C_SEG_PAIRS + k];
-            worst = std::max(worst, c->h_ctr[C_SEG_PAIRS + k]);
-            tworst = std::max(tworst, c->h_ctr[C_SEG_TASKS + k]);
-            ttotal += c->h_ctr[C_SEG_TASKS + k];
-        }
-        for (int k = 0; k < STAT_SLOTS; ++k) np += c->h_ctr[C_STAT_EMIT + k];
-        c->h_ctr[C_SCRATCH0] = worst;
-        c->h_ctr[C_SCRATCH1] = tworst;
-        overflow = worst > segcap || tworst > tsegcap;
-        c->tasks_expected = (int64_t)ttotal;
-    } else {
-        const u64 segcap = c->pairs.cap / PAIR_SEGS;
-        for (int k = 0; k < PAIR_SEGS; ++k) { np += c->h_ctr[C_SEG_PAIRS + k]; worst = std::max(worst, c->h_ctr[C_SEG_PAIRS + k]); }
-        c->h_ctr[C_SCRATCH0] = worst;
-        overflow = worst > segcap;
-    }
+    for (int k = 0; k < PAIR_SEGS; ++k) { np += c->h_ctr[C_SEG_PAIRS + k]; worst = std::max(worst, c->h_ctr[C_SEG_PAIRS + k]); }
     c->h_ctr[C_PAIRS] = np;
-    if (overflow) return true;
+    c->h_ctr[C_SCRATCH0] = worst;
+    if (worst > segcap) return true;
     c->n_contacts = (int64_t)np;
     c->contacts_expected = (int64_t)np;
     c->contacts_valid = true;
@@ -1327,13 +1247,6 @@ bool finish_bag(arp_ctx* c, Bag& b, int slot) {
     return false;
 }
 int grow_pairs(arp_ctx* c) {
-    if (c->fused_pass) {
-        const size_t need = ((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 2 * REC_CHUNK) * PAIR_SEGS;
-        const size_t tneed = ((size_t)c->h_ctr[C_SCRATCH1] + (size_t)c->h_ctr[C_SCRATCH1] / 8 + 2 * TASK_CHUNK) * PAIR_SEGS;
-        if (need > c->recs.cap) { c->recs.release(); HIPCHK(c, c->recs.reserve(need)); }
-        if (tneed > c->tasks.cap) { c->tasks.release(); HIPCHK(c, c->tasks.reserve(tneed)); }
-        return ARP_OK;
-    }
     const size_t need = ((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 64) * PAIR_SEGS;
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     HIPCHK(c, c->pairs.reserve(need));
@@ -1347,33 +1260,6 @@ int grow_bag(arp_ctx* c, Bag& b, int slot, bool d, bool f) {
 int device_error(arp_ctx* c) {
     if ((int)(uint32_t)c->h_ctr[C_ERR] == ARP_E_XBOND_NBR)
         FAIL(c, ARP_E_XBOND_NBR, "xbond donor without a single-bond heavy neighbour (reference: AttributeError at utils.py:173)");
-    return ARP_OK;
-}
-
-// Dense i / j / distance / sift / type columns of the resident contact list (what the C ABI hands out and the per-atom
-// accumulators read): k_contacts leaves chunks of records with a fill count each; two short launches pack them.
-int ensure_packed(arp_ctx* c) {
-    if (!c->fused_pass || c->packed_valid) return ARP_OK;
-    const size_t k = (size_t)std::max<int64_t>(c->n_contacts, 1);
-    HIPCHK(c, c->out_i.reserve(k)); HIPCHK(c, c->out_j.reserve(k)); HIPCHK(c, c->out_d.reserve(k));
-    HIPCHK(c, c->out_s.reserve(k)); HIPCHK(c, c->out_ct.reserve(k));
-    const u64 segcap = c->recs.cap / PAIR_SEGS / REC_CHUNK * REC_CHUNK;
-    PackArgs P;
-    P.recs = c->recs.p; P.rec_fill = c->rec_fill.p; P.cap = segcap; P.nfill = (unsigned int)(segcap / REC_CHUNK + 1);
-    size_t total = 0;
-    for (int s_ = 0; s_ < PAIR_SEGS; ++s_) {
-        P.nchunk[s_] = (unsigned int)(std::min<u64>(c->rec_heads[s_], segcap) / REC_CHUNK);
-        total += P.nchunk[s_];
-    }
-    HIPCHK(c, c->pack_offsets.reserve(total + 1));
-    P.offsets = c->pack_offsets.p;
-    P.out_i = c->out_i.p; P.out_j = c->out_j.p; P.out_d = c->out_d.p; P.out_s = c->out_s.p; P.out_ct = c->out_ct.p;
-    if (total > 0) {
-        hipLaunchKernelGGL(k_chunk_offsets, dim3(1), dim3(1024), 0, c->stream, P);
-        hipLaunchKernelGGL(k_pack_contacts, dim3(nblocks((int64_t)total * 64, 256, 4096)), dim3(256), 0, c->stream, P);
-        CHK(check_launch(c, "k_pack_contacts"));
-    }
-    c->packed_valid = true;
     return ARP_OK;
 }
 
@@ -1431,8 +1317,6 @@ int arp_create(int device, arp_ctx** out) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_search<MODE_CONTACTS>, 64 * SEARCH_WAVES, 0) == hipSuccess && per_cu > 0)
             c->search_resident = per_cu * c->num_cu;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_contacts, 64 * SEARCH_WAVES, 0) == hipSuccess && per_cu > 0)
-            c->contact_resident = per_cu * c->num_cu;
     }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     c->stream = c->own_stream;
@@ -2501,7 +2385,6 @@ int arp_atom_contacts_fetch(arp_ctx* c, int64_t cap, int32_t* out_i, int32_t* ou
     *count = c->n_contacts;
     if (c->n_contacts > cap) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_fetch: output buffer too small");
     const size_t k = (size_t)c->n_contacts;
-    CHK(ensure_packed(c));
     // five copies in flight, one synchronisation (into buffers from arp_host_alloc they run at PCIe speed)
     if (k) {
         if (out_i) HIPCHK(c, hipMemcpyAsync(out_i, c->out_i.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -2527,7 +2410,6 @@ int arp_atom_accumulators(arp_ctx* c, uint16_t* out_sift4, int32_t* out_counts8)
     if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_atom_accumulators: no atom-contact results (call a launch first)");
     if (c->has_gid) FAIL(c, ARP_E_ARG, "arp_atom_accumulators: not available on a shard (contacts carry global ids)");
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure_packed(c));
     const size_t n = (size_t)std::max<int64_t>(c->n, 1);
     DevBuf<unsigned int> acc_s;
     DevBuf<int> acc_c;
@@ -2560,7 +2442,6 @@ int arp_atom_integer_sifts(arp_ctx* c, uint8_t* out_isift) {
     if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_atom_integer_sifts: no atom-contact results (call a launch first)");
     if (c->has_gid) FAIL(c, ARP_E_ARG, "arp_atom_integer_sifts: not available on a shard (contacts carry global ids)");
     HIPCHK(c, hipSetDevice(c->device));
-    CHK(ensure_packed(c));
     const size_t n4 = 4 * (size_t)std::max<int64_t>(c->n, 1);
     DevBuf<u64> last_rank;
     DevBuf<unsigned int> before, last_sift;
@@ -2926,7 +2807,6 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         // the expansion statistics of stage 0 live in the counter block: keep them, clear the rest
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_STAT_MCAND, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ctr + C_SEG_PAIRS, 0, sizeof(u64) * PAIR_SEGS, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_ctr + C_SEG_TASKS, 0, sizeof(u64) * (PAIR_SEGS + STAT_SLOTS), c->stream));
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
         if (c->nring + c->namide > 0)

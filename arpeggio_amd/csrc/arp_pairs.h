@@ -29,9 +29,6 @@
 #define M_RES_POLY (1u << 21)
 #define M_RES_HASSEQ (1u << 22)
 #define M_HOME (1u << 24)
-#define RAD_META_SHIFT 25          // bits 25..29: index of the atom's {vdw, cov} pair in the radius table, RAD_META_NONE: look it up
-#define RAD_META_NONE 31u
-#define M_HAS_H (1u << 30)         // the atom has explicit hydrogens (h_off[i + 1] > h_off[i])
 
 // device counters (one u64 each); kernels receive pointers to the slots they update
 #define STAT_SLOTS 16
@@ -57,11 +54,9 @@ enum {
     // (two sets of 8 group tickets + 1 kernel ticket: the sift kernel and the ring / amide kernel end a pass together)
     C_TICKET_GROUP = C_TAIL + 16, C_TICKET_KERNEL = C_TAIL + 24, C_TICKET_SET = 16, C_KERNELS_DONE = C_TAIL + 15,
     C_PLIST = C_TAIL + 8,   // 4 slots: entries of the static ring / amide candidate lists (copied from their own counters each pass)
-    // k_contacts: task queue heads (one per XCD segment) and the records written (hashed slots)
-    C_SEG_TASKS = C_TAIL + 48, C_STAT_EMIT = C_TAIL + 56,
-    // 152 words in all: the last block of a pass hands the whole block to the host with ONE round of returning atomics per
-    // thread (pass_end: 256 threads); with 64 statistics slots it took two
-    C_COUNT = C_TAIL + 56 + STAT_SLOTS
+    // 128 words in all: the last block of a pass hands the whole block to the host with ONE round of returning atomics per
+    // thread (pass_end); with 64 statistics slots it took two
+    C_COUNT = C_TAIL + 48
 };
 #define PAIR_SEGS 8
 typedef unsigned long long u64;
@@ -232,11 +227,9 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
         const float4 sb = r.sb[i];
         if (sb.w != 0.0f) m |= M_HAS_SB;
+        v.w = __uint_as_float(m);
         const int h0 = r.h_off[i], b0 = r.bond_off[i], b1 = r.bond_off[i + 1];
         const int hc = min(r.h_off[i + 1] - h0, CNT_SAT), bc = min(b1 - b0, CNT_SAT);
-        if (hc > 0) m |= M_HAS_H;
-        m |= min((uint32_t)r.rad_idx[i], RAD_META_NONE) << RAD_META_SHIFT;   // (RAD_NONE and indices >= 31: looked up by k_contacts)
-        v.w = __uint_as_float(m);
         // the first bonded neighbours beside the record (-1: none; w = -2: more than four, the fourth and later ones are in the CSR list)
         int4 b4 = make_int4(-1, -1, -1, -1);
         if (b1 > b0) b4.x = r.bond_idx[b0];
