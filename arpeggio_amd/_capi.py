@@ -13,7 +13,8 @@ import numpy as np
 from .core.exceptions import NativeLibraryError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libarpeggio_hip.so')
+# ARP_LIB_PATH: another build of the same library (A/B comparisons of kernel variants on one GPU box)
+LIB_PATH = os.environ.get('ARP_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libarpeggio_hip.so')
 
 ARP_OK, ARP_E_ARG, ARP_E_HIP, ARP_E_CAPACITY, ARP_E_XBOND_NBR, ARP_E_NOMEM = 0, -1, -2, -3, -4, -5
 

@@ -597,97 +597,6 @@ int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr, hipS
     return ARP_OK;
 }
 
-#ifdef ARP_SEARCH_TRACE
-static unsigned long long* trace_buf() {   // stamps of 12 blocks x 2 waves x 10 words (arp_pairs.h, ARP_SEARCH_TRACE)
-    static unsigned long long* p = nullptr;
-    if (!p && hipMalloc(&p, 400 * 8) == hipSuccess) (void)hipMemset(p, 0, 400 * 8);
-    return p;
-}
-static void trace_dump(hipStream_t st) {
-    static int passes = 0;
-    if (!getenv("ARP_TRACE_DUMP") || ++passes != 30) return;
-    (void)hipStreamSynchronize(st);
-    unsigned long long h[400];
-    if (hipMemcpy(h, trace_buf(), sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
-    {
-        static unsigned long long e[8192 * 2];
-        if (hipMemcpyFromSymbol(e, HIP_SYMBOL(g_search_ends), sizeof(e)) == hipSuccess) {
-            unsigned long long t0 = ~0ull;
-            int nblk = 0;
-            for (int k = 0; k < 8192; ++k) if (e[2 * k]) { t0 = std::min(t0, e[2 * k]); nblk = k + 1; }
-            std::vector<double> ends, starts;
-            for (int k = 0; k < nblk; ++k) { ends.push_back((double)(e[2 * k + 1] - t0) * 0.01); starts.push_back((double)(e[2 * k] - t0) * 0.01); }
-            std::sort(ends.begin(), ends.end());
-            std::sort(starts.begin(), starts.end());
-            if (nblk > 0)
-                fprintf(stderr, "SEARCH BLOCK ENDS (%d blocks; starts: median %.2f, max %.2f us): 10%% %.2f, median %.2f, 90%% %.2f, 99%% %.2f, max %.2f us\n", nblk,
-                        starts[nblk / 2], starts[nblk - 1], ends[nblk / 10], ends[nblk / 2], ends[nblk * 9 / 10], ends[nblk * 99 / 100], ends[nblk - 1]);
-            for (int g8 = 0; g8 < 8 && nblk >= 8; ++g8) {
-                double sum = 0, mx = 0, mn = 1e9; int cnt = 0;
-                for (int k = g8; k < nblk; k += 8) { const double v = (double)(e[2 * k + 1] - t0) * 0.01; sum += v; mx = std::max(mx, v); mn = std::min(mn, v); ++cnt; }
-                fprintf(stderr, "  blocks %% 8 == %d: mean end %.2f, min %.2f, max %.2f us;", g8, sum / cnt, mn, mx);
-                // by position inside the XCD's run of cells: first, middle and last third
-                const int per = nblk / 8;
-                for (int third = 0; third < 3; ++third) {
-                    double s3 = 0; int c3 = 0;
-                    for (int k = g8; k < nblk; k += 8) { const int pos = k >> 3; if (pos * 3 / per == third) { s3 += (double)(e[2 * k + 1] - t0) * 0.01; ++c3; } }
-                    fprintf(stderr, " third %d: %.2f", third, s3 / std::max(c3, 1));
-                }
-                fprintf(stderr, "\n");
-            }
-        }
-    }
-    for (int k = 0; k < 24; ++k) {
-        const unsigned long long* o = h + k * 10;
-        if (!o[0]) continue;
-        fprintf(stderr, "TRACE block %4llu qn %3llu :", o[8], o[9]);
-        for (int j = 1; j < 8; ++j) fprintf(stderr, " %6.2f", o[j] ? (double)(o[j] - o[0]) * 0.01 : -1.0);
-        fprintf(stderr, "  start %.2f us\n", (double)(long long)(o[0] - h[0]) * 0.01);
-    }
-}
-#define SEARCH_TRACE_ARG ((uint8_t*)trace_buf())
-#else
-#define SEARCH_TRACE_ARG ((uint8_t*)nullptr)
-#endif
-#ifdef ARP_SIFT_TRACE
-static void sift_trace_dump(hipStream_t st, int np) {
-    static int passes = 0;
-    if (!getenv("ARP_TRACE_DUMP") || ++passes != 30) return;
-    (void)hipStreamSynchronize(st);
-    unsigned long long h[32 * 8];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sift_trace), sizeof(h)) != hipSuccess) return;
-    {
-        static unsigned long long e[2048 * 2];
-        if (hipMemcpyFromSymbol(e, HIP_SYMBOL(g_sift_ends), sizeof(e)) == hipSuccess) {
-            unsigned long long t0 = ~0ull;
-            int nblk = 0;
-            for (int k = 0; k < 2048; ++k) if (e[2 * k]) { t0 = std::min(t0, e[2 * k]); nblk = k + 1; }
-            std::vector<std::pair<double, int>> ends;
-            double latest_start = 0;
-            for (int k = 0; k < nblk; ++k) { ends.push_back({(double)(e[2 * k + 1] - t0) * 0.01, k}); latest_start = std::max(latest_start, (double)(e[2 * k] - t0) * 0.01); }
-            std::sort(ends.begin(), ends.end());
-            fprintf(stderr, "BLOCK ENDS (%d blocks, %d list blocks; latest start %.2f us): median %.2f, 90%% %.2f, 99%% %.2f; last ten:", nblk, np, latest_start,
-                    ends[nblk / 2].first, ends[nblk * 9 / 10].first, ends[nblk * 99 / 100].first);
-            for (int k = std::max(0, nblk - 10); k < nblk; ++k) fprintf(stderr, " %d@%.2f(start %.2f)", ends[k].second, ends[k].first, (double)(e[2 * ends[k].second] - t0) * 0.01);
-            fprintf(stderr, "\n");
-            for (int g8 = 0; g8 < 8; ++g8) {
-                double sum = 0, mx = 0; int cnt = 0;
-                for (int k = np + ((g8 - np) & 7); k < nblk; k += 8) { const double v = (double)(e[2 * k + 1] - t0) * 0.01; sum += v; mx = std::max(mx, v); ++cnt; }
-                fprintf(stderr, "  blocks %% 8 == %d: %d sift blocks, mean end %.2f, max %.2f us\n", g8, cnt, sum / std::max(cnt, 1), mx);
-            }
-        }
-    }
-    for (int k = 0; k < 32; ++k) {
-        const unsigned long long* o = h + k * 8;
-        if (!o[0]) continue;
-        const int blk = k < 24 ? k * 32 : (k - 24) * 8;
-        if (k == 23) fprintf(stderr, "PUBLISHER (ticket in, tickets done, counters fetched, fence, flag):"); else
-        fprintf(stderr, "SIFT TRACE block %4d (%s):", blk, blk < np ? "lists" : "sift");
-        for (int j = 1; j < 6; ++j) fprintf(stderr, " %6.2f", o[j] >= o[0] ? (double)(o[j] - o[0]) * 0.01 : -1.0);
-        fprintf(stderr, "  start %.2f us\n", (double)(long long)(o[0] - h[24 * 8]) * 0.01);
-    }
-}
-#endif
 // Blocks of the neighbour search: ~ARP_SEARCH_CPW cells per wave, a multiple of 8 (one per XCD).
 int search_blocks(const GridDesc& d, int cpw = 1) {
     int nb = (d.ncell + SEARCH_WAVES * cpw - 1) / (SEARCH_WAVES * cpw);
@@ -1120,7 +1029,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // so the sift part gets num_cu * blocks-per-CU minus these.  Sixteen list chunks (of 64 entries) per wave are still
         // inside the time the sift blocks need (sweep in profiles/README.md); ring-heavy structures get more blocks, up to half the slots.
         // ... and fewer when the sift part itself is short: a list chunk takes about as long as a batch of 64 pairs (2.3 vs 2.5-3 us
-        // in the block traces, -DARP_SIFT_TRACE), and a sift wave of a small structure has only a batch or two.
+        // in the block traces of round 2, profiles/README.md), and a sift wave of a small structure has only a batch or two.
         static const int cpw_max = std::max(1, env_int("ARP_PLANE_CPW", 16));
         const int64_t expect_pairs = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
         const double batches_per_wave = (double)expect_pairs / (64.0 * 4.0 * std::min<double>(c->num_cu * 4.0, std::max(1.0, expect_pairs / 256.0)));
@@ -1148,11 +1057,8 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
                            c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
                            include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
-                           c->d_ctr + C_STAT_ACC, SEARCH_TRACE_ARG);
+                           c->d_ctr + C_STAT_ACC, (uint8_t*)nullptr);
         CHK(check_launch(c, "k_search<CONTACTS>"));
-#ifdef ARP_SEARCH_TRACE
-        trace_dump(c->stream);
-#endif
     }
     if (planes_alone) {
         if (st2 != c->stream) HIPCHK(c, hipStreamWaitEvent(st2, c->ev_sel, 0));
@@ -1188,9 +1094,6 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         else
             hipLaunchKernelGGL(k_sift<0>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         CHK(check_launch(c, "k_sift"));
-#ifdef ARP_SIFT_TRACE
-        sift_trace_dump(c->stream, np);
-#endif
     } else if (!planes_alone) {
         c->pub.expected = 0;   // nothing was launched that could publish: the caller falls back to k_publish_counters
     }

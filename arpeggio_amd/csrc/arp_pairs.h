@@ -474,25 +474,6 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     }
 }
 
-// -DARP_SIFT_TRACE: thread 0 of every 32nd block of k_sift_planes stamps the 100 MHz clock at entry (0), after the prologue's
-// barrier (1), after its first batch (2), after its last batch (3), after the remaining hydrogen tasks (4) and after pass_end (5);
-// ARP_TRACE_DUMP=1 prints them at the 30th pass (arp_api.hip)
-#ifdef ARP_SIFT_TRACE
-__device__ unsigned long long g_sift_trace[32 * 8];
-__device__ unsigned long long g_sift_ends[2048 * 2];   // start / end of every block (thread 0)
-// slots 0-23: every 32nd block; slots 24-31: blocks 0, 8, .. 56 (the list blocks come first)
-#define SIFT_TRACE(k) do { if (threadIdx.x == 0) { \
-        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
-        if ((blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 23 && blockIdx.x > 0) g_sift_trace[(blockIdx.x >> 5) * 8 + (k)] = t_; \
-        if ((blockIdx.x & 7) == 0 && blockIdx.x < 64) g_sift_trace[(24 + (blockIdx.x >> 3)) * 8 + (k)] = t_; } } while (0)
-#else
-#define SIFT_TRACE(k)
-#endif
-#ifdef ARP_SIFT_TRACE
-#define PUB_TRACE(k) do { if (threadIdx.x == 0) g_sift_trace[23 * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PUB_TRACE(k)
-#endif
 // ---- end of a pass, without a launch of its own ------------------------------------------------------------
 // The last kernels of a pass (k_sift on the main stream, k_planes beside it on the second one) call pass_end() as their
 // final statement: every block takes a ticket once its own atomics have been performed, the last block of a kernel
@@ -513,9 +494,6 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     __shared__ int s_publisher;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's counter atomics have been performed (memory side)
     __syncthreads();
-#ifdef ARP_SIFT_TRACE
-    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-#endif
     if (threadIdx.x == 0) {
         int pub = 0;
         const unsigned grp = blockIdx.x & 7u;
@@ -529,18 +507,11 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     }
     __syncthreads();
     if (!s_publisher) return;
-#ifdef ARP_SIFT_TRACE
-    if (threadIdx.x == 0) g_sift_trace[23 * 8 + 0] = t_in;
-#endif
-    PUB_TRACE(1);
     // returning atomics read the memory-side value whatever this XCD's L2 holds, and leave the slot zero
     for (int i = threadIdx.x; i < (int)C_COUNT; i += blockDim.x) pa.host[i] = atomicExch(pa.ctr + i, 0ull);
-    PUB_TRACE(2);
     __threadfence_system();
-    PUB_TRACE(3);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(pa.host + C_COUNT, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    PUB_TRACE(4);
 }
 
 // ---- neighbour search ---------------------------------------------------------------
@@ -554,43 +525,9 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
 #define SEARCH_MIN_WAVES 1
 #endif
 #define HOME_BLOCK 32
+#define DESC_CAP 256
 
 enum { MODE_CONTACTS = 0, MODE_PAIRS = 1, MODE_MARK = 2 };
-
-// Build with -DARP_SEARCH_TRACE to see where a wave of k_search<MODE_CONTACTS> spends its time: lane 0 of the first and the last
-// wave of every 97th block stamp the 100 MHz clock after the start table has arrived (1), after the atoms of the first chunk have (2),
-// after its distance loop (3), after its hits are queued (4), when the wave's home blocks are done (5), after the block's
-// reservation (6) and after the final write (7); the stamps leave through the `plus` argument (unused in this mode) and
-// ARP_TRACE_DUMP=1 prints them at the 30th pass (arp_api.hip).  The stamps of (1) and (2) wait for the loads — they perturb
-// what they measure a little.
-#ifdef ARP_SEARCH_TRACE
-__device__ unsigned long long g_search_ends[8192 * 2];   // start / end of every block (wave 0)
-// (the stamps live in LDS, not in registers: the trace build keeps the occupancy of the production build)
-#define TRACE_DECL __shared__ unsigned long long s_tr[SEARCH_WAVES][8]; int tr_on = 1; \
-    if (lane < 8) s_tr[w][lane] = 0; \
-    if (MODE == MODE_CONTACTS && threadIdx.x == 0 && blockIdx.x < 8192) g_search_ends[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime()
-#define TRACE_PUT(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) s_tr[w][k] = t_; } while (0)
-#define TRACE_STAMP(k) do { if (tr_on) TRACE_PUT(k); } while (0)
-#define TRACE_STAMP_LOADED(k) do { if (tr_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE_PUT(k); } } while (0)
-#define TRACE_FIRST_ONLY tr_on = 0
-#define TRACE_ALWAYS(k) TRACE_PUT(k)
-#define TRACE_DUMP do { \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        TRACE_PUT(7); \
-        if (MODE == MODE_CONTACTS && threadIdx.x == 0 && blockIdx.x < 8192) g_search_ends[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); \
-        if (MODE == MODE_CONTACTS && plus && lane == 0 && (w == 0 || w == SEARCH_WAVES - 1) && (blockIdx.x % 97 == 0)) { \
-            unsigned long long* o = (unsigned long long*)plus + ((blockIdx.x / 97) * 2 + (w ? 1 : 0)) * 10; \
-            for (int k = 0; k < 8; ++k) o[k] = s_tr[w][k]; \
-            o[8] = blockIdx.x; o[9] = (unsigned long long)qn; \
-        } } while (0)
-#else
-#define TRACE_DECL
-#define TRACE_STAMP(k)
-#define TRACE_STAMP_LOADED(k)
-#define TRACE_FIRST_ONLY
-#define TRACE_ALWAYS(k)
-#define TRACE_DUMP
-#endif
 
 // One wavefront per home cell.  Half stencil: own cell (later entries) + 13 forward cells,
 // expressed as 5 contiguous ranges of the cell-sorted array (cells are x-fastest, so 3
@@ -633,9 +570,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                                                                unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus) {
-    __shared__ int2 q[SEARCH_WAVES][QCAP];
+    __shared__ int2 q[MODE == MODE_MARK ? 1 : SEARCH_WAVES][QCAP];   // (the expansion search queues nothing)
     __shared__ float4 s_hx[SEARCH_WAVES][HOME_BLOCK];   // home atoms of the moment: x, y, z, meta
     __shared__ int4 s_ha[SEARCH_WAVES][HOME_BLOCK];     //                         local id, residue, prev, next
+    __shared__ uint16_t s_desc[MODE == MODE_MARK ? 1 : SEARCH_WAVES][DESC_CAP]; // hits of the chunk: candidate slot << 5 | home atom
+    __shared__ int s_dn[SEARCH_WAVES];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     // XCD-aware remap: blocks that land on one XCD (b % 8) walk a contiguous run of cells,
@@ -651,8 +590,6 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
 
     int qn = 0;
     unsigned int n_cand = 0, n_acc = 0;   // per lane; reduced over the wave at the end
-    TRACE_DECL;
-    TRACE_STAMP(0);
     const float r2_lo = (float)(r2 * (1.0 - 1e-5)), r2_hi = (float)(r2 * (1.0 + 1e-5));
 
     // output segment of this block (cap = capacity of ONE segment)
@@ -697,7 +634,6 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
             }
         }
       }
-      TRACE_STAMP_LOADED(1);
 #pragma unroll 1
       for (int ci = 0; ci < 8; ++ci) {
         const int cell = cg + ci * SEARCH_WAVES;
@@ -776,14 +712,9 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                 // float32 pre-filter: |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded squares, two
                 // rounded sums), so outside the +-1e-5 band the float32 answer IS the float64 answer.
                 uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
-                TRACE_STAMP_LOADED(2);
                 const v2f cx = {x0.x, x1.x}, cy = {x0.y, x1.y}, cz = {x0.z, x1.z};
 #pragma unroll 1
-#ifdef ARP_EXP_SKIP_STAGE1
-                for (int hh = (x0.x == 12345.0f ? hcount - 1 : -1); hh >= 0; --hh) {
-#else
                 for (int hh = hcount - 1; hh >= 0; --hh) {
-#endif
                     // broadcast the home atom from lane hh (v_readlane, no memory traffic)
                     const float hx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.x), hh));
                     const float hy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hreg.y), hh));
@@ -820,7 +751,6 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                     }
                     lo0 &= te0; hi0 &= te0; lo1 &= te1; hi1 &= te1;
                 }
-                TRACE_STAMP(3);
                 // inside the band (rare) the exact Bio.PDB.kdtrees float64 test decides
                 uint32_t band0 = hi0 & ~lo0, band1 = hi1 & ~lo1;
                 if (__any((band0 | band1) != 0)) {
@@ -840,71 +770,105 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                     }
                 }
                 n_acc += __popc(lo0) + __popc(lo1);
-#ifdef ARP_EXP_SKIP_STAGE2
-                if (lo0 | lo1) { q[w][0] = make_int2((int)lo0, (int)lo1); }
-                lo0 = lo1 = 0;
-#endif
-                // ---- stage 2: every lane walks its own hits (residue filters, orientation, queueing)
-                // (both masks of the lane as one 64-bit word: the walk needs no branch to tell the two candidates apart — the
-                // compiler turned `use1 ? a1 : a0` plus the two ways of clearing a bit into two arms of register moves)
-                unsigned long long lo = (unsigned long long)lo0 | ((unsigned long long)lo1 << 32);
-                while (__any(lo != 0)) {
-                    const bool has = lo != 0;
-                    const int bit = __ffsll((long long)lo) - 1;     // (-1 for a lane without hits: it reads home atom 31 and is masked by `has`)
-                    lo &= lo - 1ull;
-                    const int hh = bit & 31;
-                    const bool use1 = bit >= 32;
-                    const int4 aj = make_int4(use1 ? a1.x : a0.x, use1 ? a1.y : a0.y, use1 ? a1.z : a0.z, use1 ? a1.w : a0.w);
-                    const uint32_t mj = use1 ? mj1 : mj0;
-                    const int j = use1 ? j1 : j0;
-                    const int h = hb + hh;
-                    const uint32_t mh = __float_as_uint(s_hx[w][hh].w);
-                    const int4 ah = s_ha[w][hh];
-                    if (MODE == MODE_MARK) {
-                        // interactions.py:1420-1424: either atom selected -> both join selection_plus
-                        if (has && ((mh | mj) & M_SEL)) {
-                            plus[aj.x] = 1;
-                            plus[ah.x] = 1;
+                if (MODE == MODE_MARK) {
+                    // interactions.py:1420-1424: either atom selected -> both join selection_plus (every lane walks its own hits)
+                    unsigned long long lo = (unsigned long long)lo0 | ((unsigned long long)lo1 << 32);
+                    while (lo != 0) {
+                        const int bit = __ffsll((long long)lo) - 1;
+                        lo &= lo - 1ull;
+                        const int hh = bit & 31;
+                        const bool use1 = bit >= 32;
+                        const uint32_t mh = __float_as_uint(s_hx[w][hh].w);
+                        if ((mh | (use1 ? mj1 : mj0)) & M_SEL) {
+                            plus[use1 ? a1.x : a0.x] = 1;
+                            plus[s_ha[w][hh].x] = 1;
                         }
-                        continue;
                     }
-                    bool pass = has;
-                    int pb, pe;
-                    if (MODE == MODE_CONTACTS) {
-                        // canonical orientation: bgn = lower packed index.  Only three things depend on it — which
-                        // residue's polypeptide flag is read (I:734 tests res_end twice), whose HOME bit decides
-                        // ownership, and the order of the stored positions; the same-residue and sequence-neighbour
-                        // tests are symmetric in the two atoms.
-                        const bool h_first = ah.x < aj.x;
-                        const uint32_t m_bgn = h_first ? mh : mj;
-                        const uint32_t m_end = h_first ? mj : mh;
-                        pb = h_first ? h : j;
-                        pe = h_first ? j : h;
-                        // Straight-line filters (a branch costs this loop more than the handful of integer operations it skips):
-                        // interactions.py:729 same residue; 733-741 sequence-adjacent residues — one of the four links equal
-                        // <=> the smallest of the four XORs is zero —; ownership: the rank owning the bgn atom emits the pair
-                        const unsigned adj = min(min((unsigned)(ah.w ^ aj.y), (unsigned)(ah.z ^ aj.y)), min((unsigned)(aj.w ^ ah.y), (unsigned)(aj.z ^ ah.y)));
-                        const unsigned gate = (include_seq_adj ? 0u : 1u) & ((m_end & M_RES_POLY) ? 1u : 0u) & ((mh & mj & M_RES_HASSEQ) ? 1u : 0u);
-                        const unsigned drop = (ah.y == aj.y ? 1u : 0u) | (gate & (adj == 0u ? 1u : 0u)) | ((m_bgn & M_HOME) ? 0u : 1u);
-                        pass = has & (drop == 0u);
-                    } else {  // MODE_PAIRS: raw search_all, report packed ids (i < j)
-                        pb = min(ah.x, aj.x);
-                        pe = max(ah.x, aj.x);
-                    }
-                    const unsigned long long mp = __ballot(pass);
-                    if (mp) {
-                        if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
-                        qn += __popcll(mp);
-                        if (qn > QCAP - 64) flush();
-                    }
+                    continue;
                 }
-                TRACE_STAMP(4);
-                TRACE_FIRST_ONLY;
+                // ---- stage 2: residue filters, orientation and queueing of the hits.
+                // A lane has 0-5 hits, ~1.1 on average: walking them lane by lane kept a quarter of the wave busy in the
+                // ~70 instructions a hit costs.  Instead the hits are first COMPACTED: every lane drops a 16-bit descriptor
+                // {candidate slot, home atom} per hit into a per-wave LDS list (positions from one LDS atomicAdd per lane), and
+                // the filters then run on 64 descriptors at a time with full lanes; a lane fetches its candidate's operands
+                // from the registers of the lane that holds them (ds_bpermute: no LDS storage, the kernel keeps 3 blocks per CU).
+                __builtin_amdgcn_wave_barrier();
+                uint32_t l0 = lo0, l1 = lo1;
+                for (;;) {
+                    const int c = __popc(l0) + __popc(l1);
+                    if (!__any(c != 0)) break;
+                    if (lane == 0) s_dn[w] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    int pos = DESC_CAP;
+                    if (c != 0) pos = atomicAdd(&s_dn[w], c);                   // (LDS; the order of the descriptors does not matter)
+                    int room = min(max(DESC_CAP - pos, 0), c);                  // hits beyond the list wait for the next round
+                    while (room > 0) {
+                        const bool from0 = l0 != 0;
+                        const uint32_t m = from0 ? l0 : l1;
+                        const int bit = __ffs((int)m) - 1;
+                        const uint32_t m2 = m & (m - 1u);
+                        l0 = from0 ? m2 : l0;
+                        l1 = from0 ? l1 : m2;
+                        s_desc[w][pos] = (uint16_t)((((from0 ? 0 : 64) + lane) << 5) | bit);
+                        ++pos;
+                        --room;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int T = min(s_dn[w], DESC_CAP);
+                    for (int r0 = 0; r0 < T; r0 += 64) {
+                        const bool has = r0 + lane < T;
+                        const unsigned dsc = s_desc[w][min(r0 + lane, DESC_CAP - 1)];
+                        const int hh = dsc & 31, cidx = (dsc >> 5) & 127;
+                        // (slot l < 64 = first candidate of lane l, 64 + l its second one)
+                        const int src = (cidx & 63) << 2;
+                        const bool second = cidx >= 64;
+                        auto fetch = [&](int v0, int v1) -> int {
+                            const int f0 = __builtin_amdgcn_ds_bpermute(src, v0), f1 = __builtin_amdgcn_ds_bpermute(src, v1);
+                            return second ? f1 : f0;
+                        };
+                        const uint32_t mj = (uint32_t)fetch((int)mj0, (int)mj1);
+                        const int j = fetch(j0, j1);
+                        const int h = hb + hh;
+                        bool pass = has;
+                        int pb, pe;
+                        if (MODE == MODE_CONTACTS) {
+                            const int4 aj = make_int4(fetch(a0.x, a1.x), fetch(a0.y, a1.y), fetch(a0.z, a1.z), fetch(a0.w, a1.w));
+                            const int4 ah = s_ha[w][hh];
+                            const uint32_t mh = __float_as_uint(s_hx[w][hh].w);
+                            // canonical orientation: bgn = lower packed index.  Only three things depend on it — which
+                            // residue's polypeptide flag is read (I:734 tests res_end twice), whose HOME bit decides
+                            // ownership, and the order of the stored positions; the same-residue and sequence-neighbour
+                            // tests are symmetric in the two atoms.
+                            const bool h_first = ah.x < aj.x;
+                            const uint32_t m_bgn = h_first ? mh : mj;
+                            const uint32_t m_end = h_first ? mj : mh;
+                            pb = h_first ? h : j;
+                            pe = h_first ? j : h;
+                            // Straight-line filters: interactions.py:729 same residue; 733-741 sequence-adjacent residues — one
+                            // of the four links equal <=> the smallest of the four XORs is zero —; ownership: the rank owning
+                            // the bgn atom emits the pair
+                            const unsigned adj = min(min((unsigned)(ah.w ^ aj.y), (unsigned)(ah.z ^ aj.y)), min((unsigned)(aj.w ^ ah.y), (unsigned)(aj.z ^ ah.y)));
+                            const unsigned gate = (include_seq_adj ? 0u : 1u) & ((m_end & M_RES_POLY) ? 1u : 0u) & ((mh & mj & M_RES_HASSEQ) ? 1u : 0u);
+                            const unsigned drop = (ah.y == aj.y ? 1u : 0u) | (gate & (adj == 0u ? 1u : 0u)) | ((m_bgn & M_HOME) ? 0u : 1u);
+                            pass = has & (drop == 0u);
+                        } else {  // MODE_PAIRS: raw search_all, report packed ids (i < j)
+                            const int lj = fetch(a0.x, a1.x), lh = s_ha[w][hh].x;
+                            pb = min(lh, lj);
+                            pe = max(lh, lj);
+                        }
+                        const unsigned long long mp = __ballot(pass);
+                        if (mp) {
+                            if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
+                            qn += __popcll(mp);
+                            if (qn > QCAP - 64) flush();
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
       }
     }
-    TRACE_ALWAYS(5);
     // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
     // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
     __shared__ int s_qn[SEARCH_WAVES];
@@ -916,28 +880,18 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         int tot = 0;
         u64 tc = 0, ta = 0;
         for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
-#ifdef ARP_EXP_SKIP_OUTPUT
-        s_base = 0;
-#else
         s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot) : 0;
-#endif
         const int slot = blockIdx.x & (STAT_SLOTS - 1);
         atomicAdd(ctr_cand + slot, tc);
         atomicAdd(ctr_acc + slot, ta);
     }
     __syncthreads();
-    TRACE_ALWAYS(6);
     if (MODE != MODE_MARK && qn > 0) {
         u64 base = s_base;
         for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
-#ifndef ARP_EXP_SKIP_OUTPUT
         for (int k = lane; k < qn; k += 64)
             if (base + k < cap) seg_pairs[base + k] = q[w][k];
-#else
-        if (base == 12345 && cap == 77) seg_pairs[lane] = q[w][lane];
-#endif
     }
-    TRACE_DUMP;
 }
 
 // ---- per-pair SIFt --------------------------------------------------------------------
@@ -1013,6 +967,28 @@ __device__ __forceinline__ int contact_type(bool bs, bool es, bool bw, bool ew) 
     if ((!bs && ew) || (!es && bw)) ct = ARP_CT_NON_SELECTION_WATER;
     if (bw && ew) ct = ARP_CT_WATER_WATER;
     return ct;
+}
+
+// interactions.py:643-691 as a table: entry k (4 bits) = contact_type(k & 1, k & 2, k & 4, k & 8)
+__host__ __device__ constexpr int contact_type_c(bool bs, bool es, bool bw, bool ew) {
+    int ct = 0;
+    if (!bs && !es) ct = ARP_CT_INTRA_NON_SELECTION;
+    if (bs && es) ct = ARP_CT_INTRA_SELECTION;
+    if ((bs && !es) || (es && !bs)) ct = ARP_CT_INTER;
+    if ((bs && ew) || (es && bw)) ct = ARP_CT_SELECTION_WATER;
+    if ((!bs && ew) || (!es && bw)) ct = ARP_CT_NON_SELECTION_WATER;
+    if (bw && ew) ct = ARP_CT_WATER_WATER;
+    return ct;
+}
+__host__ __device__ constexpr unsigned long long contact_type_table() {
+    unsigned long long t = 0;
+    for (int k = 0; k < 16; ++k) t |= (unsigned long long)contact_type_c(k & 1, k & 2, k & 4, k & 8) << (4 * k);
+    return t;
+}
+// float32 upper bound of the reach of a hydrogen test against an atom of radius vdw (U:86, 109, 145): 1.2 + vdw + comp plus
+// the longest atom - hydrogen distance of the structure; rounded up, so `d > reach` implies the same in float64
+__device__ __forceinline__ float reach_float(double vdw, double comp, double h_slack) {
+    return (float)((1.2 + vdw + comp + h_slack) * (1.0 + 1e-6));
 }
 
 // One thread per accepted pair (full 64-lane occupancy for the divergent chemistry).
@@ -1109,16 +1085,13 @@ struct SiftArgs {
 // behind a run-time flag the compiler merges the two stores into a plain one.)
 template <int STREAM, typename T>
 __device__ __forceinline__ void put_record(T v, T* p) {
-#ifdef ARP_EXP_SIFT_NO_STORE
-    if ((size_t)p != 0x1234567) return;
-#endif
     if (STREAM) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 struct SiftShared {
     uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
     double2 tab[RAD_TABLE];      // the structure's distinct {vdw, cov} pairs
-    float4 thr[256];             // for the first 16 of them, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), -}
+    float4 thr[256];             // for the first 16 of them, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), reach of the second}
 };
 // vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
 // vblock % 8 is still the XCD the dispatcher put the block on)
@@ -1170,10 +1143,9 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         // radius pairs only: for the common case — both atoms among the first 16 table entries — they are looked up, not computed
         const double2 ra = sd.rad_tab[threadIdx.x >> 4], rb_ = sd.rad_tab[threadIdx.x & 15];
         const double sv = ra.x + rb_.x;
-        sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), 0.0f);
+        sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), reach_float(rb_.x, comp, h_slack));
     }
     __syncthreads();
-    SIFT_TRACE(1);
     int tn = 0;
     auto run_tasks = [&](int first_, int count) {   // stage B on tq[w][first_ .. first_ + count)
         if (lane < count) {
@@ -1203,105 +1175,85 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
         const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
         const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
-        const bool bw = mb & M_WATER, ew = me & M_WATER;
-        const int ct = contact_type(mb & M_SEL, me & M_SEL, bw, ew);  // interactions.py:715
+        // Straight-line integer / mask code from here on: the reference's chains of `if` over the two type masks cost this
+        // kernel an exec-mask branch each (~350 VALU + 220 SALU instructions per batch of 64 pairs, and VALU issue is what
+        // the SIMDs run out of).  Only what is rare keeps a branch: radii outside the threshold table, a bonded-neighbour
+        // list longer than four, the halogen-bond angle.
+        const uint32_t bw = (mb / M_WATER) & 1u, ew = (me / M_WATER) & 1u;
+        // interactions.py:643-691 (__get_contact_type): the six overriding assignments as a 16-entry table of 4-bit codes,
+        // indexed by bgn selected | end selected << 1 | bgn water << 2 | end water << 3
+        const uint32_t ct_idx = ((mb / M_SEL) & 1u) | (((me / M_SEL) & 1u) << 1) | (bw << 2) | (ew << 3);
+        const int ct = (int)((contact_type_table() >> (4u * ct_idx)) & 15ull);
         float f_sum_cov, f_sum_vdw, f_vdw_comp;                         // interactions.py:717-718 and the casts of 756-773
+        float reach_e, reach_b;    // >= 1.2 + vdw + comp + the longest atom - hydrogen distance: beyond it no hydrogen of the partner reaches (U:86, 109, 145)
         {
             const unsigned rib = (unsigned)qb.q1.w >> 16, rie = (unsigned)qe.q1.w >> 16;
             if ((rib | rie) < 16u) {
                 const float4 t = sh->thr[rib * 16u + rie];
-                f_sum_cov = t.x; f_sum_vdw = t.y; f_vdw_comp = t.z;
+                f_sum_cov = t.x; f_sum_vdw = t.y; f_vdw_comp = t.z; reach_e = t.w;
+                reach_b = sh->thr[rie * 16u + rib].w;
             } else {
                 const double2 rb = rec_rad(qb.q1, s_tab, sd), re = rec_rad(qe.q1, s_tab, sd);   // {vdw, cov}
                 const double sum_vdw = rb.x + re.x;
                 f_sum_cov = (float)(rb.y + re.y); f_sum_vdw = (float)sum_vdw; f_vdw_comp = (float)(sum_vdw + comp);
+                reach_e = reach_float(re.x, comp, h_slack); reach_b = reach_float(rb.x, comp, h_slack);
             }
         }
         const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
-        uint32_t s = 0;
-        unsigned need = 0;
         // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
-        bool cov = false;
-#ifndef ARP_EXP_SIFT_NO_COVALENT
-        if (d <= longest_bond) {
-            cov = nbr.x == e || nbr.y == e || nbr.z == e || nbr.w == e;       // (-1 / -2 never equal a local id)
-            if (!cov && nbr.w == -2)                                          // more than four neighbours: the rest of the list
-                for (int k = qb.q1.y + 3, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
-                    if (bond_idx[k] == e) { cov = true; break; }
+        bool cov = (d <= longest_bond) & ((nbr.x == e) | (nbr.y == e) | (nbr.z == e) | (nbr.w == e));       // (-1 / -2 never equal a local id)
+        if ((d <= longest_bond) & !cov & (nbr.w == -2))                           // more than four neighbours: the rest of the list
+            for (int k = qb.q1.y + 3, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
+                if (bond_idx[k] == e) { cov = true; break; }
+        // interactions.py:756-773: float32 distance against Python floats -> float32 compare; an exclusive ladder
+        uint32_t s = cov ? ARP_S_COVALENT : (d < f_sum_cov) ? ARP_S_CLASH : (d < f_sum_vdw) ? ARP_S_VDW_CLASH : (d <= f_vdw_comp) ? ARP_S_VDW : ARP_S_PROXIMAL;
+        // interactions.py:777-783: an hbond acceptor beside a metal
+        const uint32_t metal = ((tb & (me >> 12)) | (te & (mb >> 12))) & 1u;        // ARP_T_HBOND_ACCEPTOR = bit 0, M_METAL = bit 12
+        s |= (d <= (float)2.8) ? metal * ARP_S_METAL_COMPLEX : 0u;
+        // The type tests of I:791-921 pair up neighbouring bits of the two masks — (acceptor 0, donor 1), (xbond acceptor 2,
+        // donor 3), (weak acceptor 4, weak donor 5), (positive 6, negative 7), (carbonyl O 9, C 10):
+        // X bit k = bgn has k + 1 and end has k, Y the same with the two atoms exchanged.
+        const uint32_t X = (tb >> 1) & te, Y = (te >> 1) & tb, XY = X | Y;
+        const bool in_vc = d <= f_vdw_comp, d35 = d <= (float)3.5;
+        // interactions.py:791-819: water rule, else donor / acceptor (if / elif); the water branches set POLAR whatever the distance
+        const uint32_t wb = bw & (in_vc ? 1u : 0u), we = ew & (in_vc ? 1u : 0u) & ~wb;
+        const uint32_t nowat = (wb | we) ^ 1u;
+        const uint32_t hb_w = (wb & (((te & 3u) != 0u) ? 1u : 0u)) | (we & (((tb & 3u) != 0u) ? 1u : 0u));
+        const uint32_t c1 = nowat & X & 1u, c2 = nowat & ~X & Y & 1u;
+        // interactions.py:857-886: the four weak branches
+        const uint32_t n4 = tb & (te >> 5) & 1u, n8 = (tb >> 5) & te & 1u;
+        const uint32_t n16 = (tb >> 4) & (mb >> 13) & (((te & 0x22u) != 0u) ? 1u : 0u) & 1u;    // weak acceptor 4, M_HALOGEN 13, donor 1 | weak donor 5
+        const uint32_t n32 = (te >> 4) & (me >> 13) & (((tb & 0x22u) != 0u) ? 1u : 0u) & 1u;
+        unsigned need = c1 | (c2 << 1) | (n4 << 2) | (n8 << 3) | (n16 << 4) | (n32 << 5);
+        uint32_t f = hb_w * (ARP_S_HBOND | ARP_S_POLAR);
+        f |= (d35 & ((c1 | c2) != 0u)) ? ARP_S_POLAR : 0u;                       // I:806, 814
+        f |= (d35 & ((need & 60u) != 0u)) ? ARP_S_WEAK_POLAR : 0u;               // I:861, 869, 877, 885
+        // interactions.py:898-921: ionic (bit 6 -> 8), carbonyl (9 -> 12), aromatic (11 -> 10), hydrophobic (8 -> 11), each behind its distance
+        const uint32_t near4 = ((XY & 0x40u) << 2) | ((tb & te & ARP_T_AROMATIC) >> 1);
+        f |= (d <= (float)4.0) ? near4 : 0u;
+        f |= (d <= (float)3.6) ? ((XY & 0x200u) << 3) : 0u;
+        f |= (tb & te & ARP_T_HYDROPHOBE) << 3;
+        // interactions.py:786: feature flags only for pairs that do not clash (covalent ones do get them) within 4.5 A
+        const bool feat = !(s & ARP_S_CLASH) & (d <= (float)4.5);
+        s |= feat ? f : 0u;
+        need = feat ? need : 0u;
+        // interactions.py:889-895 (halogen bond: float32 angle at the donor), rare
+        if (feat & in_vc & ((XY & 4u) != 0u)) {
+            if (X & 4u) { if (xbond(sd.sb[b], xb, xe, err)) s |= ARP_S_XBOND; }
+            else if (xbond(sd.sb[e], xe, xb, err)) s |= ARP_S_XBOND;
         }
-#endif
-        // interactions.py:756-773: float32 distance against Python floats -> float32 compare
-        if (cov) s |= ARP_S_COVALENT;
-        else if (d < f_sum_cov) s |= ARP_S_CLASH;
-        else if (d < f_sum_vdw) s |= ARP_S_VDW_CLASH;
-        else if (d <= f_vdw_comp) s |= ARP_S_VDW;
-        else s |= ARP_S_PROXIMAL;
-        // interactions.py:777-783
-        if (d <= (float)2.8) {
-            if ((tb & ARP_T_HBOND_ACCEPTOR) && (me & M_METAL)) s |= ARP_S_METAL_COMPLEX;
-            else if ((te & ARP_T_HBOND_ACCEPTOR) && (mb & M_METAL)) s |= ARP_S_METAL_COMPLEX;
-        }
-        // interactions.py:786: not clash (covalent pairs do get feature flags) and d <= 4.5
-        if (!(s & ARP_S_CLASH) && d <= (float)4.5) {
-            // interactions.py:791-819 (hbond / polar) and 857-886 (weak hbond / weak polar): the flags that need no
-            // geometry are set here, the hydrogen-geometry branches go to the task list
-            if (bw && d <= f_vdw_comp) {
-                if (te & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
-            } else if (ew && d <= f_vdw_comp) {
-                if (tb & (ARP_T_HBOND_ACCEPTOR | ARP_T_HBOND_DONOR)) s |= ARP_S_HBOND | ARP_S_POLAR;
-            } else {
-                if ((tb & ARP_T_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) {
-                    need |= 1u;
-                    if (d <= (float)3.5) s |= ARP_S_POLAR;
-                } else if ((te & ARP_T_HBOND_DONOR) && (tb & ARP_T_HBOND_ACCEPTOR)) {
-                    need |= 2u;
-                    if (d <= (float)3.5) s |= ARP_S_POLAR;
-                }
-            }
-            if ((tb & ARP_T_HBOND_ACCEPTOR) && (te & ARP_T_WEAK_HBOND_DONOR)) need |= 4u;
-            if ((tb & ARP_T_WEAK_HBOND_DONOR) && (te & ARP_T_HBOND_ACCEPTOR)) need |= 8u;
-            if ((tb & ARP_T_WEAK_HBOND_ACCEPTOR) && (mb & M_HALOGEN) && (te & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 16u;
-            if ((te & ARP_T_WEAK_HBOND_ACCEPTOR) && (me & M_HALOGEN) && (tb & (ARP_T_HBOND_DONOR | ARP_T_WEAK_HBOND_DONOR))) need |= 32u;
-            if ((need & 60u) && d <= (float)3.5) s |= ARP_S_WEAK_POLAR;   // each applicable weak branch sets it (I:861,869,877,885)
-            if (need) {
-                // Branches that cannot succeed need no hydrogen loop: the donor has no hydrogen, the halogen no single-bond
-                // neighbour (U:139-141), or the partner is further from the donor than the test's reach 1.2 + vdw + comp
-                // (U:86, 109, 145) plus the longest atom - hydrogen distance of the structure.  If EVERY applicable branch is
-                // such a one the pair gets no hbond / weak hbond bit — what the loops would find — and is not queued; if one
-                // is left the task runs with the full set (the last applicable weak branch decides, I:857-886).
-                const double dd = (double)d;
-                const bool far_e = dd > 1.2 + rec_rad(qe.q1, s_tab, sd).x + comp + h_slack;   // target = end (acceptor / halogen)
-                const bool far_b = dd > 1.2 + rec_rad(qb.q1, s_tab, sd).x + comp + h_slack;   // target = bgn
-                unsigned dead = 0;
-                if (((qb.q1.w >> 8) & 255) == 0 || far_e) dead |= 1u | 8u | 32u;               // hydrogens of bgn
-                if (((qe.q1.w >> 8) & 255) == 0 || far_b) dead |= 2u | 4u | 16u;               // hydrogens of end
-                if (!(mb & M_HAS_SB)) dead |= 16u;
-                if (!(me & M_HAS_SB)) dead |= 32u;
-#ifndef ARP_EXP_NO_HPRUNE
-                if ((need & ~dead) == 0) need = 0;
-#endif
-            }
-            // interactions.py:889-895
-            if (d <= f_vdw_comp) {
-                if ((tb & ARP_T_XBOND_DONOR) && (te & ARP_T_XBOND_ACCEPTOR)) {
-                    if (xbond(sd.sb[b], xb, xe, err)) s |= ARP_S_XBOND;
-                } else if ((te & ARP_T_XBOND_DONOR) && (tb & ARP_T_XBOND_ACCEPTOR)) {
-                    if (xbond(sd.sb[e], xe, xb, err)) s |= ARP_S_XBOND;
-                }
-            }
-            // interactions.py:898-904
-            if (d <= (float)4.0) {
-                if ((tb & ARP_T_POS_IONISABLE) && (te & ARP_T_NEG_IONISABLE)) s |= ARP_S_IONIC;
-                else if ((tb & ARP_T_NEG_IONISABLE) && (te & ARP_T_POS_IONISABLE)) s |= ARP_S_IONIC;
-            }
-            // interactions.py:907-913
-            if (d <= (float)3.6) {
-                if ((tb & ARP_T_CARBONYL_OXYGEN) && (te & ARP_T_CARBONYL_CARBON)) s |= ARP_S_CARBONYL;
-                else if ((te & ARP_T_CARBONYL_OXYGEN) && (tb & ARP_T_CARBONYL_CARBON)) s |= ARP_S_CARBONYL;
-            }
-            // interactions.py:916-917, 920-921
-            if ((tb & te & ARP_T_AROMATIC) && d <= (float)4.0) s |= ARP_S_AROMATIC;
-            if ((tb & te & ARP_T_HYDROPHOBE) && d <= (float)4.5) s |= ARP_S_HYDROPHOBIC;
+        {
+            // Branches that cannot succeed need no hydrogen loop: the donor has no hydrogen, the halogen no single-bond
+            // neighbour (U:139-141), or the partner is beyond the test's reach.  If EVERY applicable branch is such a one the
+            // pair gets no hbond / weak hbond bit — what the loops would find — and is not queued; if one is left the task
+            // runs with the full set (the last applicable weak branch decides, I:857-886).
+            const bool no_hb = (((unsigned)qb.q1.w >> 8) & 255u) == 0u, no_he = (((unsigned)qe.q1.w >> 8) & 255u) == 0u;
+            unsigned dead = 0;
+            dead |= (no_hb | (d > reach_e)) ? (1u | 8u | 32u) : 0u;               // hydrogens of bgn, target = end
+            dead |= (no_he | (d > reach_b)) ? (2u | 4u | 16u) : 0u;               // hydrogens of end, target = bgn
+            dead |= (mb & M_HAS_SB) ? 0u : 16u;
+            dead |= (me & M_HAS_SB) ? 0u : 32u;
+            need = ((need & ~dead) == 0u) ? 0u : need;
         }
         put_record<STREAM>(gid ? gid[b] : b, out_i + p);
         put_record<STREAM>(gid ? gid[e] : e, out_j + p);
@@ -1315,9 +1267,6 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         }
         }
         // stage B bookkeeping (whole wave)
-#ifdef ARP_EXP_SIFT_NO_TASKS
-        if (queued) { put_record<STREAM>((uint16_t)(task.w & 0xFFFFu), out_s + task.x); queued = false; }
-#endif
         const unsigned long long mq = __ballot(queued);
         if (mq) {
             if (queued) tq[w][tn + __popcll(mq & ((1ull << lane) - 1ull))] = task;
@@ -1327,11 +1276,8 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
                 run_tasks(tn, 64);
             }
         }
-        if (base == first) SIFT_TRACE(2);
     }
-    SIFT_TRACE(3);
     if (tn > 0) run_tasks(0, tn);
-    SIFT_TRACE(4);
 }
 
 // Per-atom accumulators of the contact loop (interactions.py:821-852, 923-934; utils.py:182-221) from the

@@ -767,22 +767,10 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa
                                                                      GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
                                                                      u64* publish_counts, int np, PublishArgs pub) {
     __shared__ SiftPlanesShared s_sh;
-    SIFT_TRACE(0);
-#ifdef ARP_SIFT_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < 2048) g_sift_ends[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
-#endif
     const int b = (int)blockIdx.x;
     if (b >= np) sift_body<STREAM>(sa, b - np, nsift, &s_sh.sift);
-    else {
-        planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
-        SIFT_TRACE(4);
-    }
-#ifdef ARP_SIFT_TRACE
-    __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x < 2048) g_sift_ends[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
+    else planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
     pass_end(pub, 0);
-    SIFT_TRACE(5);
 }
 // the two halves as separate kernels (sharded stage path with a caller-owned stream, structures without atoms / planes)
 __global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
