@@ -29,7 +29,7 @@ SYMBOLS = (
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
-    'arp_get_host_times', 'arp_set_whole_structure', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
+    'arp_get_host_times', 'arp_set_whole_structure', 'arp_set_batch', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
     'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob', 'arp_blob_fill',
     'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_records_fill', 'arp_shard_set_home', 'arp_shard_pack_face',
     'arp_shard_assemble', 'arp_shard_layout', 'arp_get_blob', 'arp_cif_open', 'arp_cif_close', 'arp_cif_rows', 'arp_cif_cols',
@@ -124,6 +124,7 @@ def load():
     L.arp_get_kernel_times.argtypes = [vp, vp, vp, i32]
     L.arp_get_host_times.argtypes = [vp, vp, vp, i32]
     L.arp_set_whole_structure.argtypes = [vp, i32]
+    L.arp_set_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     L.arp_ring_geometry.argtypes = [vp, i64, vp, vp, vp, vp]
     L.arp_amide_geometry.argtypes = [vp, i64, vp, vp, vp]
     L.arp_ring_residues.argtypes = [vp, i64, vp, vp, vp]
@@ -440,6 +441,42 @@ class Context:
         self._check(L.arp_set_rings(h, pc.n_rings, _p(pc.ring_center), _p(pc.ring_normal), _p(pc.ring_res)), 'arp_set_rings')
         self._check(L.arp_set_amides(h, pc.n_amides, _p(pc.amide_center), _p(pc.amide_normal), _p(pc.amide_res)), 'arp_set_amides')
         self.n, self.n_rings, self.n_amides = pc.n_atoms, pc.n_rings, pc.n_amides
+
+    def set_batch(self, pcs, selections=None):
+        """Several structures in one pass (arpeggio_amd.batch): uploads the concatenation of ``pcs`` and tells the library
+        where each structure begins.  ``selections``: per-structure uint8 masks (None = whole structure).  Returns the
+        offsets that ``run_batch`` / ``batch.split_*`` use."""
+        from . import batch as _batch
+        big, off = _batch.concat_complexes(pcs)
+        self.set_complex(big)
+        self.declare_batch(off)
+        if selections is not None:
+            sel = np.concatenate([np.ones(pc.n_atoms, np.uint8) if s_ is None else np.asarray(s_, np.uint8) for pc, s_ in zip(pcs, selections)])
+            self.set_selection(sel)
+        return off
+
+    def declare_batch(self, off):
+        """Tell the library how the resident (concatenated) structure splits into structures: ``off`` as returned by
+        ``batch.concat_complexes`` (after ``set_complex`` / ``set_blob`` of the concatenation)."""
+        a, r, m, bx = (np.ascontiguousarray(off[k]) for k in ('atom', 'ring', 'amide', 'boxes'))
+        self._check(self._L.arp_set_batch(self._h, len(a) - 1, _p(a), _p(r), _p(m), _p(bx)), 'arp_set_batch')
+        self._batch = off
+
+    def run_batch(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, expand_radius=6.0, fetch=True):
+        """run_arpeggio on every structure of the resident batch in ONE pass.  Returns a list of per-structure dicts
+        {atom_atom, atom_plane, plane_plane, group_group, group_plane} with structure-local ids, canonically sorted."""
+        from . import batch as _batch
+        counts = self.run_launch(cutoff, vdw_comp, include_sequence_adjacent, expand_radius)
+        if not fetch:
+            return counts
+        off = self._batch
+        per = [dict() for _ in range(len(off['atom']) - 1)]
+        for s_, d in enumerate(_batch.split_atom_contacts(self.atom_contacts_fetch(counts['atom_atom'], sort=True), off)):
+            per[s_]['atom_atom'] = d
+        for name in ('atom_plane', 'plane_plane', 'group_group', 'group_plane'):
+            for s_, d in enumerate(_batch.split_bag(name, self.fetch_bag(name, sort=True), off)):
+                per[s_][name] = d
+        return per
 
     def set_blob(self, blob, counts=None):
         """Upload a structure packed by ``pack_blob`` (one host-to-device copy); ``blob`` must stay alive during the call."""

@@ -240,6 +240,12 @@ struct arp_ctx {
     DevBuf<uint8_t> bag_pack;      // staging of small bags: device side ...
     uint8_t* bag_stage = nullptr;  // ... and its page-locked host copy
     size_t bag_stage_cap = 0;
+    // ---- several structures in one pass (arp_set_batch): structure s = atoms [atom_off[s], atom_off[s + 1]), rings, amides likewise
+    int64_t batch_n = 0;
+    std::vector<int64_t> batch_atom_off, batch_ring_off, batch_amide_off;
+    std::vector<double> batch_box;       // 6 per structure: lo xyz, hi xyz
+    DevBuf<int> sid_atom, sid_ring, sid_amide;
+    struct BatchGrid { double radius = 0; bool valid = false; DevBuf<BatchPlace> place; GridDesc d{}; } batch_grid[4];
     // ---- profiling
     bool profiling = false;
     std::vector<EventPair> ev_pool;
@@ -364,6 +370,81 @@ void make_grid_desc(GridDesc& d, const double lo[3], const double hi[3], double 
     d.ncell = d.nx * d.ny * d.nz;
     d.ox = lo[0]; d.oy = lo[1]; d.oz = lo[2];
     d.inv = 1.0 / edge;
+    d.place = nullptr; d.sid_atom = nullptr; d.sid_ring = nullptr; d.sid_amide = nullptr;
+}
+
+// Several structures in one grid (arp_set_batch): every structure gets the cells its own box needs at this cell edge and a
+// place in a common grid — shelves along x, rows along y, layers along z, one empty cell between neighbours in every
+// direction, the whole as near to a cube as the largest structure allows.  Cached per radius.
+int batch_grid_desc(arp_ctx* c, GridDesc& d, double radius) {
+    arp_ctx::BatchGrid* slot = nullptr;
+    for (auto& g : c->batch_grid)
+        if (g.valid && g.radius == radius) { d = g.d; return ARP_OK; }
+    for (auto& g : c->batch_grid)
+        if (!g.valid) { slot = &g; break; }
+    if (!slot) {   // every slot holds another radius: start over (grids built with the old tables are rebuilt)
+        for (auto& g : c->batch_grid) g.valid = false;
+        slot = &c->batch_grid[0];
+        c->static_dirty = true; c->lists_dirty = true;
+        c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
+    }
+    const int64_t B = c->batch_n;
+    double edge = radius * (1.0 + 1e-6);
+    if (!(edge > 0)) edge = 1.0;
+    std::vector<BatchPlace> pl((size_t)B);
+    int NX = 1, NY = 1, NZ = 1;
+    for (;;) {
+        double vol = 0;
+        int mx = 1, my = 1, mz = 1;
+        bool too_big = false;
+        for (int64_t s_ = 0; s_ < B; ++s_) {
+            const double* lo = &c->batch_box[(size_t)s_ * 6];
+            const double* hi = lo + 3;
+            const double nx = std::floor((hi[0] - lo[0]) / edge) + 1, ny = std::floor((hi[1] - lo[1]) / edge) + 1, nz = std::floor((hi[2] - lo[2]) / edge) + 1;
+            if (!(nx < 4096 && ny < 4096 && nz < 4096)) { too_big = true; break; }
+            pl[(size_t)s_] = BatchPlace{lo[0], lo[1], lo[2], 0, 0, 0, (int)nx, (int)ny, (int)nz};
+            vol += (nx + 1) * (ny + 1) * (nz + 1);
+            mx = std::max(mx, (int)nx); my = std::max(my, (int)ny); mz = std::max(mz, (int)nz);
+        }
+        if (!too_big) {
+            const int side = (int)std::ceil(std::cbrt(vol));
+            const int LX = std::max(side, mx), LY = std::max(side, my);
+            int x = 0, y = 0, z = 0, row_h = 0, layer_h = 0;
+            NX = NY = NZ = 1;
+            for (int64_t s_ = 0; s_ < B; ++s_) {
+                BatchPlace& b = pl[(size_t)s_];
+                if (x > 0 && x + b.nx > LX) { x = 0; y += row_h + 1; row_h = 0; }
+                if (y > 0 && y + b.ny > LY) { x = 0; y = 0; z += layer_h + 1; layer_h = 0; row_h = 0; }
+                b.cx = x; b.cy = y; b.cz = z;
+                NX = std::max(NX, x + b.nx); NY = std::max(NY, y + b.ny); NZ = std::max(NZ, z + b.nz);
+                x += b.nx + 1;
+                row_h = std::max(row_h, b.ny);
+                layer_h = std::max(layer_h, b.nz);
+            }
+            if ((double)NX * NY * NZ <= (double)(1 << 26)) break;
+        }
+        edge *= 1.26;
+    }
+    HIPCHK(c, slot->place.reserve((size_t)B));
+    HIPCHK(c, hipMemcpy(slot->place.p, pl.data(), (size_t)B * sizeof(BatchPlace), hipMemcpyHostToDevice));
+    GridDesc g{};
+    g.nx = NX; g.ny = NY; g.nz = NZ; g.ncell = NX * NY * NZ;
+    g.ox = c->lo[0]; g.oy = c->lo[1]; g.oz = c->lo[2];   // (not used for binning: every structure has its own origin)
+    g.inv = 1.0 / edge;
+    g.place = slot->place.p; g.sid_atom = c->sid_atom.p; g.sid_ring = c->sid_ring.p; g.sid_amide = c->sid_amide.p;
+    slot->d = g; slot->radius = radius; slot->valid = true;
+    d = g;
+    return ARP_OK;
+}
+void batch_reset(arp_ctx* c) {   // a new upload: one structure until arp_set_batch says otherwise
+    c->batch_n = 0;
+    for (auto& g : c->batch_grid) g.valid = false;
+}
+// the grid of a pass over the resident structure(s)
+int grid_desc_for(arp_ctx* c, GridDesc& d, const double lo[3], const double hi[3], double radius) {
+    if (c->batch_n > 0) return batch_grid_desc(c, d, radius);
+    make_grid_desc(d, lo, hi, radius);
+    return ARP_OK;
 }
 
 // exclusive scan of the cell histogram: one launch up to 32768 cells, two (tiles + fix-up) above
@@ -409,8 +490,8 @@ int reserve_grid(arp_ctx* c, Grid& G, int n, hipStream_t st = nullptr) {
 
 // bin + scan + scatter (+ optional cell sort) for rings / amides.  P = point accessor.
 template <class P>
-int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const double hi[3], double radius) {
-    make_grid_desc(G.d, lo, hi, radius);
+int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const double hi[3], double radius, const int* sid) {
+    CHK(grid_desc_for(c, G.d, lo, hi, radius));
     G.radius = radius;
     G.n_points = n;
     const int ncell = G.d.ncell;
@@ -418,7 +499,7 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     {
         Prof p(c, SLOT_BIN);
         if (n > 0) {
-            hipLaunchKernelGGL((k_bin<P>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, pts, n, G.d, G.cell_of.p, G.cnt.p);
+            hipLaunchKernelGGL((k_bin<P>), dim3(nblocks(n, 256)), dim3(256), 0, c->stream, pts, n, G.d, sid, G.cell_of.p, G.cnt.p);
             CHK(check_launch(c, "k_bin"));
         }
     }
@@ -465,7 +546,7 @@ int ensure_static(arp_ctx* c) {
         CHK(check_launch(c, "k_prepare_static"));
         // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure
         GridDesc d;
-        make_grid_desc(d, c->lo, c->hi, 6.0);
+        CHK(grid_desc_for(c, d, c->lo, c->hi, 6.0));
         HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_q1.reserve((size_t)n)); HIPCHK(c, c->sp_b4.reserve((size_t)n));
         HIPCHK(c, c->sp_cr.reserve((size_t)n));
         HIPCHK(c, c->sp_cnt.reserve((size_t)d.ncell + 1));
@@ -503,7 +584,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
                     hipStream_t st = nullptr, ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
     if (!st) st = c->stream;
     const int n = (int)c->n;
-    make_grid_desc(G.d, c->lo, c->hi, radius);
+    CHK(grid_desc_for(c, G.d, c->lo, c->hi, radius));
     G.radius = radius;
     G.n_points = n;
     const int ncell = G.d.ncell;
@@ -698,12 +779,12 @@ void host_bbox_d(const double* xyz, int64_t n, double lo[3], double hi[3]) {
 int ensure_ring_grid(arp_ctx* c) {
     if (c->ring_grid.valid) return ARP_OK;
     PtsD3 pts{c->ring_c.p};
-    return build_grid<PtsD3>(c, c->ring_grid, pts, (int)c->nring, c->ring_lo, c->ring_hi, 6.0);
+    return build_grid<PtsD3>(c, c->ring_grid, pts, (int)c->nring, c->ring_lo, c->ring_hi, 6.0, c->sid_ring.p);
 }
 int ensure_amide_grid(arp_ctx* c) {
     if (c->amide_grid.valid) return ARP_OK;
     PtsF3 pts{c->am_c.p};
-    return build_grid<PtsF3>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0);
+    return build_grid<PtsF3>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0, c->sid_amide.p);
 }
 
 // ---- enqueue-only building blocks (no host synchronisation) -----------------------------------
@@ -1350,6 +1431,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     CHK(upload_async(c, c->sb, sb0.data(), (size_t)n));
     CHK(upload_done(c));   // (the staging vectors above live until here)
     c->has_gid = c->has_home = false;
+    batch_reset(c);
     c->sel_made = false;
     c->sel_uploaded = false;   // a new structure starts with the default selection: everything (I:1395)
     c->nsel = -1;
@@ -1707,6 +1789,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     c->lists_dirty = true;
     c->has_gid = c->has_home = c->has_group_owner = false;
     c->shard_resident = false;
+    batch_reset(c);
     c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
     c->contacts_valid = false;
     c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
@@ -2561,8 +2644,9 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // nsel <= SMALL_SEL_MAX, worth it while the N x S direct tests stay below ~1.7e7) gets selection_plus from a
         // direct test of every atom against the selected ones — one short kernel.  Anything else: the all-atom 6 A
         // grid and the expansion search.
+        // (not for several structures in one pass: their coordinates overlap, only the grid keeps them apart)
         const bool small_sel = !c->sel_all && c->nsel > 0 && c->nsel <= SMALL_SEL_MAX && c->n > 0 && !c->has_home &&
-                               c->n * c->nsel <= (int64_t)1 << 24;
+                               c->n * c->nsel <= (int64_t)1 << 24 && c->batch_n == 0;
         if (c->sel_all || small_sel) {
             c->sel_made = true;
             HIPCHK(c, c->plus.reserve((size_t)std::max<int64_t>(c->n, 1)));
@@ -2901,6 +2985,54 @@ int arp_host_alloc(uint64_t bytes, void** out) {
 int arp_host_free(void* p) {
     if (!p) return ARP_OK;
     return hipHostFree(p) == hipSuccess ? ARP_OK : ARP_E_HIP;
+}
+
+int arp_set_batch(arp_ctx* c, int64_t nstruct, const int64_t* atom_off, const int64_t* ring_off, const int64_t* amide_off,
+                  const double* boxes) {
+    if (!c) return ARP_E_ARG;
+    if (nstruct == 0) {   // back to one structure
+        batch_reset(c);
+        c->static_dirty = true; c->lists_dirty = true;
+        c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
+        return ARP_OK;
+    }
+    if (nstruct < 0 || !atom_off || !ring_off || !amide_off || !boxes) FAIL(c, ARP_E_ARG, "arp_set_batch: bad input");
+    if (c->has_home || c->has_gid || c->shard_resident) FAIL(c, ARP_E_ARG, "arp_set_batch: not for a shard of a distributed structure");
+    auto check = [&](const int64_t* off, int64_t total) {
+        if (off[0] != 0 || off[nstruct] != total) return false;
+        for (int64_t s_ = 0; s_ < nstruct; ++s_)
+            if (off[s_ + 1] < off[s_]) return false;
+        return true;
+    };
+    if (!check(atom_off, c->n) || !check(ring_off, c->nring) || !check(amide_off, c->namide))
+        FAIL(c, ARP_E_ARG, "arp_set_batch: offsets must start at 0, never decrease and end at the resident atom / ring / amide counts");
+    for (int64_t k = 0; k < nstruct; ++k)
+        for (int a = 0; a < 3; ++a) {
+            const double lo = boxes[6 * k + a], hi = boxes[6 * k + 3 + a];
+            if (!std::isfinite(lo) || !std::isfinite(hi) || hi < lo) FAIL(c, ARP_E_ARG, "arp_set_batch: a box is not finite or has hi < lo");
+        }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    batch_reset(c);
+    c->batch_atom_off.assign(atom_off, atom_off + nstruct + 1);
+    c->batch_ring_off.assign(ring_off, ring_off + nstruct + 1);
+    c->batch_amide_off.assign(amide_off, amide_off + nstruct + 1);
+    c->batch_box.assign(boxes, boxes + 6 * nstruct);
+    auto upload_sid = [&](DevBuf<int>& buf, const int64_t* off, int64_t total) -> int {
+        std::vector<int> h((size_t)std::max<int64_t>(total, 1), 0);
+        for (int64_t s_ = 0; s_ < nstruct; ++s_)
+            for (int64_t i = off[s_]; i < off[s_ + 1]; ++i) h[(size_t)i] = (int)s_;
+        return upload(c, buf, h.data(), h.size());
+    };
+    CHK(upload_sid(c->sid_atom, atom_off, c->n));
+    CHK(upload_sid(c->sid_ring, ring_off, c->nring));
+    CHK(upload_sid(c->sid_amide, amide_off, c->namide));
+    c->batch_n = nstruct;
+    c->static_dirty = true; c->lists_dirty = true;
+    c->contacts_valid = false;
+    c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
+    c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
+    return ARP_OK;
 }
 
 int arp_set_whole_structure(arp_ctx* c, int enabled) {

@@ -14,9 +14,21 @@
 
 #include "arp_numerics.h"
 
+// Several structures in one grid (arp_set_batch): every structure keeps its own coordinates and its own box; its cells sit
+// at an integer offset inside a common grid, with at least one empty cell between two structures, so that no stencil ever
+// reaches from one structure into another.  place[s] = origin of structure s's box, its cell offset and its cell counts;
+// sid_* = structure of every atom (by local id), ring and amide.
+struct BatchPlace {
+    double ox, oy, oz;
+    int cx, cy, cz, nx, ny, nz;
+};
 struct GridDesc {
     double ox, oy, oz, inv;
     int nx, ny, nz, ncell;
+    const BatchPlace* place;      // null: one structure, the box of the grid is its box
+    const int* sid_atom;
+    const int* sid_ring;
+    const int* sid_amide;
 };
 
 struct PtsF3 {  // packed float32[3] (amide centres)
@@ -49,11 +61,23 @@ __device__ __forceinline__ int cell_index(const GridDesc& g, num::d3 p) {
     return (cz * g.ny + cy) * g.nx + cx;
 }
 
-// cell id + histogram for every point (ring and amide centres)
+// ... of a point of structure sid when the grid holds several structures (points outside their structure's box count
+// as its border cells: clamping is monotone, so two points within the radius still land at most one cell apart)
+__device__ __forceinline__ int cell_index(const GridDesc& g, num::d3 p, int sid) {
+    if (!g.place) return cell_index(g, p);
+    const BatchPlace b = g.place[sid];
+    const int cx = b.cx + cell_coord(p.x, b.ox, g.inv, b.nx);
+    const int cy = b.cy + cell_coord(p.y, b.oy, g.inv, b.ny);
+    const int cz = b.cz + cell_coord(p.z, b.oz, g.inv, b.nz);
+    return (cz * g.ny + cy) * g.nx + cx;
+}
+
+// cell id + histogram for every point (ring and amide centres); sid: structure of every point (batched grids)
 template <class P>
-__global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, int* __restrict__ cell_of, int* __restrict__ cell_cnt) {
+__global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, const int* __restrict__ sid, int* __restrict__ cell_of,
+                                             int* __restrict__ cell_cnt) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int c = cell_index(g, pts.get(i));
+        const int c = cell_index(g, pts.get(i), g.place ? sid[i] : 0);
         atomicAdd(&cell_cnt[c], 1);
         cell_of[i] = c;
     }

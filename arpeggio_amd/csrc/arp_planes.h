@@ -40,6 +40,13 @@ __device__ __forceinline__ CellBox cell_box(const GridDesc& g, num::d3 p) {
     return {cell_coord_raw(p.x, g.ox, g.inv, g.nx), cell_coord_raw(p.y, g.oy, g.inv, g.ny),
             cell_coord_raw(p.z, g.oz, g.inv, g.nz)};
 }
+// ... of a point of structure sid in a grid that holds several structures (clamped into the structure's own cells: one
+// step further is the empty gap around it, never another structure)
+__device__ __forceinline__ CellBox cell_box(const GridDesc& g, num::d3 p, int sid) {
+    if (!g.place) return cell_box(g, p);
+    const BatchPlace b = g.place[sid];
+    return {b.cx + cell_coord(p.x, b.ox, g.inv, b.nx), b.cy + cell_coord(p.y, b.oy, g.inv, b.ny), b.cz + cell_coord(p.z, b.oz, g.inv, b.nz)};
+}
 
 // ---- 27-cell stencil, flattened over the lanes of one wavefront ------------------------------
 // Lane r < 9 owns one (dy, dz) row of the stencil: three x-neighbour cells are contiguous in
@@ -433,7 +440,7 @@ template <bool DYNAMIC, class Sink>
 __device__ __forceinline__ void ap_enumerate(const AtomPlaneArgs& A, int r, int lane, Sink sink) {   // 27-cell stencil of a >= 6 A atom grid
     if (DYNAMIC && (!A.ring_plus[r] || (A.ring_home && !A.ring_home[r]))) return;   // I:957; multi-GPU: the ring's owner emits
     const num::d3 ctr_ = ld3(A.ring_c, r);
-    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, ctr_), lane);
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, ctr_, A.g.place ? A.g.sid_ring[r] : 0), lane);
     for (int kb = 0; kb < st.pre[9]; kb += 64) {
         const int k = kb + lane;
         bool ok = false;
@@ -459,7 +466,7 @@ __device__ __forceinline__ void ap_enumerate_cg(const AtomPlaneArgs& A, int r, i
     const GridDesc g = A.g;
     const int R = (int)floor(6.0 * g.inv) + 1, W = 2 * R + 1, nrows = W * W;
     const num::d3 ctr_ = ld3(A.ring_c, r);
-    const CellBox cb = cell_box(g, ctr_);
+    const CellBox cb = cell_box(g, ctr_, g.place ? g.sid_ring[r] : 0);
     for (int row0 = 0; row0 < nrows; row0 += 64) {
         int my_js = 0, my_len = 0;
         const int row = row0 + lane;
@@ -492,7 +499,7 @@ template <bool DYNAMIC, class Sink>
 __device__ __forceinline__ void pp_enumerate(const PlanePlaneArgs& A, int a, int lane, Sink sink) {
     if (DYNAMIC && (!A.ring_plus[a] || (A.ring_home && !A.ring_home[a]))) return;   // I:1081; multi-GPU: owner of the lower ring id emits
     const num::d3 ca = ld3(A.ring_c, a);
-    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, ca), lane);
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, ca, A.g.place ? A.g.sid_ring[a] : 0), lane);
     for (int kb = 0; kb < st.pre[9]; kb += 64) {
         const int k = kb + lane;
         bool ok = false;
@@ -510,7 +517,7 @@ template <bool DYNAMIC, class Sink>
 __device__ __forceinline__ void gg_enumerate(const GroupGroupArgs& A, int a, int lane, Sink sink) {
     if (DYNAMIC && (!A.am_plus[a] || (A.am_home && !A.am_home[a]))) return;   // multi-GPU: owner of the bgn amide emits
     const num::d3 cad = num::to_d3(lf3(A.am_c, a));
-    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, cad), lane);
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, cad, A.g.place ? A.g.sid_amide[a] : 0), lane);
     for (int kb = 0; kb < st.pre[9]; kb += 64) {
         const int k = kb + lane;
         bool ok = false;
@@ -528,7 +535,7 @@ template <bool DYNAMIC, class Sink>
 __device__ __forceinline__ void gp_enumerate(const GroupPlaneArgs& A, int a, int lane, Sink sink) {
     if (DYNAMIC && (!A.am_plus[a] || (A.am_home && !A.am_home[a]))) return;   // multi-GPU: owner of the amide emits
     const num::d3 cad = num::to_d3(lf3(A.am_c, a));
-    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, cad), lane);
+    const Stencil st = stencil_load(A.g, A.start, cell_box(A.g, cad, A.g.place ? A.g.sid_amide[a] : 0), lane);
     for (int kb = 0; kb < st.pre[9]; kb += 64) {
         const int k = kb + lane;
         bool ok = false;

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--workload', choices=('config3', 'standin'), default='config3',
                     help="config3: BASELINE configs[2] (the headline); standin: the 1tqn_h stand-in of configs[1] (5.9 k atoms incl. "
                          "explicit hydrogens, whole structure) on one GPU beside the CPU restatement")
+    ap.add_argument('--batch', type=int, default=1,
+                    help='N = 1 only: B structures of the stand-in family in ONE pass (arp_set_batch); prints the batched line instead')
     ap.add_argument('--inflight', type=int, default=3, help='contexts (host threads) of the extra several-structures-in-flight measurement; 1 = skip')
     ap.add_argument('--host-halo', action='store_true', help='N > 1: pack / merge the halo records on the host (the round-1 path) instead of on the device')
     ap.add_argument('--staged-exchange', action='store_true',
@@ -67,8 +69,136 @@ def algorithmic_bytes(kernel, n_binned, ncell, n_pairs, n_h=0):
     raise KeyError(kernel)
 
 
+def bench_batch(args):
+    """B protein-sized structures per pass (arp_set_batch): the reference's production use is the weekly PDBe release —
+    10^5 entries of a few thousand atoms — and one such structure is four launches of fixed cost.  Prints one JSON line
+    with the contract's keys; `value` = candidate pairs of all structures of the batch x steps / time."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
+    from arpeggio_amd import synth, _capi, batch as _batch
+    B = args.batch
+    t0 = time.perf_counter()
+    distinct = [synth.proteinlike(seed=2 + k, id=f'standin{k}') for k in range(min(B, 8))]
+    pcs = [distinct[k % len(distinct)] for k in range(B)]
+    big, off = _batch.concat_complexes(pcs)
+    gen_s = time.perf_counter() - t0
+    ctx = _capi.Context(0)
+    ctx.set_complex(big)
+    ctx.declare_batch(off)
+
+    def step():
+        return ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+
+    for _ in range(5 + args.warmup):
+        counts = step()
+    torch.cuda.synchronize()
+    t_trial = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    repeats = max(1, int(math.ceil(args.min_seconds / max(time.perf_counter() - t_trial, 1e-6))))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(repeats * args.steps):
+        counts = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    timed_steps = repeats * args.steps
+    st = ctx.stats()
+    ctx.set_profiling(True)
+    ctx.kernel_times(reset=True)
+    for _ in range(args.steps):
+        step()
+    ktimes = ctx.kernel_times(reset=True)
+    ctx.set_profiling(False)
+    per_kernel = {k: (v['ms'] / max(v['launches'], 1)) for k, v in ktimes.items() if v['launches']}
+    dom = max((k for k in ('search', 'sift') if k in per_kernel), key=lambda k: per_kernel[k])
+    b_alg = algorithmic_bytes(dom, st['binned'], st['cells'], st['emitted'], int(big.h_xyz.shape[0]))
+    ms_per_step = elapsed / timed_steps * 1e3
+    # the same structures one at a time on the same context (resident pass of each distinct structure)
+    single_ms = []
+    for pc in distinct:
+        ctx.set_complex(pc)
+        for _ in range(8):
+            ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+        tt = time.perf_counter()
+        for _ in range(200):
+            ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+        single_ms.append((time.perf_counter() - tt) / 200 * 1e3)
+    # end to end: a FRESH batch every step (blob H2D + partition + static columns + lists + pass + five bags D2H), two batches alternating
+    e2e = None
+    try:
+        pcs2 = pcs[1:] + pcs[:1]
+        big2, off2 = _batch.concat_complexes(pcs2)
+        blobs = [(_capi.pack_blob(big), off), (_capi.pack_blob(big2), off2)]
+        ctx.set_blob(blobs[0][0]); ctx.declare_batch(blobs[0][1])
+        cnt = ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+        cbuf = ctx.pinned_contact_buffers(int(cnt['atom_atom'] * 1.2) + 1024)
+        bbuf = {k: ctx.pinned_bag_buffers(k, 4 * max(cnt[k], 256)) for k in ('plane_plane', 'atom_plane', 'group_group', 'group_plane')}
+
+        def one(k):
+            ctx.set_blob(blobs[k % 2][0]); ctx.declare_batch(blobs[k % 2][1])
+            c_ = ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+            ctx.atom_contacts_fetch(c_['atom_atom'], sort=False, out=cbuf)
+            for nm in bbuf:
+                ctx.fetch_bag(nm, sort=False, out=bbuf[nm])
+        for k in range(4):
+            one(k)
+        n_e, tt = 0, time.perf_counter()
+        while n_e < 10 or time.perf_counter() - tt < 0.5:
+            one(n_e); n_e += 1
+        e2e_ms = (time.perf_counter() - tt) / n_e * 1e3
+        e2e = {'ms_per_batch': round(e2e_ms, 4), 'us_per_structure': round(e2e_ms / B * 1e3, 2), 'batches': n_e,
+               'upload_bytes': int(blobs[0][0].nbytes),
+               'note': 'fresh batch per step: arp_set_blob (one H2D copy + device validation) + arp_set_batch + static columns + '
+                       'ring / amide lists + pass + all five bags into page-locked buffers (records not yet split per structure)'}
+    except Exception as exc:
+        e2e = {'error': repr(exc)}
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle
+        tt = time.perf_counter()
+        for pc in distinct:
+            oc = oracle.OracleComplex(pc)
+            oc.make_selection(None)
+            oc.atom_contacts(args.cutoff, args.vdw_comp, False)
+            oc.plane_plane(); oc.atom_plane(); oc.group_group(); oc.group_plane()
+        cpu_s = time.perf_counter() - tt
+        cpu = {'value': round(st['candidates'] / B * len(distinct) / cpu_s, 1), 'unit': 'candidate atom-pairs/s', 'cores': 1, 'kind': 'port',
+               'ms_per_structure': round(cpu_s / len(distinct) * 1e3, 2),
+               'sample': f'one full run_arpeggio pass of the C oracle (oracle/ref_c.c, gcc -O2, 1 thread) over each of the {len(distinct)} distinct '
+                         f'structures of the batch, {cpu_s:.2f} s; pairs counted as the GPU counts them'}
+    line = {
+        'metric': 'evaluated atom-pairs/s', 'value': round(st['candidates'] * timed_steps / elapsed, 1), 'unit': 'candidate atom-pairs/s',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'timed_steps': timed_steps,
+        'timed_region_s': round(elapsed, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64 distance test / f32+f64 SIFt', 'data': 'synthetic',
+        'config': {'workload': f'{B} structures of the 1tqn_h stand-in family (BASELINE configs[1]; {len(distinct)} distinct synthetic chains of 480 residues + '
+                               f'haem-like ligand + waters, ~5.9 k atoms each incl. explicit hydrogens, repeated) in ONE pass (arp_set_batch), whole structures, 5 A cutoff',
+                   'structures_per_pass': B, 'atoms_per_pass': int(big.n_atoms), 'cutoff_A': args.cutoff, 'vdw_comp': args.vdw_comp, 'parallelism': 'single'},
+        'structures_per_s': round(B * timed_steps / elapsed, 1), 'us_per_structure': round(ms_per_step / B * 1e3, 3),
+        'single_structure_pass_ms': {'mean': round(float(np.mean(single_ms)), 4), 'min': round(float(np.min(single_ms)), 4), 'max': round(float(np.max(single_ms)), 4),
+                                     'note': 'resident pass of each distinct structure alone on the same context'},
+        'speedup_vs_one_at_a_time': round(float(np.mean(single_ms)) / (ms_per_step / B), 2),
+        'pairs': {'candidates': float(st['candidates']), 'accepted': float(st['accepted']), 'contacts_emitted': float(st['emitted']),
+                  'bags': {k: int(v) for k, v in counts.items()}},
+        'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()},
+        'roofline': {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(b_alg / (per_kernel[dom] * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
+                     'frac': round(b_alg / (per_kernel[dom] * 1e-3) / 1e9 / 8000.0, 6), 'traffic': None,
+                     'algorithmic_bytes_per_launch': int(b_alg), 'avg_launch_ms': round(per_kernel[dom], 5),
+                     'note': 'HIP-event duration of the dominant kernel in this run; no PMC run of this workload is committed, hence traffic = null'},
+        'cpu_baseline': cpu, 'end_to_end': e2e, 'setup_s': round(gen_s, 2),
+    }
+    print(json.dumps(line))
+    ctx.close()
+
+
 def main():
     args = parse()
+    if args.batch > 1:
+        if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
+            raise SystemExit('--batch is a one-GPU measurement')
+        return bench_batch(args)
     os.environ.setdefault('OMP_WAIT_POLICY', 'passive')   # (cpu_baseline_all_cores: idle OpenMP threads must not spin inside a CPU quota)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -401,6 +401,20 @@ int arp_host_free(void* p);
  * ranks.  arp_run_launch refuses (ARP_E_ARG) when the flag is on and the uploaded selection is partial.
  * Precondition: every residue of the table has at least one atom somewhere. */
 int arp_set_whole_structure(arp_ctx* ctx, int enabled);
+/* Several structures in ONE pass — the reference's production use is the weekly PDBe release, ~10^5 entries of a few
+ * thousand atoms each (README.md:4), and one such structure is four launches of fixed cost on this chip.  The caller
+ * uploads the CONCATENATION of nstruct structures through the usual setters (atom / residue / ring / amide indices
+ * shifted by each structure's offsets, coordinates unchanged) and then declares the partition: structure s = atoms
+ * [atom_off[s], atom_off[s + 1]), rings [ring_off[s], ..), amides [amide_off[s], ..) (nstruct + 1 entries each, first 0,
+ * last = the resident counts); boxes[6 * s ..] = lo x, y, z, hi x, y, z of everything structure s holds (atoms, ring and
+ * amide centres).  Every grid of a pass then gives each structure its own cells — its box at an integer cell offset, an
+ * empty cell between any two structures — so no neighbour search, selection expansion (I:1420) or ring / amide loop
+ * ever pairs items of different structures, while every distance is computed from the same coordinates as in a
+ * single-structure run: each structure's five bags are bit-identical to its own run.  Selections: one mask over the
+ * concatenated atoms (arp_set_selection).  Results carry the concatenated ids; a record belongs to the structure of its
+ * first id.  nstruct = 0 returns to one structure.  Not available on a shard (arp_set_ownership). */
+int arp_set_batch(arp_ctx* ctx, int64_t nstruct, const int64_t* atom_off, const int64_t* ring_off, const int64_t* amide_off,
+                  const double* boxes);
 /* Host side of arp_run_launch, accumulated over *passes calls: us[0] = time spent enqueueing the pass
  * (kernel launches, memsets, events), us[1] = time spent blocked in the one synchronisation. */
 int arp_get_host_times(arp_ctx* ctx, double us[2], int64_t* passes, int reset);

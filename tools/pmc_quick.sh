@@ -5,7 +5,7 @@ tag=${1:-q}
 out=gpurun_out/pmcq_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python tools/pass_probe.py --steps 60 ${PROBE_ARGS:-}"
+B="${PROBE_CMD:-python tools/pass_probe.py --steps 60} ${PROBE_ARGS:-}"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- $B > "$out/trace.log" 2>&1 < /dev/null
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$out/sq" -o s -- $B > "$out/sq.log" 2>&1 < /dev/null
 python - "$out" <<'PY'
