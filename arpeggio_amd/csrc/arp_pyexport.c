@@ -12,8 +12,9 @@ static PyObject* atom_atom_records(PyObject* self, PyObject* args) {
     (void)self;
     Py_buffer bi, bj, bd, bs, bc;
     PyObject *atom_dicts, *names_by_sift, *ctype_names;
-    if (!PyArg_ParseTuple(args, "y*y*y*y*y*O!O!O!", &bi, &bj, &bd, &bs, &bc, &PyList_Type, &atom_dicts, &PyList_Type, &names_by_sift,
-                          &PyList_Type, &ctype_names))
+    int share = 0;   /* 1: the records of an atom share ONE inner dictionary (and the records of a fingerprint one name list) */
+    if (!PyArg_ParseTuple(args, "y*y*y*y*y*O!O!O!|p", &bi, &bj, &bd, &bs, &bc, &PyList_Type, &atom_dicts, &PyList_Type, &names_by_sift,
+                          &PyList_Type, &ctype_names, &share))
         return NULL;
     PyObject* out = NULL;
     const Py_ssize_t n = bi.len / 4;
@@ -34,8 +35,15 @@ static PyObject* atom_atom_records(PyObject* self, PyObject* args) {
     PyObject* k_contact = PyUnicode_InternFromString("contact");
     PyObject* k_ent = PyUnicode_InternFromString("interacting_entities");
     PyObject* v_type = PyUnicode_InternFromString("atom-atom");
+    /* every record is a copy of one template (keys in place, one allocation for the table) whose values are then replaced */
+    PyObject* tmpl = PyDict_New();
+    if (!tmpl || PyDict_SetItem(tmpl, k_bgn, Py_None) || PyDict_SetItem(tmpl, k_end, Py_None) || PyDict_SetItem(tmpl, k_type, v_type) ||
+        PyDict_SetItem(tmpl, k_dist, Py_None) || PyDict_SetItem(tmpl, k_contact, Py_None) || PyDict_SetItem(tmpl, k_ent, Py_None)) {
+        Py_XDECREF(tmpl);
+        goto keys;
+    }
     out = PyList_New(n);
-    if (!out) goto keys;
+    if (!out) { Py_DECREF(tmpl); goto keys; }
     for (Py_ssize_t r = 0; r < n; ++r) {
         if (ci[r] < 0 || ci[r] >= n_atoms || cj[r] < 0 || cj[r] >= n_atoms || cs[r] >= n_sift || cc[r] >= n_ct) {
             PyErr_SetString(PyExc_IndexError, "atom_atom_records: index out of range");
@@ -50,14 +58,14 @@ static PyObject* atom_atom_records(PyObject* self, PyObject* args) {
             Py_CLEAR(out);
             break;
         }
-        PyObject* rec = PyDict_New();
-        PyObject* b = PyDict_Copy(ab);
-        PyObject* e = PyDict_Copy(ae);
+        PyObject* rec = PyDict_Copy(tmpl);
+        PyObject *b, *e, *names;
+        if (share) { b = ab; e = ae; names = nm; Py_INCREF(b); Py_INCREF(e); Py_INCREF(names); }
+        else { b = PyDict_Copy(ab); e = PyDict_Copy(ae); names = PyList_GetSlice(nm, 0, PyList_GET_SIZE(nm)); }
         PyObject* d = PyFloat_FromDouble(cd[r]);
-        PyObject* names = PyList_GetSlice(nm, 0, PyList_GET_SIZE(nm));
         int bad = !rec || !b || !e || !d || !names;
         if (!bad) {
-            bad = PyDict_SetItem(rec, k_bgn, b) || PyDict_SetItem(rec, k_end, e) || PyDict_SetItem(rec, k_type, v_type) ||
+            bad = PyDict_SetItem(rec, k_bgn, b) || PyDict_SetItem(rec, k_end, e) ||
                   PyDict_SetItem(rec, k_dist, d) || PyDict_SetItem(rec, k_contact, names) ||
                   PyDict_SetItem(rec, k_ent, PyList_GET_ITEM(ctype_names, cc[r]));
         }
@@ -69,6 +77,7 @@ static PyObject* atom_atom_records(PyObject* self, PyObject* args) {
         }
         PyList_SET_ITEM(out, r, rec);
     }
+    Py_DECREF(tmpl);
 keys:
     Py_XDECREF(k_bgn); Py_XDECREF(k_end); Py_XDECREF(k_type); Py_XDECREF(k_dist); Py_XDECREF(k_contact); Py_XDECREF(k_ent); Py_XDECREF(v_type);
 done:
@@ -78,7 +87,7 @@ done:
 
 static PyMethodDef methods[] = {
     {"atom_atom_records", atom_atom_records, METH_VARARGS,
-     "atom_atom_records(i, j, distance, sift, ctype, atom_dicts, names_by_sift, ctype_names) -> list of record dicts"},
+     "atom_atom_records(i, j, distance, sift, ctype, atom_dicts, names_by_sift, ctype_names, share=False) -> list of record dicts"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_pyexport", "get_contacts() records in C", -1, methods, NULL, NULL, NULL, NULL};
 PyMODINIT_FUNC PyInit__pyexport(void) { return PyModule_Create(&module); }
