@@ -34,6 +34,14 @@ AtomAtomContact = collections.namedtuple('AtomAtomContact', ['bgn_atom', 'end_at
 Parameters = collections.namedtuple('Parameters', ['vdw_comp_factor', 'interacting_threshold', 'has_hydrogens', 'ph'])
 
 
+def amide_majority_residue(res_id, amide_atoms):
+    """I:1554-1559: the residue of an amide group = ``max(residues, key=residues.count)`` over its four atoms N, C, O,
+    C-alpha — the most frequent one, the FIRST such in that order on a tie."""
+    r = np.asarray(res_id)[np.asarray(amide_atoms).reshape(-1, 4)]                     # [A, 4]
+    cnt = (r[:, :, None] == r[:, None, :]).sum(axis=2)                                  # occurrences of each entry
+    return r[np.arange(len(r)), cnt.argmax(axis=1)].astype(np.int32)                    # argmax: first maximum
+
+
 class InteractionComplex:
     def __init__(self, filename, vdw_comp=0.1, interacting=5.0, ph=7.4, device=0):
         """Args mirror I:37.  ``filename``: a PackedComplex or the path of a packed ``.npz``."""
@@ -114,6 +122,8 @@ class InteractionComplex:
                 pc.ring_res, self.ring_residue_shortest_distance = ctx.ring_residues(pc.ring_center)
         if pc.n_amides and (pc.amide_atoms[:, :3] >= 0).all():
             pc.amide_center, pc.amide_normal = ctx.amide_geometry(pc.amide_atoms)
+            if (pc.amide_atoms >= 0).all():
+                pc.amide_res = amide_majority_residue(pc.res_id, pc.amide_atoms)
         ctx.set_complex(pc)
 
     def run_arpeggio(self, user_selections, interacting_cutoff, vdw_comp, include_sequence_adjacent):

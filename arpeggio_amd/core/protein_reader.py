@@ -270,16 +270,102 @@ def polypeptide_bookkeeping(polypeptides):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# what gemmi does to the table before the reference reads it (recalled: gemmi is not in the image)
+# ---------------------------------------------------------------------------------------------------------------------
+def gemmi_normalised(atom_sites):
+    """The reference reads ``gemmi.read_structure(path, merge_chain_parts=True)`` -> first model -> ``make_mmcif_block``
+    (P:61-68, 272-277), not the file's own table.  Restated here on the columns: (1) rows of the first model only; (2) the
+    parts of a chain (polymer, ligands, waters: same auth_asym_id, apart in the file) follow each other — chains in the
+    order of their first row, rows of a chain in file order; (3) coordinates re-written with three decimals
+    (``%.3f``, then parsed again)."""
+    n = len(atom_sites['id'])
+    models = atom_sites['pdbx_PDB_model_num']
+    keep = [i for i in range(n) if models[i] == models[0]]
+    first = {}
+    for i in keep:
+        first.setdefault(atom_sites['auth_asym_id'][i], len(first))
+    order = sorted(keep, key=lambda i: (first[atom_sites['auth_asym_id'][i]], i))
+    out = {k: [v[i] for i in order] for k, v in atom_sites.items()}
+    for k in ('Cartn_x', 'Cartn_y', 'Cartn_z'):
+        out[k] = ['%.3f' % float(v) for v in out[k]]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# _struct_conn -> bonds (P:139-212)
+# ---------------------------------------------------------------------------------------------------------------------
+def struct_conn_pairs(atom_sites, struct_conn):
+    """``parse_struct_conn_bonds`` / ``__process_struct_conn`` (P:139-194): for every row of ``_struct_conn`` — whatever its
+    conn_type_id — the ``_atom_site.id`` of the FIRST row that has partner 1's (auth_asym_id, auth_seq_id, label_atom_id)
+    and the same for partner 2 (strings compared as they stand; alternative locations and insertion codes are not
+    looked at); rows with a partner that is not found are dropped.  Returns the list of (id_a, id_b)."""
+    lookup = {}
+    for i in range(len(atom_sites['id'])):
+        lookup.setdefault((atom_sites['auth_asym_id'][i], atom_sites['auth_seq_id'][i], atom_sites['label_atom_id'][i]), int(atom_sites['id'][i]))
+    pairs = []
+    pivot = next(iter(struct_conn))
+    for k in range(len(struct_conn[pivot])):
+        a = lookup.get((struct_conn['ptnr1_auth_asym_id'][k], struct_conn['ptnr1_auth_seq_id'][k], struct_conn['ptnr1_label_atom_id'][k]), 0)
+        b = lookup.get((struct_conn['ptnr2_auth_asym_id'][k], struct_conn['ptnr2_auth_seq_id'][k], struct_conn['ptnr2_label_atom_id'][k]), 0)
+        if a != 0 and b != 0:
+            pairs.append((a, b))
+    return pairs
+
+
+def add_bonds(neighbours, pairs):
+    """``__add_bond_to_openbabel`` (P:197-212) on adjacency lists {atom id: [neighbour ids]}: a bond that exists already
+    (in either direction: OBAtomAtomIter walks both) is not added again; a new one is appended to both atoms' lists."""
+    for a, b in pairs:
+        if b in neighbours.setdefault(a, []):
+            continue
+        neighbours[a].append(b)
+        neighbours.setdefault(b, []).append(a)
+    return neighbours
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# explicit hydrogens of a hydrogenated file -> h_coords of their heavy atom (I:1513-1529)
+# ---------------------------------------------------------------------------------------------------------------------
+def attach_hydrogens(xyz64, is_h, res_id, max_dist=1.3):
+    """The reference finds the hydrogens of an atom through OpenBabel's bond graph (ConnectTheDots, I:1521-1529).  Without
+    OpenBabel: a hydrogen belongs to the nearest non-hydrogen atom of its own residue within ``max_dist`` A (any residue
+    when its own has none) — for a file hydrogenated at standard bond lengths (X-H <= 1.1 A) the same parent.
+    Returns parent index per atom (-1: not a hydrogen / no parent)."""
+    n = len(xyz64)
+    parent = np.full(n, -1, np.int64)
+    heavy = np.nonzero(~is_h)[0]
+    if not len(heavy) or not is_h.any():
+        return parent
+    from scipy.spatial import cKDTree
+    tree = cKDTree(xyz64[heavy])
+    for h in np.nonzero(is_h)[0]:
+        near = tree.query_ball_point(xyz64[h], max_dist)
+        if not near:
+            continue
+        cand = heavy[np.array(near)]
+        d = np.linalg.norm(xyz64[cand] - xyz64[h], axis=1)
+        same = res_id[cand] == res_id[h]
+        pick = np.where(same)[0] if same.any() else np.arange(len(cand))
+        parent[h] = cand[pick[np.argmin(d[pick])]]
+    return parent
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # file -> PackedComplex
 # ---------------------------------------------------------------------------------------------------------------------
-def read_mmcif(path, use_ambiguities=False):
-    """The atom / residue part of ``initialize()``'s result for an mmCIF file: see the module docstring for what is and
-    what is not there (``pc.incomplete``)."""
+def read_mmcif(path, use_ambiguities=False, normalise=True):
+    """``initialize()``'s result for an mmCIF file as far as the file alone goes (see the module docstring and
+    ``pc.incomplete``): atoms, residues, polypeptide links, table types and radii; bonds from ``_struct_conn``, the peptide
+    bonds of the polypeptides and the X-H bonds of explicit hydrogens; the hydrogens' coordinates on their heavy atoms.
+    ``normalise``: apply what gemmi does to the table first (``gemmi_normalised``)."""
     text = _read_text(path)
     cat = _category(text, '_atom_site.')
     if cat.rows == 0:
         raise ValueError('The cif file does not contain _atom_site record')           # P:285-287
-    chains = build_structure(structure_events(cat.columns()))
+    cols = cat.columns()
+    if normalise:
+        cols = gemmi_normalised(cols)
+    chains = build_structure(structure_events(cols))
     links = polypeptide_bookkeeping(build_peptides(chains))
     residues = [r for _, rs in chains for r in rs]
     res_index = {id(r): k for k, r in enumerate(residues)}
@@ -304,10 +390,50 @@ def read_mmcif(path, use_ambiguities=False):
         comp = component_types_from_columns(_category(text, '_chem_comp.').columns())
     except (KeyError, ValueError):
         comp = {}
+    # ---- bonds the file itself gives: _struct_conn (P:124-131), the C-N bonds of the polypeptides, X-H of explicit hydrogens
+    by_serial = {int(a.serial): k for k, a in enumerate(atoms)}
+    # OpenBabel's copy of an atom holds the coordinate TEXT as float64 (P:231-235); BioPython's holds float32
+    xyz64 = np.zeros((n, 3))
+    text_xyz = {int(cols['id'][i]): (float(cols['Cartn_x'][i]), float(cols['Cartn_y'][i]), float(cols['Cartn_z'][i])) for i in range(len(cols['id']))}
+    for k, a in enumerate(atoms):
+        xyz64[k] = text_xyz[int(a.serial)]
+    neighbours = {}
+    try:
+        sc = _category(text, '_struct_conn.')
+        if sc.rows:
+            pairs = [(by_serial[a], by_serial[b]) for a, b in struct_conn_pairs(cols, sc.columns()) if a in by_serial and b in by_serial]
+            add_bonds(neighbours, pairs)
+    except KeyError:
+        pass
+    atom_index = {id(a): k for k, a in enumerate(atoms)}
+    pep = []                                                          # peptide bonds: C of a residue - N of its successor in the polypeptide
+    for k, r in enumerate(residues):
+        if res_next[k] >= 0:
+            c_, n_ = r.by_name.get('C'), residues[res_next[k]].by_name.get('N')
+            if c_ is not None and n_ is not None:
+                pep.append((atom_index[id(c_)], atom_index[id(n_)]))
+    add_bonds(neighbours, pep)
+    is_h = np.array([e in ('H', 'D') for e in element], bool) if n else np.zeros(0, bool)
+    parent = attach_hydrogens(xyz64, is_h, res_id)
+    add_bonds(neighbours, [(int(p_), int(h_)) for h_, p_ in enumerate(parent) if p_ >= 0])
+    bond_off = np.zeros(n + 1, np.int32)
+    for k in range(n):
+        bond_off[k + 1] = bond_off[k] + len(neighbours.get(k, ()))
+    bond_idx = np.array([b for k in range(n) for b in neighbours.get(k, ())], np.int32)
+    h_lists = [[] for _ in range(n)]
+    for h_, p_ in enumerate(parent):
+        if p_ >= 0:
+            h_lists[p_].append(h_)
+    h_off = np.zeros(n + 1, np.int32)
+    for k in range(n):
+        h_off[k + 1] = h_off[k] + len(h_lists[k])
+    h_xyz = np.array([xyz64[h_] for k in range(n) for h_ in h_lists[k]], np.float64).reshape(-1, 3)
+    from .packed import single_bond_neighbours
+    sb_nbr = single_bond_neighbours(bond_off, bond_idx, np.ones(len(bond_idx), np.int32), np.zeros(len(bond_idx), np.int32), is_h)
     pc = PackedComplex(
         xyz=np.array([a.coord for a in atoms], np.float32).reshape(-1, 3), vdw=vdw, cov=cov, type_mask=np.zeros(n, np.uint16), flags=flags,
-        res_id=res_id, res_flags=res_flags, res_prev=res_prev, res_next=res_next, bond_off=np.zeros(n + 1, np.int32),
-        bond_idx=np.zeros(0, np.int32), h_off=np.zeros(n + 1, np.int32), h_xyz=np.zeros((0, 3)), sb_nbr=np.full(n, -1, np.int32),
+        res_id=res_id, res_flags=res_flags, res_prev=res_prev, res_next=res_next, bond_off=bond_off,
+        bond_idx=bond_idx, h_off=h_off, h_xyz=h_xyz, sb_nbr=sb_nbr,
         ring_center=np.zeros((0, 3)), ring_normal=np.zeros((0, 3)), ring_res=np.zeros(0, np.int32),
         amide_center=np.zeros((0, 3), np.float32), amide_normal=np.zeros((0, 3), np.float32), amide_res=np.zeros(0, np.int32),
         id=os.path.basename(path).split('.')[0])
@@ -321,5 +447,9 @@ def read_mmcif(path, use_ambiguities=False):
     pc.res_het = [r.het for r in residues]
     pc.component_types = comp
     pc.type_mask = typing.apply_protein_typing(pc, use_ambiguities=use_ambiguities)
-    pc.incomplete = ('bonds', 'hydrogen coordinates', 'ligand atom types', 'rings', 'amides')
+    # what only OpenBabel can add: bonds INSIDE residues (residue templates / ConnectTheDots: they matter for the single-bond
+    # neighbour of halogens and for hydrogens further than 1.3 A from any atom — pairs inside a residue are never contacts,
+    # I:729), hydrogens of a file that has none (AddHydrogens), SMARTS types of non-standard residues, rings, amides
+    pc.incomplete = ('bonds inside residues', 'added hydrogens', 'ligand atom types', 'rings', 'amides')
+    pc.hydrogen_parent = parent
     return pc

@@ -135,7 +135,7 @@ def test_read_mmcif_end_to_end(golden, tmp_path):
     assert not pc.type_mask[lig].any()
     o = [i for i in range(pc.n_atoms) if pc.atom_name[i] == 'O' and pc.res_name[pc.res_id[i]] == 'GLY']
     assert o and all(pc.type_mask[i] & config.ATOM_TYPE_BIT['hbond acceptor'] for i in o)
-    assert {k: pc.component_types[k] for k in case['component_types']} == case['component_types'] and 'bonds' in pc.incomplete
+    assert {k: pc.component_types[k] for k in case['component_types']} == case['component_types'] and 'bonds inside residues' in pc.incomplete
     with pytest.raises(ValueError, match='_atom_site'):
         q = tmp_path / 'empty.cif'
         q.write_text('data_x\n_entry.id x\n')
@@ -165,3 +165,111 @@ def test_read_mmcif_structure_runs_on_the_gpu(golden, tmp_path):
     assert np.array_equal(got['dist'].view(np.uint32), exp['dist'].view(np.uint32))
     names = {r['bgn']['auth_atom_id'] for r in recs} | {r['end']['auth_atom_id'] for r in recs}
     assert names & {"O5'", "C1'", 'N 1', 'C"2', 'PA', 'FE'}
+
+
+# ---- _struct_conn, explicit hydrogens, gemmi's normalisation (round 3) ----------------------------------------------------
+@pytest.fixture(scope='module')
+def conn(golden_dir):
+    return json.load(open(os.path.join(golden_dir, 'struct_conn.json')))
+
+
+def test_struct_conn_bonds_equal_the_executed_reference(conn, tmp_path):
+    """parse_struct_conn_bonds / __process_struct_conn / __add_bond_to_openbabel (P:139-212), executed on holders
+    (tests/golden/make_golden_struct_conn.py), against struct_conn_pairs + add_bonds — and against the bond graph of the
+    pack read_mmcif builds from the same text."""
+    for case in conn:
+        pairs = protein_reader.struct_conn_pairs(case['atom_site'], case['struct_conn'])
+        nb = {}
+        protein_reader.add_bonds(nb, [tuple(b) for b in case['existing_bonds']])
+        protein_reader.add_bonds(nb, pairs)
+        assert {str(k): v for k, v in nb.items() if v} == case['neighbours']
+        # through the file: every bond the reference added is in the pack's bond graph (ids -> packed indices by serial)
+        p = tmp_path / 'conn.cif'
+        p.write_text(case['text'])
+        pc = protein_reader.read_mmcif(str(p))
+        idx = {int(s): k for k, s in enumerate(pc.serial.tolist())}
+        for a, b, order in case['new_bonds']:
+            if a in idx and b in idx:          # (the B child of an alternative location is not an atom of the pack)
+                ia, ib = idx[a], idx[b]
+                assert ib in pc.bond_idx[pc.bond_off[ia]:pc.bond_off[ia + 1]] and ia in pc.bond_idx[pc.bond_off[ib]:pc.bond_off[ib + 1]]
+        assert 'bonds inside residues' in pc.incomplete and 'bonds' not in pc.incomplete
+
+
+def _cif_of(pc, decimals=3, split_chain=False):
+    """mmCIF text of a PackedComplex (explicit hydrogens are atoms of the pack)."""
+    pc.ensure_labels()
+    head = ['group_PDB', 'id', 'type_symbol', 'label_atom_id', 'label_alt_id', 'label_comp_id', 'label_asym_id', 'label_entity_id',
+            'label_seq_id', 'pdbx_PDB_ins_code', 'Cartn_x', 'Cartn_y', 'Cartn_z', 'occupancy', 'B_iso_or_equiv', 'auth_seq_id',
+            'auth_asym_id', 'pdbx_PDB_model_num']
+    rows = []
+    for i in range(pc.n_atoms):
+        r = int(pc.res_id[i])
+        het = pc.res_name[r] in ('HOH', 'HEM')
+        name = pc.atom_name[i]
+        q = '"' + name + '"' if "'" in name else name
+        rows.append((r, ['HETATM' if het else 'ATOM', str(i + 1), pc.element[i].upper(), q, '.', pc.res_name[r], pc.res_chain[r], '1',
+                         str(int(pc.res_seq[r])), '?'] + [f'%.{decimals}f' % float(v) for v in pc.xyz[i].astype(np.float64)] +
+                     ['1.00', '10.00', str(int(pc.res_seq[r])), pc.res_chain[r], '1']))
+    if split_chain:      # hetero groups of a chain after the polymers of ALL chains, as deposited files have them
+        rows = [x for x in rows if x[1][0] == 'ATOM'] + [x for x in rows if x[1][0] != 'ATOM']
+    return 'data_synth\n_entry.id SYNTH\nloop_\n' + ''.join('_atom_site.' + h + '\n' for h in head) + ''.join(' '.join(x[1]) + '\n' for x in rows)
+
+
+def test_explicit_hydrogens_are_attached_to_their_heavy_atom(tmp_path):
+    from arpeggio_amd import synth
+    pc0 = synth.proteinlike(n_res=40, seed=21, n_waters=10)
+    p = tmp_path / 'synth_h.cif'
+    p.write_text(_cif_of(pc0))
+    pc = protein_reader.read_mmcif(str(p))
+    assert pc.n_atoms == pc0.n_atoms and np.array_equal(pc.xyz, np.round(pc0.xyz.astype(np.float64), 3).astype(np.float32))
+    is_h = (pc.flags & config.F_HYDROGEN) != 0
+    assert is_h.sum() == ((pc0.flags & config.F_HYDROGEN) != 0).sum() > 100
+    # the generator's own parent of every hydrogen: the atom whose h_xyz list holds it (built from bonds in synth.proteinlike)
+    want = np.full(pc0.n_atoms, -1)
+    hx = pc0.h_xyz.reshape(-1, 3)
+    hpos = {tuple(np.round(pc0.xyz[h].astype(np.float64), 3)): h for h in np.nonzero(is_h)[0]}
+    for a in range(pc0.n_atoms):
+        for k in range(pc0.h_off[a], pc0.h_off[a + 1]):
+            h = hpos.get(tuple(np.round(hx[k], 3)))
+            if h is not None:
+                want[h] = a
+    known = want >= 0
+    # (the synthetic chain is not physical: a hydrogen placed 1.0 A from its parent can lie nearer to another atom — keep the
+    # hydrogens whose parent is also their nearest heavy atom, as in a real hydrogenated file)
+    x64 = pc0.xyz.astype(np.float64)
+    heavy = np.nonzero(~is_h)[0]
+    for h in np.nonzero(known)[0]:
+        d = np.linalg.norm(x64[heavy] - x64[h], axis=1)
+        if heavy[np.argmin(d)] != want[h]:
+            known[h] = False
+    assert known.sum() > 0.7 * is_h.sum() and np.array_equal(pc.hydrogen_parent[known], want[known])
+    # h_coords are the float64 of the coordinate text (I:1527: OpenBabel's GetX / GetY / GetZ)
+    for a in np.nonzero(np.diff(pc.h_off))[0][:50]:
+        hs = np.nonzero(pc.hydrogen_parent == a)[0]
+        got = pc.h_xyz[pc.h_off[a]:pc.h_off[a + 1]]
+        exp = np.array([[float('%.3f' % v) for v in pc0.xyz[h].astype(np.float64)] for h in hs])
+        assert np.array_equal(got, exp)
+    assert 'hydrogen coordinates' not in pc.incomplete and 'added hydrogens' in pc.incomplete
+    pc.validate()
+
+
+def test_gemmi_normalisation_of_the_table(tmp_path):
+    """merge_chain_parts (a chain's hetero groups follow its polymer), first model only, three-decimal coordinates."""
+    from arpeggio_amd import synth
+    pc0 = synth.proteinlike(n_res=30, seed=22, n_waters=6)
+    pc0.ensure_labels()
+    half = pc0.n_residues // 2
+    pc0.res_chain = ['A' if r < half else 'B' for r in range(pc0.n_residues)]
+    p = tmp_path / 'split.cif'
+    p.write_text(_cif_of(pc0, decimals=5, split_chain=True))
+    pc = protein_reader.read_mmcif(str(p))
+    chains = [pc.res_chain[r] for r in pc.res_id]
+    assert chains == sorted(chains)                                   # A's polymer, A's hetero groups, then B's: contiguous
+    raw = protein_reader.read_mmcif(str(p), normalise=False)          # (BioPython's builder re-opens chain A for its hetero groups:
+    assert [raw.res_chain[r] for r in raw.res_id] == chains           #  the hierarchy has the same order either way)
+    assert not np.array_equal(raw.xyz, pc.xyz)                        # ... but the raw table keeps five decimals
+    # %.3f of the five-decimal text
+    by_serial = {int(s): k for k, s in enumerate(pc.serial.tolist())}
+    for i in range(0, pc0.n_atoms, 37):
+        want = np.array([float('%.3f' % float('%.5f' % v)) for v in pc0.xyz[i].astype(np.float64)], np.float32)
+        assert np.array_equal(pc.xyz[by_serial[i + 1]], want)
