@@ -34,6 +34,24 @@ AtomAtomContact = collections.namedtuple('AtomAtomContact', ['bgn_atom', 'end_at
 Parameters = collections.namedtuple('Parameters', ['vdw_comp_factor', 'interacting_threshold', 'has_hydrogens', 'ph'])
 
 
+def ring_path_order(atoms, adj):
+    """The atoms of one ring re-ordered so that consecutive ones (and the last and the first) are bonded: a walk over the
+    bond graph ``adj`` (list of neighbour lists by packed index) restricted to the ring's atoms, from its first atom.
+    Left as it is when the atoms do not form a single cycle in ``adj``."""
+    atoms = [int(a) for a in atoms]
+    members = set(atoms)
+    path, seen = [atoms[0]], {atoms[0]}
+    while len(path) < len(atoms):
+        nxt = [b for b in adj[path[-1]] if b in members and b not in seen]
+        if not nxt:
+            return np.array(atoms, np.int32)
+        path.append(int(nxt[0]))
+        seen.add(path[-1])
+    if path[0] not in adj[path[-1]]:
+        return np.array(atoms, np.int32)
+    return np.array(path, np.int32)
+
+
 def amide_majority_residue(res_id, amide_atoms):
     """I:1554-1559: the residue of an amide group = ``max(residues, key=residues.count)`` over its four atoms N, C, O,
     C-alpha — the most frequent one, the FIRST such in that order on a tie."""
@@ -389,13 +407,13 @@ def residue_plane_sifts(pc, bags):
     return out
 
 
-def pack_from_reference_objects(ic):
-    """Build a PackedComplex from a *reference* ``arpeggio.core.InteractionComplex`` on which
-    ``initialize()`` has run (needs BioPython + OpenBabel, so it cannot be exercised in this
-    repository's environment; it documents the mapping of I:54-60, 1494-1529, 1591-1733,
-    1531-1589, 1923-1991 onto the packed arrays).
-    """
-    from openbabel import openbabel as ob  # noqa: F401  (import-guard: reference environment only)
+def pack_from_reference_objects(ic, ob=None):
+    """Build a PackedComplex from a *reference* ``arpeggio.core.InteractionComplex`` on which ``initialize()`` has run:
+    the mapping of I:54-60, 1494-1529, 1591-1733, 1531-1589, 1923-1991 onto the packed arrays.  ``ob``: the OpenBabel
+    module (``from openbabel import openbabel``, imported here when not given; the tests pass the iterator holders of
+    tests/golden/make_golden_core.py — neither BioPython nor OpenBabel is in this repository's image)."""
+    if ob is None:
+        from openbabel import openbabel as ob
     atoms = list(ic.s_atoms)
     index = {a: i for i, a in enumerate(atoms)}
     residues, res_index = [], {}
@@ -460,7 +478,9 @@ def pack_from_reference_objects(ic):
         ring_center=np.array([rings[k]['center'] for k in rkeys], np.float64).reshape(-1, 3),
         ring_normal=np.array([rings[k]['normal'] for k in rkeys], np.float64).reshape(-1, 3),
         ring_res=[res_index[id(rings[k]['residue'])] if rings[k].get('residue') is not None else -1 for k in rkeys],
-        ring_atoms=[np.array([index[a] for a in rings[k]['atoms']], np.int32) for k in rkeys],
+        # (the reference lists a ring's atoms in molecule order, I:1728-1733; the pack holds the ring PATH, which is what a
+        # ring normal is computed along: consecutive atoms bonded)
+        ring_atoms=[ring_path_order(np.array([index[a] for a in rings[k]['atoms']], np.int32), adj) for k in rkeys],
         amide_center=np.array([amides[k]['center'] for k in akeys], np.float32).reshape(-1, 3),
         amide_normal=np.array([amides[k]['normal'] for k in akeys], np.float32).reshape(-1, 3),
         amide_res=[res_index[id(amides[k]['residue'])] for k in akeys],

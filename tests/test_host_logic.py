@@ -328,3 +328,61 @@ def test_contact_table_writer_equals_the_csv_module(tmp_path):
         export.write_contact_file(a, pc, lab, bag, rows)
         export.write_contact_file_csv_module(b, pc, lab, bag, rows)
         assert open(a, 'rb').read() == open(b, 'rb').read(), tag
+
+
+def test_pack_from_reference_objects_round_trip():
+    """A PackedComplex -> objects shaped like the reference's InteractionComplex after initialize() (the data holders the
+    golden fixtures are made with) -> pack_from_reference_objects: the same arrays come back; rings listed in molecule
+    order (as I:1728-1733 stores them) are returned in ring-path order."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import types
+    import make_golden_core as G
+    from arpeggio_amd.core.interactions import pack_from_reference_objects
+    pc = synth.proteinlike(n_res=60, seed=9, n_waters=12)
+    pc.ensure_labels()
+    chains, residues = {}, []
+    for r in range(pc.n_residues):
+        chains.setdefault(pc.res_chain[r], G.Chain(pc.res_chain[r]))
+        residues.append(G.Residue(r, chains[pc.res_chain[r]], pc.res_name[r], ' ', int(pc.res_seq[r]), pc.res_icode[r]))
+    names = config.ATOM_TYPE_NAMES
+    atoms = []
+    for i in range(pc.n_atoms):
+        f = int(pc.flags[i])
+        a = G.Atom(i, residues[int(pc.res_id[i])], pc.atom_name[i], pc.element[i], pc.xyz[i].copy(), int(pc.serial[i]), bool(f & config.F_WATER))
+        a.atom_types = {names[b] for b in range(12) if (int(pc.type_mask[i]) >> b) & 1}
+        a.is_metal, a.is_halogen = bool(f & config.F_METAL), bool(f & config.F_HALOGEN)
+        a.vdw_radius, a.cov_radius = float(pc.vdw[i]), float(pc.cov[i])
+        a.h_coords = [np.array(pc.h_xyz[k], np.float64) for k in range(pc.h_off[i], pc.h_off[i + 1])]
+        atoms.append(a)
+    obatoms = [G.OBAtom(1000 + i, 1 if (int(pc.flags[i]) & config.F_HYDROGEN) else 6) for i in range(pc.n_atoms)]
+    for i in range(pc.n_atoms):
+        me = obatoms[i]
+        for k in range(pc.bond_off[i], pc.bond_off[i + 1]):
+            me.nbrs.append(obatoms[int(pc.bond_idx[k])])
+        me.bonds = [G.OBBond(me, G.OBAtom(-1, 6), 2, False), G.OBBond(me, G.OBAtom(-2, 1), 1, False)]      # decoys: double bond, hydrogen
+        if pc.sb_nbr[i] >= 0:
+            me.bonds.append(G.OBBond(me, obatoms[int(pc.sb_nbr[i])], 1, False))
+    for r in range(pc.n_residues):
+        if int(pc.res_flags[r]) & config.R_POLYPEPTIDE:
+            residues[r].is_polypeptide = True
+        if int(pc.res_flags[r]) & config.R_HAS_SEQ:
+            residues[r].prev_residue = residues[pc.res_prev[r]] if pc.res_prev[r] >= 0 else None
+            residues[r].next_residue = residues[pc.res_next[r]] if pc.res_next[r] >= 0 else None
+    st = G.Structure(residues)
+    for r in range(pc.n_rings):      # molecule order = ascending atom index, as OBMolAtomIter delivers the members
+        st.rings[r] = {'ring_id': r, 'center': pc.ring_center[r].copy(), 'normal': pc.ring_normal[r].copy(),
+                       'atoms': [atoms[int(k)] for k in sorted(pc.ring_atoms[r].tolist())], 'residue': residues[int(pc.ring_res[r])] if pc.ring_res[r] >= 0 else None}
+    for e in range(pc.n_amides):
+        st.amides[e] = {'amide_id': e, 'center': pc.amide_center[e].copy(), 'normal': pc.amide_normal[e].copy(),
+                        'atoms': [atoms[int(k)] for k in pc.amide_atoms[e]], 'residue': residues[int(pc.amide_res[e])]}
+    ic = types.SimpleNamespace(id=pc.id, s_atoms=atoms, biopython_str=st, ob_mol=G.OBMol({a.oid: a for a in obatoms}),
+                               bio_to_ob={a: obatoms[a.idx].oid for a in atoms}, ob_to_bio={obatoms[a.idx].oid: a for a in atoms},
+                               component_types=dict(pc.component_types))
+    back = pack_from_reference_objects(ic, ob=G.ob)
+    for k in ('xyz', 'vdw', 'cov', 'type_mask', 'flags', 'res_id', 'res_flags', 'res_prev', 'res_next', 'bond_off', 'bond_idx', 'h_off',
+              'h_xyz', 'sb_nbr', 'ring_center', 'ring_normal', 'ring_res', 'amide_center', 'amide_normal', 'amide_res', 'amide_atoms'):
+        assert np.array_equal(getattr(back, k), getattr(pc, k)), k
+    assert back.n_rings > 0 and not back.rings_not_in_path_order()
+    for a, b in zip(back.ring_atoms, pc.ring_atoms):
+        assert sorted(a.tolist()) == sorted(b.tolist())
