@@ -86,7 +86,7 @@ def load():
     L.arp_records_size.argtypes = [i64] * 5
     L.arp_records_size.restype = C.c_uint64
     L.arp_records_layout.argtypes = [vp, C.c_uint64] + [i64] * 5
-    L.arp_records_fill.argtypes = [vp, C.c_uint64, i64] + [vp] * 24
+    L.arp_records_fill.argtypes = [vp, C.c_uint64, i64, i64, i64, i64] + [vp] * 24
     L.arp_shard_set_home.argtypes = [vp, vp, C.c_uint64]
     L.arp_shard_pack_face.argtypes = [vp, i32, dbl, dbl, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.arp_shard_assemble.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, i64, vp]
@@ -307,7 +307,7 @@ def pack_records_native(pc, atom_ids, ring_ids, amide_ids, sel=None, pinned=True
               c(pc.bond_idx, np.int32), h_off, c(pc.h_xyz, np.float64), c(pc.sb_nbr, np.int32), c(pc.ring_center, np.float64),
               c(pc.ring_normal, np.float64), c(pc.ring_res, np.int32), c(pc.amide_center, np.float32), c(pc.amide_normal, np.float32),
               c(pc.amide_res, np.int32), (None if sel is None else c(sel, np.uint8)), a, r, m]
-    if L.arp_records_fill(_p(buf), size, pc.n_atoms, *[_p(x) for x in arrays]) != ARP_OK:
+    if L.arp_records_fill(_p(buf), size, pc.n_atoms, pc.n_residues, pc.n_rings, pc.n_amides, *[_p(x) for x in arrays]) != ARP_OK:
         raise ValueError('arp_records_fill failed (ids must ascend and lie inside the structure)')
     return buf
 

@@ -14,6 +14,7 @@ packed atom / residue order.
 from __future__ import annotations
 
 import csv
+import logging
 import os
 
 import numpy as np
@@ -364,7 +365,13 @@ def potential_counts(pc):
     bound hydrogens.  Python numbers, int or float exactly as the reference's arithmetic yields them."""
     T = config.ATOM_TYPE_BIT
     nh = np.diff(pc.h_off).tolist()
-    lone = pc.lone_pair_electrons.tolist()
+    if pc.lone_pair_electrons is None:
+        if (pc.type_mask & T['hbond acceptor']).any():
+            logging.warning('potential hbond / polar counts: the pack carries no lone_pair_electrons (OpenBabel valence data, I:1804); '
+                            'acceptors are counted with 0 lone pairs')
+        lone = [0] * pc.n_atoms
+    else:
+        lone = pc.lone_pair_electrons.tolist()
     out = []
     for m, h, lp in zip(pc.type_mask.tolist(), nh, lone):
         v = 0

@@ -85,6 +85,10 @@ class PackedComplex:
     # ---- config.VALENCE[atomic_number] - atom.bond_order - atom.formal_charge (interactions.py:1804): what the
     #      potential hbond / polar counts of acceptors are made of (write_polar_matching only) ----
     lone_pair_electrons: Optional[np.ndarray] = None   # i32 [N]
+    # ---- the SMARTS types of every atom with the four ambiguous patterns struck (address_ambiguities, I:120-133: 'NH2
+    #      terminal amide' as hbond / xbond / weak hbond acceptor, 'oxygen amide term' as hbond donor); produced by the packer
+    #      where OpenBabel is available; None: unknown ----
+    type_mask_ambiguities: Optional[np.ndarray] = None   # u16 [N]
     id: str = 'packed'
 
     def __post_init__(self):
@@ -200,9 +204,10 @@ class PackedComplex:
             self.serial = np.arange(1, n + 1, dtype=np.int32)
         if self.component_types is None:
             self.component_types = {}
-        if self.lone_pair_electrons is None:
-            self.lone_pair_electrons = np.zeros(n, np.int32)
-        self.lone_pair_electrons = _arr(self.lone_pair_electrons, np.int32)
+        if self.lone_pair_electrons is not None:      # (None stays None: the polar-matching writer says so instead of writing zeros)
+            self.lone_pair_electrons = _arr(self.lone_pair_electrons, np.int32)
+        if self.type_mask_ambiguities is not None:
+            self.type_mask_ambiguities = _arr(self.type_mask_ambiguities, np.uint16)
         for rn in set(self.res_name):
             self.component_types.setdefault(rn, 'P')
         return self
@@ -220,7 +225,9 @@ class PackedComplex:
     def to_arrays(self, prefix=''):
         """Every field as a NumPy array under ``prefix + name`` (what ``save`` writes)."""
         self.ensure_labels()
-        d = {prefix + k: getattr(self, k) for k in self._ARRAYS}
+        d = {prefix + k: getattr(self, k) for k in self._ARRAYS if getattr(self, k) is not None}
+        if self.type_mask_ambiguities is not None:
+            d[prefix + 'type_mask_ambiguities'] = self.type_mask_ambiguities
         for k in self._LISTS:
             d[prefix + k] = np.array(getattr(self, k), dtype=np.str_)
         ro = np.concatenate([[0], np.cumsum([len(a) for a in self.ring_atoms])]).astype(np.int32) if self.ring_atoms \
@@ -235,7 +242,7 @@ class PackedComplex:
 
     @classmethod
     def from_arrays(cls, z, prefix=''):
-        kw = {k: z[prefix + k] for k in cls._ARRAYS if (prefix + k) in z}
+        kw = {k: z[prefix + k] for k in cls._ARRAYS + ('type_mask_ambiguities',) if (prefix + k) in z}
         for k in cls._LISTS:
             kw[k] = [str(x) for x in z[prefix + k]]
         ro, ri = z[prefix + 'ring_atoms_off'], z[prefix + 'ring_atoms_idx']

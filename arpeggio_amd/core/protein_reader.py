@@ -450,6 +450,7 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
     # what only OpenBabel can add: bonds INSIDE residues (residue templates / ConnectTheDots: they matter for the single-bond
     # neighbour of halogens and for hydrogens further than 1.3 A from any atom — pairs inside a residue are never contacts,
     # I:729), hydrogens of a file that has none (AddHydrogens), SMARTS types of non-standard residues, rings, amides
-    pc.incomplete = ('bonds inside residues', 'added hydrogens', 'ligand atom types', 'rings', 'amides')
+    # ... and the element radii: OpenBabel's table restated from memory in core/typing.py, not verified against an OpenBabel build
+    pc.incomplete = ('bonds inside residues', 'added hydrogens', 'ligand atom types', 'rings', 'amides', 'element radii unverified')
     pc.hydrogen_parent = parent
     return pc

@@ -63,6 +63,23 @@ def apply_protein_typing(pc, use_ambiguities=False, waters=True):
     masks = key_masks(use_ambiguities)
     covered = np.uint16(table_type_mask())
     out = pc.type_mask.copy()
+    if use_ambiguities:
+        # I:124-127: the four ambiguous SMARTS patterns are struck as well, which changes the types of ligand / hetero
+        # atoms.  Their matches are OpenBabel's: a pack made where it is available carries the re-typed masks.
+        alt = getattr(pc, 'type_mask_ambiguities', None)
+        if alt is not None:
+            out = np.asarray(alt, np.uint16).copy()
+        else:
+            t_ = table()
+            nonstd = np.array([rn not in set(t_['std_res']) for rn in pc.res_name], bool)[pc.res_id]
+            affected = np.uint16(config.ATOM_TYPE_BIT['hbond acceptor'] | config.ATOM_TYPE_BIT['hbond donor'] |
+                                 config.ATOM_TYPE_BIT['xbond acceptor'] | config.ATOM_TYPE_BIT['weak hbond acceptor'])
+            water = (pc.flags & config.F_WATER) != 0
+            k = int((nonstd & ~water & ((pc.type_mask & affected) != 0)).sum())
+            if k:
+                import logging
+                logging.warning('address_ambiguities: %d atoms of non-standard residues keep the SMARTS types they were packed with '
+                                '(the pack has no type_mask_ambiguities: terminal-amide N / O of ligands are typed as without -a)', k)
     if waters:      # interactions.py:1953-1956 (before the dictionary override, so a standard residue flagged W loses them again)
         w = (pc.flags & config.F_WATER) != 0
         out[w] |= np.uint16(config.ATOM_TYPE_BIT['hbond acceptor'] | config.ATOM_TYPE_BIT['hbond donor'])

@@ -642,12 +642,16 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
                 Prof p(c, SLOT_SCAN, st);
                 const int ntiles = (ncell + TILE_CELLS - 1) / TILE_CELLS;
                 static const int chained = env_int("ARP_CHAINED_SCAN", 1);
-                if (chained && ntiles <= CHAIN_TILES) {   // one launch: the tiles hand their totals on themselves
+                if (chained && ntiles <= CHAIN_TILES && ntiles <= 2 * c->num_cu) {   // one launch: the tiles hand their totals on themselves (all resident at once)
                     bool fresh = false;
                     HIPCHK(c, G.chain.reserve(CHAIN_TILES, &fresh));
-                    if (fresh) { HIPCHK(c, hipMemsetAsync(G.chain.p, 0, G.chain.cap * sizeof(unsigned long long), st)); G.chain_epoch = 0; }
-                    if (++G.chain_epoch == 0) ++G.chain_epoch;
-                    hipLaunchKernelGGL(k_scan_tiles_chained, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.chain.p, G.chain_epoch, total_out);
+                    if (fresh || G.chain_epoch == 0xFFFFFFFFu) {   // new buffer, or the launch number wraps: no stale word may match a future one
+                        HIPCHK(c, hipMemsetAsync(G.chain.p, 0, G.chain.cap * sizeof(unsigned long long), st));
+                        G.chain_epoch = 0;
+                    }
+                    ++G.chain_epoch;
+                    hipLaunchKernelGGL(k_scan_tiles_chained, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.chain.p, G.chain_epoch, total_out,
+                                       (int*)(c->d_ctr + C_ERR));
                 } else {
                     hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.sums.p);
                     hipLaunchKernelGGL(k_scan_fix, dim3((ncell + 4095) / 4096), dim3(1024), 0, st, G.start.p, ncell, G.sums.p, ntiles, total_out);
@@ -1050,6 +1054,7 @@ int ensure_plane_lists(arp_ctx* c) {
 int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq_adj, bool with_planes) {
     // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
     if (!c->ctr_clean) CHK(zero_counter(c, C_BINNED, 1));
+    CHK(zero_counter(c, C_ERR, 1));      // (before the grid build: its chained scan may raise the flag)
     ResMarks rm{nullptr, nullptr, 0};
     GroupMasks gm{};
     bool masks_after_bin = false;
@@ -1084,7 +1089,6 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
     CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
     CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
-    CHK(zero_counter(c, C_ERR, 1));
     // ---- ring / amide loops (I:938-1382): evaluated from the static candidate lists by the leading blocks of the
     // last launch (ARP_PLANES_MODE=1: as a kernel of their own on the second stream, beside the search)
     AtomPlaneArgs ap{};
@@ -1244,6 +1248,9 @@ int grow_bag(arp_ctx* c, Bag& b, int slot, bool d, bool f) {
 int device_error(arp_ctx* c) {
     if ((int)(uint32_t)c->h_ctr[C_ERR] == ARP_E_XBOND_NBR)
         FAIL(c, ARP_E_XBOND_NBR, "xbond donor without a single-bond heavy neighbour (reference: AttributeError at utils.py:173)");
+    if ((int)(uint32_t)c->h_ctr[C_ERR] == ARP_E_HIP)
+        FAIL(c, ARP_E_HIP, "the grid's prefix scan timed out waiting for another tile (device shared or partly masked?): results of this pass are invalid; "
+                           "ARP_CHAINED_SCAN=0 selects the two-launch scan");
     return ARP_OK;
 }
 
@@ -1897,7 +1904,7 @@ int arp_records_layout(void* buf, uint64_t bytes, int64_t na, int64_t nh, int64_
     return ARP_OK;
 }
 
-int arp_records_fill(void* buf, uint64_t bytes, int64_t n_total, const float* xyz, const double* vdw, const double* cov,
+int arp_records_fill(void* buf, uint64_t bytes, int64_t n_total, int64_t nres_total, int64_t nring_total, int64_t namide_total, const float* xyz, const double* vdw, const double* cov,
                      const uint16_t* type_mask, const uint16_t* flags, const int32_t* res_id, const uint8_t* res_flags,
                      const int32_t* res_prev, const int32_t* res_next, const int32_t* bond_off, const int32_t* bond_idx,
                      const int32_t* h_off, const double* h_xyz, const int32_t* sb_nbr, const double* ring_center,
@@ -1931,8 +1938,10 @@ int arp_records_fill(void* buf, uint64_t bytes, int64_t n_total, const float* xy
         r.x = xyz[3 * i]; r.y = xyz[3 * i + 1]; r.z = xyz[3 * i + 2]; r.gid = (int32_t)i;
         r.vdw = vdw[i]; r.cov = cov[i];
         const int32_t nb = sb_nbr[i];
+        if (nb < -1 || nb >= n_total) return ARP_E_ARG;
         if (nb >= 0) { r.sb_x = xyz[3 * (int64_t)nb]; r.sb_y = xyz[3 * (int64_t)nb + 1]; r.sb_z = xyz[3 * (int64_t)nb + 2]; r.sb_has = 1; }
         const int32_t res = res_id[i];
+        if (res < 0 || res >= nres_total) return ARP_E_ARG;
         r.res_gid = res; r.res_prev = res_prev[res]; r.res_next = res_next[res]; r.res_flags = res_flags[res];
         r.tmask = type_mask[i]; r.flags = flags[i];
         r.sel = sel ? sel[i] : (uint8_t)1;
@@ -1950,11 +1959,13 @@ int arp_records_fill(void* buf, uint64_t bytes, int64_t n_total, const float* xy
     if (hs != h.nh || bs != h.nb) return ARP_E_ARG;
     for (int64_t k = 0; k < h.nring; ++k) {
         const int64_t i = ring_ids[k];
+        if (i < 0 || i >= nring_total || (k > 0 && ring_ids[k - 1] >= i) || ring_res[i] < -1 || ring_res[i] >= nres_total) return ARP_E_ARG;
         for (int q = 0; q < 3; ++q) { R[k].c[q] = ring_center[3 * i + q]; R[k].n[q] = ring_normal[3 * i + q]; }
         R[k].gid = (int32_t)i; R[k].res = ring_res[i];
     }
     for (int64_t k = 0; k < h.namide; ++k) {
         const int64_t i = amide_ids[k];
+        if (i < 0 || i >= namide_total || (k > 0 && amide_ids[k - 1] >= i) || amide_res[i] < -1 || amide_res[i] >= nres_total) return ARP_E_ARG;
         for (int q = 0; q < 3; ++q) { M[k].c[q] = amide_center[3 * i + q]; M[k].n[q] = amide_normal[3 * i + q]; }
         M[k].gid = (int32_t)i; M[k].res = amide_res[i];
     }

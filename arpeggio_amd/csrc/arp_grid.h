@@ -159,12 +159,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ in,
 // The same in ONE launch for up to CHAIN_TILES tiles (every block of the launch is resident at once: two 1024-thread blocks
 // per CU): a tile publishes its total as soon as it has it — one 64-bit word {launch number, total}, so nothing needs
 // clearing between launches — and waits for the totals of the tiles before it (they are a handful of words), adds their
-// sum to its prefixes before it writes them.  The wait is bounded: a tile that is not served traps (the launch fails
-// loudly) instead of hanging the queue.
+// sum to its prefixes before it writes them.  The wait is bounded: a tile that is not served within ~2^20 polls raises the
+// device error flag (*err = ARP_E_HIP: the host fails the pass with a message) and goes on with what it has, instead of
+// hanging the queue or killing the context.  The host uses this path only while every tile is resident at once
+// (ntiles <= 2 blocks per CU) and clears the chain when the 32-bit launch number wraps.
 #define CHAIN_TILES 128
 __global__ __launch_bounds__(1024) void k_scan_tiles_chained(const int* __restrict__ in, int n, int* __restrict__ out,
                                                              unsigned long long* __restrict__ chain, unsigned int epoch,
-                                                             unsigned long long* __restrict__ total_out) {
+                                                             unsigned long long* __restrict__ total_out, int* __restrict__ err) {
     __shared__ int sh[32];
     __shared__ int s_off;
     constexpr int ITEMS = TILE_ITEMS;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles_chained(const int* __restri
             for (;;) {
                 w = __hip_atomic_load(chain + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned int)(w >> 32) == epoch) break;
-                if (++spins > (1 << 22)) __builtin_trap();
+                if (++spins > (1 << 20)) { atomicExch(err, -2 /* ARP_E_HIP */); w = 0; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             before += (int)(unsigned int)w;

@@ -464,7 +464,8 @@ int arp_records_layout(void* buf, uint64_t bytes, int64_t na, int64_t nh, int64_
  * the arrays of the classic setters, written into a buffer whose header arp_records_layout has prepared (na, nring,
  * namide = the list lengths; nh, nb = the hydrogens / bonds of the listed atoms).  sel = selection mask over ALL atoms
  * (NULL: everything selected).  Fills the sections, the radius dictionary of the listed atoms and the boxes. */
-int arp_records_fill(void* buf, uint64_t bytes, int64_t n_atoms_total, const float* xyz, const double* vdw, const double* cov,
+int arp_records_fill(void* buf, uint64_t bytes, int64_t n_atoms_total, int64_t n_res_total, int64_t n_rings_total, int64_t n_amides_total,
+                     const float* xyz, const double* vdw, const double* cov,
                      const uint16_t* type_mask, const uint16_t* flags, const int32_t* res_id, const uint8_t* res_flags,
                      const int32_t* res_prev, const int32_t* res_next, const int32_t* bond_off, const int32_t* bond_idx,
                      const int32_t* h_off, const double* h_xyz, const int32_t* sb_nbr, const double* ring_center,
