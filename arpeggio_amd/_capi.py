@@ -29,7 +29,8 @@ SYMBOLS = (
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
-    'arp_get_host_times', 'arp_set_whole_structure', 'arp_set_batch', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
+    'arp_get_host_times', 'arp_set_whole_structure', 'arp_set_batch', 'arp_device_count', 'arp_comm_unique_id', 'arp_comm_init', 'arp_comm_destroy', 'arp_comm_info',
+    'arp_shard_exchange_faces', 'arp_shard_set_exchange_lists', 'arp_shard_exchange_plus', 'arp_shard_reduce_residue_sets', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
     'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob', 'arp_blob_fill',
     'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_records_fill', 'arp_shard_set_home', 'arp_shard_pack_face',
     'arp_shard_assemble', 'arp_shard_layout', 'arp_get_blob', 'arp_cif_open', 'arp_cif_close', 'arp_cif_rows', 'arp_cif_cols',
@@ -37,6 +38,11 @@ SYMBOLS = (
 )
 
 _lib = None
+
+
+def device_count():
+    """GPUs this process can see (the library's own answer: no torch involved)."""
+    return int(load().arp_device_count())
 
 
 def load():
@@ -125,6 +131,14 @@ def load():
     L.arp_get_host_times.argtypes = [vp, vp, vp, i32]
     L.arp_set_whole_structure.argtypes = [vp, i32]
     L.arp_set_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.arp_comm_unique_id.argtypes = [vp, C.c_uint64]
+    L.arp_comm_init.argtypes = [vp, i32, i32, vp]
+    L.arp_comm_destroy.argtypes = [vp]
+    L.arp_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.arp_shard_exchange_faces.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    L.arp_shard_set_exchange_lists.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, i64]
+    L.arp_shard_exchange_plus.argtypes = [vp]
+    L.arp_shard_reduce_residue_sets.argtypes = [vp]
     L.arp_ring_geometry.argtypes = [vp, i64, vp, vp, vp, vp]
     L.arp_amide_geometry.argtypes = [vp, i64, vp, vp, vp]
     L.arp_ring_residues.argtypes = [vp, i64, vp, vp, vp]
@@ -492,6 +506,52 @@ class Context:
         buf = np.empty(int(nb.value), np.uint8)
         self._check(self._L.arp_get_blob(self._h, _p(buf), int(buf.nbytes), C.byref(nb)), 'arp_get_blob')
         return buf
+
+    # ---- exchange between shards: RCCL behind the C ABI (include/arpeggio_hip.h, arp_comm_*)
+    @staticmethod
+    def comm_unique_id():
+        """128-byte id of a new communicator (rank 0 calls this and hands the bytes to the other ranks)."""
+        buf = np.zeros(128, np.uint8)
+        rc = load().arp_comm_unique_id(_p(buf), 128)
+        if rc != ARP_OK:
+            raise NativeLibraryError('arp_comm_unique_id failed: ' + load().arp_last_error(None).decode())
+        return buf
+
+    def comm_init(self, rank, world, unique_id):
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        if uid.size != 128:
+            raise ValueError('the unique id has 128 bytes')
+        self._check(self._L.arp_comm_init(self._h, int(rank), int(world), _p(uid)), 'arp_comm_init')
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._check(self._L.arp_comm_destroy(self._h), 'arp_comm_destroy')
+
+    def shard_exchange_faces(self, left, right):
+        """``left`` / ``right``: (device pointer, bytes) from ``shard_pack_face`` or None.  Returns {-1: (ptr, bytes), +1: ...}
+        of what the neighbours sent (buffers owned by the context)."""
+        lp, lb = left if left else (0, 0)
+        rp, rb = right if right else (0, 0)
+        out = np.zeros(4, np.uint64)
+        self._check(self._L.arp_shard_exchange_faces(self._h, lp, lb, rp, rb, _p(out)), 'arp_shard_exchange_faces')
+        got = {}
+        if out[1]:
+            got[-1] = (int(out[0]), int(out[1]))
+        if out[3]:
+            got[+1] = (int(out[2]), int(out[3]))
+        return got
+
+    def shard_set_exchange_lists(self, send_left, send_right, recv_left, recv_right):
+        a = [np.ascontiguousarray(x if x is not None else [], np.int32) for x in (send_left, send_right, recv_left, recv_right)]
+        self._keep_lists = a
+        self._check(self._L.arp_shard_set_exchange_lists(self._h, _p(a[0]), len(a[0]), _p(a[1]), len(a[1]), _p(a[2]), len(a[2]), _p(a[3]), len(a[3])),
+                    'arp_shard_set_exchange_lists')
+
+    def shard_exchange_plus(self):
+        self._check(self._L.arp_shard_exchange_plus(self._h), 'arp_shard_exchange_plus')
+
+    def shard_reduce_residue_sets(self):
+        self._check(self._L.arp_shard_reduce_residue_sets(self._h), 'arp_shard_reduce_residue_sets')
 
     # ---- shard assembled on the device (sharding.make_shard_device)
     def shard_set_home(self, records):

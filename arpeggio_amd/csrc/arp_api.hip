@@ -24,6 +24,7 @@
 #include "arp_json.h"
 #include "arp_shard.h"
 #include "arp_cif.h"
+#include "arp_comm.h"
 
 namespace {
 
@@ -240,6 +241,14 @@ struct arp_ctx {
     DevBuf<uint8_t> bag_pack;      // staging of small bags: device side ...
     uint8_t* bag_stage = nullptr;  // ... and its page-locked host copy
     size_t bag_stage_cap = 0;
+    // ---- exchange between shards (arp_comm_*: RCCL on the context's stream)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf<uint8_t> comm_recv[2];          // what the left / right neighbour sent last
+    DevBuf<unsigned long long> comm_words; // sizes on their way: [0, 1] out (left, right), [2, 3] in
+    DevBuf<int> xl_send[2], xl_recv[2];    // per-pass selection exchange: local atom indices sent to / received from each neighbour
+    DevBuf<uint8_t> xl_send_buf[2], xl_recv_buf[2];
+    int64_t xl_nsend[2] = {0, 0}, xl_nrecv[2] = {0, 0};
     // ---- several structures in one pass (arp_set_batch): structure s = atoms [atom_off[s], atom_off[s + 1]), rings, amides likewise
     int64_t batch_n = 0;
     std::vector<int64_t> batch_atom_off, batch_ring_off, batch_amide_off;
@@ -1277,6 +1286,11 @@ extern "C" {
 
 const char* arp_version(void) { return "arpeggio_hip 0.2.0 (gfx950)"; }
 
+int arp_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int arp_create(int device, arp_ctx** out) {
     if (!out) return ARP_E_ARG;
     *out = nullptr;
@@ -1332,6 +1346,7 @@ int arp_create(int device, arp_ctx** out) {
 }
 
 void arp_destroy(arp_ctx* c) {
+    if (c && c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -2780,7 +2795,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         int rc = enqueue_expansion(c, expand_radius);
         c->ctr_clean = false;
         CHK(rc);
-        if (!c->external_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->external_stream && !c->comm) HIPCHK(c, hipStreamSynchronize(c->stream));   // (with a communicator the exchange follows on the same stream)
         return ARP_OK;
     }
     if (!c->sel_made) FAIL(c, ARP_E_ARG, "arp_run_stage: stage 0 has not run");
@@ -2794,7 +2809,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
             hipLaunchKernelGGL(k_res_mark, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->res_id.p, c->sel.p, c->plus.p,
                                c->res_sel.p, c->res_sel.p + nres);
         CHK(check_launch(c, "k_res_mark"));
-        if (!c->external_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->external_stream && !c->comm) HIPCHK(c, hipStreamSynchronize(c->stream));   // (with a communicator the exchange follows on the same stream)
         return ARP_OK;
     }
     // stage 2: ring / amide sets from the (now globally reduced) residue sets, then every contact bag
@@ -3043,6 +3058,150 @@ int arp_set_batch(arp_ctx* c, int64_t nstruct, const int64_t* atom_off, const in
     c->contacts_valid = false;
     c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
+    return ARP_OK;
+}
+
+// ---- exchange between the shards of a distributed structure (RCCL behind the C ABI) -----------------------------------
+#define NCCLCHK(ctx, expr)                                                                              \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) {                                                                        \
+            (ctx)->err = std::string(#expr) + ": " + rccl().GetErrorString(r_);                         \
+            return ARP_E_HIP;                                                                           \
+        }                                                                                               \
+    } while (0)
+
+int arp_comm_unique_id(uint8_t* out, uint64_t cap) {
+    if (!out || cap < NCCL_UNIQUE_ID_BYTES) return ARP_E_ARG;
+    if (!rccl().load()) { set_create_error(rccl().error); return ARP_E_HIP; }
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) { set_create_error("ncclGetUniqueId failed"); return ARP_E_HIP; }
+    memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return ARP_OK;
+}
+
+int arp_comm_init(arp_ctx* c, int rank, int world, const uint8_t* unique_id) {
+    if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return ARP_E_ARG;
+    if (c->comm) FAIL(c, ARP_E_ARG, "arp_comm_init: the context has a communicator already (arp_comm_destroy first)");
+    if (!rccl().load()) FAIL(c, ARP_E_HIP, rccl().error);
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+    NCCLCHK(c, rccl().CommInitRank(&c->comm, world, id, rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    HIPCHK(c, c->comm_words.reserve(4));
+    return ARP_OK;
+}
+
+int arp_comm_destroy(arp_ctx* c) {
+    if (!c) return ARP_E_ARG;
+    if (c->comm) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return ARP_OK;
+}
+
+int arp_comm_info(arp_ctx* c, int* rank, int* world) {
+    if (!c) return ARP_E_ARG;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm_world;
+    return c->comm ? ARP_OK : ARP_E_ARG;
+}
+
+int arp_shard_exchange_faces(arp_ctx* c, uint64_t left_ptr, uint64_t left_bytes, uint64_t right_ptr, uint64_t right_bytes, uint64_t received[4]) {
+    if (!c || !received) return ARP_E_ARG;
+    if (!c->comm) FAIL(c, ARP_E_ARG, "arp_shard_exchange_faces: no communicator (arp_comm_init)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int peer[2] = {c->comm_rank - 1, c->comm_rank + 1};
+    const bool has[2] = {peer[0] >= 0, peer[1] < c->comm_world};
+    const void* out_ptr[2] = {(const void*)(uintptr_t)left_ptr, (const void*)(uintptr_t)right_ptr};
+    const unsigned long long out_bytes[2] = {has[0] ? left_bytes : 0ull, has[1] ? right_bytes : 0ull};
+    // sizes first: one 64-bit word each way (device words, filled / read through the stream)
+    unsigned long long words[4] = {out_bytes[0], out_bytes[1], 0ull, 0ull};
+    HIPCHK(c, hipMemcpyAsync(c->comm_words.p, words, sizeof(words), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, rccl().GroupStart());
+    for (int s_ = 0; s_ < 2; ++s_)
+        if (has[s_]) {
+            NCCLCHK(c, rccl().Send(c->comm_words.p + s_, 8, ncclUint8, peer[s_], c->comm, c->stream));
+            NCCLCHK(c, rccl().Recv(c->comm_words.p + 2 + s_, 8, ncclUint8, peer[s_], c->comm, c->stream));
+        }
+    NCCLCHK(c, rccl().GroupEnd());
+    HIPCHK(c, hipMemcpyAsync(words, c->comm_words.p, sizeof(words), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s_ = 0; s_ < 2; ++s_) HIPCHK(c, c->comm_recv[s_].reserve((size_t)std::max<unsigned long long>(words[2 + s_], 1)));
+    NCCLCHK(c, rccl().GroupStart());
+    for (int s_ = 0; s_ < 2; ++s_)
+        if (has[s_]) {
+            if (out_bytes[s_]) NCCLCHK(c, rccl().Send(out_ptr[s_], (size_t)out_bytes[s_], ncclUint8, peer[s_], c->comm, c->stream));
+            if (words[2 + s_]) NCCLCHK(c, rccl().Recv(c->comm_recv[s_].p, (size_t)words[2 + s_], ncclUint8, peer[s_], c->comm, c->stream));
+        }
+    NCCLCHK(c, rccl().GroupEnd());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s_ = 0; s_ < 2; ++s_) {
+        received[2 * s_] = (has[s_] && words[2 + s_]) ? (uint64_t)(uintptr_t)c->comm_recv[s_].p : 0;
+        received[2 * s_ + 1] = has[s_] ? words[2 + s_] : 0;
+    }
+    return ARP_OK;
+}
+
+int arp_shard_set_exchange_lists(arp_ctx* c, const int32_t* send_left, int64_t n_send_left, const int32_t* send_right, int64_t n_send_right,
+                                 const int32_t* recv_left, int64_t n_recv_left, const int32_t* recv_right, int64_t n_recv_right) {
+    if (!c || n_send_left < 0 || n_send_right < 0 || n_recv_left < 0 || n_recv_right < 0) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int32_t* src[4] = {send_left, send_right, recv_left, recv_right};
+    const int64_t cnt[4] = {n_send_left, n_send_right, n_recv_left, n_recv_right};
+    for (int k = 0; k < 4; ++k) {
+        if (cnt[k] > 0 && !src[k]) return ARP_E_ARG;
+        for (int64_t i = 0; i < cnt[k]; ++i)
+            if (src[k][i] < 0 || src[k][i] >= c->n) FAIL(c, ARP_E_ARG, "arp_shard_set_exchange_lists: atom index out of range");
+    }
+    for (int s_ = 0; s_ < 2; ++s_) {
+        CHK(upload_async(c, c->xl_send[s_], src[s_], (size_t)cnt[s_]));
+        CHK(upload_async(c, c->xl_recv[s_], src[2 + s_], (size_t)cnt[2 + s_]));
+        HIPCHK(c, c->xl_send_buf[s_].reserve((size_t)std::max<int64_t>(cnt[s_], 1)));
+        HIPCHK(c, c->xl_recv_buf[s_].reserve((size_t)std::max<int64_t>(cnt[2 + s_], 1)));
+        c->xl_nsend[s_] = cnt[s_];
+        c->xl_nrecv[s_] = cnt[2 + s_];
+    }
+    return upload_done(c);
+}
+
+int arp_shard_exchange_plus(arp_ctx* c) {
+    if (!c) return ARP_E_ARG;
+    if (!c->comm) FAIL(c, ARP_E_ARG, "arp_shard_exchange_plus: no communicator (arp_comm_init)");
+    if (!c->plus.p) FAIL(c, ARP_E_ARG, "arp_shard_exchange_plus: selection_plus does not exist yet (run stage 0 first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int peer[2] = {c->comm_rank - 1, c->comm_rank + 1};
+    const bool has[2] = {peer[0] >= 0, peer[1] < c->comm_world};
+    for (int s_ = 0; s_ < 2; ++s_)
+        if (has[s_] && c->xl_nsend[s_] > 0)
+            hipLaunchKernelGGL(k_gather_u8, dim3(nblocks(c->xl_nsend[s_], 256)), dim3(256), 0, c->stream, (int)c->xl_nsend[s_], c->xl_send[s_].p, c->plus.p, c->xl_send_buf[s_].p);
+    CHK(check_launch(c, "k_gather_u8"));
+    NCCLCHK(c, rccl().GroupStart());
+    for (int s_ = 0; s_ < 2; ++s_)
+        if (has[s_]) {
+            if (c->xl_nsend[s_] > 0) NCCLCHK(c, rccl().Send(c->xl_send_buf[s_].p, (size_t)c->xl_nsend[s_], ncclUint8, peer[s_], c->comm, c->stream));
+            if (c->xl_nrecv[s_] > 0) NCCLCHK(c, rccl().Recv(c->xl_recv_buf[s_].p, (size_t)c->xl_nrecv[s_], ncclUint8, peer[s_], c->comm, c->stream));
+        }
+    NCCLCHK(c, rccl().GroupEnd());
+    for (int s_ = 0; s_ < 2; ++s_)
+        if (has[s_] && c->xl_nrecv[s_] > 0)
+            hipLaunchKernelGGL(k_scatter_u8, dim3(nblocks(c->xl_nrecv[s_], 256)), dim3(256), 0, c->stream, (int)c->xl_nrecv[s_], c->xl_recv[s_].p, c->xl_recv_buf[s_].p, c->plus.p);
+    return check_launch(c, "k_scatter_u8");
+}
+
+int arp_shard_reduce_residue_sets(arp_ctx* c) {
+    if (!c) return ARP_E_ARG;
+    if (!c->comm) FAIL(c, ARP_E_ARG, "arp_shard_reduce_residue_sets: no communicator (arp_comm_init)");
+    if (!c->res_sel.p) FAIL(c, ARP_E_ARG, "arp_shard_reduce_residue_sets: residue sets do not exist yet (run stage 1 first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = 2 * (size_t)std::max<int64_t>(c->nres, 1);
+    NCCLCHK(c, rccl().AllReduce(c->res_sel.p, c->res_sel.p, nb, ncclUint8, ncclMax, c->comm, c->stream));
     return ARP_OK;
 }
 

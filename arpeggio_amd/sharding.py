@@ -1,10 +1,15 @@
 """Slab sharding of one structure across the GPUs of a node.
 
 The box is cut into ``world`` slabs along x.  Each rank owns the atoms, rings and amides
-whose (centre) x lies in its slab and receives a one-cell halo from its two neighbours —
-point-to-point exchange over ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on the
-GPU box, ``gloo`` in the CPU tests).  Halo records are self-contained: hydrogens, bonded
-global ids, residue links and the single-bond-neighbour coordinates travel with the atom.
+whose (centre) x lies in its slab and receives a one-cell halo from its two neighbours.
+On the GPUs the exchange is the library's own (include/arpeggio_hip.h, ``arp_comm_*`` /
+``arp_shard_exchange_*``: RCCL over xGMI on the context's stream); this module only
+partitions and keeps the books.  The host-buffer variants (``make_shard_distributed``,
+``combine_selection``) take a ``transport`` object — ``exchange({side: uint8 array}) ->
+{side: uint8 array}`` with the ranks ``rank - 1`` / ``rank + 1`` and ``allreduce_max(uint8
+array)`` — which the CPU tests implement over gloo; nothing here imports torch.
+Halo records are self-contained: hydrogens, bonded global ids, residue links and the
+single-bond-neighbour coordinates travel with the atom.
 
 Ownership rule: a pair is emitted by the rank that owns the atom (ring, amide) with the
 lower global id, so the union of the per-rank results equals the single-GPU result and the
@@ -248,33 +253,9 @@ def make_shard_local(full: PackedComplex, rank: int, world: int, sel=None, cutof
     return sh
 
 
-def _exchange(dist, device, rank, world, payload: Dict[int, np.ndarray]) -> Dict[int, np.ndarray]:
-    """Send payload[side] (uint8) to rank+side and receive the neighbour's buffer from each side."""
-    import torch
-    sides = [s for s in (-1, +1) if 0 <= rank + s < world]
-    lens_out = {s: torch.tensor([payload[s].size], dtype=torch.int64, device=device) for s in sides}
-    lens_in = {s: torch.zeros(1, dtype=torch.int64, device=device) for s in sides}
-    ops = []
-    for s in sides:
-        ops.append(dist.P2POp(dist.isend, lens_out[s], rank + s))
-        ops.append(dist.P2POp(dist.irecv, lens_in[s], rank + s))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    bufs_out = {s: torch.from_numpy(payload[s]).to(device) for s in sides}
-    bufs_in = {s: torch.empty(int(lens_in[s].item()), dtype=torch.uint8, device=device) for s in sides}
-    ops = []
-    for s in sides:
-        ops.append(dist.P2POp(dist.isend, bufs_out[s], rank + s))
-        ops.append(dist.P2POp(dist.irecv, bufs_in[s], rank + s))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    if device is not None and getattr(device, 'type', 'cpu') == 'cuda':
-        torch.cuda.synchronize(device)
-    return {s: bufs_in[s].cpu().numpy() for s in sides}
-
-
-def make_shard_distributed(full: PackedComplex, rank: int, world: int, dist, device=None, sel=None, cutoff=5.0) -> Shard:
-    """Each rank keeps only its slab of `full` and obtains its halo from its neighbours over `dist`."""
+def make_shard_distributed(full: PackedComplex, rank: int, world: int, transport=None, sel=None, cutoff=5.0) -> Shard:
+    """Each rank keeps only its slab of `full` and obtains its halo from its neighbours through ``transport``
+    (host buffers; see the module docstring)."""
     halo = halo_width(cutoff)
     edges, a_own, r_own, m_own = _partition(full, world, halo)
     home = pack_records(full, np.nonzero(a_own == rank)[0], np.nonzero(r_own == rank)[0], np.nonzero(m_own == rank)[0], sel)
@@ -285,7 +266,7 @@ def make_shard_distributed(full: PackedComplex, rank: int, world: int, dist, dev
             payload[side] = _to_bytes(pack_records(full, ai, ri, mi, sel))
             sends[side] = ai
     t0 = time.perf_counter()
-    received = _exchange(dist, device, rank, world, payload) if world > 1 else {}
+    received = transport.exchange(payload) if world > 1 else {}
     ms = (time.perf_counter() - t0) * 1e3
     halos = {s: _from_bytes(received[s]) for s in received}
     sh = assemble_shard(home, halos, full.n_residues, rank, world)
@@ -322,44 +303,6 @@ class DeviceShard:
     halo_ms: float = 0.0
     halo_bytes: int = 0
     timings_ms: Optional[dict] = None # where the set-up time went: host packing of the home records / device work / exchange
-
-
-class _DevAlias:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
-
-
-def exchange_device_buffers(dist, device, rank, world, payload):
-    """payload: side -> (device pointer, bytes) of the buffer for rank + side.  Returns side -> (pointer, bytes, tensor)
-    of what the neighbours sent; the tensor owns the memory.  Sizes first (one int64 each way), then the buffers, both
-    with grouped isend / irecv on device memory — RCCL over xGMI under the nccl backend.  ``device=None`` (gloo, the
-    one-GPU debug mode of bench.py): the buffers make a detour through host tensors, everything else is the same."""
-    import torch
-    sides = [s for s in (-1, +1) if 0 <= rank + s < world]
-    gpu = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-    wire = device if device is not None else torch.device('cpu')
-    lens_out = {s: torch.tensor([payload[s][1]], dtype=torch.int64, device=wire) for s in sides}
-    lens_in = {s: torch.zeros(1, dtype=torch.int64, device=wire) for s in sides}
-    ops = []
-    for s in sides:
-        ops.append(dist.P2POp(dist.isend, lens_out[s], rank + s))
-        ops.append(dist.P2POp(dist.irecv, lens_in[s], rank + s))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    out_t = {s: torch.as_tensor(_DevAlias(payload[s][0], payload[s][1]), device=gpu) for s in sides}
-    if device is None:
-        out_t = {s: t.cpu() for s, t in out_t.items()}
-    in_t = {s: torch.empty(int(lens_in[s].item()), dtype=torch.uint8, device=wire) for s in sides}
-    ops = []
-    for s in sides:
-        ops.append(dist.P2POp(dist.isend, out_t[s], rank + s))
-        ops.append(dist.P2POp(dist.irecv, in_t[s], rank + s))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    if device is None:
-        in_t = {s: t.to(gpu) for s, t in in_t.items()}
-    torch.cuda.synchronize(gpu)
-    return {s: (int(in_t[s].data_ptr()), int(in_t[s].numel()), in_t[s]) for s in sides}
 
 
 def shard_home_to_device(ctx, full: PackedComplex, rank: int, world: int, sel=None, cutoff=5.0):
@@ -406,13 +349,14 @@ def finish_shard_on_device(ctx, received, book, whole_structure=False) -> Device
                        send_left=book['sends'].get(-1), send_right=book['sends'].get(+1), halo=book['halo'])
 
 
-def make_shard_device(ctx, full: PackedComplex, rank: int, world: int, dist, device, sel=None, cutoff=5.0,
+def make_shard_device(ctx, full: PackedComplex, rank: int, world: int, sel=None, cutoff=5.0,
                       whole_structure=False) -> DeviceShard:
     """``make_shard_distributed`` + ``upload_shard`` without the host in the data path: the halo records are cut out,
-    exchanged (RCCL) and merged on the GPUs."""
+    exchanged (``arp_shard_exchange_faces``: RCCL on the context's communicator, ``Context.comm_init``) and merged on
+    the GPUs."""
     faces, book = shard_home_to_device(ctx, full, rank, world, sel, cutoff)
     t0 = time.perf_counter()
-    received = exchange_device_buffers(dist, device, rank, world, faces) if world > 1 else {}
+    received = ctx.shard_exchange_faces(faces.get(-1), faces.get(+1)) if world > 1 else {}
     ms = (time.perf_counter() - t0) * 1e3
     sh = finish_shard_on_device(ctx, received, book, whole_structure)
     sh.halo_ms = ms
@@ -424,7 +368,7 @@ def make_shard_device(ctx, full: PackedComplex, rank: int, world: int, dist, dev
 # ---------------------------------------------------------------------------------------------
 # selection: halo exchange of selection_plus bits + all-reduce of the residue sets
 # ---------------------------------------------------------------------------------------------
-def combine_selection(sh: Shard, local_plus: np.ndarray, dist=None, device=None):
+def combine_selection(sh: Shard, local_plus: np.ndarray, transport=None):
     """Turn the local result of the 6 A expansion into the global _make_selection state.
 
     local_plus is exact for home atoms (every selected atom within 6 A of a home atom is in
@@ -432,13 +376,12 @@ def combine_selection(sh: Shard, local_plus: np.ndarray, dist=None, device=None)
     are OR-ed over all ranks.
     """
     plus = np.asarray(local_plus, np.uint8).copy()
-    if dist is not None and sh.world > 1:
-        import torch
+    if transport is not None and sh.world > 1:
         payload = {}
         for side, ids in ((-1, sh.send_left), (+1, sh.send_right)):
             if ids is not None:
                 payload[side] = plus[_lookup(sh.global_id, ids)].astype(np.uint8)
-        got = _exchange(dist, device, sh.rank, sh.world, payload)
+        got = transport.exchange(payload)
         # the owner sent one bit per atom of its face set in ascending global id = the order of my halo atoms of that side
         for side, bits in got.items():
             plus[sh.origin == side] = bits
@@ -447,11 +390,8 @@ def combine_selection(sh: Shard, local_plus: np.ndarray, dist=None, device=None)
     res_g = sh.res_gid[sh.pc.res_id]
     res[res_g[hm & (sh.sel == 1)]] = 1
     res[sh.n_res_global + res_g[hm & (plus == 1)]] = 1
-    if dist is not None and sh.world > 1:
-        import torch
-        t = torch.from_numpy(res).to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        res = t.cpu().numpy()
+    if transport is not None and sh.world > 1:
+        res = transport.allreduce_max(res)
     res_sel, res_plus = res[:sh.n_res_global], res[sh.n_res_global:]
     rr, ar = sh.ring_res_gid, sh.amide_res_gid
     ring_sel = np.where(rr >= 0, res_sel[np.maximum(rr, 0)], 0).astype(np.uint8)
@@ -476,11 +416,11 @@ def upload_shard(ctx, sh: Shard, whole_structure: bool = False):
     ctx.set_whole_structure(whole_structure)
 
 
-def run_shard(ctx, sh: Shard, dist=None, device=None, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
+def run_shard(ctx, sh: Shard, transport=None, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False):
     """run_arpeggio on one shard: local expansion, selection exchange, then the five bags (results stay in HBM)."""
     _check_radius(sh, cutoff)
     local = ctx.make_selection(sh.sel)
-    st = combine_selection(sh, local['plus'], dist, device)
+    st = combine_selection(sh, local['plus'], transport)
     ctx.set_selection_state(st['sel'], st['plus'], st['ring_sel'], st['ring_plus'], st['amide_sel'], st['amide_plus'])
     counts = dict(atom_atom=ctx.atom_contacts_launch(cutoff, vdw_comp, include_sequence_adjacent))
     for name in ('plane_plane', 'atom_plane', 'group_group', 'group_plane'):
@@ -489,86 +429,37 @@ def run_shard(ctx, sh: Shard, dist=None, device=None, cutoff=5.0, vdw_comp=0.1, 
 
 
 class DeviceExchange:
-    """Selection exchange of one shard on the device: torch tensors alias the context's selection_plus and
-    residue-set buffers (``arp_device_buffer``), the halo bits travel with grouped isend/irecv and the residue
-    sets with one all-reduce (MAX) — RCCL over xGMI when ``dist`` runs the nccl backend."""
+    """Per-pass selection exchange of one shard: halo atoms take their selection_plus bit from their owner,
+    the residue sets are OR-ed over all ranks.  On the GPU (``transport=None``) both are the library's own
+    (``arp_shard_exchange_plus`` / ``arp_shard_reduce_residue_sets``: RCCL on the context's stream, no host
+    synchronisation between the stages); the index lists are uploaded once, here.  With a ``transport`` the context is
+    expected to expose its buffers as NumPy arrays (``host_buffer``: the CPU stand-in of the tests)."""
 
-    class _Alias:
-        def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
-
-    def __init__(self, ctx, sh: Shard, dist, device, share_stream: bool = True):
-        import torch
-        if device is not None and getattr(device, 'type', '') == 'cuda':
-            try:
-                torch.cuda.init()
-            except RuntimeError as exc:
-                # PyTorch-ROCm ships its own HIP runtime; it cannot start once the system runtime (which
-                # libarpeggio_hip.so binds to when it is loaded first) owns the process
-                raise RuntimeError('torch could not initialise the GPU in this process: import torch and touch the device '
-                                   '(torch.cuda.set_device) BEFORE the first arpeggio_amd Context is created, as bench.py '
-                                   'does') from exc
-        self.torch, self.ctx, self.sh, self.dist, self.device = torch, ctx, sh, dist, device
-        self.t_plus = self.t_res = None
-        self._keep = []
-        # On the GPU the context is told to enqueue on a torch stream: kernels of the stages and the exchange
-        # ops are then ordered on ONE stream and stages 0 / 1 need no host synchronisation.
-        self.stream = None
-        if share_stream and device is not None and getattr(device, 'type', '') == 'cuda':
-            self.stream = torch.cuda.Stream(device=device)
-            ctx.use_stream(self.stream.cuda_stream)
-        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(device if device is not None else 'cpu')
-        self.send_idx, self.recv_idx, self.recv_buf = {}, {}, {}
+    def __init__(self, ctx, sh, transport=None):
+        self.ctx, self.sh, self.transport = ctx, sh, transport
+        self.send_idx, self.recv_idx = {}, {}
         for side, ids in ((-1, sh.send_left), (+1, sh.send_right)):
             if ids is not None and 0 <= sh.rank + side < sh.world:
-                self.send_idx[side] = to_dev(_lookup(sh.global_id, ids))
-                self.recv_idx[side] = to_dev(np.nonzero(sh.origin == side)[0])
-                self.recv_buf[side] = torch.empty(int((sh.origin == side).sum()), dtype=torch.uint8,
-                                                  device=device if device is not None else 'cpu')
-
-    def _on_gpu(self):
-        return self.device is not None and getattr(self.device, 'type', str(self.device)) == 'cuda'
-
-    def _alias(self, which):
-        if not self._on_gpu():     # CPU tests (gloo): the "context" exposes NumPy buffers
-            return self.torch.from_numpy(self.ctx.host_buffer(which))
-        ptr, nb = self.ctx.device_buffer(which)
-        return self.torch.as_tensor(self._Alias(ptr, nb), device=self.device)
-
-    def _sync(self):
-        if self._on_gpu() and self.stream is None:     # own-stream contexts: hand over through the host
-            self.torch.cuda.current_stream(self.device).synchronize()
-
-    def _scope(self):
-        import contextlib
-        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+                self.send_idx[side] = _lookup(sh.global_id, ids).astype(np.int32)
+                self.recv_idx[side] = np.nonzero(sh.origin == side)[0].astype(np.int32)
+        if transport is None:
+            ctx.shard_set_exchange_lists(self.send_idx.get(-1), self.send_idx.get(+1), self.recv_idx.get(-1), self.recv_idx.get(+1))
 
     def exchange_plus(self):
-        dist = self.dist
-        if self.t_plus is None:
-            self.t_plus = self._alias(self.ctx.BUF_PLUS)
-        with self._scope():
-            ops, keep = [], []
-            for side, idx in self.send_idx.items():
-                buf = self.t_plus[idx]
-                keep.append(buf)
-                ops.append(dist.P2POp(dist.isend, buf, self.sh.rank + side))
-                ops.append(dist.P2POp(dist.irecv, self.recv_buf[side], self.sh.rank + side))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            for side, idx in self.recv_idx.items():
-                self.t_plus[idx] = self.recv_buf[side]
-            self._keep = keep      # send buffers stay referenced until the next exchange
-        self._sync()
+        if self.transport is None:
+            self.ctx.shard_exchange_plus()
+            return
+        plus = self.ctx.host_buffer(self.ctx.BUF_PLUS)
+        got = self.transport.exchange({side: plus[idx].astype(np.uint8) for side, idx in self.send_idx.items()})
+        for side, bits in got.items():
+            plus[self.recv_idx[side]] = bits
 
     def reduce_residue_sets(self):
-        dist = self.dist
-        if self.t_res is None:
-            self.t_res = self._alias(self.ctx.BUF_RES_SETS)
-        with self._scope():
-            dist.all_reduce(self.t_res, op=dist.ReduceOp.MAX)
-        self._sync()
+        if self.transport is None:
+            self.ctx.shard_reduce_residue_sets()
+            return
+        res = self.ctx.host_buffer(self.ctx.BUF_RES_SETS)
+        res[:] = self.transport.allreduce_max(res)
 
 
 def run_shard_whole_structure(ctx, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, sh=None):

@@ -211,23 +211,45 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
-    # ARP_BENCH_SHARE_GPU=1 (debug only): every rank uses GPU 0 and the exchange goes over gloo, so the
-    # N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
+    # ARP_BENCH_SHARE_GPU=1 (debug only): every rank uses GPU 0 and the exchange goes through host buffers over gloo (RCCL
+    # refuses two ranks on one device), so the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
     share_gpu = os.environ.get('ARP_BENCH_SHARE_GPU') == '1'
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist, comm_device = None, torch.device('cuda', local_rank)
+    # Data path: the library's own RCCL communicator (arp_comm_*: ncclSend / ncclRecv / ncclAllReduce on the context's stream).
+    # torch.distributed (gloo, host) is the rendezvous only: it carries the 128-byte unique id, the barriers around the
+    # timed region and the reduction of the per-rank timings.
+    dist, comm_device = None, (None if share_gpu else torch.device('cuda', local_rank))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if share_gpu:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-            comm_device = None
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=comm_device)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from arpeggio_amd import synth, _capi
+
+    class HostTransport:
+        """arpeggio_amd.sharding's host-buffer transport over the rendezvous group (--host-halo and the one-GPU debug mode)."""
+
+        def exchange(self, payload):
+            sides = [s_ for s_ in (-1, +1) if 0 <= rank + s_ < world]
+            lens_out = {s_: torch.tensor([payload[s_].size if s_ in payload else 0], dtype=torch.int64) for s_ in sides}
+            lens_in = {s_: torch.zeros(1, dtype=torch.int64) for s_ in sides}
+            ops = [dist.P2POp(op, t[s_], rank + s_) for s_ in sides for op, t in ((dist.isend, lens_out), (dist.irecv, lens_in))]
+            for w_ in dist.batch_isend_irecv(ops):
+                w_.wait()
+            out = {s_: torch.from_numpy(np.ascontiguousarray(payload[s_], np.uint8)) for s_ in sides if s_ in payload and payload[s_].size}
+            inn = {s_: torch.empty(int(lens_in[s_].item()), dtype=torch.uint8) for s_ in sides if int(lens_in[s_].item())}
+            ops = [dist.P2POp(dist.isend, out[s_], rank + s_) for s_ in out] + [dist.P2POp(dist.irecv, inn[s_], rank + s_) for s_ in inn]
+            if ops:
+                for w_ in dist.batch_isend_irecv(ops):
+                    w_.wait()
+            return {s_: t.numpy() for s_, t in inn.items()}
+
+        def allreduce_max(self, a):
+            t = torch.from_numpy(np.ascontiguousarray(a).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.numpy()
 
     # ---------------- workload ----------------
     t0 = time.perf_counter()
@@ -251,18 +273,23 @@ def main():
                     f'(BASELINE configs[3]{"" if args.atoms * world == 2_000_000 else " family"}), one-cell halo over RCCL')
         # no fallback: if the exchange over RCCL fails, the run fails (a scaling figure must not be printed without it)
         ctx = _capi.Context(local_rank)
+        transport = HostTransport()
+        if comm_device is not None:
+            uid = torch.from_numpy(_capi.Context.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8))
+            dist.broadcast(uid, 0)
+            ctx.comm_init(rank, world, uid.numpy())
         t_sh = time.perf_counter()
-        if args.staged_exchange and comm_device is None:
-            args.host_halo = True      # (one-GPU debug mode over gloo: the per-step exchange then goes through host buffers, which needs the host-side shard)
+        if comm_device is None:
+            args.host_halo = True      # (one-GPU debug mode: no RCCL between ranks that share a device)
         if args.host_halo:
-            halo_note = 'records of the one-cell halo packed on the host, exchanged with grouped isend/irecv (RCCL), merged on the host'
-            shard = sharding.make_shard_distributed(full, rank, world, dist, device=comm_device)
+            halo_note = 'records of the one-cell halo packed on the host, exchanged through host buffers (gloo), merged on the host'
+            shard = sharding.make_shard_distributed(full, rank, world, transport)
             sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
             n_local = shard.pc.n_atoms
         else:
-            halo_note = ('home records uploaded once; the one-cell halo cut out on the device, exchanged with grouped isend/irecv on the '
-                         'device buffers (RCCL), merged into the resident structure on the device (arp_shard_*)')
-            shard = sharding.make_shard_device(ctx, full, rank, world, dist, comm_device, whole_structure=not args.staged_exchange)
+            halo_note = ('home records uploaded once; the one-cell halo cut out on the device, exchanged with grouped ncclSend / ncclRecv on the '
+                         'device buffers (RCCL behind the C ABI: arp_shard_exchange_faces), merged into the resident structure on the device (arp_shard_*)')
+            shard = sharding.make_shard_device(ctx, full, rank, world, whole_structure=not args.staged_exchange)
             n_local = shard.n_atoms
             shard_timings = shard.timings_ms
         shard_setup_ms = (time.perf_counter() - t_sh) * 1e3
@@ -281,15 +308,15 @@ def main():
         def step():
             return sharding.run_shard_whole_structure(ctx, args.cutoff, args.vdw_comp, False)
     elif comm_device is not None:
-        # device-resident exchange: torch tensors alias the context's buffers, RCCL moves the halo bits and reduces
-        # the residue sets between the three stages of the pass
-        exchange = sharding.DeviceExchange(ctx, shard, dist, comm_device)
+        # device-resident exchange: the library gathers the halo bits, moves them (ncclSend / ncclRecv) and reduces the
+        # residue sets (ncclAllReduce) on the context's stream between the three stages of the pass
+        exchange = sharding.DeviceExchange(ctx, shard)
 
         def step():
             return sharding.run_shard_device(ctx, exchange, args.cutoff, args.vdw_comp, False)
     else:
         def step():   # debug path (gloo, host buffers)
-            return sharding.run_shard(ctx, shard, dist, comm_device, args.cutoff, args.vdw_comp, False)
+            return sharding.run_shard(ctx, shard, transport, args.cutoff, args.vdw_comp, False)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -315,7 +342,7 @@ def main():
     trial_s = max(time.perf_counter() - t_trial, 1e-6)
     repeats = max(1, int(math.ceil(args.min_seconds / trial_s)))
     if dist is not None:
-        flag = torch.tensor([float(repeats)], device=('cpu' if comm_device is None else comm_device))
+        flag = torch.tensor([float(repeats)])
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         repeats = int(flag.item())
     sync_all()
@@ -503,7 +530,7 @@ def main():
     # max over ranks of the elapsed time, sum over ranks of the work
     cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
     if dist is not None:
-        rdev = 'cpu' if comm_device is None else comm_device
+        rdev = 'cpu'
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

@@ -121,6 +121,8 @@ typedef struct arp_ctx arp_ctx;
 const char* arp_version(void);
 /* device = HIP device ordinal.  Fails with ARP_E_HIP when no gfx950 device is
  * usable: there is no CPU fallback in this library. */
+/* GPUs this process can see (0: none, or no HIP runtime) */
+int  arp_device_count(void);
 int  arp_create(int device, arp_ctx** out);
 void arp_destroy(arp_ctx* ctx);
 const char* arp_last_error(arp_ctx* ctx);   /* ctx may be NULL: last create error */
@@ -401,6 +403,31 @@ int arp_host_free(void* p);
  * ranks.  arp_run_launch refuses (ARP_E_ARG) when the flag is on and the uploaded selection is partial.
  * Precondition: every residue of the table has at least one atom somewhere. */
 int arp_set_whole_structure(arp_ctx* ctx, int enabled);
+/* ---- exchange between the shards of a distributed structure: RCCL behind the C ABI (the reference has no
+ * multi-process mode, so nothing is replaced — these carry the one-cell halo the grid sharding needs).  One process per
+ * GPU, one arp_ctx each.  Rank 0 asks for a 128-byte id (arp_comm_unique_id) and hands it to the other processes by
+ * whatever means the application has (a file, MPI, a TCP store); every rank then calls arp_comm_init with it.  All
+ * transfers run on the context's stream (ncclSend / ncclRecv grouped per neighbour, one ncclAllReduce): no host
+ * synchronisation between the kernels of a stage and the exchange that follows.  `librccl.so` is loaded on first use. */
+int arp_comm_unique_id(uint8_t* out_id, uint64_t capacity /* >= 128 */);
+int arp_comm_init(arp_ctx* ctx, int rank, int world, const uint8_t* unique_id /* 128 bytes */);
+int arp_comm_destroy(arp_ctx* ctx);
+int arp_comm_info(arp_ctx* ctx, int* rank, int* world);          /* ARP_E_ARG while there is no communicator */
+/* Halo records of a structure: the two face buffers cut out by arp_shard_pack_face (device pointers; bytes = 0 or a missing
+ * neighbour: nothing sent) go to ranks rank - 1 / rank + 1, theirs arrive in buffers the context owns:
+ * received = {left pointer, left bytes, right pointer, right bytes}, valid until the next call — the arguments of
+ * arp_shard_assemble.  Sizes travel first (one 64-bit word each way), then the records. */
+int arp_shard_exchange_faces(arp_ctx* ctx, uint64_t left_ptr, uint64_t left_bytes, uint64_t right_ptr, uint64_t right_bytes,
+                             uint64_t received[4]);
+/* Per-pass selection exchange of a sharded run WITH a selection (arp_run_stage): the local indices of the atoms whose
+ * selection_plus bit each neighbour needs (my home atoms inside its halo, ascending global id) and of the halo atoms it
+ * owns (same order on its side).  Uploaded once per structure. */
+int arp_shard_set_exchange_lists(arp_ctx* ctx, const int32_t* send_left, int64_t n_send_left, const int32_t* send_right, int64_t n_send_right,
+                                 const int32_t* recv_left, int64_t n_recv_left, const int32_t* recv_right, int64_t n_recv_right);
+/* between stage 0 and stage 1: halo atoms take their selection_plus bit from their owner (gather, grouped send / recv, scatter) */
+int arp_shard_exchange_plus(arp_ctx* ctx);
+/* between stage 1 and stage 2: the residue sets (I:1413, 1431) OR-ed over all ranks, in place (ncclAllReduce, MAX over uint8) */
+int arp_shard_reduce_residue_sets(arp_ctx* ctx);
 /* Several structures in ONE pass — the reference's production use is the weekly PDBe release, ~10^5 entries of a few
  * thousand atoms each (README.md:4), and one such structure is four launches of fixed cost on this chip.  The caller
  * uploads the CONCATENATION of nstruct structures through the usual setters (atom / residue / ring / amide indices

@@ -281,3 +281,43 @@ def concat_packs(p, q, shift=(0.0, 0.0, 0.0)):
         amide_center=np.concatenate([p.amide_center, moved(q.amide_center)]),
         amide_normal=np.concatenate([p.amide_normal, q.amide_normal]),
         amide_res=np.concatenate([p.amide_res, link(q.amide_res, r)]).astype(np.int32))
+
+
+class GlooTransport:
+    """The host-buffer transport of arpeggio_amd.sharding over torch.distributed (gloo in the CPU tests): neighbour exchange of
+    uint8 arrays (sizes first) and an all-reduce (MAX).  Test infrastructure: the product moves its halos with RCCL behind the
+    C ABI and never imports torch."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def exchange(self, payload):
+        import torch
+        dist, rank = self.dist, self.rank
+        sides = [s for s in (-1, +1) if 0 <= rank + s < self.world]
+        lens_out = {s: torch.tensor([payload[s].size if s in payload else 0], dtype=torch.int64) for s in sides}
+        lens_in = {s: torch.zeros(1, dtype=torch.int64) for s in sides}
+        ops = []
+        for s in sides:
+            ops.append(dist.P2POp(dist.isend, lens_out[s], rank + s))
+            ops.append(dist.P2POp(dist.irecv, lens_in[s], rank + s))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        out = {s: torch.from_numpy(np.ascontiguousarray(payload[s], np.uint8)) if s in payload else torch.zeros(0, dtype=torch.uint8) for s in sides}
+        inn = {s: torch.empty(int(lens_in[s].item()), dtype=torch.uint8) for s in sides}
+        ops = []
+        for s in sides:
+            if out[s].numel():
+                ops.append(dist.P2POp(dist.isend, out[s], rank + s))
+            if inn[s].numel():
+                ops.append(dist.P2POp(dist.irecv, inn[s], rank + s))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return {s: inn[s].numpy() for s in sides if inn[s].numel()}
+
+    def allreduce_max(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.numpy()

@@ -619,48 +619,32 @@ def test_staged_run_equals_run_launch(ctx):
     assert ctx.stats()['expand_candidates'] > 0
 
 
-def test_device_exchange_over_nccl_world1():
-    """DeviceExchange on the real backend (nccl = RCCL) with a one-rank group: tensors aliasing the context's buffers,
-    in-place all-reduce of the residue sets, staged pass == arp_run_launch.  Runs in a subprocess (own process group)."""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, numpy as np, torch, torch.distributed as dist
-sys.path.insert(0, os.getcwd())
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1')
-dev = torch.device('cuda', 0)
-torch.cuda.set_device(0)
-dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-from arpeggio_amd import synth, sharding, _capi
-full = synth.slab_config(6000, 2, seed=8)
-sel = (full.res_id % 7 == 1).astype(np.uint8)
-sh = sharding.make_shard_distributed(full, 0, 1, dist, device=dev, sel=sel)
-ctx = _capi.Context(0)
-sharding.upload_shard(ctx, sh)
-ex = sharding.DeviceExchange(ctx, sh, dist, dev)          # shares one torch stream with the context: no host syncs in stages 0/1
-assert ex.stream is not None and ctx.stream_handle() == ex.stream.cuda_stream
-for _ in range(3):
-    c1 = sharding.run_shard_device(ctx, ex)
-a = ctx.atom_contacts_fetch(c1['atom_atom'])
-ctx.use_stream(0)
-ex2 = sharding.DeviceExchange(ctx, sh, dist, dev, share_stream=False)   # host-synchronised variant
-assert sharding.run_shard_device(ctx, ex2) == c1
-assert ex.t_plus.data_ptr() == ctx.device_buffer(ctx.BUF_PLUS)[0] and int(ex.t_plus.sum().item()) > 0
-ref = _capi.Context(0)
-ref.set_complex(full)
-ref.set_selection(sel)
-c2 = ref.run_launch()
-b = ref.atom_contacts_fetch(c2['atom_atom'])
-assert c1 == c2, (c1, c2)
-for k in ('i', 'j', 'sift', 'ctype'):
-    assert np.array_equal(a[k], b[k]), k
-assert np.array_equal(a['dist'].view(np.uint32), b['dist'].view(np.uint32))
-dist.destroy_process_group()
-print('NCCL_WORLD1_OK')
-'''
-    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert 'NCCL_WORLD1_OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+def test_device_exchange_over_rccl_world1():
+    """DeviceExchange on the real transport (RCCL behind the C ABI, a one-rank communicator) with a HOST-assembled shard:
+    the per-pass exchange calls run on the context's stream between the stages (gather / grouped send-recv / scatter,
+    in-place ncclAllReduce of the residue sets), staged pass == arp_run_launch, repeatedly."""
+    from arpeggio_amd import synth, sharding, _capi
+    full = synth.slab_config(6000, 2, seed=8)
+    sel = (full.res_id % 7 == 1).astype(np.uint8)
+    sh = sharding.make_shard_distributed(full, 0, 1, None, sel=sel)
+    ctx = _capi.Context(0)
+    ctx.comm_init(0, 1, _capi.Context.comm_unique_id())
+    sharding.upload_shard(ctx, sh)
+    ex = sharding.DeviceExchange(ctx, sh)
+    for _ in range(3):
+        c1 = sharding.run_shard_device(ctx, ex)
+    a = ctx.atom_contacts_fetch(c1['atom_atom'])
+    ref = _capi.Context(0)
+    ref.set_complex(full)
+    ref.set_selection(sel)
+    c2 = ref.run_launch()
+    b = ref.atom_contacts_fetch(c2['atom_atom'])
+    assert c1 == c2, (c1, c2)
+    for k in ('i', 'j', 'sift', 'ctype'):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a['dist'].view(np.uint32), b['dist'].view(np.uint32))
+    ctx.comm_destroy()
+    ctx.close(); ref.close()
 
 
 @pytest.mark.parametrize('selectors', [['/A/508/'], [], ['RESNAME:PHE'], ['LIGANDS']])

@@ -117,69 +117,35 @@ def test_device_assembly_rejects_bad_buffers(capi):
     c0.close(); c1.close()
 
 
-_TORCH_SCRIPT = r"""
-import sys
-import numpy as np
-import torch
-torch.cuda.set_device(0); torch.cuda.init()            # torch touches the device first (INTEGRATION.md)
-import torch.distributed as dist
-dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-from arpeggio_amd import _capi, sharding, synth
-dev = torch.device('cuda', 0)
-full = synth.slab_config(4000, 2, seed=6)
-c = [_capi.Context(0), _capi.Context(0)]
-step1 = [sharding.shard_home_to_device(c[r], full, r, 2) for r in range(2)]
-
-def through_torch(pb):      # both ends of exchange_device_buffers without the wire: alias the face buffer, copy into a torch tensor
-    t = torch.as_tensor(sharding._DevAlias(pb[0], pb[1]), device=dev)
-    r = torch.empty(pb[1], dtype=torch.uint8, device=dev)
-    r.copy_(t)
-    torch.cuda.synchronize(dev)
-    return (int(r.data_ptr()), int(r.numel()), r)
-
-got = []
-for r in range(2):
-    recv = {+1: through_torch(step1[1][0][-1])} if r == 0 else {-1: through_torch(step1[0][0][+1])}
-    ds = sharding.finish_shard_on_device(c[r], recv, step1[r][1], whole_structure=True)
-    n = sharding.run_shard_whole_structure(c[r], sh=ds)
-    got.append(c[r].atom_contacts_fetch(n['atom_atom']))
-one = _capi.Context(0)
-one.set_complex(full)
-n1 = one.run_launch()
-ref = one.atom_contacts_fetch(n1['atom_atom'])
-key = lambda d: d['i'].astype(np.int64) * full.n_atoms + d['j']
-union = np.sort(np.concatenate([key(g) for g in got]))
-assert np.array_equal(union, key(ref)), (len(union), len(ref['i']))
-# world 1 through the whole driver: no neighbours, no faces, the shard is the structure
-c1 = _capi.Context(0)
-ds = sharding.make_shard_device(c1, full, 0, 1, dist, dev, whole_structure=True)
-assert ds.n_atoms == full.n_atoms and sharding.run_shard_whole_structure(c1, sh=ds) == n1
-# ... and the three-stage pass with the exchange objects built from a device-assembled shard
-sel = (full.res_id %% 7 == 3).astype(np.uint8)
-c2 = _capi.Context(0)
-ds2 = sharding.make_shard_device(c2, full, 0, 1, dist, dev, sel=sel)
-ex = sharding.DeviceExchange(c2, ds2, dist, dev)
-one.set_selection(sel)
-assert sharding.run_shard_device(c2, ex) == one.run_launch()
-dist.destroy_process_group()
-print('TORCH_ALIAS_OK')
-"""
-
-
-def test_face_buffers_through_torch_tensors(capi):
-    """The torch side of ``exchange_device_buffers``: face buffers aliased as torch tensors (``__cuda_array_interface__``),
-    received into torch-owned memory, handed to arp_shard_assemble by pointer.  Own process: torch must start first."""
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    out = subprocess.run([sys.executable, '-c', _TORCH_SCRIPT % port], cwd=root, capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY='0'))
-    assert out.returncode == 0 and 'TORCH_ALIAS_OK' in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+def test_one_rank_communicator_through_the_c_abi(capi):
+    """arp_comm_* with a one-rank RCCL communicator (the boxes of this pool have one GPU): librccl.so is loaded, the
+    communicator is created from a unique id, the whole driver of a device-assembled shard runs (no neighbours: no faces
+    travel), and the three-stage pass with the per-pass exchange calls — gather / grouped send-recv / scatter with no
+    peers, ncclAllReduce over one rank on the context's stream — equals the single-context pass."""
+    full = synth.slab_config(4000, 2, seed=6)
+    one = capi.Context(0)
+    one.set_complex(full)
+    n1 = one.run_launch()
+    c1 = capi.Context(0)
+    c1.comm_init(0, 1, capi.Context.comm_unique_id())
+    ds = sharding.make_shard_device(c1, full, 0, 1, whole_structure=True)
+    assert ds.n_atoms == full.n_atoms and sharding.run_shard_whole_structure(c1, sh=ds) == n1
+    sel = (full.res_id % 7 == 3).astype(np.uint8)
+    c2 = capi.Context(0)
+    c2.comm_init(0, 1, capi.Context.comm_unique_id())
+    ds2 = sharding.make_shard_device(c2, full, 0, 1, sel=sel)
+    ex = sharding.DeviceExchange(c2, ds2)
+    one.set_selection(sel)
+    exp = one.run_launch()
+    assert sharding.run_shard_device(c2, ex) == exp
+    got, ref = c2.atom_contacts_fetch(exp['atom_atom']), one.atom_contacts_fetch(exp['atom_atom'])
+    for k in ('i', 'j', 'sift', 'ctype'):
+        assert np.array_equal(got[k], ref[k]), k
+    with pytest.raises(Exception):
+        c2.comm_init(0, 1, capi.Context.comm_unique_id())      # a second communicator on the same context is refused
+    c1.comm_destroy(); c2.comm_destroy()
+    for c in (c1, c2, one):
+        c.close()
 
 
 @pytest.mark.parametrize('seed', range(6))

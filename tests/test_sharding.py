@@ -11,6 +11,7 @@ import pytest
 
 import oracle
 from arpeggio_amd import sharding, synth
+from helpers import GlooTransport
 
 
 def _free_port():
@@ -188,9 +189,10 @@ def _worker_staged(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         full, sel = _workload()
-        sh = sharding.make_shard_distributed(full, rank, world, dist, device=None, sel=sel)
+        tr = GlooTransport(dist, rank, world)
+        sh = sharding.make_shard_distributed(full, rank, world, tr, sel=sel)
         ctx = _OracleStageContext(sh)
-        ex = sharding.DeviceExchange(ctx, sh, dist, None)
+        ex = sharding.DeviceExchange(ctx, sh, tr)
         out = sharding.run_shard_device(ctx, ex)
         gathered = [None] * world
         dist.all_gather_object(gathered, (True, out, ctx.masks['plus'], sh.global_id))
@@ -207,7 +209,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         full, sel = _workload()
-        sh = sharding.make_shard_distributed(full, rank, world, dist, device=None, sel=sel)
+        tr = GlooTransport(dist, rank, world)
+        sh = sharding.make_shard_distributed(full, rank, world, tr, sel=sel)
         ref = sharding.make_shard_local(full, rank, world, sel)
         same = all(np.array_equal(getattr(sh.pc, k), getattr(ref.pc, k)) for k in
                    ('xyz', 'vdw', 'type_mask', 'flags', 'res_id', 'res_prev', 'res_next', 'bond_off', 'bond_idx', 'h_off', 'h_xyz',
@@ -216,7 +219,7 @@ def _worker(rank, world, port, q):
             and np.array_equal(sh.sb_xyz, ref.sb_xyz) and np.array_equal(sh.origin, ref.origin)
         loc = oracle.OracleComplex(sh.pc)
         plus_local = loc.make_selection(sh.sel, use_grid=False)
-        masks = sharding.combine_selection(sh, plus_local, dist, device=None)   # plus-bit halo exchange + residue all-reduce
+        masks = sharding.combine_selection(sh, plus_local, tr)   # plus-bit halo exchange + residue all-reduce
         out = _eval_shard(sh, masks)
         gathered = [None] * world
         dist.all_gather_object(gathered, (same, out, masks['plus'], sh.global_id))
@@ -253,13 +256,14 @@ def test_gloo_halo_exchange_and_selection_combine(world, worker):
 
 @pytest.mark.gpu
 def test_two_ranks_over_rccl_when_two_gpus_are_visible():
-    """The real thing — two processes, two GPUs, backend nccl (= RCCL over xGMI): halo records exchanged with grouped
-    isend / irecv, the three-stage pass with the selection_plus bits and the residue sets exchanged on the device, and
-    the union of what the two ranks own equal to the single-GPU result.  Skipped on a one-GPU box."""
+    """The real thing — two processes, two GPUs, RCCL over xGMI behind the C ABI (arp_comm_init; the 128-byte id travels
+    over a gloo group that serves as rendezvous only): halo records exchanged with grouped ncclSend / ncclRecv, the
+    three-stage pass with the selection_plus bits and the residue sets exchanged on the context's stream, and the union
+    of what the two ranks own equal to the single-GPU result.  Skipped on a one-GPU box."""
     import subprocess
     import sys
-    import torch
-    if torch.cuda.device_count() < 2:
+    from arpeggio_amd import _capi      # (not torch: a second HIP / RCCL runtime in this process is what the workers are for)
+    if _capi.device_count() < 2:
         pytest.skip('needs two GPUs')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
