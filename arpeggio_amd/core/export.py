@@ -217,21 +217,28 @@ def write_contacts_json(path, pc, bags, component_types, indent=4):
     z = np.zeros(0, np.int32)
     ci = np.ascontiguousarray(b['i'], np.int32) if n else z
     cj = np.ascontiguousarray(b['j'], np.int32) if n else z
-    dist = np.round(np.asarray(b['dist'], np.float64), 2) if n else np.zeros(0)
+    dist = np.ascontiguousarray(b['dist'], np.float64) if n else np.zeros(0)     # rounded like np.round(x, 2) by the writer (flags bit 0)
     sift = np.ascontiguousarray(b['sift'], np.uint16) if n else np.zeros(0, np.uint16)
     ctype = np.ascontiguousarray(b['ctype'], np.uint8) if n else np.zeros(0, np.uint8)
 
+    keep = []
+
     def strings(items):
-        arr = (C.c_char_p * max(len(items), 1))()
-        for k, v in enumerate(items):
-            arr[k] = str(v).encode('utf-8')
-        return arr
+        """``const char* const*`` over ``items``: one NUL-separated buffer and a NumPy array of addresses into it."""
+        enc = [str(v).encode('utf-8') for v in items]
+        buf = C.create_string_buffer(b'\0'.join(enc) + b'\0')
+        off = np.zeros(max(len(enc), 1), np.uint64)
+        if len(enc) > 1:
+            np.cumsum(np.fromiter((len(e) + 1 for e in enc[:-1]), np.uint64, len(enc) - 1), out=off[1:])
+        ptrs = off + np.uint64(C.addressof(buf))
+        keep.append((buf, ptrs))
+        return _capi._p(ptrs)
 
     nr = pc.n_residues
     comp = [component_types[pc.res_name[r]] for r in range(nr)]       # KeyError like I:186
     atom_res = np.ascontiguousarray(pc.res_id, np.int32)
     res_seq = np.ascontiguousarray(pc.res_seq, np.int32)
-    rc = L.arp_write_contacts_json(os.fsencode(path), int(indent), 0, n, _capi._p(ci), _capi._p(cj), _capi._p(dist), _capi._p(sift),
+    rc = L.arp_write_contacts_json(os.fsencode(path), int(indent), 1, n, _capi._p(ci), _capi._p(cj), _capi._p(dist), _capi._p(sift),
                                    _capi._p(ctype), pc.n_atoms, _capi._p(atom_res), strings(pc.atom_name), nr, strings(pc.res_name),
                                    _capi._p(res_seq), strings(pc.res_chain), strings(pc.res_icode), strings(comp),
                                    strings(config.SIFT_NAMES), strings(config.CONTACT_TYPE_NAMES), tail_text.encode('utf-8'), len(tail))

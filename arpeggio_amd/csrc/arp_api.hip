@@ -546,21 +546,19 @@ int ensure_static(arp_ctx* c) {
     r.res_next = c->has_res ? c->res_next.p : nullptr;
     r.home = c->has_home ? c->home.p : nullptr;
     r.rad = c->rad.p; r.rad_idx = c->rad_idx.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.bond_idx = c->bond_idx.p; r.sb = c->sb.p;
-    HIPCHK(c, c->longest_bond.reserve(2));
-    HIPCHK(c, hipMemsetAsync(c->longest_bond.p, 0, 2 * sizeof(float), c->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p, c->st_b4.p);
-        hipLaunchKernelGGL(k_longest_bond, dim3(nblocks(n, 256, 512)), dim3(256), 0, c->stream, n, c->xyz.p, c->bond_off.p, c->bond_idx.p,
-                           c->h_off.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
-        CHK(check_launch(c, "k_prepare_static"));
-        // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure
+        // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure.  The longest-bond words sit
+        // behind the histogram, so ONE fill clears both.
         GridDesc d;
         CHK(grid_desc_for(c, d, c->lo, c->hi, 6.0));
         HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_q1.reserve((size_t)n)); HIPCHK(c, c->sp_b4.reserve((size_t)n));
         HIPCHK(c, c->sp_cr.reserve((size_t)n));
-        HIPCHK(c, c->sp_cnt.reserve((size_t)d.ncell + 1));
-        HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, ((size_t)d.ncell + 1) * sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_static_bin, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->st_xyzm.p, d, c->sp_cnt.p, c->sp_cr.p);
+        HIPCHK(c, c->sp_cnt.reserve((size_t)d.ncell + 4));
+        HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, ((size_t)d.ncell + 4) * sizeof(int), c->stream));
+        c->longest_bond.borrow(c->sp_cnt.p + d.ncell + 2, 2);
+        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p, c->st_b4.p,
+                           d, c->sp_cnt.p, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
+        CHK(check_launch(c, "k_prepare_static"));
         ScanSegs S;
         memset(&S, 0, sizeof(S));
         S.p[0] = c->sp_cnt.p; S.n[0] = d.ncell;
@@ -568,6 +566,11 @@ int ensure_static(arp_ctx* c) {
         hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, c->sp_cnt.p, c->st_xyzm.p,
                            c->st_aux.p, c->st_q1.p, c->st_b4.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p, c->sp_b4.p);
         CHK(check_launch(c, "k_static_permute"));
+    }
+    else {      // no atoms: nothing to order; the two longest-distance words still exist (zero)
+        HIPCHK(c, c->sp_cnt.reserve(4));
+        HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, 4 * sizeof(int), c->stream));
+        c->longest_bond.borrow(c->sp_cnt.p + 2, 2);
     }
     c->static_dirty = false;
     return ARP_OK;
@@ -1780,10 +1783,12 @@ void borrow_blob_views(arp_ctx* c, const arp_blob_header& h) {
 
 // Device-side validation of the resident blob (what arp_set_atoms ... check on the host) + the bookkeeping of a new
 // structure.  Waits for the stream.  `also` = further device error words OR-ed in (shard assembly), may be null.
-int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr) {
+int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr, bool gather_sb = false) {
     int* const d_err = (int*)(c->d_ctr + C_ERR);
+    const bool counters_were_zero = c->ctr_zero_ok;      // (the error word is the only counter touched here, and it ends as zero when all is well)
     c->ctr_zero_ok = false;
     HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(u64), c->stream));
+    if (gather_sb) HIPCHK(c, c->sb.reserve((size_t)std::max<int64_t>(h.n, 1)));
     BlobCheck bc;
     bc.n = (int)h.n; bc.nres = (int)h.nres; bc.nbond = (int)h.nbond; bc.nh = (int)h.nh; bc.nring = (int)h.nring; bc.namide = (int)h.namide;
     bc.nrad = (int)h.n_rad;
@@ -1795,6 +1800,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     bc.res_next = c->res_next.p; bc.bond_off = c->bond_off.p; bc.bond_idx = c->bond_idx.p; bc.h_off = c->h_off.p;
     bc.h_xyz = c->h_xyz_d.p; bc.sb_nbr = c->blob_sb_nbr.p; bc.ring_c = c->ring_c.p; bc.ring_res = c->ring_res.p;
     bc.am_c = c->am_c.p; bc.am_res = c->am_res.p; bc.err = d_err;
+    bc.sb_out = gather_sb ? c->sb.p : nullptr;
     const int64_t work = std::max({h.n, h.nbond, 3 * h.nh, h.nring, h.namide, h.nres, (int64_t)1});
     hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256)), dim3(256), 0, c->stream, bc);
     CHK(check_launch(c, "k_validate_blob"));
@@ -1823,6 +1829,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
                                     "offsets that are not a CSR, or an item that occurs twice)";
         return ARP_E_ARG;
     }
+    c->ctr_zero_ok = counters_were_zero;
     return ARP_OK;
 }
 }  // namespace
@@ -1836,12 +1843,7 @@ int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
     HIPCHK(c, c->blob_dev.reserve((size_t)h.bytes));
     HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, blob, (size_t)h.bytes, hipMemcpyHostToDevice, c->stream));
     borrow_blob_views(c, h);
-    CHK(validate_resident_blob(c, h, "arp_set_blob"));
-    if (h.n > 0) {
-        hipLaunchKernelGGL(k_gather_neighbours, dim3(nblocks(h.n, 256)), dim3(256), 0, c->stream, (int)h.n, c->blob_sb_nbr.p, c->xyz.p, c->sb.p);
-        CHK(check_launch(c, "k_gather_neighbours"));
-    }
-    return ARP_OK;
+    return validate_resident_blob(c, h, "arp_set_blob", nullptr, /*gather_sb=*/true);   // (one launch: checks + single-bond neighbour coordinates)
 }
 
 int arp_get_blob(arp_ctx* c, void* host, uint64_t cap, uint64_t* bytes) {

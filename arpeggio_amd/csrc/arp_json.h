@@ -105,9 +105,12 @@ extern "C" int arp_write_contacts_json(const char* path, int indent, int append_
     // per-atom and per-fingerprint text fragments are rendered once, pass 1 sizes every block of 8192 records (each record's
     // length is the sum of its fragments' lengths), a prefix sum gives every block its file offset, pass 2 renders the blocks
     // and writes them with pwrite() at their offsets.
-    (void)append_mode;
+    // flags (the parameter once called append_mode; 0 keeps the old meaning): bit 0 = `dist_rounded` holds the distances as
+    // computed (float32 values widened to double) and they are rounded here the way np.round(x, 2) rounds — rint(x * 100) / 100 —
+    const bool round_here = (append_mode & 1) != 0;
     if (!path || indent < 0 || n < 0 || n_atoms < 0 || n_res < 0) return -1;
     using namespace arpjson;
+    auto dist_of = [&](int64_t k) -> double { return round_here ? std::nearbyint(dist_rounded[k] * 100.0) / 100.0 : dist_rounded[k]; };
     const int i1 = indent, i2 = 2 * indent, i3 = 3 * indent;
     const int64_t total = n + n_tail;
     int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -126,6 +129,12 @@ extern "C" int arp_write_contacts_json(const char* path, int indent, int append_
     if (nthreads <= 0) {
         cpu_set_t set;
         nthreads = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        if (FILE* q = fopen("/sys/fs/cgroup/cpu.max", "r")) {      // a container's CPU quota counts, not the cores the host shows
+            long long quota = 0, period = 0;
+            if (fscanf(q, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                nthreads = std::min<long long>(nthreads, std::max<long long>(1, quota / period));
+            fclose(q);
+        }
         nthreads = std::min(nthreads, 32);
     }
     nthreads = std::max(1, nthreads);
@@ -200,20 +209,23 @@ extern "C" int arp_write_contacts_json(const char* path, int indent, int append_
             uint64_t bytes = 0;
             for (int64_t k = b * BLOCK, k1 = std::min(n, (b + 1) * BLOCK); k < k1; ++k)
                 bytes += fixed + atom_text[(size_t)ci[k]].size() + atom_text[(size_t)cj[k]].size() + contact_text[sift[k]].size() +
-                         number_len(dist_rounded[k]) + ctype_text[ctype[k]].size() + ((k + 1 < total) ? 2 : 1);
+                         number_len(dist_of(k)) + ctype_text[ctype[k]].size() + ((k + 1 < total) ? 2 : 1);
             off[(size_t)b + 1] = bytes;
         }
     });
     off[0] = 2;   // "[\n"
     for (int64_t b = 0; b < nblocks; ++b) off[(size_t)b + 1] += off[(size_t)b];
-    // ---- pass 2: render.  Buffered write()s to ONE file take the inode lock one after the other, so the blocks go straight
-    // into a shared mapping of the file (sized first); pwrite() is the fallback where the file cannot be mapped.
+    // ---- pass 2: render in parallel, write each block at its offset.  Buffered pwrite()s to ONE file take the inode lock one
+    // after the other (the copies into the page cache serialise at ~2-3 GB/s; the rendering overlaps them);
+    // ARP_EXPORT_MMAP=1 writes through a shared mapping instead (no inode lock, one page fault per 4 KiB: faster on tmpfs,
+    // slower on the overlay / ext4 file systems of the test boxes).
     std::string tail;
     if (n_tail > 0 && tail_records) { tail += tail_records; tail += "\n"; }
     tail += "]";
     const uint64_t file_bytes = off[(size_t)nblocks] + tail.size();
     char* map = nullptr;
-    if (ftruncate(fd, (off_t)file_bytes) == 0) {
+    const char* use_map = getenv("ARP_EXPORT_MMAP");
+    if (use_map && atoi(use_map) > 0 && ftruncate(fd, (off_t)file_bytes) == 0) {
         // (O_WRONLY files cannot be mapped shared: reopen read-write for the mapping)
         const int fd2 = open(path, O_RDWR);
         if (fd2 >= 0) {
@@ -234,7 +246,7 @@ extern "C" int arp_write_contacts_json(const char* path, int indent, int append_
             for (int64_t k = b * BLOCK, k1 = std::min(n, (b + 1) * BLOCK); k < k1; ++k) {
                 buf += f0; buf += atom_text[(size_t)ci[k]];
                 buf += f1; buf += contact_text[sift[k]];
-                buf += f2; number(buf, dist_rounded[k]);
+                buf += f2; number(buf, dist_of(k));
                 buf += f3; buf += atom_text[(size_t)cj[k]];
                 buf += f4; buf += ctype_text[ctype[k]];
                 buf += f5; buf += (k + 1 < total) ? ",\n" : "\n";

@@ -133,9 +133,9 @@ struct StaticAtoms {
 // (positive floats order like their bit patterns).
 // out[1] = the longest distance between an atom and one of its hydrogens (same rounding up): a hydrogen of D is no nearer to A
 // than |D - A| minus this, which lets k_sift leave the hydrogen loops of far pairs alone.
-__global__ __launch_bounds__(256) void k_longest_bond(int n, const float4* __restrict__ xyz, const int* __restrict__ bond_off,
-                                                      const int* __restrict__ bond_idx, const int* __restrict__ h_off,
-                                                      const double* __restrict__ h_xyz, unsigned int* __restrict__ out) {
+__device__ __forceinline__ void longest_bond_body(int n, const float4* __restrict__ xyz, const int* __restrict__ bond_off,
+                                                  const int* __restrict__ bond_idx, const int* __restrict__ h_off,
+                                                  const double* __restrict__ h_xyz, unsigned int* __restrict__ out) {
     float m = 0.0f, mh = 0.0f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 a = xyz[i];
@@ -182,6 +182,7 @@ struct BlobCheck {
     const float* am_c;
     const int* am_res;
     int* err;
+    float4* sb_out;               // not null: also the coordinates of every atom's single-bond heavy neighbour (k_gather_neighbours' work)
 };
 __global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
@@ -209,14 +210,24 @@ __global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc) {
         bad |= !(isfinite(rd.x) && isfinite(rd.y));
         const unsigned ri = bc.rad_idx[i];
         bad |= ri != RAD_NONE && ri >= (unsigned)bc.nrad;
-        bad |= bc.sb_nbr[i] < -1 || bc.sb_nbr[i] >= bc.n;
+        const int nb = bc.sb_nbr[i];
+        bad |= nb < -1 || nb >= bc.n;
+        if (bc.sb_out) {
+            float4 s_ = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nb >= 0 && nb < bc.n) { s_ = bc.xyz[nb]; s_.w = 1.0f; }
+            bc.sb_out[i] = s_;
+        }
     }
     if (bad) atomicExch(bc.err, ARP_E_ARG);
 }
 
+// Once per uploaded structure, ONE launch: the static record columns, the 6 A cell of every atom for their spatial order
+// (histogram + rank in cell: what k_static_bin did as a launch of its own) and the longest bond / atom - hydrogen distance.
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
-                                                        int4* __restrict__ st_q1, int4* __restrict__ st_b4) {
+                                                        int4* __restrict__ st_q1, int4* __restrict__ st_b4, GridDesc g6, int* __restrict__ cnt6,
+                                                        int2* __restrict__ cr6, const double* __restrict__ h_xyz, unsigned int* __restrict__ longest) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    longest_bond_body(n, r.xyz, r.bond_off, r.bond_idx, r.h_off, h_xyz, longest);
     for (int i = gtid; i < n; i += gstride) {
         float4 v = r.xyz[i];
         const int res = r.res_id[i];
@@ -240,6 +251,8 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         st_xyzm[i] = v;
         st_q1[i] = make_int4(i, b0, h0, bc | (hc << 8) | ((int)r.rad_idx[i] << 16));
         st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
+        const int c6 = cell_index(g6, num::d3{(double)v.x, (double)v.y, (double)v.z}, g6.place ? g6.sid_atom[i] : 0);
+        cr6[i] = make_int2(c6, atomicAdd(&cnt6[c6], 1));
     }
 }
 
@@ -257,14 +270,6 @@ __device__ __forceinline__ float4 compose_xyzm(const StaticAtoms& r, int i, int 
 }
 
 // ---- the spatial order of the static columns (once per structure) ----
-__global__ __launch_bounds__(256) void k_static_bin(int n, const float4* __restrict__ st_xyzm, GridDesc g, int* __restrict__ cnt,
-                                                    int2* __restrict__ cr) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 v = st_xyzm[i];
-        const int c = cell_index(g, num::d3{(double)v.x, (double)v.y, (double)v.z}, g.place ? g.sid_atom[i] : 0);
-        cr[i] = make_int2(c, atomicAdd(&cnt[c], 1));
-    }
-}
 __global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __restrict__ cr, const int* __restrict__ start,
                                                         const float4* __restrict__ st_xyzm, const int4* __restrict__ st_aux,
                                                         const int4* __restrict__ st_q1, const int4* __restrict__ st_b4,

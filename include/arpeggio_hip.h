@@ -547,10 +547,13 @@ int arp_cif_column_i64(const arp_cif* t, int col, int64_t missing, int64_t* out,
  * (sorted keys, indentation, float repr and string escaping of Python's json module) — a Python dict per record costs
  * seconds on a whole-structure run — followed by `tail_records`: the n_tail records of the four ring / amide bags, already
  * rendered at the same indentation and joined with ",\n" (they are few; the Python layer renders them).
- * dist_rounded = round(float64(distance), 2) of every contact (I:190).  sift_names: 15 strings, ctype_names: 7 strings.
+ * dist = float64(distance) of every contact; flags bit 0: round it here as I:190 does (round(x, 2) = rint(x * 100) / 100),
+ * flags = 0: the caller has rounded already.  sift_names: 15 strings, ctype_names: 7 strings.
+ * The records are rendered and written by several host threads (ARP_EXPORT_THREADS; default: the CPUs / CPU quota of the
+ * process, at most 32): 814 MB for a 100 k-atom structure in 0.12 s of library time on a 16-CPU quota, 0.41 s with one.
  * Returns 0, or a negative number (-1 bad argument, -2 cannot open, -3 index out of range, -4 write error). */
-int arp_write_contacts_json(const char* path, int indent, int append_mode, int64_t n, const int32_t* ci, const int32_t* cj,
-                            const double* dist_rounded, const uint16_t* sift, const uint8_t* ctype, int64_t n_atoms,
+int arp_write_contacts_json(const char* path, int indent, int flags, int64_t n, const int32_t* ci, const int32_t* cj,
+                            const double* dist, const uint16_t* sift, const uint8_t* ctype, int64_t n_atoms,
                             const int32_t* atom_res, const char* const* atom_name, int64_t n_res,
                             const char* const* res_name, const int32_t* res_seq, const char* const* res_chain,
                             const char* const* res_icode, const char* const* res_comp_type,

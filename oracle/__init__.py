@@ -134,12 +134,17 @@ class OracleComplex:
         return plus
 
     # I:693-936
-    def atom_contacts(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, use_grid=True):
+    def atom_contacts(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, use_grid=True, cap_hint=None):
+        """``cap_hint``: a capacity known to be enough (e.g. the count of an earlier call on the same structure): the
+        search and the per-pair evaluation then run ONCE instead of once to count and once to fill (bench.py's baseline)."""
         L = lib()
         stats = np.zeros(8, np.int64)
         err = C.c_int(0)
         args = (C.byref(self.s), C.c_double(cutoff), C.c_double(vdw_comp), int(include_sequence_adjacent), int(use_grid))
-        cnt = L.orc_atom_contacts(*args, C.c_int64(0), None, None, None, None, None, _p(stats), C.byref(err))
+        if cap_hint is None:
+            cnt = L.orc_atom_contacts(*args, C.c_int64(0), None, None, None, None, None, _p(stats), C.byref(err))
+        else:
+            cnt = int(cap_hint)
         cap = max(int(cnt), 1)
         oi, oj = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
         od, osf, oc = np.zeros(cap, np.float32), np.zeros(cap, np.uint16), np.zeros(cap, np.uint8)

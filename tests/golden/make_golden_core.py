@@ -47,6 +47,7 @@ import operator
 import os
 import sys
 import tempfile
+import time
 import types
 from functools import reduce
 
@@ -679,6 +680,47 @@ def main():
         add(name, pc, out, pack='proteinlike', selectors=selectors, sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode='canonical')
         if exp:
             exports[name] = exp
+    # the WHOLE stand-in (BASELINE configs[1]: no selectors = every atom, I:1395) — I:709 rebuilds set(self.selection) for every
+    # neighbour pair, ~1e9 hash inserts here: minutes, once — and the same with sequence-adjacent residues included
+    for tag, kw in (('whole', dict()), ('whole_seqadj', dict(seq_adj=True)), ('lig508_seqadj_comp', dict(selectors=['/A/508/'], seq_adj=True, comp=0.3, cutoff=4.5))):
+        t_run = time.time()
+        out, _ = run_case(IC, config, pc, bond_order=order, bond_aromatic=arom, **kw)
+        add(f'proteinlike:{tag}', pc, out, pack='proteinlike', selectors=kw.get('selectors'), sel=None, cutoff=kw.get('cutoff', 5.0),
+            comp=kw.get('comp', 0.1), seq_adj=kw.get('seq_adj', False), mode='canonical')
+        print(f'   ({time.time() - t_run:.0f} s)')
+    # ---- D. a structure that came through the mmCIF reader (core/protein_reader.read_mmcif): alternative locations (the B
+    # child wins on occupancy), insertion codes 17A / 17B, a modified residue in the chain, a chain break, hetero groups, waters
+    # of two names, and a heavy water (element D: not a hydrogen at I:712, but its deuterons are hydrogens to OpenBabel, I:1524)
+    import tempfile
+    from make_golden_reader import peptide_atom_site, chem_comp, cif_text
+    from arpeggio_amd.core import protein_reader
+    cols = peptide_atom_site(np.random.default_rng(5), 0)
+    nrow = len(cols['id'])
+
+    def add_row(**kv):
+        for k in cols:
+            cols[k].append(kv.get(k, cols[k][nrow - 1]))
+    ox = np.array([float(cols['Cartn_x'][3]) + 2.9, float(cols['Cartn_y'][3]) + 0.4, float(cols['Cartn_z'][3]) + 0.3])
+    for nm, el, d in (('O', 'O', (0, 0, 0)), ('D1', 'D', (0.76, 0.59, 0.0)), ('D2', 'D', (-0.76, 0.59, 0.0))):
+        add_row(group_PDB='HETATM', id=str(len(cols['id']) + 1), type_symbol=el, label_atom_id=nm, label_alt_id=None, label_comp_id='DOD',
+                label_asym_id='A', label_seq_id=False, pdbx_PDB_ins_code=None, Cartn_x='%.3f' % (ox[0] + d[0]), Cartn_y='%.3f' % (ox[1] + d[1]),
+                Cartn_z='%.3f' % (ox[2] + d[2]), occupancy='1.00', pdbx_formal_charge=None, auth_seq_id='450', auth_asym_id='A', pdbx_PDB_model_num='1')
+    cc = chem_comp(0)
+    cc['id'].append('DOD'); cc['type'].append('NON-POLYMER'); cc['name'].append('DEUTERATED WATER')
+    for k in cc:
+        if len(cc[k]) < len(cc['id']):
+            cc[k].append(None)
+    text = cif_text('READER', [('_atom_site.', cols), ('_chem_comp.', cc)], singles=[('_entry.id', 'READER')])
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, 'reader_h.cif')
+        open(fn, 'w').write(text)
+        rpc = protein_reader.read_mmcif(fn)
+    rpc.id = 'reader'
+    assert 'D' in rpc.element and np.diff(rpc.h_off).max() == 2           # the heavy water's oxygen carries both deuterons
+    arrays['reader/cif_text'] = np.array(text)
+    for tag, kw in (('whole', dict()), ('chain_b', dict(selectors=['/B//']))):
+        out, _ = run_case(IC, config, rpc, **kw)
+        add(f'reader:{tag}', rpc, out, pack='reader', selectors=kw.get('selectors'), sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode='canonical')
     small = synth.proteinlike(n_res=110, n_waters=70, id='proteinlike_small')
     o2, a2 = protein_bond_orders(small)
     out, exp = run_case(IC, config, small, bond_order=o2, bond_aromatic=a2, with_export=True)
