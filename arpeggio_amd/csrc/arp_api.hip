@@ -181,6 +181,11 @@ struct arp_ctx {
     DevBuf<int4> sp_aux, sp_q1;
     DevBuf<int> sp_cnt;
     DevBuf<int2> sp_cr;
+    DevBuf<int> sp_cell;          // cell of every row of the spatial order
+    GridDesc sp_grid{};           // the grid the spatial order was made for
+    double sp_radius = 0;         // ... and its cell edge (0: no order yet)
+    DevBuf<unsigned long long> compact_chain;   // k_compact_atoms: one word per block
+    unsigned int compact_epoch = 0;
     bool static_dirty = true;
     double host_enqueue_us = 0, host_wait_us = 0;   // arp_run_launch: time spent enqueueing / waiting (arp_get_host_times)
     int64_t host_passes = 0;
@@ -529,16 +534,22 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     return ARP_OK;
 }
 
-// selection-independent part of every atom record, rebuilt only when an input changed
-int ensure_static(arp_ctx* c) {
-    if (!c->static_dirty) return ARP_OK;
-    c->lists_dirty = true;
-    c->contacts_expected = 0;
+// Selection-independent part of every atom record (rebuilt only when an input changed) and its SPATIAL ORDER: the rows sorted
+// by cell of the grid with cell edge `radius` (counting sort, x fastest), which a pass with that cell edge compacts into its
+// contact grid in one launch (k_compact_atoms).  radius = 0: any order will do (the one that exists, 6 A when there is none).
+int ensure_static(arp_ctx* c, double radius = 0.0) {
+    if (radius <= 0) radius = c->sp_radius > 0 ? c->sp_radius : 6.0;
+    const bool columns = c->static_dirty;
+    if (!columns && c->sp_radius == radius) return ARP_OK;
     const int n = (int)c->n;
-    HIPCHK(c, c->st_q1.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->st_b4.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->st_xyzm.reserve((size_t)std::max(n, 1)));
+    if (columns) {
+        c->lists_dirty = true;
+        c->contacts_expected = 0;
+        HIPCHK(c, c->st_q1.reserve((size_t)std::max(n, 1)));
+        HIPCHK(c, c->st_b4.reserve((size_t)std::max(n, 1)));
+        HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
+        HIPCHK(c, c->st_xyzm.reserve((size_t)std::max(n, 1)));
+    }
     RawAtoms r;
     r.xyz = c->xyz.p; r.tmask = c->tmask.p; r.flags = c->flags.p; r.res_id = c->res_id.p;
     r.res_flags = c->has_res ? c->res_flags.p : nullptr;
@@ -547,31 +558,48 @@ int ensure_static(arp_ctx* c) {
     r.home = c->has_home ? c->home.p : nullptr;
     r.rad = c->rad.p; r.rad_idx = c->rad_idx.p; r.h_off = c->h_off.p; r.bond_off = c->bond_off.p; r.bond_idx = c->bond_idx.p; r.sb = c->sb.p;
     if (n > 0) {
-        // spatial order of the columns: counting sort by 6 A cell (x fastest), once per structure.  The longest-bond words sit
-        // behind the histogram, so ONE fill clears both.
+        // counting sort by cell.  The longest-bond words sit behind the histogram, so ONE fill clears both.
         GridDesc d;
-        CHK(grid_desc_for(c, d, c->lo, c->hi, 6.0));
+        CHK(grid_desc_for(c, d, c->lo, c->hi, radius));
         HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_q1.reserve((size_t)n)); HIPCHK(c, c->sp_b4.reserve((size_t)n));
-        HIPCHK(c, c->sp_cr.reserve((size_t)n));
-        HIPCHK(c, c->sp_cnt.reserve((size_t)d.ncell + 4));
-        HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, ((size_t)d.ncell + 4) * sizeof(int), c->stream));
-        c->longest_bond.borrow(c->sp_cnt.p + d.ncell + 2, 2);
-        hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p, c->st_b4.p,
-                           d, c->sp_cnt.p, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
+        HIPCHK(c, c->sp_cr.reserve((size_t)n)); HIPCHK(c, c->sp_cell.reserve((size_t)n));
+        // layout of sp_cnt: [longest bond, longest atom - hydrogen distance, 2 words of padding | histogram of ncell + 1 cells]:
+        // a fresh structure clears all of it with ONE fill, a new order for resident columns only the histogram
+        float keep_longest[2] = {0.0f, 0.0f};
+        const size_t want = (size_t)d.ncell + 8;
+        const bool regrow = !columns && c->sp_cnt.cap < want;
+        if (regrow) {      // (a larger grid for resident columns: the two words survive the reallocation through the host)
+            HIPCHK(c, hipMemcpyAsync(keep_longest, c->sp_cnt.p, sizeof(keep_longest), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        HIPCHK(c, c->sp_cnt.reserve(want));
+        int* const hist = c->sp_cnt.p + 4;
+        c->longest_bond.borrow(c->sp_cnt.p, 2);
+        if (columns) {
+            HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, want * sizeof(int), c->stream));
+            hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p, c->st_b4.p,
+                               d, hist, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
+        } else {
+            if (regrow) HIPCHK(c, hipMemcpyAsync(c->sp_cnt.p, keep_longest, sizeof(keep_longest), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(hist, 0, ((size_t)d.ncell + 4) * sizeof(int), c->stream));
+            hipLaunchKernelGGL(k_static_bin, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->st_xyzm.p, d, hist, c->sp_cr.p);
+        }
         CHK(check_launch(c, "k_prepare_static"));
         ScanSegs S;
         memset(&S, 0, sizeof(S));
-        S.p[0] = c->sp_cnt.p; S.n[0] = d.ncell;
+        S.p[0] = hist; S.n[0] = d.ncell;
         hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, c->stream, S);
-        hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, c->sp_cnt.p, c->st_xyzm.p,
-                           c->st_aux.p, c->st_q1.p, c->st_b4.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p, c->sp_b4.p);
+        hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, hist, c->st_xyzm.p,
+                           c->st_aux.p, c->st_q1.p, c->st_b4.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p, c->sp_b4.p, c->sp_cell.p);
         CHK(check_launch(c, "k_static_permute"));
+        c->sp_grid = d;
     }
     else {      // no atoms: nothing to order; the two longest-distance words still exist (zero)
-        HIPCHK(c, c->sp_cnt.reserve(4));
-        HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, 4 * sizeof(int), c->stream));
-        c->longest_bond.borrow(c->sp_cnt.p + 2, 2);
+        HIPCHK(c, c->sp_cnt.reserve(8));
+        HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, 8 * sizeof(int), c->stream));
+        c->longest_bond.borrow(c->sp_cnt.p, 2);
     }
+    c->sp_radius = radius;
     c->static_dirty = false;
     return ARP_OK;
 }
@@ -686,6 +714,46 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
 int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr,
                        ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
     return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
+}
+// The contact grid of a pass as an ordered compaction of the static columns (k_compact_atoms): ONE launch.
+int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t forb, u64* total_out, uint8_t* plus_init, ResMarks rm) {
+    Grid& G = c->atom_grid;
+    const int n = (int)c->n;
+    CHK(grid_desc_for(c, G.d, c->lo, c->hi, radius));
+    G.radius = radius;
+    G.n_points = n;
+    const int ncell = G.d.ncell;
+    HIPCHK(c, G.start.reserve(scan_padded(ncell)));
+    HIPCHK(c, c->s_xyzm.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_aux.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_rec.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_b4.reserve((size_t)std::max(n, 1)));
+    CHK(ensure_static(c, radius));
+    if (n > 0) {
+        Prof p(c, SLOT_BIN);
+        const int nb = (n + COMPACT_THREADS - 1) / COMPACT_THREADS;
+        bool fresh = false;
+        HIPCHK(c, c->compact_chain.reserve((size_t)nb, &fresh));
+        if (fresh || c->compact_epoch >= (1u << 30) - 1u) {   // new buffer, or the 30-bit launch number wraps: no stale word may match
+            HIPCHK(c, hipMemsetAsync(c->compact_chain.p, 0, c->compact_chain.cap * sizeof(unsigned long long), c->stream));
+            c->compact_epoch = 0;
+        }
+        ++c->compact_epoch;
+        CompactArgs A;
+        A.r = static_atoms(c);
+        A.sp_cell = c->sp_cell.p; A.n = n; A.ncell = ncell; A.req = req; A.forb = forb;
+        A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_rec = c->s_rec.p; A.s_b4 = c->s_b4.p;
+        A.start = G.start.p; A.chain = c->compact_chain.p; A.epoch = c->compact_epoch; A.total_out = total_out;
+        A.plus_init = plus_init; A.rm = rm; A.err = (int*)(c->d_ctr + C_ERR);
+        hipLaunchKernelGGL(k_compact_atoms, dim3(nb), dim3(COMPACT_THREADS), 0, c->stream, A);
+        CHK(check_launch(c, "k_compact_atoms"));
+    } else {
+        HIPCHK(c, hipMemsetAsync(G.start.p, 0, ((size_t)ncell + 1) * sizeof(int), c->stream));
+        if (total_out) HIPCHK(c, hipMemsetAsync(total_out, 0, sizeof(u64), c->stream));
+    }
+    G.valid = true;
+    G.n_binned = -1;
+    return ARP_OK;
 }
 // every atom (hydrogens included), used by the expansion and atom-plane; plus_init: also start selection_plus
 int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr, hipStream_t st = nullptr) {
@@ -820,7 +888,7 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
                            c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
-                           0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p);
+                           0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p, GroupMasks{});
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
@@ -1086,8 +1154,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                         all_res ? 1 : 0, c->ring_sel.p, c->ring_plus.p, c->am_sel.p, c->am_plus.p};
         if (c->n == 0) masks_after_bin = true;   // no scatter launch to carry them
     }
-    CHK(build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, cutoff, M_PLUS, M_HYDROGEN, nullptr, c->d_ctr + C_BINNED,
-                        c->init_plus_in_bin ? c->plus.p : nullptr, nullptr, rm, masks_after_bin ? GroupMasks{} : gm));
+    CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + C_BINNED, c->init_plus_in_bin ? c->plus.p : nullptr, rm));
     if (masks_after_bin && c->nring + c->namide > 0) {
         hipLaunchKernelGGL(k_group_masks, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, c->stream, gm);
         CHK(check_launch(c, "k_group_masks"));
@@ -1154,7 +1221,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
                            c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
                            include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
-                           c->d_ctr + C_STAT_ACC, (uint8_t*)nullptr);
+                           c->d_ctr + C_STAT_ACC, (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm);
         CHK(check_launch(c, "k_search<CONTACTS>"));
     }
     if (planes_alone) {
@@ -2319,7 +2386,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
-                           (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, (uint8_t*)nullptr);
+                           (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, (uint8_t*)nullptr, GroupMasks{});
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));
@@ -2659,7 +2726,7 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     auto enqueue_all = [&]() -> int {
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; c->pub.expected = 0; c->fuse_sets = false; c->init_plus_in_bin = false; } } unclean{c};
-        CHK(ensure_static(c));
+        CHK(ensure_static(c, cutoff));       // (the spatial order of the columns is the one of this pass's cells)
         // The pass ends inside its last kernel (k_sift_planes): the last block to finish publishes the counters.
         static const int inkernel_publish = env_int("ARP_INKERNEL_PUBLISH", 1);
         c->pub = PublishArgs{c->d_ctr, c->h_ctr_pinned, 0, 0};

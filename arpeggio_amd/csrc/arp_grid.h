@@ -202,14 +202,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles_chained(const int* __restri
         if (lane < 16) sh[16 + lane] = w_incl;   // inclusive totals of waves 0..lane
         const int total = __shfl(w_incl, 15);
         if (lane == 0)
-            __hip_atomic_store(chain + tile, ((unsigned long long)epoch << 32) | (unsigned int)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(chain + tile, ((unsigned long long)epoch << 32) | (unsigned int)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the word is all a reader needs)
         // the totals of the tiles before this one (lane l takes tiles l, l + 64)
         int before = 0;
         for (int k = lane; k < tile; k += 64) {
             unsigned long long w = 0;
             int spins = 0;
             for (;;) {
-                w = __hip_atomic_load(chain + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                w = __hip_atomic_load(chain + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned int)(w >> 32) == epoch) break;
                 if (++spins > (1 << 20)) { atomicExch(err, -2 /* ARP_E_HIP */); w = 0; break; }
                 __builtin_amdgcn_s_sleep(2);

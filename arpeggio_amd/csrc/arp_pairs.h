@@ -270,11 +270,20 @@ __device__ __forceinline__ float4 compose_xyzm(const StaticAtoms& r, int i, int 
 }
 
 // ---- the spatial order of the static columns (once per structure) ----
+// the same binning alone: a pass with another cell edge re-orders the columns of a structure that is already resident
+__global__ __launch_bounds__(256) void k_static_bin(int n, const float4* __restrict__ st_xyzm, GridDesc g, int* __restrict__ cnt,
+                                                    int2* __restrict__ cr) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 v = st_xyzm[i];
+        const int c = cell_index(g, num::d3{(double)v.x, (double)v.y, (double)v.z}, g.place ? g.sid_atom[i] : 0);
+        cr[i] = make_int2(c, atomicAdd(&cnt[c], 1));
+    }
+}
 __global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __restrict__ cr, const int* __restrict__ start,
                                                         const float4* __restrict__ st_xyzm, const int4* __restrict__ st_aux,
                                                         const int4* __restrict__ st_q1, const int4* __restrict__ st_b4,
                                                         float4* __restrict__ sp_xyzm, int4* __restrict__ sp_aux, int4* __restrict__ sp_q1,
-                                                        int4* __restrict__ sp_b4) {
+                                                        int4* __restrict__ sp_b4, int* __restrict__ sp_cell) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 c = cr[i];
         const int pos = start[c.x] + c.y;
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __res
         sp_aux[pos] = st_aux[i];
         sp_q1[pos] = st_q1[i];
         sp_b4[pos] = st_b4[i];
+        sp_cell[pos] = c.x;
     }
 }
 
@@ -479,6 +489,141 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     }
 }
 
+// ---- the contact grid of a pass in ONE launch ---------------------------------------------------------------------
+// The static columns of a structure are kept in the order of the pass's own cells (ensure_spatial: counting sort by cell,
+// once per structure and cell edge).  The atoms a pass lets into its grid — selection_plus without hydrogens, I:707-712 —
+// are then an ORDERED subset of that array: the grid build is a stream compaction.  Every 1024-thread block takes 1024
+// consecutive rows, counts what it keeps (ballot / popcount), publishes the count and finds its base with a decoupled
+// look-back over the blocks before it (one 64-bit word per block: launch number, state, value — nothing to clear between
+// launches), writes the kept records at base + rank, and the first row of every cell writes the cell's new start.  No
+// histogram, no atomics on cells, no second launch: 8.7 + 9.6 us for k_bin_atoms + k_scan_scatter_atoms become one kernel.
+struct CompactArgs {
+    StaticAtoms r;             // columns in cell order + the selection of the moment
+    const int* sp_cell;        // cell of every row (ascending)
+    int n, ncell;
+    uint32_t req, forb;        // kept: (meta & req) == req && !(meta & forb)
+    float4* s_xyzm;
+    int4* s_aux;
+    SiftRec* s_rec;
+    int4* s_b4;
+    int* start;                // out: ncell + 1
+    unsigned long long* chain; // one word per block
+    unsigned int epoch;        // launch number (30 bits)
+    unsigned long long* total_out;
+    uint8_t* plus_init;        // not null: selection_plus = selection (I:1407), by local id
+    ResMarks rm;
+    int* err;
+};
+#define CHAIN_AGG 1ull
+#define CHAIN_PFX 2ull
+__device__ __forceinline__ unsigned long long chain_word(unsigned int epoch, unsigned long long state, unsigned int value) {
+    return ((unsigned long long)epoch << 34) | (state << 32) | (unsigned long long)value;
+}
+#ifndef COMPACT_THREADS
+#define COMPACT_THREADS 1024
+#endif
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A) {
+    __shared__ int s_wtot[16], s_woff[16];
+    __shared__ int s_base;
+    constexpr int NW = COMPACT_THREADS / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * COMPACT_THREADS + threadIdx.x;
+    const bool valid = i < A.n;
+    const int ii = valid ? i : A.n - 1;
+    const bool need_aux = !A.r.all || A.rm.res_sel || A.plus_init;
+    const int4 aux = A.r.aux[ii];
+    const float4 xyzm = compose_xyzm(A.r, ii, aux.x);
+    const uint32_t m = __float_as_uint(xyzm.w);
+    (void)need_aux;
+    if (valid) {
+        if (A.plus_init) A.plus_init[aux.x] = A.r.all ? (uint8_t)1 : A.r.sel[aux.x];   // I:1407
+        if (A.rm.res_sel) {   // I:1413, 1431: residues of the selection / of selection_plus (hydrogens included), tagged with the pass
+            if (m & M_SEL) A.rm.res_sel[aux.y] = A.rm.tag;
+            if (m & M_PLUS) A.rm.res_plus[aux.y] = A.rm.tag;
+        }
+    }
+    const bool keep = valid && ((m & A.req) == A.req) && !(m & A.forb);
+    // the columns of a kept row travel while the counts meet
+    const int4 q1 = A.r.q1[ii], b4 = A.r.b4[ii];
+    const int my_cell = A.sp_cell[ii];
+    const int prev_cell = (i > 0 && valid) ? A.sp_cell[i - 1] : -1;
+    const unsigned long long mk = __ballot(keep);
+    const int rank_w = __popcll(mk & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wtot[wv] = __popcll(mk);
+    __syncthreads();
+    if (wv == 0) {
+        // block total, wave offsets; publish the aggregate; look back for the base
+        int t = (lane < NW) ? s_wtot[lane] : 0;
+        int incl = t;
+#pragma unroll
+        for (int off = 1; off < NW; off <<= 1) {
+            const int u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
+        }
+        if (lane < NW) s_woff[lane] = incl - t;
+        const int total = __shfl(incl, NW - 1);
+        const int b = (int)blockIdx.x;
+        // (relaxed device-scope atomics: a word carries everything its readers need — no other memory is published through it,
+        // so none of the L2 write-back / invalidate of a release / acquire pair is wanted: that pair cost 44 us in round 1)
+        if (lane == 0)
+            __hip_atomic_store(A.chain + b, chain_word(A.epoch, b == 0 ? CHAIN_PFX : CHAIN_AGG, (unsigned)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int base = 0;
+        for (int hi = b - 1; hi >= 0; hi -= 64) {       // 64 predecessors at a time, nearest first: lane l looks at block hi - l
+            const int k = hi - lane;
+            unsigned long long wd = chain_word(A.epoch, CHAIN_PFX, 0);      // (lanes before block 0: a zero prefix)
+            if (k >= 0) {
+                int spins = 0;
+                for (;;) {
+                    wd = __hip_atomic_load(A.chain + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(wd >> 34) == A.epoch) break;
+                    if (++spins > (1 << 20)) { atomicExch(A.err, -2 /* ARP_E_HIP */); wd = chain_word(A.epoch, CHAIN_PFX, 0); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const bool is_pfx = ((wd >> 32) & 3ull) == CHAIN_PFX;
+            const unsigned long long mp = __ballot(is_pfx);
+            const int stop = mp ? (__ffsll((long long)mp) - 1) : 64;      // nearest block that knows its whole prefix
+            int v = (lane <= stop) ? (int)(unsigned int)wd : 0;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            base += v;
+            if (mp) break;
+        }
+        if (lane == 0) {
+            s_base = base;
+            if (b > 0) __hip_atomic_store(A.chain + b, chain_word(A.epoch, CHAIN_PFX, (unsigned)(base + total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b == (int)gridDim.x - 1 && A.total_out) *A.total_out = (unsigned long long)(base + total);
+        }
+    }
+    __syncthreads();
+    const int kp = s_base + s_woff[wv] + rank_w;        // kept rows before this one
+    if (keep) {
+        A.s_xyzm[kp] = xyzm;
+        A.s_aux[kp] = aux;
+        if (A.s_rec) {
+            SiftRec q;
+            q.xyzm = xyzm;
+            q.q1 = q1;
+            A.s_rec[kp] = q;
+            A.s_b4[kp] = b4;
+        }
+    }
+    // The first row of a cell knows where the cell's kept rows begin; so do the empty cells before it (a protein in its
+    // bounding box, the gaps between the structures of a batch: runs of thousands), which the wave fills together.
+    if (valid && my_cell != prev_cell) A.start[my_cell] = kp;
+    const bool last = valid && i == A.n - 1;
+    unsigned long long mg = __ballot((valid && my_cell - prev_cell > 1) || last);
+    while (mg) {
+        const int l = __ffsll((long long)mg) - 1;
+        mg &= mg - 1ull;
+        const int lo = __shfl(prev_cell, l) + 1, hi = __shfl(my_cell, l), v = __shfl(kp, l);
+        for (int c = lo + lane; c < hi; c += 64) A.start[c] = v;
+        if (__shfl(last ? 1 : 0, l)) {       // cells after the last row: the total
+            const int tot = v + __shfl(keep ? 1 : 0, l);
+            for (int c = hi + 1 + lane; c <= A.ncell; c += 64) A.start[c] = tot;
+        }
+    }
+}
+
 // ---- end of a pass, without a launch of its own ------------------------------------------------------------
 // The last kernels of a pass (k_sift on the main stream, k_planes beside it on the second one) call pass_end() as their
 // final statement: every block takes a ticket once its own atomics have been performed, the last block of a kernel
@@ -574,7 +719,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                                                                int include_seq_adj, int count_owned, int2* __restrict__ pairs,
                                                                unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
-                                                               uint8_t* __restrict__ plus) {
+                                                               uint8_t* __restrict__ plus, GroupMasks gm) {
+    // ring / amide sets of _make_selection (I:1433-1437) from the residue tags the grid build of this pass left: every thread
+    // of the launch takes at most a few (nothing to do when gm is empty)
+    group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ int2 q[MODE == MODE_MARK ? 1 : SEARCH_WAVES][QCAP];   // (the expansion search queues nothing)
     __shared__ float4 s_hx[SEARCH_WAVES][HOME_BLOCK];   // home atoms of the moment: x, y, z, meta
     __shared__ int4 s_ha[SEARCH_WAVES][HOME_BLOCK];     //                         local id, residue, prev, next
