@@ -574,12 +574,14 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     # The number that actually bounds these kernels: VALU issue.  SQ_INSTS_VALU of the committed PMC run (per launch) /
-    # (launch duration x 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32)
+    # (launch duration x 1024 SIMDs x 2.4 GHz / 4 cycles: a wave64 instruction occupies its 16-lane SIMD four cycles —
+    # SQ_ACTIVE_INST_VALU counts one quad-cycle per instruction in every committed profile; only packed-FP32 work gets two
+    # results per lane and cycle, and these kernels are integer / compare / float64 code)
     roofline_valu = None
     try:
         pv = pj['kernels'][f'k_{dom}']
         if args.atoms == 100_000 and world == 1 and 'valu_insts_per_launch' in pv:
-            peak = 1024 * 2.4e9 / 2.0
+            peak = 1024 * 2.4e9 / 4.0
             roofline_valu = {'kernel': f'k_{dom}', 'valu_wave_instructions_per_launch': pv['valu_insts_per_launch'],
                              'issue_peak_per_s': peak, 'frac': round(pv['valu_insts_per_launch'] / (dom_ms * 1e-3) / peak, 4),
                              'source': f'instruction count from the committed profile, NOT this run ({pj["source"]}); duration of this run'}
@@ -590,8 +592,8 @@ def main():
                 'traffic_source': (None if traffic_src is None else f'committed profile, NOT this run: {traffic_src}'),
                 'algorithmic_bytes_per_launch': int(b_alg), 'algorithmic_bytes_without_hydrogen_coordinates': int(b_alg - (24 * n_h if dom == 'sift' else 0)),
                 'avg_launch_ms': round(dom_ms, 5),
-                'note': {'search': 'VALU / LDS issue-bound geometry kernel (12 M wave-instructions per launch, profiles/round2_k_pmc_per_launch.csv); ',
-                         'sift': 'gather-latency-bound at 4 waves per SIMD (125 VGPRs): 72 % of the wave cycles are waits (SQ_WAIT_ANY); ',
+                'note': {'search': 'VALU-issue-bound geometry kernel (8.8 M wave-instructions per launch at ~4 cycles each, profiles/round3_pmc_per_launch.csv); ',
+                         'sift': 'VALU issue + gather latency at 4 waves per SIMD (127 VGPRs): 7.1 M wave-instructions per launch, 63 % of the wave cycles are waits (SQ_WAIT_ANY); ',
                          'mark_search': 'VALU / LDS issue-bound geometry kernel; '}.get(dom, '') +
                         'the HBM fraction is small by construction: register-tiled pair tests move ~35 MB per 100 k-atom pass (SURVEY 8d)'}
 
@@ -715,12 +717,12 @@ def main():
         'cpu_baseline_all_cores': cpu_mc,
         'cpu_baseline_python': cpu_py,
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
-        'launch_mode': 'four launches on one HIP stream (bin, scan+scatter, search, sift+ring/amide loops), the last one publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
+        'launch_mode': 'three launches on one HIP stream (k_compact_atoms = the contact grid, k_search, k_sift_planes = per-pair evaluation + ring/amide loops; kernel_ms lists them as bin / search / sift), the last one publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
         'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2), 'shard_setup_breakdown_ms': shard_timings,
         'halo_exchange': (halo_note if world > 1 else None),
         'scaling_note': (None if world == 1 else f'per-GPU work is {args.atoms} atoms (+ halo); the default N = 1 line is the 100 000-atom headline workload, '
-                                                 f'so the single-GPU figure to compare with is `bench.py --gpus 1 --atoms {args.atoms}` (profiles/README.md: 1.18e11 pairs/s at 250 000 atoms)'), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
+                                                 f'so the single-GPU figure to compare with is `bench.py --gpus 1 --atoms {args.atoms}` (profiles/round3_bench_250k.json: 1.55e11 pairs/s at 250 000 atoms)'), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
         'end_to_end': end_to_end,
         'end_to_end_ms_per_structure': (end_to_end or {}).get('ms_per_structure'),
         'get_contacts_ms': (end_to_end or {}).get('get_contacts_ms'),
