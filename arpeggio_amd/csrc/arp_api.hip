@@ -691,7 +691,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
                     }
                     ++G.chain_epoch;
                     hipLaunchKernelGGL(k_scan_tiles_chained, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.chain.p, G.chain_epoch, total_out,
-                                       (int*)(c->d_ctr + C_ERR));
+                                       (int*)(c->d_ctr + ctr_dev(C_ERR)));
                 } else {
                     hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, st, hist, ncell, G.start.p, G.sums.p);
                     hipLaunchKernelGGL(k_scan_fix, dim3((ncell + 4095) / 4096), dim3(1024), 0, st, G.start.p, ncell, G.sums.p, ntiles, total_out);
@@ -744,7 +744,7 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
         A.sp_cell = c->sp_cell.p; A.n = n; A.ncell = ncell; A.req = req; A.forb = forb;
         A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_rec = c->s_rec.p; A.s_b4 = c->s_b4.p;
         A.start = G.start.p; A.chain = c->compact_chain.p; A.epoch = c->compact_epoch; A.total_out = total_out;
-        A.plus_init = plus_init; A.rm = rm; A.err = (int*)(c->d_ctr + C_ERR);
+        A.plus_init = plus_init; A.rm = rm; A.err = (int*)(c->d_ctr + ctr_dev(C_ERR));
         hipLaunchKernelGGL(k_compact_atoms, dim3(nb), dim3(COMPACT_THREADS), 0, c->stream, A);
         CHK(check_launch(c, "k_compact_atoms"));
     } else {
@@ -779,10 +779,19 @@ int search_blocks_balanced(const arp_ctx* c, const GridDesc& d, int cpw) {
     return std::min(std::max(1, (nb + R / 2) / R) * R, 8192) & ~7;
 }
 
+// zero a range of LOGICAL counters (callers outside a whole pass: a pass zeroes the block as it publishes it)
 int zero_counter(arp_ctx* c, int first, int count) {
     if (c->ctr_clean) return ARP_OK;  // arp_run_launch cleared the whole block with one memset
     c->ctr_zero_ok = false;
-    HIPCHK(c, hipMemsetAsync(c->d_ctr + first, 0, sizeof(u64) * (size_t)count, c->stream));
+    if ((first == C_STAT_CAND || first == C_STAT_MCAND) && count == 2 * STAT_SLOTS) {   // two neighbouring words of every slot line: one 2-D fill
+        HIPCHK(c, hipMemset2DAsync(c->d_ctr + ctr_dev(first), sizeof(u64) * CTR_LINE, 0, 2 * sizeof(u64), STAT_SLOTS, c->stream));
+        return ARP_OK;
+    }
+    if (first == C_SEG_PAIRS && count == PAIR_SEGS) {                                   // eight whole lines
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(first), 0, sizeof(u64) * PAIR_SEGS * CTR_LINE, c->stream));
+        return ARP_OK;
+    }
+    for (int k = first; k < first + count; ++k) HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(k), 0, sizeof(u64), c->stream));
     return ARP_OK;
 }
 int enqueue_counter_copy(arp_ctx* c, int zero = 0) {  // counter block -> pinned host memory (capturable)
@@ -888,7 +897,7 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
                            c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
-                           0ull, c->d_ctr + C_SCRATCH0, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, c->plus.p, GroupMasks{});
+                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{});
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
@@ -997,7 +1006,7 @@ int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb, bool contact_grid 
         a = AtomPlaneArgs{c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
                           c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                           c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
-                          b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP,
+                          b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + ctr_dev(C_AP),
                           c->st_xyzm.p, c->sel_made ? c->sel.p : nullptr, (c->sel_made && c->sel_all) ? 1 : 0};
         nb = plane_blocks(c->nring);
         return ARP_OK;
@@ -1007,7 +1016,7 @@ int prepare_atom_plane(arp_ctx* c, AtomPlaneArgs& a, int& nb, bool contact_grid 
     a = AtomPlaneArgs{c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
                       c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                       c->has_group_owner ? c->ring_gid.p : nullptr, c->has_gid ? c->gid.p : nullptr, (long long)b.cap,
-                      b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + C_AP,
+                      b.a.p, b.b.p, b.d0.p, b.d1.p, b.u0.p, b.u1.p, c->d_ctr + ctr_dev(C_AP),
                       c->st_xyzm.p, c->sel_made ? c->sel.p : nullptr, (c->sel_made && c->sel_all) ? 1 : 0};
     nb = plane_blocks(c->nring);
     return ARP_OK;
@@ -1022,7 +1031,7 @@ int prepare_plane_plane(arp_ctx* c, PlanePlaneArgs& a, int& nb) {  // I:1064-119
     a = PlanePlaneArgs{c->ring_grid.d, c->ring_grid.start.p, c->ring_grid.perm.p, (int)c->nring, c->ring_c.p, c->ring_n.p,
                        c->ring_res.p, c->ring_sel.p, c->ring_plus.p, c->has_group_owner ? c->ring_home.p : nullptr,
                        c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
-                       b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + C_PP};
+                       b.d3.p, b.u0.p, b.u1.p, b.u2.p, c->d_ctr + ctr_dev(C_PP)};
     nb = plane_blocks(c->nring);
     return ARP_OK;
 }
@@ -1036,7 +1045,7 @@ int prepare_group_group(arp_ctx* c, GroupGroupArgs& a, int& nb) {  // I:1217-130
     a = GroupGroupArgs{c->amide_grid.d, c->amide_grid.start.p, c->amide_grid.perm.p, (int)c->namide, c->am_c.p, c->am_n.p,
                        c->am_sel.p, c->am_plus.p, c->has_group_owner ? c->am_home.p : nullptr,
                        c->has_group_owner ? c->am_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.f0.p, b.f1.p, b.f2.p,
-                       b.u0.p, c->d_ctr + C_GG};
+                       b.u0.p, c->d_ctr + ctr_dev(C_GG)};
     nb = plane_blocks(c->namide);
     return ARP_OK;
 }
@@ -1051,7 +1060,7 @@ int prepare_group_plane(arp_ctx* c, GroupPlaneArgs& a, int& nb) {  // I:1302-138
                        c->am_sel.p, c->am_plus.p, c->ring_c.p, c->ring_n.p, c->ring_sel.p, c->ring_plus.p,
                        c->has_group_owner ? c->am_home.p : nullptr, c->has_group_owner ? c->am_gid.p : nullptr,
                        c->has_group_owner ? c->ring_gid.p : nullptr, (long long)b.cap, b.a.p, b.b.p, b.d0.p, b.d1.p, b.d2.p,
-                       b.u0.p, c->d_ctr + C_GP};
+                       b.u0.p, c->d_ctr + ctr_dev(C_GP)};
     nb = plane_blocks(c->namide);
     return ARP_OK;
 }
@@ -1154,7 +1163,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                         all_res ? 1 : 0, c->ring_sel.p, c->ring_plus.p, c->am_sel.p, c->am_plus.p};
         if (c->n == 0) masks_after_bin = true;   // no scatter launch to carry them
     }
-    CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + C_BINNED, c->init_plus_in_bin ? c->plus.p : nullptr, rm));
+    CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + ctr_dev(C_BINNED), c->init_plus_in_bin ? c->plus.p : nullptr, rm));
     if (masks_after_bin && c->nring + c->namide > 0) {
         hipLaunchKernelGGL(k_group_masks, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, c->stream, gm);
         CHK(check_launch(c, "k_group_masks"));
@@ -1220,23 +1229,23 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
         hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
                            c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                           include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + C_SEG_PAIRS, c->d_ctr + C_STAT_CAND,
-                           c->d_ctr + C_STAT_ACC, (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm);
+                           include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                           c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm);
         CHK(check_launch(c, "k_search<CONTACTS>"));
     }
     if (planes_alone) {
         if (st2 != c->stream) HIPCHK(c, hipStreamWaitEvent(st2, c->ev_sel, 0));
         Prof p(c, SLOT_PLANES, st2);
-        hipLaunchKernelGGL(k_planes, dim3(np), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + C_PLIST, c->pub);
+        hipLaunchKernelGGL(k_planes, dim3(np), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + ctr_dev(C_PLIST), c->pub);
         CHK(check_launch(c, "k_planes"));
     }
     if (c->n > 0) {
         Prof p(c, SLOT_SIFT);
         static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
-        const SiftArgs sa{c->pairs.p, c->d_ctr + C_SEG_PAIRS, (u64)segcap, c->s_rec.p, c->s_b4.p,
+        const SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_rec.p, c->s_b4.p,
                           SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
-                          (int*)(c->d_ctr + C_ERR)};
+                          (int*)(c->d_ctr + ctr_dev(C_ERR))};
         // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
         // this structure found, or ~13 per heavy atom for the first one.  A protein-sized structure then runs 70-odd blocks
         // instead of 1024, whose start-up and end-of-pass tickets were most of the kernel (stand-in: 25 -> 16 us).
@@ -1249,10 +1258,10 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
         if (merged && stream_out)
             hipLaunchKernelGGL(k_sift_planes<1>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
-                               c->d_ctr + C_PLIST, np, c->pub);
+                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
         else if (merged)
             hipLaunchKernelGGL(k_sift_planes<0>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
-                               c->d_ctr + C_PLIST, np, c->pub);
+                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
         else if (stream_out)
             hipLaunchKernelGGL(k_sift<1>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         else
@@ -1402,8 +1411,8 @@ int arp_create(int device, arp_ctx** out) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_COUNT);
-    if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(u64) * C_COUNT);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_DEV_WORDS);
+    if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_ctr_pinned, sizeof(u64) * (C_COUNT + 1), hipHostMallocDefault);
     if (e == hipSuccess) memset(c->h_ctr_pinned, 0, sizeof(u64) * (C_COUNT + 1));
     if (e != hipSuccess) {
@@ -1851,7 +1860,7 @@ void borrow_blob_views(arp_ctx* c, const arp_blob_header& h) {
 // Device-side validation of the resident blob (what arp_set_atoms ... check on the host) + the bookkeeping of a new
 // structure.  Waits for the stream.  `also` = further device error words OR-ed in (shard assembly), may be null.
 int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr, bool gather_sb = false) {
-    int* const d_err = (int*)(c->d_ctr + C_ERR);
+    int* const d_err = (int*)(c->d_ctr + ctr_dev(C_ERR));
     const bool counters_were_zero = c->ctr_zero_ok;      // (the error word is the only counter touched here, and it ends as zero when all is well)
     c->ctr_zero_ok = false;
     HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(u64), c->stream));
@@ -2386,7 +2395,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
-                           (u64)cap, c->d_ctr + C_SEARCH_PAIRS, c->d_ctr + C_STAT_MCAND, c->d_ctr + C_STAT_MACC, (uint8_t*)nullptr, GroupMasks{});
+                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{});
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));
@@ -2719,7 +2728,7 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     // every stage enqueued back to back (no host synchronisation, no allocation once the buffers are sized)
     // the counter block must be zero when a pass starts; a pass leaves it zeroed (k_publish_counters)
     auto ensure_zero = [&]() -> int {
-        if (!c->ctr_zero_ok) HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
+        if (!c->ctr_zero_ok) HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS, c->stream));
         c->ctr_zero_ok = false;
         return ARP_OK;
     };
@@ -2754,7 +2763,7 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         if (small_sel) {
             Prof p(c, SLOT_MARK);
             hipLaunchKernelGGL(k_expand_small, dim3(nblocks(c->n, 256, 1 << 22)), dim3(256), 0, c->stream, (int)c->n, c->xyz.p, c->sel_list.p,
-                               (int)c->nsel, c->sel.p, expand_radius * expand_radius, c->plus.p, c->d_ctr + C_STAT_MCAND);
+                               (int)c->nsel, c->sel.p, expand_radius * expand_radius, c->plus.p, c->d_ctr + ctr_dev(C_STAT_MCAND));
             CHK(check_launch(c, "k_expand_small"));
         }
         // ring / amide grids: built once per structure
@@ -2859,7 +2868,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
             c->sel_all = true;
             c->sel_uploaded = true;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_COUNT, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS, c->stream));
         c->ctr_clean = true;
         int rc = enqueue_expansion(c, expand_radius);
         c->ctr_clean = false;
@@ -2887,8 +2896,9 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
     for (int attempt = 0;; ++attempt) {
         const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
         // the expansion statistics of stage 0 live in the counter block: keep them, clear the rest
-        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_STAT_MCAND, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_ctr + C_SEG_PAIRS, 0, sizeof(u64) * PAIR_SEGS, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * 5 * CTR_LINE, c->stream));                      // scalars, the four bags
+        HIPCHK(c, hipMemset2DAsync(c->d_ctr + ctr_dev(C_STAT_CAND), sizeof(u64) * CTR_LINE, 0, 2 * sizeof(u64), STAT_SLOTS, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(C_SEG_PAIRS), 0, sizeof(u64) * PAIR_SEGS * CTR_LINE, c->stream));
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
         if (c->nring + c->namide > 0)

@@ -30,8 +30,14 @@
 #define M_RES_HASSEQ (1u << 22)
 #define M_HOME (1u << 24)
 
-// device counters (one u64 each); kernels receive pointers to the slots they update
+// Counters of a pass (one u64 each).  The enum is the LOGICAL layout — the order of the page-locked host mirror and of every
+// h_ctr[] index.  On the device a counter sits at word ctr_dev(logical) of a block of 128-byte lines, because returning
+// atomics of different workgroups serialise per cache LINE, not per word (tools/micro/atomic_lines.hip: 768 blocks, one
+// atomic each — one word +8 us, eight neighbouring words +8 us, eight words on eight lines +0.9 us): everything that many
+// blocks hit at about the same moment — the pair-list heads, the statistics slots, the end-of-pass tickets, the result bags —
+// has a line of its own.  Kernels receive pointers to the first of their slots and step by CTR_LINE.
 #define STAT_SLOTS 16
+#define CTR_LINE 16   // u64 words per 128-byte line
 enum {
     C_PAIRS = 0,      // contact pairs enqueued (after the residue filters)
     C_CAND = 1,       // distance tests of the contact search
@@ -43,21 +49,32 @@ enum {
     C_SCRATCH0 = 10, C_SCRATCH1 = 11,
     C_BINNED = 12,    // atoms in the contact grid (low 32 bits)
     C_ERR = 15,       // ARP_E_* raised on the device (low 32 bits)
-    // statistics counters are spread over STAT_SLOTS addresses (hashed by block) so that the
-    // end-of-block atomics of thousands of blocks do not serialise on one L2 line
+    // statistics counters are spread over STAT_SLOTS lines (hashed by block): slot s holds {cand, acc, mark cand, mark acc}
     C_STAT_CAND = 16, C_STAT_ACC = 16 + STAT_SLOTS, C_STAT_MCAND = 16 + 2 * STAT_SLOTS, C_STAT_MACC = 16 + 3 * STAT_SLOTS,
     C_TAIL = 16 + 4 * STAT_SLOTS,
-    // the pair list is written in PAIR_SEGS segments, one queue head per XCD (blockIdx % 8): the
-    // per-block atomicAdd then runs on 8 different L2s instead of serialising on one address
+    // the pair list is written in PAIR_SEGS segments, one queue head per XCD (blockIdx % 8)
     C_SEG_PAIRS = C_TAIL,
     // end-of-pass tickets (pass_end): blocks of k_sift / k_planes that have finished, kernels that have finished
     // (two sets of 8 group tickets + 1 kernel ticket: the sift kernel and the ring / amide kernel end a pass together)
     C_TICKET_GROUP = C_TAIL + 16, C_TICKET_KERNEL = C_TAIL + 24, C_TICKET_SET = 16, C_KERNELS_DONE = C_TAIL + 15,
     C_PLIST = C_TAIL + 8,   // 4 slots: entries of the static ring / amide candidate lists (copied from their own counters each pass)
-    // 128 words in all: the last block of a pass hands the whole block to the host with ONE round of returning atomics per
-    // thread (pass_end); with 64 statistics slots it took two
-    C_COUNT = C_TAIL + 48
+    // 128 logical words: the last block of a pass hands them to the host with ONE round of returning atomics per thread (pass_end)
+    C_COUNT = C_TAIL + 48,
+    // device lines: 0 scalars | 1-4 the four bags | 5-20 statistics slots | 21-28 pair-list heads | 29 list entries |
+    // 30 kernels done (+ parking for the unused logical words) | 31-39, 40-48 the two ticket sets
+    C_DEV_LINES = 49, C_DEV_WORDS = C_DEV_LINES * CTR_LINE
 };
+__host__ __device__ constexpr int ctr_dev(int i) {
+    if (i >= C_AP && i <= C_GP) return (1 + (i - C_AP)) * CTR_LINE;
+    if (i < 16) return i;
+    if (i < C_TAIL) return (5 + (i - 16) % STAT_SLOTS) * CTR_LINE + (i - 16) / STAT_SLOTS;
+    if (i < C_TAIL + 8) return (21 + (i - C_TAIL)) * CTR_LINE;
+    if (i >= C_PLIST && i < C_PLIST + 4) return 29 * CTR_LINE + (i - C_PLIST);
+    if (i == C_KERNELS_DONE) return 30 * CTR_LINE;
+    if (i >= C_TICKET_GROUP && i < C_COUNT && (i - C_TICKET_GROUP) % C_TICKET_SET <= 8)
+        return (31 + 9 * ((i - C_TICKET_GROUP) / C_TICKET_SET) + (i - C_TICKET_GROUP) % C_TICKET_SET) * CTR_LINE;
+    return 30 * CTR_LINE + 1 + i % 15;   // logical words nothing uses
+}
 #define PAIR_SEGS 8
 typedef unsigned long long u64;
 
@@ -637,10 +654,11 @@ struct PublishArgs {
     u64 seq;         // value of the completion word for this pass
 };
 // Tickets are hierarchical — one counter per (blockIdx % 8), i.e. per XCD as the dispatcher places blocks, then one for
-// the eight groups — because same-address atomics run at ~90 per microsecond: 2500 blocks on one word were a 15 us tail.
+// the eight groups — because atomics on one LINE run at ~90 per microsecond: 2500 blocks on one word were a 15 us tail, and
+// 1024 blocks on eight words of one line still 7 us (config 3); each ticket has a line of its own (ctr_dev).
 __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     if (!pa.expected) return;
-    u64* const tickets = pa.ctr + set * C_TICKET_SET;
+    const int tset = set * C_TICKET_SET;
     __shared__ int s_publisher;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's counter atomics have been performed (memory side)
     __syncthreads();
@@ -648,20 +666,26 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
         int pub = 0;
         const unsigned grp = blockIdx.x & 7u;
         const u64 members = ((u64)gridDim.x + 7ull - grp) >> 3;                  // blocks b < gridDim.x with b % 8 == grp
-        if (atomicAdd(tickets + C_TICKET_GROUP + grp, 1ull) == members - 1ull) {
+        if (atomicAdd(pa.ctr + ctr_dev(C_TICKET_GROUP + tset + (int)grp), 1ull) == members - 1ull) {
             const u64 groups = gridDim.x < 8u ? (u64)gridDim.x : 8ull;
-            if (atomicAdd(tickets + C_TICKET_KERNEL, 1ull) == groups - 1ull)            // last block of this kernel
-                pub = pa.expected == 1 || atomicAdd(pa.ctr + C_KERNELS_DONE, 1ull) == (u64)pa.expected - 1ull;
+            if (atomicAdd(pa.ctr + ctr_dev(C_TICKET_KERNEL + tset), 1ull) == groups - 1ull)     // last block of this kernel
+                pub = pa.expected == 1 || atomicAdd(pa.ctr + ctr_dev(C_KERNELS_DONE), 1ull) == (u64)pa.expected - 1ull;
         }
         s_publisher = pub;
     }
     __syncthreads();
     if (!s_publisher) return;
     // returning atomics read the memory-side value whatever this XCD's L2 holds, and leave the slot zero
-    for (int i = threadIdx.x; i < (int)C_COUNT; i += blockDim.x) pa.host[i] = atomicExch(pa.ctr + i, 0ull);
-    __threadfence_system();
+    // The mirror is page-locked host memory: system-scope stores go straight to the fabric.  No release fence here — a fence
+    // of that scope writes back every dirty line of this XCD's L2 first, and at the end of a pass those are the contact records
+    // the kernel has just written (config 3: 19 MB across the eight L2s; the fence was 4 - 5 us of the pass).  What the flag
+    // needs is that the counter stores have left this CU (vmcnt(0) of every wave, then the barrier); writes to the host
+    // arrive in the order they were sent.
+    for (int i = threadIdx.x; i < (int)C_COUNT; i += blockDim.x)
+        __hip_atomic_store(pa.host + i, atomicExch(pa.ctr + ctr_dev(i), 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(pa.host + C_COUNT, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(pa.host + C_COUNT, pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- neighbour search ---------------------------------------------------------------
@@ -746,7 +770,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
 
     // output segment of this block (cap = capacity of ONE segment)
     const int seg = (MODE == MODE_CONTACTS) ? (blockIdx.x & (PAIR_SEGS - 1)) : 0;
-    u64* const seg_ctr = ctr_pairs + seg;
+    u64* const seg_ctr = ctr_pairs + seg * CTR_LINE;
     int2* const seg_pairs = pairs + (size_t)seg * cap;
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
@@ -1051,8 +1075,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
         s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot) : 0;
         const int slot = blockIdx.x & (STAT_SLOTS - 1);
-        atomicAdd(ctr_cand + slot, tc);
-        atomicAdd(ctr_acc + slot, ta);
+        atomicAdd(ctr_cand + slot * CTR_LINE, tc);
+        atomicAdd(ctr_acc + slot * CTR_LINE, ta);
     }
     __syncthreads();
     if (MODE != MODE_MARK && qn > 0) {
@@ -1298,7 +1322,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     const int sgm = vblock & (PAIR_SEGS - 1);
     u64 heads[PAIR_SEGS];
 #pragma unroll
-    for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_];
+    for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_ * CTR_LINE];
     const float longest_bond = sd.longest_bond[0];
     const double h_slack = (double)sd.longest_bond[1] + 1e-4;   // |H - A| >= |D - A| - h_slack for every hydrogen H of D (margin: float32 distance, roundings)
     const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
@@ -1540,8 +1564,8 @@ __global__ __launch_bounds__(256) void k_isift_compose(long long n4, const unsig
 // launch; a D2H hipMemcpyAsync of 3 KB costs an SDMA round trip) and, when asked, returns to zero for the next pass.
 __global__ __launch_bounds__(256) void k_publish_counters(u64* __restrict__ ctr, u64* __restrict__ host, int n, int zero, u64 seq) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        host[i] = ctr[i];
-        if (zero) ctr[i] = 0;
+        host[i] = ctr[ctr_dev(i)];
+        if (zero) ctr[ctr_dev(i)] = 0;
     }
     // host[n] = sequence number of this pass, stored after everything else is visible to the host: the host may
     // poll it instead of blocking in hipStreamSynchronize (this kernel is the last one of the pass)
@@ -1591,8 +1615,8 @@ __global__ __launch_bounds__(256) void k_expand_small(int n, const float4* __res
     if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = t; s_a[threadIdx.x >> 6] = a; }
     __syncthreads();
     if (threadIdx.x == 0 && stats) {
-        atomicAdd(stats + (blockIdx.x & (STAT_SLOTS - 1)), (u64)(s_t[0] + s_t[1] + s_t[2] + s_t[3]));
-        atomicAdd(stats + STAT_SLOTS + (blockIdx.x & (STAT_SLOTS - 1)), (u64)(s_a[0] + s_a[1] + s_a[2] + s_a[3]));
+        atomicAdd(stats + (blockIdx.x & (STAT_SLOTS - 1)) * CTR_LINE, (u64)(s_t[0] + s_t[1] + s_t[2] + s_t[3]));       // (mark cand, mark acc: neighbours in the slot's line)
+        atomicAdd(stats + (blockIdx.x & (STAT_SLOTS - 1)) * CTR_LINE + 1, (u64)(s_a[0] + s_a[1] + s_a[2] + s_a[3]));
     }
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Resident-pass time and per-kernel HIP-event times of one structure (GPU box only): the quick figure to compare
-kernel variants with.    python tools/pass_probe.py [--atoms 100000] [--steps 400] [--workload config3|standin]"""
+kernel variants with.    python tools/pass_probe.py [--atoms 100000] [--steps 400] [--workload config3|standin|noplanes]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from arpeggio_amd import synth, _capi  # noqa: E402
@@ -11,7 +11,13 @@ ap.add_argument('--steps', type=int, default=400)
 ap.add_argument('--workload', default='config3')
 ap.add_argument('--tag', default='')
 args = ap.parse_args()
-pc = synth.proteinlike(seed=1) if args.workload == 'standin' else synth.config3(args.atoms, seed=3)
+if args.workload == 'standin':
+    pc = synth.proteinlike(seed=1)
+elif args.workload == 'noplanes':     # config 3's atoms without rings and amides: the last launch is the per-pair kernel alone
+    L = (args.atoms / 0.05) ** (1 / 3)
+    pc = synth.make_synthetic(args.atoms, seed=3, box=(L, L, L), n_rings=0, n_amides=0)
+else:
+    pc = synth.config3(args.atoms, seed=3)
 ctx = _capi.Context(0)
 ctx.set_complex(pc)
 for _ in range(8):
