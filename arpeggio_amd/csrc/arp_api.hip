@@ -194,7 +194,7 @@ struct arp_ctx {
     DevBuf<int4> a_aux;
     bool all_grid_current = false;  // all_grid matches the current inputs and selection
     hipStream_t stream2 = nullptr;  // ring / amide kernels run here, concurrently with the contact pipeline
-    hipEvent_t ev_sel = nullptr, ev_planes = nullptr;
+    hipEvent_t ev_sel = nullptr, ev_planes = nullptr, ev_lists = nullptr;
     DevBuf<uint8_t> tmp_u8;
     // ---- pair list and outputs of the atom-contact pass
     DevBuf<int2> pairs;
@@ -221,6 +221,7 @@ struct arp_ctx {
     // static candidate lists of the ring / amide loops (k_plane_lists), rebuilt when the structure changes
     DevBuf<int2> plist[4];
     DevBuf<u64> plist_count;       // [4]
+    bool plist_count_cleared = false;   // k_point_grids has just zeroed them (same stream, same pass)
     bool lists_dirty = true;
     long long plist_known[4] = {-1, -1, -1, -1};   // entries the lists held at the end of the last pass (-1: not known yet)
     DevBuf<uint8_t> blob_dev;      // device copy of the last arp_set_blob upload (the input arrays are views into it)
@@ -566,7 +567,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         // layout of sp_cnt: [longest bond, longest atom - hydrogen distance, 2 words of padding | histogram of ncell + 1 cells]:
         // a fresh structure clears all of it with ONE fill, a new order for resident columns only the histogram
         float keep_longest[2] = {0.0f, 0.0f};
-        const size_t want = (size_t)d.ncell + 8;
+        const size_t want = std::max<size_t>((size_t)d.ncell + 8, 32768 + 8);     // (the one-block scan reads and writes whole int4s up to its 32768 slots)
         const bool regrow = !columns && c->sp_cnt.cap < want;
         if (regrow) {      // (a larger grid for resident columns: the two words survive the reallocation through the host)
             HIPCHK(c, hipMemcpyAsync(keep_longest, c->sp_cnt.p, sizeof(keep_longest), hipMemcpyDeviceToHost, c->stream));
@@ -585,10 +586,15 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
             hipLaunchKernelGGL(k_static_bin, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->st_xyzm.p, d, hist, c->sp_cr.p);
         }
         CHK(check_launch(c, "k_prepare_static"));
-        ScanSegs S;
-        memset(&S, 0, sizeof(S));
-        S.p[0] = hist; S.n[0] = d.ncell;
-        hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, c->stream, S);
+        if (d.ncell <= 4096) hipLaunchKernelGGL((k_scan_inplace<4>), dim3(1), dim3(1024), 0, c->stream, hist, d.ncell);
+        else if (d.ncell <= 16384) hipLaunchKernelGGL((k_scan_inplace<16>), dim3(1), dim3(1024), 0, c->stream, hist, d.ncell);
+        else if (d.ncell <= 32768) hipLaunchKernelGGL((k_scan_inplace<32>), dim3(1), dim3(1024), 0, c->stream, hist, d.ncell);
+        else {      // larger grids: chunks of 4096 cells with a running carry
+            ScanSegs S;
+            memset(&S, 0, sizeof(S));
+            S.p[0] = hist; S.n[0] = d.ncell;
+            hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, c->stream, S);
+        }
         hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, hist, c->st_xyzm.p,
                            c->st_aux.p, c->st_q1.p, c->st_b4.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p, c->sp_b4.p, c->sp_cell.p);
         CHK(check_launch(c, "k_static_permute"));
@@ -880,6 +886,55 @@ int ensure_amide_grid(arp_ctx* c) {
     return build_grid<PtsF3>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0, c->sid_amide.p);
 }
 
+// both centre grids in one launch when they are small (k_point_grids); otherwise each by the general path
+int ensure_center_grids(arp_ctx* c) {
+    static const int deterministic = env_int("ARP_DETERMINISTIC", 0);
+    const bool want_r = c->nring > 0 && !c->ring_grid.valid, want_a = c->namide > 0 && !c->amide_grid.valid;
+    const int small_points = 16384;
+    if ((want_r || want_a) && !deterministic && c->nring <= small_points && c->namide <= small_points) {
+        PointGridJob<PtsD3> jr{};
+        PointGridJob<PtsF3> ja{};
+        bool fits = true;
+        if (want_r) {
+            Grid& G = c->ring_grid;
+            CHK(grid_desc_for(c, G.d, c->ring_lo, c->ring_hi, 6.0));
+            fits = fits && G.d.ncell <= POINT_GRID_ITEMS * 1024;
+        }
+        if (want_a) {
+            Grid& G = c->amide_grid;
+            CHK(grid_desc_for(c, G.d, c->am_lo, c->am_hi, 6.0));
+            fits = fits && G.d.ncell <= POINT_GRID_ITEMS * 1024;
+        }
+        if (fits) {
+            if (want_r) {
+                Grid& G = c->ring_grid;
+                G.radius = 6.0; G.n_points = (int)c->nring;
+                CHK(reserve_grid(c, G, (int)c->nring));
+                jr = PointGridJob<PtsD3>{PtsD3{c->ring_c.p}, (int)c->nring, G.d, c->sid_ring.p, G.cell_of.p, G.cnt.p, G.start.p, G.perm.p};
+            }
+            if (want_a) {
+                Grid& G = c->amide_grid;
+                G.radius = 6.0; G.n_points = (int)c->namide;
+                CHK(reserve_grid(c, G, (int)c->namide));
+                ja = PointGridJob<PtsF3>{PtsF3{c->am_c.p}, (int)c->namide, G.d, c->sid_amide.p, G.cell_of.p, G.cnt.p, G.start.p, G.perm.p};
+            }
+            // (the entry counts of the candidate lists, which are rebuilt whenever the grids are, cleared on the way)
+            const bool with_counts = c->lists_dirty || !c->plist_count.p;
+            if (with_counts) { HIPCHK(c, c->plist_count.reserve(4)); c->lists_dirty = true; }
+            Prof p(c, SLOT_BIN);
+            hipLaunchKernelGGL(k_point_grids, dim3(2), dim3(1024), 0, c->stream, jr, ja, with_counts ? c->plist_count.p : (u64*)nullptr);
+            CHK(check_launch(c, "k_point_grids"));
+            c->plist_count_cleared = with_counts;
+            if (want_r) c->ring_grid.valid = true;
+            if (want_a) c->amide_grid.valid = true;
+            return ARP_OK;
+        }
+    }
+    if (c->nring > 0) CHK(ensure_ring_grid(c));
+    if (c->namide > 0) CHK(ensure_amide_grid(c));
+    return ARP_OK;
+}
+
 // ---- enqueue-only building blocks (no host synchronisation) -----------------------------------
 
 // _make_selection, part 1 (I:1384-1424): selection_plus from the selection mask already in c->sel
@@ -1113,7 +1168,8 @@ int ensure_plane_lists(arp_ctx* c) {
     const size_t want[4] = {(size_t)c->nring * 96 + 256, (size_t)c->nring * 16 + 256, (size_t)c->namide * 16 + 256, (size_t)c->namide * 8 + 256};
     for (int k = 0; k < 4; ++k) HIPCHK(c, c->plist[k].reserve(want[k]));
     HIPCHK(c, c->plist_count.reserve(4));
-    HIPCHK(c, hipMemsetAsync(c->plist_count.p, 0, 4 * sizeof(u64), c->stream));
+    if (!c->plist_count_cleared) HIPCHK(c, hipMemsetAsync(c->plist_count.p, 0, 4 * sizeof(u64), c->stream));   // (else: k_point_grids did, on this stream)
+    c->plist_count_cleared = false;
     AtomPlaneArgs ap{};
     PlanePlaneArgs pp{};
     GroupGroupArgs gg{};
@@ -1163,6 +1219,19 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                         all_res ? 1 : 0, c->ring_sel.p, c->ring_plus.p, c->am_sel.p, c->am_plus.p};
         if (c->n == 0) masks_after_bin = true;   // no scatter launch to carry them
     }
+    // A structure's first pass also builds the static candidate lists of its ring / amide loops — two centre grids, the 6 A atom
+    // grid, k_plane_lists: 67 us of small launches in a row at 100 k atoms — and nothing before the last launch of the pass
+    // reads them: they go on the second stream, beside the grid build and the search of this pass, and are enqueued AFTER the
+    // search (the host needs ~5 us per launch: enqueued first they held the main stream's kernels back by as much).
+    // (The other way round — search on the second stream, lists on the main one, so that the last launch follows the longer
+    // chain in stream order — was no faster: the search then shares the chip with the 1024-thread scan blocks of the lists.)
+    const bool fork_lists = with_planes && c->nring + c->namide > 0 && c->n > 0 &&
+                            (c->lists_dirty || !c->plist_count.p || (c->nring > 0 && !c->ring_grid.valid) || (c->namide > 0 && !c->amide_grid.valid)) &&
+                            !c->external_stream && c->stream2;
+    if (fork_lists) {
+        CHK(ensure_static(c, cutoff));                                  // (what the lists read is in place on the main stream here)
+        HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
+    }
     CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + ctr_dev(C_BINNED), c->init_plus_in_bin ? c->plus.p : nullptr, rm));
     if (masks_after_bin && c->nring + c->namide > 0) {
         hipLaunchKernelGGL(k_group_masks, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, c->stream, gm);
@@ -1177,6 +1246,35 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
     CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
     CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
+    bool search_launched = false;
+    auto launch_search = [&]() -> int {
+        if (search_launched || c->n == 0) return ARP_OK;
+        search_launched = true;
+        Prof p(c, SLOT_SEARCH);
+        // the contact search ends with a block-level flush of its pair queues, which amortises better over
+        // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
+        // Small grids (a protein of a few thousand atoms has ~1000 cells) get fewer cells per wave: the chip is far from full
+        // and a wave's cells are a serial chain (1tqn_h stand-in: 22 -> 16 us).
+        static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 3));
+        const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
+        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
+                           c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
+                           include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                           c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm);
+        return check_launch(c, "k_search<CONTACTS>");
+    };
+    bool lists_forked = false;
+    if (fork_lists) {
+        CHK(launch_search());
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
+        std::swap(c->stream, c->stream2);
+        int rc = ensure_center_grids(c);
+        if (rc == ARP_OK) rc = ensure_plane_lists(c);
+        std::swap(c->stream, c->stream2);
+        CHK(rc);
+        HIPCHK(c, hipEventRecord(c->ev_lists, c->stream2));
+        lists_forked = true;
+    }
     // ---- ring / amide loops (I:938-1382): evaluated from the static candidate lists by the leading blocks of the
     // last launch (ARP_PLANES_MODE=1: as a kernel of their own on the second stream, beside the search)
     AtomPlaneArgs ap{};
@@ -1185,6 +1283,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     GroupPlaneArgs gp{};
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     if (with_planes && c->nring + c->namide > 0) {
+        CHK(ensure_center_grids(c));
         CHK(ensure_plane_lists(c));
         CHK(prepare_atom_plane(c, ap, n0, /*contact_grid=*/true));   // (argument blocks and bag buffers; no grid is walked)
         CHK(prepare_plane_plane(c, pp, n1));
@@ -1219,26 +1318,14 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         if (c->pub.expected) c->pub.expected = (c->n > 0) ? 2 : 1;
         if (st2 != c->stream) HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));   // masks (and lists) are in place here
     }
-    if (c->n > 0) {
-        Prof p(c, SLOT_SEARCH);
-        // the contact search ends with a block-level flush of its pair queues, which amortises better over
-        // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
-        // Small grids (a protein of a few thousand atoms has ~1000 cells) get fewer cells per wave: the chip is far from full
-        // and a wave's cells are a serial chain (1tqn_h stand-in: 22 -> 16 us).
-        static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 3));
-        const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
-        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
-                           c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                           include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
-                           c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm);
-        CHK(check_launch(c, "k_search<CONTACTS>"));
-    }
+    CHK(launch_search());
     if (planes_alone) {
         if (st2 != c->stream) HIPCHK(c, hipStreamWaitEvent(st2, c->ev_sel, 0));
         Prof p(c, SLOT_PLANES, st2);
         hipLaunchKernelGGL(k_planes, dim3(np), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + ctr_dev(C_PLIST), c->pub);
         CHK(check_launch(c, "k_planes"));
     }
+    if (lists_forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lists, 0));   // (k_planes on the second stream follows the lists in order)
     if (c->n > 0) {
         Prof p(c, SLOT_SIFT);
         static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
@@ -1411,6 +1498,7 @@ int arp_create(int device, arp_ctx** out) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_DEV_WORDS);
     if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_ctr_pinned, sizeof(u64) * (C_COUNT + 1), hipHostMallocDefault);
@@ -1454,6 +1542,7 @@ void arp_destroy(arp_ctx* c) {
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
+    if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -2766,9 +2855,7 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                                (int)c->nsel, c->sel.p, expand_radius * expand_radius, c->plus.p, c->d_ctr + ctr_dev(C_STAT_MCAND));
             CHK(check_launch(c, "k_expand_small"));
         }
-        // ring / amide grids: built once per structure
-        if (c->nring > 0) CHK(ensure_ring_grid(c));
-        if (c->namide > 0) CHK(ensure_amide_grid(c));
+        // (ring / amide grids, built once per structure: with the candidate lists, in enqueue_contacts)
         // I:1413-1437 (residue / ring / amide sets) ride on the contact grid build, I:345-347 in three launches
         c->fuse_sets = true;
         CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent, true));
@@ -2906,8 +2993,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
                                (int)c->namide, c->ring_res.p, c->am_res.p, c->res_sel.p, c->res_sel.p + nres, c->ring_sel.p,
                                c->ring_plus.p, c->am_sel.p, c->am_plus.p);
         CHK(check_launch(c, "k_group_mask"));
-        if (c->nring > 0) CHK(ensure_ring_grid(c));
-        if (c->namide > 0) CHK(ensure_amide_grid(c));
+        CHK(ensure_center_grids(c));
         CHK(enqueue_contacts(c, cutoff, vdw_comp, include_sequence_adjacent, true));
         CHK(enqueue_counter_copy(c));
         CHK(collect_counters(c));

@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void k_bin(P pts, int n, GridDesc g, const int
 // Small grids (<= 65536 cells): the whole exclusive scan in ONE 1024-thread block (one launch
 // instead of three).  Thread t owns ITEMS consecutive counters (int4 loads, kept in registers);
 // out[n] = grand total.  Both arrays must be readable/writable up to ITEMS * 1024 elements.
+// (in == out is allowed: a thread reads all of its own counters before anything is written)
 template <int ITEMS>
-__device__ __forceinline__ void scan_small_body(const int* __restrict__ in, int n, int* __restrict__ out,
-                                                int* __restrict__ total_slot, unsigned long long* __restrict__ total_out) {
+__device__ __forceinline__ void scan_small_body(const int* in, int n, int* out, int* total_slot, unsigned long long* total_out) {
     __shared__ int sh[32];
     const int base = threadIdx.x * ITEMS;
     int v[ITEMS];
@@ -144,6 +144,62 @@ template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_scan_small(const int* __restrict__ in, int n, int* __restrict__ out,
                                                      unsigned long long* __restrict__ total_out) {
     scan_small_body<ITEMS>(in, n, out, out + n, total_out);
+}
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_scan_inplace(int* a, int n) {    // a[0..n) -> exclusive prefix, a[n] = total
+    scan_small_body<ITEMS>(a, n, a, a + n, nullptr);
+}
+
+// Ring AND amide centre grids of a structure in ONE launch (block 0: rings, block 1: amides): bin, scan and scatter by a
+// single 1024-thread block each — a few thousand points in a few thousand cells, where the six launches of the general path
+// (k_bin / k_scan_small / k_scatter, twice) were 28 us of launch latency in every structure's first pass.  The histogram is
+// zero on entry and on exit (the scatter counts it down again), as in the general path.
+template <class P>
+struct PointGridJob {
+    P pts;
+    int n;
+    GridDesc g;
+    const int* sid;
+    int* cell_of;
+    int* cnt;
+    int* start;
+    int* perm;
+};
+#define POINT_GRID_ITEMS 32          // cells per thread of the one-block scan: grids up to 32768 cells
+#define POINT_GRID_LDS_CELLS 12288   // up to this many cells the histogram lives in LDS (48 KB)
+template <class P>
+__device__ __forceinline__ void point_grid_body(const PointGridJob<P>& J, int* s_cnt) {
+    if (J.n <= 0) return;
+    const int ncell = J.g.ncell;
+    const bool in_lds = ncell <= POINT_GRID_LDS_CELLS;     // (block-uniform)
+    int* const cnt = in_lds ? s_cnt : J.cnt;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < POINT_GRID_LDS_CELLS; k += blockDim.x) s_cnt[k] = 0;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < J.n; i += blockDim.x) {
+        const int c = cell_index(J.g, J.pts.get(i), J.g.place ? J.sid[i] : 0);
+        atomicAdd(&cnt[c], 1);
+        J.cell_of[i] = c;
+    }
+    if (!in_lds) __threadfence();      // (counters updated on the memory side: the scan must not read them from this CU's L1)
+    __syncthreads();
+    if (in_lds) scan_small_body<POINT_GRID_LDS_CELLS / 1024>(cnt, ncell, J.start, J.start + ncell, nullptr);
+    else scan_small_body<POINT_GRID_ITEMS>(cnt, ncell, J.start, J.start + ncell, nullptr);
+    __threadfence_block();
+    __syncthreads();
+    for (int i = threadIdx.x; i < J.n; i += blockDim.x) {
+        const int c = J.cell_of[i];
+        const int slot = atomicSub(&cnt[c], 1) - 1;      // (the global histogram ends at zero again, as the general path leaves it)
+        J.perm[J.start[c] + slot] = i;
+    }
+}
+// zero4: four 64-bit words this launch clears on the way (the entry counts of the candidate lists that are built next)
+__global__ __launch_bounds__(1024) void k_point_grids(PointGridJob<PtsD3> rings, PointGridJob<PtsF3> amides, unsigned long long* zero4) {
+    __shared__ int s_cnt[POINT_GRID_LDS_CELLS];
+    if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0ull;
+    if (blockIdx.x == 0) point_grid_body(rings, s_cnt);
+    else point_grid_body(amides, s_cnt);
 }
 
 // Larger histograms, two launches: every 1024-thread block scans one tile of TILE_ITEMS * 1024 counters with the
