@@ -570,6 +570,28 @@ def test_config5_full_size(ctx):
     assert len(np.unique(key)) == len(key) and gpp['dist'].max() <= 6.0
 
 
+def test_quarter_million_atoms_centre_grids(ctx):
+    """The per-GPU size of BASELINE configs[3]: the ring / amide centre grids have 24 k cells here — k_point_grids keeps their
+    histogram in global memory (above 12 288 cells; below, in LDS: every smaller test) — and the candidate lists are built on the
+    second stream beside the first pass's search.  Ring / amide bags of run_launch against the oracle."""
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.config3(250_000, seed=6)
+    ctx.set_complex(pc)
+    counts = ctx.run_launch()
+    assert counts['plane_plane'] > 0 and counts['group_group'] > 0 and counts['group_plane'] > 0
+    oc = oracle.OracleComplex(pc)
+    oc.make_selection(None)
+    epp = oc.plane_plane()
+    o = np.lexsort((epp['end'], epp['bgn']))
+    epp = {k: v[o] for k, v in epp.items()}
+    _assert_planes_equal(ctx.fetch_bag('plane_plane'), epp, ('bgn', 'end', 'type1', 'type2', 'ctype', 'dist'), ('dihedral', 'theta_bgn', 'theta_end'))
+    _assert_planes_equal(ctx.fetch_bag('group_group'), oc.group_group(), ('bgn', 'end', 'ctype', 'dist'), ('dihedral', 'theta'), tol=1e-4)
+    _assert_planes_equal(ctx.fetch_bag('group_plane'), oc.group_plane(), ('amide', 'ring', 'ctype', 'dist'), ('dihedral', 'theta'))
+    again = ctx.run_launch()             # the resident pass (lists and grids in place) finds the same
+    assert dict(again) == dict(counts)
+
+
 def test_one_million_atoms_single_gpu(ctx):
     """Half of BASELINE configs[3] (2M atoms over 8 GPUs = 250k per GPU) times four on ONE GPU: parity with the
     grid oracle and the size-independent properties of the contact list."""
