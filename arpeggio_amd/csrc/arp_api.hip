@@ -1457,6 +1457,13 @@ int arp_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+int arp_device_synchronize(arp_ctx* c) {
+    if (!c) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    return ARP_OK;
+}
+
 int arp_create(int device, arp_ctx** out) {
     if (!out) return ARP_E_ARG;
     *out = nullptr;

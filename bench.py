@@ -73,10 +73,9 @@ def bench_batch(args):
     """B protein-sized structures per pass (arp_set_batch): the reference's production use is the weekly PDBe release —
     10^5 entries of a few thousand atoms — and one such structure is four launches of fixed cost.  Prints one JSON line
     with the contract's keys; `value` = candidate pairs of all structures of the batch x steps / time."""
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
     from arpeggio_amd import synth, _capi, batch as _batch
+    if _capi.device_count() < 1:
+        raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
     B = args.batch
     t0 = time.perf_counter()
     distinct = [synth.proteinlike(seed=2 + k, id=f'standin{k}') for k in range(min(B, 8))]
@@ -92,16 +91,16 @@ def bench_batch(args):
 
     for _ in range(5 + args.warmup):
         counts = step()
-    torch.cuda.synchronize()
+    ctx.device_synchronize()
     t_trial = time.perf_counter()
     for _ in range(args.steps):
         counts = step()
     repeats = max(1, int(math.ceil(args.min_seconds / max(time.perf_counter() - t_trial, 1e-6))))
-    torch.cuda.synchronize()
+    ctx.device_synchronize()
     t1 = time.perf_counter()
     for _ in range(repeats * args.steps):
         counts = step()
-    torch.cuda.synchronize()
+    ctx.device_synchronize()
     elapsed = time.perf_counter() - t1
     timed_steps = repeats * args.steps
     st = ctx.stats()
@@ -208,48 +207,22 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
-    import torch
-    if not torch.cuda.is_available():
+    from arpeggio_amd import synth, _capi
+    from arpeggio_amd.rendezvous import TcpRendezvous
+    if _capi.device_count() < 1:
         raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
-    # ARP_BENCH_SHARE_GPU=1 (debug only): every rank uses GPU 0 and the exchange goes through host buffers over gloo (RCCL
-    # refuses two ranks on one device), so the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
+    # ARP_BENCH_SHARE_GPU=1 (debug only): every rank uses GPU 0 and the exchange goes through host buffers (RCCL refuses two
+    # ranks on one device), so the N > 1 code path can be exercised on a one-GPU box.  Never set by the driver.
     share_gpu = os.environ.get('ARP_BENCH_SHARE_GPU') == '1'
     if share_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
     # Data path: the library's own RCCL communicator (arp_comm_*: ncclSend / ncclRecv / ncclAllReduce on the context's stream).
-    # torch.distributed (gloo, host) is the rendezvous only: it carries the 128-byte unique id, the barriers around the
-    # timed region and the reduction of the per-rank timings.
-    dist, comm_device = None, (None if share_gpu else torch.device('cuda', local_rank))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-
-    from arpeggio_amd import synth, _capi
-
-    class HostTransport:
-        """arpeggio_amd.sharding's host-buffer transport over the rendezvous group (--host-halo and the one-GPU debug mode)."""
-
-        def exchange(self, payload):
-            sides = [s_ for s_ in (-1, +1) if 0 <= rank + s_ < world]
-            lens_out = {s_: torch.tensor([payload[s_].size if s_ in payload else 0], dtype=torch.int64) for s_ in sides}
-            lens_in = {s_: torch.zeros(1, dtype=torch.int64) for s_ in sides}
-            ops = [dist.P2POp(op, t[s_], rank + s_) for s_ in sides for op, t in ((dist.isend, lens_out), (dist.irecv, lens_in))]
-            for w_ in dist.batch_isend_irecv(ops):
-                w_.wait()
-            out = {s_: torch.from_numpy(np.ascontiguousarray(payload[s_], np.uint8)) for s_ in sides if s_ in payload and payload[s_].size}
-            inn = {s_: torch.empty(int(lens_in[s_].item()), dtype=torch.uint8) for s_ in sides if int(lens_in[s_].item())}
-            ops = [dist.P2POp(dist.isend, out[s_], rank + s_) for s_ in out] + [dist.P2POp(dist.irecv, inn[s_], rank + s_) for s_ in inn]
-            if ops:
-                for w_ in dist.batch_isend_irecv(ops):
-                    w_.wait()
-            return {s_: t.numpy() for s_, t in inn.items()}
-
-        def allreduce_max(self, a):
-            t = torch.from_numpy(np.ascontiguousarray(a).copy())
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return t.numpy()
+    # The rendezvous of the ranks — the 128-byte communicator id, the barriers around the timed region, the reduction of the
+    # per-rank timings — is a few TCP messages through rank 0 (arpeggio_amd/rendezvous.py).  No PyTorch in this process: its
+    # ROCm build brings a HIP runtime and an RCCL of its own, and two of each in one process do not end well.
+    comm_device = None if share_gpu else local_rank
+    rdzv = TcpRendezvous(rank, world) if world > 1 else None
+    transport = rdzv
 
     # ---------------- workload ----------------
     t0 = time.perf_counter()
@@ -273,16 +246,14 @@ def main():
                     f'(BASELINE configs[3]{"" if args.atoms * world == 2_000_000 else " family"}), one-cell halo over RCCL')
         # no fallback: if the exchange over RCCL fails, the run fails (a scaling figure must not be printed without it)
         ctx = _capi.Context(local_rank)
-        transport = HostTransport()
         if comm_device is not None:
-            uid = torch.from_numpy(_capi.Context.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8))
-            dist.broadcast(uid, 0)
-            ctx.comm_init(rank, world, uid.numpy())
+            uid = np.frombuffer(rdzv.broadcast(_capi.Context.comm_unique_id().tobytes() if rank == 0 else None), np.uint8).copy()
+            ctx.comm_init(rank, world, uid)
         t_sh = time.perf_counter()
         if comm_device is None:
             args.host_halo = True      # (one-GPU debug mode: no RCCL between ranks that share a device)
         if args.host_halo:
-            halo_note = 'records of the one-cell halo packed on the host, exchanged through host buffers (gloo), merged on the host'
+            halo_note = 'records of the one-cell halo packed on the host, exchanged through host buffers (TCP rendezvous), merged on the host'
             shard = sharding.make_shard_distributed(full, rank, world, transport)
             sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
             n_local = shard.pc.n_atoms
@@ -315,14 +286,14 @@ def main():
         def step():
             return sharding.run_shard_device(ctx, exchange, args.cutoff, args.vdw_comp, False)
     else:
-        def step():   # debug path (gloo, host buffers)
+        def step():   # debug path (host buffers through the rendezvous)
             return sharding.run_shard(ctx, shard, transport, args.cutoff, args.vdw_comp, False)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def sync_all():      # device idle, every rank here, device idle (the bracket of the timed region)
+        ctx.device_synchronize()
+        if rdzv is not None:
+            rdzv.barrier()
+        ctx.device_synchronize()
 
     # set-up, not steps: the first passes size the result buffers (a pass is re-run when one was too small); reported
     # in the line as `setup_passes`.  Then the W warm-up steps and the timed region: the K steps, repeated as a block
@@ -341,10 +312,8 @@ def main():
         counts = step()
     trial_s = max(time.perf_counter() - t_trial, 1e-6)
     repeats = max(1, int(math.ceil(args.min_seconds / trial_s)))
-    if dist is not None:
-        flag = torch.tensor([float(repeats)])
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        repeats = int(flag.item())
+    if rdzv is not None:
+        repeats = int(rdzv.allreduce(np.array([float(repeats)]), 'max')[0])
     sync_all()
     ctx.host_times(reset=True)
     t0 = time.perf_counter()
@@ -391,12 +360,12 @@ def main():
             threads = [threading.Thread(target=worker, args=(cx,)) for cx in ctxs]
             for t in threads:
                 t.start()
-            torch.cuda.synchronize()
+            ctx.device_synchronize()
             gate.wait()
             t2 = time.perf_counter()
             for t in threads:
                 t.join()
-            torch.cuda.synchronize()
+            ctx.device_synchronize()
             el2 = time.perf_counter() - t2
             in_flight = {'contexts': args.inflight, 'steps': per_thread * args.inflight,
                          'ms_per_step': round(el2 / (per_thread * args.inflight) * 1e3, 4),
@@ -404,7 +373,7 @@ def main():
                          'note': 'one arp_ctx per host thread, same structure resident in each; not the headline value'}
             # the same contexts driven by ONE host thread: enqueue the pass of each (arp_run_enqueue), then wait for each
             rounds = max(per_thread, 1)
-            torch.cuda.synchronize()
+            ctx.device_synchronize()
             t3 = time.perf_counter()
             for _ in range(rounds):
                 for cx in ctxs:
@@ -534,20 +503,16 @@ def main():
 
     # max over ranks of the elapsed time, sum over ranks of the work
     cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
-    if dist is not None:
-        rdev = 'cpu'
-        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        w = torch.tensor([cand, acc, emitted, st['expand_candidates']], dtype=torch.float64, device=rdev)
-        dist.all_reduce(w, op=dist.ReduceOp.SUM)
-        cand_all, acc_all, emitted_all, exp_all = (float(x) for x in w.tolist())
+    if rdzv is not None:
+        elapsed = float(rdzv.allreduce(np.array([elapsed], np.float64), 'max')[0])
+        cand_all, acc_all, emitted_all, exp_all = (float(x) for x in rdzv.allreduce(np.array([cand, acc, emitted, st['expand_candidates']], np.float64), 'sum'))
     else:
         cand_all, acc_all, emitted_all, exp_all = float(cand), float(acc), float(emitted), float(st['expand_candidates'])
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        rdzv.barrier()      # (rank 0 prints its line before anybody leaves)
+        ctx.comm_destroy()
+        rdzv.close()
         return
 
     ms_per_step = elapsed / timed_steps * 1e3
@@ -734,9 +699,11 @@ def main():
                           'frac': round((140 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)} if world == 1 else None,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
-    print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    print(json.dumps(line), flush=True)
+    if rdzv is not None:
+        rdzv.barrier()
+        ctx.comm_destroy()
+        rdzv.close()
 
 
 if __name__ == '__main__':

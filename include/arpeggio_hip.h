@@ -123,6 +123,9 @@ const char* arp_version(void);
  * usable: there is no CPU fallback in this library. */
 /* GPUs this process can see (0: none, or no HIP runtime) */
 int  arp_device_count(void);
+/* Waits until everything enqueued on the context's device has completed (every stream of every context on it): the
+ * bracket of a timed region in a host program that has no HIP runtime of its own to ask (bench.py). */
+int  arp_device_synchronize(arp_ctx* ctx);
 int  arp_create(int device, arp_ctx** out);
 void arp_destroy(arp_ctx* ctx);
 const char* arp_last_error(arp_ctx* ctx);   /* ctx may be NULL: last create error */

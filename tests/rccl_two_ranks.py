@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Worker of tests/test_sharding.py::test_two_ranks_over_rccl_when_two_gpus_are_visible (launched by torch.distributed.run
-with two ranks, one GPU each).  The data path is the library's own RCCL communicator (arp_comm_*); torch.distributed (gloo,
-host) is the rendezvous: it carries the 128-byte unique id and gathers the results for the check."""
+with two ranks, one GPU each).  The data path is the library's own RCCL communicator (arp_comm_*); the rendezvous — the
+128-byte unique id, the gathered results for the check — is arpeggio_amd.rendezvous (TCP through rank 0): no PyTorch in a
+process that holds the library's RCCL."""
 import os
 import sys
 
@@ -13,20 +14,18 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
 def main():
-    import torch
-    import torch.distributed as dist
+    import pickle
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     local = int(os.environ.get('LOCAL_RANK', rank))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
     from arpeggio_amd import _capi, sharding, synth
-    from helpers import GlooTransport
-    uid = torch.from_numpy(_capi.Context.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8))
-    dist.broadcast(uid, 0)
-    host_transport = GlooTransport(dist, rank, world)
+    from arpeggio_amd.rendezvous import TcpRendezvous
+    rdzv = TcpRendezvous(rank, world)
+    uid = np.frombuffer(rdzv.broadcast(_capi.Context.comm_unique_id().tobytes() if rank == 0 else None), np.uint8).copy()
+    host_transport = rdzv
     full = synth.slab_config(30_000, world, seed=4)
     sel = (full.res_id % 9 == 2).astype(np.uint8)
     comm_ctx = _capi.Context(local)
-    comm_ctx.comm_init(rank, world, uid.numpy())          # one communicator per process, reused by every mode below
+    comm_ctx.comm_init(rank, world, uid)                  # one communicator per process, reused by every mode below
     for mode, assembly in (('whole', 'device'), ('staged', 'device'), ('whole', 'host'), ('staged', 'host')):
         ctx = comm_ctx
         if assembly == 'device':    # halo records cut out, exchanged (RCCL on device pointers) and merged in HBM
@@ -41,8 +40,7 @@ def main():
             counts = sharding.run_shard_device(ctx, ex)
         mine = ctx.atom_contacts_fetch(counts['atom_atom'], sort=False)
         key = np.sort(mine['i'].astype(np.int64) * full.n_atoms + mine['j'])
-        gathered = [None] * world
-        dist.all_gather_object(gathered, key)
+        gathered = [pickle.loads(b) for b in rdzv.allgather(pickle.dumps(key))]
         if rank == 0:
             union = np.sort(np.concatenate(gathered))
             one = _capi.Context(local)
@@ -54,12 +52,12 @@ def main():
             want = ref['i'].astype(np.int64) * full.n_atoms + ref['j']
             assert np.array_equal(union, want), (mode, assembly, len(union), len(want))
             one.close()
-        dist.barrier()
+        rdzv.barrier()
     comm_ctx.comm_destroy()
     comm_ctx.close()
     if rank == 0:
         print('RCCL_TWO_RANKS_OK')
-    dist.destroy_process_group()
+    rdzv.close()
 
 
 if __name__ == '__main__':

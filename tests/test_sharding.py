@@ -257,7 +257,7 @@ def test_gloo_halo_exchange_and_selection_combine(world, worker):
 @pytest.mark.gpu
 def test_two_ranks_over_rccl_when_two_gpus_are_visible():
     """The real thing — two processes, two GPUs, RCCL over xGMI behind the C ABI (arp_comm_init; the 128-byte id travels
-    over a gloo group that serves as rendezvous only): halo records exchanged with grouped ncclSend / ncclRecv, the
+    through arpeggio_amd.rendezvous, a few TCP messages): halo records exchanged with grouped ncclSend / ncclRecv, the
     three-stage pass with the selection_plus bits and the residue sets exchanged on the context's stream, and the union
     of what the two ranks own equal to the single-GPU result.  Skipped on a one-GPU box."""
     import subprocess
@@ -272,3 +272,41 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'RCCL_TWO_RANKS_OK' in out.stdout
+
+
+def _rendezvous_worker(rank, world, port, q):
+    from arpeggio_amd.rendezvous import TcpRendezvous
+    r = TcpRendezvous(rank, world, '127.0.0.1', port)
+    b = r.broadcast(b'id-of-rank-0' if rank == 0 else None)
+    r.barrier()
+    s = r.allreduce(np.array([rank, 1.0]), 'sum')
+    m = r.allreduce_max(np.array([rank * 2], np.uint8))
+    pay = {}
+    if rank > 0:
+        pay[-1] = np.full(3 + rank, rank, np.uint8)
+    if rank < world - 1:
+        pay[+1] = np.full(5 + rank, 100 + rank, np.uint8)
+    got = r.exchange(pay)
+    q.put((rank, b, s.tolist(), m.tolist(), {k: (int(v.size), int(v[0])) for k, v in got.items()}))
+    r.close()
+
+
+def test_tcp_rendezvous_three_ranks():
+    """arpeggio_amd.rendezvous — what bench.py --gpus N and the two-rank RCCL worker use instead of torch.distributed:
+    broadcast, barrier, all-reduce and the neighbour exchange of the sharding transport, three processes."""
+    import multiprocessing as mp
+    ctxm = mp.get_context('spawn')
+    q, W = ctxm.Queue(), 3
+    port = 20000 + (os.getpid() * 7) % 20000
+    ps = [ctxm.Process(target=_rendezvous_worker, args=(k, W, port, q)) for k in range(W)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(W))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, b, s, m, ex in got:
+        assert b == b'id-of-rank-0' and s == [3.0, 3.0] and m == [4]
+    assert got[0][4] == {1: (4, 1)}
+    assert got[1][4] == {-1: (5, 100), 1: (5, 2)}
+    assert got[2][4] == {-1: (6, 101)}
