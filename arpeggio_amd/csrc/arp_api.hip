@@ -187,6 +187,16 @@ struct arp_ctx {
     DevBuf<unsigned long long> compact_chain;   // k_compact_atoms: one word per block
     unsigned int compact_epoch = 0;
     bool static_dirty = true;
+    // The contact grid of a WHOLE-STRUCTURE pass (every atom selected: selection_plus = all atoms, I:1395 / 1407) depends on the
+    // structure and the cell edge only — it is the structure's own neighbour grid, the counterpart of the KD-tree the reference
+    // builds over `entity` (I:1394).  Such a pass keeps it: the next one with the same structure, cell edge and (whole)
+    // selection launches no k_compact_atoms.  Any other selection compacts per pass, as the reference rebuilds
+    // NeighborSearch(selection_plus) (I:1442).  arp_set_grid_reuse(ctx, 0) switches the reuse off (bench.py reports both).
+    bool grid_reuse = true;
+    bool cg_valid = false, cg_fuse = false, cg_init_plus = false, cg_all_res = false, cg_pending = false, cg_reused = false;
+    double cg_radius = 0.0;
+    uint64_t static_epoch = 0, sel_epoch = 0, cg_static_epoch = 0, cg_sel_epoch = 0;
+    int64_t cg_binned = 0;
     double host_enqueue_us = 0, host_wait_us = 0;   // arp_run_launch: time spent enqueueing / waiting (arp_get_host_times)
     int64_t host_passes = 0;
     Grid atom_grid, all_grid, ring_grid, amide_grid;   // contact grid (selection_plus, no H) / every atom at 6 A
@@ -607,6 +617,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
     }
     c->sp_radius = radius;
     c->static_dirty = false;
+    ++c->static_epoch;      // (whatever was derived from the old columns or their order is stale)
     return ARP_OK;
 }
 
@@ -719,6 +730,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
 }
 int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr,
                        ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
+    c->cg_valid = false;      // (the buffers of the pass's grid are rewritten)
     return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
 }
 // The contact grid of a pass as an ordered compaction of the static columns (k_compact_atoms): ONE launch.
@@ -939,6 +951,7 @@ int ensure_center_grids(arp_ctx* c) {
 
 // _make_selection, part 1 (I:1384-1424): selection_plus from the selection mask already in c->sel
 int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
+    ++c->sel_epoch;
     if (!st) st = c->stream;
     const int n = (int)c->n;
     HIPCHK(c, c->plus.reserve((size_t)std::max(n, 1)));
@@ -990,6 +1003,7 @@ int enqueue_selection_sets(arp_ctx* c, hipStream_t st) {
 }
 
 int enqueue_selection(arp_ctx* c, double radius) {   // the whole _make_selection on the main stream
+    ++c->sel_epoch;
     CHK(enqueue_expansion(c, radius));
     return enqueue_selection_sets(c, c->stream);
 }
@@ -1203,16 +1217,24 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     ResMarks rm{nullptr, nullptr, 0};
     GroupMasks gm{};
     bool masks_after_bin = false;
+    // the grid of the previous whole-structure pass, if nothing it depends on has changed (see grid_reuse)
+    const bool all_res_now = c->whole_structure && c->sel_all;
+    const bool whole = c->sel_made && c->sel_all && c->n > 0;
+    const bool reuse_grid = c->grid_reuse && whole && c->cg_valid && !c->cg_pending && c->atom_grid.valid && c->cg_radius == cutoff &&
+                            c->cg_static_epoch == c->static_epoch && c->cg_sel_epoch == c->sel_epoch && c->cg_fuse == c->fuse_sets &&
+                            c->cg_init_plus == c->init_plus_in_bin && c->cg_all_res == all_res_now && !c->static_dirty && c->sp_radius == cutoff;
+    c->cg_reused = reuse_grid;
     if (c->fuse_sets) {
         const size_t nres = (size_t)std::max<int64_t>(c->nres, 1);
         CHK(check_residue_ranges(c));
         bool fresh = false;
         HIPCHK(c, c->res_tag.reserve(2 * nres, &fresh));
-        if (fresh || c->res_tag_value >= 255) {
+        if (!reuse_grid && (fresh || c->res_tag_value >= 255)) {
             HIPCHK(c, hipMemsetAsync(c->res_tag.p, 0, c->res_tag.cap, c->stream));
             c->res_tag_value = 0;
         }
-        const uint8_t tag = (uint8_t)++c->res_tag_value;
+        // (a reused grid keeps the residue tags its build left: the masks below are made from the same tag value)
+        const uint8_t tag = reuse_grid ? (uint8_t)c->res_tag_value : (uint8_t)++c->res_tag_value;
         const bool all_res = c->whole_structure && c->sel_all;   // every residue of the (global) table is selected
         if (!all_res) rm = ResMarks{c->res_tag.p, c->res_tag.p + nres, tag};
         gm = GroupMasks{(int)c->nring, (int)c->namide, c->ring_res.p, c->am_res.p, c->res_tag.p, c->res_tag.p + nres, tag,
@@ -1232,7 +1254,14 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         CHK(ensure_static(c, cutoff));                                  // (what the lists read is in place on the main stream here)
         HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));
     }
-    CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + ctr_dev(C_BINNED), c->init_plus_in_bin ? c->plus.p : nullptr, rm));
+    if (!reuse_grid) {
+        c->cg_valid = false;
+        CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + ctr_dev(C_BINNED), c->init_plus_in_bin ? c->plus.p : nullptr, rm));
+        if (whole) {      // what this grid was built from; its atom count arrives with the counters of the pass (finish_contacts)
+            c->cg_valid = true; c->cg_pending = true; c->cg_radius = cutoff; c->cg_static_epoch = c->static_epoch; c->cg_sel_epoch = c->sel_epoch;
+            c->cg_fuse = c->fuse_sets; c->cg_init_plus = c->init_plus_in_bin; c->cg_all_res = all_res_now;
+        }
+    }
     if (masks_after_bin && c->nring + c->namide > 0) {
         hipLaunchKernelGGL(k_group_masks, dim3(nblocks(c->nring + c->namide, 256)), dim3(256), 0, c->stream, gm);
         CHK(check_launch(c, "k_group_masks"));
@@ -1378,6 +1407,8 @@ bool finish_contacts(arp_ctx* c) {
     c->stats[0] = (int64_t)c->h_ctr[C_CAND];
     c->stats[1] = (int64_t)c->h_ctr[C_ACC];
     c->stats[2] = (int64_t)np;
+    if (c->cg_reused) c->h_ctr[C_BINNED] = (u64)c->cg_binned;         // (no grid build in this pass: the count its build reported)
+    else if (c->cg_pending) { c->cg_binned = (int64_t)(uint32_t)c->h_ctr[C_BINNED]; c->cg_pending = false; }
     c->stats[3] = (int64_t)(uint32_t)c->h_ctr[C_BINNED];
     c->stats[4] = c->contact_cells;
     return false;
@@ -2440,6 +2471,7 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
     c->sel_uploaded = true;
     c->nsel = -1;
     c->sel_all = false;   // the caller's masks are taken as they are
+    ++c->sel_epoch;
     CHK(upload(c, c->ring_sel, ring_sel, (size_t)c->nring)); CHK(upload(c, c->ring_plus, ring_plus, (size_t)c->nring));
     CHK(upload(c, c->am_sel, amide_sel, (size_t)c->namide)); CHK(upload(c, c->am_plus, amide_plus, (size_t)c->namide));
     c->sel_made = true;
@@ -2468,6 +2500,7 @@ int arp_set_selection(arp_ctx* c, const uint8_t* in_selection) {
     c->sel_all = (nsel == c->n);
     if (nsel > 0 && nsel <= SMALL_SEL_MAX) CHK(upload(c, c->sel_list, list.data(), (size_t)nsel));
     c->sel_made = false;  // expansion pending
+    ++c->sel_epoch;
     c->all_grid_current = false;
     c->contacts_valid = false;
     return ARP_OK;
@@ -3374,6 +3407,13 @@ int arp_shard_reduce_residue_sets(arp_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nb = 2 * (size_t)std::max<int64_t>(c->nres, 1);
     NCCLCHK(c, rccl().AllReduce(c->res_sel.p, c->res_sel.p, nb, ncclUint8, ncclMax, c->comm, c->stream));
+    return ARP_OK;
+}
+
+int arp_set_grid_reuse(arp_ctx* c, int enabled) {
+    if (!c) return ARP_E_ARG;
+    c->grid_reuse = enabled != 0;
+    c->cg_valid = false;
     return ARP_OK;
 }
 

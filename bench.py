@@ -114,6 +114,20 @@ def bench_batch(args):
     dom = max((k for k in ('search', 'sift') if k in per_kernel), key=lambda k: per_kernel[k])
     b_alg = algorithmic_bytes(dom, st['binned'], st['cells'], st['emitted'], int(big.h_xyz.shape[0]))
     ms_per_step = elapsed / timed_steps * 1e3
+    # the same batch with its contact grid built in every pass (see main(): pass_with_grid_rebuild)
+    ctx.set_grid_reuse(False)
+    for _ in range(5):
+        step()
+    ctx.device_synchronize()
+    n_rb, t_rb = 0, time.perf_counter()
+    while n_rb < args.steps or time.perf_counter() - t_rb < 0.25:
+        step()
+        n_rb += 1
+    ctx.device_synchronize()
+    el_rb = time.perf_counter() - t_rb
+    grid_rebuild = {'ms_per_step': round(el_rb / n_rb * 1e3, 4), 'us_per_structure': round(el_rb / n_rb / B * 1e6, 3), 'steps': n_rb,
+                    'note': 'every pass compacts its atoms into a new contact grid (k_compact_atoms), as passes with a partial selection do'}
+    ctx.set_grid_reuse(True)
     # the same structures one at a time on the same context (resident pass of each distinct structure)
     single_ms = []
     for pc in distinct:
@@ -181,7 +195,7 @@ def bench_batch(args):
         'speedup_vs_one_at_a_time': round(float(np.mean(single_ms)) / (ms_per_step / B), 2),
         'pairs': {'candidates': float(st['candidates']), 'accepted': float(st['accepted']), 'contacts_emitted': float(st['emitted']),
                   'bags': {k: int(v) for k, v in counts.items()}},
-        'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()},
+        'kernel_ms': {k: round(v, 5) for k, v in per_kernel.items()}, 'pass_with_grid_rebuild': grid_rebuild,
         'roofline': {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(b_alg / (per_kernel[dom] * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
                      'frac': round(b_alg / (per_kernel[dom] * 1e-3) / 1e9 / 8000.0, 6), 'traffic': None,
                      'algorithmic_bytes_per_launch': int(b_alg), 'avg_launch_ms': round(per_kernel[dom], 5),
@@ -337,6 +351,40 @@ def main():
     elapsed_profiled = time.perf_counter() - t1
     ktimes = ctx.kernel_times(reset=True)
     ctx.set_profiling(False)
+
+    # The same pass with its contact grid BUILT every time (arp_set_grid_reuse(0)).  A whole-structure pass over a resident
+    # structure keeps the grid of the pass before it — the structure's own neighbour grid, which depends on nothing a pass
+    # changes — so the timed steps above launch k_search and k_sift_planes only; with a partial selection, a new cutoff or a new
+    # structure the grid is compacted by k_compact_atoms first.  Both figures belong in the line.
+    grid_rebuild = None
+    if world == 1:
+        ctx.set_grid_reuse(False)
+        for _ in range(5):
+            step()
+        sync_all()
+        n_rb, t_rb = 0, time.perf_counter()
+        while n_rb < args.steps or time.perf_counter() - t_rb < 0.25:
+            step()
+            n_rb += 1
+        sync_all()
+        el_rb = time.perf_counter() - t_rb
+        ctx.set_profiling(True)
+        ctx.kernel_times(reset=True)
+        for _ in range(args.steps):
+            step()
+        kt_rb = ctx.kernel_times(reset=True)
+        ctx.set_profiling(False)
+        st_rb = ctx.stats()
+        b_rb = 140 * st_rb['binned'] + 16 * st_rb['emitted']
+        grid_rebuild = {'ms_per_step': round(el_rb / n_rb * 1e3, 4), 'steps': n_rb, 'value': round(st_rb['candidates'] * n_rb / el_rb, 1),
+                        'kernel_ms': {k: round(v['ms'] / max(v['launches'], 1), 5) for k, v in kt_rb.items() if v['launches']},
+                        'roofline_pass': {'bytes_per_pass': int(b_rb), 'achieved_GBps': round(b_rb / (el_rb / n_rb) / 1e9, 2),
+                                          'frac': round(b_rb / (el_rb / n_rb) / 1e9 / HBM_PEAK_GBS, 6)},
+                        'note': 'every pass compacts selection_plus into a new contact grid (k_compact_atoms = kernel_ms.bin), as passes with a '
+                                'partial selection always do; bytes = SURVEY 8d\'s 140 N + 16 P, which includes the grid build'}
+        ctx.set_grid_reuse(True)
+        for _ in range(3):
+            step()
 
     # Throughput with several structures in flight (world == 1, informational, never `value`): one context per host
     # thread, as INTEGRATION.md prescribes; the passes of different contexts overlap on the GPU (each has its own
@@ -693,7 +741,7 @@ def main():
         'cpu_baseline_all_cores': cpu_mc,
         'cpu_baseline_python': cpu_py,
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
-        'launch_mode': 'three launches on one HIP stream (k_compact_atoms = the contact grid, k_search, k_sift_planes = per-pair evaluation + ring/amide loops; kernel_ms lists them as bin / search / sift), the last one publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
+        'launch_mode': 'a whole-structure pass over a resident structure is two launches on one HIP stream (k_search, k_sift_planes = per-pair evaluation + ring/amide loops; kernel_ms: search / sift) on the contact grid the structure\'s first pass left — the grid depends on the structure and the cutoff only; with a partial selection, another cutoff or a new structure k_compact_atoms builds it first (pass_with_grid_rebuild, kernel_ms.bin; end_to_end builds everything for every structure); the last launch publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
         'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2), 'shard_setup_breakdown_ms': shard_timings,
         'halo_exchange': (halo_note if world > 1 else None),
@@ -705,9 +753,12 @@ def main():
         'roofline_valu': roofline_valu,
         # the whole pass against the HBM peak with SURVEY 8d's contract bytes (140 B per atom binned + 16 B per contact) and the
         # step time of this run: what one 100 k-atom pass moves is a few per cent of what 8 TB/s could move in that time
-        'roofline_pass': {'bytes_per_pass': int(140 * st['binned'] + 16 * emitted), 'ms_per_step': round(ms_per_step, 4),
-                          'achieved': round((140 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                          'frac': round((140 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)} if world == 1 else None,
+        # (48 N + 16 P: SURVEY 8d's pair pass + side arrays + output — the 92 N of its bin / sort passes are not moved by a pass that
+        # keeps its grid; pass_with_grid_rebuild carries the figure with all 140 N)
+        'roofline_pass': {'bytes_per_pass': int(48 * st['binned'] + 16 * emitted), 'bytes_model': '48 N + 16 P (no grid build in this pass)', 'ms_per_step': round(ms_per_step, 4),
+                          'achieved': round((48 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                          'frac': round((48 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)} if world == 1 else None,
+        'pass_with_grid_rebuild': grid_rebuild,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(line), flush=True)

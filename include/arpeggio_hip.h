@@ -399,6 +399,13 @@ int arp_ring_residues(arp_ctx* ctx, int64_t nring, const double* center, int32_t
  * (a 1.25 M-contact list: 0.5 ms instead of 2.5 ms into pageable memory); any host pointer is accepted by every call. */
 int arp_host_alloc(uint64_t bytes, void** out);
 int arp_host_free(void* p);
+/* The contact grid of a whole-structure pass (no selection, or every atom selected: interactions.py:1395, 1407) is the
+ * structure's own neighbour grid — the counterpart of the KD-tree over `entity` (interactions.py:1394) — and is kept: the
+ * next pass with the same structure, cutoff and whole selection builds none.  Passes with any other selection compact
+ * selection_plus into a new grid every time, as the reference rebuilds NeighborSearch(selection_plus) (interactions.py:1442).
+ * enabled = 0 makes every pass build its grid (measurements); default 1. */
+int  arp_set_grid_reuse(arp_ctx* ctx, int enabled);
+
 /* Sharded runs with NO selection (the reference's default, I:1395: every atom of the structure): the caller
  * asserts that the selection is the whole global structure.  Then selection_plus = selection on every rank and every
  * residue of the table is in both residue sets (I:1413-1437) — including residues whose atoms live on another rank,

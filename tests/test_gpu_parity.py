@@ -570,6 +570,64 @@ def test_config5_full_size(ctx):
     assert len(np.unique(key)) == len(key) and gpp['dist'].max() <= 6.0
 
 
+def test_whole_structure_grid_is_kept_only_while_nothing_it_depends_on_changes(capi):
+    """A whole-structure pass keeps its contact grid for the next one (arp_set_grid_reuse).  Every pass of a sequence that changes
+    the selection, the cutoff, the structure, or overwrites the grid's buffers in between must equal the same pass on a context
+    that builds its grid every time — all five bags, bit for bit — and the statistics must report the same atom count."""
+    from arpeggio_amd import synth
+    pcs = [synth.config3(20_000, seed=31), synth.proteinlike(seed=5)]
+    keep, rebuild = capi.Context(0), capi.Context(0)
+    rebuild.set_grid_reuse(False)
+
+    def everything(cx, counts):
+        out = {'atom_atom': cx.atom_contacts_fetch(counts['atom_atom'])}
+        for k in ('atom_plane', 'plane_plane', 'group_group', 'group_plane'):
+            out[k] = cx.fetch_bag(k)
+        return out
+
+    def same(step):
+        a, b = step(keep), step(rebuild)
+        assert dict(a[0]) == dict(b[0]), (dict(a[0]), dict(b[0]))
+        for bag in a[1]:
+            for col in a[1][bag]:
+                x, y = a[1][bag][col], b[1][bag][col]
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (bag, col)
+        assert a[2]['binned'] == b[2]['binned'] and a[2]['cells'] == b[2]['cells']
+
+    def run(cutoff=5.0, comp=0.1, seq=False):
+        def step(cx):
+            c = cx.run_launch(cutoff, comp, seq)
+            return c, everything(cx, c), cx.stats()
+        return step
+
+    for pc in pcs:
+        part = (pc.res_id % 7 == 3).astype(np.uint8)
+        for cx in (keep, rebuild):
+            cx.set_complex(pc)
+        same(run()); same(run()); same(run(5.0, 0.3, True))          # built, kept, kept (other per-pair parameters)
+        same(run(4.0)); same(run(4.0)); same(run(5.0))                 # another cell edge, and back
+        for cx in (keep, rebuild):
+            cx.set_selection(part)
+        same(run()); same(run())                                       # a partial selection compacts every time ...
+        for cx in (keep, rebuild):
+            cx.set_selection(np.ones(pc.n_atoms, np.uint8))
+        same(run()); same(run())                                       # ... and selection_plus is whole again afterwards
+        for cx in (keep, rebuild):
+            cx.search_all(4.5)                                         # writes its own grid into the same buffers
+        same(run()); same(run())
+    for cx in (keep, rebuild):                                         # back to a structure seen before
+        cx.set_complex(pcs[0])
+    same(run()); same(run())
+    launches = []
+    for cx in (keep, rebuild):                                         # ... and the kept grid really is not built again
+        cx.set_profiling(True)
+        cx.kernel_times(reset=True)
+        cx.run_launch()
+        launches.append(cx.kernel_times(reset=True).get('bin', {}).get('launches', 0))
+    assert launches[0] == 0 and launches[1] >= 1, launches
+    keep.close(); rebuild.close()
+
+
 def test_quarter_million_atoms_centre_grids(ctx):
     """The per-GPU size of BASELINE configs[3]: the ring / amide centre grids have 24 k cells here — k_point_grids keeps their
     histogram in global memory (above 12 288 cells; below, in LDS: every smaller test) — and the candidate lists are built on the
