@@ -305,6 +305,20 @@ class DeviceShard:
     timings_ms: Optional[dict] = None # where the set-up time went: host packing of the home records / device work / exchange
 
 
+def _home_buffer_to_device(ctx, buf, home_ids, hx, edges, halo, n_res_global, rank, world, pack_ms):
+    t1 = time.perf_counter()
+    ctx.shard_set_home(buf)
+    faces, sends = {}, {}
+    for side in (-1, +1):
+        if 0 <= rank + side < world:
+            lo, hi = (-np.inf, edges[rank] + halo) if side < 0 else (edges[rank + 1] - halo, np.inf)
+            faces[side] = ctx.shard_pack_face(0 if side < 0 else 1, lo, hi)
+            sends[side] = home_ids[(hx >= lo) & (hx <= hi)]           # the same comparison the kernel makes
+    t2 = time.perf_counter()
+    return faces, dict(sends=sends, halo=halo, n_res_global=n_res_global, rank=rank, world=world,
+                       timings={'host_pack_home_records': pack_ms, 'upload_home_and_cut_faces': (t2 - t1) * 1e3})
+
+
 def shard_home_to_device(ctx, full: PackedComplex, rank: int, world: int, sel=None, cutoff=5.0):
     """Step 1 of the device assembly: this rank's home records to its GPU, the two face buffers cut out there.
     Returns (faces: side -> (pointer, bytes), bookkeeping for ``finish_shard_on_device``)."""
@@ -314,18 +328,24 @@ def shard_home_to_device(ctx, full: PackedComplex, rank: int, world: int, sel=No
     t0 = time.perf_counter()
     home_ids = np.nonzero(a_own == rank)[0]
     buf = _capi.pack_records_native(full, home_ids, np.nonzero(r_own == rank)[0], np.nonzero(m_own == rank)[0], sel)
-    t1 = time.perf_counter()
-    ctx.shard_set_home(buf)
-    faces, sends = {}, {}
-    hx = full.xyz[home_ids, 0].astype(np.float64)
-    for side in (-1, +1):
-        if 0 <= rank + side < world:
-            lo, hi = (-np.inf, edges[rank] + halo) if side < 0 else (edges[rank + 1] - halo, np.inf)
-            faces[side] = ctx.shard_pack_face(0 if side < 0 else 1, lo, hi)
-            sends[side] = home_ids[(hx >= lo) & (hx <= hi)]           # the same comparison the kernel makes
-    t2 = time.perf_counter()
-    return faces, dict(sends=sends, halo=halo, n_res_global=full.n_residues, rank=rank, world=world,
-                       timings={'host_pack_home_records': (t1 - t0) * 1e3, 'upload_home_and_cut_faces': (t2 - t1) * 1e3})
+    return _home_buffer_to_device(ctx, buf, home_ids, full.xyz[home_ids, 0].astype(np.float64), edges, halo, full.n_residues, rank, world,
+                                  (time.perf_counter() - t0) * 1e3)
+
+
+def shard_records_to_device(ctx, rec: Dict[str, np.ndarray], book: dict, rank: int, world: int, cutoff=5.0):
+    """The same from home records a rank made itself (``synth.slab_home_records``: a rank that generates — or reads — only
+    its own slab never holds the whole structure).  ``book``: edges of the slabs, size of the global residue table, x of the
+    home atoms."""
+    halo = halo_width(cutoff)
+    edges = np.asarray(book['edges'], np.float64)
+    inner = np.diff(edges[1:-1]) if world > 2 else np.array([np.inf])
+    if world > 1 and np.any(inner < halo):
+        raise ValueError('slabs are thinner than the halo: use fewer ranks for this structure')
+    from . import _capi
+    t0 = time.perf_counter()
+    buf = _capi.pack_records_buffer(rec)
+    return _home_buffer_to_device(ctx, buf, np.asarray(rec['gid'], np.int64), np.asarray(book['home_x'], np.float64), edges, halo,
+                                  int(book['n_res_global']), rank, world, (time.perf_counter() - t0) * 1e3)
 
 
 def finish_shard_on_device(ctx, received, book, whole_structure=False) -> DeviceShard:
@@ -349,12 +369,18 @@ def finish_shard_on_device(ctx, received, book, whole_structure=False) -> Device
                        send_left=book['sends'].get(-1), send_right=book['sends'].get(+1), halo=book['halo'])
 
 
-def make_shard_device(ctx, full: PackedComplex, rank: int, world: int, sel=None, cutoff=5.0,
+def make_shard_device(ctx, full, rank: int, world: int, sel=None, cutoff=5.0,
                       whole_structure=False) -> DeviceShard:
     """``make_shard_distributed`` + ``upload_shard`` without the host in the data path: the halo records are cut out,
     exchanged (``arp_shard_exchange_faces``: RCCL on the context's communicator, ``Context.comm_init``) and merged on
-    the GPUs."""
-    faces, book = shard_home_to_device(ctx, full, rank, world, sel, cutoff)
+    the GPUs.  ``full``: the whole structure (a PackedComplex), or ``(records, book)`` of this rank's home part alone
+    (``synth.slab_home_records``)."""
+    if isinstance(full, tuple):
+        if sel is not None:
+            raise ValueError('make_shard_device: home records carry their own selection column')
+        faces, book = shard_records_to_device(ctx, full[0], full[1], rank, world, cutoff)
+    else:
+        faces, book = shard_home_to_device(ctx, full, rank, world, sel, cutoff)
     t0 = time.perf_counter()
     received = ctx.shard_exchange_faces(faces.get(-1), faces.get(+1)) if world > 1 else {}
     ms = (time.perf_counter() - t0) * 1e3

@@ -86,6 +86,69 @@ def _close_pairs(xyz32, radius):
     return pairs[order].astype(np.int64)
 
 
+def _uniform_atoms(seed, idx, box, origin, water_frac):
+    """Coordinates (float32), water flag, element and type mask of the uniform atoms with indices ``idx`` — every quantity a
+    function of (seed, index) alone, so any subset of a structure can be generated without the rest."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    xyz_u = np.stack([u01(seed, 10 + a, idx) * box[a] + origin[a] for a in range(3)], axis=1).astype(np.float32) if idx.size else np.zeros((0, 3), np.float32)
+    is_water = u01(seed, 20, idx) < water_frac
+    ue = u01(seed, 21, idx)
+    cdf = np.cumsum([e[1] for e in _ELEMENTS])
+    cdf[-1] = 1.0 + 1e-9
+    elem_u = np.searchsorted(cdf, ue, side='right').astype(np.int64)
+    elem_u[is_water] = _EL_O
+
+    def p(stream):
+        return u01(seed, stream, idx)
+
+    tm = np.zeros(idx.size, np.uint32)
+    o, nn, c, s_, cl = (elem_u == _EL_O), (elem_u == _EL_N), (elem_u == _EL_C), (elem_u == _EL_S), (elem_u == _EL_CL)
+    acc = (o & (p(30) < 0.9)) | (nn & (p(30) < 0.2)) | (s_ & (p(30) < 0.3))
+    don = (o & (p(31) < 0.3)) | (nn & (p(31) < 0.7))
+    tm[acc] |= T['hbond acceptor'] | T['weak hbond acceptor']
+    tm[acc & (p(32) < 0.9)] |= T['xbond acceptor']
+    tm[don] |= T['hbond donor']
+    tm[o & (p(33) < 0.5)] |= T['carbonyl oxygen']
+    tm[o & (p(34) < 0.1)] |= T['neg ionisable']
+    tm[nn & (p(34) < 0.1)] |= T['pos ionisable']
+    wdon = c & (p(35) < 0.6)
+    tm[wdon] |= T['weak hbond donor']
+    tm[(c & (p(36) < 0.4)) | (s_ & (p(36) < 0.5)) | (cl & (p(36) < 0.5))] |= T['hydrophobe']
+    tm[c & (p(37) < 0.15)] |= T['aromatic']
+    tm[c & (p(38) < 0.2)] |= T['carbonyl carbon']
+    tm[cl] |= T['weak hbond acceptor']
+    # waters are donors and acceptors (interactions.py:1953-1956)
+    tm[is_water] = T['hbond acceptor'] | T['hbond donor']
+    return xyz_u, is_water, elem_u, tm
+
+
+def _ring_atoms(seed, ridx, box, origin):
+    """float32 [K, 6, 3]: the six atoms of the rings with indices ``ridx`` (regular hexagons, radius 1.39)."""
+    ridx = np.asarray(ridx, dtype=np.uint64)
+    if ridx.size == 0:
+        return np.zeros((0, 6, 3), np.float32)
+    rc = np.stack([u01(seed, 50 + a, ridx) * box[a] + origin[a] for a in range(3)], axis=1)
+    rrot = _rotation_matrices(seed, 53, ridx)
+    ang = np.arange(6) * (np.pi / 3.0)
+    hexa = 1.39 * (np.cos(ang)[None, :, None] * rrot[:, None, :, 0] + np.sin(ang)[None, :, None] * rrot[:, None, :, 1])
+    return (rc[:, None, :] + hexa).astype(np.float32)
+
+
+def _amide_atoms(seed, aidx, box, origin):
+    """float32 [K, 4, 3]: N, C, O, CA of the amide groups with indices ``aidx`` (planar)."""
+    aidx = np.asarray(aidx, dtype=np.uint64)
+    if aidx.size == 0:
+        return np.zeros((0, 4, 3), np.float32)
+    ac = np.stack([u01(seed, 60 + a, aidx) * box[a] + origin[a] for a in range(3)], axis=1)
+    arot = _rotation_matrices(seed, 63, aidx)
+    local = np.array([[1.33 * np.cos(np.deg2rad(120.0)), 1.33 * np.sin(np.deg2rad(120.0))],   # N
+                      [0.0, 0.0],                                                                # C
+                      [1.23 * np.cos(np.deg2rad(-120.0)), 1.23 * np.sin(np.deg2rad(-120.0))],  # O
+                      [1.52, 0.0]])                                                              # CA
+    am = local[None, :, 0, None] * arot[:, None, :, 0] + local[None, :, 1, None] * arot[:, None, :, 1]
+    return (ac[:, None, :] + am).astype(np.float32)
+
+
 def make_synthetic(n_uniform: int, seed: int = 3, density: float = 0.05, box=None,
                    origin=(0.0, 0.0, 0.0), n_rings: int = 0, n_amides: int = 0,
                    water_frac: float = 0.05, bond_radius: float = 1.7,
@@ -106,35 +169,7 @@ def make_synthetic(n_uniform: int, seed: int = 3, density: float = 0.05, box=Non
     idx = np.arange(n_uniform, dtype=np.uint64)
 
     # ---------------- uniform atoms ----------------
-    xyz_u = np.stack([u01(seed, 10 + a, idx) * box[a] + origin[a] for a in range(3)], axis=1).astype(np.float32)
-    is_water = u01(seed, 20, idx) < water_frac
-    ue = u01(seed, 21, idx)
-    cdf = np.cumsum([e[1] for e in _ELEMENTS])
-    cdf[-1] = 1.0 + 1e-9
-    elem_u = np.searchsorted(cdf, ue, side='right').astype(np.int64)
-    elem_u[is_water] = _EL_O
-
-    def p(stream):
-        return u01(seed, stream, idx)
-
-    tm = np.zeros(n_uniform, np.uint32)
-    o, nn, c, s_, cl = (elem_u == _EL_O), (elem_u == _EL_N), (elem_u == _EL_C), (elem_u == _EL_S), (elem_u == _EL_CL)
-    acc = (o & (p(30) < 0.9)) | (nn & (p(30) < 0.2)) | (s_ & (p(30) < 0.3))
-    don = (o & (p(31) < 0.3)) | (nn & (p(31) < 0.7))
-    tm[acc] |= T['hbond acceptor'] | T['weak hbond acceptor']
-    tm[acc & (p(32) < 0.9)] |= T['xbond acceptor']
-    tm[don] |= T['hbond donor']
-    tm[o & (p(33) < 0.5)] |= T['carbonyl oxygen']
-    tm[o & (p(34) < 0.1)] |= T['neg ionisable']
-    tm[nn & (p(34) < 0.1)] |= T['pos ionisable']
-    wdon = c & (p(35) < 0.6)
-    tm[wdon] |= T['weak hbond donor']
-    tm[(c & (p(36) < 0.4)) | (s_ & (p(36) < 0.5)) | (cl & (p(36) < 0.5))] |= T['hydrophobe']
-    tm[c & (p(37) < 0.15)] |= T['aromatic']
-    tm[c & (p(38) < 0.2)] |= T['carbonyl carbon']
-    tm[cl] |= T['weak hbond acceptor']
-    # waters are donors and acceptors (interactions.py:1953-1956)
-    tm[is_water] = T['hbond acceptor'] | T['hbond donor']
+    xyz_u, is_water, elem_u, tm = _uniform_atoms(seed, idx, box, origin, water_frac)
 
     # residues of the uniform block: runs of `atoms_per_residue` non-water atoms, then waters
     prot = ~is_water
@@ -144,24 +179,9 @@ def make_synthetic(n_uniform: int, seed: int = 3, density: float = 0.05, box=Non
     n_wat = int(is_water.sum())
     nres_u = n_prot_res + n_wat
 
-    # ---------------- rings: regular hexagons, radius 1.39 ----------------
-    ridx = np.arange(n_rings, dtype=np.uint64)
-    rc = np.stack([u01(seed, 50 + a, ridx) * box[a] + origin[a] for a in range(3)], axis=1)
-    rrot = _rotation_matrices(seed, 53, ridx)
-    ang = np.arange(6) * (np.pi / 3.0)
-    hexa = 1.39 * (np.cos(ang)[None, :, None] * rrot[:, None, :, 0] + np.sin(ang)[None, :, None] * rrot[:, None, :, 1])
-    xyz_r = (rc[:, None, :] + hexa).reshape(-1, 3).astype(np.float32)
-
-    # ---------------- amides: N, C, O, CA planar ----------------
-    aidx = np.arange(n_amides, dtype=np.uint64)
-    ac = np.stack([u01(seed, 60 + a, aidx) * box[a] + origin[a] for a in range(3)], axis=1)
-    arot = _rotation_matrices(seed, 63, aidx)
-    local = np.array([[1.33 * np.cos(np.deg2rad(120.0)), 1.33 * np.sin(np.deg2rad(120.0))],   # N
-                      [0.0, 0.0],                                                                # C
-                      [1.23 * np.cos(np.deg2rad(-120.0)), 1.23 * np.sin(np.deg2rad(-120.0))],  # O
-                      [1.52, 0.0]])                                                              # CA
-    am = local[None, :, 0, None] * arot[:, None, :, 0] + local[None, :, 1, None] * arot[:, None, :, 1]
-    xyz_a = (ac[:, None, :] + am).reshape(-1, 3).astype(np.float32)
+    # ---------------- rings: regular hexagons, radius 1.39; amides: N, C, O, CA planar ----------------
+    xyz_r = _ring_atoms(seed, np.arange(n_rings, dtype=np.uint64), box, origin).reshape(-1, 3)
+    xyz_a = _amide_atoms(seed, np.arange(n_amides, dtype=np.uint64), box, origin).reshape(-1, 3)
 
     # ---------------- assemble atoms ----------------
     xyz = np.concatenate([xyz_u, xyz_r, xyz_a], axis=0) if n else np.zeros((0, 3), np.float32)
@@ -316,6 +336,148 @@ def slab_config(n_per_slab: int, n_slabs: int, seed: int = 4) -> PackedComplex:
     n_rings, n_amides = n // 100, n // 50
     return make_synthetic(n - 6 * n_rings - 4 * n_amides, seed=seed, box=(L * n_slabs, L, L), n_rings=n_rings,
                           n_amides=n_amides, id=f'slab_{n_slabs}x{n_per_slab}')
+
+
+
+def slab_home_records(n_per_slab: int, n_slabs: int, rank: int, seed: int = 4, bond_radius: float = 1.7,
+                      water_frac: float = 0.05, atoms_per_residue: int = 8, residues_per_chain: int = 300):
+    """What rank ``rank`` of ``n_slabs`` owns of ``slab_config(n_per_slab, n_slabs, seed)`` — the records ``sharding.pack_records``
+    would cut out of the whole structure, bit for bit — WITHOUT building the whole structure: every per-atom quantity of the
+    synthetic model is a function of (seed, index), so a rank evaluates them for its slab (plus the 1.7 A of neighbours its
+    proximity bonds can reach) and computes for all atoms only the three cheap columns the partition needs (x, the water flag
+    behind the residue numbering, ring / amide positions).  Returns (records, book) for ``sharding.shard_records_to_device``."""
+    from . import sharding
+    n = n_per_slab * n_slabs
+    L = (n_per_slab / 0.05) ** (1.0 / 3.0)
+    n_rings, n_amides = n // 100, n // 50
+    n_uniform = n - 6 * n_rings - 4 * n_amides
+    box = np.asarray((L * n_slabs, L, L), np.float64)
+    origin = np.zeros(3)
+    n_ring_atoms = 6 * n_rings
+    # ---- columns of ALL atoms the partition and the residue numbering need
+    idx_all = np.arange(n_uniform, dtype=np.uint64)
+    x_u = (u01(seed, 10, idx_all) * box[0] + origin[0]).astype(np.float32)
+    water_all = u01(seed, 20, idx_all) < water_frac
+    prot_all = ~water_all
+    n_prot = int(prot_all.sum())
+    n_prot_res = (n_prot + atoms_per_residue - 1) // atoms_per_residue
+    n_wat = int(water_all.sum())
+    nres_u = n_prot_res + n_wat
+    nres = nres_u + n_rings + n_amides
+    res_u_all = np.where(prot_all, (np.cumsum(prot_all) - 1) // atoms_per_residue, n_prot_res + np.cumsum(water_all) - 1).astype(np.int64)
+    xyz_r_all = _ring_atoms(seed, np.arange(n_rings, dtype=np.uint64), box, origin)        # [R, 6, 3] float32 (1 % of the atoms)
+    xyz_a_all = _amide_atoms(seed, np.arange(n_amides, dtype=np.uint64), box, origin)      # [A, 4, 3]
+    x_all = np.concatenate([x_u, xyz_r_all[:, :, 0].ravel(), xyz_a_all[:, :, 0].ravel()])
+    edges = sharding.slab_edges(float(x_all.min()), float(x_all.max()), n_slabs)
+    a_own = sharding.owner_of(x_all, edges)
+    # rings / amides belong to the rank of their centre (float64 mean of the float32 atoms / float32 mean of C and N)
+    ring_center_all = xyz_r_all.astype(np.float64).mean(axis=1) if n_rings else np.zeros((0, 3))
+    amide_center_all = ((xyz_a_all[:, 1, :] + xyz_a_all[:, 0, :]) / np.float32(2.0)).astype(np.float32) if n_amides else np.zeros((0, 3), np.float32)
+    r_own = sharding.owner_of(ring_center_all[:, 0], edges)
+    m_own = sharding.owner_of(amide_center_all[:, 0], edges)
+    home = np.nonzero(a_own == rank)[0]                       # global atom ids, ascending
+    # ---- the margin set: home atoms and everything a proximity bond of a home atom can reach
+    lo = float(x_all[home].min()) - bond_radius - 1e-3 if home.size else 0.0
+    hi = float(x_all[home].max()) + bond_radius + 1e-3 if home.size else 0.0
+    marg = np.nonzero((x_all >= lo) & (x_all <= hi))[0]
+    mu = marg[marg < n_uniform]
+    mr = marg[(marg >= n_uniform) & (marg < n_uniform + n_ring_atoms)] - n_uniform
+    ma = marg[marg >= n_uniform + n_ring_atoms] - n_uniform - n_ring_atoms
+    xyz_mu, water_mu, elem_mu, tm_mu = _uniform_atoms(seed, mu.astype(np.uint64), box, origin, water_frac)
+    xyz_m = np.concatenate([xyz_mu, xyz_r_all.reshape(-1, 3)[mr], xyz_a_all.reshape(-1, 3)[ma]], axis=0)
+    elem_m = np.concatenate([elem_mu, np.full(mr.size, _EL_C), np.array([_EL_N, _EL_C, _EL_O, _EL_C])[ma % 4]]).astype(np.int64)
+    tmask_m = np.concatenate([tm_mu, np.full(mr.size, T['aromatic'] | T['hydrophobe'], np.uint32),
+                              np.array([T['hbond donor'], T['carbonyl carbon'],
+                                        T['hbond acceptor'] | T['weak hbond acceptor'] | T['xbond acceptor'] | T['carbonyl oxygen'],
+                                        T['weak hbond donor']], np.uint32)[ma % 4]]).astype(np.uint16)
+    water_m = np.concatenate([water_mu, np.zeros(mr.size + ma.size, bool)])
+    res_m = np.concatenate([res_u_all[mu], nres_u + mr // 6, nres_u + n_rings + ma // 4]).astype(np.int64)
+    # ---- bonds with at least one end in the margin set: ring / amide bonds by construction, proximity bonds by distance
+    pos_of = np.full(n, -1, np.int64)
+    pos_of[marg] = np.arange(marg.size)
+    bp = []
+    if n_rings:
+        rings_here = np.unique(mr // 6)
+        base = n_uniform + 6 * rings_here[:, None]
+        k = np.arange(6)[None, :]
+        bp.append(np.stack([(base + k).ravel(), (base + (k + 1) % 6).ravel()], axis=1))
+    if n_amides:
+        amides_here = np.unique(ma // 4)
+        base = n_uniform + n_ring_atoms + 4 * amides_here
+        for a_, b_ in ((0, 1), (1, 2), (1, 3)):
+            bp.append(np.stack([base + a_, base + b_], axis=1))
+    cp = _close_pairs(xyz_m, bond_radius)
+    bp.append(marg[cp])
+    bp = np.concatenate(bp, axis=0) if bp else np.zeros((0, 2), np.int64)
+    if bp.size:
+        bp = np.unique(np.sort(bp, axis=1), axis=0)
+    both = np.concatenate([bp, bp[:, ::-1]], axis=0)
+    is_home = np.zeros(n, bool)
+    is_home[home] = True
+    both = both[is_home[both[:, 0]]]                                   # the lists of home atoms only
+    both = both[np.lexsort((both[:, 1], both[:, 0]))]
+    hpos = pos_of[home]
+    deg = np.bincount(np.searchsorted(home, both[:, 0]), minlength=home.size).astype(np.int32) if home.size else np.zeros(0, np.int32)
+    bond_gid = both[:, 1].astype(np.int32)
+    first = np.concatenate([[0], np.cumsum(deg)])[:-1]
+    has = deg > 0
+    sb_xyz = np.zeros((home.size, 3), np.float32)
+    sb_xyz[has] = xyz_m[pos_of[bond_gid[first[has]]]]                  # first bonded atom = lowest id (utils.py:612-635)
+    tmask_h = tmask_m[hpos].copy()
+    elem_h = elem_m[hpos]
+    tmask_h[(elem_h == _EL_CL) & has] |= T['xbond donor']
+    # ---- hydrogens of the home atoms
+    wants_h = (tmask_h & (T['hbond donor'] | T['weak hbond donor'])) != 0
+    nh = np.where(wants_h, 1 + (u01(seed, 80, home.astype(np.uint64)) * 3).astype(np.int64), 0)
+    nh[water_m[hpos]] = 2
+    owner = np.repeat(home, nh)
+    slot = np.arange(int(nh.sum())) - np.repeat(np.concatenate([[0], np.cumsum(nh)])[:-1], nh)
+    hdir = _unit_vectors(seed, 81, owner.astype(np.uint64) * np.uint64(4) + slot.astype(np.uint64))
+    h_xyz = xyz_m[pos_of[owner]].astype(np.float64) + 1.0 * hdir if owner.size else np.zeros((0, 3))
+    # ---- flags, radii, residue rows
+    vdw_t = np.array([e[2] for e in _ELEMENTS])
+    cov_t = np.array([e[3] for e in _ELEMENTS])
+    flags = np.zeros(home.size, np.uint16)
+    flags[elem_h == _EL_ZN] |= config.F_METAL
+    flags[elem_h == _EL_CL] |= config.F_HALOGEN
+    flags[water_m[hpos]] |= config.F_WATER
+    flags[elem_h == _EL_C] |= config.F_ELEM_C
+    flags[elem_h == _EL_S] |= config.F_ELEM_S
+    res_h = res_m[hpos]
+    uni_prot = (home < n_uniform) & ~water_m[hpos]
+    if n_prot_res:
+        met_h = u01(seed, 70, np.minimum(res_h, n_prot_res - 1).astype(np.uint64)) < 0.05
+        flags[uni_prot & met_h] |= config.F_RES_MET
+    is_prot_res = res_h < n_prot_res
+    res_flags = np.where(is_prot_res, config.R_POLYPEPTIDE | config.R_HAS_SEQ, 0).astype(np.uint8)
+    res_prev = np.where(is_prot_res & (res_h % residues_per_chain != 0), res_h - 1, -1).astype(np.int32)
+    res_next = np.where(is_prot_res & (res_h % residues_per_chain != residues_per_chain - 1) & (res_h + 1 < n_prot_res), res_h + 1, -1).astype(np.int32)
+    # ---- rings / amides of this rank
+    rh, mh = np.nonzero(r_own == rank)[0], np.nonzero(m_own == rank)[0]
+    rp = xyz_r_all[rh].astype(np.float64)
+    if rh.size:
+        v = rp - ring_center_all[rh][:, None, :]
+        nrm = np.cross(v, np.roll(v, -1, axis=1)).sum(axis=1)
+        ring_normal = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    else:
+        ring_normal = np.zeros((0, 3))
+    ap = xyz_a_all[mh]
+    if mh.size:
+        nv = np.cross((ap[:, 2, :] - ap[:, 1, :]).astype(np.float64), (ap[:, 0, :] - ap[:, 1, :]).astype(np.float64))
+        amide_normal = (nv / np.linalg.norm(nv, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        amide_normal = np.zeros((0, 3), np.float32)
+    rec = {
+        'gid': home.astype(np.int32), 'xyz': xyz_m[hpos], 'vdw': vdw_t[elem_h], 'cov': cov_t[elem_h], 'tmask': tmask_h, 'flags': flags,
+        'res_gid': res_h.astype(np.int32), 'res_flags': res_flags, 'res_prev': res_prev, 'res_next': res_next,
+        'sel': np.ones(home.size, np.uint8), 'sb_xyz': sb_xyz, 'sb_has': has.astype(np.uint8), 'h_cnt': nh.astype(np.int32), 'h_xyz': h_xyz,
+        'bond_cnt': deg, 'bond_gid': bond_gid,
+        'ring_gid': rh.astype(np.int32), 'ring_center': ring_center_all[rh], 'ring_normal': ring_normal, 'ring_res': (nres_u + rh).astype(np.int32),
+        'amide_gid': mh.astype(np.int32), 'amide_center': amide_center_all[mh], 'amide_normal': amide_normal,
+        'amide_res': (nres_u + n_rings + mh).astype(np.int32),
+    }
+    book = dict(edges=edges, n_res_global=int(nres), n_atoms_global=int(n), home_x=x_all[home].astype(np.float64))
+    return rec, book
 
 
 def proteinlike(n_res: int = 480, seed: int = 2, n_waters: int = 300, id: str = 'proteinlike') -> PackedComplex:

@@ -255,7 +255,7 @@ def main():
         n_local_home = pc.n_atoms
     else:
         from arpeggio_amd import sharding
-        full = synth.slab_config(args.atoms, world, seed=4)
+        full = None      # (only the host-buffer debug modes build the whole structure: a rank generates its own slab)
         workload = (f'synthetic {args.atoms * world} atoms in {world} x-slabs of {args.atoms} '
                     f'(BASELINE configs[3]{"" if args.atoms * world == 2_000_000 else " family"}), one-cell halo over RCCL')
         # no fallback: if the exchange over RCCL fails, the run fails (a scaling figure must not be printed without it)
@@ -268,13 +268,19 @@ def main():
             args.host_halo = True      # (one-GPU debug mode: no RCCL between ranks that share a device)
         if args.host_halo:
             halo_note = 'records of the one-cell halo packed on the host, exchanged through host buffers (TCP rendezvous), merged on the host'
+            full = synth.slab_config(args.atoms, world, seed=4)
             shard = sharding.make_shard_distributed(full, rank, world, transport)
             sharding.upload_shard(ctx, shard, whole_structure=not args.staged_exchange)
             n_local = shard.pc.n_atoms
         else:
             halo_note = ('home records uploaded once; the one-cell halo cut out on the device, exchanged with grouped ncclSend / ncclRecv on the '
-                         'device buffers (RCCL behind the C ABI: arp_shard_exchange_faces), merged into the resident structure on the device (arp_shard_*)')
-            shard = sharding.make_shard_device(ctx, full, rank, world, whole_structure=not args.staged_exchange)
+                         'device buffers (RCCL behind the C ABI: arp_shard_exchange_faces), merged into the resident structure on the device (arp_shard_*); '
+                         'every rank generates the records of its own slab only (synth.slab_home_records)')
+            t_gen = time.perf_counter()
+            home = synth.slab_home_records(args.atoms, world, rank, seed=4)      # this rank's part of slab_config(atoms, world), nothing else
+            gen_home_ms = (time.perf_counter() - t_gen) * 1e3
+            shard = sharding.make_shard_device(ctx, home, rank, world, whole_structure=not args.staged_exchange)
+            shard.timings_ms['generate_home_records'] = round(gen_home_ms, 3)
             n_local = shard.n_atoms
             shard_timings = shard.timings_ms
         shard_setup_ms = (time.perf_counter() - t_sh) * 1e3

@@ -208,3 +208,48 @@ def test_rank_with_an_empty_slab(capi):
     assert planes == sum(n_one[k] for k in NAMES) > 0
     for c in ctxs + [one]:
         c.close()
+
+
+def test_shards_from_per_rank_records_equal_shards_from_the_whole_structure(capi):
+    """bench.py --gpus N: every rank makes the records of its own slab (synth.slab_home_records) and never holds the whole
+    structure; the shard assembled from them on the device — id maps, resident arrays, the contacts of a whole-structure pass —
+    equals the one cut out of slab_config(...)."""
+    n_per_slab, world = 6000, 3
+    full = synth.slab_config(n_per_slab, world, seed=4)
+    ctxs, shards = _assemble_all(capi, full, world, None, True)
+    ctxs2 = [capi.Context(0) for _ in range(world)]
+    step1 = [sharding.shard_records_to_device(c, *synth.slab_home_records(n_per_slab, world, r, seed=4), r, world) for r, c in enumerate(ctxs2)]
+    for r, c in enumerate(ctxs2):
+        received = {}
+        if r > 0:
+            received[-1] = step1[r - 1][0][+1]
+        if r + 1 < world:
+            received[+1] = step1[r + 1][0][-1]
+        ds = sharding.finish_shard_on_device(c, received, step1[r][1], whole_structure=True)
+        ref = shards[r]
+        for k in ('global_id', 'origin', 'is_home', 'sel', 'ring_gid', 'ring_home', 'amide_gid', 'amide_home'):
+            assert np.array_equal(getattr(ds, k), getattr(ref, k)), (r, k)
+        for k in ('send_left', 'send_right'):
+            x, y = getattr(ds, k), getattr(ref, k)
+            assert (x is None) == (y is None) and (x is None or np.array_equal(x, y)), (r, k)
+        got, want = capi.unpack_blob(c.get_blob()), capi.unpack_blob(ctxs[r].get_blob())
+        for k in ('xyz', 'rad', 'type_mask', 'flags', 'res_id', 'res_flags', 'res_prev', 'res_next', 'bond_off', 'bond_idx', 'h_off', 'h_xyz',
+                  'ring_center', 'ring_normal', 'ring_res', 'amide_center', 'amide_normal', 'amide_res'):
+            assert np.array_equal(got[k], want[k]), (r, k)
+        n_a, n_b = sharding.run_shard_whole_structure(c, sh=ds), sharding.run_shard_whole_structure(ctxs[r], sh=ref)
+        assert n_a == n_b and n_a['atom_atom'] > 100
+        a, b = c.atom_contacts_fetch(n_a['atom_atom']), ctxs[r].atom_contacts_fetch(n_b['atom_atom'])
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (r, k)
+    for c in ctxs + ctxs2:
+        c.close()
+    # the one-call form bench.py uses, on a world of one (no neighbour, no exchange)
+    one, whole = capi.Context(0), capi.Context(0)
+    ds = sharding.make_shard_device(one, synth.slab_home_records(n_per_slab, 1, 0, seed=4), 0, 1, whole_structure=True)
+    whole.set_complex(synth.slab_config(n_per_slab, 1, seed=4))
+    n_a, n_b = sharding.run_shard_whole_structure(one, sh=ds), whole.run_launch()
+    assert dict(n_a) == dict(n_b) and n_a['atom_atom'] > 100
+    a, b = one.atom_contacts_fetch(n_a['atom_atom']), whole.atom_contacts_fetch(n_b['atom_atom'])
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    one.close(); whole.close()

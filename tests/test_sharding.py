@@ -310,3 +310,27 @@ def test_tcp_rendezvous_three_ranks():
     assert got[0][4] == {1: (4, 1)}
     assert got[1][4] == {-1: (5, 100), 1: (5, 2)}
     assert got[2][4] == {-1: (6, 101)}
+
+
+@pytest.mark.parametrize('n_per_slab,world', [(5000, 3), (3000, 2)])
+def test_a_rank_generates_its_own_slab(n_per_slab, world):
+    """synth.slab_home_records: what a rank owns of slab_config(...) WITHOUT the whole structure in its memory — every field of
+    the records sharding.pack_records cuts out of the whole structure, same dtypes, same bytes; and the record buffer
+    (the C ABI's packer on the records alone) equals the one the native packer makes from the whole structure."""
+    from arpeggio_amd import _capi
+    full = synth.slab_config(n_per_slab, world, seed=4)
+    edges, a_own, r_own, m_own = sharding._partition(full, world, sharding.halo_width())
+    for rank in range(world):
+        ids = [np.nonzero(o == rank)[0] for o in (a_own, r_own, m_own)]
+        want = sharding.pack_records(full, *ids)
+        got, book = synth.slab_home_records(n_per_slab, world, rank, seed=4)
+        assert np.array_equal(book['edges'], edges) and book['n_res_global'] == full.n_residues and book['n_atoms_global'] == full.n_atoms
+        assert np.array_equal(book['home_x'], full.xyz[ids[0], 0].astype(np.float64))
+        assert set(got) == set(want)
+        for k in want:
+            w, g = np.asarray(want[k]), np.asarray(got[k])
+            assert w.dtype == g.dtype and w.shape == g.shape, (rank, k, w.dtype, g.dtype, w.shape, g.shape)
+            assert np.array_equal(np.ascontiguousarray(w).view(np.uint8), np.ascontiguousarray(g).view(np.uint8)), (rank, k)
+        a = _capi.pack_records_buffer(got, pinned=False)
+        b = _capi.pack_records_native(full, *ids, pinned=False)
+        assert a.size == b.size and np.array_equal(a, b), rank
