@@ -185,6 +185,8 @@ struct arp_ctx {
     GridDesc sp_grid{};           // the grid the spatial order was made for
     double sp_radius = 0;         // ... and its cell edge (0: no order yet)
     DevBuf<unsigned long long> compact_chain;   // k_compact_atoms: one word per block
+    DevBuf<int> s_cell;                         // cell of every row of the contact grid (k_search: blocks split by atoms)
+    bool s_cell_valid = false;                  // ... written by the build of the grid that is in place
     unsigned int compact_epoch = 0;
     bool static_dirty = true;
     // The contact grid of a WHOLE-STRUCTURE pass (every atom selected: selection_plus = all atoms, I:1395 / 1407) depends on the
@@ -731,6 +733,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
 int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr,
                        ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
     c->cg_valid = false;      // (the buffers of the pass's grid are rewritten)
+    c->s_cell_valid = false;
     return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
 }
 // The contact grid of a pass as an ordered compaction of the static columns (k_compact_atoms): ONE launch.
@@ -761,10 +764,13 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
         A.r = static_atoms(c);
         A.sp_cell = c->sp_cell.p; A.n = n; A.ncell = ncell; A.req = req; A.forb = forb;
         A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_rec = c->s_rec.p; A.s_b4 = c->s_b4.p;
+        HIPCHK(c, c->s_cell.reserve((size_t)std::max(n, 1)));
+        A.s_cell = c->s_cell.p;
         A.start = G.start.p; A.chain = c->compact_chain.p; A.epoch = c->compact_epoch; A.total_out = total_out;
         A.plus_init = plus_init; A.rm = rm; A.err = (int*)(c->d_ctr + ctr_dev(C_ERR));
         hipLaunchKernelGGL(k_compact_atoms, dim3(nb), dim3(COMPACT_THREADS), 0, c->stream, A);
         CHK(check_launch(c, "k_compact_atoms"));
+        c->s_cell_valid = true;
     } else {
         HIPCHK(c, hipMemsetAsync(G.start.p, 0, ((size_t)ncell + 1) * sizeof(int), c->stream));
         if (total_out) HIPCHK(c, hipMemsetAsync(total_out, 0, sizeof(u64), c->stream));
@@ -965,7 +971,7 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
                            c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
-                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{});
+                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
@@ -1286,10 +1292,24 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // and a wave's cells are a serial chain (1tqn_h stand-in: 22 -> 16 us).
         static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 3));
         const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
-        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(search_blocks_balanced(c, c->atom_grid.d, cpw)), dim3(64 * SEARCH_WAVES), 0,
+        // Sparse grids (fewer atoms than cells: a protein in its box, a ligand's selection_plus, a batch): the blocks split the
+        // ATOMS of the grid evenly instead of its cells (k_search, cell_of_pos) and their number goes with the atoms — what the
+        // grid's build reported last time, all atoms of the structure before that is known.
+        static const int balance_mode = env_int("ARP_SEARCH_BALANCE", -1);     // -1: by sparsity, 0: never, 1: whenever the cells of the rows are known
+        const int64_t atoms_est = c->cg_reused ? c->cg_binned : (c->stats[4] == c->atom_grid.d.ncell && c->stats[3] > 0 ? c->stats[3] : c->n);
+        const bool by_atoms = c->s_cell_valid && (balance_mode == 1 || (balance_mode < 0 && (int64_t)c->atom_grid.d.ncell > atoms_est));
+        int nblocks_search = search_blocks_balanced(c, c->atom_grid.d, cpw);
+        if (by_atoms) {
+            const int R = c->search_resident;
+            int nbk = (int)std::min<int64_t>(std::max<int64_t>((atoms_est + 127) / 128, 8), 8192);
+            nbk = (nbk + 7) & ~7;
+            nblocks_search = (R >= 8 && 2 * nbk >= R) ? std::min(std::max(1, (nbk + R / 2) / R) * R, 8192) & ~7 : nbk;
+        }
+        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                            c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
                            include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
-                           c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm);
+                           c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
+                           by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
         return check_launch(c, "k_search<CONTACTS>");
     };
     bool lists_forked = false;
@@ -2524,7 +2544,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
-                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{});
+                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));
