@@ -1412,12 +1412,18 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         }
         const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
         // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
-        bool cov = (d <= longest_bond) & ((nbr.x == e) | (nbr.y == e) | (nbr.z == e) | (nbr.w == e));       // (-1 / -2 never equal a local id)
+        // (one of the four equal <=> the smallest of the four XORs is zero; -1 / -2 never equal a local id)
+        const unsigned nx_ = min(min((unsigned)(nbr.x ^ e), (unsigned)(nbr.y ^ e)), min((unsigned)(nbr.z ^ e), (unsigned)(nbr.w ^ e)));
+        bool cov = (d <= longest_bond) & (nx_ == 0u);
         if ((d <= longest_bond) & !cov & (nbr.w == -2))                           // more than four neighbours: the rest of the list
             for (int k = qb.q1.y + 3, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
                 if (bond_idx[k] == e) { cov = true; break; }
         // interactions.py:756-773: float32 distance against Python floats -> float32 compare; an exclusive ladder
-        uint32_t s = cov ? ARP_S_COVALENT : (d < f_sum_cov) ? ARP_S_CLASH : (d < f_sum_vdw) ? ARP_S_VDW_CLASH : (d <= f_vdw_comp) ? ARP_S_VDW : ARP_S_PROXIMAL;
+        uint32_t s = ARP_S_PROXIMAL;                                   // (selects from the bottom up: no branch per rung)
+        s = (d <= f_vdw_comp) ? ARP_S_VDW : s;
+        s = (d < f_sum_vdw) ? ARP_S_VDW_CLASH : s;
+        s = (d < f_sum_cov) ? ARP_S_CLASH : s;
+        s = cov ? ARP_S_COVALENT : s;
         // interactions.py:777-783: an hbond acceptor beside a metal
         const uint32_t metal = ((tb & (me >> 12)) | (te & (mb >> 12))) & 1u;        // ARP_T_HBOND_ACCEPTOR = bit 0, M_METAL = bit 12
         s |= (d <= (float)2.8) ? metal * ARP_S_METAL_COMPLEX : 0u;
