@@ -362,8 +362,7 @@ def main():
     # structure keeps the grid of the pass before it — the structure's own neighbour grid, which depends on nothing a pass
     # changes — so the timed steps above launch k_search and k_sift_planes only; with a partial selection, a new cutoff or a new
     # structure the grid is compacted by k_compact_atoms first.  Both figures belong in the line.
-    grid_rebuild = None
-    if world == 1:
+    def measure_with_grid_rebuild():
         ctx.set_grid_reuse(False)
         for _ in range(5):
             step()
@@ -391,6 +390,16 @@ def main():
         ctx.set_grid_reuse(True)
         for _ in range(3):
             step()
+        return grid_rebuild
+
+    grid_rebuild = None
+    if world == 1:
+        try:
+            grid_rebuild = measure_with_grid_rebuild()
+        except Exception as exc:   # never lose the main line over the extra measurement
+            grid_rebuild = {'error': repr(exc)}
+            ctx.set_profiling(False)
+            ctx.set_grid_reuse(True)
 
     # Throughput with several structures in flight (world == 1, informational, never `value`): one context per host
     # thread, as INTEGRATION.md prescribes; the passes of different contexts overlap on the GPU (each has its own
