@@ -7,8 +7,13 @@ One "step" = one pass of the whole hot path (InteractionComplex.run_arpeggio,
 interactions.py:329-347: 6 A selection expansion, 5 A neighbour search + fused 15-flag
 SIFt evaluation, ring/amide plane kernels) over the structure resident in HBM; results
 stay in HBM.  Unit of work = one candidate atom pair of the 5 A contact search (SURVEY.md
-§8d).  N > 1: the box is elongated along x (weak scaling, BASELINE configs[3] family),
-sharded into N slabs with a one-cell halo exchanged over RCCL before the timed region.
+§8d).  The workload selects the whole structure, so a pass keeps the neighbour grid of the
+pass before it; `pass_with_grid_rebuild` in the line is the same pass with
+the grid built every time, `end_to_end` a new structure every step.  N > 1: the box is
+elongated along x (weak scaling, BASELINE configs[3] family), sharded into N slabs with a
+one-cell halo exchanged over RCCL before the timed region; the ranks meet over plain TCP
+(arpeggio_amd/rendezvous.py) and the timed region is bracketed by arp_device_synchronize +
+barrier — no PyTorch in this process.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
 dominant kernel (HIP-event time on the context's own stream) and `cpu_baseline` (the C
