@@ -636,7 +636,7 @@ def main():
                 'traffic_source': (None if traffic_src is None else f'committed profile, NOT this run: {traffic_src}'),
                 'algorithmic_bytes_per_launch': int(b_alg), 'algorithmic_bytes_without_hydrogen_coordinates': int(b_alg - (24 * n_h if dom == 'sift' else 0)),
                 'avg_launch_ms': round(dom_ms, 5), 'dominant_kernel_rule': tie_rule,
-                'note': {'search': 'VALU-issue-bound geometry kernel (8.8 M wave-instructions per launch at ~4 cycles each, profiles/round3_final_pmc_per_launch.csv); half of the kernel is the decay of occupancy while the slowest waves of every CU finish (block trace, profiles/README.md); ',
+                'note': {'search': 'VALU-issue-bound geometry kernel (8.8 M wave-instructions per launch at ~4 cycles each, profiles/round3_head_pmc_per_launch.csv); half of the kernel is the decay of occupancy while the slowest waves of every CU finish (block trace, profiles/README.md); ',
                          'sift': 'VALU issue at 4 waves per SIMD (127 VGPRs; ~285 VALU per batch of 64 pairs keeps the SIMD issuing, more waves were slower): 7.1 M wave-instructions per launch, 59 % of the wave cycles are waits (SQ_WAIT_ANY) — the dependent round trips at the start and the end of every wave; ',
                          'mark_search': 'VALU / LDS issue-bound geometry kernel; '}.get(dom, '') +
                         'the HBM fraction is small by construction: register-tiled pair tests move ~35 MB per 100 k-atom pass (SURVEY 8d)'}
