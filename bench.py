@@ -462,6 +462,27 @@ def main():
     # ring / amide grids rebuilt, the pass, and every result bag copied into page-locked host buffers.  The structures
     # cycle through four different seeds of the same workload.  Measured with one context (latency of one structure)
     # and with three contexts on three host threads (upload / pass / download of consecutive structures overlap).
+    # BASELINE configs[0]'s use of the reference (`-s /A/508/`: a ligand and its binding site) on the stand-in: the selection is
+    # expanded (k_expand_small), selection_plus compacted into the pass's grid (k_compact_atoms), then search + per-pair kernel
+    ligand_pass = None
+    if world == 1 and args.workload == 'standin':
+        try:
+            lig = (np.asarray(pc.res_seq)[np.asarray(pc.res_id)] == 508).astype(np.uint8)
+            if lig.sum() > 0:
+                ctx.set_selection(lig)
+                for _ in range(10):
+                    cl = ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+                tl = time.perf_counter()
+                for _ in range(500):
+                    cl = ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+                ligand_pass = {'selection': '/A/508/', 'selected_atoms': int(lig.sum()), 'ms_per_pass': round((time.perf_counter() - tl) / 500 * 1e3, 4),
+                               'candidate_pairs': int(ctx.stats()['candidates']), 'bags': {k: int(v) for k, v in cl.items()}}
+            ctx.set_selection(np.ones(pc.n_atoms, np.uint8))
+            for _ in range(3):
+                step()
+        except Exception as exc:   # never lose the main line over the extra measurement
+            ligand_pass = {'error': repr(exc)}
+
     end_to_end = None
     if world == 1 and not args.no_end_to_end:
         try:
@@ -778,7 +799,7 @@ def main():
         'roofline_pass': {'bytes_per_pass': int(48 * st['binned'] + 16 * emitted), 'bytes_model': '48 N + 16 P (no grid build in this pass)', 'ms_per_step': round(ms_per_step, 4),
                           'achieved': round((48 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': round((48 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)} if world == 1 else None,
-        'pass_with_grid_rebuild': grid_rebuild,
+        'pass_with_grid_rebuild': grid_rebuild, 'ligand_selection_pass': ligand_pass,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(line), flush=True)
