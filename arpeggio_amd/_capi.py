@@ -35,6 +35,7 @@ SYMBOLS = (
     'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_records_fill', 'arp_shard_set_home', 'arp_shard_pack_face',
     'arp_shard_assemble', 'arp_shard_layout', 'arp_get_blob', 'arp_cif_open', 'arp_cif_close', 'arp_cif_rows', 'arp_cif_cols',
     'arp_cif_blocks', 'arp_cif_tag', 'arp_cif_text', 'arp_cif_column', 'arp_cif_column_f64', 'arp_cif_column_i64',
+    'arp_atom_contacts_sort', 'arp_fetch_packed',
 )
 
 _lib = None
@@ -76,6 +77,8 @@ def load():
     L.arp_atom_contacts_launch.argtypes = [vp, dbl, dbl, i32, C.POINTER(i64)]
     L.arp_atom_contacts_fetch.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_atom_contacts.argtypes = [vp, dbl, dbl, i32, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.arp_atom_contacts_sort.argtypes = [vp]
+    L.arp_fetch_packed.argtypes = [vp, vp, C.c_uint64, vp, vp, C.POINTER(C.c_uint64)]
     L.arp_atom_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_plane_plane.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.arp_group_group.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]
@@ -734,14 +737,60 @@ class Context:
             oi, oj = np.empty(cap, np.int32), np.empty(cap, np.int32)
             od, osf, oc = np.empty(cap, np.float32), np.empty(cap, np.uint16), np.empty(cap, np.uint8)
         cnt = C.c_int64(0)
+        if sort:      # canonical (i, j) order, made on the device (csrc/arp_sort.h)
+            self._check(self._L.arp_atom_contacts_sort(self._h), 'arp_atom_contacts_sort')
         self._check(self._L.arp_atom_contacts_fetch(self._h, cap, _p(oi), _p(oj), _p(od), _p(osf), _p(oc), C.byref(cnt)),
                     'arp_atom_contacts_fetch')
         k = int(cnt.value)
-        out = dict(i=oi[:k], j=oj[:k], dist=od[:k], sift=osf[:k], ctype=oc[:k])
-        if sort:
-            o = np.lexsort((out['j'], out['i']))
-            out = {kk: v[o] for kk, v in out.items()}
-        return out
+        return dict(i=oi[:k], j=oj[:k], dist=od[:k], sift=osf[:k], ctype=oc[:k])
+
+    def sort_contacts(self):
+        """Put the resident atom-atom bag into the canonical (i, j) order (device radix sort; fetches after it deliver that order)."""
+        self._check(self._L.arp_atom_contacts_sort(self._h), 'arp_atom_contacts_sort')
+
+    # columns of the four ring / amide bags inside a packed fetch: (key, slot q of arp_fetch_packed's offsets, dtype)
+    _PACKED_BAGS = (
+        ('plane_plane', (('bgn', 0, np.int32), ('end', 1, np.int32), ('dist', 2, np.float64), ('dihedral', 3, np.float64),
+                         ('theta_bgn', 4, np.float64), ('theta_end', 5, np.float64), ('type1', 9, np.uint8), ('type2', 10, np.uint8),
+                         ('ctype', 11, np.uint8))),
+        ('atom_plane', (('atom', 0, np.int32), ('ring', 1, np.int32), ('dist', 2, np.float64), ('theta', 3, np.float64),
+                        ('mask', 9, np.uint8), ('ctype', 10, np.uint8))),
+        ('group_group', (('bgn', 0, np.int32), ('end', 1, np.int32), ('dist', 6, np.float32), ('dihedral', 7, np.float32),
+                         ('theta', 8, np.float32), ('ctype', 9, np.uint8))),
+        ('group_plane', (('amide', 0, np.int32), ('ring', 1, np.int32), ('dist', 2, np.float64), ('dihedral', 3, np.float64),
+                         ('theta', 4, np.float64), ('ctype', 9, np.uint8))),
+    )
+
+    def fetch_packed(self, buf=None, sort_bags=True):
+        """All five result bags of the last pass with ONE device-to-host copy (arp_fetch_packed): the atom-atom bag in
+        canonical order (sorted on the device) and the ring / amide bags behind it.  ``buf``: a page-locked uint8 buffer
+        from ``pinned_empty`` (reused from structure to structure; the returned arrays are views into it, valid until the
+        next fetch into it); grown when too small.  Returns ``(bags, buf)``."""
+        counts = (C.c_int64 * 5)()
+        offs = (C.c_uint64 * 53)()
+        used = C.c_uint64(0)
+        if buf is None:
+            buf = pinned_empty(1 << 20, np.uint8)
+        rc = self._L.arp_fetch_packed(self._h, _p(buf), buf.nbytes, counts, offs, C.byref(used))
+        if rc == ARP_E_CAPACITY and int(used.value) > buf.nbytes:
+            buf = pinned_empty(int(used.value) + int(used.value) // 4 + 4096, np.uint8)
+            rc = self._L.arp_fetch_packed(self._h, _p(buf), buf.nbytes, counts, offs, C.byref(used))
+        self._check(rc, 'arp_fetch_packed')
+
+        def view(off, dtype, n):
+            return np.frombuffer(buf, dtype, n, int(off)) if n else np.empty(0, dtype)
+        k = int(counts[0])
+        bags = {'atom_atom': dict(i=view(offs[0], np.int32, k), j=view(offs[1], np.int32, k), dist=view(offs[2], np.float32, k),
+                                  sift=view(offs[3], np.uint16, k), ctype=view(offs[4], np.uint8, k))}
+        for b, (name, cols) in enumerate(self._PACKED_BAGS):
+            m = int(counts[1 + b])
+            res = {key: view(offs[5 + 12 * b + q], dt, m) for key, q, dt in cols}
+            if sort_bags and m:
+                order = self._BAGS[name][2]
+                o = np.lexsort((res[order[1]], res[order[0]]))
+                res = {kk: v[o] for kk, v in res.items()}
+            bags[name] = res
+        return bags, buf
 
     def atom_contacts(self, cutoff=5.0, vdw_comp=0.1, include_sequence_adjacent=False, sort=True):
         n = self.atom_contacts_launch(cutoff, vdw_comp, include_sequence_adjacent)

@@ -174,13 +174,9 @@ class InteractionComplex:
         self.selection_plus_ring_ids = set(np.nonzero(masks['ring_plus'])[0].tolist())
         self.selection_amide_ids = set(np.nonzero(masks['amide_sel'])[0].tolist())
         self.selection_plus_amide_ids = set(np.nonzero(masks['amide_plus'])[0].tolist())
-        self._bags = {
-            'atom_atom': ctx.atom_contacts_fetch(counts['atom_atom']),
-            'plane_plane': ctx.fetch_bag('plane_plane'),
-            'atom_plane': ctx.fetch_bag('atom_plane'),
-            'group_group': ctx.fetch_bag('group_group'),
-            'group_plane': ctx.fetch_bag('group_plane'),
-        }
+        # all five bags with one copy; the atom-atom bag arrives in the canonical (i, j) order, made on the device
+        # (the arrays are views into a page-locked buffer of their own: the next run allocates another one)
+        self._bags, _ = ctx.fetch_packed()
         self.stats = ctx.stats()
 
     # ---- result bags as lists of the reference's namedtuples (built on demand) ----

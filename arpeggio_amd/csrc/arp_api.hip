@@ -25,6 +25,7 @@
 #include "arp_shard.h"
 #include "arp_cif.h"
 #include "arp_comm.h"
+#include "arp_sort.h"
 
 namespace {
 
@@ -215,6 +216,15 @@ struct arp_ctx {
     DevBuf<uint16_t> out_s;
     DevBuf<uint8_t> out_ct;
     int64_t n_contacts = 0;
+    // ---- canonical (i, j) order of the atom-atom bag, made on the device (arp_sort.h; arp_atom_contacts_sort)
+    DevBuf<unsigned long long> sort_key[2];
+    DevBuf<uint32_t> sort_idx[2];
+    DevBuf<int> sort_table;
+    DevBuf<uint8_t> sorted_slab;        // the five sorted columns (+ the packed ring / amide bags of a packed fetch) in one piece
+    size_t srt_off[5] = {0, 0, 0, 0, 0};  // byte offsets of i, j, distance, SIFt, contact type in sorted_slab
+    size_t srt_bytes = 0;               // bytes of the five columns
+    bool contacts_sorted = false;       // sorted_slab holds the records of the last launch in (i, j) order
+    int64_t gid_max = -1;               // largest global atom id of a shard (-1: not known, 31-bit keys)
     bool pass_pending = false;      // arp_run_enqueue without its arp_run_wait yet
     double pending_cutoff = 5.0, pending_comp = 0.1, pending_expand = 6.0;
     int pending_seq_adj = 0;
@@ -1424,6 +1434,7 @@ bool finish_contacts(arp_ctx* c) {
     c->n_contacts = (int64_t)np;
     c->contacts_expected = (int64_t)np;
     c->contacts_valid = true;
+    c->contacts_sorted = false;
     c->stats[0] = (int64_t)c->h_ctr[C_CAND];
     c->stats[1] = (int64_t)c->h_ctr[C_ACC];
     c->stats[2] = (int64_t)np;
@@ -1432,6 +1443,75 @@ bool finish_contacts(arp_ctx* c) {
     c->stats[3] = (int64_t)(uint32_t)c->h_ctr[C_BINNED];
     c->stats[4] = c->contact_cells;
     return false;
+}
+
+// ---- canonical order of the atom-atom bag (arp_sort.h) --------------------------------------------------------
+// Layout of the sorted slab: the five columns one after the other, each on a 256-byte boundary; what follows them
+// (sorted_extra bytes) is the caller's (the packed ring / amide bags of arp_fetch_packed).
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+void sorted_layout(size_t k, size_t off[5], size_t* bytes) {
+    off[0] = 0;
+    off[1] = off[0] + al256(k * sizeof(int32_t));
+    off[2] = off[1] + al256(k * sizeof(int32_t));
+    off[3] = off[2] + al256(k * sizeof(float));
+    off[4] = off[3] + al256(k * sizeof(uint16_t));
+    *bytes = off[4] + al256(k * sizeof(uint8_t));
+}
+int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
+    if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_atom_contacts_sort: no atom-contact results (call a launch first)");
+    const size_t k = (size_t)c->n_contacts;
+    size_t off[5], bytes;
+    sorted_layout(k, off, &bytes);
+    if (c->contacts_sorted && c->sorted_slab.cap >= bytes + extra_bytes) return ARP_OK;
+    {   // sized from the capacity of the unsorted columns, so that the slab is allocated once per structure size
+        size_t off_cap[5], bytes_cap;
+        sorted_layout(std::max(k, c->out_i.cap), off_cap, &bytes_cap);
+        HIPCHK(c, c->sorted_slab.reserve(std::max(bytes_cap, bytes + extra_bytes)));
+    }
+    for (int q = 0; q < 5; ++q) c->srt_off[q] = off[q];
+    c->srt_bytes = bytes;
+    if (k == 0) { c->contacts_sorted = true; return ARP_OK; }
+    // significant bits of an atom index: packed ids of the resident structure, global ids on a shard
+    const int64_t idmax = c->has_gid ? (c->gid_max >= 0 ? c->gid_max : ((int64_t)1 << 31) - 1) : std::max<int64_t>(c->n - 1, 1);
+    int idbits = 1;
+    while (((int64_t)1 << idbits) <= idmax) ++idbits;
+    const int keybits = 2 * idbits;
+    const int passes = (keybits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
+    const size_t cap = std::max(k, c->out_i.cap);
+    if (passes > 1) {
+        HIPCHK(c, c->sort_key[0].reserve(cap)); HIPCHK(c, c->sort_idx[0].reserve(cap));
+        if (passes > 2) { HIPCHK(c, c->sort_key[1].reserve(cap)); HIPCHK(c, c->sort_idx[1].reserve(cap)); }
+    }
+    HIPCHK(c, c->sort_table.reserve((size_t)SORT_BINS * SORT_MAXT));
+    SortArgs A{};
+    A.ci = c->out_i.p; A.cj = c->out_j.p;
+    A.d_in = c->out_d.p; A.s_in = c->out_s.p; A.ct_in = c->out_ct.p;
+    uint8_t* slab = c->sorted_slab.p;
+    A.i_out = (int*)(slab + off[0]); A.j_out = (int*)(slab + off[1]); A.d_out = (float*)(slab + off[2]);
+    A.s_out = (uint16_t*)(slab + off[3]); A.ct_out = slab + off[4];
+    A.n = (long long)k;
+    const long long tiles = ((long long)k + SORT_TILE - 1) / SORT_TILE;
+    A.T = (int)std::min<long long>(tiles, SORT_MAXT);
+    A.range = ((tiles + A.T - 1) / A.T) * SORT_TILE;
+    A.T = (int)(((long long)k + A.range - 1) / A.range);
+    A.jbits = idbits;
+    A.table = c->sort_table.p;
+    int shift = 0;
+    for (int ps = 0; ps < passes; ++ps) {
+        A.first = ps == 0; A.last = ps == passes - 1;
+        A.shift = shift;
+        A.bits = keybits / passes + (ps < keybits % passes ? 1 : 0);
+        shift += A.bits;
+        A.key_in = ps > 0 ? c->sort_key[(ps - 1) & 1].p : nullptr;
+        A.idx_in = ps > 0 ? c->sort_idx[(ps - 1) & 1].p : nullptr;
+        A.key_out = A.last ? nullptr : c->sort_key[ps & 1].p;
+        A.idx_out = A.last ? nullptr : c->sort_idx[ps & 1].p;
+        hipLaunchKernelGGL(k_sort_hist, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
+    }
+    CHK(check_launch(c, "k_sort_scatter"));
+    c->contacts_sorted = true;
+    return ARP_OK;
 }
 // static candidate lists: entry counts travel with the counters of the pass; a list that was too small is re-sized and
 // rebuilt before the pass is repeated
@@ -1589,6 +1669,8 @@ void arp_destroy(arp_ctx* c) {
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->bag_pack.release();
+    c->sort_key[0].release(); c->sort_key[1].release(); c->sort_idx[0].release(); c->sort_idx[1].release();
+    c->sort_table.release(); c->sorted_slab.release();
     if (c->bag_stage) (void)hipHostFree(c->bag_stage);
     c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release(); c->longest_bond.release();
     c->rec_home.release(); c->rec_face[0].release(); c->rec_face[1].release(); c->sh_scan.release(); c->sh_src.release();
@@ -2441,6 +2523,7 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
             if (global_id[i] <= global_id[i - 1]) FAIL(c, ARP_E_ARG, "arp_set_ownership: global_id must be strictly increasing");
         CHK(upload(c, c->gid, global_id, (size_t)c->n));
         c->has_gid = true;
+        c->gid_max = c->n > 0 ? (int64_t)global_id[c->n - 1] : -1;
     } else c->has_gid = false;
     c->atom_grid.valid = false;   // M_HOME is part of the sorted records
     c->all_grid_current = false;
@@ -2624,14 +2707,68 @@ int arp_atom_contacts_fetch(arp_ctx* c, int64_t cap, int32_t* out_i, int32_t* ou
     *count = c->n_contacts;
     if (c->n_contacts > cap) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_fetch: output buffer too small");
     const size_t k = (size_t)c->n_contacts;
-    // five copies in flight, one synchronisation (into buffers from arp_host_alloc they run at PCIe speed)
+    // five copies in flight, one synchronisation (into buffers from arp_host_alloc they run at PCIe speed); the records come
+    // in the canonical (i, j) order once arp_atom_contacts_sort has run on them, in the order of the pair list before
+    const uint8_t* sl = c->sorted_slab.p;
+    const bool srt = c->contacts_sorted;
     if (k) {
-        if (out_i) HIPCHK(c, hipMemcpyAsync(out_i, c->out_i.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (out_j) HIPCHK(c, hipMemcpyAsync(out_j, c->out_j.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, c->out_d.p, k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        if (out_sift) HIPCHK(c, hipMemcpyAsync(out_sift, c->out_s.p, k * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
-        if (out_ctype) HIPCHK(c, hipMemcpyAsync(out_ctype, c->out_ct.p, k * sizeof(uint8_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_i) HIPCHK(c, hipMemcpyAsync(out_i, srt ? (const void*)(sl + c->srt_off[0]) : (const void*)c->out_i.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_j) HIPCHK(c, hipMemcpyAsync(out_j, srt ? (const void*)(sl + c->srt_off[1]) : (const void*)c->out_j.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, srt ? (const void*)(sl + c->srt_off[2]) : (const void*)c->out_d.p, k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (out_sift) HIPCHK(c, hipMemcpyAsync(out_sift, srt ? (const void*)(sl + c->srt_off[3]) : (const void*)c->out_s.p, k * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_ctype) HIPCHK(c, hipMemcpyAsync(out_ctype, srt ? (const void*)(sl + c->srt_off[4]) : (const void*)c->out_ct.p, k * sizeof(uint8_t), hipMemcpyDeviceToHost, c->stream));
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ARP_OK;
+}
+
+int arp_atom_contacts_sort(arp_ctx* c) {
+    if (!c) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return sort_contacts(c);
+}
+
+// Every result of the last pass with ONE copy: the atom-atom bag in canonical order (sorted on the device if it is not yet)
+// and the used prefixes of the four ring / amide bags behind it, gathered in HBM (k_pack_segments) and copied in one piece.
+int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts[5], uint64_t offsets[ARP_PACKED_OFFSETS], uint64_t* bytes_used) {
+    if (!c || !counts || !offsets || !bytes_used) return ARP_E_ARG;
+    if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_fetch_packed: no launch results");
+    HIPCHK(c, hipSetDevice(c->device));
+    Bag* bags[4] = {&c->bag_pp, &c->bag_ap, &c->bag_gg, &c->bag_gp};      // (the order of get_contacts, I:183-210)
+    static const size_t es[12] = {4, 4, 8, 8, 8, 8, 4, 4, 4, 1, 1, 1};
+    size_t off[5], cbytes;
+    sorted_layout((size_t)c->n_contacts, off, &cbytes);
+    size_t total = cbytes;
+    PackTable t;
+    t.n = 0;
+    for (int q = 0; q < ARP_PACKED_OFFSETS; ++q) offsets[q] = 0;
+    for (int q = 0; q < 5; ++q) offsets[q] = off[q];
+    counts[0] = c->n_contacts;
+    for (int b = 0; b < 4; ++b) {
+        Bag& g = *bags[b];
+        counts[1 + b] = g.valid ? g.count : 0;
+        if (!g.valid || g.count == 0) continue;
+        const uint8_t* ptr[12] = {(const uint8_t*)g.a.p, (const uint8_t*)g.b.p, (const uint8_t*)g.d0.p, (const uint8_t*)g.d1.p,
+                                  (const uint8_t*)g.d2.p, (const uint8_t*)g.d3.p, (const uint8_t*)g.f0.p, (const uint8_t*)g.f1.p,
+                                  (const uint8_t*)g.f2.p, g.u0.p, g.u1.p, g.u2.p};
+        for (int q = 0; q < 12; ++q) {
+            if (!ptr[q]) continue;
+            const size_t bytes = (size_t)g.count * es[q];
+            if (t.n >= 48 || bytes >= ((size_t)1 << 32) || total >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: ring / amide bags too large for one piece (fetch them one by one)");
+            offsets[5 + 12 * b + q] = total;
+            t.s[t.n++] = PackSeg{ptr[q], (uint32_t)total, (uint32_t)bytes};
+            total = (total + bytes + 15) & ~(size_t)15;
+        }
+    }
+    *bytes_used = total;
+    if (!host || host_bytes < total) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: host buffer too small (bytes_used holds the size needed)");
+    c->contacts_sorted = c->contacts_sorted && c->sorted_slab.cap >= total;
+    CHK(sort_contacts(c, total - cbytes));
+    if (t.n > 0) {
+        hipLaunchKernelGGL(k_pack_segments, dim3(t.n), dim3(256), 0, c->stream, t, c->sorted_slab.p);
+        CHK(check_launch(c, "k_pack_segments"));
+    }
+    if (total) HIPCHK(c, hipMemcpyAsync(host, c->sorted_slab.p, total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }

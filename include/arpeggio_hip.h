@@ -258,11 +258,33 @@ int arp_run_wait(arp_ctx* ctx, int64_t counts[5]);
  * buffer was too small it is regrown and the pass re-run internally. */
 int arp_atom_contacts_launch(arp_ctx* ctx, double cutoff, double vdw_comp,
                              int include_sequence_adjacent, int64_t* count);
-/* Copy the results of the last launch to the host (any order; callers sort by
- * (i,j) for the canonical order). */
+/* Copy the results of the last launch to the host: in the canonical order — ascending
+ * (i, j), the order the boundary defines for the reference's KD-tree delivery order
+ * (I:707, exported in that order at I:183-190) — once arp_atom_contacts_sort has run on
+ * them, otherwise in the order of the device's pair list (any order). */
 int arp_atom_contacts_fetch(arp_ctx* ctx, int64_t cap, int32_t* out_i, int32_t* out_j,
                             float* out_dist, uint16_t* out_sift, uint8_t* out_ctype,
                             int64_t* count);
+/* Put the atom-atom records of the last launch into the canonical (i, j) order in HBM
+ * (least-significant-digit radix sort on i << b | j, csrc/arp_sort.h: two launches per 9-bit
+ * digit, the last pass writes the five columns).  Enqueued on the context stream, no host
+ * synchronisation; a second call on the same results is a no-op.  Per-atom accumulators
+ * and integer sifts do not depend on it. */
+int arp_atom_contacts_sort(arp_ctx* ctx);
+/* Every result bag of the last pass with ONE device-to-host copy: the atom-atom bag in
+ * canonical order (sorted on the device first if it is not yet) and the used prefixes of the
+ * four ring / amide bags behind it.  host = caller's buffer (arp_host_alloc for PCIe speed)
+ * of host_bytes; counts = records per bag in get_contacts order (I:183-210: atom-atom,
+ * plane-plane, atom-plane, group-group, group-plane); offsets[0..4] = byte offsets of i
+ * (int32), j (int32), distance (float32), SIFt (uint16), contact type (uint8) of the
+ * atom-atom bag; offsets[5 + 12 * b + q] = array q of ring / amide bag b (b = 0..3 in the
+ * order of counts[1..4]; q = 0, 1: the two int32 id columns, 2..5: float64 columns, 6..8:
+ * float32 columns, 9..11: uint8 columns — the columns of the bag's *_fetch call in its
+ * argument order within each type; 0 = the bag has no such array).  bytes_used = bytes
+ * written; ARP_E_CAPACITY with bytes_used set when host_bytes is too small. */
+#define ARP_PACKED_OFFSETS 53
+int arp_fetch_packed(arp_ctx* ctx, void* host, uint64_t host_bytes, int64_t counts[5],
+                     uint64_t offsets[ARP_PACKED_OFFSETS], uint64_t* bytes_used);
 /* launch + fetch. */
 int arp_atom_contacts(arp_ctx* ctx, double cutoff, double vdw_comp,
                       int include_sequence_adjacent, int64_t cap, int32_t* out_i,

@@ -1,0 +1,111 @@
+"""The canonical (i, j) order of the atom-atom bag made on the device (csrc/arp_sort.h) and the one-copy fetch of all
+five bags (arp_fetch_packed), through the C ABI.  Needs a real MI355X: `pytest -m gpu`.
+
+The order is the boundary's definition of the reference's record order (interactions.py:707 delivers the pairs in KD-tree
+order, interactions.py:183-190 exports them in that order; DESIGN.md 1 defines ascending (bgn, end) packed index instead):
+the checks are bit-exact — the sorted columns must be the unsorted ones permuted by np.lexsort."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from arpeggio_amd import _capi
+    return _capi
+
+
+@pytest.fixture(scope='module')
+def ctx(capi):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _same_bag(a, b):
+    assert len(a['i']) == len(b['i'])
+    for k in ('i', 'j', 'sift', 'ctype'):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a['dist'].view(np.uint32), b['dist'].view(np.uint32))
+
+
+def _host_sorted(raw):
+    o = np.lexsort((raw['j'], raw['i']))
+    return {k: v[o] for k, v in raw.items()}
+
+
+# 1 contact .. several tiles of 16 384 per block (more than 256 tiles: 4.3 M records at 350 k atoms)
+@pytest.mark.parametrize('n,seed', [(2, 1), (40, 2), (700, 3), (1300, 4), (2600, 5), (20000, 6), (100000, 3), (350000, 7)])
+def test_device_order_is_the_lexsort_of_the_unsorted_bag(ctx, n, seed):
+    from arpeggio_amd import synth
+    pc = synth.config3(n, seed=seed)
+    ctx.set_complex(pc)
+    cnt = ctx.atom_contacts_launch(5.0, 0.1, False)
+    raw = {k: v.copy() for k, v in ctx.atom_contacts_fetch(cnt, sort=False).items()}
+    acc0 = ctx.atom_accumulators()
+    got = ctx.atom_contacts_fetch(cnt, sort=True)
+    assert len(got['i']) == cnt
+    _same_bag(got, _host_sorted(raw))
+    if cnt:
+        key = got['i'].astype(np.int64) << 32 | got['j'].astype(np.int64)
+        assert np.all(np.diff(key) > 0), 'strictly ascending (every pair once)'
+    # the sort is idempotent, fetches after it keep the order, and the per-atom accumulators do not depend on it
+    ctx.sort_contacts()
+    _same_bag(ctx.atom_contacts_fetch(cnt, sort=False), got)
+    acc1 = ctx.atom_accumulators()
+    assert np.array_equal(acc0['sift'], acc1['sift']) and np.array_equal(acc0['counts'], acc1['counts'])
+    # a new launch brings back the device's own order until sorted again
+    cnt2 = ctx.atom_contacts_launch(5.0, 0.1, False)
+    assert cnt2 == cnt
+    _same_bag(_host_sorted(ctx.atom_contacts_fetch(cnt2, sort=False)), got)
+
+
+def test_no_contacts(ctx):
+    from helpers import tiny_complex
+    ctx.set_complex(tiny_complex([[0, 0, 0], [50, 0, 0]]))
+    cnt = ctx.atom_contacts_launch(5.0, 0.1, False)
+    assert cnt == 0
+    got = ctx.atom_contacts_fetch(cnt, sort=True)
+    assert all(len(v) == 0 for v in got.values())
+    bags, _ = ctx.fetch_packed()
+    assert len(bags['atom_atom']['i']) == 0
+
+
+def test_global_ids_of_a_shard_sort_as_31_bit_keys(ctx):
+    """Contacts of a shard carry global atom ids (arp_set_ownership): the key is built from them."""
+    from arpeggio_amd import synth
+    pc = synth.config3(5000, seed=11)
+    ctx.set_complex(pc)
+    rng = np.random.default_rng(5)
+    gid = np.sort(rng.choice(2**31 - 2, pc.n_atoms, replace=False)).astype(np.int32)
+    ctx.set_ownership(np.ones(pc.n_atoms, np.uint8), gid)
+    cnt = ctx.atom_contacts_launch(5.0, 0.1, False)
+    raw = {k: v.copy() for k, v in ctx.atom_contacts_fetch(cnt, sort=False).items()}
+    got = ctx.atom_contacts_fetch(cnt, sort=True)
+    assert cnt > 0 and got['i'].max() > 2**24
+    _same_bag(got, _host_sorted(raw))
+    ctx.set_complex(pc)      # (drops the ownership)
+
+
+def test_packed_fetch_equals_the_five_fetches(ctx, capi):
+    from arpeggio_amd import synth
+    for pc in (synth.proteinlike(), synth.config5(600, 500)):
+        ctx.set_complex(pc)
+        counts = ctx.run_launch(5.0, 0.1, False, 6.0)
+        one_by_one = {'atom_atom': {k: v.copy() for k, v in ctx.atom_contacts_fetch(counts['atom_atom'], sort=True).items()}}
+        for name in ('plane_plane', 'atom_plane', 'group_group', 'group_plane'):
+            one_by_one[name] = {k: v.copy() for k, v in ctx.fetch_bag(name).items()}
+        buf = capi.pinned_empty(64, np.uint8)          # too small on purpose: grown by the call
+        bags, buf = ctx.fetch_packed(buf)
+        assert set(bags) == set(one_by_one)
+        for name, exp in one_by_one.items():
+            assert len(exp[next(iter(exp))]) == counts[name]
+            for k, v in exp.items():
+                g = bags[name][k]
+                assert g.dtype == v.dtype and g.shape == v.shape, (name, k)
+                assert np.array_equal(g.view(np.uint8), v.view(np.uint8)), (name, k)     # bit-identical, NaN angles included
+        # a second call into the same buffer (already sorted on the device) gives the same bytes
+        again, buf2 = ctx.fetch_packed(buf)
+        assert buf2 is buf
+        _same_bag(again['atom_atom'], one_by_one['atom_atom'])
