@@ -537,6 +537,12 @@ class Context:
         self._check(self._L.arp_comm_init(self._h, int(rank), int(world), _p(uid)), 'arp_comm_init')
         self.comm_rank, self.comm_world = int(rank), int(world)
 
+    def comm_info(self):
+        """(rank, world) of the context's RCCL communicator as the library sees it (arp_comm_info)."""
+        r, w = C.c_int(-1), C.c_int(0)
+        self._check(self._L.arp_comm_info(self._h, C.byref(r), C.byref(w)), 'arp_comm_info')
+        return int(r.value), int(w.value)
+
     def comm_destroy(self):
         self._check(self._L.arp_comm_destroy(self._h), 'arp_comm_destroy')
 

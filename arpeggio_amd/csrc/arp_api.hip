@@ -108,12 +108,18 @@ struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
 struct PackSeg { const uint8_t* src; uint32_t dst, bytes; };
 struct PackTable { PackSeg s[48]; int n; };
 __global__ __launch_bounds__(256) void k_pack_segments(PackTable t, uint8_t* __restrict__ out) {
-    const PackSeg g = t.s[blockIdx.x];
+    const PackSeg g = t.s[blockIdx.y];        // segment blockIdx.y, spread over the gridDim.x blocks of its row
     const uint32_t words = g.bytes >> 2;
     const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(g.src);      // (arrays of a slab start on 256-byte boundaries,
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(out + g.dst);            //  destinations on 16-byte ones)
-    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
-    if (threadIdx.x < (g.bytes & 3u)) out[g.dst + (words << 2) + threadIdx.x] = g.src[(words << 2) + threadIdx.x];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < (g.bytes & 3u)) out[g.dst + (words << 2) + threadIdx.x] = g.src[(words << 2) + threadIdx.x];
+}
+// blocks per segment: one per 16 KiB of the largest segment, at most 64
+inline dim3 pack_grid(const PackTable& t) {
+    uint32_t mx = 0;
+    for (int k = 0; k < t.n; ++k) mx = std::max(mx, t.s[k].bytes);
+    return dim3(std::min<uint32_t>(std::max<uint32_t>((mx + 16383u) >> 14, 1u), 64u), (unsigned)t.n);
 }
 
 enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_UNUSED = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
@@ -220,6 +226,7 @@ struct arp_ctx {
     DevBuf<unsigned long long> sort_key[2];
     DevBuf<uint32_t> sort_idx[2];
     DevBuf<int> sort_table;
+    DevBuf<long long> sort_total;
     DevBuf<uint8_t> sorted_slab;        // the five sorted columns (+ the packed ring / amide bags of a packed fetch) in one piece
     size_t srt_off[5] = {0, 0, 0, 0, 0};  // byte offsets of i, j, distance, SIFt, contact type in sorted_slab
     size_t srt_bytes = 0;               // bytes of the five columns
@@ -1482,7 +1489,11 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
         HIPCHK(c, c->sort_key[0].reserve(cap)); HIPCHK(c, c->sort_idx[0].reserve(cap));
         if (passes > 2) { HIPCHK(c, c->sort_key[1].reserve(cap)); HIPCHK(c, c->sort_idx[1].reserve(cap)); }
     }
-    HIPCHK(c, c->sort_table.reserve((size_t)SORT_BINS * SORT_MAXT));
+    const long long tiles = ((long long)k + SORT_TILE - 1) / SORT_TILE;
+    if (tiles > ((long long)1 << 30) / SORT_BINS) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_sort: too many records for the digit table");
+    const int tstride = (int)((tiles + 3) & ~3ll);
+    HIPCHK(c, c->sort_table.reserve((size_t)SORT_BINS * (size_t)tstride));
+    HIPCHK(c, c->sort_total.reserve(SORT_BINS));
     SortArgs A{};
     A.ci = c->out_i.p; A.cj = c->out_j.p;
     A.d_in = c->out_d.p; A.s_in = c->out_s.p; A.ct_in = c->out_ct.p;
@@ -1490,12 +1501,11 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     A.i_out = (int*)(slab + off[0]); A.j_out = (int*)(slab + off[1]); A.d_out = (float*)(slab + off[2]);
     A.s_out = (uint16_t*)(slab + off[3]); A.ct_out = slab + off[4];
     A.n = (long long)k;
-    const long long tiles = ((long long)k + SORT_TILE - 1) / SORT_TILE;
-    A.T = (int)std::min<long long>(tiles, SORT_MAXT);
-    A.range = ((tiles + A.T - 1) / A.T) * SORT_TILE;
-    A.T = (int)(((long long)k + A.range - 1) / A.range);
+    A.T = (int)tiles;
+    A.tstride = tstride;
     A.jbits = idbits;
     A.table = c->sort_table.p;
+    A.total = c->sort_total.p;
     int shift = 0;
     for (int ps = 0; ps < passes; ++ps) {
         A.first = ps == 0; A.last = ps == passes - 1;
@@ -1507,6 +1517,7 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
         A.key_out = A.last ? nullptr : c->sort_key[ps & 1].p;
         A.idx_out = A.last ? nullptr : c->sort_idx[ps & 1].p;
         hipLaunchKernelGGL(k_sort_hist, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1 << A.bits), dim3(SORT_THREADS), 0, c->stream, A);
         hipLaunchKernelGGL(k_sort_scatter, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
     }
     CHK(check_launch(c, "k_sort_scatter"));
@@ -1670,7 +1681,7 @@ void arp_destroy(arp_ctx* c) {
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->bag_pack.release();
     c->sort_key[0].release(); c->sort_key[1].release(); c->sort_idx[0].release(); c->sort_idx[1].release();
-    c->sort_table.release(); c->sorted_slab.release();
+    c->sort_table.release(); c->sort_total.release(); c->sorted_slab.release();
     if (c->bag_stage) (void)hipHostFree(c->bag_stage);
     c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release(); c->longest_bond.release();
     c->rec_home.release(); c->rec_face[0].release(); c->rec_face[1].release(); c->sh_scan.release(); c->sh_src.release();
@@ -2765,7 +2776,7 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     c->contacts_sorted = c->contacts_sorted && c->sorted_slab.cap >= total;
     CHK(sort_contacts(c, total - cbytes));
     if (t.n > 0) {
-        hipLaunchKernelGGL(k_pack_segments, dim3(t.n), dim3(256), 0, c->stream, t, c->sorted_slab.p);
+        hipLaunchKernelGGL(k_pack_segments, pack_grid(t), dim3(256), 0, c->stream, t, c->sorted_slab.p);
         CHK(check_launch(c, "k_pack_segments"));
     }
     if (total) HIPCHK(c, hipMemcpyAsync(host, c->sorted_slab.p, total, hipMemcpyDeviceToHost, c->stream));
@@ -2911,7 +2922,7 @@ int stage_bags(arp_ctx* c) {
             c->bag_stage_cap = want;
         }
         HIPCHK(c, c->bag_pack.reserve(total));
-        hipLaunchKernelGGL(k_pack_segments, dim3(t.n), dim3(256), 0, c->stream, t, c->bag_pack.p);
+        hipLaunchKernelGGL(k_pack_segments, pack_grid(t), dim3(256), 0, c->stream, t, c->bag_pack.p);
         CHK(check_launch(c, "k_pack_segments"));
         HIPCHK(c, hipMemcpyAsync(c->bag_stage, c->bag_pack.p, total, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3472,7 +3483,11 @@ int arp_comm_info(arp_ctx* c, int* rank, int* world) {
     if (!c) return ARP_E_ARG;
     if (rank) *rank = c->comm_rank;
     if (world) *world = c->comm_world;
-    return c->comm ? ARP_OK : ARP_E_ARG;
+    if (!c->comm) return ARP_E_ARG;
+    // what RCCL itself says about the communicator (the ranks it connected), where the library exports the queries
+    if (world && rccl().CommCount) NCCLCHK(c, rccl().CommCount(c->comm, world));
+    if (rank && rccl().CommUserRank) NCCLCHK(c, rccl().CommUserRank(c->comm, rank));
+    return ARP_OK;
 }
 
 int arp_shard_exchange_faces(arp_ctx* c, uint64_t left_ptr, uint64_t left_bytes, uint64_t right_ptr, uint64_t right_bytes, uint64_t received[4]) {

@@ -24,6 +24,8 @@ struct RcclApi {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // optional: what the communicator itself reports (arp_comm_info)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     std::string error;
     bool load() {
         if (lib) return true;
@@ -42,6 +44,8 @@ struct RcclApi {
         Recv = (decltype(Recv))sym("ncclRecv");
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        CommCount = (decltype(CommCount))dlsym(lib, "ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))dlsym(lib, "ncclCommUserRank");
         if (!(GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && GetErrorString)) {
             dlclose(lib);
             lib = nullptr;

@@ -8,23 +8,22 @@
 // payload, whose LAST pass writes the five result columns themselves — i and j from the key, distance / SIFt / contact type
 // gathered through the index — into one slab, so that the host gets all five columns with ONE copy.
 //
-// Two launches per digit pass, no atomics on global memory, no data-dependent launch sizes:
-//   k_sort_hist     block t counts the digits of its contiguous range of the input   -> table[digit][t]
-//   k_sort_scatter  block t sums row `digit` of the table itself (T <= 256 entries per row, all rows in flight together: the
-//                   "every block scans the small histogram out of L2" trick of k_scan_scatter_atoms), ranks its items
-//                   stably — wave-level match by ballots, one LDS counter per (wave, digit) — and writes them
-// A block's range is a whole number of tiles of 16 384 items which it walks in order, so T stays <= 256 whatever the
-// count (25.6 M records of the 2 M-atom config: 7 tiles per block).
+// Three launches per digit pass (up to 9 bits), no atomics on global memory, every launch fills the chip:
+//   k_sort_hist     block t counts the digits of tile t (4096 records)                              -> table[digit][t]
+//   k_sort_scan     block d turns row d of the table into exclusive prefixes over the tiles, total[d] = its sum
+//   k_sort_scatter  block t: base of digit d = (exclusive scan of total[])[d] + table[d][t]; ranks its records stably —
+//                   wave-level match by ballots, one LDS counter per (wave, digit), the sixteen rounds' counter updates
+//                   issued back to back as returning LDS adds —, puts them into tile order in LDS and writes them out
+//                   with consecutive lanes on consecutive addresses of a digit's run
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define SORT_THREADS 1024
+#define SORT_THREADS 256
 #define SORT_ITEMS 16
 #define SORT_TILE (SORT_THREADS * SORT_ITEMS)
 #define SORT_MAX_BITS 9
 #define SORT_BINS (1 << SORT_MAX_BITS)
-#define SORT_MAXT 256
 #define SORT_WAVES (SORT_THREADS / 64)
 
 struct SortArgs {
@@ -45,12 +44,13 @@ struct SortArgs {
     uint16_t* s_out;
     uint8_t* ct_out;
     long long n;       // records
-    long long range;   // records per block (a multiple of SORT_TILE)
-    int T;             // blocks
+    int T;             // tiles = blocks of k_sort_hist / k_sort_scatter
+    int tstride;       // entries per row of the table (>= T, a multiple of 4)
     int first, last;   // first / last pass
     int shift, bits;   // the digit of this pass: (key >> shift) & ((1 << bits) - 1)
     int jbits;         // key = i << jbits | j
-    int* table;        // [SORT_BINS][SORT_MAXT]: items of block t with digit d
+    int* table;        // [SORT_BINS][tstride]: records of tile t with digit d, then their exclusive prefix over the tiles
+    long long* total;  // [SORT_BINS]: records with digit d
 };
 
 __device__ __forceinline__ unsigned long long sort_key_at(const SortArgs& A, long long p) {
@@ -62,119 +62,145 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(SortArgs A) {
     __shared__ int s_hist[SORT_BINS];
     for (int d = threadIdx.x; d < SORT_BINS; d += SORT_THREADS) s_hist[d] = 0;
     __syncthreads();
-    const long long lo = (long long)blockIdx.x * A.range, hi = min(lo + A.range, A.n);
+    const long long lo = (long long)blockIdx.x * SORT_TILE, hi = min(lo + SORT_TILE, A.n);
     const uint32_t mask = (1u << A.bits) - 1u;
-    for (long long p = lo + threadIdx.x; p < hi; p += SORT_THREADS)
-        atomicAdd(&s_hist[(uint32_t)(sort_key_at(A, p) >> A.shift) & mask], 1);
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const long long p = lo + r * SORT_THREADS + threadIdx.x;
+        if (p < hi) atomicAdd(&s_hist[(uint32_t)(sort_key_at(A, p) >> A.shift) & mask], 1);
+    }
     __syncthreads();
-    for (int d = threadIdx.x; d < SORT_BINS; d += SORT_THREADS) A.table[d * SORT_MAXT + blockIdx.x] = s_hist[d];
+    for (int d = threadIdx.x; d < (1 << A.bits); d += SORT_THREADS) A.table[(size_t)d * A.tstride + blockIdx.x] = s_hist[d];
+}
+
+// exclusive scan of one value per thread over the block (SORT_THREADS threads); *sum = the block's total
+__device__ __forceinline__ long long sort_block_scan(long long v, long long* s_w, long long* sum) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long u = __shfl_up(incl, off);
+        if (lane >= off) incl += u;
+    }
+    __syncthreads();                 // (s_w may still be read by the scan before)
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    long long woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SORT_WAVES; ++k) { const long long x = s_w[k]; if (k < w) woff += x; tot += x; }
+    if (sum) *sum = tot;
+    return woff + incl - v;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(SortArgs A) {
+    __shared__ long long s_w[SORT_WAVES];
+    int* row = A.table + (size_t)blockIdx.x * A.tstride;
+    long long run = 0;
+    for (int t0 = 0; t0 < A.T; t0 += SORT_THREADS) {      // (block-uniform trip count)
+        const int t = t0 + threadIdx.x;
+        const int v = t < A.T ? row[t] : 0;
+        long long sum;
+        const long long e = sort_block_scan((long long)v, s_w, &sum);
+        if (t < A.T) row[t] = (int)(run + e);              // (a tile's prefix inside one digit is below 2^31: the index payload is 32 bits)
+        run += sum;
+    }
+    if (threadIdx.x == 0) A.total[blockIdx.x] = run;
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortArgs A) {
-    __shared__ int s_whist[SORT_WAVES][SORT_BINS];   // per wave and digit: items seen so far in this tile, then the wave's offset
-    __shared__ long long s_base[SORT_BINS];          // where the block's next item of a digit goes
-    __shared__ int s_tot[SORT_BINS];
-    __shared__ long long s_wsum[SORT_WAVES];
+    __shared__ unsigned long long s_key[SORT_TILE];
+    __shared__ uint32_t s_idx[SORT_TILE];
+    __shared__ int s_whist[SORT_WAVES][SORT_BINS];   // per wave and digit: records seen so far, then the wave's offset in the digit's run
+    __shared__ int s_texcl[SORT_BINS];               // first slot of digit d in the tile's sorted order
+    __shared__ long long s_gbase[SORT_BINS];         // global position of that slot
+    __shared__ long long s_w[SORT_WAVES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t = blockIdx.x;
-    const uint32_t mask = (1u << A.bits) - 1u;
-    // ---- global base of every digit for this block: items of smaller digits in ALL blocks + items of this digit in the blocks before
-    {
-        long long before = 0, total = 0;
-        if (threadIdx.x < SORT_BINS) {
-            const int4* row = reinterpret_cast<const int4*>(A.table + threadIdx.x * SORT_MAXT);
-            for (int q = 0; q * 4 < A.T; ++q) {
-                const int4 v = row[q];
-                const int vv[4] = {v.x, v.y, v.z, v.w};
+    const int nb = 1 << A.bits;
+    const uint32_t mask = (uint32_t)nb - 1u;
+    // ---- global base of my two digits: records of smaller digits in all tiles + records of the digit in the tiles before
+    const int d0 = 2 * threadIdx.x, d1 = d0 + 1;
+    const long long tot0 = d0 < nb ? A.total[d0] : 0, tot1 = d1 < nb ? A.total[d1] : 0;
+    const int pre0 = d0 < nb ? A.table[(size_t)d0 * A.tstride + t] : 0, pre1 = d1 < nb ? A.table[(size_t)d1 * A.tstride + t] : 0;
+    // ---- the tile's records
+    const long long lo = (long long)t * SORT_TILE, hi = min(lo + SORT_TILE, A.n);
+    const long long wbase = lo + (long long)w * (64 * SORT_ITEMS);
+    unsigned long long key[SORT_ITEMS];
+    uint32_t idx[SORT_ITEMS];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int tt = q * 4 + k;
-                    if (tt < A.T) { total += vv[k]; if (tt < t) before += vv[k]; }
-                }
-            }
-        }
-        // exclusive scan of `total` over the SORT_BINS digits (threads 0 .. SORT_BINS - 1 = waves 0 .. 7)
-        long long incl = total;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const long long u = __shfl_up(incl, off);
-            if (lane >= off) incl += u;
-        }
-        if (lane == 63) s_wsum[w] = incl;
-        __syncthreads();
-        long long woff = 0;
-        for (int k = 0; k < w; ++k) woff += s_wsum[k];
-        if (threadIdx.x < SORT_BINS) s_base[threadIdx.x] = woff + incl - total + before;
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const long long p = wbase + r * 64 + lane;
+        const bool valid = p < hi;
+        key[r] = valid ? sort_key_at(A, p) : ~0ull;
+        idx[r] = valid ? (A.first ? (uint32_t)p : A.idx_in[p]) : 0u;
     }
-    const long long lo = (long long)t * A.range, hi = min(lo + A.range, A.n);
+    for (int d = threadIdx.x; d < SORT_WAVES * SORT_BINS; d += SORT_THREADS) (&s_whist[0][0])[d] = 0;
+    {
+        const long long e = sort_block_scan(tot0 + tot1, s_w, nullptr);      // (its barriers also publish the zeroed counters)
+        if (d0 < SORT_BINS) { s_gbase[d0] = e + pre0; s_gbase[d1] = e + tot0 + pre1; }
+    }
+    // ---- stable rank of every record among the records of its digit in this wave's part of the tile
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (long long tile = lo; tile < hi; tile += SORT_TILE) {
-        for (int d = threadIdx.x; d < SORT_WAVES * SORT_BINS; d += SORT_THREADS) (&s_whist[0][0])[d] = 0;
-        __syncthreads();     // (also orders s_base of the tile before / of the prologue)
-        unsigned long long key[SORT_ITEMS];
-        uint32_t idx[SORT_ITEMS];
-        int rank[SORT_ITEMS];
-        const long long wbase = tile + (long long)w * (64 * SORT_ITEMS);
+    int rk[SORT_ITEMS];      // peers below me | leader << 8
+    int old[SORT_ITEMS];
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const long long p = wbase + r * 64 + lane;
-            const bool valid = p < hi;
-            key[r] = valid ? sort_key_at(A, p) : 0ull;
-            idx[r] = valid ? (A.first ? (uint32_t)p : A.idx_in[p]) : 0u;
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const bool valid = wbase + r * 64 + lane < hi;
+        const uint32_t d = (uint32_t)(key[r] >> A.shift) & mask;
+        unsigned long long peers = __ballot(valid);
+        for (int k = 0; k < A.bits; ++k) {
+            const bool bit = (d >> k) & 1u;
+            const unsigned long long b = __ballot(bit);
+            peers &= bit ? b : ~b;
         }
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        rk[r] = __popcll(peers & below) | (leader << 8);
+        old[r] = 0;
+        // one returning LDS add per digit and round, by its first lane; the sixteen rounds' adds leave back to back (LDS
+        // operations of a wave execute in order, so a digit's counter sees the rounds in order) and are waited for once
+        if (valid && lane == leader) old[r] = atomicAdd(&s_whist[w][d], __popcll(peers));
+    }
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const long long p = wbase + r * 64 + lane;
-            const bool valid = p < hi;
-            const uint32_t d = (uint32_t)(key[r] >> A.shift) & mask;
-            // lanes of this round with my digit (stable: lower lanes = earlier items)
-            unsigned long long peers = __ballot(valid);
-            for (int k = 0; k < A.bits; ++k) {
-                const bool bit = (d >> k) & 1u;
-                const unsigned long long b = __ballot(bit);
-                peers &= bit ? b : ~b;
-            }
-            int old = 0;
-            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-            if (valid && lane == leader) {
-                old = s_whist[w][d];
-                s_whist[w][d] = old + __popcll(peers);
-            }
-            old = __shfl(old, leader);
-            rank[r] = old + __popcll(peers & below);
-        }
-        __syncthreads();
-        // per digit: counts of the waves -> exclusive offsets of the waves, total of the tile
-        if (threadIdx.x < SORT_BINS) {
-            int acc = 0;
+    for (int r = 0; r < SORT_ITEMS; ++r) rk[r] = __shfl(old[r], rk[r] >> 8) + (rk[r] & 255);
+    __syncthreads();
+    // ---- per digit: exclusive offsets of the waves, size of the digit's run in the tile, first slot of the run
+    {
+        int c0 = 0, c1 = 0;
 #pragma unroll
-            for (int k = 0; k < SORT_WAVES; ++k) {
-                const int c = s_whist[k][threadIdx.x];
-                s_whist[k][threadIdx.x] = acc;
-                acc += c;
-            }
-            s_tot[threadIdx.x] = acc;
+        for (int k = 0; k < SORT_WAVES; ++k) {
+            const int a = s_whist[k][d0], b = s_whist[k][d1];
+            s_whist[k][d0] = c0; s_whist[k][d1] = c1;
+            c0 += a; c1 += b;
         }
-        __syncthreads();
+        const int e = (int)sort_block_scan((long long)(c0 + c1), s_w, nullptr);
+        s_texcl[d0] = e; s_texcl[d1] = e + c0;
+        s_gbase[d0] -= e; s_gbase[d1] -= e + c0;       // position of slot s of digit d = s_gbase[d] + s
+    }
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const long long p = wbase + r * 64 + lane;
-            if (p >= hi) continue;
-            const uint32_t d = (uint32_t)(key[r] >> A.shift) & mask;
-            const long long pos = s_base[d] + s_whist[w][d] + rank[r];
-            if (!A.last) {
-                A.key_out[pos] = key[r];
-                A.idx_out[pos] = idx[r];
-            } else {
-                const uint32_t q = idx[r];
-                A.i_out[pos] = (int)(key[r] >> A.jbits);
-                A.j_out[pos] = (int)(key[r] & ((1ull << A.jbits) - 1ull));
-                A.d_out[pos] = A.d_in[q];
-                A.s_out[pos] = A.s_in[q];
-                A.ct_out[pos] = A.ct_in[q];
-            }
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        if (wbase + r * 64 + lane >= hi) continue;
+        const uint32_t d = (uint32_t)(key[r] >> A.shift) & mask;
+        const int slot = s_texcl[d] + s_whist[w][d] + rk[r];
+        s_key[slot] = key[r];
+        s_idx[slot] = idx[r];
+    }
+    __syncthreads();
+    const int cnt = (int)(hi - lo);
+#pragma unroll 4
+    for (int s = threadIdx.x; s < cnt; s += SORT_THREADS) {
+        const unsigned long long k = s_key[s];
+        const uint32_t q = s_idx[s];
+        const long long pos = s_gbase[(uint32_t)(k >> A.shift) & mask] + s;
+        if (!A.last) {
+            A.key_out[pos] = k;
+            A.idx_out[pos] = q;
+        } else {
+            A.i_out[pos] = (int)(k >> A.jbits);
+            A.j_out[pos] = (int)(k & ((1ull << A.jbits) - 1ull));
+            A.d_out[pos] = A.d_in[q];
+            A.s_out[pos] = A.s_in[q];
+            A.ct_out[pos] = A.ct_in[q];
         }
-        __syncthreads();
-        if (threadIdx.x < SORT_BINS) s_base[threadIdx.x] += s_tot[threadIdx.x];
     }
 }

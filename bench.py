@@ -4,20 +4,23 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms A]
 
 One "step" = one pass of the whole hot path (InteractionComplex.run_arpeggio,
-interactions.py:329-347: 6 A selection expansion, 5 A neighbour search + fused 15-flag
-SIFt evaluation, ring/amide plane kernels) over the structure resident in HBM; results
+interactions.py:329-347: selection, the neighbour grid of the pass, 5 A neighbour search + fused
+15-flag SIFt evaluation, ring/amide plane kernels) over the structure resident in HBM; results
 stay in HBM.  Unit of work = one candidate atom pair of the 5 A contact search (SURVEY.md
-§8d).  The workload selects the whole structure, so a pass keeps the neighbour grid of the
-pass before it; `pass_with_grid_rebuild` in the line is the same pass with
-the grid built every time, `end_to_end` a new structure every step.  N > 1: the box is
-elongated along x (weak scaling, BASELINE configs[3] family), sharded into N slabs with a
-one-cell halo exchanged over RCCL before the timed region; the ranks meet over plain TCP
+§8d).  EVERY timed step builds its contact grid (arp_set_grid_reuse(0)): `value` and
+`ms_per_step` are that pass; the pass that keeps the grid of the pass before it
+is the extra key `pass_with_grid_kept`, `end_to_end` is a new structure every step with all
+five bags fetched in canonical order, and `wall_clock_per_structure_ms` is that figure.
+N > 1: the box is elongated along x (weak scaling: every GPU owns one config-3 cube of
+--atoms atoms, the same per-GPU workload as N = 1), sharded into N slabs with a one-cell
+halo exchanged over RCCL before the timed region; the ranks meet over plain TCP
 (arpeggio_amd/rendezvous.py) and the timed region is bracketed by arp_device_synchronize +
 barrier — no PyTorch in this process.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
-dominant kernel (HIP-event time on the context's own stream) and `cpu_baseline` (the C
-oracle timed on one host core on a bounded sample of the same workload).
+dominant kernel (HIP-event time on the context's own stream, SURVEY 8d's compulsory bytes of
+that kernel) and `cpu_baseline` (the C oracle timed on one host core on a bounded sample of
+the same workload).  The GPU legs run back to back; the CPU baselines come last.
 """
 import argparse
 import json
@@ -40,9 +43,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--atoms', type=int, default=None,
-                    help='atoms per GPU; default: 100 000 at N = 1 (BASELINE configs[2]), 250 000 at N > 1 (configs[3]: 2 M atoms on 8 GPUs)')
-    ap.add_argument('--min-seconds', type=float, default=1.0,
+    ap.add_argument('--atoms', type=int, default=100_000,
+                    help='atoms per GPU (weak scaling): 100 000 = BASELINE configs[2] on every GPU, at N = 1 and at N > 1 alike; '
+                         '--gpus 8 --atoms 250000 is configs[3] (2 M atoms on 8 GPUs)')
+    ap.add_argument('--min-seconds', type=float, default=2.0,
                     help='the K timed steps are repeated as a block until the timed region is at least this long')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the fresh-structure-per-step measurement')
     ap.add_argument('--cutoff', type=float, default=5.0)
@@ -63,14 +67,29 @@ def parse():
 
 
 def algorithmic_bytes(kernel, n_binned, ncell, n_pairs, n_h=0):
-    """Compulsory HBM bytes of one launch (DESIGN.md 'Kernels and rooflines').  n_h = explicit hydrogens of the structure
-    (24-byte float64 coordinates, read by the hydrogen-geometry tests of k_sift; 0 when the caller does not know the count)."""
+    """HBM bytes one launch moves AS IMPLEMENTED, the 8 B / pair intermediate list included.  n_h = explicit
+    hydrogens of the structure (24-byte float64 coordinates, read by the hydrogen-geometry tests of k_sift)."""
+    if kernel == 'bin':         # k_compact_atoms: 68 B of static columns + the row's cell read, 80 B of records + the cell written, the cell table
+        return 72 * n_binned + 84 * n_binned + 4 * (ncell + 1)
     if kernel == 'search':      # read each sorted record once (xyzm 16 B + aux 16 B), the cell table, write the pair list
         return 32 * n_binned + 4 * (ncell + 1) + 8 * n_pairs
     if kernel == 'mark_search':  # same reads, writes one byte per marked atom
         return 32 * n_binned + 4 * (ncell + 1) + n_binned
     if kernel == 'sift':        # pair list + each atom's 32-byte record and 16-byte bonded-neighbour quad once + its hydrogens + 15-byte output record
         return 8 * n_pairs + 48 * n_binned + 24 * n_h + 15 * n_pairs
+    raise KeyError(kernel)
+
+
+def survey_8d_bytes(kernel, n_binned, ncell, n_pairs):
+    """SURVEY.md 8(d)'s COMPULSORY bytes (B_alg = 140 N + 16 P for the whole pipeline), split over the kernels that move them;
+    the intermediate pair list of the split design (8 B / pair written by k_search, read by k_sift) is NOT compulsory and not
+    counted.  bin + search + sift = 140 N + 16 P (+ the cell table)."""
+    if kernel == 'bin':          # bin pass (16 N read, 4 N written) + sort / scatter (36 N read, 36 N written)
+        return 92 * n_binned
+    if kernel in ('search', 'mark_search'):   # each sorted record once + the cell table
+        return 32 * n_binned + 4 * (ncell + 1)
+    if kernel == 'sift':         # hydrogen / bond side arrays + the output records
+        return 16 * n_binned + 16 * n_pairs
     raise KeyError(kernel)
 
 
@@ -221,8 +240,6 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.atoms is None:
-        args.atoms = 100_000 if max(world, args.gpus) == 1 else 250_000
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
@@ -314,12 +331,17 @@ def main():
         def step():   # debug path (host buffers through the rendezvous)
             return sharding.run_shard(ctx, shard, transport, args.cutoff, args.vdw_comp, False)
 
+    t_gpu_legs_begin = time.perf_counter()
+
     def sync_all():      # device idle, every rank here, device idle (the bracket of the timed region)
         ctx.device_synchronize()
         if rdzv is not None:
             rdzv.barrier()
         ctx.device_synchronize()
 
+    # EVERY step of the headline builds its contact grid (the bin / sort passes are part of the pipeline; no caller
+    # runs the same pass twice on one structure, so nothing a pass made may be reused by the next one).
+    ctx.set_grid_reuse(False)
     # set-up, not steps: the first passes size the result buffers (a pass is re-run when one was too small); reported
     # in the line as `setup_passes`.  Then the W warm-up steps and the timed region: the K steps, repeated as a block
     # until the region is at least --min-seconds long (K x repeats steps are timed; `steps` stays K).
@@ -363,48 +385,32 @@ def main():
     ktimes = ctx.kernel_times(reset=True)
     ctx.set_profiling(False)
 
-    # The same pass with its contact grid BUILT every time (arp_set_grid_reuse(0)).  A whole-structure pass over a resident
-    # structure keeps the grid of the pass before it — the structure's own neighbour grid, which depends on nothing a pass
-    # changes — so the timed steps above launch k_search and k_sift_planes only; with a partial selection, a new cutoff or a new
-    # structure the grid is compacted by k_compact_atoms first.  Both figures belong in the line.
-    def measure_with_grid_rebuild():
-        ctx.set_grid_reuse(False)
-        for _ in range(5):
-            step()
-        sync_all()
-        n_rb, t_rb = 0, time.perf_counter()
-        while n_rb < args.steps or time.perf_counter() - t_rb < 0.25:
-            step()
-            n_rb += 1
-        sync_all()
-        el_rb = time.perf_counter() - t_rb
-        ctx.set_profiling(True)
-        ctx.kernel_times(reset=True)
-        for _ in range(args.steps):
-            step()
-        kt_rb = ctx.kernel_times(reset=True)
-        ctx.set_profiling(False)
-        st_rb = ctx.stats()
-        b_rb = 140 * st_rb['binned'] + 16 * st_rb['emitted']
-        grid_rebuild = {'ms_per_step': round(el_rb / n_rb * 1e3, 4), 'steps': n_rb, 'value': round(st_rb['candidates'] * n_rb / el_rb, 1),
-                        'kernel_ms': {k: round(v['ms'] / max(v['launches'], 1), 5) for k, v in kt_rb.items() if v['launches']},
-                        'roofline_pass': {'bytes_per_pass': int(b_rb), 'achieved_GBps': round(b_rb / (el_rb / n_rb) / 1e9, 2),
-                                          'frac': round(b_rb / (el_rb / n_rb) / 1e9 / HBM_PEAK_GBS, 6)},
-                        'note': 'every pass compacts selection_plus into a new contact grid (k_compact_atoms = kernel_ms.bin), as passes with a '
-                                'partial selection always do; bytes = SURVEY 8d\'s 140 N + 16 P, which includes the grid build'}
-        ctx.set_grid_reuse(True)
-        for _ in range(3):
-            step()
-        return grid_rebuild
-
-    grid_rebuild = None
+    # ---- extra GPU legs (world == 1; informational, never `value`), back to back before any CPU baseline ----
+    # (a) the pass that KEEPS the grid of the pass before it: a whole-structure pass over a resident structure whose grid
+    #     the library caches — two launches instead of three
+    grid_kept = None
     if world == 1:
         try:
-            grid_rebuild = measure_with_grid_rebuild()
-        except Exception as exc:   # never lose the main line over the extra measurement
-            grid_rebuild = {'error': repr(exc)}
-            ctx.set_profiling(False)
             ctx.set_grid_reuse(True)
+            for _ in range(5):
+                step()
+            sync_all()
+            n_gk, t_gk = 0, time.perf_counter()
+            while n_gk < args.steps or time.perf_counter() - t_gk < 0.25:
+                step()
+                n_gk += 1
+            sync_all()
+            el_gk = time.perf_counter() - t_gk
+            st_gk = ctx.stats()
+            b_gk = 48 * st_gk['binned'] + 16 * st_gk['emitted']
+            grid_kept = {'ms_per_step': round(el_gk / n_gk * 1e3, 4), 'steps': n_gk, 'value': round(st_gk['candidates'] * n_gk / el_gk, 1),
+                         'roofline_pass': {'bytes_per_pass': int(b_gk), 'bytes_model': '48 N + 16 P (SURVEY 8d without its bin / sort passes)',
+                                           'achieved_GBps': round(b_gk / (el_gk / n_gk) / 1e9, 2), 'frac': round(b_gk / (el_gk / n_gk) / 1e9 / HBM_PEAK_GBS, 6)},
+                         'note': 'the same pass on the grid the pass before it built (arp_set_grid_reuse(1), the library default for whole-structure '
+                                 'passes over a resident structure): no k_compact_atoms launch.  Not the headline: a cache across identical passes'}
+        except Exception as exc:   # never lose the main line over the extra measurement
+            grid_kept = {'error': repr(exc)}
+        ctx.set_grid_reuse(False)
 
     # Throughput with several structures in flight (world == 1, informational, never `value`): one context per host
     # thread, as INTEGRATION.md prescribes; the passes of different contexts overlap on the GPU (each has its own
@@ -416,6 +422,7 @@ def main():
             ctxs = [ctx] + [_capi.Context(local_rank) for _ in range(args.inflight - 1)]
             for c2 in ctxs[1:]:
                 c2.set_complex(pc)
+                c2.set_grid_reuse(False)
                 c2.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
             per_thread = max(max(args.steps, 600) // args.inflight, 1)      # (a stable figure also when the harness asks for few steps)
             gate = threading.Barrier(args.inflight + 1)
@@ -438,7 +445,7 @@ def main():
             in_flight = {'contexts': args.inflight, 'steps': per_thread * args.inflight,
                          'ms_per_step': round(el2 / (per_thread * args.inflight) * 1e3, 4),
                          'value': round(st['candidates'] * per_thread * args.inflight / el2, 1),
-                         'note': 'one arp_ctx per host thread, same structure resident in each; not the headline value'}
+                         'note': 'one arp_ctx per host thread, same structure resident in each, every pass builds its grid; not the headline value'}
             # the same contexts driven by ONE host thread: enqueue the pass of each (arp_run_enqueue), then wait for each
             rounds = max(per_thread, 1)
             ctx.device_synchronize()
@@ -457,11 +464,6 @@ def main():
         except Exception as exc:   # never lose the main line over the extra measurement
             in_flight = {'error': repr(exc)}
 
-    # ---- wall clock per structure, end to end (world == 1; never `value`): a FRESH structure every step — one packed
-    # upload from page-locked memory (arp_set_blob: copy + device-side validation), the static record columns and the
-    # ring / amide grids rebuilt, the pass, and every result bag copied into page-locked host buffers.  The structures
-    # cycle through four different seeds of the same workload.  Measured with one context (latency of one structure)
-    # and with three contexts on three host threads (upload / pass / download of consecutive structures overlap).
     # BASELINE configs[0]'s use of the reference (`-s /A/508/`: a ligand and its binding site) on the stand-in: the selection is
     # expanded (k_expand_small), selection_plus compacted into the pass's grid (k_compact_atoms), then search + per-pair kernel
     ligand_pass = None
@@ -483,7 +485,13 @@ def main():
         except Exception as exc:   # never lose the main line over the extra measurement
             ligand_pass = {'error': repr(exc)}
 
-    end_to_end = None
+    # ---- wall clock per structure, end to end (world == 1; never `value`): a FRESH structure every step — one packed
+    # upload from page-locked memory (arp_set_blob: copy + device-side validation), the static record columns and the
+    # ring / amide grids rebuilt, the pass, the atom-atom bag put into the canonical (i, j) order ON THE DEVICE and all
+    # five bags copied into one page-locked host buffer with one copy (arp_fetch_packed).  The structures cycle through
+    # four different seeds of the same workload.  Measured with one context (latency of one structure) and with three
+    # contexts on three host threads (upload / pass / download of consecutive structures overlap).
+    end_to_end, e2e_host = None, None
     if world == 1 and not args.no_end_to_end:
         try:
             import threading
@@ -495,61 +503,42 @@ def main():
             blobs = [_capi.pack_blob(f) for f in fresh]
             pack_ms = (time.perf_counter() - t_pack) / len(blobs) * 1e3
 
-            def make_buffers(cx):
+            def make_buffer(cx):
                 cx.set_blob(blobs[0])
                 cnt = cx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
-                cap = int(cnt['atom_atom'] * 1.2) + 1024
-                return cx.pinned_contact_buffers(cap), {k: cx.pinned_bag_buffers(k, 4 * max(cnt[k], 256)) for k in ('plane_plane', 'atom_plane', 'group_group', 'group_plane')}
+                return _capi.pinned_empty(int(cnt['atom_atom'] * 1.25) * 16 + (4 << 20), np.uint8)
 
-            def one_structure(cx, blob, bufs):
+            def one_structure(cx, blob, buf):
                 cx.set_blob(blob)
                 cnt = cx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
-                res = cx.atom_contacts_fetch(cnt['atom_atom'], sort=False, out=bufs[0])
-                bags = {k: cx.fetch_bag(k, sort=False, out=bufs[1][k]) for k in bufs[1]}
-                return cnt, res, bags
+                bags, _ = cx.fetch_packed(buf)          # device sort of the atom-atom bag + one D2H copy of everything
+                return cnt, bags
 
-            bufs = make_buffers(ctx)
+            buf = make_buffer(ctx)
             for k in range(8):
-                one_structure(ctx, blobs[k % 4], bufs)
+                one_structure(ctx, blobs[k % 4], buf)
             n_e2e, t1 = 0, time.perf_counter()
             while n_e2e < 40 or time.perf_counter() - t1 < 0.5:
-                cnt_e, res_e, bags_e = one_structure(ctx, blobs[n_e2e % 4], bufs)
+                cnt_e, bags_e = one_structure(ctx, blobs[n_e2e % 4], buf)
                 n_e2e += 1
             e2e_ms = (time.perf_counter() - t1) / n_e2e * 1e3
             # breakdown of one structure (separately timed calls; their sum is a little above the loop figure)
             br = {}
             tt = time.perf_counter(); ctx.set_blob(blobs[1]); br['upload_validate_ms'] = (time.perf_counter() - tt) * 1e3
             tt = time.perf_counter(); cnt_e = ctx.run_launch(args.cutoff, args.vdw_comp, False, 6.0); br['first_pass_ms'] = (time.perf_counter() - tt) * 1e3
-            tt = time.perf_counter(); res_e = ctx.atom_contacts_fetch(cnt_e['atom_atom'], sort=False, out=bufs[0]); br['download_contacts_ms'] = (time.perf_counter() - tt) * 1e3
-            tt = time.perf_counter(); bags_e = {k: ctx.fetch_bag(k, sort=False, out=bufs[1][k]) for k in bufs[1]}; br['download_bags_ms'] = (time.perf_counter() - tt) * 1e3
+            tt = time.perf_counter(); ctx.sort_contacts(); ctx.device_synchronize(); br['device_sort_ms'] = (time.perf_counter() - tt) * 1e3
+            tt = time.perf_counter(); bags_e, _ = ctx.fetch_packed(buf); br['download_all_bags_one_copy_ms'] = (time.perf_counter() - tt) * 1e3
             nbytes_up = int(blobs[1].nbytes)
-            nbytes_down = int(sum(v.nbytes for v in res_e.values()) + sum(v.nbytes for b in bags_e.values() for v in b.values()))
-            # the exporter of the drop-in class on this result (JSON records as the reference's get_contacts builds them)
-            from arpeggio_amd.core import export as _export
-            o = np.lexsort((res_e['j'], res_e['i']))
-            bag_sorted = {'atom_atom': {k: v[o] for k, v in res_e.items()}}
-            bag_sorted.update({k: ctx.fetch_bag(k) for k in bufs[1]})
-            fresh[1].ensure_labels()
-            tt = time.perf_counter()
-            recs = _export.contacts_json(fresh[1], bag_sorted, fresh[1].component_types)
-            get_contacts_ms = (time.perf_counter() - tt) * 1e3
-            n_recs = len(recs)
-            del recs
-            tt = time.perf_counter()
-            recs = _export.contacts_json(fresh[1], bag_sorted, fresh[1].component_types, share_atoms=True)
-            get_contacts_shared_ms = (time.perf_counter() - tt) * 1e3
-            del recs
-            import tempfile
-            with tempfile.TemporaryDirectory() as td:     # the CLI's output file, written by the native formatter
-                tt = time.perf_counter()
-                _export.write_contacts_json(os.path.join(td, 'out.json'), fresh[1], bag_sorted, fresh[1].component_types)
-                write_json_ms = (time.perf_counter() - tt) * 1e3
-                json_bytes = os.path.getsize(os.path.join(td, 'out.json'))
+            nbytes_down = int(sum(v.nbytes for b in bags_e.values() for v in b.values()))
+            k_aa = bags_e['atom_atom']
+            key = k_aa['i'].astype(np.int64) << 32 | k_aa['j'].astype(np.int64)
+            assert len(key) == cnt_e['atom_atom'] and bool(np.all(np.diff(key) > 0)), 'end_to_end: the atom-atom bag is not in canonical order'
+            e2e_host = (fresh[1], {k: {kk: vv.copy() for kk, vv in v.items()} for k, v in bags_e.items()})
             # pipelined: three contexts, three host threads
             pipelined = None
             if args.inflight > 1:
                 ctxs = [_capi.Context(local_rank) for _ in range(args.inflight)]
-                bb = [make_buffers(cx) for cx in ctxs]
+                bb = [make_buffer(cx) for cx in ctxs]
                 per_thread = max(30, n_e2e // args.inflight)
                 gate = threading.Barrier(args.inflight + 1)
 
@@ -570,31 +559,60 @@ def main():
                 pipelined = round((time.perf_counter() - t2) / (per_thread * args.inflight) * 1e3, 4)
                 for cx in ctxs:
                     cx.close()
-            end_to_end = {'ms_per_structure': round(e2e_ms, 4), 'structures': n_e2e,
+            end_to_end = {'ms_per_structure': round(e2e_ms, 4), 'structures': n_e2e, 'canonical_order': 'atom-atom bag sorted by (i, j) on the device (arp_atom_contacts_sort), ring / amide bags by their two ids on the host (a few thousand records)',
                           'ms_per_structure_3_contexts_in_flight': pipelined,
                           'breakdown_ms': {k: round(v, 4) for k, v in br.items()},
+                          'run_arpeggio_on_an_unseen_structure_ms': round(br['first_pass_ms'], 4),
                           'upload_bytes': nbytes_up, 'download_bytes': nbytes_down,
                           'candidate_pairs_per_s': round(st['candidates'] / (e2e_ms * 1e-3), 1),
                           'pack_blob_ms_host': round(pack_ms, 3),
-                          'get_contacts_ms': round(get_contacts_ms, 2), 'get_contacts_records': n_recs,
-                          'get_contacts_share_atoms_ms': round(get_contacts_shared_ms, 2),
-                          'write_json_ms': round(write_json_ms, 2), 'write_json_bytes': json_bytes,
                           'note': 'fresh structure per step: arp_set_blob (one H2D copy from page-locked memory + device-side validation) + '
-                                  'static columns + ring / amide grids + pass + all five result bags into page-locked host buffers; '
-                                  'pack_blob_ms_host = NumPy packing of a PackedComplex into the blob (done by the producer of the '
-                                  'structure, outside the figure); get_contacts_ms = building the JSON records of the drop-in class '
-                                  'from the fetched arrays (host Python, outside the figure)'}
+                                  'static columns + ring / amide grids + pass + device sort of the atom-atom bag + all five result bags into one '
+                                  'page-locked host buffer with one copy; pack_blob_ms_host = NumPy packing of a PackedComplex into the blob (done '
+                                  'by the producer of the structure, outside the figure)'}
             ctx.set_complex(pc)     # back to the resident benchmark structure
+            ctx.set_grid_reuse(False)
             for _ in range(3):
                 step()
         except Exception as exc:   # never lose the main line over the extra measurement
             end_to_end = {'error': repr(exc)}
+    ctx.device_synchronize()
+    t_gpu_legs_done = time.perf_counter()
+
+    # host-only: the exporter of the drop-in class on the result fetched above (JSON records as the reference's get_contacts builds them)
+    if end_to_end is not None and e2e_host is not None and 'error' not in end_to_end:
+        try:
+            from arpeggio_amd.core import export as _export
+            pc_e, bag_sorted = e2e_host
+            pc_e.ensure_labels()
+            tt = time.perf_counter()
+            recs = _export.contacts_json(pc_e, bag_sorted, pc_e.component_types)
+            end_to_end['get_contacts_ms'] = round((time.perf_counter() - tt) * 1e3, 2)
+            end_to_end['get_contacts_records'] = len(recs)
+            del recs
+            tt = time.perf_counter()
+            recs = _export.contacts_json(pc_e, bag_sorted, pc_e.component_types, share_atoms=True)
+            end_to_end['get_contacts_share_atoms_ms'] = round((time.perf_counter() - tt) * 1e3, 2)
+            del recs
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:     # the CLI's output file, written by the native formatter
+                tt = time.perf_counter()
+                _export.write_contacts_json(os.path.join(td, 'out.json'), pc_e, bag_sorted, pc_e.component_types)
+                end_to_end['write_json_ms'] = round((time.perf_counter() - tt) * 1e3, 2)
+                end_to_end['write_json_bytes'] = os.path.getsize(os.path.join(td, 'out.json'))
+            end_to_end['host_export_note'] = 'get_contacts_ms / write_json_ms: host Python / IO on the fetched arrays, outside every GPU figure'
+        except Exception as exc:
+            end_to_end['host_export_error'] = repr(exc)
+    e2e_host = None
 
     # max over ranks of the elapsed time, sum over ranks of the work
     cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
+    rccl_ranks_seen = None
     if rdzv is not None:
         elapsed = float(rdzv.allreduce(np.array([elapsed], np.float64), 'max')[0])
         cand_all, acc_all, emitted_all, exp_all = (float(x) for x in rdzv.allreduce(np.array([cand, acc, emitted, st['expand_candidates']], np.float64), 'sum'))
+        if comm_device is not None:
+            rccl_ranks_seen = ctx.comm_info()[1]
     else:
         cand_all, acc_all, emitted_all, exp_all = float(cand), float(acc), float(emitted), float(st['expand_candidates'])
 
@@ -608,69 +626,76 @@ def main():
     value = cand_all * timed_steps / elapsed
 
     # ---------------- roofline of the dominant kernel (rank 0) ----------------
+    # The dominant kernel is the one with the longest HIP-event duration in this run; its bytes are SURVEY 8d's compulsory
+    # bytes of that stage (survey_8d_bytes: no intermediate pair list).  roofline_all_kernels gives every kernel of the pass
+    # under both byte models, roofline_pass the whole pass (140 N + 16 P over ms_per_step), roofline_valu the issue-rate view.
     per_kernel = {k: (v['ms'] / max(v['launches'], 1)) for k, v in ktimes.items() if v['launches']}
-    candidates_for_dominant = {k: per_kernel[k] for k in ('search', 'sift', 'mark_search') if k in per_kernel}
+    candidates_for_dominant = {k: per_kernel[k] for k in ('bin', 'search', 'sift', 'mark_search') if k in per_kernel}
     dom = max(candidates_for_dominant, key=candidates_for_dominant.get)
-    # k_search and k_sift_planes last the same at 100 k atoms (28.1 and 27.7 us under rocprofv3; which one the HIP events of a run
-    # put first changes from box to box).  Between kernels within 5 % of each other the line takes the one that moves more
-    # bytes — the one an HBM roofline says something about, and the kernel of rounds 1 and 2 —; `roofline_all_kernels` has both.
-    tie_rule = None
-    for k_, ms_ in candidates_for_dominant.items():
-        if k_ != dom and ms_ >= 0.95 * candidates_for_dominant[dom] and \
-           algorithmic_bytes(k_, st['binned'] if k_ != 'mark_search' else pc.n_atoms, st['cells'], emitted) > \
-           algorithmic_bytes(dom, st['binned'] if dom != 'mark_search' else pc.n_atoms, st['cells'], emitted):
-            tie_rule = (f'k_{dom} {candidates_for_dominant[dom] * 1e3:.1f} us and k_{k_} {ms_ * 1e3:.1f} us are within 5 %: the figure is '
-                        f'given for k_{k_}, which moves more bytes; roofline_all_kernels has both')
-            dom = k_
     dom_ms = candidates_for_dominant[dom]
-    n_binned = st['binned'] if dom != 'mark_search' else pc.n_atoms
     ncell = st['cells']
     n_h = int(pc.h_xyz.shape[0]) if getattr(pc, 'h_xyz', None) is not None else 0
-    b_alg = algorithmic_bytes(dom, n_binned, ncell, emitted, n_h)
+
+    def n_of(k):
+        return st['binned'] if k != 'mark_search' else pc.n_atoms
+    b_alg = survey_8d_bytes(dom, n_of(dom), ncell, emitted)
     achieved = b_alg / (dom_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC counters of the last committed rocprofv3 run (profiles/pmc_traffic.json,
-    # written by tools/export_profile.py; separate --pmc passes, gfx950 FETCH_SIZE correction applied)
-    traffic, traffic_src = None, None
+    # HBM bytes and VALU instructions per launch from the PMC counters of the last committed rocprofv3 run
+    # (profiles/pmc_traffic.json, written by tools/export_profile.py; separate --pmc passes, gfx950 FETCH_SIZE correction applied)
+    pj = None
     try:
         pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        if args.atoms == 100_000 and world == 1 and f'k_{dom}' in pj['kernels']:
-            traffic = pj['kernels'][f'k_{dom}']['hbm_bytes_per_launch']
-            traffic_src = pj['source']
-    except (OSError, KeyError, ValueError):
-        pass
+        if not (args.atoms == 100_000 and world == 1 and args.workload == 'config3'):
+            pj = None
+    except (OSError, ValueError):
+        pj = None
+    traffic = traffic_src = None
+    if pj is not None and f'k_{dom}' in pj.get('kernels', {}):
+        traffic = pj['kernels'][f'k_{dom}'].get('hbm_bytes_per_launch')
+        traffic_src = pj.get('source')
     # The number that actually bounds these kernels: VALU issue.  SQ_INSTS_VALU of the committed PMC run (per launch) /
-    # (launch duration x 1024 SIMDs x 2.4 GHz / 4 cycles: a wave64 instruction occupies its 16-lane SIMD four cycles —
-    # SQ_ACTIVE_INST_VALU counts one quad-cycle per instruction in every committed profile; only packed-FP32 work gets two
-    # results per lane and cycle, and these kernels are integer / compare / float64 code)
+    # (launch duration x 1024 SIMDs x 2.4 GHz / 4 cycles: a wave64 instruction occupies its 16-lane SIMD four cycles)
+    VALU_PEAK = 1024 * 2.4e9 / 4.0
     roofline_valu = None
-    try:
-        pv = pj['kernels'][f'k_{dom}']
-        if args.atoms == 100_000 and world == 1 and 'valu_insts_per_launch' in pv:
-            peak = 1024 * 2.4e9 / 4.0
-            roofline_valu = {'kernel': f'k_{dom}', 'valu_wave_instructions_per_launch': pv['valu_insts_per_launch'],
-                             'issue_peak_per_s': peak, 'frac': round(pv['valu_insts_per_launch'] / (dom_ms * 1e-3) / peak, 4),
-                             'source': f'instruction count from the committed profile, NOT this run ({pj["source"]}); duration of this run'}
-    except (OSError, KeyError, ValueError, NameError):
-        pass
+    if pj is not None:
+        roofline_valu = {'issue_peak_per_s': VALU_PEAK, 'source': f'instruction counts from the committed profile, NOT this run ({pj.get("source")}); durations of this run', 'kernels': {}}
+        total_insts = 0
+        for k_, ms_ in candidates_for_dominant.items():
+            pv = pj['kernels'].get(f'k_{k_}', {})
+            if 'valu_insts_per_launch' in pv:
+                total_insts += pv['valu_insts_per_launch']
+                roofline_valu['kernels'][f'k_{k_}'] = {'valu_wave_instructions_per_launch': pv['valu_insts_per_launch'],
+                                                       'frac': round(pv['valu_insts_per_launch'] / (ms_ * 1e-3) / VALU_PEAK, 4)}
+        if total_insts:
+            roofline_valu['pass'] = {'valu_wave_instructions_per_pass': total_insts, 'ms_per_step': round(ms_per_step, 4),
+                                     'frac': round(total_insts / (ms_per_step * 1e-3) / VALU_PEAK, 4)}
     roofline = {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
                 'traffic_source': (None if traffic_src is None else f'committed profile, NOT this run: {traffic_src}'),
-                'algorithmic_bytes_per_launch': int(b_alg), 'algorithmic_bytes_without_hydrogen_coordinates': int(b_alg - (24 * n_h if dom == 'sift' else 0)),
-                'avg_launch_ms': round(dom_ms, 5), 'dominant_kernel_rule': tie_rule,
-                'note': {'search': 'VALU-issue-bound geometry kernel (8.8 M wave-instructions per launch at ~4 cycles each, profiles/round3_head_pmc_per_launch.csv); half of the kernel is the decay of occupancy while the slowest waves of every CU finish (block trace, profiles/README.md); ',
-                         'sift': 'VALU issue at 4 waves per SIMD (127 VGPRs; ~285 VALU per batch of 64 pairs keeps the SIMD issuing, more waves were slower): 7.1 M wave-instructions per launch, 59 % of the wave cycles are waits (SQ_WAIT_ANY) — the dependent round trips at the start and the end of every wave; ',
-                         'mark_search': 'VALU / LDS issue-bound geometry kernel; '}.get(dom, '') +
-                        'the HBM fraction is small by construction: register-tiled pair tests move ~35 MB per 100 k-atom pass (SURVEY 8d)'}
+                'algorithmic_bytes_per_launch': int(b_alg),
+                'bytes_model': {'bin': 'SURVEY 8d bin + sort / scatter passes: 92 N', 'search': 'SURVEY 8d: each sorted record once, 32 N + 4 (C + 1); the 8 B / pair list it writes is an intermediate of the split design, not counted',
+                                'sift': 'SURVEY 8d: side arrays + output records, 16 N + 16 P; the pair list and the record gathers are not counted',
+                                'mark_search': '32 N + 4 (C + 1)'}[dom],
+                'avg_launch_ms': round(dom_ms, 5),
+                'dominant_kernel_rule': 'longest average HIP-event duration among the kernels of the pass in this run (kernel_ms)',
+                'note': 'VALU-issue-bound geometry kernels (roofline_valu); the HBM fraction is small by construction: register-tiled pair tests '
+                        'move ~35 MB per 100 k-atom pass (SURVEY 8d)'}
 
     # the same figure for every big kernel of the pass (informational; `roofline` above is the dominant one)
     roofline_all = {}
     for k, ms in candidates_for_dominant.items():
-        nb = st['binned'] if k != 'mark_search' else pc.n_atoms
-        b = algorithmic_bytes(k, nb, ncell, emitted, n_h)
-        roofline_all[f'k_{k}'] = {'avg_launch_ms': round(ms, 5), 'algorithmic_bytes_per_launch': int(b),
-                                  'achieved_GBps': round(b / (ms * 1e-3) / 1e9, 2), 'frac': round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+        b8 = survey_8d_bytes(k, n_of(k), ncell, emitted)
+        bi = algorithmic_bytes(k, n_of(k), ncell, emitted, n_h)
+        roofline_all[f'k_{k}'] = {'avg_launch_ms': round(ms, 5), 'survey_8d_bytes_per_launch': int(b8),
+                                  'frac': round(b8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                  'bytes_as_implemented': int(bi), 'frac_as_implemented': round(bi / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+    b_pass = 140 * st['binned'] + 16 * emitted
+    roofline_pass = {'bytes_per_pass': int(b_pass), 'bytes_model': 'SURVEY 8d: B_alg = 140 N + 16 P (grid build included)', 'ms_per_step': round(ms_per_step, 4),
+                     'achieved': round(b_pass / (ms_per_step * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(b_pass / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)} if world == 1 else None
 
     # ---------------- CPU baseline: the C oracle on one host core, bounded sample ----------------
+    gpu_legs_s = t_gpu_legs_done - t_gpu_legs_begin
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # (rank 0 at N = 1 only, as the bench contract says)
         import oracle
@@ -762,6 +787,7 @@ def main():
         except Exception as exc:
             cpu_py = {'error': repr(exc)}
 
+    e2e_ms_sorted = (end_to_end or {}).get('ms_per_structure')
     line = {
         'metric': 'evaluated atom-pairs/s', 'value': round(value, 1), 'unit': 'candidate atom-pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
@@ -770,7 +796,12 @@ def main():
         'data': 'synthetic',
         'config': {'workload': workload, 'atoms_per_gpu': args.atoms, 'cutoff_A': args.cutoff, 'vdw_comp': args.vdw_comp,
                    'parallelism': f'slab{world}' if world > 1 else 'single'},
-        'wall_clock_per_structure_ms': round(ms_per_step, 4),   # RESIDENT structure re-evaluated; fresh structures: end_to_end
+        'step_definition': 'one whole run_arpeggio pass over the resident structure that BUILDS its contact grid (k_compact_atoms + k_search + k_sift_planes, '
+                           'arp_set_grid_reuse(0)); nothing a pass made is reused by the next one',
+        # wall clock per structure = a FRESH structure end to end, canonical order included (end_to_end); null when that leg was skipped
+        'wall_clock_per_structure_ms': e2e_ms_sorted,
+        'wall_clock_per_structure_definition': 'end_to_end.ms_per_structure: upload + first pass + device sort + one-copy fetch of all five bags, new structure every step',
+        'run_arpeggio_on_an_unseen_structure_ms': (end_to_end or {}).get('run_arpeggio_on_an_unseen_structure_ms'),
         'pairs': {'candidates': cand_all, 'accepted': acc_all, 'contacts_emitted': emitted_all,
                   'expansion_candidates_6A': exp_all, 'bags': counts},
         'accepted_pairs_per_s': round(acc_all * timed_steps / elapsed, 1),
@@ -782,24 +813,20 @@ def main():
         'cpu_baseline_all_cores': cpu_mc,
         'cpu_baseline_python': cpu_py,
         'host_us_per_step': {k: round(v, 1) for k, v in host_times.items() if k != 'passes'} if world == 1 else None,
-        'launch_mode': 'a whole-structure pass over a resident structure is two launches on one HIP stream (k_search, k_sift_planes = per-pair evaluation + ring/amide loops; kernel_ms: search / sift) on the contact grid the structure\'s first pass left — the grid depends on the structure and the cutoff only; with a partial selection, another cutoff or a new structure k_compact_atoms builds it first (pass_with_grid_rebuild, kernel_ms.bin; end_to_end builds everything for every structure); the last launch publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
+        'launch_mode': 'three launches on one HIP stream per pass: k_compact_atoms (kernel_ms.bin: the contact grid of the pass), k_search, k_sift_planes (per-pair evaluation + ring/amide loops; kernel_ms: search / sift); the last launch publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
+        'rccl_ranks_seen': rccl_ranks_seen,
         'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2), 'shard_setup_breakdown_ms': shard_timings,
         'halo_exchange': (halo_note if world > 1 else None),
-        'scaling_note': (None if world == 1 else f'per-GPU work is {args.atoms} atoms (+ halo); the default N = 1 line is the 100 000-atom headline workload, '
-                                                 f'so the single-GPU figure to compare with is `bench.py --gpus 1 --atoms {args.atoms}` (profiles/round3_bench_250k.json: 1.55e11 pairs/s at 250 000 atoms)'), 'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
+        'scaling_note': (None if world == 1 else f'weak scaling: every GPU owns one config-3 cube of {args.atoms} atoms (+ a one-cell halo) — the workload of the N = 1 line with the same --atoms'),
+        'setup_s': round(gen_s, 2), 'home_atoms_rank0': n_local_home,
+        'gpu_legs_s': round(gpu_legs_s, 2),
         'end_to_end': end_to_end,
-        'end_to_end_ms_per_structure': (end_to_end or {}).get('ms_per_structure'),
+        'end_to_end_ms_per_structure': e2e_ms_sorted,
         'get_contacts_ms': (end_to_end or {}).get('get_contacts_ms'),
         'roofline_valu': roofline_valu,
-        # the whole pass against the HBM peak with SURVEY 8d's contract bytes (140 B per atom binned + 16 B per contact) and the
-        # step time of this run: what one 100 k-atom pass moves is a few per cent of what 8 TB/s could move in that time
-        # (48 N + 16 P: SURVEY 8d's pair pass + side arrays + output — the 92 N of its bin / sort passes are not moved by a pass that
-        # keeps its grid; pass_with_grid_rebuild carries the figure with all 140 N)
-        'roofline_pass': {'bytes_per_pass': int(48 * st['binned'] + 16 * emitted), 'bytes_model': '48 N + 16 P (no grid build in this pass)', 'ms_per_step': round(ms_per_step, 4),
-                          'achieved': round((48 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                          'frac': round((48 * st['binned'] + 16 * emitted) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)} if world == 1 else None,
-        'pass_with_grid_rebuild': grid_rebuild, 'ligand_selection_pass': ligand_pass,
+        'roofline_pass': roofline_pass,
+        'pass_with_grid_kept': grid_kept, 'ligand_selection_pass': ligand_pass,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(line), flush=True)

@@ -444,7 +444,8 @@ int arp_set_whole_structure(arp_ctx* ctx, int enabled);
 int arp_comm_unique_id(uint8_t* out_id, uint64_t capacity /* >= 128 */);
 int arp_comm_init(arp_ctx* ctx, int rank, int world, const uint8_t* unique_id /* 128 bytes */);
 int arp_comm_destroy(arp_ctx* ctx);
-int arp_comm_info(arp_ctx* ctx, int* rank, int* world);          /* ARP_E_ARG while there is no communicator */
+int arp_comm_info(arp_ctx* ctx, int* rank, int* world);          /* rank / size as RCCL reports them (ncclCommUserRank / ncclCommCount);
+                                                                   * ARP_E_ARG while there is no communicator */
 /* Halo records of a structure: the two face buffers cut out by arp_shard_pack_face (device pointers; bytes = 0 or a missing
  * neighbour: nothing sent) go to ranks rank - 1 / rank + 1, theirs arrive in buffers the context owns:
  * received = {left pointer, left bytes, right pointer, right bytes}, valid until the next call — the arguments of

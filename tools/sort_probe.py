@@ -37,3 +37,16 @@ t0 = time.perf_counter()
 o = np.lexsort((raw['j'], raw['i']))
 s = {kk: v[o] for kk, v in raw.items()}
 print(f'  host np.lexsort + 5 gathers: {(time.perf_counter() - t0) * 1e3:.1f} ms')
+# copies alone (the bag is already sorted: no sort kernels in these calls)
+ctx.run_launch(5.0, 0.1, False, 6.0)
+ctx.sort_contacts(); ctx.device_synchronize()
+for name, fn in (('five copies from the sorted slab', lambda: ctx.atom_contacts_fetch(k, sort=False, out=cb)),
+                 ('one packed copy (no sort)', lambda: ctx.fetch_packed(buf, sort_bags=False)),
+                 ('five copies from the sorted slab', lambda: ctx.atom_contacts_fetch(k, sort=False, out=cb)),
+                 ('one packed copy (no sort)', lambda: ctx.fetch_packed(buf, sort_bags=False))):
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    print(f'  {name}: {np.median(ts) * 1e3:.3f} ms (min {min(ts) * 1e3:.3f})')
