@@ -403,7 +403,7 @@ class CifCategory:
         return out
 
 
-KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'sift_early', 'search', 'sift', 'mark_search', 'planes')
+KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')
 
 
 class Context:

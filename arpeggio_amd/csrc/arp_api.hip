@@ -122,7 +122,7 @@ inline dim3 pack_grid(const PackTable& t) {
     return dim3(std::min<uint32_t>(std::max<uint32_t>((mx + 16383u) >> 14, 1u), 64u), (unsigned)t.n);
 }
 
-enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_SIFT_EARLY = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
+enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_UNUSED = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
 
 struct EventPair { int slot; hipEvent_t a, b; };
 
@@ -222,20 +222,6 @@ struct arp_ctx {
     DevBuf<uint16_t> out_s;
     DevBuf<uint8_t> out_ct;
     int64_t n_contacts = 0;
-    // the chunk queue between k_search and the sift kernels (ChunkQueue, arp_pairs.h); the records of segment s sit at
-    // [s * seg_cap, s * seg_cap + seg_count[s]) of the out_* columns until something asks for them in one piece (ensure_dense)
-    DevBuf<unsigned> qfill;
-    bool qfill_clean = false;           // every fill counter is zero (a published pass leaves them so)
-    bool pass_zeroes_fill = false;      // the pass in flight publishes in-kernel and returns the fill counters to zero
-    int64_t seg_count[PAIR_SEGS] = {0};
-    int64_t seg_cap = 0;
-    bool contacts_dense = false;        // den_* hold the records of the last launch back to back (order of the segments)
-    DevBuf<int> den_i, den_j;
-    DevBuf<float> den_d;
-    DevBuf<uint16_t> den_s;
-    DevBuf<uint8_t> den_ct;
-    hipEvent_t ev_grid = nullptr, ev_early = nullptr;
-    bool early_pending = false;         // an early sift launch on stream2 that the main stream has not been told to wait for yet
     // ---- canonical (i, j) order of the atom-atom bag, made on the device (arp_sort.h; arp_atom_contacts_sort)
     DevBuf<unsigned long long> sort_key[2];
     DevBuf<uint32_t> sort_idx[2];
@@ -846,10 +832,6 @@ int zero_counter(arp_ctx* c, int first, int count) {
         HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(first), 0, sizeof(u64) * PAIR_SEGS * CTR_LINE, c->stream));
         return ARP_OK;
     }
-    if (first == C_SEG_TAIL && count == PAIR_SEGS * QSUB + 1) {                         // the queue's ticket lines and the done word behind them
-        HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(first), 0, sizeof(u64) * (PAIR_SEGS * QSUB + 1) * CTR_LINE, c->stream));
-        return ARP_OK;
-    }
     for (int k = first; k < first + count; ++k) HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(k), 0, sizeof(u64), c->stream));
     return ARP_OK;
 }
@@ -1005,9 +987,8 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
     if (n > 0 && !c->sel_all) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
-                           c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0,
-                           ChunkQueue{nullptr, 0ull, c->d_ctr + ctr_dev(C_SCRATCH0), nullptr, nullptr, nullptr, 0u, 0u, 0},
-                           c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
+                           c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
+                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
@@ -1316,34 +1297,11 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
     CHK(zero_counter(c, C_SEG_PAIRS, PAIR_SEGS));
-    CHK(zero_counter(c, C_SEG_TAIL, PAIR_SEGS * QSUB + 1));      // (ticket counters and the search-blocks-done word behind them)
     CHK(zero_counter(c, C_STAT_CAND, 2 * STAT_SLOTS));
-    // the chunk queue of the pass (ChunkQueue): fill counters per chunk of every segment, zero when the search starts
-    const unsigned fcap = (unsigned)(segcap / QCHUNK + 2);
-    {
-        bool fresh = false;
-        HIPCHK(c, c->qfill.reserve((size_t)fcap * PAIR_SEGS, &fresh));
-        if (fresh || !c->qfill_clean) HIPCHK(c, hipMemsetAsync(c->qfill.p, 0, (size_t)fcap * PAIR_SEGS * sizeof(unsigned), c->stream));
-        c->qfill_clean = false;
-        c->pass_zeroes_fill = c->pub.expected != 0;
-        if (c->pub.expected) { c->pub.fill = c->qfill.p; c->pub.fcap = fcap; c->pub.chunk = QCHUNK; }
-    }
-    ChunkQueue PQ{c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_SEG_TAIL), c->d_ctr + ctr_dev(C_SEARCH_DONE),
-                 c->qfill.p, fcap, 0u, 0};
-    c->seg_cap = (int64_t)segcap;
-    // the per-pair kernel also runs BESIDE the search, on the second stream (see the launches below): decided here, because the
-    // second stream has to wait for the grid of this pass — an event recorded right in front of the search launch
-    static const int overlap_mode = env_int("ARP_OVERLAP", 1);
-    static const int64_t overlap_min = (int64_t)env_int("ARP_OVERLAP_MIN_PAIRS", 65536);
-    static const int planes_mode_ = env_int("ARP_PLANES_MODE", 0);
-    const int64_t expect_pairs_ = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
-    const bool want_overlap = overlap_mode && planes_mode_ == 0 && c->pub.expected == 1 && !c->external_stream && c->stream2 && c->n > 0 &&
-                              expect_pairs_ >= overlap_min && c->ev_grid && c->ev_early;
     bool search_launched = false;
     auto launch_search = [&]() -> int {
         if (search_launched || c->n == 0) return ARP_OK;
         search_launched = true;
-        if (want_overlap) HIPCHK(c, hipEventRecord(c->ev_grid, c->stream));
         Prof p(c, SLOT_SEARCH);
         // the contact search ends with a block-level flush of its pair queues, which amortises better over
         // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
@@ -1356,18 +1314,21 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // grid's build reported last time, all atoms of the structure before that is known.
         static const int balance_mode = env_int("ARP_SEARCH_BALANCE", -1);     // -1: by sparsity, 0: never, 1: whenever the cells of the rows are known
         const int64_t atoms_est = c->cg_reused ? c->cg_binned : (c->stats[4] == c->atom_grid.d.ncell && c->stats[3] > 0 ? c->stats[3] : c->n);
-        const bool by_atoms = c->s_cell_valid && (balance_mode == 1 || (balance_mode < 0 && (int64_t)c->atom_grid.d.ncell > atoms_est));
+        // ... and so do the blocks of a CLUMPED structure (cells with hundreds of atoms: a chain folded onto itself), which the
+        // previous pass over this structure gives away by its distance tests per atom (uniform protein density: ~80)
+        const bool clumped = c->stats[3] > 0 && c->stats[4] == c->atom_grid.d.ncell && c->stats[0] > 150 * c->stats[3];
+        const bool by_atoms = c->s_cell_valid && (balance_mode == 1 || (balance_mode < 0 && ((int64_t)c->atom_grid.d.ncell > atoms_est || clumped)));
         int nblocks_search = search_blocks_balanced(c, c->atom_grid.d, cpw);
         if (by_atoms) {
             const int R = c->search_resident;
-            int nbk = (int)std::min<int64_t>(std::max<int64_t>((atoms_est + 127) / 128, 8), 8192);
+            static const int atoms_per_block = std::max(8, env_int("ARP_SEARCH_APB", 128));
+            int nbk = (int)std::min<int64_t>(std::max<int64_t>((atoms_est + atoms_per_block - 1) / atoms_per_block, 8), 8192);
             nbk = (nbk + 7) & ~7;
             nblocks_search = (R >= 8 && 2 * nbk >= R) ? std::min(std::max(1, (nbk + R / 2) / R) * R, 8192) & ~7 : nbk;
         }
-        PQ.producers = (unsigned)nblocks_search;
         hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                            c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                           include_seq_adj, c->has_home ? 1 : 0, PQ, c->d_ctr + ctr_dev(C_STAT_CAND),
+                           include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
                            c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
                            by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
         return check_launch(c, "k_search<CONTACTS>");
@@ -1436,12 +1397,13 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     }
     if (lists_forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lists, 0));   // (k_planes on the second stream follows the lists in order)
     if (c->n > 0) {
+        Prof p(c, SLOT_SIFT);
         static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
-        SiftArgs sa{PQ, c->s_rec.p, c->s_b4.p,
-                    SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
-                    c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
-                    (int*)(c->d_ctr + ctr_dev(C_ERR))};
-        // No more sift blocks than the pairs can feed (one chunk per wave and block at least): what the previous pass over
+        const SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_rec.p, c->s_b4.p,
+                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
+                          c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
+                          (int*)(c->d_ctr + ctr_dev(C_ERR))};
+        // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
         // this structure found, or ~13 per heavy atom for the first one.  A protein-sized structure then runs 70-odd blocks
         // instead of 1024, whose start-up and end-of-pass tickets were most of the kernel (stand-in: 25 -> 16 us).
         static const int pairs_per_block = std::max(64, env_int("ARP_SIFT_PPB", 256));
@@ -1451,30 +1413,6 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         const int by_work = (int)std::min<int64_t>((expect + pairs_per_block - 1) / pairs_per_block + PAIR_SEGS, 1 << 20);
         const int slots = merged ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * sift_blocks_per_cu;
         const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
-        // ---- the early consumers: the same per-pair kernel on the second stream, BESIDE the search.  Its waves take chunks
-        // of the pair list as the search blocks hand them over (ChunkQueue) — the registers a finished search block leaves
-        // behind are theirs, and their prologue is over by the time the search ends — and go on, together with the launch
-        // below, until the queue is empty.  Never more blocks than half the chip holds: waiting consumers must not keep
-        // search blocks of a later round from being placed.  Both launches end the pass together (pass_end: two ticket sets).
-        static const int early_bpc = std::max(1, env_int("ARP_EARLY_BPC", 2));
-        const bool overlap = want_overlap && !planes_alone && c->pub.expected == 1;
-        if (overlap) {
-            const int nearly = std::max(std::min(c->num_cu * early_bpc, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
-            c->pub.expected = 2;
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_grid, 0));     // (recorded behind the search launch's predecessors: the grid of this pass is in place)
-            {
-                Prof p(c, SLOT_SIFT_EARLY, c->stream2);
-                SiftArgs se = sa;
-                se.Q.final = 0;
-                if (stream_out) hipLaunchKernelGGL(k_sift<1>, dim3(nearly), dim3(256), 0, c->stream2, se, c->pub, 1);
-                else hipLaunchKernelGGL(k_sift<0>, dim3(nearly), dim3(256), 0, c->stream2, se, c->pub, 1);
-                CHK(check_launch(c, "k_sift (early)"));
-            }
-            HIPCHK(c, hipEventRecord(c->ev_early, c->stream2));
-            c->early_pending = true;
-        }
-        sa.Q.final = 1;       // (launched behind the search in stream order)
-        Prof p(c, SLOT_SIFT);
         if (merged && stream_out)
             hipLaunchKernelGGL(k_sift_planes<1>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
                                c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
@@ -1482,9 +1420,9 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             hipLaunchKernelGGL(k_sift_planes<0>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
                                c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
         else if (stream_out)
-            hipLaunchKernelGGL(k_sift<1>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub, 0);
+            hipLaunchKernelGGL(k_sift<1>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         else
-            hipLaunchKernelGGL(k_sift<0>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub, 0);
+            hipLaunchKernelGGL(k_sift<0>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
         CHK(check_launch(c, "k_sift"));
     } else if (!planes_alone) {
         c->pub.expected = 0;   // nothing was launched that could publish: the caller falls back to k_publish_counters
@@ -1504,8 +1442,6 @@ bool finish_contacts(arp_ctx* c) {
     c->h_ctr[C_PAIRS] = np;
     c->h_ctr[C_SCRATCH0] = worst;
     if (worst > segcap) return true;
-    for (int k = 0; k < PAIR_SEGS; ++k) c->seg_count[k] = (int64_t)c->h_ctr[C_SEG_PAIRS + k];
-    c->contacts_dense = false;
     c->n_contacts = (int64_t)np;
     c->contacts_expected = (int64_t)np;
     c->contacts_valid = true;
@@ -1523,47 +1459,6 @@ bool finish_contacts(arp_ctx* c) {
 // ---- canonical order of the atom-atom bag (arp_sort.h) --------------------------------------------------------
 // Layout of the sorted slab: the five columns one after the other, each on a 256-byte boundary; what follows them
 // (sorted_extra bytes) is the caller's (the packed ring / amide bags of arp_fetch_packed).
-// Records of the atom-atom bag sit segment by segment (PAIR_SEGS segments of seg_cap slots, the first seg_count[s] of each
-// used).  Whatever wants them in one piece gets a copy (den_*), made once per launch.
-struct SegMap { long long prefix[PAIR_SEGS + 1]; long long cap; };
-inline SegMap seg_map(const arp_ctx* c) {
-    SegMap m;
-    m.prefix[0] = 0;
-    for (int k = 0; k < PAIR_SEGS; ++k) m.prefix[k + 1] = m.prefix[k] + c->seg_count[k];
-    m.cap = c->seg_cap;
-    return m;
-}
-__global__ __launch_bounds__(256) void k_dense_contacts(SegMap m, const int* __restrict__ si, const int* __restrict__ sj, const float* __restrict__ sd_,
-                                                        const uint16_t* __restrict__ ss, const uint8_t* __restrict__ sc, int* __restrict__ di,
-                                                        int* __restrict__ dj, float* __restrict__ dd, uint16_t* __restrict__ ds, uint8_t* __restrict__ dc) {
-    const long long n = m.prefix[PAIR_SEGS];
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-        const long long p = sort_phys(v, m.prefix, m.cap);
-        di[v] = si[p]; dj[v] = sj[p]; dd[v] = sd_[p]; ds[v] = ss[p]; dc[v] = sc[p];
-    }
-}
-// an early sift launch on the second stream (enqueue_contacts): whatever reads the results on the main stream comes after it
-int join_early(arp_ctx* c) {
-    if (c->early_pending) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_early, 0));
-        c->early_pending = false;
-    }
-    return ARP_OK;
-}
-int ensure_dense(arp_ctx* c) {
-    if (c->contacts_dense) return ARP_OK;
-    CHK(join_early(c));
-    const size_t k = (size_t)c->n_contacts, cap = std::max(k, c->out_i.cap / 2) + 64;
-    HIPCHK(c, c->den_i.reserve(cap)); HIPCHK(c, c->den_j.reserve(cap)); HIPCHK(c, c->den_d.reserve(cap));
-    HIPCHK(c, c->den_s.reserve(cap)); HIPCHK(c, c->den_ct.reserve(cap));
-    if (k > 0) {
-        hipLaunchKernelGGL(k_dense_contacts, dim3(nblocks((int64_t)k, 256, 4096)), dim3(256), 0, c->stream, seg_map(c), c->out_i.p, c->out_j.p, c->out_d.p,
-                           c->out_s.p, c->out_ct.p, c->den_i.p, c->den_j.p, c->den_d.p, c->den_s.p, c->den_ct.p);
-        CHK(check_launch(c, "k_dense_contacts"));
-    }
-    c->contacts_dense = true;
-    return ARP_OK;
-}
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 void sorted_layout(size_t k, size_t off[5], size_t* bytes) {
     off[0] = 0;
@@ -1603,13 +1498,7 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     const int tstride = (int)((tiles + 3) & ~3ll);
     HIPCHK(c, c->sort_table.reserve((size_t)SORT_BINS * (size_t)tstride));
     HIPCHK(c, c->sort_total.reserve(SORT_BINS));
-    CHK(join_early(c));
     SortArgs A{};
-    {
-        const SegMap m = seg_map(c);
-        for (int q = 0; q <= PAIR_SEGS; ++q) A.seg_prefix[q] = m.prefix[q];
-        A.seg_cap = m.cap;
-    }
     A.ci = c->out_i.p; A.cj = c->out_j.p;
     A.d_in = c->out_d.p; A.s_in = c->out_s.p; A.ct_in = c->out_ct.p;
     uint8_t* slab = c->sorted_slab.p;
@@ -1763,8 +1652,6 @@ int arp_create(int device, arp_ctx** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_grid, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_DEV_WORDS);
     if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_ctr_pinned, sizeof(u64) * (C_COUNT + 1), hipHostMallocDefault);
@@ -1799,7 +1686,6 @@ void arp_destroy(arp_ctx* c) {
     c->bag_pack.release();
     c->sort_key[0].release(); c->sort_key[1].release(); c->sort_idx[0].release(); c->sort_idx[1].release();
     c->sort_table.release(); c->sort_total.release(); c->sorted_slab.release();
-    c->qfill.release(); c->den_i.release(); c->den_j.release(); c->den_d.release(); c->den_s.release(); c->den_ct.release();
     if (c->bag_stage) (void)hipHostFree(c->bag_stage);
     c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release(); c->longest_bond.release();
     c->rec_home.release(); c->rec_face[0].release(); c->rec_face[1].release(); c->sh_scan.release(); c->sh_src.release();
@@ -1812,8 +1698,6 @@ void arp_destroy(arp_ctx* c) {
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
     if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
-    if (c->ev_grid) (void)hipEventDestroy(c->ev_grid);
-    if (c->ev_early) (void)hipEventDestroy(c->ev_early);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -2757,9 +2641,8 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     CHK(zero_counter(c, C_STAT_MCAND, 2 * STAT_SLOTS));
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
-                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0,
-                           ChunkQueue{c->pairs.p, (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), nullptr, nullptr, nullptr, 0u, 0u, 0},
-                           c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
+                           c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
+                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));
@@ -2843,13 +2726,12 @@ int arp_atom_contacts_fetch(arp_ctx* c, int64_t cap, int32_t* out_i, int32_t* ou
     // in the canonical (i, j) order once arp_atom_contacts_sort has run on them, in the order of the pair list before
     const uint8_t* sl = c->sorted_slab.p;
     const bool srt = c->contacts_sorted;
-    if (!srt) CHK(ensure_dense(c));      // (the segments of the device's pair list, back to back)
     if (k) {
-        if (out_i) HIPCHK(c, hipMemcpyAsync(out_i, srt ? (const void*)(sl + c->srt_off[0]) : (const void*)c->den_i.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (out_j) HIPCHK(c, hipMemcpyAsync(out_j, srt ? (const void*)(sl + c->srt_off[1]) : (const void*)c->den_j.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, srt ? (const void*)(sl + c->srt_off[2]) : (const void*)c->den_d.p, k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        if (out_sift) HIPCHK(c, hipMemcpyAsync(out_sift, srt ? (const void*)(sl + c->srt_off[3]) : (const void*)c->den_s.p, k * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
-        if (out_ctype) HIPCHK(c, hipMemcpyAsync(out_ctype, srt ? (const void*)(sl + c->srt_off[4]) : (const void*)c->den_ct.p, k * sizeof(uint8_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_i) HIPCHK(c, hipMemcpyAsync(out_i, srt ? (const void*)(sl + c->srt_off[0]) : (const void*)c->out_i.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_j) HIPCHK(c, hipMemcpyAsync(out_j, srt ? (const void*)(sl + c->srt_off[1]) : (const void*)c->out_j.p, k * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_dist) HIPCHK(c, hipMemcpyAsync(out_dist, srt ? (const void*)(sl + c->srt_off[2]) : (const void*)c->out_d.p, k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (out_sift) HIPCHK(c, hipMemcpyAsync(out_sift, srt ? (const void*)(sl + c->srt_off[3]) : (const void*)c->out_s.p, k * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+        if (out_ctype) HIPCHK(c, hipMemcpyAsync(out_ctype, srt ? (const void*)(sl + c->srt_off[4]) : (const void*)c->out_ct.p, k * sizeof(uint8_t), hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
@@ -2927,9 +2809,8 @@ int arp_atom_accumulators(arp_ctx* c, uint16_t* out_sift4, int32_t* out_counts8)
     HIPCHK(c, hipMemsetAsync(acc_s.p, 0, 2 * n * sizeof(unsigned int), c->stream));
     HIPCHK(c, hipMemsetAsync(acc_c.p, 0, 8 * n * sizeof(int), c->stream));
     if (c->n_contacts > 0) {
-        CHK(ensure_dense(c));
         hipLaunchKernelGGL(k_accumulate, dim3(nblocks(c->n_contacts, 256, 4096)), dim3(256), 0, c->stream, (long long)c->n_contacts,
-                           c->den_i.p, c->den_j.p, c->den_s.p, c->den_ct.p, acc_s.p, acc_c.p);
+                           c->out_i.p, c->out_j.p, c->out_s.p, c->out_ct.p, acc_s.p, acc_c.p);
         CHK(check_launch(c, "k_accumulate"));
     }
     std::vector<unsigned int> hs(2 * n);
@@ -2965,11 +2846,10 @@ int arp_atom_integer_sifts(arp_ctx* c, uint8_t* out_isift) {
     HIPCHK(c, hipMemsetAsync(last_sift.p, 0, n4 * sizeof(unsigned int), c->stream));
     if (c->n_contacts > 0) {
         const dim3 grid(nblocks(c->n_contacts, 256, 4096));
-        CHK(ensure_dense(c));
-        hipLaunchKernelGGL(k_isift_last, grid, dim3(256), 0, c->stream, (long long)c->n_contacts, c->den_i.p, c->den_j.p,
-                           c->den_ct.p, last_rank.p);
-        hipLaunchKernelGGL(k_isift_fill, grid, dim3(256), 0, c->stream, (long long)c->n_contacts, c->den_i.p, c->den_j.p,
-                           c->den_s.p, c->den_ct.p, last_rank.p, before.p, last_sift.p);
+        hipLaunchKernelGGL(k_isift_last, grid, dim3(256), 0, c->stream, (long long)c->n_contacts, c->out_i.p, c->out_j.p,
+                           c->out_ct.p, last_rank.p);
+        hipLaunchKernelGGL(k_isift_fill, grid, dim3(256), 0, c->stream, (long long)c->n_contacts, c->out_i.p, c->out_j.p,
+                           c->out_s.p, c->out_ct.p, last_rank.p, before.p, last_sift.p);
         CHK(check_launch(c, "k_isift_fill"));
     }
     hipLaunchKernelGGL(k_isift_compose, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, (long long)n4, before.p,
@@ -3218,8 +3098,6 @@ int run_pass_wait(arp_ctx* c, int64_t counts[5]) {
         const auto t1 = std::chrono::steady_clock::now();
         CHK(collect_counters(c));
         c->ctr_zero_ok = true;
-        c->qfill_clean = c->pass_zeroes_fill;      // (the publishing block returned the fill counters of the chunk queue to zero)
-        CHK(join_early(c));                        // (whatever follows on the main stream follows the early sift launch as well)
         c->host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         ++c->host_passes;
         collect_events(c);
@@ -3320,7 +3198,6 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * 5 * CTR_LINE, c->stream));                      // scalars, the four bags
         HIPCHK(c, hipMemset2DAsync(c->d_ctr + ctr_dev(C_STAT_CAND), sizeof(u64) * CTR_LINE, 0, 2 * sizeof(u64), STAT_SLOTS, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(C_SEG_PAIRS), 0, sizeof(u64) * PAIR_SEGS * CTR_LINE, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_ctr + ctr_dev(C_SEG_TAIL), 0, sizeof(u64) * (PAIR_SEGS * QSUB + 1) * CTR_LINE, c->stream));
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; } } unclean{c};
         if (c->nring + c->namide > 0)
@@ -3708,6 +3585,27 @@ int arp_shard_reduce_residue_sets(arp_ctx* c) {
     NCCLCHK(c, rccl().AllReduce(c->res_sel.p, c->res_sel.p, nb, ncclUint8, ncclMax, c->comm, c->stream));
     return ARP_OK;
 }
+
+#ifdef ARP_SEARCH_TRACE
+// developer builds only: where k_search<MODE_CONTACTS> leaves its per-wave trace (device pointer to 4 u64 per wave, 0 = off)
+int arp_debug_search_trace(arp_ctx* c, uint64_t device_ptr) {
+    if (!c) return ARP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long* p = (unsigned long long*)(uintptr_t)device_ptr;
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_search_trace), &p, sizeof(p)));
+    return ARP_OK;
+}
+int arp_debug_alloc(uint64_t bytes, uint64_t* device_ptr) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return ARP_E_HIP;
+    (void)hipMemset(p, 0, bytes);
+    *device_ptr = (uint64_t)(uintptr_t)p;
+    return ARP_OK;
+}
+int arp_debug_read(uint64_t device_ptr, void* host, uint64_t bytes) {
+    return hipMemcpy(host, (const void*)(uintptr_t)device_ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess ? ARP_OK : ARP_E_HIP;
+}
+#endif
 
 int arp_set_grid_reuse(arp_ctx* c, int enabled) {
     if (!c) return ARP_E_ARG;

@@ -58,14 +58,11 @@ enum {
     // (two sets of 8 group tickets + 1 kernel ticket: the sift kernel and the ring / amide kernel end a pass together)
     C_TICKET_GROUP = C_TAIL + 16, C_TICKET_KERNEL = C_TAIL + 24, C_TICKET_SET = 16, C_KERNELS_DONE = C_TAIL + 15,
     C_PLIST = C_TAIL + 8,   // 4 slots: entries of the static ring / amide candidate lists (copied from their own counters each pass)
-    // the chunk queue between k_search and the sift kernels (ChunkQueue): per segment the consumers' ticket counter, and the
-    // number of search blocks that have finished
-    C_SEG_TAIL = C_TAIL + 48, C_SEARCH_DONE = C_TAIL + 48 + 32,      // (PAIR_SEGS * QSUB ticket counters)
-    // logical words: the last block of a pass hands them to the host with returning atomics (pass_end)
-    C_COUNT = C_TAIL + 48 + 40,
+    // 128 logical words: the last block of a pass hands them to the host with ONE round of returning atomics per thread (pass_end)
+    C_COUNT = C_TAIL + 48,
     // device lines: 0 scalars | 1-4 the four bags | 5-20 statistics slots | 21-28 pair-list heads | 29 list entries |
-    // 30 kernels done (+ parking for the unused logical words) | 31-39, 40-48 the two ticket sets | 49-80 queue tails | 81 search blocks done
-    C_DEV_LINES = 82, C_DEV_WORDS = C_DEV_LINES * CTR_LINE
+    // 30 kernels done (+ parking for the unused logical words) | 31-39, 40-48 the two ticket sets
+    C_DEV_LINES = 49, C_DEV_WORDS = C_DEV_LINES * CTR_LINE
 };
 __host__ __device__ constexpr int ctr_dev(int i) {
     if (i >= C_AP && i <= C_GP) return (1 + (i - C_AP)) * CTR_LINE;
@@ -74,10 +71,7 @@ __host__ __device__ constexpr int ctr_dev(int i) {
     if (i < C_TAIL + 8) return (21 + (i - C_TAIL)) * CTR_LINE;
     if (i >= C_PLIST && i < C_PLIST + 4) return 29 * CTR_LINE + (i - C_PLIST);
     if (i == C_KERNELS_DONE) return 30 * CTR_LINE;
-    if (i >= C_SEG_TAIL && i < C_SEG_TAIL + 32) return (49 + (i - C_SEG_TAIL)) * CTR_LINE;
-    if (i == C_SEARCH_DONE) return 81 * CTR_LINE;
-    if (i > C_SEARCH_DONE) return 81 * CTR_LINE + 1 + (i - C_SEARCH_DONE);   // unused
-    if (i >= C_TICKET_GROUP && i < C_SEG_TAIL && (i - C_TICKET_GROUP) % C_TICKET_SET <= 8)
+    if (i >= C_TICKET_GROUP && i < C_COUNT && (i - C_TICKET_GROUP) % C_TICKET_SET <= 8)
         return (31 + 9 * ((i - C_TICKET_GROUP) / C_TICKET_SET) + (i - C_TICKET_GROUP) % C_TICKET_SET) * CTR_LINE;
     return 30 * CTR_LINE + 1 + i % 15;   // logical words nothing uses
 }
@@ -660,9 +654,6 @@ struct PublishArgs {
     u64* host;       // pinned mirror, C_COUNT + 1 words (the last one = completion word)
     int expected;    // kernels that end this pass (0: off)
     u64 seq;         // value of the completion word for this pass
-    unsigned* fill;  // fill counters of the chunk queue (ChunkQueue): PAIR_SEGS segments of fcap; the publisher returns the used ones to zero
-    unsigned fcap;
-    unsigned chunk;  // pairs per chunk
 };
 // Tickets are hierarchical — one counter per (blockIdx % 8), i.e. per XCD as the dispatcher places blocks, then one for
 // the eight groups — because atomics on one LINE run at ~90 per microsecond: 2500 blocks on one word were a 15 us tail, and
@@ -692,21 +683,11 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     // the kernel has just written (config 3: 19 MB across the eight L2s; the fence was 4 - 5 us of the pass).  What the flag
     // needs is that the counter stores have left this CU (vmcnt(0) of every wave, then the barrier); writes to the host
     // arrive in the order they were sent.
-    __shared__ u64 s_heads[PAIR_SEGS];
-    for (int i = threadIdx.x; i < (int)C_COUNT; i += blockDim.x) {
-        const u64 v = atomicExch(pa.ctr + ctr_dev(i), 0ull);
-        if (i >= C_SEG_PAIRS && i < C_SEG_PAIRS + PAIR_SEGS) s_heads[i - C_SEG_PAIRS] = v;
-        __hip_atomic_store(pa.host + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    for (int i = threadIdx.x; i < (int)C_COUNT; i += blockDim.x)
+        __hip_atomic_store(pa.host + i, atomicExch(pa.ctr + ctr_dev(i), 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(pa.host + C_COUNT, pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // the chunk queue of the pass is empty: its fill counters go back to zero for the next pass (after the host has its word)
-    if (pa.fill)
-        for (int x = 0; x < PAIR_SEGS; ++x) {
-            const u64 used = min((s_heads[x] + pa.chunk - 1) / pa.chunk, (u64)pa.fcap);
-            for (u64 k = threadIdx.x; k < used; k += blockDim.x) pa.fill[(size_t)x * pa.fcap + k] = 0u;
-        }
 }
 
 // ---- neighbour search ---------------------------------------------------------------
@@ -757,67 +738,30 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
     return s;
 }
 
-// ---- the chunk queue between the contact search and the per-pair kernels -------------------------------------------
-// k_search<MODE_CONTACTS> hands its pairs over WHILE IT RUNS.  The pair list is PAIR_SEGS segments (one per XCD: the segment
-// of a block is the XCD it runs on, HW_REG_XCC_ID — blockIdx % 8 is that only up to a rotation that changes from launch to
-// launch, tools/micro/xcc_queue.hip), each cut into CHUNKS of QCHUNK consecutive pairs.  A flush takes its place in the
-// segment with one returning atomic on the segment's head (as before), writes its pairs, waits for them (vmcnt) and adds,
-// to the fill counter of every chunk it has written into, the number of pairs it put there; a block that has finished
-// bumps `done`.  Consumer waves (sift_body) take chunk tickets from the segment's tail counter; chunk t is ready when
-// its fill counter says QCHUNK — or, once every search block has reported (done == blocks of the search launch: the heads
-// are final), when it holds all that is left of the segment; a ticket beyond the final head means the segment is exhausted.
-// Pairs and fill counters travel as relaxed agent-scope 64-bit stores / loads and memory-side atomics (write-through past
-// the XCD's L2, sc1): a consumer on ANY XCD — a kernel on a second stream that runs beside the search — sees the pairs of a
-// chunk whose count it has seen, without fences (the same micro-benchmark: 3e8 words, none stale).  A kernel launched after
-// the search (`final`) needs neither counters nor waiting: ticket -> position.  The fill counters are returned to zero by the
-// block that publishes the pass (pass_end).
-// Ticket counters are returning atomics, and those of different blocks serialise per 128-byte line at ~90 per microsecond
-// (tools/micro/atomic_lines.hip): the ~10 k chunks of a 100 k-atom pass on eight counters would spend most of the kernel
-// queueing for tickets.  Every segment therefore has QSUB ticket counters, each on a line of its own: counter q hands out
-// the chunks t * QSUB + q of its segment.
-#ifndef QCHUNK
-#define QCHUNK 128
+// the XCD a wave runs on (HW_REG_XCC_ID[3:0]).  blockIdx % 8 is that only up to a rotation that differs from launch to launch
+// (tools/micro/xcc_queue.hip: block b of a 768-block launch ran on XCD (b + 7) % 8)
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
+
+#ifdef ARP_SEARCH_TRACE
+// developer builds only (tools/search_trace.py): per block of k_search<MODE_CONTACTS> {start, end of the cell loops, end} in
+// s_memrealtime ticks (100 MHz), the XCD and the hardware id of the block's first wave
+__device__ unsigned long long* g_search_trace = nullptr;
 #endif
-#define QSUB 4
-struct ChunkQueue {
-    int2* pairs;            // PAIR_SEGS segments of cap pairs
-    u64 cap;
-    u64* heads;             // per segment (stride CTR_LINE): pairs written / reserved
-    u64* tails;             // PAIR_SEGS * QSUB ticket counters (stride CTR_LINE): counter s * QSUB + q hands out the chunks t * QSUB + q of segment s
-    u64* done;              // search blocks that have finished
-    unsigned* fill;         // PAIR_SEGS segments of fcap counters: pairs of chunk t that have been written
-    unsigned fcap;
-    unsigned producers;     // blocks of the search launch
-    int final;              // consumers: the search has finished (stream order): nothing to wait for
-};
-__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }   // HW_REG_XCC_ID[3:0]: the XCD of this wave
-__device__ __forceinline__ void q_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 q_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned q_load32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 pack_pair(int2 v) { return (u64)(uint32_t)v.x | ((u64)(uint32_t)v.y << 32); }
-// the pairs [base, base + n) of a segment have been written: tell their chunks (lane k: the k-th chunk the range touches)
-__device__ __forceinline__ void q_commit(unsigned* seg_fill, unsigned fcap, u64 cap, u64 base, int n, int lane) {
-    if (n <= 0) return;
-    const u64 c0 = base / QCHUNK, c1 = (min(base + (u64)n, cap) + QCHUNK - 1) / QCHUNK;      // (pairs beyond the capacity were not written)
-    for (u64 c = c0 + lane; c < c1; c += 64) {
-        const u64 lo = max(base, c * QCHUNK), hi = min(min(base + (u64)n, cap), (c + 1) * QCHUNK);
-        if (c < fcap && hi > lo) atomicAdd(seg_fill + c, (unsigned)(hi - lo));
-    }
-}
 
 template <int MODE>
 __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
-                                                               int include_seq_adj, int count_owned, ChunkQueue Q,
+                                                               int include_seq_adj, int count_owned, int2* __restrict__ pairs,
+                                                               unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus, GroupMasks gm, const int* __restrict__ cell_of_pos) {
-    int2* __restrict__ const pairs = Q.pairs;
-    const unsigned long long cap = Q.cap;
-    u64* __restrict__ const ctr_pairs = Q.heads;
-    constexpr bool QUEUE = MODE == MODE_CONTACTS;     // (arp_search_all's raw pair list is read after the launch: plain stores, no entries)
     // ring / amide sets of _make_selection (I:1433-1437) from the residue tags the grid build of this pass left: every thread
     // of the launch takes at most a few (nothing to do when gm is empty)
+#ifdef ARP_SEARCH_TRACE
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_loops = 0;
+#endif
     group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     __shared__ int2 q[MODE == MODE_MARK ? 1 : SEARCH_WAVES][QCAP];   // (the expansion search queues nothing)
     __shared__ float4 s_hx[SEARCH_WAVES][HOME_BLOCK];   // home atoms of the moment: x, y, z, meta
@@ -836,76 +780,88 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     const int cells_per_block = (g.ncell + nb - 1) / nb;
     int blk_begin = vb * cells_per_block;
     int c_end = min((vb + 1) * cells_per_block, g.ncell);
+    int h_lo = 0, h_hi = INT_MAX;      // positions of the cell-sorted array whose atoms this block takes as HOME atoms
     if (cell_of_pos) {
-        // Sparse grids — a protein in its bounding box, the selection_plus of a ligand inside a large structure, a batch with its
-        // gaps — put their atoms into a fraction of the cells, and equal runs of CELLS gave a few blocks all the work (a 96 k-atom
-        // chain: 280 us where uniform atoms of the same number take 28; a ligand's binding site in it: 188 us for 3.5e5 tests).
-        // Here every block takes an equal run of ATOMS of the cell-sorted array, i.e. the cells whose first atom lies in
-        // [p0, p1): the cell of an atom position is written by the grid build (three dependent loads before the first cell).
+        // Sparse or clumped grids — a protein in its bounding box, the selection_plus of a ligand inside a large structure, a
+        // batch with its gaps, a chain folded onto itself — put their atoms into a fraction of the cells, and equal runs of
+        // CELLS gave a few blocks all the work (a 96 k-atom chain: 280 us where uniform atoms of the same number take 28).
+        // Here every block takes an equal run [p0, p1) of the cell-sorted ATOMS as its home atoms, wherever the cell
+        // boundaries are: a cell that straddles p0 or p1 is shared with the neighbouring block, each taking its own home atoms
+        // against the cell's whole candidate set (the cell of an atom position is written by the grid build: two dependent
+        // load rounds before the first cell).
         const long long T = start[g.ncell];
         const int p0 = (int)((long long)vb * T / nb), p1 = (int)((long long)(vb + 1) * T / nb);
-        auto first_cell_from = [&](int p) -> int {       // the first cell whose atoms begin at or after position p
-            if (p >= (int)T) return g.ncell;
-            const int c = cell_of_pos[p];
-            return (start[c] < p) ? c + 1 : c;
-        };
-        blk_begin = (vb == 0) ? 0 : first_cell_from(p0);
-        c_end = (vb == nb - 1) ? g.ncell : first_cell_from(p1);
+        if (p1 > p0) {
+            blk_begin = cell_of_pos[p0];
+            c_end = cell_of_pos[p1 - 1] + 1;
+            h_lo = p0; h_hi = p1;
+        } else {
+            blk_begin = c_end = 0;
+        }
     }
 
     int qn = 0;
     unsigned int n_cand = 0, n_acc = 0;   // per lane; reduced over the wave at the end
     const float r2_lo = (float)(r2 * (1.0 - 1e-5)), r2_hi = (float)(r2 * (1.0 + 1e-5));
 
-    // output segment of this block (cap = capacity of ONE segment): the XCD it runs on
-    const int seg = QUEUE ? xcc_id() : 0;
+    // output segment of this block (cap = capacity of ONE segment)
+    // (the XCD the block runs on: the sift blocks of that XCD consume the segment, and the records its pairs point at are in that L2)
+    const int seg = (MODE == MODE_CONTACTS) ? xcc_id() : 0;
     u64* const seg_ctr = ctr_pairs + seg * CTR_LINE;
     int2* const seg_pairs = pairs + (size_t)seg * cap;
-    unsigned* const seg_fill = QUEUE ? Q.fill + (size_t)seg * Q.fcap : nullptr;
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(seg_ctr, (unsigned long long)qn);
         base = __shfl(base, 0);
-        if (QUEUE) {
-            for (int k = lane; k < qn; k += 64)
-                if (base + k < cap) q_store(reinterpret_cast<u64*>(seg_pairs + base + k), pack_pair(q[w][k]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pairs have left (write-through) before their chunks hear of them
-            q_commit(seg_fill, Q.fcap, cap, base, qn, lane);
-        } else {
-            for (int k = lane; k < qn; k += 64)
-                if (base + k < cap) seg_pairs[base + k] = q[w][k];
-        }
+        for (int k = lane; k < qn; k += 64)
+            if (base + k < cap) seg_pairs[base + k] = q[w][k];
         __builtin_amdgcn_wave_barrier();
         qn = 0;
     };
 
-    // The cells of a block are looked at 64 per wave and step (lane l: cell win + l * SEARCH_WAVES + w — the waves of a block
-    // interleave over its run of cells): ONE load round tells which of them hold atoms, and only those are visited.  A
-    // protein in its bounding box, or a batch of structures with the gaps between them (arp_set_batch), leaves most cells
-    // empty: 88 % for 64 stand-in structures, where skipping them one by one was most of the kernel.
-    // The occupied cells are then taken eight at a time: lane 8 * ci + r fetches the bounds of range r of cell ci
-    // (range 0 = home pencil [own cell, cx+1], ranges 1..4 = the forward pencils [cx-1, cx+1], r = 5: end of
-    // the home cell), so the start table costs ONE load latency per eight cells instead of two per cell.
+    // The waves of a block CLAIM its work one HOME BLOCK at a time (a cell's home atoms in blocks of 32: nearly always the
+    // whole cell).  A cell's work goes with the square of its atom count, and with a fixed three cells per wave the slowest wave
+    // of a block had twice the mean; a cell with hundreds of atoms (a clump: the 96 k-atom chain of tools/small_bench.py) was a
+    // serial chain on one wave, whatever the other waves did.  What made claiming dear is one start-table round trip per
+    // claim; here the block looks at its cells together:
+    //   A  runs of more than 64 cells only, 512 cells per step, one per thread: which hold atoms (ONE load round) ->
+    //      compacted list in LDS.  A protein in its bounding box, or a batch of structures with the gaps between them
+    //      (arp_set_batch), leaves most cells empty;
+    //   B  64 cells at a time, thread 8 * i + r: the bounds of range r of cell i (range 0 = home pencil [own cell, cx + 1],
+    //      ranges 1..4 = the forward pencils [cx - 1, cx + 1], r = 5: end of the home cell) -> LDS; every wave then
+    //      numbers the home blocks of the 64 cells (lane = cell, a prefix sum over the lanes);
+    //   C  every wave takes the next home block with an LDS atomic until none is left.
+    __shared__ int s_occ[64 * SEARCH_WAVES];
+    __shared__ int s_info[8 * SEARCH_WAVES][12];      // per cell: start of ranges 0..4, end of the home cell, -, length of ranges 0..4
+    __shared__ int s_nocc, s_next;
+    __shared__ int s_upre[65];
+    constexpr int CLAIM_CELLS = 8 * SEARCH_WAVES;
+    constexpr int CAND_SPAN = 1024;      // candidates of a cell one unit tests its home block against (a multiple of 128)
     for (int win = blk_begin; win < c_end; win += 64 * SEARCH_WAVES) {
-     const int wcell = win + lane * SEARCH_WAVES + w;
-     unsigned long long occ = __ballot(wcell < c_end && start[wcell + 1] != start[wcell]);
-     while (occ) {
-      int my_js = 0, my_len = 0;
-      int ng = 0;
+     const bool listed = c_end - win > CLAIM_CELLS;      // (a short run: every cell of it is looked at, stage A would be a round trip for nothing)
+     int nocc = min(c_end - win, CLAIM_CELLS);
+     if (listed) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_nocc = 0;
+        __syncthreads();
+        const int cell = win + (int)threadIdx.x;
+        const bool oc = cell < c_end && start[cell + 1] != start[cell];
+        const unsigned long long m = __ballot(oc);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_nocc, __popcll(m));
+        base = __shfl(base, 0);
+        if (oc) s_occ[base + __popcll(m & ((1ull << lane) - 1ull))] = cell;
+        __syncthreads();
+        nocc = s_nocc;
+     }
+     for (int k0 = 0; k0 < nocc; k0 += CLAIM_CELLS) {
+      const int nk = min(CLAIM_CELLS, nocc - k0);
       {
-        int mycell = -1;
-#pragma unroll
-        for (int ci = 0; ci < 8; ++ci) {
-            if (occ) {
-                const int l = __ffsll((long long)occ) - 1;
-                occ &= occ - 1ull;
-                if ((lane >> 3) == ci) mycell = win + l * SEARCH_WAVES + w;
-                ng = ci + 1;
-            }
-        }
-        const int r = lane & 7;
-        if (mycell >= 0 && r < 6) {
+        const int i = (int)threadIdx.x >> 3, r = (int)threadIdx.x & 7;
+        if (i < nk && r < 6) {
+            const int mycell = listed ? s_occ[k0 + i] : win + i;
+            int my_js = 0, my_len = 0;
             const int cz = mycell / (g.nx * g.ny);
             const int rem = mycell - cz * g.nx * g.ny;
             const int cy = rem / g.nx;
@@ -922,23 +878,54 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                 my_js = start[rowbase + xlo];
                 my_len = start[rowbase + xhi + 1] - my_js;
             }
+            s_info[i][r] = my_js;
+            if (r < 5) s_info[i][7 + r] = my_len;
         }
+        if (threadIdx.x == 0) s_next = 0;
       }
+      __syncthreads();
+      // home blocks of cell `lane`, and how many there are in the cells before it (first wave; kept in LDS: the kernel has no
+      // vector register to spare for it)
+      if (w == 0) {
+        // (a unit = one home block against at most CAND_SPAN candidates of its cell: a clump of hundreds of atoms with thousands of
+        // candidates is many units, for many waves)
+        int nhb = (lane < nk) ? max(min(s_info[lane][5], h_hi) - max(s_info[lane][0], h_lo) + HOME_BLOCK - 1, 0) / HOME_BLOCK : 0;
+        if (lane < nk) nhb *= max((s_info[lane][7] + s_info[lane][8] + s_info[lane][9] + s_info[lane][10] + s_info[lane][11] + CAND_SPAN - 1) / CAND_SPAN, 1);
+        int incl = nhb;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        s_upre[lane] = incl - nhb;
+        if (lane == 63) s_upre[64] = incl;
+      }
+      __syncthreads();
+      const int n_units = __builtin_amdgcn_readfirstlane(s_upre[64]);
 #pragma unroll 1
-      for (int ci = 0; ci < ng; ++ci) {
-        const int hs = __builtin_amdgcn_readlane(my_js, ci * 8);
-        const int he = __builtin_amdgcn_readlane(my_js, ci * 8 + 5);
-        if (hs == he) continue;
-        const int js0 = hs, js1 = __builtin_amdgcn_readlane(my_js, ci * 8 + 1),
-                  js2 = __builtin_amdgcn_readlane(my_js, ci * 8 + 2), js3 = __builtin_amdgcn_readlane(my_js, ci * 8 + 3),
-                  js4 = __builtin_amdgcn_readlane(my_js, ci * 8 + 4);
-        const int o1 = __builtin_amdgcn_readlane(my_len, ci * 8);      // candidates [0, o1) come from range 0
-        const int o2 = o1 + __builtin_amdgcn_readlane(my_len, ci * 8 + 1);
-        const int o3 = o2 + __builtin_amdgcn_readlane(my_len, ci * 8 + 2);
-        const int o4 = o3 + __builtin_amdgcn_readlane(my_len, ci * 8 + 3);
-        const int total = o4 + __builtin_amdgcn_readlane(my_len, ci * 8 + 4);
-#pragma unroll 1
-        for (int hb = hs; hb < he; hb += HOME_BLOCK) {  // home atoms, 32 at a time: one bit each in the per-lane hit masks
+      for (;;) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(&s_next, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= n_units) break;
+        const int ci = __popcll(__ballot(lane < nk && s_upre[lane] <= u)) - 1;      // the last cell whose first home block is not after u
+        const int uu = u - __builtin_amdgcn_readfirstlane(s_upre[ci]);
+        const int4 ia = *reinterpret_cast<const int4*>(&s_info[ci][0]), ib = *reinterpret_cast<const int4*>(&s_info[ci][4]),
+                   ic = *reinterpret_cast<const int4*>(&s_info[ci][8]);
+        const int hs = __builtin_amdgcn_readfirstlane(ia.x);
+        const int he = min(__builtin_amdgcn_readfirstlane(ib.y), h_hi);      // (home atoms of this block only)
+        const int js0 = hs, js1 = __builtin_amdgcn_readfirstlane(ia.y), js2 = __builtin_amdgcn_readfirstlane(ia.z),
+                  js3 = __builtin_amdgcn_readfirstlane(ia.w), js4 = __builtin_amdgcn_readfirstlane(ib.x);
+        const int o1 = __builtin_amdgcn_readfirstlane(ib.w);      // candidates [0, o1) come from range 0
+        const int o2 = o1 + __builtin_amdgcn_readfirstlane(ic.x);
+        const int o3 = o2 + __builtin_amdgcn_readfirstlane(ic.y);
+        const int o4 = o3 + __builtin_amdgcn_readfirstlane(ic.z);
+        const int total = o4 + __builtin_amdgcn_readfirstlane(ic.w);
+        const int nks = max((total + CAND_SPAN - 1) / CAND_SPAN, 1);      // candidate spans of this cell (1 unless it is a clump)
+        const int hbi = (nks == 1) ? uu : uu / nks;
+        const int kb_begin = (uu - hbi * nks) * CAND_SPAN, kb_end = min(total, kb_begin + CAND_SPAN);
+        {   // home atoms [hb, hb + 32) of the cell: one bit each in the per-lane hit masks
+            const int hb = max(hs, h_lo) + HOME_BLOCK * hbi;
             const int hcount = min(HOME_BLOCK, he - hb);
             const bool hvalid = lane < hcount;
             const int hpos = min(hb + lane, he - 1);   // (clamped: no branch around the loads; lanes >= hcount are never read)
@@ -954,7 +941,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
             const uint32_t m_hvalid = (uint32_t)__ballot(hvalid);
             const uint32_t m_selh = (MODE == MODE_MARK) ? (uint32_t)__ballot(hvalid && (__float_as_uint(hreg.w) & M_SEL)) : 0u;
 #pragma unroll 1
-            for (int kb = 0; kb < total; kb += 128) {  // the ~87 candidates of this cell, two per lane
+            for (int kb = kb_begin; kb < kb_end; kb += 128) {  // the ~87 candidates of this cell, two per lane
                 // second candidate of the lane in REVERSE order: the candidates most likely to hit come first in the list (home
                 // pencil, then the pencils of the same layer), and a lane holding two of those walks twice as many hits in
                 // stage 2 as the rest — whose iteration count is the fullest lane's.  Lane l pairs candidate l with 127 - l.
@@ -1156,8 +1143,12 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
             }
         }
       }
+      __syncthreads();      // (before the cell bounds and the claim counter are written again)
      }
     }
+#ifdef ARP_SEARCH_TRACE
+    t_loops = __builtin_amdgcn_s_memrealtime();
+#endif
     // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
     // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
     __shared__ int s_qn[SEARCH_WAVES];
@@ -1165,13 +1156,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     const u64 w_cand = wave_sum_u32(n_cand), w_acc = wave_sum_u32(n_acc);
     if (lane == 0) { s_qn[w] = qn; s_cand[w] = w_cand; s_acc[w] = w_acc; }
     __syncthreads();
-    __shared__ int s_tot;
     if (threadIdx.x == 0) {
         int tot = 0;
         u64 tc = 0, ta = 0;
         for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
         s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot) : 0;
-        s_tot = tot;
         const int slot = blockIdx.x & (STAT_SLOTS - 1);
         atomicAdd(ctr_cand + slot * CTR_LINE, tc);
         atomicAdd(ctr_acc + slot * CTR_LINE, ta);
@@ -1180,24 +1169,16 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     if (MODE != MODE_MARK && qn > 0) {
         u64 base = s_base;
         for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
-        if (QUEUE) {
-            for (int k = lane; k < qn; k += 64)
-                if (base + k < cap) q_store(reinterpret_cast<u64*>(seg_pairs + base + k), pack_pair(q[w][k]));
-        } else {
-            for (int k = lane; k < qn; k += 64)
-                if (base + k < cap) seg_pairs[base + k] = q[w][k];
-        }
+        for (int k = lane; k < qn; k += 64)
+            if (base + k < cap) seg_pairs[base + k] = q[w][k];
     }
-    if (QUEUE) {
-        // the block's pairs have left (every wave waits for its own), then their chunks hear of them, then the block reports
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (w == 0) {
-            q_commit(seg_fill, Q.fcap, cap, s_base, s_tot, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) atomicAdd(Q.done, 1ull);
-        }
+#ifdef ARP_SEARCH_TRACE
+    if (MODE == MODE_CONTACTS && g_search_trace && lane == 0) {
+        unsigned long long* t = g_search_trace + ((size_t)blockIdx.x * SEARCH_WAVES + w) * 4;
+        t[0] = t_begin; t[1] = t_loops; t[2] = __builtin_amdgcn_s_memrealtime();
+        t[3] = (unsigned long long)xcc_id() | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | ((unsigned long long)w_cand << 40);   // HW_REG_HW_ID
     }
+#endif
 }
 
 // ---- per-pair SIFt --------------------------------------------------------------------
@@ -1367,7 +1348,9 @@ __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftR
 
 #define SIFT_TASKQ 128
 struct SiftArgs {
-    ChunkQueue Q;            // the pair list and its chunk queue (k_search): the output index of pair p of segment x is x * cap + p
+    const int2* pairs;
+    const u64* npairs_ptr;
+    u64 cap;
     const SiftRec* s_rec;
     const int4* s_b4;       // first bonded neighbours of the atom at each sorted position (k_prepare_static)
     SiftSide sd;
@@ -1395,13 +1378,15 @@ __device__ __forceinline__ void put_record(T v, T* p) {
 struct SiftShared {
     uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
     double2 tab[RAD_TABLE];      // the structure's distinct {vdw, cov} pairs
-    unsigned qheads[PAIR_SEGS * QSUB];   // final head of the segment of every ticket counter of the chunk queue (once the search has finished)
     float4 thr[256];             // for the first 16 of them, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), reach of the second}
 };
+// vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
+// vblock % 8 is still the XCD the dispatcher put the block on)
 template <int STREAM>
-__device__ __forceinline__ void sift_body(const SiftArgs& A, SiftShared* sh) {
-    const ChunkQueue Q = A.Q;
-    const u64 cap = Q.cap;
+__device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgrid, SiftShared* sh) {
+    const int2* __restrict__ pairs = A.pairs;
+    const u64* __restrict__ npairs_ptr = A.npairs_ptr;
+    const u64 cap = A.cap;
     const SiftRec* __restrict__ s_rec = A.s_rec;
     const SiftSide sd = A.sd;
     const int* __restrict__ bond_idx = A.bond_idx;
@@ -1422,22 +1407,24 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, SiftShared* sh) {
     //   2 is_weak_hbond(end, bgn)   3 is_weak_hbond(bgn, end)   4 / 5 is_halogen_weak_hbond  (I:857-886)
     // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
     // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
+    // (everything the first batch needs is asked for before the barrier: the queue heads, the first pairs and the radius table
+    // travel together instead of one dependent round trip after the other)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // Work comes in CHUNKS of QCHUNK pairs from the queue k_search fills (ChunkQueue): a wave takes a ticket of its XCD's
-    // segment — the pairs written by the search blocks that ran on the same XCD, whose atom records are in that XCD's L2 —,
-    // waits for the chunk to fill up if the search is still running (this kernel may have been launched beside it), and
-    // evaluates its pairs 64 at a time; when the segment is exhausted it helps with the next one.  The ticket of the next
-    // chunk is asked for — and, in a kernel launched after the search, its first pairs are fetched — while the current chunk
-    // is evaluated (a returning atomic is a round trip to the memory side).  A wave asks for no ticket once the tail
-    // counter has passed the final head: returning atomics of a few thousand leaving waves on one line would be a tail.
+    // The segment fill counts are read on the device: no host round trip between search and sift.
+    // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
+    // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
+    const int sgm = xcc_id();      // (blocks b with the same b % 8 share an XCD, whichever it is: vblock / 8 still numbers the blocks of a segment)
+    u64 heads[PAIR_SEGS];
+#pragma unroll
+    for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_ * CTR_LINE];
     const float longest_bond = sd.longest_bond[0];
     const double h_slack = (double)sd.longest_bond[1] + 1e-4;   // |H - A| >= |D - A| - h_slack for every hydrogen H of D (margin: float32 distance, roundings)
-    // queue of this wave: segment = its XCD, ticket counter by block and wave.  (Positions inside a segment, chunk numbers and
-    // output indices fit 32 bits: enqueue_contacts refuses lists of 2^32 entries.)
-    // (wave-uniform values are forced into scalar registers: the kernel has no vector register to spare)
-    int qid = xcc_id() * QSUB + (int)((blockIdx.x / PAIR_SEGS + (unsigned)__builtin_amdgcn_readfirstlane(w)) % QSUB);
-    unsigned t_raw = 0;
-    if (lane == 0) t_raw = (unsigned)atomicAdd(Q.tails + qid * CTR_LINE, 1ull);
+    const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
+    const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
+    const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
+    // (a pair beyond the end of the segment is read and ignored: the list is padded — see enqueue_contacts — and the count
+    // that says so is still on its way)
+    int2 pr_next = (first + lane < (long long)cap) ? seg_pairs[first + lane] : make_int2(0, 0);
     s_tab[threadIdx.x] = sd.rad_tab[threadIdx.x];   // (blockDim.x == RAD_TABLE)
     {   // the three float32 thresholds of the ladder (I:717-718, 756-773: float64 sums, compared as float32) depend on the two
         // radius pairs only: for the common case — both atoms among the first 16 table entries — they are looked up, not computed
@@ -1445,12 +1432,6 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, SiftShared* sh) {
         const double sv = ra.x + rb_.x;
         sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), reach_float(rb_.x, comp, h_slack));
     }
-    // (lane l < 32: final head of the segment of queue l, once the search has finished)
-    const unsigned ucap = (unsigned)cap;
-    bool fin = Q.final != 0;
-    // (final heads in LDS, one word per ticket counter: every wave that learns that the search has finished writes the same values)
-    auto load_heads = [&]() { if (lane < PAIR_SEGS * QSUB) sh->qheads[lane] = (unsigned)min(q_load(Q.heads + (lane / QSUB) * CTR_LINE), (u64)ucap); };
-    if (fin && w == 0) load_heads();
     __syncthreads();
     int tn = 0;
     auto run_tasks = [&](int first_, int count) {   // stage B on tq[w][first_ .. first_ + count)
@@ -1460,69 +1441,19 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, SiftShared* sh) {
             put_record<STREAM>((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
         }
     };
-    auto load_pair = [&](const int2* seg_pairs, unsigned pos) -> int2 {
-#ifdef Q_PLAIN_PAIRS
-        if (Q.final) return seg_pairs[pos];
-#endif
-        const u64 v = q_load(reinterpret_cast<const u64*>(seg_pairs + pos));
-        return make_int2((int)(uint32_t)v, (int)(uint32_t)(v >> 32));
-    };
-    for (;;) {      // one queue after the other: the wave's own first, then whichever still has chunks nobody has asked for
-      const int x = qid / QSUB;
-      const unsigned sub = (unsigned)(qid % QSUB);
-      const int2* __restrict__ seg_pairs = Q.pairs + (size_t)x * cap;
-      const unsigned* __restrict__ seg_fill = Q.fill + (size_t)x * Q.fcap;
-      u64* const my_tail = Q.tails + qid * CTR_LINE;
-      const unsigned out_base = (unsigned)x * ucap;
-      int2 pr_first = make_int2(0, 0);     // first pairs of the chunk of t_raw, fetched ahead (final heads only)
-      bool have_first = false;
-      for (;;) {
-        const unsigned chunk = (unsigned)__builtin_amdgcn_readfirstlane((int)t_raw) * QSUB + sub;
-        if (chunk >= Q.fcap) break;                   // (beyond the fill table = beyond the capacity: nothing there)
-        const unsigned c_first = chunk * QCHUNK;
-        // ---- how many pairs the chunk holds (waiting for them while the search runs)
-        int c_n = 0;
-        unsigned my_head = 0;
-        if (!fin) {
-            for (unsigned spins = 0;; ++spins) {
-                if ((unsigned)__builtin_amdgcn_readfirstlane((int)q_load32(seg_fill + chunk)) >= (unsigned)QCHUNK) { c_n = QCHUNK; break; }
-                if ((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q_load(Q.done)) >= Q.producers) {       // every search block has reported: heads and fill counters are final
-                    fin = true;
-                    load_heads();
-                    break;
-                }
-                if (spins > (1u << 21)) { atomicExch(err, -2 /* ARP_E_HIP */); fin = true; if (lane < PAIR_SEGS * QSUB) sh->qheads[lane] = 0u; break; }     // (~2 s: a search that never finishes)
-                __builtin_amdgcn_s_sleep(32);
-            }
-        }
-        if (fin) {
-            my_head = (unsigned)__builtin_amdgcn_readfirstlane((int)sh->qheads[qid]);
-            c_n = my_head > c_first ? (int)min((unsigned)QCHUNK, my_head - c_first) : 0;
-        }
-        if (c_n <= 0) break;                          // beyond the head: the queue is exhausted
-        int2 pr_next = have_first ? pr_first : (lane < c_n ? load_pair(seg_pairs, c_first + lane) : make_int2(0, 0));
-        // the next ticket travels while this chunk is evaluated.  (Looking at the tail counter first, to save the atomic of a
-        // wave about to leave, cost 26 us of a 37 us kernel: a load of a line that atomics are queueing for waits with them.)
-        const bool more = true;
-        if (lane == 0) t_raw = (unsigned)atomicAdd(my_tail, 1ull);
-        have_first = false;
-        for (int k0 = 0; k0 < c_n; k0 += 64) {
-        const int kk = k0 + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
+    long long out_base = 0;
+#pragma unroll
+    for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
+        if (q_ < sgm) out_base += (long long)min(heads[q_], cap);
+    const long long nseg = (long long)min(heads[sgm], cap);
+    for (long long base = first; base < nseg; base += stride) {
+        const long long ps = base + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
         bool queued = false;
         uint4 task = make_uint4(0u, 0u, 0u, 0u);
         const int2 pr = pr_next;
-        if (k0 + 64 < c_n) {
-            if (kk + 64 < c_n) pr_next = load_pair(seg_pairs, c_first + kk + 64);
-#ifndef Q_NO_FIRST
-        } else if (more && fin) {
-            // last batch of the chunk: the next chunk's first pairs (its ticket has arrived by now)
-            const unsigned nf = ((unsigned)__builtin_amdgcn_readfirstlane((int)t_raw) * QSUB + sub) * QCHUNK;
-            have_first = true;
-            pr_first = (nf + lane < my_head) ? load_pair(seg_pairs, nf + lane) : make_int2(0, 0);
-#endif
-        }
-        if (kk < c_n) {
-        const unsigned p = out_base + c_first + (unsigned)kk;
+        if (ps + stride < nseg) pr_next = seg_pairs[ps + stride];     // the next batch's pairs travel while this one is evaluated
+        if (ps < nseg) {
+        const long long p = out_base + ps;
         const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // two 16-byte quads per atom
         const int4 nbr = A.s_b4[pr.x];                     // bgn's first bonded neighbours: travels WITH the records (addressed by position),
                                                            // not after them as the walk over the CSR list did
@@ -1638,14 +1569,6 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, SiftShared* sh) {
                 run_tasks(tn, 64);
             }
         }
-        }
-        if (!more) break;
-      }
-      // This queue has nothing left to hand out (so the search has finished).  The wave leaves: the ticket counters of a
-      // segment hand out its chunks round-robin and every counter has the same number of waves, so the queues run dry
-      // together; waves that went looking for leftovers in other queues all found the same last chunks at the same moment, and
-      // their returning atomics on those few lines (~90 per microsecond and line) tripled the kernel.
-      break;
     }
     if (tn > 0) run_tasks(0, tn);
 }

@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa
                                                                      u64* publish_counts, int np, PublishArgs pub) {
     __shared__ SiftPlanesShared s_sh;
     const int b = (int)blockIdx.x;
-    if (b >= np) sift_body<STREAM>(sa, &s_sh.sift);
+    if (b >= np) sift_body<STREAM>(sa, b - np, nsift, &s_sh.sift);
     else planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
     pass_end(pub, 0);
 }
@@ -786,10 +786,9 @@ __global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs
     planes_from_lists(ap, pp, gg, gp, L, publish_counts, (int)blockIdx.x, (int)gridDim.x, &s_sh);
     pass_end(pub, 1);
 }
-// (ticket_set: the early launch of a pass — beside the search, on the second stream — ends with the second set of tickets)
 template <int STREAM>
-__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(SiftArgs sa, PublishArgs pub, int ticket_set) {
+__global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(SiftArgs sa, PublishArgs pub) {
     __shared__ SiftShared s_sh;
-    sift_body<STREAM>(sa, &s_sh);
-    pass_end(pub, ticket_set);
+    sift_body<STREAM>(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+    pass_end(pub, 0);
 }

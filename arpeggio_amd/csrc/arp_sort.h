@@ -26,18 +26,7 @@
 #define SORT_BINS (1 << SORT_MAX_BITS)
 #define SORT_WAVES (SORT_THREADS / 64)
 
-// The unsorted bag sits in segments (the per-XCD segments of the pair list, arp_pairs.h): record v of the bag, counted
-// through the segments in order, is slot v - prefix[s] of segment s.
-__host__ __device__ __forceinline__ long long sort_phys(long long v, const long long* prefix, long long cap) {
-    int s = 0;
-#pragma unroll
-    for (int q = 1; q < 8; ++q) s += (v >= prefix[q]) ? 1 : 0;
-    return (long long)s * cap + (v - prefix[s]);
-}
-
 struct SortArgs {
-    long long seg_prefix[9];   // records before segment s (first pass: where the bag's own columns are read)
-    long long seg_cap;
     // input of this pass: keys + record indices of the pass before, or (first pass) the bag's own i / j columns
     const unsigned long long* key_in;
     const uint32_t* idx_in;
@@ -65,10 +54,7 @@ struct SortArgs {
 };
 
 __device__ __forceinline__ unsigned long long sort_key_at(const SortArgs& A, long long p) {
-    if (A.first) {
-        const long long q = sort_phys(p, A.seg_prefix, A.seg_cap);
-        return ((unsigned long long)(uint32_t)A.ci[q] << A.jbits) | (unsigned long long)(uint32_t)A.cj[q];
-    }
+    if (A.first) return ((unsigned long long)(uint32_t)A.ci[p] << A.jbits) | (unsigned long long)(uint32_t)A.cj[p];
     return A.key_in[p];
 }
 
@@ -146,7 +132,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortArgs A) {
         const long long p = wbase + r * 64 + lane;
         const bool valid = p < hi;
         key[r] = valid ? sort_key_at(A, p) : ~0ull;
-        idx[r] = valid ? (A.first ? (uint32_t)sort_phys(p, A.seg_prefix, A.seg_cap) : A.idx_in[p]) : 0u;
+        idx[r] = valid ? (A.first ? (uint32_t)p : A.idx_in[p]) : 0u;
     }
     for (int d = threadIdx.x; d < SORT_WAVES * SORT_BINS; d += SORT_THREADS) (&s_whist[0][0])[d] = 0;
     {
