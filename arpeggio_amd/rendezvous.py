@@ -7,7 +7,9 @@ RCCL holds two HIP runtimes and two RCCLs; this module need
 
 Environment (as ``python -m torch.distributed.run`` sets it): RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT.  The launcher's own
 store listens on MASTER_PORT, so rank 0 listens on the first free port of MASTER_PORT + 1000 .. + 1007 (``ARP_RDZV_PORT``
-overrides the first) and the others find it by the handshake.
+overrides the first) and the others find it by the handshake.  Rank 0 binds MASTER_ADDR's interface only; a connection
+that does not say hello within 3 s is dropped; the hello carries an optional token (``ARP_RDZV_TOKEN``, by default the launcher's
+``TORCHELASTIC_RUN_ID``) so that a stray process of another launch cannot claim a rank; announced message lengths are capped.
 """
 import os
 import socket
@@ -17,6 +19,13 @@ import time
 import numpy as np
 
 _MAGIC = b'ARPRDZV1'
+_MAX_MESSAGE = 1 << 31       # a length prefix beyond this is not one of ours (the halo buffers of the host-buffer debug path stay far below)
+_HELLO_TIMEOUT = 3.0         # a connection that does not say hello within this is dropped: it must not eat the rendezvous deadline
+
+
+def _token() -> bytes:
+    """Optional shared secret of one launch (ARP_RDZV_TOKEN, e.g. the launcher's run id): part of the hello both ways."""
+    return os.environ.get('ARP_RDZV_TOKEN', os.environ.get('TORCHELASTIC_RUN_ID', '')).encode()[:64]
 
 
 def _send(sock, data: bytes):
@@ -33,8 +42,10 @@ def _recv_exact(sock, n: int) -> bytes:
     return bytes(buf)
 
 
-def _recv(sock) -> bytes:
+def _recv(sock, limit=_MAX_MESSAGE) -> bytes:
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    if n > limit:
+        raise ConnectionError('rendezvous: message of %d bytes announced (limit %d)' % (n, limit))
     return _recv_exact(sock, n)
 
 
@@ -57,7 +68,7 @@ class TcpRendezvous:
                 try:
                     srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                    srv.bind(('' if addr not in ('127.0.0.1', 'localhost') else addr, p))
+                    srv.bind((self._bind_address(addr), p))
                     break
                 except OSError:
                     srv.close()
@@ -73,20 +84,21 @@ class TcpRendezvous:
                     s, _ = srv.accept()
                 except socket.timeout:
                     continue
-                s.settimeout(timeout)
+                s.settimeout(_HELLO_TIMEOUT)
                 try:
-                    hello = _recv(s)
-                    if hello[:8] != _MAGIC:
+                    hello = _recv(s, 256)
+                    if hello[:8] != _MAGIC or hello[16:] != _token():
                         s.close()
                         continue
                     r, w = struct.unpack('<ii', hello[8:16])
                     if w != self.world or not (0 < r < self.world) or r in self.peers:
                         s.close()
                         continue
-                    _send(s, _MAGIC)
+                    _send(s, _MAGIC + _token())
+                    s.settimeout(timeout)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     self.peers[r] = s
-                except (OSError, struct.error):
+                except (OSError, struct.error, ConnectionError):
                     s.close()
             srv.close()
         else:
@@ -99,8 +111,8 @@ class TcpRendezvous:
                 try:
                     s = socket.create_connection((addr, p), timeout=2.0)
                     s.settimeout(5.0)
-                    _send(s, _MAGIC + struct.pack('<ii', self.rank, self.world))
-                    if _recv(s) != _MAGIC:
+                    _send(s, _MAGIC + struct.pack('<ii', self.rank, self.world) + _token())
+                    if _recv(s, 256) != _MAGIC + _token():
                         raise ConnectionError('not the rendezvous')
                     s.settimeout(timeout)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
@@ -112,6 +124,23 @@ class TcpRendezvous:
                         pass
                     if k % len(ports) == 0:
                         time.sleep(0.2)
+
+    @staticmethod
+    def _bind_address(addr):
+        """Rank 0 listens on MASTER_ADDR's own interface (the loopback for 127.0.0.1), not on every interface; a name that does
+        not resolve to a local address (a NAT'ed or virtual master address) falls back to all interfaces."""
+        if addr in ('127.0.0.1', 'localhost'):
+            return '127.0.0.1'
+        try:
+            ip = socket.gethostbyname(addr)
+            probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                probe.bind((ip, 0))
+            finally:
+                probe.close()
+            return ip
+        except OSError:
+            return ''
 
     # ---- collectives over the star --------------------------------------------------------------------------
     def gather(self, data: bytes):

@@ -63,6 +63,9 @@ def parse():
                     help='N > 1: run the general three-stage protocol (selection_plus bits over P2P + residue-set all-reduce '
                          'every step) although the whole-structure selection of the benchmark does not need it')
     ap.add_argument('--cpu-sample-atoms', type=int, default=100_000)
+    ap.add_argument('--dry-run', action='store_true',
+                    help='everything a --gpus N launch does up to (not including) the first HIP call: environment, rank -> device mapping, '
+                         'rendezvous of the ranks, broadcast of a 128-byte id, barrier, reduction; prints one JSON line on rank 0 (tests/test_sharding.py)')
     return ap.parse_args()
 
 
@@ -91,6 +94,40 @@ def survey_8d_bytes(kernel, n_binned, ncell, n_pairs):
     if kernel == 'sift':         # hydrogen / bond side arrays + the output records
         return 16 * n_binned + 16 * n_pairs
     raise KeyError(kernel)
+
+
+def per_gpu_workload(atoms):
+    """config.workload: what ONE GPU works on — the same string at every N (weak scaling)."""
+    return f'synthetic {atoms} random-coordinate atoms per GPU, rho=0.05/A^3, 5 A cutoff (BASELINE configs[2] on every GPU)'
+
+
+def dry_run(args, rank, local_rank, world, timeout):
+    """What a `--gpus N` launch does before its first HIP call, without a GPU: the launcher's environment, the rank -> device
+    mapping, the rendezvous (arpeggio_amd/rendezvous.py), the broadcast of a 128-byte communicator id, a barrier and a
+    reduction.  Rank 0 prints one JSON line."""
+    import zlib
+    from arpeggio_amd.rendezvous import TcpRendezvous
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    share_gpu = os.environ.get('ARP_BENCH_SHARE_GPU') == '1'
+    device = 0 if share_gpu else local_rank
+    t0 = time.perf_counter()
+    rdzv = TcpRendezvous(rank, world, timeout=timeout) if world > 1 else None
+    uid = os.urandom(128) if rank == 0 else None
+    if rdzv is not None:
+        uid = rdzv.broadcast(uid)
+    me = {'rank': rank, 'local_rank': local_rank, 'device': device, 'world': world, 'pid': os.getpid(), 'uid_crc32': zlib.crc32(uid),
+          'master': f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '29500')}", 'rendezvous_s': round(time.perf_counter() - t0, 3)}
+    everybody = [json.loads(b) for b in (rdzv.allgather(json.dumps(me).encode()) if rdzv is not None else [json.dumps(me).encode()])]
+    total = float(rdzv.allreduce(np.array([rank + 1.0]), 'sum')[0]) if rdzv is not None else 1.0
+    if rdzv is not None:
+        rdzv.barrier()
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks': everybody, 'allreduce_sum': total,
+                          'config': {'workload': per_gpu_workload(args.atoms), 'atoms_per_gpu': args.atoms}}), flush=True)
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 def bench_batch(args):
@@ -243,6 +280,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
+    rdzv_timeout = float(os.environ.get('ARP_RDZV_TIMEOUT', '180'))
+    if args.dry_run:
+        return dry_run(args, rank, local_rank, world, rdzv_timeout)
     from arpeggio_amd import synth, _capi
     from arpeggio_amd.rendezvous import TcpRendezvous
     if _capi.device_count() < 1:
@@ -257,7 +297,7 @@ def main():
     # per-rank timings — is a few TCP messages through rank 0 (arpeggio_amd/rendezvous.py).  No PyTorch in this process: its
     # ROCm build brings a HIP runtime and an RCCL of its own, and two of each in one process do not end well.
     comm_device = None if share_gpu else local_rank
-    rdzv = TcpRendezvous(rank, world) if world > 1 else None
+    rdzv = TcpRendezvous(rank, world, timeout=rdzv_timeout) if world > 1 else None
     transport = rdzv
 
     # ---------------- workload ----------------
@@ -271,15 +311,14 @@ def main():
                         f'ligand + waters, {pc.n_atoms} atoms incl. explicit hydrogens, whole structure, 5 A cutoff')
         else:
             pc = synth.config3(args.atoms, seed=3)
-            workload = f'synthetic {args.atoms} random-coordinate atoms, rho=0.05/A^3, 5 A cutoff (BASELINE configs[2])'
+            workload = per_gpu_workload(args.atoms)
         ctx = _capi.Context(local_rank)
         ctx.set_complex(pc)
         n_local_home = pc.n_atoms
     else:
         from arpeggio_amd import sharding
         full = None      # (only the host-buffer debug modes build the whole structure: a rank generates its own slab)
-        workload = (f'synthetic {args.atoms * world} atoms in {world} x-slabs of {args.atoms} '
-                    f'(BASELINE configs[3]{"" if args.atoms * world == 2_000_000 else " family"}), one-cell halo over RCCL')
+        workload = per_gpu_workload(args.atoms)      # (the same per-GPU workload as N = 1; the slabs are in config.sharding)
         # no fallback: if the exchange over RCCL fails, the run fails (a scaling figure must not be printed without it)
         ctx = _capi.Context(local_rank)
         if comm_device is not None:
@@ -795,7 +834,9 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64 distance test / f32+f64 SIFt',
         'data': 'synthetic',
         'config': {'workload': workload, 'atoms_per_gpu': args.atoms, 'cutoff_A': args.cutoff, 'vdw_comp': args.vdw_comp,
-                   'parallelism': f'slab{world}' if world > 1 else 'single'},
+                   'parallelism': f'slab{world}' if world > 1 else 'single',
+                   'sharding': (None if world == 1 else f'{args.atoms * world} atoms, box elongated along x, {world} x-slabs of {args.atoms} atoms (one config-3 cube each'
+                                                        f'{"; BASELINE configs[3]" if args.atoms * world == 2_000_000 else ""}), one-cell halo over RCCL')},
         'step_definition': 'one whole run_arpeggio pass over the resident structure that BUILDS its contact grid (k_compact_atoms + k_search + k_sift_planes, '
                            'arp_set_grid_reuse(0)); nothing a pass made is reused by the next one',
         # wall clock per structure = a FRESH structure end to end, canonical order included (end_to_end); null when that leg was skipped

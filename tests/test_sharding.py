@@ -312,6 +312,103 @@ def test_tcp_rendezvous_three_ranks():
     assert got[2][4] == {-1: (6, 101)}
 
 
+def _launch_bench_dry(nproc, port, extra_env=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env.update(extra_env or {})
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nproc), '--steps', '5', '--warmup', '1', '--dry-run']
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+def _dry_line(out):
+    import json
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{') and '"dry_run"' in ln]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_as_the_driver_launches_it_up_to_the_first_hip_call():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2
+    ... --dry-run` on CPU: everything of the N > 1 launch before its first HIP call — RANK / LOCAL_RANK / WORLD_SIZE from the
+    launcher, one rank per device (LOCAL_RANK -> device), the TCP rendezvous beside the launcher's own store on MASTER_PORT,
+    the 128-byte communicator id from rank 0 to everybody, a reduction and the barriers; twice in a row on the SAME port (the
+    driver runs N = 1, 2, 4, 8 back to back), and once with four ranks.  The per-GPU workload of the line is the N = 1 one."""
+    import json
+    import subprocess
+    import sys
+    port = 21000 + (os.getpid() * 13) % 20000
+    first = _dry_line(_launch_bench_dry(2, port))
+    again = _dry_line(_launch_bench_dry(2, port))            # the port (and the rendezvous port derived from it) is free again
+    for line in (first, again):
+        ranks = sorted(line['ranks'], key=lambda r: r['rank'])
+        assert line['n_gpus'] == 2 and [r['rank'] for r in ranks] == [0, 1]
+        assert [r['device'] for r in ranks] == [r['local_rank'] for r in ranks] == [0, 1]      # one rank per GPU
+        assert len({r['uid_crc32'] for r in ranks}) == 1 and len({r['pid'] for r in ranks}) == 2
+        assert line['allreduce_sum'] == 3.0 and all(r['master'] == f'127.0.0.1:{port}' for r in ranks)
+    assert first['ranks'][0]['uid_crc32'] != again['ranks'][0]['uid_crc32']                   # (a fresh id per launch)
+    four = _dry_line(_launch_bench_dry(4, port + 1))
+    assert sorted(r['device'] for r in four['ranks']) == [0, 1, 2, 3] and four['allreduce_sum'] == 10.0
+    # the same per-GPU workload at N = 1 (what SCALE divides by) as at N > 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry-run'], capture_output=True, text=True, timeout=120, cwd=root)
+    one_line = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith('{')][-1])
+    assert one_line['config'] == first['config'] == four['config'] and one_line['config']['atoms_per_gpu'] == 100_000
+
+
+def test_bench_rendezvous_times_out_when_a_rank_is_missing():
+    """A rank whose peers never arrive gives up after ARP_RDZV_TIMEOUT with a message that says who is missing (rank 0: how many
+    arrived; another rank: that rank 0 was not found), instead of hanging the launch."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 23000 + (os.getpid() * 17) % 20000
+    for rank, needle in ((0, '1 of 2 ranks arrived'), (1, 'rank 0 not found')):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port + rank),
+                   ARP_RDZV_TIMEOUT='3')
+        t0 = time.time()
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=env, capture_output=True,
+                             text=True, timeout=120, cwd=root)
+        assert out.returncode != 0 and needle in out.stderr, out.stderr[-1500:]
+        assert time.time() - t0 < 60
+
+
+def test_rendezvous_ignores_strangers():
+    """A connection that never says hello, one that announces a huge message and one with another launch's token do not claim a
+    rank and do not use up the deadline."""
+    import multiprocessing as mp
+    import socket
+    import struct
+    import time
+    from arpeggio_amd import rendezvous
+    port = 25000 + (os.getpid() * 19) % 20000
+    ctxm = mp.get_context('spawn')
+    q = ctxm.Queue()
+    ps = [ctxm.Process(target=_rendezvous_worker, args=(k, 2, port, q)) for k in range(1)]      # rank 0 only, for now
+    ps[0].start()
+    time.sleep(1.0)
+    silent = socket.create_connection(('127.0.0.1', port), timeout=5)                             # says nothing
+    greedy = socket.create_connection(('127.0.0.1', port), timeout=5)
+    greedy.sendall(struct.pack('<Q', 1 << 40))                                                      # "a terabyte follows"
+    wrong = socket.create_connection(('127.0.0.1', port), timeout=5)
+    hello = rendezvous._MAGIC + struct.pack('<ii', 1, 2) + b'token-of-another-launch'
+    wrong.sendall(struct.pack('<Q', len(hello)) + hello)
+    p1 = ctxm.Process(target=_rendezvous_worker, args=(1, 2, port, q))
+    t0 = time.time()
+    p1.start()
+    got = sorted(q.get(timeout=60) for _ in range(2))
+    assert time.time() - t0 < 30
+    for s_ in (silent, greedy, wrong):
+        s_.close()
+    for p in ps + [p1]:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [0, 1] and all(g[1] == b'id-of-rank-0' for g in got)
+
+
 @pytest.mark.parametrize('n_per_slab,world', [(5000, 3), (3000, 2)])
 def test_a_rank_generates_its_own_slab(n_per_slab, world):
     """synth.slab_home_records: what a rank owns of slab_config(...) WITHOUT the whole structure in its memory — every field of
