@@ -1,4 +1,4 @@
 from .exceptions import (HydrogenError, OBBioMatchError, AtomSerialError,  # noqa: F401
-                         SiftMatchError, SelectionError, NativeLibraryError)
+                         SiftMatchError, SelectionError, NativeLibraryError, IncompleteStructureError)
 from .packed import PackedComplex  # noqa: F401
 from .interactions import InteractionComplex, pack_from_reference_objects  # noqa: F401

@@ -58,5 +58,22 @@ class SelectionError(ArpeggioError):
         return f'Invalid selector: {selection}'
 
 
+class IncompleteStructureError(ArpeggioError, NotImplementedError):
+    """A structure read from a file alone (``core.protein_reader.read_mmcif``) lacks something the requested run needs and
+    only the reference's OpenBabel preparation could supply (I:53-105, 288-327).  Not part of the reference: it prepares
+    every structure with OpenBabel.  ``InteractionComplex(path, allow_incomplete=True)`` turns the refusal into a warning."""
+
+    def __init__(self, needs):
+        self.needs = tuple(needs)
+        ArpeggioError.__init__(self, self.needs)
+
+    def describe(self, needs):
+        return ('The structure was read without OpenBabel and the run needs: ' + '; '.join(needs) +
+                '.  Pass a PackedComplex prepared with OpenBabel (pack_from_reference_objects) or allow_incomplete=True.')
+
+    def __str__(self):
+        return self.describe(self.needs)
+
+
 class NativeLibraryError(RuntimeError):
     """The HIP library is missing or a HIP call failed.  There is no CPU fallback."""

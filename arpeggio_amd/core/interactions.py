@@ -61,20 +61,27 @@ def amide_majority_residue(res_id, amide_atoms):
 
 
 class InteractionComplex:
-    def __init__(self, filename, vdw_comp=0.1, interacting=5.0, ph=7.4, device=0):
-        """Args mirror I:37.  ``filename``: a PackedComplex or the path of a packed ``.npz``."""
+    def __init__(self, filename, vdw_comp=0.1, interacting=5.0, ph=7.4, device=0, allow_incomplete=False):
+        """Args mirror I:37.  ``filename``: the path of an mmCIF file (I:37-105 — read by ``core.protein_reader.read_mmcif``:
+        what the file alone determines; see ``allow_incomplete``), a PackedComplex, or the path of a packed ``.npz``.
+        ``allow_incomplete``: a structure read from a file lacks what only the reference's OpenBabel preparation gives
+        (``pc.incomplete``); a run that needs a missing part raises ``IncompleteStructureError`` — with True it logs a warning
+        and goes on (the records that depend on the missing part are then not the reference's)."""
+        self.allow_incomplete = bool(allow_incomplete)
         if isinstance(filename, PackedComplex):
             self.pc = filename
             self.id = filename.id
         elif isinstance(filename, (str, os.PathLike)) and str(filename).endswith('.npz'):
             self.pc = PackedComplex.load(filename)
             self.id = os.path.basename(str(filename)).split('.')[0]        # I:51
+        elif isinstance(filename, (str, os.PathLike)) and str(filename).lower().endswith(('.cif', '.mmcif')):
+            from . import protein_reader
+            self.pc = protein_reader.read_mmcif(str(filename))             # I:54-60, P:258-411
+            self.id = os.path.basename(str(filename)).split('.')[0]        # I:51
         else:
             raise NotImplementedError(
-                'Reading mmCIF/PDB needs the reference\'s BioPython/OpenBabel/gemmi preparation (I:53-105, 288-327), '
-                'which is outside the accelerated path: pass a PackedComplex (see pack_from_reference_objects).  '
-                'core.protein_reader.read_mmcif(path) gives the part of a pack a file alone determines (atoms, residues, '
-                'polypeptide links, table types of standard residues; no bonds, hydrogens, ligand types, rings or amides).')
+                'Only mmCIF files (.cif), PackedComplex objects and packed .npz files are read: the reference converts every other '
+                'format to mmCIF with gemmi first (P:258-295), which is outside the accelerated path.')
         self.pc.ensure_labels()
         self.device = device
         self._ctx = None
@@ -112,12 +119,53 @@ class InteractionComplex:
             self._ctx.set_complex(self.pc)
 
     def initialize(self):
-        """I:288-327 prepares per-atom state; here: create the GPU context and upload the pack."""
+        """I:288-327 prepares per-atom state; here: create the GPU context and upload the pack.  A structure that came from a
+        file (``read_mmcif``) gets the centres / normals / residues of its template rings and amide groups computed on the GPU
+        (the geometric part of I:1453-1492, 1531-1589, 1697-1733)."""
         from .. import _capi
+        incomplete = getattr(self.pc, 'incomplete', ())
+        if 'added hydrogens' in incomplete and not self.params.has_hydrogens and self.pc.n_atoms:
+            # I:99-105: a structure without hydrogens gets them from OpenBabel (AddHydrogens at the given pH) — every hbond /
+            # weak hbond flag depends on them
+            self._incomplete(['hydrogens (the file has none; the reference adds them with OpenBabel, I:99-105)'])
         if self._ctx is None:
             self._ctx = _capi.Context(self.device)
         self._ctx.set_complex(self.pc)
+        if getattr(self.pc, 'plane_geometry_pending', False):
+            self.compute_plane_geometry()
+            self.pc.plane_geometry_pending = False
         logging.debug('Uploaded packed structure to the GPU.')
+
+    def _incomplete(self, needs):
+        """A run on a structure read without OpenBabel needs something the file does not give."""
+        from .exceptions import IncompleteStructureError
+        if not self.allow_incomplete:
+            raise IncompleteStructureError(needs)
+        logging.warning('Structure read without OpenBabel, going on as asked (allow_incomplete); missing: %s', '; '.join(needs))
+
+    def _check_incomplete_after_run(self):
+        """What of ``pc.incomplete`` the run that has just finished would have needed: atom types, rings and amide groups of the
+        non-standard residues inside selection_plus (OpenBabel's SMARTS and ring perception, I:1697-1733, 1531-1589, 1966-1983),
+        and the single-bond neighbour of a halogen that takes part in a contact (U:139-141, 173)."""
+        pc = self.pc
+        incomplete = getattr(pc, 'incomplete', ())
+        untyped = getattr(pc, 'untyped_atoms', None)
+        if not incomplete or untyped is None or not len(untyped):
+            return
+        needs = []
+        aa = self._bags.get('atom_atom', {})
+        if len(aa.get('i', ())):
+            hit = untyped[aa['i']] | untyped[aa['j']]
+            if hit.any():
+                res = sorted({pc.res_name[r].strip() for r in np.unique(pc.res_id[np.concatenate([aa['i'][hit], aa['j'][hit]])]).tolist()
+                              if r in set(pc.res_id[untyped].tolist())})
+                needs.append(f'atom types of the non-standard residues {", ".join(res[:8])} ({int(hit.sum())} of the contacts found touch '
+                             f'their untyped atoms; also their rings and amide groups, if any)')
+            hal = (pc.flags & config.F_HALOGEN) != 0
+            if hal.any() and (hal[aa['i']] | hal[aa['j']]).any() and (pc.sb_nbr[hal] < 0).any():
+                needs.append('bonds inside residues (the single-bond neighbour of a halogen in contact, U:139-141, 173)')
+        if needs:
+            self._incomplete(needs)
 
     def compute_plane_geometry(self, assign_ring_residues=True):
         """The geometric part of the reference's initialize() on the GPU, for packs that carry the perceived rings /
@@ -177,6 +225,7 @@ class InteractionComplex:
         # all five bags with one copy; the atom-atom bag arrives in the canonical (i, j) order, made on the device
         # (the arrays are views into a page-locked buffer of their own: the next run allocates another one)
         self._bags, _ = ctx.fetch_packed()
+        self._check_incomplete_after_run()
         self.stats = ctx.stats()
 
     # ---- result bags as lists of the reference's namedtuples (built on demand) ----

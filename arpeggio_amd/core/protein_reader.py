@@ -23,9 +23,12 @@ gemmi ``get_mmcif_category``          ``_capi.CifCategory`` (native CIF tokenize
 ====================================  ==========================================================================
 
 What a file alone does NOT give: the OpenBabel bond graph, hydrogens added by OpenBabel, SMARTS types of ligand atoms,
-aromatic rings and amide groups.  ``read_mmcif`` therefore returns a pack whose atoms of standard residues are typed by
-table (``core/typing.py``), whose other atoms carry no type, and whose bond / ring / amide sections are empty;
-``pc.incomplete`` lists what is missing.  The reference also passes the file through gemmi's ``read_structure`` +
+and OpenBabel's perception of aromatic rings and amide groups.  ``read_mmcif`` therefore returns a pack whose atoms of
+standard residues are typed by table (``core/typing.py``) and whose other atoms carry no type; the aromatic rings and the
+amide groups of STANDARD residues are taken from residue templates (``template_rings`` / ``template_amides``: what
+OpenBabel's SSSR + aromaticity and the SMARTS of C:37 find in a protein — recalled, the order of OpenBabel's lists is not
+pinned); ``pc.incomplete`` lists what is missing, and ``InteractionComplex(path)`` refuses a run that needs a missing part
+(``IncompleteStructureError``) unless it is told to go on.  The reference also passes the file through gemmi's ``read_structure`` +
 ``make_mmcif_block`` (first model only, merged chain parts, coordinates re-formatted to three decimals) before reading
 the table; this reader takes the first model of the file's own ``_atom_site`` table.
 """
@@ -353,6 +356,52 @@ def attach_hydrogens(xyz64, is_h, res_id, max_dist=1.3):
 # ---------------------------------------------------------------------------------------------------------------------
 # file -> PackedComplex
 # ---------------------------------------------------------------------------------------------------------------------
+# Aromatic rings of the standard residues, each as the ring PATH (consecutive atoms bonded), and the side-chain amide groups
+# (N, C, O, the carbon on C): what OpenBabel's ring perception (GetSSSR + IsAromatic, I:1697-1733) and the SMARTS
+# '[NX3][CX3](=[OX1])[#6]' (C:37, I:1531-1589) give for a protein with explicit hydrogens.  Recalled, not pinned: OpenBabel is
+# not in the image; in particular the ORDER of its ring list (ring ids) and whether it calls a given histidine aromatic.
+RING_TEMPLATES = {
+    'PHE': (('CG', 'CD1', 'CE1', 'CZ', 'CE2', 'CD2'),),
+    'TYR': (('CG', 'CD1', 'CE1', 'CZ', 'CE2', 'CD2'),),
+    'TRP': (('CG', 'CD1', 'NE1', 'CE2', 'CD2'), ('CD2', 'CE2', 'CZ2', 'CH2', 'CZ3', 'CE3')),
+    'HIS': (('CG', 'ND1', 'CE1', 'NE2', 'CD2'),),
+}
+SIDE_CHAIN_AMIDES = {'ASN': ('ND2', 'CG', 'OD1', 'CB'), 'GLN': ('NE2', 'CD', 'OE1', 'CG')}
+
+
+def template_rings(residues, atom_index):
+    """Ring atom lists (packed indices, ring-path order) of the standard residues that have all atoms of a template, in the
+    order of their first atom in the file."""
+    out = []
+    for r in residues:
+        for names in RING_TEMPLATES.get(r.name.strip(), ()):
+            atoms = [r.by_name.get(nm) for nm in names]
+            if all(a is not None for a in atoms):
+                out.append(np.array([atom_index[id(a)] for a in atoms], np.int32))
+    out.sort(key=lambda a: int(a.min()))
+    return out
+
+
+def template_amides(residues, res_next, atom_index):
+    """Amide groups [N, C, O, carbon on C] of a protein: one per peptide bond (N of the next residue of the polypeptide; C, O,
+    CA of this one) and the side chains of ASN / GLN; ordered by the nitrogen's position in the file (the SMARTS matcher walks
+    the atoms in order).  A proline nitrogen (three connections) matches like any other."""
+    out = []
+    for k, r in enumerate(residues):
+        if res_next[k] >= 0:
+            n_ = residues[res_next[k]].by_name.get('N')
+            grp = [n_, r.by_name.get('C'), r.by_name.get('O'), r.by_name.get('CA')]
+            if all(a is not None for a in grp):
+                out.append([atom_index[id(a)] for a in grp])
+        names = SIDE_CHAIN_AMIDES.get(r.name.strip())
+        if names:
+            grp = [r.by_name.get(nm) for nm in names]
+            if all(a is not None for a in grp):
+                out.append([atom_index[id(a)] for a in grp])
+    out.sort(key=lambda g: g[0])
+    return np.array(out, np.int32).reshape(-1, 4)
+
+
 def read_mmcif(path, use_ambiguities=False, normalise=True):
     """``initialize()``'s result for an mmCIF file as far as the file alone goes (see the module docstring and
     ``pc.incomplete``): atoms, residues, polypeptide links, table types and radii; bonds from ``_struct_conn``, the peptide
@@ -430,12 +479,17 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
     h_xyz = np.array([xyz64[h_] for k in range(n) for h_ in h_lists[k]], np.float64).reshape(-1, 3)
     from .packed import single_bond_neighbours
     sb_nbr = single_bond_neighbours(bond_off, bond_idx, np.ones(len(bond_idx), np.int32), np.zeros(len(bond_idx), np.int32), is_h)
+    ring_atoms = template_rings(residues, atom_index)
+    amide_atoms = template_amides(residues, res_next, atom_index)
     pc = PackedComplex(
         xyz=np.array([a.coord for a in atoms], np.float32).reshape(-1, 3), vdw=vdw, cov=cov, type_mask=np.zeros(n, np.uint16), flags=flags,
         res_id=res_id, res_flags=res_flags, res_prev=res_prev, res_next=res_next, bond_off=bond_off,
         bond_idx=bond_idx, h_off=h_off, h_xyz=h_xyz, sb_nbr=sb_nbr,
-        ring_center=np.zeros((0, 3)), ring_normal=np.zeros((0, 3)), ring_res=np.zeros(0, np.int32),
-        amide_center=np.zeros((0, 3), np.float32), amide_normal=np.zeros((0, 3), np.float32), amide_res=np.zeros(0, np.int32),
+        # (centres / normals / residues of the template rings and amides: InteractionComplex.compute_plane_geometry, on the GPU)
+        ring_center=np.zeros((len(ring_atoms), 3)), ring_normal=np.zeros((len(ring_atoms), 3)), ring_res=np.full(len(ring_atoms), -1, np.int32),
+        ring_atoms=ring_atoms,
+        amide_center=np.zeros((len(amide_atoms), 3), np.float32), amide_normal=np.zeros((len(amide_atoms), 3), np.float32),
+        amide_res=np.full(len(amide_atoms), -1, np.int32), amide_atoms=amide_atoms,
         id=os.path.basename(path).split('.')[0])
     pc.atom_name = [a.name for a in atoms]
     pc.element = element
@@ -451,6 +505,21 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
     # neighbour of halogens and for hydrogens further than 1.3 A from any atom — pairs inside a residue are never contacts,
     # I:729), hydrogens of a file that has none (AddHydrogens), SMARTS types of non-standard residues, rings, amides
     # ... and the element radii: OpenBabel's table restated from memory in core/typing.py, not verified against an OpenBabel build
-    pc.incomplete = ('bonds inside residues', 'added hydrogens', 'ligand atom types', 'rings', 'amides', 'element radii unverified')
+    pc.incomplete = ('bonds inside residues', 'added hydrogens', 'ligand atom types', 'rings of non-standard residues',
+                     'amides of non-standard residues', 'element radii unverified')
+    pc.plane_geometry_pending = len(ring_atoms) + len(amide_atoms) > 0      # centres / normals not computed yet
     pc.hydrogen_parent = parent
+    # atoms whose types only OpenBabel's SMARTS could give: heavy atoms of residues outside the typing dictionary that are not water
+    std = set(typing.table()['std_res'])
+    res_untyped = np.array([(rn not in std) and not w_ for rn, w_ in zip(res_name, [r.het == 'W' for r in residues])], bool)
+    pc.untyped_atoms = (res_untyped[res_id] & ~is_h) if n else np.zeros(0, bool)
+    import logging
+    orphans = int((is_h & (parent < 0)).sum()) if n else 0
+    logging.info('read_mmcif(%s): %d atoms, %d residues; bonds inferred: %d peptide, %d X-H; %d hydrogens without a heavy atom within 1.3 A; '
+                 '%d rings and %d amide groups from residue templates; %d heavy atoms of %d non-standard residues carry no atom type',
+                 os.path.basename(path), n, nres, len(pep), int((parent >= 0).sum()) if n else 0, orphans, len(ring_atoms), len(amide_atoms),
+                 int(pc.untyped_atoms.sum()), int(res_untyped.sum()))
+    if orphans:
+        logging.warning('read_mmcif(%s): %d explicit hydrogens have no heavy atom of their residue within 1.3 A and take no part in the '
+                        'hydrogen-bond geometry (OpenBabel would attach them by its own bond perception)', os.path.basename(path), orphans)
     return pc

@@ -149,7 +149,7 @@ def test_read_mmcif_structure_runs_on_the_gpu(golden, tmp_path):
     from arpeggio_amd.core import InteractionComplex
     p = tmp_path / 'case0.cif'
     p.write_text(golden['cases'][0]['text'])
-    ic = InteractionComplex(protein_reader.read_mmcif(str(p)), 0.1, 5.0, 7.4)
+    ic = InteractionComplex(protein_reader.read_mmcif(str(p)), 0.1, 5.0, 7.4, allow_incomplete=True)      # (a file without hydrogens, hetero groups)
     ic.structure_checks()
     ic.initialize()
     ic.run_arpeggio([], 5.0, 0.1, False)
@@ -165,6 +165,90 @@ def test_read_mmcif_structure_runs_on_the_gpu(golden, tmp_path):
     assert np.array_equal(got['dist'].view(np.uint32), exp['dist'].view(np.uint32))
     names = {r['bgn']['auth_atom_id'] for r in recs} | {r['end']['auth_atom_id'] for r in recs}
     assert names & {"O5'", "C1'", 'N 1', 'C"2', 'PA', 'FE'}
+
+
+def _protein_cif(tmp_path, name='prot_h.cif'):
+    """A hydrogenated synthetic protein (aromatic residues, ASN / GLN, waters, a haem-like hetero group) written as mmCIF."""
+    from arpeggio_amd import synth
+    pc0 = synth.proteinlike(n_res=60, n_waters=25, seed=9)
+    p = tmp_path / name
+    p.write_text(_cif_of(pc0))
+    return p, pc0
+
+
+def test_interaction_complex_reads_a_cif_path(tmp_path):
+    """I:37-105: InteractionComplex(filename) — here an mmCIF path goes through read_mmcif; rings and amide groups of the
+    standard residues come from residue templates, the atoms only OpenBabel could type are marked."""
+    from arpeggio_amd.core import InteractionComplex, IncompleteStructureError
+    p, pc0 = _protein_cif(tmp_path)
+    ic = InteractionComplex(str(p), 0.1, 5.0, 7.4)
+    assert ic.id == 'prot_h' and ic.pc.n_atoms == pc0.n_atoms and ic.params.has_hydrogens
+    ic.structure_checks()
+    pc = ic.pc
+    names = np.array([pc.res_name[r].strip() for r in pc.res_id])
+    # one ring per PHE / TYR / HIS, two per TRP (all their atoms are in the file), listed along the ring path
+    want = sum({'PHE': 1, 'TYR': 1, 'HIS': 1, 'TRP': 2}.get(rn.strip(), 0) for rn in pc.res_name)
+    assert len(pc.ring_atoms) == want and want > 0
+    for atoms in pc.ring_atoms:
+        assert len(set(pc.res_id[atoms].tolist())) == 1 and len(atoms) in (5, 6)
+        xyz = pc.xyz[atoms].astype(np.float64)
+        d = np.linalg.norm(xyz - np.roll(xyz, -1, axis=0), axis=1)
+        assert d.max() < 1.6, 'consecutive atoms of a template ring are bonded'
+    # one amide group per peptide bond (N of the next residue) + ASN / GLN side chains; N, C, O, C in that order
+    n_pep = int((pc.res_next >= 0).sum())
+    n_side = sum(rn.strip() in ('ASN', 'GLN') for rn in pc.res_name)
+    assert pc.n_amides == n_pep + n_side and pc.n_amides > 0
+    el = np.array(pc.element)
+    assert (el[pc.amide_atoms[:, 0]] == 'N').all() and (el[pc.amide_atoms[:, 1]] == 'C').all() and (el[pc.amide_atoms[:, 2]] == 'O').all()
+    assert np.all(np.diff(pc.amide_atoms[:, 0]) > 0)
+    assert np.linalg.norm(pc.xyz[pc.amide_atoms[:, 0]] - pc.xyz[pc.amide_atoms[:, 1]], axis=1).max() < 1.8
+    # the haem-like group is not in the typing dictionary: its heavy atoms are the ones only OpenBabel could type
+    assert pc.untyped_atoms.any() and set(names[pc.untyped_atoms]) == {'HEM'} and not (pc.type_mask[pc.untyped_atoms] != 0).any()
+    # a file without hydrogens needs OpenBabel's AddHydrogens (I:99-105): refused before anything touches the GPU
+    q = tmp_path / 'prot.cif'
+    q.write_text('\n'.join(ln for ln in p.read_text().splitlines() if not (ln.startswith(('ATOM', 'HETATM')) and ln.split()[2] in ('H', 'D'))) + '\n')
+    bare = InteractionComplex(str(q))
+    assert not bare.params.has_hydrogens
+    with pytest.raises(IncompleteStructureError, match='hydrogens'):
+        bare.initialize()
+    with pytest.raises(NotImplementedError):
+        InteractionComplex(str(tmp_path / 'structure.pdb'))
+
+
+@pytest.mark.gpu
+def test_cif_path_through_the_constructor_equals_the_executed_reference(tmp_path, golden_dir):
+    """The structure of the executed-reference fixture that came through the mmCIF reader (`reader:*` cases of
+    tests/golden/core_cases.npz: alternative locations, insertion codes, a modified residue, hetero groups, waters, a heavy
+    water), this time from the FILE through InteractionComplex(path): structure_checks -> initialize -> run_arpeggio ->
+    get_contacts, as the reference's only caller does (CLI:159-182).  The atom-atom bag must be the reference's own records;
+    without allow_incomplete the run is refused, naming the hetero groups whose types only OpenBabel could give."""
+    import json
+    from arpeggio_amd.core import InteractionComplex, IncompleteStructureError
+    z = np.load(os.path.join(golden_dir, 'core_cases.npz'), allow_pickle=False)
+    p = tmp_path / 'reader_h.cif'
+    p.write_text(str(z['reader/cif_text']))
+    strict = InteractionComplex(str(p), 0.1, 5.0, 7.4)
+    strict.structure_checks()
+    strict.initialize()
+    with pytest.raises(IncompleteStructureError, match='atom types of the non-standard residues') as ei:
+        strict.run_arpeggio([], 5.0, 0.1, False)
+    assert isinstance(ei.value, NotImplementedError) and ei.value.needs
+    for case, selectors in (('reader:whole', []), ('reader:chain_b', ['/B//'])):
+        ic = InteractionComplex(str(p), 0.1, 5.0, 7.4, allow_incomplete=True)
+        ic.structure_checks()
+        ic.initialize()
+        ic.run_arpeggio(selectors, 5.0, 0.1, False)
+        got = ic._bags['atom_atom']
+        b, e = z[case + '/aa_bgn'], z[case + '/aa_end']          # the reference's records (canonical orientation), in (i, j) order
+        assert np.all(b < e)
+        o = np.lexsort((e, b))
+        assert np.array_equal(got['i'], b[o]) and np.array_equal(got['j'], e[o]), case
+        assert np.array_equal(got['dist'].view(np.uint32), z[case + '/aa_dist'][o].view(np.uint32)), case
+        assert np.array_equal(got['sift'], z[case + '/aa_sift'][o]) and np.array_equal(got['ctype'], z[case + '/aa_ctype'][o]), case
+        assert np.array_equal(np.sort(ic.selection_plus), np.sort(z[case + '/selection_plus'])), case
+        recs = ic.get_contacts()
+        assert sum(r['type'] == 'atom-atom' for r in recs) == len(got['i']) > 0
+        json.dumps(recs)
 
 
 # ---- _struct_conn, explicit hydrogens, gemmi's normalisation (round 3) ----------------------------------------------------
