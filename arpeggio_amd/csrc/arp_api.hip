@@ -1860,6 +1860,7 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
         c->max_ring_res = std::max<int64_t>(c->max_ring_res, ring_res[i]);
     }
     HIPCHK(c, hipSetDevice(c->device));
+    batch_reset(c);      // (the partition of a batch was declared for the arrays that were resident then: arp_set_batch again after this call)
     c->static_dirty = true;
     c->nring = nring;
     host_bbox_d(center, nring, c->ring_lo, c->ring_hi);
@@ -1884,6 +1885,7 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
         c->max_amide_res = std::max<int64_t>(c->max_amide_res, amide_res[i]);
     }
     HIPCHK(c, hipSetDevice(c->device));
+    batch_reset(c);      // (the partition of a batch was declared for the arrays that were resident then: arp_set_batch again after this call)
     c->static_dirty = true;
     c->namide = namide;
     host_bbox(center, namide, c->am_lo, c->am_hi);
@@ -2403,6 +2405,7 @@ int arp_shard_assemble(arp_ctx* c, uint64_t dev_left, uint64_t bytes_left, uint6
     if (!c || nres_global < 0) return ARP_E_ARG;
     if (!c->has_rec_home) FAIL(c, ARP_E_ARG, "arp_shard_assemble: call arp_shard_set_home first");
     HIPCHK(c, hipSetDevice(c->device));
+    batch_reset(c);      // (a shard is one structure)
     arp_rec_header hd[3];
     hd[0] = c->rec_home_hdr;
     const uint8_t* base[3] = {c->rec_home.p, (const uint8_t*)(uintptr_t)dev_left, (const uint8_t*)(uintptr_t)dev_right};
@@ -2530,6 +2533,7 @@ int arp_shard_layout(arp_ctx* c, int32_t* global_id, int8_t* origin, uint8_t* se
 int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_id) {
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    batch_reset(c);      // (the partition of a batch was declared for the arrays that were resident then: arp_set_batch again after this call)
     c->static_dirty = true;
     if (is_home) { CHK(upload(c, c->home, is_home, (size_t)c->n)); c->has_home = true; }
     else c->has_home = false;
@@ -2550,6 +2554,7 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
                             const int32_t* amide_gid) {
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    batch_reset(c);      // (a shard is one structure)
     c->static_dirty = true;
     if (!ring_home && !ring_gid && !amide_home && !amide_gid) { c->has_group_owner = false; return ARP_OK; }
     if ((c->nring > 0 && (!ring_home || !ring_gid)) || (c->namide > 0 && (!amide_home || !amide_gid)))

@@ -658,6 +658,14 @@ struct PublishArgs {
 // Tickets are hierarchical — one counter per (blockIdx % 8), i.e. per XCD as the dispatcher places blocks, then one for
 // the eight groups — because atomics on one LINE run at ~90 per microsecond: 2500 blocks on one word were a 15 us tail, and
 // 1024 blocks on eight words of one line still 7 us (config 3); each ticket has a line of its own (ctr_dev).
+// The ordering below is spelled for gfx9 (gfx942 / gfx950), not for the language's memory model: on these chips vmcnt counts
+// stores as well as loads and returns only when the store has left the CU (on gfx10+ stores have a counter of their own), so
+// "s_waitcnt vmcnt(0)" of every wave + the workgroup barrier is what a release of the counter stores amounts to, without the
+// L2 write-back a release FENCE of that scope performs.  The asm statements carry a "memory" clobber: the compiler keeps
+// the relaxed flag store behind them.  tools/pub_stress.py is the check on hardware.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "pass_end relies on the gfx9 meaning of s_waitcnt vmcnt(0) for stores (this library is built for gfx950)"
+#endif
 __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     if (!pa.expected) return;
     const int tset = set * C_TICKET_SET;

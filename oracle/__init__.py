@@ -149,6 +149,11 @@ class OracleComplex:
         oi, oj = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
         od, osf, oc = np.zeros(cap, np.float32), np.zeros(cap, np.uint16), np.zeros(cap, np.uint8)
         cnt = L.orc_atom_contacts(*args, C.c_int64(cap), _p(oi), _p(oj), _p(od), _p(osf), _p(oc), _p(stats), C.byref(err))
+        if int(cnt) > cap:       # a cap_hint that was too small: once more with the count the call reported (never a short list)
+            cap = int(cnt)
+            oi, oj = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+            od, osf, oc = np.zeros(cap, np.float32), np.zeros(cap, np.uint16), np.zeros(cap, np.uint8)
+            cnt = L.orc_atom_contacts(*args, C.c_int64(cap), _p(oi), _p(oj), _p(od), _p(osf), _p(oc), _p(stats), C.byref(err))
         k = int(cnt)
         out = dict(i=oi[:k], j=oj[:k], dist=od[:k], sift=osf[:k], ctype=oc[:k], stats=stats, err=err.value)
         return sort_pairs(out)
