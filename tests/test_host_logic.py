@@ -85,8 +85,10 @@ def test_interaction_complex_constructor_and_checks(tmp_path):
     pc.serial[10] = pc.serial[11]
     with pytest.raises(AtomSerialError):
         InteractionComplex(pc).structure_checks()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(IOError, match='File 1tqn_h.cif not found'):      # (P:58-59: the reader's own message for a missing file)
         InteractionComplex('1tqn_h.cif')
+    with pytest.raises(NotImplementedError):                              # other formats: gemmi's conversion is out of scope
+        InteractionComplex('1tqn_h.pdb')
     p = tmp_path / '1abc_h.npz'
     synth.config3(600, seed=1).save(p)
     assert InteractionComplex(str(p)).id == '1abc_h'
