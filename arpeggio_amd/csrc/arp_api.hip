@@ -224,7 +224,7 @@ struct arp_ctx {
     int64_t n_contacts = 0;
     // ---- canonical (i, j) order of the atom-atom bag, made on the device (arp_sort.h; arp_atom_contacts_sort)
     DevBuf<unsigned long long> sort_key[2];
-    DevBuf<uint32_t> sort_idx[2];
+    DevBuf<unsigned long long> sort_val[2];
     DevBuf<int> sort_table;
     DevBuf<long long> sort_total;
     DevBuf<uint8_t> sorted_slab;        // the five sorted columns (+ the packed ring / amide bags of a packed fetch) in one piece
@@ -1486,13 +1486,11 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     const int64_t idmax = c->has_gid ? (c->gid_max >= 0 ? c->gid_max : ((int64_t)1 << 31) - 1) : std::max<int64_t>(c->n - 1, 1);
     int idbits = 1;
     while (((int64_t)1 << idbits) <= idmax) ++idbits;
-    const int keybits = 2 * idbits;
-    const int passes = (keybits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
+    // radix passes over the bits of i only; the runs of equal i are ordered by j in one launch (k_sort_runs)
+    const int passes = (idbits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
     const size_t cap = std::max(k, c->out_i.cap);
-    if (passes > 1) {
-        HIPCHK(c, c->sort_key[0].reserve(cap)); HIPCHK(c, c->sort_idx[0].reserve(cap));
-        if (passes > 2) { HIPCHK(c, c->sort_key[1].reserve(cap)); HIPCHK(c, c->sort_idx[1].reserve(cap)); }
-    }
+    HIPCHK(c, c->sort_key[0].reserve(cap)); HIPCHK(c, c->sort_val[0].reserve(cap));
+    if (passes > 1) { HIPCHK(c, c->sort_key[1].reserve(cap)); HIPCHK(c, c->sort_val[1].reserve(cap)); }
     const long long tiles = ((long long)k + SORT_TILE - 1) / SORT_TILE;
     if (tiles > ((long long)1 << 30) / SORT_BINS) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_sort: too many records for the digit table");
     const int tstride = (int)((tiles + 3) & ~3ll);
@@ -1510,20 +1508,23 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     A.jbits = idbits;
     A.table = c->sort_table.p;
     A.total = c->sort_total.p;
-    int shift = 0;
+    int shift = idbits;       // (key = i << idbits | j)
     for (int ps = 0; ps < passes; ++ps) {
-        A.first = ps == 0; A.last = ps == passes - 1;
+        A.first = ps == 0; A.last = 0;
         A.shift = shift;
-        A.bits = keybits / passes + (ps < keybits % passes ? 1 : 0);
+        A.bits = idbits / passes + (ps < idbits % passes ? 1 : 0);
         shift += A.bits;
         A.key_in = ps > 0 ? c->sort_key[(ps - 1) & 1].p : nullptr;
-        A.idx_in = ps > 0 ? c->sort_idx[(ps - 1) & 1].p : nullptr;
-        A.key_out = A.last ? nullptr : c->sort_key[ps & 1].p;
-        A.idx_out = A.last ? nullptr : c->sort_idx[ps & 1].p;
+        A.val_in = ps > 0 ? c->sort_val[(ps - 1) & 1].p : nullptr;
+        A.key_out = c->sort_key[ps & 1].p;
+        A.val_out = c->sort_val[ps & 1].p;
         hipLaunchKernelGGL(k_sort_hist, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
         hipLaunchKernelGGL(k_sort_scan, dim3(1 << A.bits), dim3(SORT_THREADS), 0, c->stream, A);
         hipLaunchKernelGGL(k_sort_scatter, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
     }
+    A.key_in = c->sort_key[(passes - 1) & 1].p;
+    A.val_in = c->sort_val[(passes - 1) & 1].p;
+    hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, A);
     CHK(check_launch(c, "k_sort_scatter"));
     c->contacts_sorted = true;
     return ARP_OK;
@@ -1684,7 +1685,7 @@ void arp_destroy(arp_ctx* c) {
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->bag_pack.release();
-    c->sort_key[0].release(); c->sort_key[1].release(); c->sort_idx[0].release(); c->sort_idx[1].release();
+    c->sort_key[0].release(); c->sort_key[1].release(); c->sort_val[0].release(); c->sort_val[1].release();
     c->sort_table.release(); c->sort_total.release(); c->sorted_slab.release();
     if (c->bag_stage) (void)hipHostFree(c->bag_stage);
     c->res_tag.release(); c->blob_sb_nbr.release(); c->blob_dev.release(); c->longest_bond.release();

@@ -4,17 +4,23 @@
 // and exports them in that order (interactions.py:183-190); that order is a property of a KD-tree over a hashed `set`, so the
 // boundary defines a canonical one instead: ascending (bgn, end) = (i, j) packed atom index.  k_sift_planes
 // leaves the records in the order of the pair list (eight per-XCD segments, cell by cell); this header puts them into the
-// canonical order in HBM: a least-significant-digit radix sort on the key i << jbits | j with a 32-bit record index as
-// payload, whose LAST pass writes the five result columns themselves — i and j from the key, distance / SIFt / contact type
-// gathered through the index — into one slab, so that the host gets all five columns with ONE copy.
+// canonical order in HBM: least-significant-digit radix passes on the key i << jbits | j with the rest of the record
+// (distance, SIFt, contact type: 56 bits) as payload, and a last launch that writes the five result columns themselves into
+// one slab, so that the host gets all five columns with ONE copy.
 //
-// Three launches per digit pass (up to 9 bits), no atomics on global memory, every launch fills the chip:
+// The radix passes sort by i ONLY (its significant bits, up to 9 per pass: two passes below 262 144 atoms); three launches
+// per pass, no atomics on global memory, every launch fills the chip:
 //   k_sort_hist     block t counts the digits of tile t (4096 records)                              -> table[digit][t]
 //   k_sort_scan     block d turns row d of the table into exclusive prefixes over the tiles, total[d] = its sum
 //   k_sort_scatter  block t: base of digit d = (exclusive scan of total[])[d] + table[d][t]; ranks its records stably —
 //                   wave-level match by ballots, one LDS counter per (wave, digit), the sixteen rounds' counter updates
 //                   issued back to back as returning LDS adds —, puts them into tile order in LDS and writes them out
 //                   with consecutive lanes on consecutive addresses of a digit's run
+// The records of one bgn atom are then one short run (a dozen records, a few hundred in a clump), in any order:
+//   k_sort_runs     one thread per record: the run it is in (neighbours with the same i, read through L1), its rank by j among
+//                   them — the pairs of a bag are distinct, so there are no ties — and the five columns written at
+//                   run start + rank.  Two radix passes on j (two thirds of the launches of a four-pass sort) become one
+//                   launch that moves no keys.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,12 +35,12 @@
 struct SortArgs {
     // input of this pass: keys + record indices of the pass before, or (first pass) the bag's own i / j columns
     const unsigned long long* key_in;
-    const uint32_t* idx_in;
+    const unsigned long long* val_in;      // the record's payload: distance bits | SIFt << 32 | contact type << 48
     const int* ci;
     const int* cj;
     // output of this pass: keys + indices, or (last pass) the five columns of the sorted bag
     unsigned long long* key_out;
-    uint32_t* idx_out;
+    unsigned long long* val_out;
     const float* d_in;
     const uint16_t* s_in;
     const uint8_t* ct_in;
@@ -56,6 +62,12 @@ struct SortArgs {
 __device__ __forceinline__ unsigned long long sort_key_at(const SortArgs& A, long long p) {
     if (A.first) return ((unsigned long long)(uint32_t)A.ci[p] << A.jbits) | (unsigned long long)(uint32_t)A.cj[p];
     return A.key_in[p];
+}
+
+// the payload travels with the key (a gather through a record index at the end was three random sector reads per record)
+__device__ __forceinline__ unsigned long long sort_val_at(const SortArgs& A, long long p) {
+    if (A.first) return (unsigned long long)__float_as_uint(A.d_in[p]) | ((unsigned long long)A.s_in[p] << 32) | ((unsigned long long)A.ct_in[p] << 48);
+    return A.val_in[p];
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(SortArgs A) {
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(SortArgs A) {
 
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortArgs A) {
     __shared__ unsigned long long s_key[SORT_TILE];
-    __shared__ uint32_t s_idx[SORT_TILE];
+    __shared__ unsigned long long s_val[SORT_TILE];
     __shared__ int s_whist[SORT_WAVES][SORT_BINS];   // per wave and digit: records seen so far, then the wave's offset in the digit's run
     __shared__ int s_texcl[SORT_BINS];               // first slot of digit d in the tile's sorted order
     __shared__ long long s_gbase[SORT_BINS];         // global position of that slot
@@ -126,13 +138,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortArgs A) {
     const long long lo = (long long)t * SORT_TILE, hi = min(lo + SORT_TILE, A.n);
     const long long wbase = lo + (long long)w * (64 * SORT_ITEMS);
     unsigned long long key[SORT_ITEMS];
-    uint32_t idx[SORT_ITEMS];
+    unsigned long long val[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const long long p = wbase + r * 64 + lane;
         const bool valid = p < hi;
         key[r] = valid ? sort_key_at(A, p) : ~0ull;
-        idx[r] = valid ? (A.first ? (uint32_t)p : A.idx_in[p]) : 0u;
+        val[r] = valid ? sort_val_at(A, p) : 0ull;
     }
     for (int d = threadIdx.x; d < SORT_WAVES * SORT_BINS; d += SORT_THREADS) (&s_whist[0][0])[d] = 0;
     {
@@ -183,24 +195,73 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortArgs A) {
         const uint32_t d = (uint32_t)(key[r] >> A.shift) & mask;
         const int slot = s_texcl[d] + s_whist[w][d] + rk[r];
         s_key[slot] = key[r];
-        s_idx[slot] = idx[r];
+        s_val[slot] = val[r];
     }
     __syncthreads();
     const int cnt = (int)(hi - lo);
 #pragma unroll 4
     for (int s = threadIdx.x; s < cnt; s += SORT_THREADS) {
         const unsigned long long k = s_key[s];
-        const uint32_t q = s_idx[s];
+        const unsigned long long q = s_val[s];
         const long long pos = s_gbase[(uint32_t)(k >> A.shift) & mask] + s;
-        if (!A.last) {
-            A.key_out[pos] = k;
-            A.idx_out[pos] = q;
-        } else {
-            A.i_out[pos] = (int)(k >> A.jbits);
-            A.j_out[pos] = (int)(k & ((1ull << A.jbits) - 1ull));
-            A.d_out[pos] = A.d_in[q];
-            A.s_out[pos] = A.s_in[q];
-            A.ct_out[pos] = A.ct_in[q];
-        }
+        A.key_out[pos] = k;
+        A.val_out[pos] = q;
     }
+}
+
+// After the radix passes: key_in / idx_in sorted by i.  Thread p: the run of records with its i, its rank by j inside the
+// run, the five columns of the sorted bag at run start + rank.
+#define RUN_HALO 64
+__global__ __launch_bounds__(256) void k_sort_runs(SortArgs A) {
+    // i and j of the block's 256 positions and of RUN_HALO on either side, in LDS: a record looks at its neighbours without a
+    // chain of dependent loads (the run of a bgn atom is a dozen records; what is longer than the halo goes on through global
+    // memory).  Atom indices are below 2^31: both halves of a key are 32-bit numbers, 0xFFFFFFFF marks "no record".
+    __shared__ uint32_t s_i[256 + 2 * RUN_HALO], s_j[256 + 2 * RUN_HALO];
+    const long long b0 = (long long)blockIdx.x * 256;
+    const unsigned long long jmask = (1ull << A.jbits) - 1ull;
+    for (int t = threadIdx.x; t < 256 + 2 * RUN_HALO; t += 256) {
+        const long long q = b0 - RUN_HALO + t;
+        const bool in = q >= 0 && q < A.n;
+        const unsigned long long k = in ? A.key_in[q] : 0ull;
+        s_i[t] = in ? (uint32_t)(k >> A.jbits) : 0xFFFFFFFFu;
+        s_j[t] = (uint32_t)(k & jmask);
+    }
+    __syncthreads();
+    const long long p = b0 + threadIdx.x;
+    if (p >= A.n) return;
+    const int s = (int)threadIdx.x + RUN_HALO;
+    const uint32_t i = s_i[s], j = s_j[s];
+    int rank = 0, left = 0, right = 0;
+    for (int k0 = 1; k0 <= RUN_HALO; k0 += 8) {      // (a run is contiguous: `same` is 1, 1, ..., 1, 0, 0, ...; the wave stops when all its runs have ended)
+        int any = 0;
+#pragma unroll
+        for (int k = k0; k < k0 + 8; ++k) {
+            const int sl = (s_i[s - k] == i) ? 1 : 0, sr = (s_i[s + k] == i) ? 1 : 0;
+            left += sl; right += sr;
+            rank += (sl & ((s_j[s - k] < j) ? 1 : 0)) + (sr & ((s_j[s + k] < j) ? 1 : 0));
+            any = sl | sr;
+        }
+        if (!__any(any)) break;
+    }
+    long long a = p - left;
+    if (left == RUN_HALO)
+        for (long long q = p - RUN_HALO - 1; q >= 0; --q) {
+            const unsigned long long kq = A.key_in[q];
+            if ((uint32_t)(kq >> A.jbits) != i) break;
+            rank += ((uint32_t)(kq & jmask) < j) ? 1 : 0;
+            a = q;
+        }
+    if (right == RUN_HALO)
+        for (long long q = p + RUN_HALO + 1; q < A.n; ++q) {
+            const unsigned long long kq = A.key_in[q];
+            if ((uint32_t)(kq >> A.jbits) != i) break;
+            rank += ((uint32_t)(kq & jmask) < j) ? 1 : 0;
+        }
+    const long long pos = a + rank;
+    const unsigned long long v = A.val_in[p];
+    A.i_out[pos] = (int)i;
+    A.j_out[pos] = (int)j;
+    A.d_out[pos] = __uint_as_float((uint32_t)v);
+    A.s_out[pos] = (uint16_t)(v >> 32);
+    A.ct_out[pos] = (uint8_t)(v >> 48);
 }

@@ -266,8 +266,9 @@ int arp_atom_contacts_fetch(arp_ctx* ctx, int64_t cap, int32_t* out_i, int32_t* 
                             float* out_dist, uint16_t* out_sift, uint8_t* out_ctype,
                             int64_t* count);
 /* Put the atom-atom records of the last launch into the canonical (i, j) order in HBM
- * (least-significant-digit radix sort on i << b | j, csrc/arp_sort.h: two launches per 9-bit
- * digit, the last pass writes the five columns).  Enqueued on the context stream, no host
+ * (csrc/arp_sort.h: least-significant-digit radix passes over the bits of i, three launches per
+ * 9-bit digit; then one launch ranks every record by j inside the run of its i and writes the
+ * five columns).  Enqueued on the context stream, no host
  * synchronisation; a second call on the same results is a no-op.  Per-atom accumulators
  * and integer sifts do not depend on it. */
 int arp_atom_contacts_sort(arp_ctx* ctx);
