@@ -403,6 +403,7 @@ class CifCategory:
         return out
 
 
+BAG_SORT_MAX = 4096       # ARP_BAG_SORT_MAX of include/arpeggio_hip.h
 KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')
 
 
@@ -791,7 +792,7 @@ class Context:
         for b, (name, cols) in enumerate(self._PACKED_BAGS):
             m = int(counts[1 + b])
             res = {key: view(offs[5 + 12 * b + q], dt, m) for key, q, dt in cols}
-            if sort_bags and m:
+            if sort_bags and m > BAG_SORT_MAX:       # (smaller bags were put into their canonical order on the device)
                 order = self._BAGS[name][2]
                 o = np.lexsort((res[order[1]], res[order[0]]))
                 res = {kk: v[o] for kk, v in res.items()}

@@ -105,15 +105,61 @@ struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
 };
 
 // the used prefixes of every array of every bag, gathered into one device buffer for one copy to the host
-struct PackSeg { const uint8_t* src; uint32_t dst, bytes; };
+// (perm: the segment's elements — es bytes each — leave in the order perm[0], perm[1], ...: the canonical order of a small bag)
+struct PackSeg { const uint8_t* src; uint32_t dst, bytes; const uint32_t* perm; uint32_t es; };
 struct PackTable { PackSeg s[48]; int n; };
 __global__ __launch_bounds__(256) void k_pack_segments(PackTable t, uint8_t* __restrict__ out) {
     const PackSeg g = t.s[blockIdx.y];        // segment blockIdx.y, spread over the gridDim.x blocks of its row
+    if (g.perm) {
+        const uint32_t n = g.bytes / g.es;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const uint32_t q = g.perm[i];
+            if (g.es == 4) reinterpret_cast<uint32_t*>(out + g.dst)[i] = reinterpret_cast<const uint32_t*>(g.src)[q];
+            else if (g.es == 8) reinterpret_cast<unsigned long long*>(out + g.dst)[i] = reinterpret_cast<const unsigned long long*>(g.src)[q];
+            else out[g.dst + i] = g.src[q];
+        }
+        return;
+    }
     const uint32_t words = g.bytes >> 2;
     const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(g.src);      // (arrays of a slab start on 256-byte boundaries,
     uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(out + g.dst);            //  destinations on 16-byte ones)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = src[i];
     if (blockIdx.x == 0 && threadIdx.x < (g.bytes & 3u)) out[g.dst + (words << 2) + threadIdx.x] = g.src[(words << 2) + threadIdx.x];
+}
+// Canonical order of the four ring / amide bags (the order the reference creates their records in: by the ids of the two
+// partners, I:947-1382): the kernels emit them through one atomic counter per bag, i.e. in any order.  A bag of up to
+// BAG_SORT_MAX records is sorted by ONE block (bitonic network in LDS on {first id, second id, record index}); larger bags keep
+// the device's order (the caller sorts them: config 5 has 10^5 records per bag, a protein a few hundred).
+#define BAG_SORT_MAX 4096
+static_assert(BAG_SORT_MAX == ARP_BAG_SORT_MAX, "include/arpeggio_hip.h");
+struct BagOrderArgs { const int* first[4]; const int* second[4]; int n[4]; uint32_t* perm[4]; };
+__global__ __launch_bounds__(1024) void k_bag_order(BagOrderArgs A) {
+    __shared__ unsigned long long s_key[BAG_SORT_MAX];
+    __shared__ uint32_t s_idx[BAG_SORT_MAX];
+    const int b = blockIdx.x, n = A.n[b];
+    if (n <= 0 || n > BAG_SORT_MAX) return;
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += 1024) {
+        s_key[i] = i < n ? (((unsigned long long)(uint32_t)A.first[b][i] << 32) | (unsigned long long)(uint32_t)A.second[b][i]) : ~0ull;
+        s_idx[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < m; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long ka = s_key[i], kb = s_key[l];
+                    const uint32_t ia = s_idx[i], ib = s_idx[l];
+                    const bool up = (i & k) == 0;
+                    const bool gt = ka > kb || (ka == kb && ia > ib);      // (ties by record index: the order is a function of the records)
+                    if (gt == up) { s_key[i] = kb; s_key[l] = ka; s_idx[i] = ib; s_idx[l] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 1024) A.perm[b][i] = s_idx[i];
 }
 // blocks per segment: one per 16 KiB of the largest segment, at most 64
 inline dim3 pack_grid(const PackTable& t) {
@@ -273,6 +319,7 @@ struct arp_ctx {
     bool init_plus_in_bin = false; // ... and writes selection_plus = selection (whole-structure selection)
     // ---- device-resident result bags of the ring / amide kernels
     Bag bag_ap, bag_pp, bag_gg, bag_gp;
+    DevBuf<uint32_t> bag_perm;     // canonical order of the small ring / amide bags (k_bag_order), BAG_SORT_MAX indices per bag
     DevBuf<uint8_t> bag_pack;      // staging of small bags: device side ...
     uint8_t* bag_stage = nullptr;  // ... and its page-locked host copy
     size_t bag_stage_cap = 0;
@@ -1684,7 +1731,7 @@ void arp_destroy(arp_ctx* c) {
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
-    c->bag_pack.release();
+    c->bag_pack.release(); c->bag_perm.release();
     c->sort_key[0].release(); c->sort_key[1].release(); c->sort_val[0].release(); c->sort_val[1].release();
     c->sort_table.release(); c->sort_total.release(); c->sorted_slab.release();
     if (c->bag_stage) (void)hipHostFree(c->bag_stage);
@@ -2765,6 +2812,24 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     for (int q = 0; q < ARP_PACKED_OFFSETS; ++q) offsets[q] = 0;
     for (int q = 0; q < 5; ++q) offsets[q] = off[q];
     counts[0] = c->n_contacts;
+    // canonical order of the small bags, made on the device: plane-plane, group-group, group-plane by (first id, second id),
+    // atom-plane by (ring, atom) — the order the reference's loops create them in
+    BagOrderArgs bo{};
+    bool any_order = false;
+    HIPCHK(c, c->bag_perm.reserve(4 * (size_t)BAG_SORT_MAX));
+    for (int b = 0; b < 4; ++b) {
+        Bag& g = *bags[b];
+        const bool small = g.valid && g.count > 0 && g.count <= BAG_SORT_MAX;
+        bo.first[b] = (b == 1) ? g.b.p : g.a.p;          // (atom-plane: a = atom, b = ring)
+        bo.second[b] = (b == 1) ? g.a.p : g.b.p;
+        bo.n[b] = small ? (int)g.count : 0;
+        bo.perm[b] = c->bag_perm.p + (size_t)b * BAG_SORT_MAX;
+        any_order = any_order || small;
+    }
+    if (any_order) {
+        hipLaunchKernelGGL(k_bag_order, dim3(4), dim3(1024), 0, c->stream, bo);
+        CHK(check_launch(c, "k_bag_order"));
+    }
     for (int b = 0; b < 4; ++b) {
         Bag& g = *bags[b];
         counts[1 + b] = g.valid ? g.count : 0;
@@ -2777,7 +2842,7 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
             const size_t bytes = (size_t)g.count * es[q];
             if (t.n >= 48 || bytes >= ((size_t)1 << 32) || total >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: ring / amide bags too large for one piece (fetch them one by one)");
             offsets[5 + 12 * b + q] = total;
-            t.s[t.n++] = PackSeg{ptr[q], (uint32_t)total, (uint32_t)bytes};
+            t.s[t.n++] = PackSeg{ptr[q], (uint32_t)total, (uint32_t)bytes, bo.n[b] > 0 ? bo.perm[b] : nullptr, (uint32_t)es[q]};
             total = (total + bytes + 15) & ~(size_t)15;
         }
     }
@@ -2914,7 +2979,7 @@ int stage_bags(arp_ctx* c) {
             b->stage_off[k] = (uint32_t)total;
             if (!ptr[k] || b->count == 0) continue;
             const size_t bytes = (size_t)b->count * es[k];
-            t.s[t.n++] = PackSeg{ptr[k], (uint32_t)total, (uint32_t)bytes};
+            t.s[t.n++] = PackSeg{ptr[k], (uint32_t)total, (uint32_t)bytes, nullptr, 0u};
             total = (total + bytes + 15) & ~(size_t)15;
         }
     }
