@@ -1354,8 +1354,14 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
         // Small grids (a protein of a few thousand atoms has ~1000 cells) get fewer cells per wave: the chip is far from full
         // and a wave's cells are a serial chain (1tqn_h stand-in: 22 -> 16 us).
-        static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 3));
+        // (twelve since the waves of a block CLAIM their work: a longer list per block evens out better — 1 M atoms 196 -> 176 us —;
+        // three was the optimum of the static three-cells-per-wave assignment)
+        static const int cpw_max = std::max(1, env_int("ARP_SEARCH_CPW", 12));
         const int cpw = std::max(1, std::min(cpw_max, c->atom_grid.d.ncell / (SEARCH_WAVES * 2 * c->num_cu)));
+        // tiles of two x-adjacent cells (k_search): fewer, fuller units — worth it where a wave still has several to claim
+        static const int tile_mode = env_int("ARP_SEARCH_TILE", -1);      // -1: by size, 1 / 2: always
+        static const int tile_min_cells = env_int("ARP_SEARCH_TILE_MIN_CELLS", 60000);
+        const int tile_x = tile_mode > 0 ? std::min(tile_mode, 2) : (c->atom_grid.d.ncell >= tile_min_cells ? 2 : 1);
         // Sparse grids (fewer atoms than cells: a protein in its box, a ligand's selection_plus, a batch): the blocks split the
         // ATOMS of the grid evenly instead of its cells (k_search, cell_of_pos) and their number goes with the atoms — what the
         // grid's build reported last time, all atoms of the structure before that is known.
@@ -1373,11 +1379,19 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             nbk = (nbk + 7) & ~7;
             nblocks_search = (R >= 8 && 2 * nbk >= R) ? std::min(std::max(1, (nbk + R / 2) / R) * R, 8192) & ~7 : nbk;
         }
-        hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
-                           c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                           include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
-                           c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
-                           by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
+        if (tile_x == 2) {
+            hipLaunchKernelGGL((k_search<MODE_CONTACTS, 2>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
+                               c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
+                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                               c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
+                               by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
+        } else {
+            hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
+                               c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
+                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                               c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
+                               by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
+        }
         return check_launch(c, "k_search<CONTACTS>");
     };
     bool lists_forked = false;

@@ -756,7 +756,9 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 __device__ unsigned long long* g_search_trace = nullptr;
 #endif
 
-template <int MODE>
+// TX: x-adjacent home cells per tile (1 or 2; a template parameter: with one cell per tile the column rules below vanish at
+// compile time — as a run-time value they cost the small grids 3 us)
+template <int MODE, int TX = 1>
 __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(GridDesc g, const int* __restrict__ start,
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
@@ -784,10 +786,15 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     const int per = nb >> 3;
     int vb = blockIdx.x;
     if (per > 0 && blockIdx.x < per * 8) vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    // waves of a block interleave over the block's run of cells (balances empty regions)
-    const int cells_per_block = (g.ncell + nb - 1) / nb;
-    int blk_begin = vb * cells_per_block;
-    int c_end = min((vb + 1) * cells_per_block, g.ncell);
+    // The unit of the walk is a TILE of one or two x-adjacent home cells (two: the home atoms of both cells share one
+    // candidate set — the pencils [cx - 1, cx + 2] instead of twice [cx - 1, cx + 1] — so the 32-slot home block and the
+    // 128-slot candidate chunk run fuller, and the set-up of a unit is paid once for two cells).  tile t = row * ntx + cx / 2.
+    const int ntx = (g.nx + TX - 1) / TX;
+    const int ntile = ntx * g.ny * g.nz;
+    const int tiles_per_block = (ntile + nb - 1) / nb;
+    int blk_begin = vb * tiles_per_block;
+    int c_end = min((vb + 1) * tiles_per_block, ntile);
+    auto tile_of_cell = [&](int c) -> int { const int row = c / g.nx; return row * ntx + (c - row * g.nx) / TX; };
     int h_lo = 0, h_hi = INT_MAX;      // positions of the cell-sorted array whose atoms this block takes as HOME atoms
     if (cell_of_pos) {
         // Sparse or clumped grids — a protein in its bounding box, the selection_plus of a ligand inside a large structure, a
@@ -800,8 +807,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         const long long T = start[g.ncell];
         const int p0 = (int)((long long)vb * T / nb), p1 = (int)((long long)(vb + 1) * T / nb);
         if (p1 > p0) {
-            blk_begin = cell_of_pos[p0];
-            c_end = cell_of_pos[p1 - 1] + 1;
+            blk_begin = tile_of_cell(cell_of_pos[p0]);
+            c_end = tile_of_cell(cell_of_pos[p1 - 1]) + 1;
             h_lo = p0; h_hi = p1;
         } else {
             blk_begin = c_end = 0;
@@ -841,25 +848,41 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     //      numbers the home blocks of the 64 cells (lane = cell, a prefix sum over the lanes);
     //   C  every wave takes the next home block with an LDS atomic until none is left.
     __shared__ int s_occ[64 * SEARCH_WAVES];
-    __shared__ int s_info[8 * SEARCH_WAVES][12];      // per cell: start of ranges 0..4, end of the home cell, -, length of ranges 0..4
+    // per tile: [0..4] start of ranges 0..4, [5] end of the home atoms, [6] end of the FIRST home cell, [7..11] length of ranges
+    // 0..4, [12..15] where column cx begins in forward rows 1..4 (candidates before it are column cx - 1: neighbours of the first
+    // home cell only), [16..19] where column cx + TX begins there (candidates from it on: neighbours of the last home cell only),
+    // [20] start of the LAST home cell
+    __shared__ __attribute__((aligned(16))) int s_info[8 * SEARCH_WAVES][24];
     __shared__ int s_nocc, s_next;
     __shared__ int s_upre[65];
     constexpr int CLAIM_CELLS = 8 * SEARCH_WAVES;
-    constexpr int CAND_SPAN = 1024;      // candidates of a cell one unit tests its home block against (a multiple of 128)
+    constexpr int CAND_SPAN = 1024;      // candidates of a tile one unit tests its home block against (a multiple of 128)
+    auto tile_cell0 = [&](int t, int& cx, int& cy, int& cz) -> int {      // first cell of tile t
+        const int row = t / ntx;
+        cx = (t - row * ntx) * TX;
+        cz = row / g.ny;
+        cy = row - cz * g.ny;
+        return row * g.nx + cx;
+    };
     for (int win = blk_begin; win < c_end; win += 64 * SEARCH_WAVES) {
-     const bool listed = c_end - win > CLAIM_CELLS;      // (a short run: every cell of it is looked at, stage A would be a round trip for nothing)
+     const bool listed = c_end - win > CLAIM_CELLS;      // (a short run: every tile of it is looked at, stage A would be a round trip for nothing)
      int nocc = min(c_end - win, CLAIM_CELLS);
      if (listed) {
         __syncthreads();
         if (threadIdx.x == 0) s_nocc = 0;
         __syncthreads();
-        const int cell = win + (int)threadIdx.x;
-        const bool oc = cell < c_end && start[cell + 1] != start[cell];
+        const int tile = win + (int)threadIdx.x;
+        bool oc = false;
+        if (tile < c_end) {
+            int cx, cy, cz;
+            const int c0 = tile_cell0(tile, cx, cy, cz);
+            oc = start[c0 + min(TX, g.nx - cx)] != start[c0];
+        }
         const unsigned long long m = __ballot(oc);
         int base = 0;
         if (lane == 0 && m) base = atomicAdd(&s_nocc, __popcll(m));
         base = __shfl(base, 0);
-        if (oc) s_occ[base + __popcll(m & ((1ull << lane) - 1ull))] = cell;
+        if (oc) s_occ[base + __popcll(m & ((1ull << lane) - 1ull))] = tile;
         __syncthreads();
         nocc = s_nocc;
      }
@@ -867,27 +890,35 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
       const int nk = min(CLAIM_CELLS, nocc - k0);
       {
         const int i = (int)threadIdx.x >> 3, r = (int)threadIdx.x & 7;
-        if (i < nk && r < 6) {
-            const int mycell = listed ? s_occ[k0 + i] : win + i;
-            int my_js = 0, my_len = 0;
-            const int cz = mycell / (g.nx * g.ny);
-            const int rem = mycell - cz * g.nx * g.ny;
-            const int cy = rem / g.nx;
-            const int cx = rem - cy * g.nx;
-            const int dy = (r == 0 || r == 5) ? 0 : (r == 1) ? 1 : (r - 3);
-            const int dz = (r <= 1 || r == 5) ? 0 : 1;
-            const int y2 = cy + dy, z2 = cz + dz;
-            if (r == 5) {
-                my_js = start[mycell + 1];
-            } else if (y2 >= 0 && y2 < g.ny && z2 < g.nz) {
-                const int rowbase = (z2 * g.ny + y2) * g.nx;
-                const int xlo = (r == 0) ? cx : max(cx - 1, 0);
-                const int xhi = min(cx + 1, g.nx - 1);
-                my_js = start[rowbase + xlo];
-                my_len = start[rowbase + xhi + 1] - my_js;
+        if (i < nk && r < 5) {
+            int cx, cy, cz;
+            const int c0 = tile_cell0(listed ? s_occ[k0 + i] : win + i, cx, cy, cz);
+            const int ncol = min(TX, g.nx - cx);                      // home cells of the tile (1 at the end of a row of odd length)
+            if (r == 0) {
+                const int rowbase = c0 - cx;
+                const int hs_ = start[c0], mid = start[c0 + 1], he_ = start[c0 + ncol], end0 = start[rowbase + min(cx + TX + 1, g.nx)];
+                s_info[i][0] = hs_;
+                s_info[i][5] = he_;
+                s_info[i][6] = (ncol > 1) ? mid : he_;               // end of the first home cell
+                s_info[i][20] = (ncol > 1) ? mid : hs_;              // start of the last home cell
+                s_info[i][7] = end0 - hs_;
+            } else {
+                const int dy = (r == 1) ? 1 : (r - 3);
+                const int dz = (r == 1) ? 0 : 1;
+                const int y2 = cy + dy, z2 = cz + dz;
+                int js = 0, len = 0, ca = 0, cb = 0;
+                if (y2 >= 0 && y2 < g.ny && z2 < g.nz) {
+                    const int rowbase = (z2 * g.ny + y2) * g.nx;
+                    js = start[rowbase + max(cx - 1, 0)];
+                    len = start[rowbase + min(cx + TX + 1, g.nx)] - js;
+                    ca = start[rowbase + cx];
+                    cb = start[rowbase + min(cx + TX, g.nx)];
+                }
+                s_info[i][r] = js;
+                s_info[i][7 + r] = len;
+                s_info[i][11 + r] = ca;
+                s_info[i][15 + r] = cb;
             }
-            s_info[i][r] = my_js;
-            if (r < 5) s_info[i][7 + r] = my_len;
         }
         if (threadIdx.x == 0) s_next = 0;
       }
@@ -920,8 +951,13 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         const int uu = u - __builtin_amdgcn_readfirstlane(s_upre[ci]);
         const int4 ia = *reinterpret_cast<const int4*>(&s_info[ci][0]), ib = *reinterpret_cast<const int4*>(&s_info[ci][4]),
                    ic = *reinterpret_cast<const int4*>(&s_info[ci][8]);
+        int4 id = make_int4(0, 0, 0, 0), ie = make_int4(0, 0, 0, 0);
+        if (TX > 1) { id = *reinterpret_cast<const int4*>(&s_info[ci][12]); ie = *reinterpret_cast<const int4*>(&s_info[ci][16]); }
         const int hs = __builtin_amdgcn_readfirstlane(ia.x);
-        const int he = min(__builtin_amdgcn_readfirstlane(ib.y), h_hi);      // (home atoms of this block only)
+        const int he_all = __builtin_amdgcn_readfirstlane(ib.y);            // end of the tile's home atoms = where column cx + TX begins in the home row
+        const int he = min(he_all, h_hi);                                   // (home atoms of this block only)
+        const int n_first = (TX > 1) ? __builtin_amdgcn_readfirstlane(ib.z) - hs : INT_MAX;      // home atoms [0, n_first) are in the first home cell,
+        const int n_last0 = (TX > 1) ? __builtin_amdgcn_readfirstlane(s_info[ci][20]) - hs : 0;  // [n_last0, ...) in the last one (the same cell when the tile has one)
         const int js0 = hs, js1 = __builtin_amdgcn_readfirstlane(ia.y), js2 = __builtin_amdgcn_readfirstlane(ia.z),
                   js3 = __builtin_amdgcn_readfirstlane(ia.w), js4 = __builtin_amdgcn_readfirstlane(ib.x);
         const int o1 = __builtin_amdgcn_readfirstlane(ib.w);      // candidates [0, o1) come from range 0
@@ -929,6 +965,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         const int o3 = o2 + __builtin_amdgcn_readfirstlane(ic.y);
         const int o4 = o3 + __builtin_amdgcn_readfirstlane(ic.z);
         const int total = o4 + __builtin_amdgcn_readfirstlane(ic.w);
+        // column boundaries of the five ranges (range 0 has no column cx - 1; its column cx + TX begins at he_all)
+        const int ca1 = __builtin_amdgcn_readfirstlane(id.x), ca2 = __builtin_amdgcn_readfirstlane(id.y),
+                  ca3 = __builtin_amdgcn_readfirstlane(id.z), ca4 = __builtin_amdgcn_readfirstlane(id.w);
+        const int cb1 = __builtin_amdgcn_readfirstlane(ie.x), cb2 = __builtin_amdgcn_readfirstlane(ie.y),
+                  cb3 = __builtin_amdgcn_readfirstlane(ie.z), cb4 = __builtin_amdgcn_readfirstlane(ie.w);
         const int nks = max((total + CAND_SPAN - 1) / CAND_SPAN, 1);      // candidate spans of this cell (1 unless it is a clump)
         const int hbi = (nks == 1) ? uu : uu / nks;
         const int kb_begin = (uu - hbi * nks) * CAND_SPAN, kb_end = min(total, kb_begin + CAND_SPAN);
@@ -984,13 +1025,32 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                     if ((m_selh == m_hvalid && ms0 == mv0 && ms1 == mv1) || (m_selh == 0 && ms0 == 0 && ms1 == 0)) continue;
                 }
                 const int t0 = hb - hs;
-                if (MODE != MODE_MARK && !count_owned) {
-                    // tests of this chunk, in closed form (candidate k of the home pencil meets home atom t iff k > t; every other
-                    // candidate meets every home atom): the loop below need not count
-                    const int c0 = kk0 < 0 ? 0 : (kk0 == INT_MAX ? hcount : min(max(kk0 - t0, 0), hcount));
-                    const int c1 = kk1 < 0 ? 0 : (kk1 == INT_MAX ? hcount : min(max(kk1 - t0, 0), hcount));
-                    n_cand += (unsigned)(c0 + c1);
+                // Which (home atom, candidate) pairs are tested — bit hh = home atom t0 + hh: a candidate k of the home pencil meets
+                // home atom t iff k > t; a candidate of column cx - 1 meets the atoms of the FIRST home cell only, one of column
+                // cx + TX those of the LAST one (the cells of a pair must be neighbours: SURVEY 8d's candidate pair); every other
+                // candidate meets every home atom.  The masks do not depend on the distances: the tests are counted from them.
+                uint32_t te0, te1;
+                {
+                    auto lowmask = [](int c) -> uint32_t { return c >= 32 ? 0xFFFFFFFFu : (c <= 0 ? 0u : ((1u << c) - 1u)); };
+                    const uint32_t m_first = lowmask(n_first - t0), m_last = ~lowmask(n_last0 - t0);
+                    auto tested = [&](int k, int kk, int j) -> uint32_t {
+                        if (kk < 0) return 0u;
+                        uint32_t m = (kk == INT_MAX) ? 0xFFFFFFFFu : lowmask(kk - t0);
+                        if (TX > 1) {
+                            int ca = INT_MIN, cb = he_all;                  // range 0
+                            ca = (k >= o1) ? ca1 : ca; cb = (k >= o1) ? cb1 : cb;
+                            ca = (k >= o2) ? ca2 : ca; cb = (k >= o2) ? cb2 : cb;
+                            ca = (k >= o3) ? ca3 : ca; cb = (k >= o3) ? cb3 : cb;
+                            ca = (k >= o4) ? ca4 : ca; cb = (k >= o4) ? cb4 : cb;
+                            m &= (j < ca) ? m_first : 0xFFFFFFFFu;
+                            m &= (j >= cb) ? m_last : 0xFFFFFFFFu;
+                        }
+                        return m;
+                    };
+                    te0 = tested(k0, kk0, j0);
+                    te1 = tested(k1, kk1, j1);
                 }
+                if (MODE != MODE_MARK && !count_owned) n_cand += __popc(te0 & m_hvalid) + __popc(te1 & m_hvalid);
                 // ---- stage 1: distance tests only.  Bit hh of lo/hi = candidate within r2_lo / r2_hi of home atom hh.
                 // float32 pre-filter: |d2f - d2| <= 4e-7 * d2 (three rounded differences, three rounded squares, two
                 // rounded sums), so outside the +-1e-5 band the float32 answer IS the float64 answer.
@@ -1013,20 +1073,14 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                     hi1 = shl1_or_le(hi1, d1, r2_hi);
                     if (count_owned) {
                         // sharded run: a boundary pair is tested on two ranks; count it for the owner of its bgn atom only
-                        const int t = t0 + hh;
-                        const bool te0 = kk0 > t, te1 = kk1 > t;
+                        const bool tb0 = (te0 >> hh) & 1u, tb1 = (te1 >> hh) & 1u;
                         const int lh = __builtin_amdgcn_readlane(hauxreg.x, hh);
                         const uint32_t mh0 = __builtin_amdgcn_readlane(__float_as_uint(hreg.w), hh);
-                        n_cand += (unsigned)(te0 && (((lh < a0.x) ? mh0 : mj0) & M_HOME));
-                        n_cand += (unsigned)(te1 && (((lh < a1.x) ? mh0 : mj1) & M_HOME));
+                        n_cand += (unsigned)(tb0 && (((lh < a0.x) ? mh0 : mj0) & M_HOME));
+                        n_cand += (unsigned)(tb1 && (((lh < a1.x) ? mh0 : mj1) & M_HOME));
                     }
                 }
-                {   // pairs that are tested: candidate k of the home pencil meets home atom t iff k > t (bit hh <-> t = t0 + hh)
-                    auto tested = [&](int kk) -> uint32_t {
-                        const int c = kk - t0;
-                        return kk < 0 ? 0u : (c >= 32 ? 0xFFFFFFFFu : (c <= 0 ? 0u : ((1u << c) - 1u)));
-                    };
-                    uint32_t te0 = tested(kk0), te1 = tested(kk1);
+                {   // only the pairs that are to be tested count as hits
                     if (MODE == MODE_MARK) {   // ... and, for the expansion, only pairs with exactly one selected atom
                         te0 &= selj0 ? ~m_selh : m_selh;
                         te1 &= selj1 ? ~m_selh : m_selh;
