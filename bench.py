@@ -689,9 +689,14 @@ def main():
     except (OSError, ValueError):
         pj = None
     traffic = traffic_src = None
+    committed = None
     if pj is not None and f'k_{dom}' in pj.get('kernels', {}):
         traffic = pj['kernels'][f'k_{dom}'].get('hbm_bytes_per_launch')
         traffic_src = pj.get('source')
+        ns = pj['kernels'][f'k_{dom}'].get('rocprof_avg_ns')
+        if ns:      # the same figure with rocprofv3's average duration of the committed profile (HIP-event brackets read 1 - 2 us long)
+            committed = {'avg_launch_ms': round(ns * 1e-6, 5), 'achieved': round(b_alg / (ns * 1e-9) / 1e9, 2),
+                         'frac': round(b_alg / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 6), 'source': pj.get('source')}
     # The number that actually bounds these kernels: VALU issue.  SQ_INSTS_VALU of the committed PMC run (per launch) /
     # (launch duration x 1024 SIMDs x 2.4 GHz / 4 cycles: a wave64 instruction occupies its 16-lane SIMD four cycles)
     VALU_PEAK = 1024 * 2.4e9 / 4.0
@@ -715,7 +720,7 @@ def main():
                 'bytes_model': {'bin': 'SURVEY 8d bin + sort / scatter passes: 92 N', 'search': 'SURVEY 8d: each sorted record once, 32 N + 4 (C + 1); the 8 B / pair list it writes is an intermediate of the split design, not counted',
                                 'sift': 'SURVEY 8d: side arrays + output records, 16 N + 16 P; the pair list and the record gathers are not counted',
                                 'mark_search': '32 N + 4 (C + 1)'}[dom],
-                'avg_launch_ms': round(dom_ms, 5),
+                'avg_launch_ms': round(dom_ms, 5), 'with_rocprofv3_duration_of_the_committed_profile': committed,
                 'dominant_kernel_rule': 'longest average HIP-event duration among the kernels of the pass in this run (kernel_ms)',
                 'note': 'VALU-issue-bound geometry kernels (roofline_valu); the HBM fraction is small by construction: register-tiled pair tests '
                         'move ~35 MB per 100 k-atom pass (SURVEY 8d)'}

@@ -87,6 +87,25 @@ int main(void) {
     for (k = 0; k < n; ++k)
         if (ci[k] >= cj[k] || res_id[ci[k]] == res_id[cj[k]] || !(cd[k] <= 5.0f) || (cs[k] & 0x1F) == 0) return 23;
     if (expect != n) { fprintf(stderr, "expected %lld contacts, got %lld\n", (long long)expect, (long long)n); return 24; }
+    /* the canonical (bgn, end) order, made on the device, and every bag with ONE copy (arp_atom_contacts_sort, arp_fetch_packed) */
+    if (arp_atom_contacts_sort(ctx) != ARP_OK) return 25;
+    if (arp_atom_contacts_fetch(ctx, n, ci, cj, cd, cs, ct, &got) != ARP_OK || got != n) return 26;
+    for (k = 1; k < n; ++k)
+        if (ci[k - 1] > ci[k] || (ci[k - 1] == ci[k] && cj[k - 1] >= cj[k])) return 27;
+    {
+        uint64_t off[ARP_PACKED_OFFSETS], used = 0;
+        int64_t pc[5];
+        void* host = NULL;
+        if (arp_fetch_packed(ctx, NULL, 0, pc, off, &used) != ARP_E_CAPACITY || used == 0) return 28;   /* asks for the size first */
+        if (arp_host_alloc(used, &host) != ARP_OK) return 29;
+        if (arp_fetch_packed(ctx, host, used, pc, off, &used) != ARP_OK || pc[0] != n) return 30;
+        const int32_t* pi = (const int32_t*)((const char*)host + off[0]);
+        const int32_t* pj = (const int32_t*)((const char*)host + off[1]);
+        const float* pd = (const float*)((const char*)host + off[2]);
+        for (k = 0; k < n; ++k)
+            if (pi[k] != ci[k] || pj[k] != cj[k] || pd[k] != cd[k]) return 31;
+        arp_host_free(host);
+    }
     printf("GPU_OK %lld contacts\n", (long long)n);
     arp_destroy(ctx);
     free(ci); free(cj); free(cd); free(cs); free(ct); free(blob);
