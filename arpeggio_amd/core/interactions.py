@@ -378,6 +378,17 @@ class InteractionComplex:
         raise NotImplementedError('write_binding_site_sifts raises TypeError in the reference (interactions.py:401-402); '
                                   'see potential_fsift() / atom_sifts() for its inputs')
 
+    def minimize_hydrogens(self, minimisation_forcefield='MMFF94', minimisation_method='ConjugateGradients', minimisation_steps=50):
+        """I:214-269 is an OpenBabel force-field run over the hydrogens before ``initialize()`` — SURVEY row 9, outside the
+        path this package replaces.  Run it with the reference (or any tool) and hand over the hydrogenated file."""
+        raise NotImplementedError('minimize_hydrogens is OpenBabel force-field code (interactions.py:214-269), outside the '
+                                  'run_arpeggio path: minimise with OpenBabel first and pass the resulting mmCIF file')
+
+    def write_hydrogenated(self, wd, input_structure):
+        """I:271-286 writes OpenBabel's molecule after hydrogen addition; this package adds no hydrogens (see ``read_mmcif``)."""
+        raise NotImplementedError('write_hydrogenated writes OpenBabel\'s hydrogenated molecule (interactions.py:271-286); '
+                                  'this package does not add hydrogens')
+
     def potential_fsift(self):
         """``atom.potential_fsift`` (I:1795-1852) as uint8 [n_atoms, 10]."""
         m = export.potential_fsift(self.pc)

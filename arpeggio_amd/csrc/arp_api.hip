@@ -1394,24 +1394,64 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         }
         return check_launch(c, "k_search<CONTACTS>");
     };
+    // the per-pair kernel of the pass; merged_: with the list blocks of the ring / amide loops in front (np of them)
+    AtomPlaneArgs ap{};
+    PlanePlaneArgs pp{};
+    GroupGroupArgs gg{};
+    GroupPlaneArgs gp{};
+    int np = 0;
+    bool sift_launched = false;
+    auto launch_sift = [&](bool merged_) -> int {
+        sift_launched = true;
+        Prof p(c, SLOT_SIFT);
+        static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
+        const SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_rec.p, c->s_b4.p,
+                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
+                          c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
+                          (int*)(c->d_ctr + ctr_dev(C_ERR))};
+        // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
+        // this structure found, or ~13 per heavy atom for the first one.  A protein-sized structure then runs 70-odd blocks
+        // instead of 1024, whose start-up and end-of-pass tickets were most of the kernel (stand-in: 25 -> 16 us).
+        static const int pairs_per_block = std::max(64, env_int("ARP_SIFT_PPB", 256));
+        const int64_t expect = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
+        static const int64_t stream_bytes = (int64_t)env_int("ARP_STREAM_OUT_MB", 96) << 20;
+        const bool stream_out = expect * 15 > stream_bytes;     // (15 B per record)
+        const int by_work = (int)std::min<int64_t>((expect + pairs_per_block - 1) / pairs_per_block + PAIR_SEGS, 1 << 20);
+        const int slots = merged_ ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * sift_blocks_per_cu;
+        const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
+        if (merged_ && stream_out)
+            hipLaunchKernelGGL(k_sift_planes<1>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
+                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
+        else if (merged_)
+            hipLaunchKernelGGL(k_sift_planes<0>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
+                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
+        else if (stream_out)
+            hipLaunchKernelGGL(k_sift<1>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
+        else
+            hipLaunchKernelGGL(k_sift<0>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
+        return check_launch(c, "k_sift");
+    };
+    // A structure's FIRST pass (fork_lists): the list chain (~55 us at 100 k atoms) is longer than grid build + search (~43 us), and
+    // the host needs ~5 us per launch.  So the main stream gets ALL its kernels first — grid, search, per-pair kernel — and the
+    // second stream the lists and, behind them and behind the search (ring / amide masks), their evaluation as a kernel of its own
+    // (k_planes); the two last kernels end the pass together (pass_end: expected = 2).  Later passes evaluate the resident lists
+    // in the leading blocks of the per-pair launch.
     bool lists_forked = false;
     if (fork_lists) {
+        if (c->pub.expected) c->pub.expected = 2;
         CHK(launch_search());
+        HIPCHK(c, hipEventRecord(c->ev_lists, c->stream));              // (the masks are in place)
+        CHK(launch_sift(false));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
         std::swap(c->stream, c->stream2);
         int rc = ensure_center_grids(c);
         if (rc == ARP_OK) rc = ensure_plane_lists(c);
         std::swap(c->stream, c->stream2);
         CHK(rc);
-        HIPCHK(c, hipEventRecord(c->ev_lists, c->stream2));
         lists_forked = true;
     }
     // ---- ring / amide loops (I:938-1382): evaluated from the static candidate lists by the leading blocks of the
     // last launch (ARP_PLANES_MODE=1: as a kernel of their own on the second stream, beside the search)
-    AtomPlaneArgs ap{};
-    PlanePlaneArgs pp{};
-    GroupGroupArgs gg{};
-    GroupPlaneArgs gp{};
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     if (with_planes && c->nring + c->namide > 0) {
         CHK(ensure_center_grids(c));
@@ -1423,7 +1463,6 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     }
     const bool have_planes = n0 + n1 + n2 + n3 > 0;
     // blocks for the list evaluation: one wave per 64 entries, from what the lists held last time (their capacity at first)
-    int np = 0;
     if (have_planes) {
         long long entries = 0;
         for (int k = 0; k < 4; ++k) entries += std::min<long long>((long long)c->plist[k].cap, c->plist_known[k] >= 0 ? c->plist_known[k] + 64 : (long long)c->plist[k].cap / 4);
@@ -1442,49 +1481,22 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         np = (np + 7) & ~7;
     }
     static const int planes_mode = env_int("ARP_PLANES_MODE", 0);   // 0: one grid with the sift kernel; 1: second stream
-    const bool merged = have_planes && c->n > 0 && (planes_mode == 0 || c->external_stream);
-    const bool planes_alone = have_planes && !merged;
+    const bool merged = have_planes && c->n > 0 && !lists_forked && (planes_mode == 0 || c->external_stream);
+    const bool planes_alone = (have_planes && !merged) || lists_forked;   // (forked: launched whatever it holds — it ends the pass with the per-pair kernel)
     hipStream_t st2 = c->external_stream ? c->stream : c->stream2;   // a caller-owned stream: everything in order on it
-    if (planes_alone) {
-        if (c->pub.expected) c->pub.expected = (c->n > 0) ? 2 : 1;
-        if (st2 != c->stream) HIPCHK(c, hipEventRecord(c->ev_sel, c->stream));   // masks (and lists) are in place here
-    }
+    if (planes_alone && !lists_forked && c->pub.expected) c->pub.expected = (c->n > 0) ? 2 : 1;
     CHK(launch_search());
     if (planes_alone) {
-        if (st2 != c->stream) HIPCHK(c, hipStreamWaitEvent(st2, c->ev_sel, 0));
+        if (st2 != c->stream) {      // the ring / amide masks are made by the search launch (or by k_group_masks before it)
+            if (!lists_forked) HIPCHK(c, hipEventRecord(c->ev_lists, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(st2, c->ev_lists, 0));
+        }
         Prof p(c, SLOT_PLANES, st2);
-        hipLaunchKernelGGL(k_planes, dim3(np), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + ctr_dev(C_PLIST), c->pub);
+        hipLaunchKernelGGL(k_planes, dim3(std::max(np, 8)), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + ctr_dev(C_PLIST), c->pub);
         CHK(check_launch(c, "k_planes"));
     }
-    if (lists_forked) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lists, 0));   // (k_planes on the second stream follows the lists in order)
     if (c->n > 0) {
-        Prof p(c, SLOT_SIFT);
-        static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
-        const SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_rec.p, c->s_b4.p,
-                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
-                          c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
-                          (int*)(c->d_ctr + ctr_dev(C_ERR))};
-        // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
-        // this structure found, or ~13 per heavy atom for the first one.  A protein-sized structure then runs 70-odd blocks
-        // instead of 1024, whose start-up and end-of-pass tickets were most of the kernel (stand-in: 25 -> 16 us).
-        static const int pairs_per_block = std::max(64, env_int("ARP_SIFT_PPB", 256));
-        const int64_t expect = (c->contacts_expected > 0) ? c->contacts_expected : (int64_t)c->n * 13;
-        static const int64_t stream_bytes = (int64_t)env_int("ARP_STREAM_OUT_MB", 96) << 20;
-        const bool stream_out = expect * 15 > stream_bytes;     // (15 B per record)
-        const int by_work = (int)std::min<int64_t>((expect + pairs_per_block - 1) / pairs_per_block + PAIR_SEGS, 1 << 20);
-        const int slots = merged ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * sift_blocks_per_cu;
-        const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
-        if (merged && stream_out)
-            hipLaunchKernelGGL(k_sift_planes<1>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
-                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
-        else if (merged)
-            hipLaunchKernelGGL(k_sift_planes<0>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
-                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
-        else if (stream_out)
-            hipLaunchKernelGGL(k_sift<1>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
-        else
-            hipLaunchKernelGGL(k_sift<0>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
-        CHK(check_launch(c, "k_sift"));
+        if (!sift_launched) CHK(launch_sift(merged));
     } else if (!planes_alone) {
         c->pub.expected = 0;   // nothing was launched that could publish: the caller falls back to k_publish_counters
     }
