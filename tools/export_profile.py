@@ -2,7 +2,7 @@
 """Export a tools/profile.sh run (gpurun_out/prof_<tag>) into profiles/: kernel stats, per-launch PMC
 averages and the corrected HBM traffic per launch that bench.py quotes in `roofline.traffic`.
 
-    python tools/export_profile.py gpurun_out/prof_r1c round1_c
+    python tools/export_profile.py gpurun_out/prof_r1c round1_c [traffic.json: profiles/pmc_traffic.json, the one bench.py reads for its default workload]
 
 Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
 (16 B per lane) coalesced stream, so it is doubled; WRITE_SIZE is used as printed — it was calibrated here
@@ -22,6 +22,7 @@ import json
 import sys
 
 base, tag = sys.argv[1], sys.argv[2]
+traffic_json = sys.argv[3] if len(sys.argv) > 3 else 'profiles/pmc_traffic.json'
 rows = list(csv.DictReader(open(f'{base}/trace/t_kernel_stats.csv')))
 with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as f:
     w = csv.writer(f)
@@ -82,7 +83,7 @@ for k, v in out.items():
 json.dump({'source': f'{tag} (tools/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes)',
            'correction': 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of a 16 B/lane stream); k_sift: '
                          'FETCH_SIZE + WRITE_SIZE + 4 B x pairs (line fills of gathers are counted in full: tools/calibrate_pmc_gather.py)',
-           'kernels': traffic}, open('profiles/pmc_traffic.json', 'w'), indent=1)
+           'kernels': traffic}, open(traffic_json, 'w'), indent=1)
 for k in ('k_search', 'k_sift', 'k_mark_search', 'k_scatter_atoms'):
     if k in traffic:
         print(k, traffic[k])
