@@ -71,7 +71,7 @@ for k, v in out.items():
            'void k_search<2, 1>': 'k_mark_search', 'k_compact_atoms': 'k_bin', 'k_sift_planes': 'k_sift',
            'void k_sift_planes<0>': 'k_sift', 'void k_sift<0>': 'k_sift', 'void k_sift_planes<1>': 'k_sift_streaming', 'void k_sift<1>': 'k_sift_streaming'}.get(k, k)
     all_streams = int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024)
-    if key == 'k_sift' and n_pairs is not None:
+    if key in ('k_sift', 'k_sift_streaming') and n_pairs is not None:
         hbm = int((v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 + 4 * n_pairs)
         model = 'gathers counted in full + half of the 8 B/pair list stream added back'
     else:
