@@ -205,6 +205,8 @@ struct arp_ctx {
     int64_t max_res_id = -1, max_ring_res = -1, max_amide_res = -1;   // host-side range checks of the uploaded indices
     bool sel_made = false;
     bool sel_uploaded = false;   // arp_set_selection / arp_set_selection_state since the last arp_set_atoms
+    bool sel_prefilled = false;  // sel already holds the default selection (all ones) for the resident structure: written while arp_set_blob waited for the validation
+    size_t sp_cnt_zeroed = 0;    // leading ints of sp_cnt cleared the same way (ensure_static's fill of a fresh structure)
     bool sel_all = false;        // the uploaded selection covers every atom: selection_plus = selection, no expansion search
     int64_t nsel = -1;            // selected atoms of the uploaded mask; their indices are in sel_list when nsel <= SMALL_SEL_MAX
     DevBuf<int> sel_list;
@@ -649,11 +651,13 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
             HIPCHK(c, hipMemcpyAsync(keep_longest, c->sp_cnt.p, sizeof(keep_longest), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
+        const bool cleared = c->sp_cnt.cap >= want && c->sp_cnt_zeroed >= want;      // (arp_set_blob did, while it waited for the validation)
+        c->sp_cnt_zeroed = 0;
         HIPCHK(c, c->sp_cnt.reserve(want));
         int* const hist = c->sp_cnt.p + 4;
         c->longest_bond.borrow(c->sp_cnt.p, 2);
         if (columns) {
-            HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, want * sizeof(int), c->stream));
+            if (!cleared) HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, want * sizeof(int), c->stream));
             hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p, c->st_b4.p,
                                d, hist, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
         } else {
@@ -677,6 +681,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         c->sp_grid = d;
     }
     else {      // no atoms: nothing to order; the two longest-distance words still exist (zero)
+        c->sp_cnt_zeroed = 0;
         HIPCHK(c, c->sp_cnt.reserve(8));
         HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, 8 * sizeof(int), c->stream));
         c->longest_bond.borrow(c->sp_cnt.p, 2);
@@ -1078,15 +1083,21 @@ int enqueue_selection(arp_ctx* c, double radius) {   // the whole _make_selectio
     return enqueue_selection_sets(c, c->stream);
 }
 
+// the default selection of a structure nobody uploaded one for: everything (I:1395 with no selectors)
+int default_selection(arp_ctx* c) {
+    if (c->sel_uploaded) return ARP_OK;
+    const size_t n = (size_t)std::max<int64_t>(c->n, 1);
+    HIPCHK(c, c->sel.reserve(n));
+    if (!c->sel_prefilled) HIPCHK(c, hipMemsetAsync(c->sel.p, 1, n, c->stream));
+    c->sel_prefilled = false;
+    c->sel_all = true;
+    c->sel_uploaded = true;
+    return ARP_OK;
+}
+
 int ensure_default_selection(arp_ctx* c) {  // whole structure selected (I:1395 with no selectors)
     if (c->sel_made) return ARP_OK;
-    if (!c->sel_uploaded) {
-        const size_t n = (size_t)std::max<int64_t>(c->n, 1);
-        HIPCHK(c, c->sel.reserve(n));
-        HIPCHK(c, hipMemsetAsync(c->sel.p, 1, n, c->stream));
-        c->sel_all = true;
-        c->sel_uploaded = true;
-    }
+    CHK(default_selection(c));
     return enqueue_selection(c, 6.0);   // an uploaded selection that was not expanded yet is expanded here
 }
 
@@ -1853,6 +1864,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     batch_reset(c);
     c->sel_made = false;
     c->sel_uploaded = false;   // a new structure starts with the default selection: everything (I:1395)
+    c->sel_prefilled = false;
     c->nsel = -1;
     c->sel_all = false;
     c->whole_structure = false;
@@ -2181,9 +2193,18 @@ void borrow_blob_views(arp_ctx* c, const arp_blob_header& h) {
 // structure.  Waits for the stream.  `also` = further device error words OR-ed in (shard assembly), may be null.
 int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr, bool gather_sb = false) {
     int* const d_err = (int*)(c->d_ctr + ctr_dev(C_ERR));
+    // The verdict reaches the host the way the counters of a pass do: the last block of the kernel stores the counter block in
+    // the pinned mirror and the host polls the completion word (pass_end) — no copy launch behind the kernel, no
+    // hipStreamSynchronize (~15 us per structure).  That needs the whole block zero at the start (its tickets live there) and
+    // leaves it zero.  With further device words to read (`also`) or a caller-owned stream: a copy and a stream wait.
+    const bool polled = !also && !c->external_stream;
     const bool counters_were_zero = c->ctr_zero_ok;      // (the error word is the only counter touched here, and it ends as zero when all is well)
+    if (polled) {
+        if (!c->ctr_zero_ok) HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS, c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(u64), c->stream));
+    }
     c->ctr_zero_ok = false;
-    HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(u64), c->stream));
     if (gather_sb) HIPCHK(c, c->sb.reserve((size_t)std::max<int64_t>(h.n, 1)));
     BlobCheck bc;
     bc.n = (int)h.n; bc.nres = (int)h.nres; bc.nbond = (int)h.nbond; bc.nh = (int)h.nh; bc.nring = (int)h.nring; bc.namide = (int)h.namide;
@@ -2197,13 +2218,27 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     bc.h_xyz = c->h_xyz_d.p; bc.sb_nbr = c->blob_sb_nbr.p; bc.ring_c = c->ring_c.p; bc.ring_res = c->ring_res.p;
     bc.am_c = c->am_c.p; bc.am_res = c->am_res.p; bc.err = d_err;
     bc.sb_out = gather_sb ? c->sb.p : nullptr;
+    // The two fills the first pass over a new structure would otherwise begin with ride in this launch (each is ~4 us of
+    // launch on the host and a gap on the device): the default selection and the cleared histogram of the static order.
+    const size_t sel_words = ((size_t)std::max<int64_t>(h.n, 1) + 3) / 4;
+    HIPCHK(c, c->sel.reserve(sel_words * 4));
+    bc.fill_ones = (uint32_t*)c->sel.p; bc.fill_ones_n = (int)sel_words;
+    const size_t zero_ints = std::min<size_t>(c->sp_cnt.cap & ~(size_t)3, (size_t)1 << 30);
+    bc.fill_zero = (int4*)c->sp_cnt.p; bc.fill_zero_n = (int)(zero_ints / 4);
     const int64_t work = std::max({h.n, h.nbond, 3 * h.nh, h.nring, h.namide, h.nres, (int64_t)1});
-    hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256)), dim3(256), 0, c->stream, bc);
+    PublishArgs pub{c->d_ctr, c->h_ctr_pinned, 0, 0};
+    if (polled) { pub.expected = 1; pub.seq = ++c->publish_seq; }
+    hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256, 2048)), dim3(256), 0, c->stream, bc, pub);
     CHK(check_launch(c, "k_validate_blob"));
     int h_err[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(&h_err[0], d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (also) HIPCHK(c, hipMemcpyAsync(&h_err[1], also, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (polled) {
+        CHK(collect_counters(c));
+        h_err[0] = (int)(uint32_t)c->h_ctr[C_ERR];
+    } else {
+        HIPCHK(c, hipMemcpyAsync(&h_err[0], d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (also) HIPCHK(c, hipMemcpyAsync(&h_err[1], also, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     // single-bond neighbour coordinates, ring / amide masks, bookkeeping: as the classic setters leave them
     const size_t n1 = (size_t)std::max<int64_t>(h.n, 1);
     HIPCHK(c, c->sb.reserve(n1));
@@ -2215,6 +2250,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     c->shard_resident = false;
     batch_reset(c);
     c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
+    c->sel_prefilled = true; c->sp_cnt_zeroed = zero_ints;      // (k_validate_blob's fills)
     c->contacts_valid = false;
     c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
@@ -2225,7 +2261,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
                                     "offsets that are not a CSR, or an item that occurs twice)";
         return ARP_E_ARG;
     }
-    c->ctr_zero_ok = counters_were_zero;
+    c->ctr_zero_ok = polled ? true : counters_were_zero;      // (polled: the publishing block returned every counter to zero)
     return ARP_OK;
 }
 }  // namespace
@@ -2743,12 +2779,7 @@ int arp_make_selection(arp_ctx* c, const uint8_t* in_selection, double expand_ra
     if (in_selection) CHK(arp_set_selection(c, in_selection));
     else {
         HIPCHK(c, hipSetDevice(c->device));
-        if (!c->sel_uploaded) {  // nothing uploaded for this structure: whole structure (I:1395)
-            HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
-            HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
-            c->sel_all = true;
-            c->sel_uploaded = true;
-        }
+        CHK(default_selection(c));  // nothing uploaded for this structure: whole structure (I:1395)
     }
     CHK(enqueue_selection(c, expand_radius));
     CHK(read_counters(c));
@@ -3115,12 +3146,7 @@ namespace {
 // give them to the caller separately, so that ONE host thread keeps several contexts busy.
 int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_sequence_adjacent, double expand_radius) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->sel_uploaded) {  // no selection uploaded for this structure: whole structure (I:1395)
-        HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
-        HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
-        c->sel_all = true;
-        c->sel_uploaded = true;
-    }
+    CHK(default_selection(c));  // no selection uploaded for this structure: whole structure (I:1395)
     if (c->whole_structure && !c->sel_all)
         FAIL(c, ARP_E_ARG, "arp_run_launch: arp_set_whole_structure is on but the uploaded selection is partial");
     // every stage enqueued back to back (no host synchronisation, no allocation once the buffers are sized)
@@ -3258,12 +3284,7 @@ int arp_run_stage(arp_ctx* c, int stage, double cutoff, double vdw_comp, int inc
     HIPCHK(c, hipSetDevice(c->device));
     if (stage == 0) {          // I:1384-1424 on the local atoms; exact for the atoms this rank owns
         if (!(expand_radius > 0)) return ARP_E_ARG;
-        if (!c->sel_uploaded) {
-            HIPCHK(c, c->sel.reserve((size_t)std::max<int64_t>(c->n, 1)));
-            HIPCHK(c, hipMemsetAsync(c->sel.p, 1, (size_t)std::max<int64_t>(c->n, 1), c->stream));
-            c->sel_all = true;
-            c->sel_uploaded = true;
-        }
+        CHK(default_selection(c));
         HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS, c->stream));
         c->ctr_clean = true;
         int rc = enqueue_expansion(c, expand_radius);

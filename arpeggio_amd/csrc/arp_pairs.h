@@ -200,43 +200,14 @@ struct BlobCheck {
     const int* am_res;
     int* err;
     float4* sb_out;               // not null: also the coordinates of every atom's single-bond heavy neighbour (k_gather_neighbours' work)
+    // two fills the first pass over the structure would otherwise launch (neither reads the structure): the default selection
+    // (all ones, n bytes) and the cleared words of the static order's histogram
+    uint32_t* fill_ones;          // may be null; fill_ones_n 32-bit words
+    int fill_ones_n;
+    int4* fill_zero;              // may be null; fill_zero_n 16-byte words
+    int fill_zero_n;
 };
-__global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc) {
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
-    bool bad = false;
-    for (int k = gtid; k < bc.nbond; k += gstride) bad |= (unsigned)bc.bond_idx[k] >= (unsigned)bc.n;
-    for (int k = gtid; k < 3 * bc.nh; k += gstride) bad |= !isfinite(bc.h_xyz[k]);
-    for (int k = gtid; k < bc.nring; k += gstride) {
-        bad |= bc.ring_res[k] < -1 || bc.ring_res[k] >= bc.nres;
-        bad |= !(isfinite(bc.ring_c[3 * k]) && isfinite(bc.ring_c[3 * k + 1]) && isfinite(bc.ring_c[3 * k + 2]));
-    }
-    for (int k = gtid; k < bc.namide; k += gstride) {
-        bad |= bc.am_res[k] < -1 || bc.am_res[k] >= bc.nres;
-        bad |= !(isfinite(bc.am_c[3 * k]) && isfinite(bc.am_c[3 * k + 1]) && isfinite(bc.am_c[3 * k + 2]));
-    }
-    for (int k = gtid; k < bc.nres; k += gstride)
-        bad |= bc.res_prev[k] < -1 || bc.res_prev[k] >= bc.nres || bc.res_next[k] < -1 || bc.res_next[k] >= bc.nres;
-    for (int i = gtid; i < bc.n; i += gstride) {
-        const float4 v = bc.xyz[i];
-        bad |= !(v.x >= bc.lo[0] && v.x <= bc.hi[0] && v.y >= bc.lo[1] && v.y <= bc.hi[1] && v.z >= bc.lo[2] && v.z <= bc.hi[2]);   // (NaN fails)
-        bad |= (unsigned)bc.res_id[i] >= (unsigned)bc.nres;
-        const int h0 = bc.h_off[i], h1 = bc.h_off[i + 1], b0 = bc.bond_off[i], b1 = bc.bond_off[i + 1];
-        bad |= h0 < 0 || h1 < h0 || h1 > bc.nh || b0 < 0 || b1 < b0 || b1 > bc.nbond;
-        bad |= (i == 0 && (h0 != 0 || b0 != 0)) || (i == bc.n - 1 && (h1 != bc.nh || b1 != bc.nbond));
-        const double2 rd = bc.rad[i];
-        bad |= !(isfinite(rd.x) && isfinite(rd.y));
-        const unsigned ri = bc.rad_idx[i];
-        bad |= ri != RAD_NONE && ri >= (unsigned)bc.nrad;
-        const int nb = bc.sb_nbr[i];
-        bad |= nb < -1 || nb >= bc.n;
-        if (bc.sb_out) {
-            float4 s_ = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nb >= 0 && nb < bc.n) { s_ = bc.xyz[nb]; s_.w = 1.0f; }
-            bc.sb_out[i] = s_;
-        }
-    }
-    if (bad) atomicExch(bc.err, ARP_E_ARG);
-}
+// (k_validate_blob itself: behind pass_end, which it ends with)
 
 // Once per uploaded structure, ONE launch: the static record columns, the 6 A cell of every atom for their spatial order
 // (histogram + rank in cell: what k_static_bin did as a launch of its own) and the longest bond / atom - hydrogen distance.
@@ -696,6 +667,49 @@ __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(pa.host + C_COUNT, pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- validation of an uploaded structure (BlobCheck above) ------------------------------------------
+// pub.expected = 1: the last block to finish stores the verdict (the counter block with the error word) in the pinned mirror,
+// which the host polls — no copy launch, no stream synchronisation (arp_set_blob); 0: the caller reads bc.err itself.
+__global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc, PublishArgs pub) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int k = gtid; k < bc.nbond; k += gstride) bad |= (unsigned)bc.bond_idx[k] >= (unsigned)bc.n;
+    for (int k = gtid; k < 3 * bc.nh; k += gstride) bad |= !isfinite(bc.h_xyz[k]);
+    for (int k = gtid; k < bc.nring; k += gstride) {
+        bad |= bc.ring_res[k] < -1 || bc.ring_res[k] >= bc.nres;
+        bad |= !(isfinite(bc.ring_c[3 * k]) && isfinite(bc.ring_c[3 * k + 1]) && isfinite(bc.ring_c[3 * k + 2]));
+    }
+    for (int k = gtid; k < bc.namide; k += gstride) {
+        bad |= bc.am_res[k] < -1 || bc.am_res[k] >= bc.nres;
+        bad |= !(isfinite(bc.am_c[3 * k]) && isfinite(bc.am_c[3 * k + 1]) && isfinite(bc.am_c[3 * k + 2]));
+    }
+    for (int k = gtid; k < bc.nres; k += gstride)
+        bad |= bc.res_prev[k] < -1 || bc.res_prev[k] >= bc.nres || bc.res_next[k] < -1 || bc.res_next[k] >= bc.nres;
+    for (int i = gtid; i < bc.n; i += gstride) {
+        const float4 v = bc.xyz[i];
+        bad |= !(v.x >= bc.lo[0] && v.x <= bc.hi[0] && v.y >= bc.lo[1] && v.y <= bc.hi[1] && v.z >= bc.lo[2] && v.z <= bc.hi[2]);   // (NaN fails)
+        bad |= (unsigned)bc.res_id[i] >= (unsigned)bc.nres;
+        const int h0 = bc.h_off[i], h1 = bc.h_off[i + 1], b0 = bc.bond_off[i], b1 = bc.bond_off[i + 1];
+        bad |= h0 < 0 || h1 < h0 || h1 > bc.nh || b0 < 0 || b1 < b0 || b1 > bc.nbond;
+        bad |= (i == 0 && (h0 != 0 || b0 != 0)) || (i == bc.n - 1 && (h1 != bc.nh || b1 != bc.nbond));
+        const double2 rd = bc.rad[i];
+        bad |= !(isfinite(rd.x) && isfinite(rd.y));
+        const unsigned ri = bc.rad_idx[i];
+        bad |= ri != RAD_NONE && ri >= (unsigned)bc.nrad;
+        const int nb = bc.sb_nbr[i];
+        bad |= nb < -1 || nb >= bc.n;
+        if (bc.sb_out) {
+            float4 s_ = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nb >= 0 && nb < bc.n) { s_ = bc.xyz[nb]; s_.w = 1.0f; }
+            bc.sb_out[i] = s_;
+        }
+    }
+    for (int k = gtid; k < bc.fill_ones_n; k += gstride) bc.fill_ones[k] = 0x01010101u;
+    for (int k = gtid; k < bc.fill_zero_n; k += gstride) bc.fill_zero[k] = make_int4(0, 0, 0, 0);
+    if (bad) atomicExch(bc.err, ARP_E_ARG);
+    pass_end(pub, 0);
 }
 
 // ---- neighbour search ---------------------------------------------------------------
