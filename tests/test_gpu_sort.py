@@ -109,3 +109,31 @@ def test_packed_fetch_equals_the_five_fetches(ctx, capi):
         again, buf2 = ctx.fetch_packed(buf)
         assert buf2 is buf
         _same_bag(again['atom_atom'], one_by_one['atom_atom'])
+
+
+def test_packed_fetch_into_pinned_and_pageable_memory(ctx, capi):
+    """The same bytes whatever the host buffer is (page-locked from arp_host_alloc, or plain pageable memory), sorted inside the
+    call or before it, and call after call into the same buffer."""
+    from arpeggio_amd import synth
+    ctx.set_complex(synth.config3(30000, seed=13))
+    counts = ctx.run_launch(5.0, 0.1, False, 6.0)
+    assert counts['atom_atom'] > 100000
+    pinned = capi.pinned_empty(64, np.uint8)
+    a, pinned = ctx.fetch_packed(pinned)
+    a = {n: {k: v.copy() for k, v in b.items()} for n, b in a.items()}
+    key = a['atom_atom']['i'].astype(np.int64) << 32 | a['atom_atom']['j'].astype(np.int64)
+    assert np.all(np.diff(key) > 0)
+    b, pinned2 = ctx.fetch_packed(pinned)                        # (sorted already)
+    assert pinned2 is pinned
+    pageable = np.empty(pinned.nbytes, np.uint8)
+    ctx.run_launch(5.0, 0.1, False, 6.0)                         # (the device's own order again)
+    c_, pageable2 = ctx.fetch_packed(pageable)
+    assert pageable2 is pageable
+    for other in (b, c_):
+        for name, bag in a.items():
+            for k, v in bag.items():
+                assert np.array_equal(other[name][k].view(np.uint8), v.view(np.uint8)), (name, k)
+    for _ in range(10):
+        ctx.run_launch(5.0, 0.1, False, 6.0)
+        d, _ = ctx.fetch_packed(pinned)
+        assert np.array_equal(d['atom_atom']['j'], a['atom_atom']['j']) and np.array_equal(d['atom_atom']['ctype'], a['atom_atom']['ctype'])
