@@ -1592,6 +1592,21 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     A.jbits = idbits;
     A.table = c->sort_table.p;
     A.total = c->sort_total.p;
+    // a small bag: one block groups the records by bgn atom in one launch (k_sort_small)
+    static const int small_mode = env_int("ARP_SORT_SMALL", 1);
+    const bool small = small_mode && k <= (size_t)SORT_SMALL_MAX_RECORDS && idmax + 1 <= (int64_t)SORT_SMALL_MAX_BINS;
+    if (small) {
+        const int nbin = (int)idmax + 1;
+        A.key_out = c->sort_key[0].p;
+        A.val_out = c->sort_val[0].p;
+        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SORT_SMALL_THREADS), 0, c->stream, A, nbin);
+        A.key_in = c->sort_key[0].p;
+        A.val_in = c->sort_val[0].p;
+        hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, A);
+        CHK(check_launch(c, "k_sort_small"));
+        c->contacts_sorted = true;
+        return ARP_OK;
+    }
     int shift = idbits;       // (key = i << idbits | j)
     for (int ps = 0; ps < passes; ++ps) {
         A.first = ps == 0; A.last = 0;

@@ -209,6 +209,73 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortArgs A) {
     }
 }
 
+// A small bag (a protein has ~2 x 10^4 contacts) in ONE launch instead of the six of two radix passes, which are all launch
+// latency at that size: one block counts the records of every bgn atom in LDS (a counter per atom id), scans the counters, and
+// moves key + payload to the start of their atom's run plus a ticket — in ANY order inside the run: k_sort_runs ranks a record
+// by j among the run whatever order the run arrives in.  (The first version kept the counters in global memory: a thread's
+// twenty returning atomics in a row, 2 - 4 us each, made it slower than the radix passes.)
+// One CU's scattered 8-byte stores bound it (1.4 us per 1000 records): 21 k records 46 against 65 us, even at 38 k.
+#define SORT_SMALL_THREADS 1024
+#define SORT_SMALL_MAX_RECORDS 32768
+#define SORT_SMALL_MAX_BINS 12288
+__global__ __launch_bounds__(SORT_SMALL_THREADS) void k_sort_small(SortArgs A, int nbin) {
+    __shared__ int s_cnt[SORT_SMALL_MAX_BINS];
+    __shared__ int s_wsum[SORT_SMALL_THREADS / 64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = (int)A.n;
+    for (int b = tid; b < nbin; b += SORT_SMALL_THREADS) s_cnt[b] = 0;
+    __syncthreads();
+    // (four records per thread and step: 16-byte loads, a quarter of the trips — the block is alone on its CU and a trip is
+    // a memory latency)
+    const int n4 = n >> 2;
+#pragma unroll 2
+    for (int q = tid; q < n4; q += SORT_SMALL_THREADS) {
+        const int4 i4 = reinterpret_cast<const int4*>(A.ci)[q];
+        atomicAdd(&s_cnt[i4.x], 1); atomicAdd(&s_cnt[i4.y], 1); atomicAdd(&s_cnt[i4.z], 1); atomicAdd(&s_cnt[i4.w], 1);
+    }
+    for (int p = (n4 << 2) + tid; p < n; p += SORT_SMALL_THREADS) atomicAdd(&s_cnt[A.ci[p]], 1);
+    __syncthreads();
+    // exclusive scan in place: a contiguous chunk of bins per thread, the chunks' sums scanned over the block
+    const int per = (nbin + SORT_SMALL_THREADS - 1) / SORT_SMALL_THREADS;
+    const int b_lo = min(tid * per, nbin), b_hi = min(b_lo + per, nbin);
+    int mine = 0;
+    for (int b = b_lo; b < b_hi; ++b) mine += s_cnt[b];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int k = 0; k < w; ++k) run += s_wsum[k];
+    for (int b = b_lo; b < b_hi; ++b) {
+        const int c = s_cnt[b];
+        s_cnt[b] = run;
+        run += c;
+    }
+    __syncthreads();
+    auto place = [&](uint32_t i, uint32_t j, float d, uint32_t sf, uint32_t ct) {
+        const int pos = atomicAdd(&s_cnt[i], 1);
+        A.key_out[pos] = ((unsigned long long)i << A.jbits) | (unsigned long long)j;
+        A.val_out[pos] = (unsigned long long)__float_as_uint(d) | ((unsigned long long)sf << 32) | ((unsigned long long)ct << 48);
+    };
+#pragma unroll 2
+    for (int q = tid; q < n4; q += SORT_SMALL_THREADS) {
+        const int4 i4 = reinterpret_cast<const int4*>(A.ci)[q], j4 = reinterpret_cast<const int4*>(A.cj)[q];
+        const float4 d4 = reinterpret_cast<const float4*>(A.d_in)[q];
+        const uint2 s4 = reinterpret_cast<const uint2*>(A.s_in)[q];
+        const uint32_t c4 = reinterpret_cast<const uint32_t*>(A.ct_in)[q];
+        place((uint32_t)i4.x, (uint32_t)j4.x, d4.x, s4.x & 0xFFFFu, c4 & 0xFFu);
+        place((uint32_t)i4.y, (uint32_t)j4.y, d4.y, s4.x >> 16, (c4 >> 8) & 0xFFu);
+        place((uint32_t)i4.z, (uint32_t)j4.z, d4.z, s4.y & 0xFFFFu, (c4 >> 16) & 0xFFu);
+        place((uint32_t)i4.w, (uint32_t)j4.w, d4.w, s4.y >> 16, c4 >> 24);
+    }
+    for (int p = (n4 << 2) + tid; p < n; p += SORT_SMALL_THREADS)
+        place((uint32_t)A.ci[p], (uint32_t)A.cj[p], A.d_in[p], A.s_in[p], A.ct_in[p]);
+}
+
 // After the radix passes: key_in / idx_in sorted by i.  Thread p: the run of records with its i, its rank by j inside the
 // run, the five columns of the sorted bag at run start + rank.
 #define RUN_HALO 64

@@ -137,3 +137,29 @@ def test_packed_fetch_into_pinned_and_pageable_memory(ctx, capi):
         ctx.run_launch(5.0, 0.1, False, 6.0)
         d, _ = ctx.fetch_packed(pinned)
         assert np.array_equal(d['atom_atom']['j'], a['atom_atom']['j']) and np.array_equal(d['atom_atom']['ctype'], a['atom_atom']['ctype'])
+
+
+@pytest.mark.parametrize('n', [300, 2500, 2900])
+def test_small_bags_take_the_one_launch_path_and_agree_with_the_radix_passes(capi, n, monkeypatch):
+    """Bags of up to 32 768 records of structures with up to 12 288 atoms are grouped by bgn atom by ONE block (k_sort_small);
+    the same bag through the radix passes (ARP_SORT_SMALL=0 is read once per process: a sharded id range forces them instead)."""
+    from arpeggio_amd import synth
+    pc = synth.config3(n, seed=31)
+    c = capi.Context(0)
+    try:
+        c.set_complex(pc)
+        cnt = c.atom_contacts_launch(5.0, 0.1, False)
+        assert 0 < cnt <= 32768
+        raw = {k: v.copy() for k, v in c.atom_contacts_fetch(cnt, sort=False).items()}
+        got = {k: v.copy() for k, v in c.atom_contacts_fetch(cnt, sort=True).items()}
+        _same_bag(got, _host_sorted(raw))
+        # global ids beyond the small path's counters: the radix passes order the same records
+        gid = (np.arange(pc.n_atoms, dtype=np.int64) * 40000 + 7).astype(np.int32)
+        c.set_ownership(np.ones(pc.n_atoms, np.uint8), gid)
+        cnt2 = c.atom_contacts_launch(5.0, 0.1, False)
+        assert cnt2 == cnt
+        big = c.atom_contacts_fetch(cnt2, sort=True)
+        assert np.array_equal(big['i'], gid[got['i']]) and np.array_equal(big['j'], gid[got['j']])
+        assert np.array_equal(big['sift'], got['sift']) and np.array_equal(big['dist'].view(np.uint32), got['dist'].view(np.uint32))
+    finally:
+        c.close()
