@@ -7,7 +7,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from arpeggio_amd import _capi, synth  # noqa: E402
 
-blobs = [_capi.pack_blob(synth.config3(100_000, seed=3 + k)) for k in range(3)]
+standin = len(sys.argv) > 1 and sys.argv[1] == 'standin'      # python tools/fresh_probe.py standin: the 5.9 k-atom 1tqn_h stand-in
+blobs = [_capi.pack_blob(synth.proteinlike(seed=2 + k) if standin else synth.config3(100_000, seed=3 + k)) for k in range(3)]
 ctx = _capi.Context(0)
 for rep in range(4):
     for b in blobs:
