@@ -403,7 +403,7 @@ class CifCategory:
         return out
 
 
-BAG_SORT_MAX = 4096       # ARP_BAG_SORT_MAX of include/arpeggio_hip.h
+BAG_SORT_MAX = 8192       # ARP_BAG_SORT_MAX of include/arpeggio_hip.h
 KERNEL_SLOTS = ('bin', 'scan', 'scatter', 'unused', 'search', 'sift', 'mark_search', 'planes')
 
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_pack_segments(PackTable t, uint8_t* __r
 // partners, I:947-1382): the kernels emit them through one atomic counter per bag, i.e. in any order.  A bag of up to
 // BAG_SORT_MAX records is sorted by ONE block (bitonic network in LDS on {first id, second id, record index}); larger bags keep
 // the device's order (the caller sorts them: config 5 has 10^5 records per bag, a protein a few hundred).
-#define BAG_SORT_MAX 4096
+#define BAG_SORT_MAX 8192      // (96 KB of LDS: key + index)
 static_assert(BAG_SORT_MAX == ARP_BAG_SORT_MAX, "include/arpeggio_hip.h");
 struct BagOrderArgs { const int* first[4]; const int* second[4]; int n[4]; uint32_t* perm[4]; };
 __global__ __launch_bounds__(1024) void k_bag_order(BagOrderArgs A) {
@@ -166,6 +166,18 @@ inline dim3 pack_grid(const PackTable& t) {
     uint32_t mx = 0;
     for (int k = 0; k < t.n; ++k) mx = std::max(mx, t.s[k].bytes);
     return dim3(std::min<uint32_t>(std::max<uint32_t>((mx + 16383u) >> 14, 1u), 64u), (unsigned)t.n);
+}
+
+// arp_set_batch: item i belongs to the structure s with off[s] <= i < off[s + 1] (empty structures have none)
+__global__ __launch_bounds__(256) void k_fill_sid(const long long* __restrict__ off, int nstruct, int* __restrict__ sid, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nstruct;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (off[mid] <= i) lo = mid; else hi = mid;
+        }
+        sid[i] = lo;
+    }
 }
 
 enum Slot { SLOT_BIN = 0, SLOT_SCAN = 1, SLOT_SCATTER = 2, SLOT_UNUSED = 3, SLOT_SEARCH = 4, SLOT_SIFT = 5, SLOT_MARK = 6, SLOT_PLANES = 7, NSLOT = 8 };
@@ -235,6 +247,7 @@ struct arp_ctx {
     DevBuf<float4> sp_xyzm;       // the same columns in the spatial order of the structure (what the per-pass grid builds read)
     DevBuf<int4> sp_aux, sp_q1;
     DevBuf<int> sp_cnt;
+    DevBuf<int> sp_sums;         // tile totals of the static order's scan (grids beyond 32768 cells)
     DevBuf<int2> sp_cr;
     DevBuf<int> sp_cell;          // cell of every row of the spatial order
     GridDesc sp_grid{};           // the grid the spatial order was made for
@@ -338,6 +351,7 @@ struct arp_ctx {
     std::vector<int64_t> batch_atom_off, batch_ring_off, batch_amide_off;
     std::vector<double> batch_box;       // 6 per structure: lo xyz, hi xyz
     DevBuf<int> sid_atom, sid_ring, sid_amide;
+    DevBuf<long long> batch_off_dev;   // the three offset tables of arp_set_batch, one after the other
     struct BatchGrid { double radius = 0; bool valid = false; DevBuf<BatchPlace> place; GridDesc d{}; } batch_grid[4];
     // ---- profiling
     bool profiling = false;
@@ -645,7 +659,8 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         // layout of sp_cnt: [longest bond, longest atom - hydrogen distance, 2 words of padding | histogram of ncell + 1 cells]:
         // a fresh structure clears all of it with ONE fill, a new order for resident columns only the histogram
         float keep_longest[2] = {0.0f, 0.0f};
-        const size_t want = std::max<size_t>((size_t)d.ncell + 8, 32768 + 8);     // (the one-block scan reads and writes whole int4s up to its 32768 slots)
+        // (the one-block scan reads and writes whole int4s up to its 32768 slots; the tiled one of larger grids whole tiles)
+        const size_t want = std::max<size_t>(d.ncell > 32768 ? scan_padded(d.ncell) + 8 : (size_t)d.ncell + 8, 32768 + 8);
         const bool regrow = !columns && c->sp_cnt.cap < want;
         if (regrow) {      // (a larger grid for resident columns: the two words survive the reallocation through the host)
             HIPCHK(c, hipMemcpyAsync(keep_longest, c->sp_cnt.p, sizeof(keep_longest), hipMemcpyDeviceToHost, c->stream));
@@ -669,11 +684,12 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         if (d.ncell <= 4096) hipLaunchKernelGGL((k_scan_inplace<4>), dim3(1), dim3(1024), 0, c->stream, hist, d.ncell);
         else if (d.ncell <= 16384) hipLaunchKernelGGL((k_scan_inplace<16>), dim3(1), dim3(1024), 0, c->stream, hist, d.ncell);
         else if (d.ncell <= 32768) hipLaunchKernelGGL((k_scan_inplace<32>), dim3(1), dim3(1024), 0, c->stream, hist, d.ncell);
-        else {      // larger grids: chunks of 4096 cells with a running carry
-            ScanSegs S;
-            memset(&S, 0, sizeof(S));
-            S.p[0] = hist; S.n[0] = d.ncell;
-            hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, c->stream, S);
+        else {      // larger grids (a batch of structures side by side: 10^6 cells): tiles of 16384 counters, two launches — one block
+                    // walking them with a running carry was 177 us of a 64-structure batch's first pass
+            const int ntiles = (d.ncell + TILE_CELLS - 1) / TILE_CELLS;
+            HIPCHK(c, c->sp_sums.reserve((size_t)ntiles + 2));
+            hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, hist, d.ncell, hist, c->sp_sums.p);
+            hipLaunchKernelGGL(k_scan_fix, dim3((d.ncell + 4095) / 4096), dim3(1024), 0, c->stream, hist, d.ncell, c->sp_sums.p, ntiles, (unsigned long long*)nullptr);
         }
         hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, hist, c->st_xyzm.p,
                            c->st_aux.p, c->st_q1.p, c->st_b4.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p, c->sp_b4.p, c->sp_cell.p);
@@ -2898,9 +2914,12 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
         bo.perm[b] = c->bag_perm.p + (size_t)b * BAG_SORT_MAX;
         any_order = any_order || small;
     }
+    // (on the second stream, beside the radix passes of the atom-atom bag: one block per bag, 80 us for a bag of 4096)
+    const bool order_aside = any_order && c->stream2 && !c->external_stream && !c->contacts_sorted;
     if (any_order) {
-        hipLaunchKernelGGL(k_bag_order, dim3(4), dim3(1024), 0, c->stream, bo);
+        hipLaunchKernelGGL(k_bag_order, dim3(4), dim3(1024), 0, order_aside ? c->stream2 : c->stream, bo);
         CHK(check_launch(c, "k_bag_order"));
+        if (order_aside) HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
     }
     for (int b = 0; b < 4; ++b) {
         Bag& g = *bags[b];
@@ -2922,6 +2941,7 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     if (!host || host_bytes < total) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: host buffer too small (bytes_used holds the size needed)");
     c->contacts_sorted = c->contacts_sorted && c->sorted_slab.cap >= total;
     CHK(sort_contacts(c, total - cbytes));
+    if (order_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
     if (t.n > 0) {
         hipLaunchKernelGGL(k_pack_segments, pack_grid(t), dim3(256), 0, c->stream, t, c->sorted_slab.p);
         CHK(check_launch(c, "k_pack_segments"));
@@ -3554,15 +3574,22 @@ int arp_set_batch(arp_ctx* c, int64_t nstruct, const int64_t* atom_off, const in
     c->batch_ring_off.assign(ring_off, ring_off + nstruct + 1);
     c->batch_amide_off.assign(amide_off, amide_off + nstruct + 1);
     c->batch_box.assign(boxes, boxes + 6 * nstruct);
-    auto upload_sid = [&](DevBuf<int>& buf, const int64_t* off, int64_t total) -> int {
-        std::vector<int> h((size_t)std::max<int64_t>(total, 1), 0);
-        for (int64_t s_ = 0; s_ < nstruct; ++s_)
-            for (int64_t i = off[s_]; i < off[s_ + 1]; ++i) h[(size_t)i] = (int)s_;
-        return upload(c, buf, h.data(), h.size());
-    };
-    CHK(upload_sid(c->sid_atom, atom_off, c->n));
-    CHK(upload_sid(c->sid_ring, ring_off, c->nring));
-    CHK(upload_sid(c->sid_amide, amide_off, c->namide));
+    // structure of every atom / ring / amide: made on the device from the three offset tables (building and uploading three
+    // arrays of that length on the host was 160 us of a 64-structure batch)
+    {
+        const size_t m = (size_t)nstruct + 1;
+        std::vector<long long> h(3 * m);
+        for (size_t k = 0; k < m; ++k) { h[k] = atom_off[k]; h[m + k] = ring_off[k]; h[2 * m + k] = amide_off[k]; }
+        CHK(upload(c, c->batch_off_dev, h.data(), h.size()));        // (waits: the staging vector ends here)
+        const int64_t tot[3] = {c->n, c->nring, c->namide};
+        DevBuf<int>* dst[3] = {&c->sid_atom, &c->sid_ring, &c->sid_amide};
+        for (int k = 0; k < 3; ++k) {
+            HIPCHK(c, dst[k]->reserve((size_t)std::max<int64_t>(tot[k], 1)));
+            if (tot[k] > 0)
+                hipLaunchKernelGGL(k_fill_sid, dim3(nblocks(tot[k], 256)), dim3(256), 0, c->stream, c->batch_off_dev.p + k * m, (int)nstruct, dst[k]->p, (long long)tot[k]);
+        }
+        CHK(check_launch(c, "k_fill_sid"));
+    }
     c->batch_n = nstruct;
     c->static_dirty = true; c->lists_dirty = true;
     c->contacts_valid = false;

@@ -286,7 +286,7 @@ int arp_atom_contacts_sort(arp_ctx* ctx);
  * and group-plane by (first id, second id), atom-plane by (ring, atom): the order the
  * reference's loops create the records in (I:947-1382) —, a larger one in the device's order.
  * bytes_used = bytes written; ARP_E_CAPACITY with bytes_used set when host_bytes is too small. */
-#define ARP_BAG_SORT_MAX 4096
+#define ARP_BAG_SORT_MAX 8192
 #define ARP_PACKED_OFFSETS 53
 int arp_fetch_packed(arp_ctx* ctx, void* host, uint64_t host_bytes, int64_t counts[5],
                      uint64_t offsets[ARP_PACKED_OFFSETS], uint64_t* bytes_used);
