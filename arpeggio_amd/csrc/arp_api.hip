@@ -138,28 +138,42 @@ __global__ __launch_bounds__(1024) void k_bag_order(BagOrderArgs A) {
     __shared__ uint32_t s_idx[BAG_SORT_MAX];
     const int b = blockIdx.x, n = A.n[b];
     if (n <= 0 || n > BAG_SORT_MAX) return;
-    int m = 1;
+    int m = 2;
     while (m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += 1024) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < m; i += 1024) {
         s_key[i] = i < n ? (((unsigned long long)(uint32_t)A.first[b][i] << 32) | (unsigned long long)(uint32_t)A.second[b][i]) : ~0ull;
         s_idx[i] = (uint32_t)i;
     }
     __syncthreads();
+    // Bitonic network over m slots.  Every wave owns a contiguous chunk of C slots: the steps whose partners lie inside a chunk
+    // (distance j < C: 81 of the 91 steps of 8192 slots) need no block barrier — a wave's LDS operations are performed in
+    // order — and a step walks the m / 2 PAIRS, not the m slots.  (One barrier per step over all slots: 176 us for 8192.)
+    const int C = max(m / 16, min(m, 128));
+    const int nwave_active = m / C;
+    auto step = [&](int pr, int j, int k) {      // compare-exchange of pair pr at distance j inside the merge of size k
+        const int i = ((pr & ~(j - 1)) << 1) | (pr & (j - 1)), l = i + j;
+        const unsigned long long ka = s_key[i], kb = s_key[l];
+        const uint32_t ia = s_idx[i], ib = s_idx[l];
+        const bool up = (i & k) == 0;
+        const bool gt = ka > kb || (ka == kb && ia > ib);      // (ties by record index: the order is a function of the records)
+        if (gt == up) { s_key[i] = kb; s_key[l] = ka; s_idx[i] = ib; s_idx[l] = ia; }
+    };
     for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < m; i += 1024) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long ka = s_key[i], kb = s_key[l];
-                    const uint32_t ia = s_idx[i], ib = s_idx[l];
-                    const bool up = (i & k) == 0;
-                    const bool gt = ka > kb || (ka == kb && ia > ib);      // (ties by record index: the order is a function of the records)
-                    if (gt == up) { s_key[i] = kb; s_key[l] = ka; s_idx[i] = ib; s_idx[l] = ia; }
-                }
+            if (j >= C) {
+                __syncthreads();
+                for (int pr = tid; pr < (m >> 1); pr += 1024) step(pr, j, k);
+                __syncthreads();
+            } else {
+                if (w < nwave_active)
+                    for (int q = lane; q < (C >> 1); q += 64) step(w * (C >> 1) + q, j, k);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            __syncthreads();
         }
-    for (int i = threadIdx.x; i < n; i += 1024) A.perm[b][i] = s_idx[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) A.perm[b][i] = s_idx[i];
 }
 // blocks per segment: one per 16 KiB of the largest segment, at most 64
 inline dim3 pack_grid(const PackTable& t) {

@@ -163,3 +163,24 @@ def test_small_bags_take_the_one_launch_path_and_agree_with_the_radix_passes(cap
         assert np.array_equal(big['sift'], got['sift']) and np.array_equal(big['dist'].view(np.uint32), got['dist'].view(np.uint32))
     finally:
         c.close()
+
+
+def test_ring_and_amide_bags_of_several_thousand_records_are_ordered_on_the_device(ctx, capi):
+    """Bags of up to ARP_BAG_SORT_MAX (8192) records leave arp_fetch_packed in their canonical order (k_bag_order: bitonic network
+    in LDS, one block per bag); checked against the host order of the same records for bags on both sides of 4096."""
+    from arpeggio_amd import synth
+    seen = []
+    for nr, na, L in ((1500, 1200, 100.0), (1800, 700, 60.0), (900, 700, 60.0)):
+        ctx.set_complex(synth.config5(nr, na, L=L))
+        counts = ctx.run_launch(5.0, 0.1, False, 6.0)
+        bags, _ = ctx.fetch_packed()
+        for name, (_, _, order) in ctx._BAGS.items():
+            m = counts[name]
+            if m == 0:
+                continue
+            seen.append(m)
+            raw = {k: v.copy() for k, v in ctx.fetch_bag(name, sort=False).items()}
+            o = np.lexsort((raw[order[1]], raw[order[0]]))
+            for k, v in raw.items():
+                assert np.array_equal(bags[name][k].view(np.uint8), v[o].view(np.uint8)), (name, k, m)
+    assert any(4096 < m <= capi.BAG_SORT_MAX for m in seen) and any(64 < m <= 4096 for m in seen), seen
