@@ -56,6 +56,19 @@ def test_all_atoms_in_one_cell_more_than_a_wavefront(ctx):
     assert len(got['i']) > 50_000
 
 
+def test_two_thousand_atoms_in_one_cell(ctx):
+    """2000 atoms inside a 4 A box: one home cell whose home blocks (32 atoms x <= 1024 candidates) are units several waves and
+    blocks claim — the clump that used to be a serial chain on one wave; ~1.9 M pairs, runs of ~1000 records per bgn atom in
+    the device sort (far beyond its 64-record LDS window)."""
+    from helpers import random_dense_pack
+    pc = random_dense_pack(22, n=2000, box=4.0)
+    got = _check(ctx, pc)
+    assert len(got['i']) > 1_500_000
+    # the same pass once more (the by-atoms split chosen from the first pass's tests per atom) gives the same records
+    again = ctx.atom_contacts()
+    assert np.array_equal(again['i'], got['i']) and np.array_equal(again['j'], got['j']) and np.array_equal(again['sift'], got['sift'])
+
+
 def test_identical_coordinates_many_atoms(ctx):
     from arpeggio_amd.core import config
     from helpers import tiny_complex
