@@ -2236,7 +2236,7 @@ void borrow_blob_views(arp_ctx* c, const arp_blob_header& h) {
 
 // Device-side validation of the resident blob (what arp_set_atoms ... check on the host) + the bookkeeping of a new
 // structure.  Waits for the stream.  `also` = further device error words OR-ed in (shard assembly), may be null.
-int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr, bool gather_sb = false) {
+int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr, bool gather_sb = false, bool rad_from_table = false) {
     int* const d_err = (int*)(c->d_ctr + ctr_dev(C_ERR));
     // The verdict reaches the host the way the counters of a pass do: the last block of the kernel stores the counter block in
     // the pinned mirror and the host polls the completion word (pass_end) — no copy launch behind the kernel, no
@@ -2263,6 +2263,8 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     bc.h_xyz = c->h_xyz_d.p; bc.sb_nbr = c->blob_sb_nbr.p; bc.ring_c = c->ring_c.p; bc.ring_res = c->ring_res.p;
     bc.am_c = c->am_c.p; bc.am_res = c->am_res.p; bc.err = d_err;
     bc.sb_out = gather_sb ? c->sb.p : nullptr;
+    bc.rad_out = rad_from_table ? (double2*)c->rad.p : nullptr;
+    bc.rad_tab = (const double2*)c->rad_tab.p;
     // The two fills the first pass over a new structure would otherwise begin with ride in this launch (each is ~4 us of
     // launch on the host and a gap on the device): the default selection and the cleared histogram of the static order.
     const size_t sel_words = ((size_t)std::max<int64_t>(h.n, 1) + 3) / 4;
@@ -2318,9 +2320,24 @@ int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
     CHK(check_blob_header(c, h, bytes));
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, c->blob_dev.reserve((size_t)h.bytes));
-    HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, blob, (size_t)h.bytes, hipMemcpyHostToDevice, c->stream));
+    // The per-atom radii (16 of a structure's ~87 bytes per atom) are redundant when every atom's {vdw, cov} pair is in the
+    // blob's table — always, for real structures: a handful of elements —: they stay on the host and the validation kernel
+    // writes them on the device from the table.
+    bool rad_from_table = h.n >= 4096 && h.n_rad > 0 && h.n_rad <= RAD_TABLE;
+    if (rad_from_table) {
+        const uint16_t* ridx = (const uint16_t*)((const uint8_t*)blob + h.off[19]);
+        unsigned any_none = 0;
+        for (int64_t i = 0; i < h.n; ++i) any_none |= (unsigned)(ridx[i] == RAD_NONE);
+        rad_from_table = any_none == 0;
+    }
+    if (rad_from_table) {
+        HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, blob, (size_t)h.off[1], hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->blob_dev.p + h.off[2], (const uint8_t*)blob + h.off[2], (size_t)(h.bytes - h.off[2]), hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->blob_dev.p, blob, (size_t)h.bytes, hipMemcpyHostToDevice, c->stream));
+    }
     borrow_blob_views(c, h);
-    return validate_resident_blob(c, h, "arp_set_blob", nullptr, /*gather_sb=*/true);   // (one launch: checks + single-bond neighbour coordinates)
+    return validate_resident_blob(c, h, "arp_set_blob", nullptr, /*gather_sb=*/true, rad_from_table);   // (one launch: checks + single-bond neighbour coordinates)
 }
 
 int arp_get_blob(arp_ctx* c, void* host, uint64_t cap, uint64_t* bytes) {

@@ -206,6 +206,10 @@ struct BlobCheck {
     int fill_ones_n;
     int4* fill_zero;              // may be null; fill_zero_n 16-byte words
     int fill_zero_n;
+    // not null: the per-atom radii did not travel (every atom's pair is in the table: arp_set_blob skips that sixth of the
+    // upload) and are written here from the table
+    double2* rad_out;
+    const double2* rad_tab;
 };
 // (k_validate_blob itself: behind pass_end, which it ends with)
 
@@ -694,10 +698,17 @@ __global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc, PublishArgs
         const int h0 = bc.h_off[i], h1 = bc.h_off[i + 1], b0 = bc.bond_off[i], b1 = bc.bond_off[i + 1];
         bad |= h0 < 0 || h1 < h0 || h1 > bc.nh || b0 < 0 || b1 < b0 || b1 > bc.nbond;
         bad |= (i == 0 && (h0 != 0 || b0 != 0)) || (i == bc.n - 1 && (h1 != bc.nh || b1 != bc.nbond));
-        const double2 rd = bc.rad[i];
-        bad |= !(isfinite(rd.x) && isfinite(rd.y));
         const unsigned ri = bc.rad_idx[i];
         bad |= ri != RAD_NONE && ri >= (unsigned)bc.nrad;
+        double2 rd;
+        if (bc.rad_out) {
+            rd = bc.rad_tab[min(ri, (unsigned)RAD_TABLE - 1u)];
+            bc.rad_out[i] = rd;
+            bad |= ri == RAD_NONE;      // (the host looked: cannot happen)
+        } else {
+            rd = bc.rad[i];
+        }
+        bad |= !(isfinite(rd.x) && isfinite(rd.y));
         const int nb = bc.sb_nbr[i];
         bad |= nb < -1 || nb >= bc.n;
         if (bc.sb_out) {

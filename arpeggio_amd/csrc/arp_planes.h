@@ -719,7 +719,12 @@ __device__ __forceinline__ void planes_from_lists(const AtomPlaneArgs& ap, const
         const u64 c = L.count[k];
         cnt[k] = (long long)(c < (u64)L.cap[k] ? c : (u64)L.cap[k]);
         chunks[k + 1] = chunks[k] + (cnt[k] + 63) / 64;
-        if (vblock == 0 && threadIdx.x == 0) publish_counts[k] = c;   // the host checks them against the capacities at the end of the pass
+        // the host checks them against the capacities at the end of the pass.  An ATOMIC, like every other write to the counter
+        // block: the block that publishes the counters (pass_end) may run on another XCD — or, on a structure's first pass, in
+        // the other kernel — and reads the memory-side values; a plain store would sit in this XCD's L2 until the kernel ends,
+        // be missed by the publisher and land on the zeroed counter afterwards (the next structure then saw this one's counts:
+        // a spurious "list too small", now and then three times in a row)
+        if (vblock == 0 && threadIdx.x == 0) atomicExch(publish_counts + k, c);
     }
     const long long wave = (long long)vblock * 4 + w, nwave = (long long)vgrid * 4;
     PlaneQueue Q{sh->q[w], 0};

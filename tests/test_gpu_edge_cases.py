@@ -490,3 +490,58 @@ def test_covalent_flag_for_every_bond_count(ctx):
     cov = 1 << config.SIFT_NAMES.index('covalent')
     pairs = {(int(a), int(b)) for a, b, s in zip(got['i'], got['j'], got['sift']) if s & cov}
     assert pairs == {(min(a, b), max(a, b)) for a, b in bonds}
+
+
+def test_blob_round_trip_with_and_without_the_radius_column(capi):
+    """arp_set_blob leaves the per-atom radii on the host when every atom's pair is in the blob's table (structures of 4096 atoms
+    and more) and writes them on the device from the table: what arp_get_blob returns is the uploaded blob, byte for byte, either
+    way — also for a structure with more than 256 distinct radius pairs, whose radii do travel."""
+    from arpeggio_amd import synth
+    for n, many in ((3000, False), (9000, False), (9000, True)):
+        pc = synth.config3(n, seed=17)
+        if many:      # 400 distinct {vdw, cov} pairs: 144 of them cannot be in the table of 256
+            pc.vdw = pc.vdw + (np.arange(pc.n_atoms) % 400) * 1e-3
+        blob = capi.pack_blob(pc)
+        hdr = capi.unpack_blob(blob)['header']
+        assert (int(hdr.n_rad) == 256) == many
+        c = capi.Context(0)
+        try:
+            c.set_blob(blob)
+            back = c.get_blob()
+            assert np.array_equal(np.asarray(back), np.asarray(blob)), (n, many)
+            got = c.atom_contacts()
+            c2 = capi.Context(0)
+            try:
+                c2.set_complex(pc)
+                exp = c2.atom_contacts()
+            finally:
+                c2.close()
+            for k in ('i', 'j', 'sift', 'ctype'):
+                assert np.array_equal(got[k], exp[k]), (n, many, k)
+        finally:
+            c.close()
+
+
+def test_list_counts_of_one_structure_never_reach_the_next(capi):
+    """The entry counts of the ring / amide candidate lists travel with the counters of a pass; they are written with atomics like
+    every other counter (a plain store used to stay in one XCD's L2 past the publication and surface in the NEXT structure's
+    first pass as a list that was 'too small', now and then three times in a row: arp_run_launch -3)."""
+    from arpeggio_amd import synth
+    from helpers import random_dense_pack
+    big = synth.config5(900, 700, L=60.0)
+    rng = np.random.default_rng(3)
+    c = capi.Context(0)
+    try:
+        for k in range(25):
+            c.set_complex(big)
+            n_big = c.run_launch()
+            assert n_big['plane_plane'] > 1000
+            small = random_dense_pack(500 + k, n=200, box=9.0)
+            small.ring_center, small.ring_normal = rng.random((3, 3)) * 9.0, rng.standard_normal((3, 3))
+            small.ring_res = np.zeros(3, np.int32)
+            small.ring_atoms = []
+            c.set_complex(small)
+            n_small = c.run_launch()                  # (must not need three attempts)
+            assert n_small['plane_plane'] <= 3
+    finally:
+        c.close()
