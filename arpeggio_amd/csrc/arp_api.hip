@@ -2322,8 +2322,8 @@ int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
     HIPCHK(c, c->blob_dev.reserve((size_t)h.bytes));
     // The per-atom radii (16 of a structure's ~87 bytes per atom) are redundant when every atom's {vdw, cov} pair is in the
     // blob's table — always, for real structures: a handful of elements —: they stay on the host and the validation kernel
-    // writes them on the device from the table.
-    bool rad_from_table = h.n >= 4096 && h.n_rad > 0 && h.n_rad <= RAD_TABLE;
+    // writes them on the device from the table.  (From 32 768 atoms on: below that the second copy costs more than the bytes.)
+    bool rad_from_table = h.n >= 32768 && h.n_rad > 0 && h.n_rad <= RAD_TABLE;
     if (rad_from_table) {
         const uint16_t* ridx = (const uint16_t*)((const uint8_t*)blob + h.off[19]);
         unsigned any_none = 0;

@@ -493,11 +493,11 @@ def test_covalent_flag_for_every_bond_count(ctx):
 
 
 def test_blob_round_trip_with_and_without_the_radius_column(capi):
-    """arp_set_blob leaves the per-atom radii on the host when every atom's pair is in the blob's table (structures of 4096 atoms
-    and more) and writes them on the device from the table: what arp_get_blob returns is the uploaded blob, byte for byte, either
+    """arp_set_blob leaves the per-atom radii on the host when every atom's pair is in the blob's table (structures of 32 768 atoms
+    and more: below that a second copy costs more than the bytes) and writes them on the device from the table: what arp_get_blob returns is the uploaded blob, byte for byte, either
     way — also for a structure with more than 256 distinct radius pairs, whose radii do travel."""
     from arpeggio_amd import synth
-    for n, many in ((3000, False), (9000, False), (9000, True)):
+    for n, many in ((3000, False), (40000, False), (40000, True)):
         pc = synth.config3(n, seed=17)
         if many:      # 400 distinct {vdw, cov} pairs: 144 of them cannot be in the table of 256
             pc.vdw = pc.vdw + (np.arange(pc.n_atoms) % 400) * 1e-3
