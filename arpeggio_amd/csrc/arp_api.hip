@@ -851,7 +851,9 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
     CHK(ensure_static(c, radius));
     if (n > 0) {
         Prof p(c, SLOT_BIN);
-        const int nb = (n + COMPACT_THREADS - 1) / COMPACT_THREADS;
+        static const int compact_small_max = env_int("ARP_COMPACT_512_MAX_ROWS", 150000);
+        const int rows_per_block = n <= compact_small_max ? 512 : 1024;
+        const int nb = (n + rows_per_block - 1) / rows_per_block;
         bool fresh = false;
         HIPCHK(c, c->compact_chain.reserve((size_t)nb, &fresh));
         if (fresh || c->compact_epoch >= (1u << 30) - 1u) {   // new buffer, or the 30-bit launch number wraps: no stale word may match
@@ -867,7 +869,8 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
         A.s_cell = c->s_cell.p;
         A.start = G.start.p; A.chain = c->compact_chain.p; A.epoch = c->compact_epoch; A.total_out = total_out;
         A.plus_init = plus_init; A.rm = rm; A.err = (int*)(c->d_ctr + ctr_dev(C_ERR));
-        hipLaunchKernelGGL(k_compact_atoms, dim3(nb), dim3(COMPACT_THREADS), 0, c->stream, A);
+        if (rows_per_block == 512) hipLaunchKernelGGL(k_compact_atoms<512>, dim3(nb), dim3(512), 0, c->stream, A);
+        else hipLaunchKernelGGL(k_compact_atoms<1024>, dim3(nb), dim3(1024), 0, c->stream, A);
         CHK(check_launch(c, "k_compact_atoms"));
         c->s_cell_valid = true;
     } else {
