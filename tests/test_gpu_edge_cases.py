@@ -545,3 +545,34 @@ def test_list_counts_of_one_structure_never_reach_the_next(capi):
             assert n_small['plane_plane'] <= 3
     finally:
         c.close()
+
+
+def test_bad_radii_are_rejected_whether_or_not_the_radius_column_travels(capi):
+    """From 32 768 atoms on the per-atom radii are written on the device from the blob's table; a non-finite table entry in
+    use, an index beyond the table, or (radii travelling: an atom outside the table) a non-finite per-atom radius fail the
+    validation either way, and the context takes a good blob afterwards."""
+    from arpeggio_amd import synth
+    pc = synth.config3(40_000, seed=23)
+    c = capi.Context(0)
+    try:
+        def broken(mutate):
+            bad = capi.pack_blob(pc)
+            h = capi.BlobHeader.from_buffer(bad)
+            mutate(bad, h)
+            del h
+            return bad
+        def tab_nan(bad, h): np.frombuffer(bad, np.float64, 2, int(h.off[20]))[0] = np.nan          # entry 0 is in use
+        def idx_range(bad, h): np.frombuffer(bad, np.uint16, 1, int(h.off[19]))[0] = int(h.n_rad)
+        def outside_table_nan(bad, h):                                                                # one atom outside the table: the column travels
+            np.frombuffer(bad, np.uint16, 8, int(h.off[19]))[5] = 0xFFFF
+            np.frombuffer(bad, np.float64, 16, int(h.off[1]))[10] = np.inf
+        for m in (tab_nan, idx_range, outside_table_nan):
+            with pytest.raises(ValueError):
+                c.set_blob(broken(m))
+        def outside_table_ok(bad, h): np.frombuffer(bad, np.uint16, 8, int(h.off[19]))[5] = 0xFFFF    # (its radii are in the column)
+        c.set_blob(broken(outside_table_ok))
+        n1 = c.run_launch()
+        c.set_blob(capi.pack_blob(pc))
+        assert c.run_launch() == n1
+    finally:
+        c.close()
