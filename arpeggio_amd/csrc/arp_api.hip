@@ -249,7 +249,7 @@ struct arp_ctx {
     // ---- derived
     DevBuf<float4> s_xyzm;
     DevBuf<int4> s_aux;
-    DevBuf<SiftRec> s_rec;
+    DevBuf<int4> s_q1;            // second quad of the sift records, cell-sorted (the first one is s_xyzm)
     DevBuf<int> tmp_i32;          // scratch for index uploads
     DevBuf<int4> st_b4, sp_b4, s_b4;   // first bonded neighbours: static, in the spatial order, cell-sorted beside s_rec
     DevBuf<int4> st_q1;           // selection-independent record columns, composed once per structure (k_prepare_static)
@@ -291,7 +291,12 @@ struct arp_ctx {
     hipEvent_t ev_sel = nullptr, ev_planes = nullptr, ev_lists = nullptr;
     DevBuf<uint8_t> tmp_u8;
     // ---- pair list and outputs of the atom-contact pass
-    DevBuf<int2> pairs;
+    DevBuf<int2> pairs;           // arp_search_all: (i, j)
+    // the pair list of a contact pass (PairList, arp_pairs.h): PAIR_SEGS segments of descriptors / group headers / descriptor -> group
+    DevBuf<uint16_t> pl_desc;
+    DevBuf<int4> pl_groups;
+    DevBuf<int> pl_gmap;
+    size_t pl_gcap = 0;           // group headers per segment
     DevBuf<int> out_i, out_j;
     DevBuf<float> out_d;
     DevBuf<uint16_t> out_s;
@@ -737,7 +742,7 @@ StaticAtoms static_atoms(arp_ctx* c) {
 // Grid over the atoms selected by the (req, forb) meta masks (or an explicit mask): three launches —
 // k_bin_atoms (records composed on the fly), scan, k_scatter_atoms (writes the cell-sorted search and
 // sift records directly).
-int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, DevBuf<SiftRec>* srec, double radius,
+int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, DevBuf<int4>* srec, double radius,
                     uint32_t req, uint32_t forb, const uint8_t* active, u64* total_out = nullptr, uint8_t* plus_init = nullptr,
                     hipStream_t st = nullptr, ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
     if (!st) st = c->stream;
@@ -774,7 +779,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
             G.used[1 - G.cur] = 0;
             G.used[G.cur] = ((size_t)ncell + 3) & ~(size_t)3;
         }
-        SiftRec* const rec = srec ? srec->p : (SiftRec*)nullptr;
+        int4* const rec = srec ? srec->p : (int4*)nullptr;
         int4* const b4 = srec ? c->s_b4.p : (int4*)nullptr;
         const int nb = (n + SCAT_ATOMS - 1) / SCAT_ATOMS;
         if (ncell <= SCAN_LDS_CELLS) {   // start table in LDS: scan + scatter in one launch
@@ -833,7 +838,7 @@ int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, c
                        ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
     c->cg_valid = false;      // (the buffers of the pass's grid are rewritten)
     c->s_cell_valid = false;
-    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_rec, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
+    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_q1, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
 }
 // The contact grid of a pass as an ordered compaction of the static columns (k_compact_atoms): ONE launch.
 int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t forb, u64* total_out, uint8_t* plus_init, ResMarks rm) {
@@ -846,7 +851,7 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
     HIPCHK(c, G.start.reserve(scan_padded(ncell)));
     HIPCHK(c, c->s_xyzm.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->s_aux.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->s_rec.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_q1.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->s_b4.reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c, radius));
     if (n > 0) {
@@ -864,7 +869,7 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
         CompactArgs A;
         A.r = static_atoms(c);
         A.sp_cell = c->sp_cell.p; A.n = n; A.ncell = ncell; A.req = req; A.forb = forb;
-        A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_rec = c->s_rec.p; A.s_b4 = c->s_b4.p;
+        A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_q1 = c->s_q1.p; A.s_b4 = c->s_b4.p;
         HIPCHK(c, c->s_cell.reserve((size_t)std::max(n, 1)));
         A.s_cell = c->s_cell.p;
         A.start = G.start.p; A.chain = c->compact_chain.p; A.epoch = c->compact_epoch; A.total_out = total_out;
@@ -1073,7 +1078,7 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
                            c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
-                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
+                           0ull, PairList{}, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
@@ -1381,9 +1386,17 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         CHK(check_launch(c, "k_group_masks"));
     }
     c->contact_cells = c->atom_grid.d.ncell;
-    if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 8192));
-    const size_t segcap = c->pairs.cap / PAIR_SEGS;   // the pair list is PAIR_SEGS segments of segcap entries
+    if (!c->pl_desc.p) HIPCHK(c, c->pl_desc.reserve((size_t)c->n * 16 + 8192));
+    const size_t segcap = (c->pl_desc.cap / PAIR_SEGS) & ~(size_t)63;   // the pair list is PAIR_SEGS segments of segcap descriptors
     const size_t cap = segcap * PAIR_SEGS;
+    // group headers: a group holds the hits of one home block among one chunk of candidates (~70 at protein density, one at
+    // least); sized for 8 per group and grown like the descriptors when a pass needs more
+    if (!c->pl_groups.p || c->pl_gcap == 0) {
+        c->pl_gcap = std::max<size_t>(c->pl_gcap, segcap / 8 + 1024);
+        HIPCHK(c, c->pl_groups.reserve(c->pl_gcap * PAIR_SEGS * GROUP_INT4));
+    }
+    HIPCHK(c, c->pl_gmap.reserve((segcap / 64 + 1) * PAIR_SEGS));
+    const PairList plist_{c->pl_desc.p, c->pl_groups.p, c->pl_gmap.p, (u64)segcap, (u64)c->pl_gcap};
     if (cap >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "contact list beyond 2^32 entries (k_sift's task queue holds 32-bit output indices)");
     HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
@@ -1426,13 +1439,13 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         if (tile_x == 2) {
             hipLaunchKernelGGL((k_search<MODE_CONTACTS, 2>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                               include_seq_adj, c->has_home ? 1 : 0, (int2*)nullptr, (u64)segcap, plist_, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
                                c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
                                by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
         } else {
             hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                               include_seq_adj, c->has_home ? 1 : 0, (int2*)nullptr, (u64)segcap, plist_, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
                                c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
                                by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
         }
@@ -1449,7 +1462,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         sift_launched = true;
         Prof p(c, SLOT_SIFT);
         static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
-        const SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_rec.p, c->s_b4.p,
+        const SiftArgs sa{c->pl_desc.p, c->pl_groups.p, c->pl_gmap.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, (u64)c->pl_gcap, c->s_xyzm.p, c->s_q1.p, c->s_b4.p,
                           SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + ctr_dev(C_ERR))};
@@ -1553,12 +1566,18 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
 
 // After read_counters(): publish contact results; returns true when the pair buffer overflowed.
 bool finish_contacts(arp_ctx* c) {
-    const u64 segcap = c->pairs.cap / PAIR_SEGS;
-    u64 np = 0, worst = 0;
-    for (int k = 0; k < PAIR_SEGS; ++k) { np += c->h_ctr[C_SEG_PAIRS + k]; worst = std::max(worst, c->h_ctr[C_SEG_PAIRS + k]); }
+    const u64 segcap = (c->pl_desc.cap / PAIR_SEGS) & ~(u64)63;
+    u64 np = 0, worst = 0, worst_g = 0;
+    for (int k = 0; k < PAIR_SEGS; ++k) {      // a segment's word: pairs | groups << GROUP_SHIFT
+        const u64 wd = c->h_ctr[C_SEG_PAIRS + k];
+        np += wd & PAIR_MASK;
+        worst = std::max(worst, wd & PAIR_MASK);
+        worst_g = std::max(worst_g, wd >> GROUP_SHIFT);
+    }
     c->h_ctr[C_PAIRS] = np;
     c->h_ctr[C_SCRATCH0] = worst;
-    if (worst > segcap) return true;
+    c->h_ctr[C_SCRATCH1] = worst_g;
+    if (worst > segcap || worst_g > (u64)c->pl_gcap) return true;
     c->n_contacts = (int64_t)np;
     c->contacts_expected = (int64_t)np;
     c->contacts_valid = true;
@@ -1689,9 +1708,16 @@ bool finish_bag(arp_ctx* c, Bag& b, int slot) {
     return false;
 }
 int grow_pairs(arp_ctx* c) {
-    const size_t need = ((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 64) * PAIR_SEGS;
-    c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
-    HIPCHK(c, c->pairs.reserve(need));
+    const size_t segcap = (c->pl_desc.cap / PAIR_SEGS) & ~(size_t)63;
+    if ((size_t)c->h_ctr[C_SCRATCH0] > segcap) {
+        const size_t need = (((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 127) & ~(size_t)63) * PAIR_SEGS;
+        c->pl_desc.release(); c->pl_gmap.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
+        HIPCHK(c, c->pl_desc.reserve(need));
+    }
+    if ((size_t)c->h_ctr[C_SCRATCH1] > c->pl_gcap) {
+        c->pl_gcap = (size_t)c->h_ctr[C_SCRATCH1] + (size_t)c->h_ctr[C_SCRATCH1] / 8 + 64;
+        c->pl_groups.release();
+    }
     return ARP_OK;
 }
 int grow_bag(arp_ctx* c, Bag& b, int slot, bool d, bool f) {
@@ -1811,10 +1837,11 @@ void arp_destroy(arp_ctx* c) {
     c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
-    c->s_xyzm.release(); c->s_aux.release(); c->s_rec.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
+    c->s_xyzm.release(); c->s_aux.release(); c->s_q1.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
     c->sp_xyzm.release(); c->sp_aux.release(); c->sp_q1.release(); c->st_b4.release(); c->sp_b4.release(); c->s_b4.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
-    c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
+    c->pairs.release(); c->pl_desc.release(); c->pl_groups.release(); c->pl_gmap.release(); c->pl_gcap = 0;
+    c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->bag_pack.release(); c->bag_perm.release();
     c->sort_key[0].release(); c->sort_key[1].release(); c->sort_val[0].release(); c->sort_val[1].release();
@@ -2822,7 +2849,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
-                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
+                           (u64)cap, PairList{}, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));

@@ -98,10 +98,10 @@ struct RawAtoms {
     const float4* sb;           // single-bond neighbour xyz, w = present
 };
 
-// 32-byte record read by k_sift for each atom of a pair (two 16-byte gathers; the L1 tag rate is what bounds
-// that kernel, so everything it needs per atom sits in these two quads):
+// What k_sift holds of each atom of a pair (two 16-byte quads, kept as two columns of the cell-sorted grid — s_xyzm, which the
+// search reads as well, and s_q1 — and staged through LDS group by group):
 //   xyzm = x, y, z, meta
-//   q1   = local atom id, bond_off, h_off, bond_cnt | h_cnt << 8 | rad_idx << 16
+//   q1   = local atom id, the record's own sorted position (bond_off in the static column), h_off, bond_cnt | h_cnt << 8 | rad_idx << 16
 // The {vdw, cov} float64 pair of an atom is one of a handful of element values: arp_set_atoms builds a table of the
 // distinct pairs (RAD_TABLE entries at most) and k_sift keeps it in LDS; an atom whose pair did not fit carries
 // RAD_NONE and its radii are fetched from the uploaded array.  Counts saturate at CNT_SAT (then the CSR offsets are
@@ -375,18 +375,18 @@ __global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDes
     }
 }
 
-// one atom's cell-sorted records (search record 32 B; the contact grid adds the 32-byte sift record)
+// one atom's cell-sorted records (search record 32 B; the contact grid adds the second quad of the sift record — with the
+// record's own sorted position in .y — and the first bonded neighbours)
 __device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos, float4* __restrict__ s_xyzm,
-                                            int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec, int4* __restrict__ s_b4) {
+                                            int4* __restrict__ s_aux, int4* __restrict__ s_q1, int4* __restrict__ s_b4) {
     const int4 aux = r.aux[i];
     const float4 xyzm = compose_xyzm(r, i, aux.x);
     s_xyzm[pos] = xyzm;
     s_aux[pos] = aux;
-    if (s_rec) {
-        SiftRec q;
-        q.xyzm = xyzm;
-        q.q1 = r.q1[i];
-        s_rec[pos] = q;
+    if (s_q1) {
+        int4 q = r.q1[i];
+        q.y = pos;
+        s_q1[pos] = q;
         s_b4[pos] = r.b4[i];
     }
 }
@@ -394,12 +394,12 @@ __device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos
 // counting-sort scatter fused with the record build, start table from a separate scan (large grids)
 __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int2* __restrict__ cell_rank,
                                                        const int* __restrict__ start, float4* __restrict__ s_xyzm,
-                                                       int4* __restrict__ s_aux, SiftRec* __restrict__ s_rec, int4* __restrict__ s_b4, GroupMasks gm) {
+                                                       int4* __restrict__ s_aux, int4* __restrict__ s_q1, int4* __restrict__ s_b4, GroupMasks gm) {
     group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 cr = cell_rank[i];
         if (cr.x < 0) continue;
-        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_rec, s_b4);
+        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_q1, s_b4);
     }
 }
 
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
                                                              const int* __restrict__ cell_cnt, int* __restrict__ start,
                                                              unsigned long long* __restrict__ total_out,
                                                              float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
-                                                             SiftRec* __restrict__ s_rec, int4* __restrict__ s_b4, GroupMasks gm) {
+                                                             int4* __restrict__ s_q1, int4* __restrict__ s_b4, GroupMasks gm) {
     extern __shared__ __attribute__((aligned(16))) int s_start[];   // 16 * STEPS * 256 ints
     group_masks(gm, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024);
     __shared__ int s_wtot[16], s_woff[17];
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     const int ii = (i < n) ? i : 0;
     const int4 my_aux = r.aux[ii];
     const float4 my_xyzm = compose_xyzm(r, ii, my_aux.x);
-    const int4 my_q1 = s_rec ? r.q1[ii] : make_int4(0, 0, 0, 0);
-    const int4 my_b4 = s_rec ? r.b4[ii] : make_int4(0, 0, 0, 0);
+    const int4 my_q1 = s_q1 ? r.q1[ii] : make_int4(0, 0, 0, 0);
+    const int4 my_b4 = s_q1 ? r.b4[ii] : make_int4(0, 0, 0, 0);
     int4 v[STEPS];
 #pragma unroll
     for (int k = 0; k < STEPS; ++k) {
@@ -471,11 +471,8 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
         const int pos = s_start[cr.x] + s_woff[cr.x / CHUNK] + cr.y;
         s_xyzm[pos] = my_xyzm;
         s_aux[pos] = my_aux;
-        if (s_rec) {
-            SiftRec q;
-            q.xyzm = my_xyzm;
-            q.q1 = my_q1;
-            s_rec[pos] = q;
+        if (s_q1) {
+            s_q1[pos] = make_int4(my_q1.x, pos, my_q1.z, my_q1.w);
             s_b4[pos] = my_b4;
         }
     }
@@ -496,7 +493,7 @@ struct CompactArgs {
     uint32_t req, forb;        // kept: (meta & req) == req && !(meta & forb)
     float4* s_xyzm;
     int4* s_aux;
-    SiftRec* s_rec;
+    int4* s_q1;                // second quad of the sift record, .y = the row's position in the grid
     int4* s_b4;
     int* start;                // out: ncell + 1
     int* s_cell;               // out: cell of every kept row (k_search splits its blocks by atoms, not by cells, when the grid is sparse)
@@ -592,11 +589,8 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
     if (keep) {
         A.s_xyzm[kp] = xyzm;
         A.s_aux[kp] = aux;
-        if (A.s_rec) {
-            SiftRec q;
-            q.xyzm = xyzm;
-            q.q1 = q1;
-            A.s_rec[kp] = q;
+        if (A.s_q1) {
+            A.s_q1[kp] = make_int4(q1.x, kp, q1.z, q1.w);
             A.s_b4[kp] = b4;
         }
         if (A.s_cell) A.s_cell[kp] = my_cell;
@@ -723,12 +717,41 @@ __global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc, PublishArgs
     pass_end(pub, 0);
 }
 
+// ---- the pair list of a pass: GROUPS + 16-bit descriptors ---------------------------------------------------------
+// k_search<MODE_CONTACTS> does not write (i, j) positions any more (8 bytes per pair, which the per-pair kernel answered with five
+// 16-byte gathers per lane).  It already holds the hits of a unit as 16-bit descriptors {candidate slot, home atom}; those are
+// what it writes, 2 bytes per pair, plus one 64-byte header per GROUP = the hits of one home block (<= 32 home atoms at sorted
+// positions [hb, hb + hcount)) among one 128-candidate chunk [kb, kb + 128) of the unit's candidate list (five contiguous ranges
+// of the cell-sorted arrays).  The per-pair kernel loads a group's home and candidate records COALESCED into LDS once and
+// evaluates its descriptors from there.  Groups and descriptors of a segment (one per XCD) are reserved together by ONE
+// returning atomic on a packed word {pairs: 36 bits, groups: 28 bits}, so the groups of a segment are in the order of their
+// descriptors and tile the descriptor index space without gaps; gmap[f / 64] = the group that holds descriptor f (every
+// multiple of 64), so that a wave of the per-pair kernel can start anywhere.
+//   header, four int4:  {js0, js1, js2, js3} {js4, o1, o2, o3} {o4, total, hb, kb} {first, count, hcount, own index}
+//                       (js = start of a range, o = candidates before it, total = candidates of the unit)
+//   descriptor:         home atom (5 bits) | candidate - kb (7 bits) << 5 | home atom is bgn (lower local id) << 12
+#define GROUP_SHIFT 36
+#define PAIR_MASK ((1ull << GROUP_SHIFT) - 1ull)
+#define GROUP_INT4 4          // int4 words per group header
+struct PairList {
+    uint16_t* desc;           // PAIR_SEGS segments of `cap` descriptors
+    int4* groups;             // PAIR_SEGS segments of `gcap` headers
+    int* gmap;                // PAIR_SEGS segments of `cap / 64 + 1` group indices
+    unsigned long long cap, gcap;
+};
+
 // ---- neighbour search ---------------------------------------------------------------
 #ifndef SEARCH_WAVES
 #define SEARCH_WAVES 8
 #endif
 #ifndef QCAP
-#define QCAP 512
+#define QCAP 512     // MODE_PAIRS: (i, j) pairs a wave queues before it flushes
+#endif
+#ifndef QD_CAP
+#define QD_CAP 1024  // MODE_CONTACTS: descriptors a wave queues ...
+#endif
+#ifndef QG_CAP
+#define QG_CAP 16    // ... in at most this many groups
 #endif
 #ifndef SEARCH_MIN_WAVES
 #define SEARCH_MIN_WAVES 6
@@ -788,7 +811,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
                                                                int include_seq_adj, int count_owned, int2* __restrict__ pairs,
-                                                               unsigned long long cap, u64* __restrict__ ctr_pairs,
+                                                               unsigned long long cap, PairList pl, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus, GroupMasks gm, const int* __restrict__ cell_of_pos) {
     // ring / amide sets of _make_selection (I:1433-1437) from the residue tags the grid build of this pass left: every thread
@@ -798,7 +821,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     unsigned long long t_loops = 0;
 #endif
     group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-    __shared__ int2 q[MODE == MODE_MARK ? 1 : SEARCH_WAVES][QCAP];   // (the expansion search queues nothing)
+    __shared__ int2 q[MODE == MODE_PAIRS ? SEARCH_WAVES : 1][MODE == MODE_PAIRS ? QCAP : 1];   // raw search_all: (i, j) pairs
+    // contact search: descriptors and group headers of the wave (the expansion search queues nothing)
+    __shared__ uint16_t qd[MODE == MODE_CONTACTS ? SEARCH_WAVES : 1][MODE == MODE_CONTACTS ? QD_CAP : 1];
+    __shared__ int4 qg[MODE == MODE_CONTACTS ? SEARCH_WAVES : 1][MODE == MODE_CONTACTS ? QG_CAP * GROUP_INT4 : 1];
     __shared__ float4 s_hx[SEARCH_WAVES][HOME_BLOCK];   // home atoms of the moment: x, y, z, meta
     __shared__ int4 s_ha[SEARCH_WAVES][HOME_BLOCK];     //                         local id, residue, prev, next
     __shared__ uint16_t s_desc[MODE == MODE_MARK ? 1 : SEARCH_WAVES][DESC_CAP]; // hits of the chunk: candidate slot << 5 | home atom
@@ -849,15 +875,43 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     const int seg = (MODE == MODE_CONTACTS) ? xcc_id() : 0;
     u64* const seg_ctr = ctr_pairs + seg * CTR_LINE;
     int2* const seg_pairs = pairs + (size_t)seg * cap;
+    uint16_t* const seg_desc = pl.desc + (size_t)seg * pl.cap;
+    int4* const seg_groups = pl.groups + (size_t)seg * pl.gcap * GROUP_INT4;
+    int* const seg_gmap = pl.gmap + (size_t)seg * (pl.cap / 64 + 1);
+    int gn = 0;               // groups in the wave's queue (MODE_CONTACTS)
+    // the wave's queue leaves for [pbase, pbase + qn) of the segment's descriptors and [gbase, gbase + gn) of its groups
+    auto write_out = [&](unsigned long long pbase, unsigned long long gbase) {
+        if (MODE == MODE_CONTACTS) {
+            for (int k = lane; k < qn; k += 64)
+                if (pbase + k < pl.cap) seg_desc[pbase + k] = qd[w][k];
+            if (lane < gn) {
+                int4 h3 = qg[w][GROUP_INT4 * lane + 3];
+                const unsigned long long first = pbase + (unsigned)h3.x, end = first + (unsigned)h3.y;
+                h3.x = (int)(unsigned)first;
+                h3.w = (int)(unsigned)(gbase + lane);
+                if (gbase + lane < pl.gcap) {
+                    int4* const dst = seg_groups + (gbase + lane) * GROUP_INT4;
+                    dst[0] = qg[w][GROUP_INT4 * lane];
+                    dst[1] = qg[w][GROUP_INT4 * lane + 1];
+                    dst[2] = qg[w][GROUP_INT4 * lane + 2];
+                    dst[3] = h3;
+                }
+                for (unsigned long long m = (first + 63) >> 6; (m << 6) < end && (m << 6) < pl.cap; ++m) seg_gmap[m] = h3.w;
+            }
+        } else {
+            for (int k = lane; k < qn; k += 64)
+                if (pbase + k < cap) seg_pairs[pbase + k] = q[w][k];
+        }
+    };
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(seg_ctr, (unsigned long long)qn);
+        if (lane == 0) base = atomicAdd(seg_ctr, (unsigned long long)qn | ((unsigned long long)gn << GROUP_SHIFT));
         base = __shfl(base, 0);
-        for (int k = lane; k < qn; k += 64)
-            if (base + k < cap) seg_pairs[base + k] = q[w][k];
+        write_out(base & PAIR_MASK, base >> GROUP_SHIFT);
         __builtin_amdgcn_wave_barrier();
         qn = 0;
+        gn = 0;
     };
 
     // The waves of a block CLAIM its work one HOME BLOCK at a time (a cell's home atoms in blocks of 32: nearly always the
@@ -1159,6 +1213,9 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                 for (;;) {
                     const int c = __popc(l0) + __popc(l1);
                     if (!__any(c != 0)) break;
+                    // MODE_CONTACTS: the hits of a round (<= DESC_CAP) that pass the filters are one GROUP of the pair list
+                    if (MODE == MODE_CONTACTS && (qn + DESC_CAP > QD_CAP || gn == QG_CAP)) flush();
+                    const int gfirst = qn;
                     if (lane == 0) s_dn[w] = 0;
                     __builtin_amdgcn_wave_barrier();
                     int pos = DESC_CAP;
@@ -1191,8 +1248,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                         const uint32_t mj = (uint32_t)fetch((int)mj0, (int)mj1);
                         const int j = fetch(j0, j1);
                         const int h = hb + hh;
-                        bool pass = has;
-                        int pb, pe;
+                        bool pass = has, h_first = false;
+                        int pb = 0, pe = 0;
                         if (MODE == MODE_CONTACTS) {
                             const int4 aj = make_int4(fetch(a0.x, a1.x), fetch(a0.y, a1.y), fetch(a0.z, a1.z), fetch(a0.w, a1.w));
                             const int4 ah = s_ha[w][hh];
@@ -1201,11 +1258,9 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                             // residue's polypeptide flag is read (I:734 tests res_end twice), whose HOME bit decides
                             // ownership, and the order of the stored positions; the same-residue and sequence-neighbour
                             // tests are symmetric in the two atoms.
-                            const bool h_first = ah.x < aj.x;
+                            h_first = ah.x < aj.x;
                             const uint32_t m_bgn = h_first ? mh : mj;
                             const uint32_t m_end = h_first ? mj : mh;
-                            pb = h_first ? h : j;
-                            pe = h_first ? j : h;
                             // Straight-line filters: interactions.py:729 same residue; 733-741 sequence-adjacent residues — one
                             // of the four links equal <=> the smallest of the four XORs is zero —; ownership: the rank owning
                             // the bgn atom emits the pair
@@ -1220,10 +1275,26 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                         }
                         const unsigned long long mp = __ballot(pass);
                         if (mp) {
-                            if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
-                            qn += __popcll(mp);
-                            if (qn > QCAP - 64) flush();
+                            if (MODE == MODE_CONTACTS) {
+                                // slot l < 64 is candidate kb + l, slot 64 + l candidate kb + 127 - l
+                                const unsigned kslot = second ? (unsigned)(191 - cidx) : (unsigned)cidx;
+                                if (pass) qd[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = (uint16_t)((unsigned)hh | (kslot << 5) | (h_first ? 0x1000u : 0u));
+                                qn += __popcll(mp);
+                            } else {
+                                if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
+                                qn += __popcll(mp);
+                                if (qn > QCAP - 64) flush();
+                            }
                         }
+                    }
+                    if (MODE == MODE_CONTACTS && qn > gfirst) {      // close the group of this round
+                        if (lane == 0) {
+                            qg[w][GROUP_INT4 * gn] = make_int4(js0, js1, js2, js3);
+                            qg[w][GROUP_INT4 * gn + 1] = make_int4(js4, o1, o2, o3);
+                            qg[w][GROUP_INT4 * gn + 2] = make_int4(o4, total, hb, kb);
+                            qg[w][GROUP_INT4 * gn + 3] = make_int4(gfirst, qn - gfirst, hcount, 0);
+                        }
+                        ++gn;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1238,26 +1309,25 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
 #endif
     // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
     // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
-    __shared__ int s_qn[SEARCH_WAVES];
+    __shared__ int s_qn[SEARCH_WAVES], s_gn[SEARCH_WAVES];
     __shared__ u64 s_base, s_cand[SEARCH_WAVES], s_acc[SEARCH_WAVES];
     const u64 w_cand = wave_sum_u32(n_cand), w_acc = wave_sum_u32(n_acc);
-    if (lane == 0) { s_qn[w] = qn; s_cand[w] = w_cand; s_acc[w] = w_acc; }
+    if (lane == 0) { s_qn[w] = qn; s_gn[w] = gn; s_cand[w] = w_cand; s_acc[w] = w_acc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int tot = 0;
+        int tot = 0, totg = 0;
         u64 tc = 0, ta = 0;
-        for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
-        s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot) : 0;
+        for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; totg += s_gn[k]; tc += s_cand[k]; ta += s_acc[k]; }
+        s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot | ((u64)totg << GROUP_SHIFT)) : 0;
         const int slot = blockIdx.x & (STAT_SLOTS - 1);
         atomicAdd(ctr_cand + slot * CTR_LINE, tc);
         atomicAdd(ctr_acc + slot * CTR_LINE, ta);
     }
     __syncthreads();
     if (MODE != MODE_MARK && qn > 0) {
-        u64 base = s_base;
-        for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
-        for (int k = lane; k < qn; k += 64)
-            if (base + k < cap) seg_pairs[base + k] = q[w][k];
+        u64 pbase = s_base & PAIR_MASK, gbase = s_base >> GROUP_SHIFT;
+        for (int k = 0; k < w; ++k) { pbase += (u64)s_qn[k]; gbase += (u64)s_gn[k]; }
+        write_out(pbase, gbase);
     }
 #ifdef ARP_SEARCH_TRACE
     if (MODE == MODE_CONTACTS && g_search_trace && lane == 0) {
@@ -1390,7 +1460,7 @@ __device__ __forceinline__ double2 rec_rad(int4 q1, const double2* s_tab, const 
 }
 __device__ __forceinline__ int rec_bond_cnt(int4 q1, const SiftSide& sd) {
     const int k = q1.w & 255;
-    return (k < CNT_SAT) ? k : sd.bond_off[q1.x + 1] - q1.y;
+    return (k < CNT_SAT) ? k : sd.bond_off[q1.x + 1] - sd.bond_off[q1.x];   // (q1.y is the record's sorted position, not bond_off)
 }
 __device__ __forceinline__ int rec_h_cnt(int4 q1, const SiftSide& sd) {
     const int k = (q1.w >> 8) & 255;
@@ -1433,12 +1503,21 @@ __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftR
     return s;
 }
 
+#ifndef SIFT_TASKQ
 #define SIFT_TASKQ 128
+#endif
+#ifndef SIFT_RING
+#define SIFT_RING 256      // records a wave of the per-pair kernel holds in LDS (a power of two; a group stages at most 32 + 128)
+#endif
+#define SIFT_GT 8          // groups a wave has staged at a time
 struct SiftArgs {
-    const int2* pairs;
-    const u64* npairs_ptr;
-    u64 cap;
-    const SiftRec* s_rec;
+    const uint16_t* desc;   // the pair list of the pass (PairList): descriptors, group headers, descriptor -> group
+    const int4* groups;
+    const int* gmap;
+    const u64* npairs_ptr;  // per segment: pairs | groups << GROUP_SHIFT
+    u64 cap, gcap;
+    const float4* s_xyzm;   // cell-sorted records: x, y, z, meta
+    const int4* s_q1;       //                      local id, own sorted position, h_off, bond_cnt | h_cnt << 8 | rad_idx << 16
     const int4* s_b4;       // first bonded neighbours of the atom at each sorted position (k_prepare_static)
     SiftSide sd;
     const int* bond_idx;
@@ -1466,15 +1545,18 @@ struct SiftShared {
     uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
     double2 tab[RAD_TABLE];      // the structure's distinct {vdw, cov} pairs
     float4 thr[256];             // for the first 16 of them, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), reach of the second}
+    float4 rx[4][SIFT_RING];     // per wave: ring of staged records, x, y, z, meta
+    int4 rq[4][SIFT_RING];       //           ... local id, sorted position, h_off, counts | radius index
+    int4 gt[4][SIFT_GT];         // per wave: the staged groups {first descriptor, end, ring slot of home atom 0 | hcount << 16, records}
 };
 // vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
 // vblock % 8 is still the XCD the dispatcher put the block on)
 template <int STREAM>
 __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgrid, SiftShared* sh) {
-    const int2* __restrict__ pairs = A.pairs;
     const u64* __restrict__ npairs_ptr = A.npairs_ptr;
     const u64 cap = A.cap;
-    const SiftRec* __restrict__ s_rec = A.s_rec;
+    const float4* __restrict__ s_xyzm = A.s_xyzm;
+    const int4* __restrict__ s_q1 = A.s_q1;
     const SiftSide sd = A.sd;
     const int* __restrict__ bond_idx = A.bond_idx;
     const double* __restrict__ h_xyz = A.h_xyz;
@@ -1494,11 +1576,16 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     //   2 is_weak_hbond(end, bgn)   3 is_weak_hbond(bgn, end)   4 / 5 is_halogen_weak_hbond  (I:857-886)
     // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
     // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
-    // (everything the first batch needs is asked for before the barrier: the queue heads, the first pairs and the radius table
-    // travel together instead of one dependent round trip after the other)
+    //
+    // Where the records of a pair come from: the pair list is groups of 16-bit descriptors (PairList).  A wave takes an equal
+    // run [f0, f1) of its segment's descriptors (a multiple of 64 each: the waves of a segment differ by one batch at most,
+    // as with the flat (i, j) list before), finds the group of f0 through gmap and walks the groups from there: the home and
+    // candidate records of a group are loaded COALESCED (consecutive sorted positions in at most six runs) into the wave's
+    // ring of SIFT_RING records in LDS, and a batch of 64 descriptors — which may span several groups: lanes stay full —
+    // reads its two records from there.
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // The segment fill counts are read on the device: no host round trip between search and sift.
-    // Block b works on segment b % 8 — the pairs written by the search blocks that ran on the same XCD,
+    // Block b works on the segment of the XCD it runs on — written by the search blocks that ran on the same XCD,
     // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
     const int sgm = xcc_id();      // (blocks b with the same b % 8 share an XCD, whichever it is: vblock / 8 still numbers the blocks of a segment)
     u64 heads[PAIR_SEGS];
@@ -1506,12 +1593,9 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_ * CTR_LINE];
     const float longest_bond = sd.longest_bond[0];
     const double h_slack = (double)sd.longest_bond[1] + 1e-4;   // |H - A| >= |D - A| - h_slack for every hydrogen H of D (margin: float32 distance, roundings)
-    const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
-    const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
-    const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
-    // (a pair beyond the end of the segment is read and ignored: the list is padded — see enqueue_contacts — and the count
-    // that says so is still on its way)
-    int2 pr_next = (first + lane < (long long)cap) ? seg_pairs[first + lane] : make_int2(0, 0);
+    const uint16_t* __restrict__ seg_desc = A.desc + (size_t)sgm * cap;
+    const int4* __restrict__ seg_groups = A.groups + (size_t)sgm * A.gcap * GROUP_INT4;
+    const int* __restrict__ seg_gmap = A.gmap + (size_t)sgm * (cap / 64 + 1);
     s_tab[threadIdx.x] = sd.rad_tab[threadIdx.x];   // (blockDim.x == RAD_TABLE)
     {   // the three float32 thresholds of the ladder (I:717-718, 756-773: float64 sums, compared as float32) depend on the two
         // radius pairs only: for the common case — both atoms among the first 16 table entries — they are looked up, not computed
@@ -1524,136 +1608,233 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     auto run_tasks = [&](int first_, int count) {   // stage B on tq[w][first_ .. first_ + count)
         if (lane < count) {
             const uint4 t = tq[w][first_ + lane];
-            const uint32_t add = sift_geometry(s_rec[t.y], s_rec[t.z], t.w >> 16, h_xyz, s_tab, sd, comp);
+            SiftRec qb, qe;
+            qb.xyzm = s_xyzm[t.y]; qb.q1 = s_q1[t.y];
+            qe.xyzm = s_xyzm[t.z]; qe.q1 = s_q1[t.z];
+            const uint32_t add = sift_geometry(qb, qe, t.w >> 16, h_xyz, s_tab, sd, comp);
             put_record<STREAM>((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
         }
     };
     long long out_base = 0;
 #pragma unroll
     for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
-        if (q_ < sgm) out_base += (long long)min(heads[q_], cap);
-    const long long nseg = (long long)min(heads[sgm], cap);
-    for (long long base = first; base < nseg; base += stride) {
-        const long long ps = base + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
-        bool queued = false;
-        uint4 task = make_uint4(0u, 0u, 0u, 0u);
-        const int2 pr = pr_next;
-        if (ps + stride < nseg) pr_next = seg_pairs[ps + stride];     // the next batch's pairs travel while this one is evaluated
-        if (ps < nseg) {
-        const long long p = out_base + ps;
-        const SiftRec qb = s_rec[pr.x], qe = s_rec[pr.y];  // two 16-byte quads per atom
-        const int4 nbr = A.s_b4[pr.x];                     // bgn's first bonded neighbours: travels WITH the records (addressed by position),
-                                                           // not after them as the walk over the CSR list did
-        const float4 vb = qb.xyzm, ve = qe.xyzm;
-        const int b = qb.q1.x, e = qe.q1.x;
-        const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
-        const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
-        const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
-        // Straight-line integer / mask code from here on: the reference's chains of `if` over the two type masks cost this
-        // kernel an exec-mask branch each (~350 VALU + 220 SALU instructions per batch of 64 pairs, and VALU issue is what
-        // the SIMDs run out of).  Only what is rare keeps a branch: radii outside the threshold table, a bonded-neighbour
-        // list longer than four, the halogen-bond angle.
-        const uint32_t bw = (mb / M_WATER) & 1u, ew = (me / M_WATER) & 1u;
-        // interactions.py:643-691 (__get_contact_type): the six overriding assignments as a 16-entry table of 4-bit codes,
-        // indexed by bgn selected | end selected << 1 | bgn water << 2 | end water << 3
-        const uint32_t ct_idx = ((mb / M_SEL) & 1u) | (((me / M_SEL) & 1u) << 1) | (bw << 2) | (ew << 3);
-        const int ct = (int)((contact_type_table() >> (4u * ct_idx)) & 15ull);
-        float f_sum_cov, f_sum_vdw, f_vdw_comp;                         // interactions.py:717-718 and the casts of 756-773
-        float reach_e, reach_b;    // >= 1.2 + vdw + comp + the longest atom - hydrogen distance: beyond it no hydrogen of the partner reaches (U:86, 109, 145)
-        {
-            const unsigned rib = (unsigned)qb.q1.w >> 16, rie = (unsigned)qe.q1.w >> 16;
-            if ((rib | rie) < 16u) {
-                const float4 t = sh->thr[rib * 16u + rie];
-                f_sum_cov = t.x; f_sum_vdw = t.y; f_vdw_comp = t.z; reach_e = t.w;
-                reach_b = sh->thr[rie * 16u + rib].w;
-            } else {
-                const double2 rb = rec_rad(qb.q1, s_tab, sd), re = rec_rad(qe.q1, s_tab, sd);   // {vdw, cov}
-                const double sum_vdw = rb.x + re.x;
-                f_sum_cov = (float)(rb.y + re.y); f_sum_vdw = (float)sum_vdw; f_vdw_comp = (float)(sum_vdw + comp);
-                reach_e = reach_float(re.x, comp, h_slack); reach_b = reach_float(rb.x, comp, h_slack);
+        if (q_ < sgm) out_base += (long long)min(heads[q_] & PAIR_MASK, cap);
+    const unsigned nseg = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)min(heads[sgm] & PAIR_MASK, cap));
+    const int ngrp = __builtin_amdgcn_readfirstlane((int)min(heads[sgm] >> GROUP_SHIFT, A.gcap));
+    // equal runs of descriptors, a multiple of 64 each
+    const unsigned nwv = (unsigned)(vgrid / PAIR_SEGS) * 4u, wid = (unsigned)(vblock / PAIR_SEGS) * 4u + (unsigned)w;
+    const unsigned quota = (unsigned)__builtin_amdgcn_readfirstlane((int)((((nseg + nwv - 1u) / nwv) + 63u) & ~63u));
+    const unsigned f0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wid * quota));
+    if (f0 < nseg) {
+        const unsigned f1 = min(f0 + quota, nseg);
+        float4* const rx = sh->rx[w];
+        int4* const rq = sh->rq[w];
+        int4* const gt = sh->gt[w];
+        constexpr int RM = SIFT_RING - 1;
+        int g = __builtin_amdgcn_readfirstlane(seg_gmap[f0 >> 6]);          // the group that holds descriptor f0
+        unsigned dsc_next = seg_desc[f0 + lane < nseg ? f0 + lane : f0];      // (travels beside the group headers)
+        g = min(max(g, 0), max(ngrp - 1, 0));
+        int4 hq = seg_groups[(size_t)g * GROUP_INT4 + (lane & 3)];           // header of group g: word k in the lanes with lane % 4 == k
+        int head = 0, used = 0;          // ring: next free slot, records in use
+        int gt_lo = 0, gt_n = 0;         // staged groups: oldest entry, how many
+        unsigned staged_end = f0;        // descriptors below this have their records in the ring
+        bool first_group = true;
+        for (unsigned b = f0; b < f1;) {
+            const unsigned need = min(b + 64u, f1);
+            // ---- stage groups until the batch is covered (or the ring / the table is full)
+            while (staged_end < need && g < ngrp && gt_n < SIFT_GT) {
+                const int js0 = __builtin_amdgcn_readlane(hq.x, 0), js1 = __builtin_amdgcn_readlane(hq.y, 0), js2 = __builtin_amdgcn_readlane(hq.z, 0),
+                          js3 = __builtin_amdgcn_readlane(hq.w, 0), js4 = __builtin_amdgcn_readlane(hq.x, 1);
+                const int o1 = __builtin_amdgcn_readlane(hq.y, 1), o2 = __builtin_amdgcn_readlane(hq.z, 1), o3 = __builtin_amdgcn_readlane(hq.w, 1),
+                          o4 = __builtin_amdgcn_readlane(hq.x, 2), total = __builtin_amdgcn_readlane(hq.y, 2);
+                const int hb = __builtin_amdgcn_readlane(hq.z, 2), kb = __builtin_amdgcn_readlane(hq.w, 2);
+                const unsigned gfirst = (unsigned)__builtin_amdgcn_readlane(hq.x, 3);
+                const int gcount = __builtin_amdgcn_readlane(hq.y, 3);
+                const int hcount = min(max(__builtin_amdgcn_readlane(hq.z, 3), 0), HOME_BLOCK);
+                const int ncand = min(max(total - kb, 0), 128);
+                const int nrec = hcount + ncand;
+                if (used + nrec > SIFT_RING) break;                           // (a single group always fits: nrec <= 160)
+                if (first_group) { staged_end = max(staged_end, gfirst); first_group = false; }
+                // the records: home atoms [hb, hb + hcount), candidates kb + lane and kb + 64 + lane of the five ranges
+                {
+                    const int k0 = kb + lane, k1 = kb + 64 + lane;
+                    const bool vh = lane < hcount, v0 = lane < ncand, v1 = lane + 64 < ncand;
+                    const int ph = hb + (vh ? lane : 0);
+                    const int p0 = v0 ? cand_pos(k0, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4) : hb;
+                    const float4 xh = s_xyzm[ph];
+                    const int4 qh = s_q1[ph];
+                    const float4 x0 = s_xyzm[p0];
+                    const int4 q0 = s_q1[p0];
+                    if (vh) { rx[(head + lane) & RM] = xh; rq[(head + lane) & RM] = qh; }
+                    if (v0) { rx[(head + hcount + lane) & RM] = x0; rq[(head + hcount + lane) & RM] = q0; }
+                    if (ncand > 64) {
+                        const int p1 = v1 ? cand_pos(k1, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4) : hb;
+                        const float4 x1 = s_xyzm[p1];
+                        const int4 q1 = s_q1[p1];
+                        if (v1) { rx[(head + hcount + 64 + lane) & RM] = x1; rq[(head + hcount + 64 + lane) & RM] = q1; }
+                    }
+                }
+                if (lane == 0) gt[(gt_lo + gt_n) & (SIFT_GT - 1)] = make_int4((int)gfirst, (int)(gfirst + (unsigned)gcount), head | (hcount << 16), nrec);
+                ++gt_n;
+                head = (head + nrec) & RM;
+                used += nrec;
+                staged_end = gfirst + (unsigned)gcount;
+                ++g;
+                if (g < ngrp) hq = seg_groups[(size_t)g * GROUP_INT4 + (lane & 3)];
             }
-        }
-        const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
-        // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
-        // (one of the four equal <=> the smallest of the four XORs is zero; -1 / -2 never equal a local id)
-        const unsigned nx_ = min(min((unsigned)(nbr.x ^ e), (unsigned)(nbr.y ^ e)), min((unsigned)(nbr.z ^ e), (unsigned)(nbr.w ^ e)));
-        bool cov = (d <= longest_bond) & (nx_ == 0u);
-        if ((d <= longest_bond) & !cov & (nbr.w == -2))                           // more than four neighbours: the rest of the list
-            for (int k = qb.q1.y + 3, k1 = qb.q1.y + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
-                if (bond_idx[k] == e) { cov = true; break; }
-        // interactions.py:756-773: float32 distance against Python floats -> float32 compare; an exclusive ladder
-        uint32_t s = ARP_S_PROXIMAL;                                   // (selects from the bottom up: no branch per rung)
-        s = (d <= f_vdw_comp) ? ARP_S_VDW : s;
-        s = (d < f_sum_vdw) ? ARP_S_VDW_CLASH : s;
-        s = (d < f_sum_cov) ? ARP_S_CLASH : s;
-        s = cov ? ARP_S_COVALENT : s;
-        // interactions.py:777-783: an hbond acceptor beside a metal
-        const uint32_t metal = ((tb & (me >> 12)) | (te & (mb >> 12))) & 1u;        // ARP_T_HBOND_ACCEPTOR = bit 0, M_METAL = bit 12
-        s |= (d <= (float)2.8) ? metal * ARP_S_METAL_COMPLEX : 0u;
-        // The type tests of I:791-921 pair up neighbouring bits of the two masks — (acceptor 0, donor 1), (xbond acceptor 2,
-        // donor 3), (weak acceptor 4, weak donor 5), (positive 6, negative 7), (carbonyl O 9, C 10):
-        // X bit k = bgn has k + 1 and end has k, Y the same with the two atoms exchanged.
-        const uint32_t X = (tb >> 1) & te, Y = (te >> 1) & tb, XY = X | Y;
-        const bool in_vc = d <= f_vdw_comp, d35 = d <= (float)3.5;
-        // interactions.py:791-819: water rule, else donor / acceptor (if / elif); the water branches set POLAR whatever the distance
-        const uint32_t wb = bw & (in_vc ? 1u : 0u), we = ew & (in_vc ? 1u : 0u) & ~wb;
-        const uint32_t nowat = (wb | we) ^ 1u;
-        const uint32_t hb_w = (wb & (((te & 3u) != 0u) ? 1u : 0u)) | (we & (((tb & 3u) != 0u) ? 1u : 0u));
-        const uint32_t c1 = nowat & X & 1u, c2 = nowat & ~X & Y & 1u;
-        // interactions.py:857-886: the four weak branches
-        const uint32_t n4 = tb & (te >> 5) & 1u, n8 = (tb >> 5) & te & 1u;
-        const uint32_t n16 = (tb >> 4) & (mb >> 13) & (((te & 0x22u) != 0u) ? 1u : 0u) & 1u;    // weak acceptor 4, M_HALOGEN 13, donor 1 | weak donor 5
-        const uint32_t n32 = (te >> 4) & (me >> 13) & (((tb & 0x22u) != 0u) ? 1u : 0u) & 1u;
-        unsigned need = c1 | (c2 << 1) | (n4 << 2) | (n8 << 3) | (n16 << 4) | (n32 << 5);
-        uint32_t f = hb_w * (ARP_S_HBOND | ARP_S_POLAR);
-        f |= (d35 & ((c1 | c2) != 0u)) ? ARP_S_POLAR : 0u;                       // I:806, 814
-        f |= (d35 & ((need & 60u) != 0u)) ? ARP_S_WEAK_POLAR : 0u;               // I:861, 869, 877, 885
-        // interactions.py:898-921: ionic (bit 6 -> 8), carbonyl (9 -> 12), aromatic (11 -> 10), hydrophobic (8 -> 11), each behind its distance
-        const uint32_t near4 = ((XY & 0x40u) << 2) | ((tb & te & ARP_T_AROMATIC) >> 1);
-        f |= (d <= (float)4.0) ? near4 : 0u;
-        f |= (d <= (float)3.6) ? ((XY & 0x200u) << 3) : 0u;
-        f |= (tb & te & ARP_T_HYDROPHOBE) << 3;
-        // interactions.py:786: feature flags only for pairs that do not clash (covalent ones do get them) within 4.5 A
-        const bool feat = !(s & ARP_S_CLASH) & (d <= (float)4.5);
-        s |= feat ? f : 0u;
-        need = feat ? need : 0u;
-        // interactions.py:889-895 (halogen bond: float32 angle at the donor), rare
-        if (feat & in_vc & ((XY & 4u) != 0u)) {
-            if (X & 4u) { if (xbond(sd.sb[b], xb, xe, err)) s |= ARP_S_XBOND; }
-            else if (xbond(sd.sb[e], xe, xb, err)) s |= ARP_S_XBOND;
-        }
-        {
-            // Branches that cannot succeed need no hydrogen loop: the donor has no hydrogen, the halogen no single-bond
-            // neighbour (U:139-141), or the partner is beyond the test's reach.  If EVERY applicable branch is such a one the
-            // pair gets no hbond / weak hbond bit — what the loops would find — and is not queued; if one is left the task
-            // runs with the full set (the last applicable weak branch decides, I:857-886).
-            const bool no_hb = (((unsigned)qb.q1.w >> 8) & 255u) == 0u, no_he = (((unsigned)qe.q1.w >> 8) & 255u) == 0u;
-            unsigned dead = 0;
-            dead |= (no_hb | (d > reach_e)) ? (1u | 8u | 32u) : 0u;               // hydrogens of bgn, target = end
-            dead |= (no_he | (d > reach_b)) ? (2u | 4u | 16u) : 0u;               // hydrogens of end, target = bgn
-            dead |= (mb & M_HAS_SB) ? 0u : 16u;
-            dead |= (me & M_HAS_SB) ? 0u : 32u;
-            need = ((need & ~dead) == 0u) ? 0u : need;
-        }
-        put_record<STREAM>(gid ? gid[b] : b, out_i + p);
-        put_record<STREAM>(gid ? gid[e] : e, out_j + p);
-        put_record<STREAM>(d, out_d + p);
-        put_record<STREAM>((uint8_t)ct, out_ct + p);
-        if (need) {
-            queued = true;
-            task = make_uint4((unsigned)p, (unsigned)pr.x, (unsigned)pr.y, s | (need << 16));
-        } else {
-            put_record<STREAM>((uint16_t)s, out_s + p);
-        }
-        }
-        // stage B bookkeeping (whole wave)
-        const unsigned long long mq = __ballot(queued);
-        if (mq) {
-            if (queued) tq[w][tn + __popcll(mq & ((1ull << lane) - 1ull))] = task;
-            tn += __popcll(mq);
-            if (tn >= 64) {
-                tn -= 64;
-                run_tasks(tn, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (staged_end <= b) break;          // (cannot happen in a pass whose lists did not overflow; such a pass is repeated)
+            const unsigned nb = min(need, staged_end) - b;
+            const unsigned ps = b + (unsigned)lane;
+            const bool live = (unsigned)lane < nb;
+            const unsigned dsc = dsc_next;
+            if (b + nb + (unsigned)lane < f1) dsc_next = seg_desc[b + nb + lane];     // the next batch's descriptors travel while this one is evaluated
+            bool queued = false;
+            uint4 task = make_uint4(0u, 0u, 0u, 0u);
+            // the group of this lane's descriptor: the last staged one that begins at or before it
+            int gslot = 0;
+            for (int e = 0; e < gt_n; ++e) {
+                const int4 t = gt[(gt_lo + e) & (SIFT_GT - 1)];
+                gslot = (ps >= (unsigned)t.x) ? t.z : gslot;
+            }
+            if (live) {
+            const long long p = out_base + (long long)ps;
+            const int hslot = gslot & 0xFFFF, hcnt = gslot >> 16;
+            const int ih = (hslot + (int)(dsc & 31u)) & RM, ic_ = (hslot + hcnt + (int)((dsc >> 5) & 127u)) & RM;
+            const bool h_first = (dsc & 0x1000u) != 0u;
+            const int ib_ = h_first ? ih : ic_, ie_ = h_first ? ic_ : ih;
+            SiftRec qb, qe;
+            qb.xyzm = rx[ib_]; qb.q1 = rq[ib_];
+            qe.xyzm = rx[ie_]; qe.q1 = rq[ie_];
+            const int posb = qb.q1.y, pose = qe.q1.y;                  // sorted positions of the two atoms
+            const float4 vb = qb.xyzm, ve = qe.xyzm;
+            const int b_ = qb.q1.x, e = qe.q1.x;
+            const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
+            const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
+            const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
+            const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
+            // bgn's first bonded neighbours, for the covalent test (I:748-757): only pairs within the longest bond of the structure
+            // can be bonded, the others read one line all lanes share; asked for here, used at the end of the stage
+            const bool near_bond = d <= longest_bond;
+            const int4 nbr = A.s_b4[near_bond ? posb : 0];
+            // Straight-line integer / mask code from here on: the reference's chains of `if` over the two type masks cost this
+            // kernel an exec-mask branch each (~350 VALU + 220 SALU instructions per batch of 64 pairs, and VALU issue is what
+            // the SIMDs run out of).  Only what is rare keeps a branch: radii outside the threshold table, a bonded-neighbour
+            // list longer than four, the halogen-bond angle.
+            const uint32_t bw = (mb / M_WATER) & 1u, ew = (me / M_WATER) & 1u;
+            // interactions.py:643-691 (__get_contact_type): the six overriding assignments as a 16-entry table of 4-bit codes,
+            // indexed by bgn selected | end selected << 1 | bgn water << 2 | end water << 3
+            const uint32_t ct_idx = ((mb / M_SEL) & 1u) | (((me / M_SEL) & 1u) << 1) | (bw << 2) | (ew << 3);
+            const int ct = (int)((contact_type_table() >> (4u * ct_idx)) & 15ull);
+            float f_sum_cov, f_sum_vdw, f_vdw_comp;                         // interactions.py:717-718 and the casts of 756-773
+            float reach_e, reach_b;    // >= 1.2 + vdw + comp + the longest atom - hydrogen distance: beyond it no hydrogen of the partner reaches (U:86, 109, 145)
+            {
+                const unsigned rib = (unsigned)qb.q1.w >> 16, rie = (unsigned)qe.q1.w >> 16;
+                if ((rib | rie) < 16u) {
+                    const float4 t = sh->thr[rib * 16u + rie];
+                    f_sum_cov = t.x; f_sum_vdw = t.y; f_vdw_comp = t.z; reach_e = t.w;
+                    reach_b = sh->thr[rie * 16u + rib].w;
+                } else {
+                    const double2 rb = rec_rad(qb.q1, s_tab, sd), re = rec_rad(qe.q1, s_tab, sd);   // {vdw, cov}
+                    const double sum_vdw = rb.x + re.x;
+                    f_sum_cov = (float)(rb.y + re.y); f_sum_vdw = (float)sum_vdw; f_vdw_comp = (float)(sum_vdw + comp);
+                    reach_e = reach_float(re.x, comp, h_slack); reach_b = reach_float(rb.x, comp, h_slack);
+                }
+            }
+            // interactions.py:756-773: float32 distance against Python floats -> float32 compare; an exclusive ladder
+            uint32_t s = ARP_S_PROXIMAL;                                   // (selects from the bottom up: no branch per rung)
+            s = (d <= f_vdw_comp) ? ARP_S_VDW : s;
+            s = (d < f_sum_vdw) ? ARP_S_VDW_CLASH : s;
+            s = (d < f_sum_cov) ? ARP_S_CLASH : s;
+            // interactions.py:777-783: an hbond acceptor beside a metal
+            const uint32_t metal = ((tb & (me >> 12)) | (te & (mb >> 12))) & 1u;        // ARP_T_HBOND_ACCEPTOR = bit 0, M_METAL = bit 12
+            const uint32_t s_metal = (d <= (float)2.8) ? metal * ARP_S_METAL_COMPLEX : 0u;
+            // The type tests of I:791-921 pair up neighbouring bits of the two masks — (acceptor 0, donor 1), (xbond acceptor 2,
+            // donor 3), (weak acceptor 4, weak donor 5), (positive 6, negative 7), (carbonyl O 9, C 10):
+            // X bit k = bgn has k + 1 and end has k, Y the same with the two atoms exchanged.
+            const uint32_t X = (tb >> 1) & te, Y = (te >> 1) & tb, XY = X | Y;
+            const bool in_vc = d <= f_vdw_comp, d35 = d <= (float)3.5;
+            // interactions.py:791-819: water rule, else donor / acceptor (if / elif); the water branches set POLAR whatever the distance
+            const uint32_t wb = bw & (in_vc ? 1u : 0u), we = ew & (in_vc ? 1u : 0u) & ~wb;
+            const uint32_t nowat = (wb | we) ^ 1u;
+            const uint32_t hb_w = (wb & (((te & 3u) != 0u) ? 1u : 0u)) | (we & (((tb & 3u) != 0u) ? 1u : 0u));
+            const uint32_t c1 = nowat & X & 1u, c2 = nowat & ~X & Y & 1u;
+            // interactions.py:857-886: the four weak branches
+            const uint32_t n4 = tb & (te >> 5) & 1u, n8 = (tb >> 5) & te & 1u;
+            const uint32_t n16 = (tb >> 4) & (mb >> 13) & (((te & 0x22u) != 0u) ? 1u : 0u) & 1u;    // weak acceptor 4, M_HALOGEN 13, donor 1 | weak donor 5
+            const uint32_t n32 = (te >> 4) & (me >> 13) & (((tb & 0x22u) != 0u) ? 1u : 0u) & 1u;
+            unsigned need_ = c1 | (c2 << 1) | (n4 << 2) | (n8 << 3) | (n16 << 4) | (n32 << 5);
+            uint32_t f = hb_w * (ARP_S_HBOND | ARP_S_POLAR);
+            f |= (d35 & ((c1 | c2) != 0u)) ? ARP_S_POLAR : 0u;                       // I:806, 814
+            f |= (d35 & ((need_ & 60u) != 0u)) ? ARP_S_WEAK_POLAR : 0u;               // I:861, 869, 877, 885
+            // interactions.py:898-921: ionic (bit 6 -> 8), carbonyl (9 -> 12), aromatic (11 -> 10), hydrophobic (8 -> 11), each behind its distance
+            const uint32_t near4 = ((XY & 0x40u) << 2) | ((tb & te & ARP_T_AROMATIC) >> 1);
+            f |= (d <= (float)4.0) ? near4 : 0u;
+            f |= (d <= (float)3.6) ? ((XY & 0x200u) << 3) : 0u;
+            f |= (tb & te & ARP_T_HYDROPHOBE) << 3;
+            {
+                // Branches that cannot succeed need no hydrogen loop: the donor has no hydrogen, the halogen no single-bond
+                // neighbour (U:139-141), or the partner is beyond the test's reach.  If EVERY applicable branch is such a one the
+                // pair gets no hbond / weak hbond bit — what the loops would find — and is not queued; if one is left the task
+                // runs with the full set (the last applicable weak branch decides, I:857-886).
+                const bool no_hb = (((unsigned)qb.q1.w >> 8) & 255u) == 0u, no_he = (((unsigned)qe.q1.w >> 8) & 255u) == 0u;
+                unsigned dead = 0;
+                dead |= (no_hb | (d > reach_e)) ? (1u | 8u | 32u) : 0u;               // hydrogens of bgn, target = end
+                dead |= (no_he | (d > reach_b)) ? (2u | 4u | 16u) : 0u;               // hydrogens of end, target = bgn
+                dead |= (mb & M_HAS_SB) ? 0u : 16u;
+                dead |= (me & M_HAS_SB) ? 0u : 32u;
+                need_ = ((need_ & ~dead) == 0u) ? 0u : need_;
+            }
+            // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
+            // (one of the four equal <=> the smallest of the four XORs is zero; -1 / -2 never equal a local id)
+            const unsigned nx_ = min(min((unsigned)(nbr.x ^ e), (unsigned)(nbr.y ^ e)), min((unsigned)(nbr.z ^ e), (unsigned)(nbr.w ^ e)));
+            bool cov = near_bond & (nx_ == 0u);
+            if (near_bond & !cov & (nbr.w == -2)) {                                   // more than four neighbours: the rest of the list
+                const int k0_ = sd.bond_off[b_];
+                for (int k = k0_ + 3, k1 = k0_ + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
+                    if (bond_idx[k] == e) { cov = true; break; }
+            }
+            s = cov ? ARP_S_COVALENT : s;
+            s |= s_metal;
+            // interactions.py:786: feature flags only for pairs that do not clash (covalent ones do get them) within 4.5 A
+            const bool feat = !(s & ARP_S_CLASH) & (d <= (float)4.5);
+            s |= feat ? f : 0u;
+            unsigned need = feat ? need_ : 0u;
+            // interactions.py:889-895 (halogen bond: float32 angle at the donor), rare
+            if (feat & in_vc & ((XY & 4u) != 0u)) {
+                if (X & 4u) { if (xbond(sd.sb[b_], xb, xe, err)) s |= ARP_S_XBOND; }
+                else if (xbond(sd.sb[e], xe, xb, err)) s |= ARP_S_XBOND;
+            }
+            put_record<STREAM>(gid ? gid[b_] : b_, out_i + p);
+            put_record<STREAM>(gid ? gid[e] : e, out_j + p);
+            put_record<STREAM>(d, out_d + p);
+            put_record<STREAM>((uint8_t)ct, out_ct + p);
+            if (need) {
+                queued = true;
+                task = make_uint4((unsigned)p, (unsigned)posb, (unsigned)pose, s | (need << 16));
+            } else {
+                put_record<STREAM>((uint16_t)s, out_s + p);
+            }
+            }
+            // stage B bookkeeping (whole wave)
+            const unsigned long long mq = __ballot(queued);
+            if (mq) {
+                if (queued) tq[w][tn + __popcll(mq & ((1ull << lane) - 1ull))] = task;
+                tn += __popcll(mq);
+                if (tn >= 64) {
+                    tn -= 64;
+                    run_tasks(tn, 64);
+                }
+            }
+            b += nb;
+            // retire the groups that are used up
+            __builtin_amdgcn_wave_barrier();
+            while (gt_n > 0) {
+                const int4 t = gt[gt_lo];
+                if ((unsigned)__builtin_amdgcn_readfirstlane(t.y) > b) break;
+                used -= __builtin_amdgcn_readfirstlane(t.w);
+                gt_lo = (gt_lo + 1) & (SIFT_GT - 1);
+                --gt_n;
             }
         }
     }
