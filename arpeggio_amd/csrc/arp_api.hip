@@ -208,6 +208,7 @@ struct arp_ctx {
     std::string err;
     int num_cu = 256;
     int search_resident = 768;          // blocks of k_search<MODE_CONTACTS> the chip holds at once (occupancy x CUs)
+    int sift_per_cu = 3;                // blocks of the per-pair kernel a CU holds at once (its LDS ring bounds it)
 
     // ---- sizes
     int64_t n = 0, nres = 0, nring = 0, namide = 0;
@@ -249,17 +250,16 @@ struct arp_ctx {
     // ---- derived
     DevBuf<float4> s_xyzm;
     DevBuf<int4> s_aux;
-    DevBuf<int4> s_q1;            // second quad of the sift records, cell-sorted (the first one is s_xyzm)
+    DevBuf<int4> s_qa;            // second quad of the sift records, cell-sorted (the first one is s_xyzm)
     DevBuf<int> tmp_i32;          // scratch for index uploads
-    DevBuf<int4> st_b4, sp_b4, s_b4;   // first bonded neighbours: static, in the spatial order, cell-sorted beside s_rec
-    DevBuf<int4> st_q1;           // selection-independent record columns, composed once per structure (k_prepare_static)
+    DevBuf<int4> st_qa;           // selection-independent record columns, composed once per structure (k_prepare_static)
     DevBuf<float> longest_bond;   // k_longest_bond, once per uploaded structure (ensure_static)
     DevBuf<uint16_t> rad_idx;     // per atom: index of its {vdw, cov} pair in rad_tab (RAD_NONE: not in the table)
     DevBuf<double2> rad_tab;      // RAD_TABLE distinct radius pairs of the structure
     DevBuf<int4> st_aux;
     DevBuf<float4> st_xyzm;
     DevBuf<float4> sp_xyzm;       // the same columns in the spatial order of the structure (what the per-pass grid builds read)
-    DevBuf<int4> sp_aux, sp_q1;
+    DevBuf<int4> sp_aux, sp_qa;
     DevBuf<int> sp_cnt;
     DevBuf<int> sp_sums;         // tile totals of the static order's scan (grids beyond 32768 cells)
     DevBuf<int2> sp_cr;
@@ -657,8 +657,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
     if (columns) {
         c->lists_dirty = true;
         c->contacts_expected = 0;
-        HIPCHK(c, c->st_q1.reserve((size_t)std::max(n, 1)));
-        HIPCHK(c, c->st_b4.reserve((size_t)std::max(n, 1)));
+        HIPCHK(c, c->st_qa.reserve((size_t)std::max(n, 1)));
         HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
         HIPCHK(c, c->st_xyzm.reserve((size_t)std::max(n, 1)));
     }
@@ -673,7 +672,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         // counting sort by cell.  The longest-bond words sit behind the histogram, so ONE fill clears both.
         GridDesc d;
         CHK(grid_desc_for(c, d, c->lo, c->hi, radius));
-        HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_q1.reserve((size_t)n)); HIPCHK(c, c->sp_b4.reserve((size_t)n));
+        HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_qa.reserve((size_t)n));
         HIPCHK(c, c->sp_cr.reserve((size_t)n)); HIPCHK(c, c->sp_cell.reserve((size_t)n));
         // layout of sp_cnt: [longest bond, longest atom - hydrogen distance, 2 words of padding | histogram of ncell + 1 cells]:
         // a fresh structure clears all of it with ONE fill, a new order for resident columns only the histogram
@@ -692,7 +691,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         c->longest_bond.borrow(c->sp_cnt.p, 2);
         if (columns) {
             if (!cleared) HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, want * sizeof(int), c->stream));
-            hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_q1.p, c->st_b4.p,
+            hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_qa.p,
                                d, hist, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
         } else {
             if (regrow) HIPCHK(c, hipMemcpyAsync(c->sp_cnt.p, keep_longest, sizeof(keep_longest), hipMemcpyHostToDevice, c->stream));
@@ -711,7 +710,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
             hipLaunchKernelGGL(k_scan_fix, dim3((d.ncell + 4095) / 4096), dim3(1024), 0, c->stream, hist, d.ncell, c->sp_sums.p, ntiles, (unsigned long long*)nullptr);
         }
         hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, hist, c->st_xyzm.p,
-                           c->st_aux.p, c->st_q1.p, c->st_b4.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_q1.p, c->sp_b4.p, c->sp_cell.p);
+                           c->st_aux.p, c->st_qa.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_qa.p, c->sp_cell.p);
         CHK(check_launch(c, "k_static_permute"));
         c->sp_grid = d;
     }
@@ -730,8 +729,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
 StaticAtoms static_atoms(arp_ctx* c) {
     StaticAtoms r;
     r.xyzm = c->sp_xyzm.p;
-    r.q1 = c->sp_q1.p;
-    r.b4 = c->sp_b4.p;
+    r.qa = c->sp_qa.p;
     r.aux = c->sp_aux.p;
     r.sel = c->sel_made ? c->sel.p : nullptr;
     r.plus = c->sel_made ? c->plus.p : nullptr;
@@ -764,7 +762,6 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
     HIPCHK(c, sx.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, sa.reserve((size_t)std::max(n, 1)));
     if (srec) HIPCHK(c, srec->reserve((size_t)std::max(n, 1)));
-    if (srec) HIPCHK(c, c->s_b4.reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c));
     const StaticAtoms r = static_atoms(c);
     int* const hist = G.cur ? G.cnt2.p : G.cnt.p;
@@ -780,13 +777,12 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
             G.used[G.cur] = ((size_t)ncell + 3) & ~(size_t)3;
         }
         int4* const rec = srec ? srec->p : (int4*)nullptr;
-        int4* const b4 = srec ? c->s_b4.p : (int4*)nullptr;
         const int nb = (n + SCAT_ATOMS - 1) / SCAT_ATOMS;
         if (ncell <= SCAN_LDS_CELLS) {   // start table in LDS: scan + scatter in one launch
             Prof p(c, SLOT_SCATTER, st);
             const int steps = (ncell + 16 * 256 - 1) / (16 * 256);
 #define LAUNCH_SS(S) hipLaunchKernelGGL((k_scan_scatter_atoms<S>), dim3(nb), dim3(1024), (S) * 16384, st, r, n, ncell, G.cell_rank.p, hist, \
-                                        G.start.p, total_out, sx.p, sa.p, rec, b4, gm)
+                                        G.start.p, total_out, sx.p, sa.p, rec, gm)
             switch (steps) {
                 case 1: LAUNCH_SS(1); break;
                 case 2: LAUNCH_SS(2); break;
@@ -822,7 +818,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
                 CHK(check_launch(c, "k_scan"));
             }
             Prof p(c, SLOT_SCATTER, st);
-            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_rank.p, G.start.p, sx.p, sa.p, rec, b4, gm);
+            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_rank.p, G.start.p, sx.p, sa.p, rec, gm);
             CHK(check_launch(c, "k_scatter_atoms"));
         }
         G.cur = 1 - G.cur;
@@ -838,7 +834,7 @@ int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, c
                        ResMarks rm = ResMarks{nullptr, nullptr, 0}, GroupMasks gm = GroupMasks{}) {
     c->cg_valid = false;      // (the buffers of the pass's grid are rewritten)
     c->s_cell_valid = false;
-    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_q1, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
+    return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_qa, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
 }
 // The contact grid of a pass as an ordered compaction of the static columns (k_compact_atoms): ONE launch.
 int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t forb, u64* total_out, uint8_t* plus_init, ResMarks rm) {
@@ -851,8 +847,7 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
     HIPCHK(c, G.start.reserve(scan_padded(ncell)));
     HIPCHK(c, c->s_xyzm.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->s_aux.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->s_q1.reserve((size_t)std::max(n, 1)));
-    HIPCHK(c, c->s_b4.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_qa.reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c, radius));
     if (n > 0) {
         Prof p(c, SLOT_BIN);
@@ -869,7 +864,7 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
         CompactArgs A;
         A.r = static_atoms(c);
         A.sp_cell = c->sp_cell.p; A.n = n; A.ncell = ncell; A.req = req; A.forb = forb;
-        A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_q1 = c->s_q1.p; A.s_b4 = c->s_b4.p;
+        A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_qa = c->s_qa.p;
         HIPCHK(c, c->s_cell.reserve((size_t)std::max(n, 1)));
         A.s_cell = c->s_cell.p;
         A.start = G.start.p; A.chain = c->compact_chain.p; A.epoch = c->compact_epoch; A.total_out = total_out;
@@ -1461,9 +1456,11 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     auto launch_sift = [&](bool merged_) -> int {
         sift_launched = true;
         Prof p(c, SLOT_SIFT);
-        static const int sift_blocks_per_cu = std::max(1, env_int("ARP_SIFT_BPC", 4));
-        const SiftArgs sa{c->pl_desc.p, c->pl_groups.p, c->pl_gmap.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, (u64)c->pl_gcap, c->s_xyzm.p, c->s_q1.p, c->s_b4.p,
-                          SiftSide{c->rad_tab.p, c->rad.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
+        // (the blocks split their work statically: all of them must be resident from the start)
+        static const int sift_bpc_env = env_int("ARP_SIFT_BPC", 0);
+        const int sift_blocks_per_cu = sift_bpc_env > 0 ? sift_bpc_env : c->sift_per_cu;
+        const SiftArgs sa{c->pl_desc.p, c->pl_groups.p, c->pl_gmap.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, (u64)c->pl_gcap, c->s_xyzm.p, c->s_qa.p,
+                          SiftSide{c->rad_tab.p, c->rad.p, c->xyz.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + ctr_dev(C_ERR))};
         // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
@@ -1800,6 +1797,9 @@ int arp_create(int device, arp_ctx** out) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_search<MODE_CONTACTS>, 64 * SEARCH_WAVES, 0) == hipSuccess && per_cu > 0)
             c->search_resident = per_cu * c->num_cu;
+        per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_sift_planes<0>, 256, 0) == hipSuccess && per_cu > 0)
+            c->sift_per_cu = per_cu;
     }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     c->stream = c->own_stream;
@@ -1837,8 +1837,8 @@ void arp_destroy(arp_ctx* c) {
     c->home.release(); c->sel.release(); c->plus.release(); c->res_sel.release(); c->res_plus.release();
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
-    c->s_xyzm.release(); c->s_aux.release(); c->s_q1.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_q1.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
-    c->sp_xyzm.release(); c->sp_aux.release(); c->sp_q1.release(); c->st_b4.release(); c->sp_b4.release(); c->s_b4.release(); c->sp_cnt.release(); c->sp_cr.release();
+    c->s_xyzm.release(); c->s_aux.release(); c->s_qa.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_qa.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
+    c->sp_xyzm.release(); c->sp_aux.release(); c->sp_qa.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->pl_desc.release(); c->pl_groups.release(); c->pl_gmap.release(); c->pl_gcap = 0;
     c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();

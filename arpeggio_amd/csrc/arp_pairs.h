@@ -29,6 +29,11 @@
 #define M_RES_POLY (1u << 21)
 #define M_RES_HASSEQ (1u << 22)
 #define M_HOME (1u << 24)
+// what the per-pair kernel needs of an atom's radii and hydrogens rides in the meta word as well (k_prepare_static): the index of
+// its {vdw, cov} pair in the radius table if that is below 15 (15: look it up by local id), and whether it has hydrogens at all
+#define M_RAD4_SHIFT 25
+#define M_RAD4_ESC 15u
+#define M_HAS_H (1u << 29)
 
 // Counters of a pass (one u64 each).  The enum is the LOGICAL layout — the order of the page-locked host mirror and of every
 // h_ctr[] index.  On the device a counter sits at word ctr_dev(logical) of a block of 128-byte lines, because returning
@@ -98,21 +103,17 @@ struct RawAtoms {
     const float4* sb;           // single-bond neighbour xyz, w = present
 };
 
-// What k_sift holds of each atom of a pair (two 16-byte quads, kept as two columns of the cell-sorted grid — s_xyzm, which the
-// search reads as well, and s_q1 — and staged through LDS group by group):
-//   xyzm = x, y, z, meta
-//   q1   = local atom id, the record's own sorted position (bond_off in the static column), h_off, bond_cnt | h_cnt << 8 | rad_idx << 16
-// The {vdw, cov} float64 pair of an atom is one of a handful of element values: arp_set_atoms builds a table of the
-// distinct pairs (RAD_TABLE entries at most) and k_sift keeps it in LDS; an atom whose pair did not fit carries
-// RAD_NONE and its radii are fetched from the uploaded array.  Counts saturate at CNT_SAT (then the CSR offsets are
-// read).  The single-bond-neighbour coordinate (halogen / xbond branches only) stays in its uploaded array.
+// What the per-pair kernel holds of each atom of a pair: two 16-byte quads, kept as two columns of the cell-sorted grid and
+// copied to LDS group by group —
+//   s_xyzm = x, y, z, meta      (the search record; meta carries the radius index and the has-hydrogens bit as well)
+//   s_qa   = local atom id, and the first three bonded neighbours (local ids) IN OTHER RESIDUES: -1 = none, .w = -2 = more than
+//            three (then the atom's whole CSR list is walked).  Bonded neighbours of the atom's own residue are left out because
+//            a pair of one residue never reaches the covalent test (I:729 comes before I:748).
+// Everything else — hydrogens, float64 radii, the halogen's neighbour — is read by local id from the uploaded arrays by the few
+// pairs that need it (stage B, rare branches of stage A).
 #define RAD_TABLE 256
 #define RAD_NONE 0xFFFFu
 #define CNT_SAT 255
-struct __attribute__((aligned(32))) SiftRec {
-    float4 xyzm;
-    int4 q1;
-};
 
 // arp_set_single_bond_neighbours: coordinates of every atom's single-bond heavy neighbour (w = 1) or zeros (w = 0)
 __global__ __launch_bounds__(256) void k_gather_neighbours(int n, const int* __restrict__ nbr, const float4* __restrict__ xyz,
@@ -137,8 +138,7 @@ __global__ __launch_bounds__(256) void k_gather_neighbours(int n, const int* __r
 struct StaticAtoms {
     const float4* xyzm;         // x, y, z, static meta
     const int4* aux;            // local id, residue, previous residue, next residue
-    const int4* q1;             // second quad of the sift record (see SiftRec)
-    const int4* b4;             // first bonded neighbours (local ids), see k_prepare_static
+    const int4* qa;             // local id + bonded neighbours in other residues (see above)
     const uint8_t* sel;         // null: nothing selected
     const uint8_t* plus;        // null: everything in selection_plus
     int all;                    // the selection is the whole structure (then selection_plus is, too): sel / plus not read
@@ -216,7 +216,7 @@ struct BlobCheck {
 // Once per uploaded structure, ONE launch: the static record columns, the 6 A cell of every atom for their spatial order
 // (histogram + rank in cell: what k_static_bin did as a launch of its own) and the longest bond / atom - hydrogen distance.
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
-                                                        int4* __restrict__ st_q1, int4* __restrict__ st_b4, GridDesc g6, int* __restrict__ cnt6,
+                                                        int4* __restrict__ st_qa, GridDesc g6, int* __restrict__ cnt6,
                                                         int2* __restrict__ cr6, const double* __restrict__ h_xyz, unsigned int* __restrict__ longest) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
     longest_bond_body(n, r.xyz, r.bond_off, r.bond_idx, r.h_off, h_xyz, longest);
@@ -230,18 +230,20 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
         const float4 sb = r.sb[i];
         if (sb.w != 0.0f) m |= M_HAS_SB;
+        m |= min((uint32_t)r.rad_idx[i], M_RAD4_ESC) << M_RAD4_SHIFT;
+        if (r.h_off[i + 1] > r.h_off[i]) m |= M_HAS_H;
         v.w = __uint_as_float(m);
-        const int h0 = r.h_off[i], b0 = r.bond_off[i], b1 = r.bond_off[i + 1];
-        const int hc = min(r.h_off[i + 1] - h0, CNT_SAT), bc = min(b1 - b0, CNT_SAT);
-        // the first bonded neighbours beside the record (-1: none; w = -2: more than four, the fourth and later ones are in the CSR list)
-        int4 b4 = make_int4(-1, -1, -1, -1);
-        if (b1 > b0) b4.x = r.bond_idx[b0];
-        if (b1 > b0 + 1) b4.y = r.bond_idx[b0 + 1];
-        if (b1 > b0 + 2) b4.z = r.bond_idx[b0 + 2];
-        if (b1 > b0 + 3) b4.w = (b1 > b0 + 4) ? -2 : r.bond_idx[b0 + 3];
-        st_b4[i] = b4;
+        // the bonded neighbours in OTHER residues beside the record (-1: none; w = -2: more than three, walk the CSR list)
+        int4 qa = make_int4(i, -1, -1, -1);
+        int k = 0;
+        for (int b = r.bond_off[i], b1 = r.bond_off[i + 1]; b < b1; ++b) {
+            const int nb = r.bond_idx[b];
+            if (r.res_id[nb] == res) continue;
+            if (k == 0) qa.y = nb; else if (k == 1) qa.z = nb; else if (k == 2) qa.w = nb; else qa.w = -2;
+            ++k;
+        }
         st_xyzm[i] = v;
-        st_q1[i] = make_int4(i, b0, h0, bc | (hc << 8) | ((int)r.rad_idx[i] << 16));
+        st_qa[i] = qa;
         st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
         const int c6 = cell_index(g6, num::d3{(double)v.x, (double)v.y, (double)v.z}, g6.place ? g6.sid_atom[i] : 0);
         cr6[i] = make_int2(c6, atomicAdd(&cnt6[c6], 1));
@@ -273,16 +275,15 @@ __global__ __launch_bounds__(256) void k_static_bin(int n, const float4* __restr
 }
 __global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __restrict__ cr, const int* __restrict__ start,
                                                         const float4* __restrict__ st_xyzm, const int4* __restrict__ st_aux,
-                                                        const int4* __restrict__ st_q1, const int4* __restrict__ st_b4,
-                                                        float4* __restrict__ sp_xyzm, int4* __restrict__ sp_aux, int4* __restrict__ sp_q1,
-                                                        int4* __restrict__ sp_b4, int* __restrict__ sp_cell) {
+                                                        const int4* __restrict__ st_qa,
+                                                        float4* __restrict__ sp_xyzm, int4* __restrict__ sp_aux, int4* __restrict__ sp_qa,
+                                                        int* __restrict__ sp_cell) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 c = cr[i];
         const int pos = start[c.x] + c.y;
         sp_xyzm[pos] = st_xyzm[i];
         sp_aux[pos] = st_aux[i];
-        sp_q1[pos] = st_q1[i];
-        sp_b4[pos] = st_b4[i];
+        sp_qa[pos] = st_qa[i];
         sp_cell[pos] = c.x;
     }
 }
@@ -375,31 +376,25 @@ __global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDes
     }
 }
 
-// one atom's cell-sorted records (search record 32 B; the contact grid adds the second quad of the sift record — with the
-// record's own sorted position in .y — and the first bonded neighbours)
+// one atom's cell-sorted records (search record 32 B; the contact grid adds the second quad of the sift record)
 __device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos, float4* __restrict__ s_xyzm,
-                                            int4* __restrict__ s_aux, int4* __restrict__ s_q1, int4* __restrict__ s_b4) {
+                                            int4* __restrict__ s_aux, int4* __restrict__ s_qa) {
     const int4 aux = r.aux[i];
     const float4 xyzm = compose_xyzm(r, i, aux.x);
     s_xyzm[pos] = xyzm;
     s_aux[pos] = aux;
-    if (s_q1) {
-        int4 q = r.q1[i];
-        q.y = pos;
-        s_q1[pos] = q;
-        s_b4[pos] = r.b4[i];
-    }
+    if (s_qa) s_qa[pos] = r.qa[i];
 }
 
 // counting-sort scatter fused with the record build, start table from a separate scan (large grids)
 __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int2* __restrict__ cell_rank,
                                                        const int* __restrict__ start, float4* __restrict__ s_xyzm,
-                                                       int4* __restrict__ s_aux, int4* __restrict__ s_q1, int4* __restrict__ s_b4, GroupMasks gm) {
+                                                       int4* __restrict__ s_aux, int4* __restrict__ s_qa, GroupMasks gm) {
     group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 cr = cell_rank[i];
         if (cr.x < 0) continue;
-        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_q1, s_b4);
+        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_qa);
     }
 }
 
@@ -417,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
                                                              const int* __restrict__ cell_cnt, int* __restrict__ start,
                                                              unsigned long long* __restrict__ total_out,
                                                              float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
-                                                             int4* __restrict__ s_q1, int4* __restrict__ s_b4, GroupMasks gm) {
+                                                             int4* __restrict__ s_qa, GroupMasks gm) {
     extern __shared__ __attribute__((aligned(16))) int s_start[];   // 16 * STEPS * 256 ints
     group_masks(gm, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024);
     __shared__ int s_wtot[16], s_woff[17];
@@ -429,8 +424,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     const int ii = (i < n) ? i : 0;
     const int4 my_aux = r.aux[ii];
     const float4 my_xyzm = compose_xyzm(r, ii, my_aux.x);
-    const int4 my_q1 = s_q1 ? r.q1[ii] : make_int4(0, 0, 0, 0);
-    const int4 my_b4 = s_q1 ? r.b4[ii] : make_int4(0, 0, 0, 0);
+    const int4 my_qa = s_qa ? r.qa[ii] : make_int4(0, 0, 0, 0);
     int4 v[STEPS];
 #pragma unroll
     for (int k = 0; k < STEPS; ++k) {
@@ -471,10 +465,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
         const int pos = s_start[cr.x] + s_woff[cr.x / CHUNK] + cr.y;
         s_xyzm[pos] = my_xyzm;
         s_aux[pos] = my_aux;
-        if (s_q1) {
-            s_q1[pos] = make_int4(my_q1.x, pos, my_q1.z, my_q1.w);
-            s_b4[pos] = my_b4;
-        }
+        if (s_qa) s_qa[pos] = my_qa;
     }
 }
 
@@ -493,8 +484,7 @@ struct CompactArgs {
     uint32_t req, forb;        // kept: (meta & req) == req && !(meta & forb)
     float4* s_xyzm;
     int4* s_aux;
-    int4* s_q1;                // second quad of the sift record, .y = the row's position in the grid
-    int4* s_b4;
+    int4* s_qa;                // second quad of the sift record
     int* start;                // out: ncell + 1
     int* s_cell;               // out: cell of every kept row (k_search splits its blocks by atoms, not by cells, when the grid is sparse)
     unsigned long long* chain; // one word per block
@@ -534,7 +524,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
     }
     const bool keep = valid && ((m & A.req) == A.req) && !(m & A.forb);
     // the columns of a kept row travel while the counts meet
-    const int4 q1 = A.r.q1[ii], b4 = A.r.b4[ii];
+    const int4 qa = A.r.qa[ii];
     const int my_cell = A.sp_cell[ii];
     const int prev_cell = (i > 0 && valid) ? A.sp_cell[i - 1] : -1;
     const unsigned long long mk = __ballot(keep);
@@ -589,10 +579,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
     if (keep) {
         A.s_xyzm[kp] = xyzm;
         A.s_aux[kp] = aux;
-        if (A.s_q1) {
-            A.s_q1[kp] = make_int4(q1.x, kp, q1.z, q1.w);
-            A.s_b4[kp] = b4;
-        }
+        if (A.s_qa) A.s_qa[kp] = qa;
         if (A.s_cell) A.s_cell[kp] = my_cell;
     }
     // The first row of a cell knows where the cell's kept rows begin; so do the empty cells before it (a protein in its
@@ -798,6 +785,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // (tools/micro/xcc_queue.hip: block b of a 768-block launch ran on XCD (b + 7) % 8)
 __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
 
+#if defined(ARP_SIFT_TRACE) && !defined(ARP_SEARCH_TRACE)
+#define ARP_SEARCH_TRACE      // (the per-pair kernel's trace shares the search trace's buffer and entry points)
+#endif
 #ifdef ARP_SEARCH_TRACE
 // developer builds only (tools/search_trace.py): per block of k_search<MODE_CONTACTS> {start, end of the cell loops, end} in
 // s_memrealtime ticks (100 MHz), the XCD and the hardware id of the block's first wave
@@ -816,7 +806,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                                                                uint8_t* __restrict__ plus, GroupMasks gm, const int* __restrict__ cell_of_pos) {
     // ring / amide sets of _make_selection (I:1433-1437) from the residue tags the grid build of this pass left: every thread
     // of the launch takes at most a few (nothing to do when gm is empty)
-#ifdef ARP_SEARCH_TRACE
+#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE)
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_loops = 0;
 #endif
@@ -1304,7 +1294,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
       __syncthreads();      // (before the cell bounds and the claim counter are written again)
      }
     }
-#ifdef ARP_SEARCH_TRACE
+#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE)
     t_loops = __builtin_amdgcn_s_memrealtime();
 #endif
     // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
@@ -1329,7 +1319,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         for (int k = 0; k < w; ++k) { pbase += (u64)s_qn[k]; gbase += (u64)s_gn[k]; }
         write_out(pbase, gbase);
     }
-#ifdef ARP_SEARCH_TRACE
+#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE)
     if (MODE == MODE_CONTACTS && g_search_trace && lane == 0) {
         unsigned long long* t = g_search_trace + ((size_t)blockIdx.x * SEARCH_WAVES + w) * 4;
         t[0] = t_begin; t[1] = t_loops; t[2] = __builtin_amdgcn_s_memrealtime();
@@ -1439,41 +1429,23 @@ __device__ __forceinline__ float reach_float(double vdw, double comp, double h_s
 #ifndef SIFT_MIN_WAVES
 #define SIFT_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for (sweep in profiles/README.md)
 #endif
-// Arrays k_sift reads beside the 32-byte records
+// Arrays the per-pair kernel reads by LOCAL ATOM ID beside the staged records (stage B and the rare branches of stage A)
 struct SiftSide {
-    const double2* rad_tab;   // RAD_TABLE distinct {vdw, cov} pairs (copied to LDS)
-    const double2* rad;       // uploaded radii by local atom id (atoms outside the table)
-    const int* h_off;         // uploaded CSR offsets by local atom id (saturated counts)
+    const double2* rad_tab;   // the structure's distinct {vdw, cov} pairs: the first 16 make the threshold table
+    const double2* rad;       // {vdw, cov} of every atom
+    const float4* xyz;        // uploaded coordinates (w unused)
+    const int* h_off;         // uploaded CSR offsets
     const int* bond_off;
-    const float4* sb;         // single-bond heavy neighbour by local atom id: x, y, z, present
+    const float4* sb;         // single-bond heavy neighbour: x, y, z, present
     const float* longest_bond;   // k_longest_bond: [0] longest bond, [1] longest atom - hydrogen distance
 };
-__device__ __forceinline__ double2 rec_rad(int4 q1, const double2* s_tab, const SiftSide& sd) {
-    const unsigned ri = (unsigned)q1.w >> 16;
-    double2 r = s_tab[ri & (RAD_TABLE - 1)];   // always an LDS read; the global fetch is a separate, rare branch
-    if (ri == RAD_NONE) {
-        int i = q1.x;
-        asm volatile("" : "+v"(i));   // opaque: keeps the compiler from folding both reads into one flat load
-        r = sd.rad[i];
-    }
-    return r;
-}
-__device__ __forceinline__ int rec_bond_cnt(int4 q1, const SiftSide& sd) {
-    const int k = q1.w & 255;
-    return (k < CNT_SAT) ? k : sd.bond_off[q1.x + 1] - sd.bond_off[q1.x];   // (q1.y is the record's sorted position, not bond_off)
-}
-__device__ __forceinline__ int rec_h_cnt(int4 q1, const SiftSide& sd) {
-    const int k = (q1.w >> 8) & 255;
-    return (k < CNT_SAT) ? k : sd.h_off[q1.x + 1] - q1.z;
-}
 
-// The hydrogen geometry of one pair: the branches in `need` (bit k = branch k of the list in k_sift), run on a
+// The hydrogen geometry of one pair (local ids b, e): the branches in `need` (bit k = branch k of the list in k_sift), run on a
 // lane of the task stage.  Returns the SIFt bits they add.
-__device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftRec& qe, unsigned need, const double* __restrict__ h_xyz,
-                                                  const double2* s_tab, const SiftSide& sd, double comp) {
-    const num::f3 xb = xyz_of(qb.xyzm), xe = xyz_of(qe.xyzm);
-    const double vb = rec_rad(qb.q1, s_tab, sd).x, ve = rec_rad(qe.q1, s_tab, sd).x;
-    const int hb0 = qb.q1.z, hb1 = hb0 + rec_h_cnt(qb.q1, sd), he0 = qe.q1.z, he1 = he0 + rec_h_cnt(qe.q1, sd);
+__device__ __forceinline__ uint32_t sift_geometry(int b, int e, unsigned need, const double* __restrict__ h_xyz, const SiftSide& sd, double comp) {
+    const num::f3 xb = xyz_of(sd.xyz[b]), xe = xyz_of(sd.xyz[e]);
+    const double vb = sd.rad[b].x, ve = sd.rad[e].x;
+    const int hb0 = sd.h_off[b], hb1 = sd.h_off[b + 1], he0 = sd.h_off[e], he1 = sd.h_off[e + 1];
     unsigned todo = need, res = 0;
     while (todo) {                     // almost always one branch per pair
         const int kind = __ffs(todo) - 1;
@@ -1487,7 +1459,7 @@ __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftR
                            donor_b ? ve : vb, comp, amin, cmin);
         } else {
             const bool hal_b = kind == 4;
-            const float4 sbh = sd.sb[hal_b ? qb.q1.x : qe.q1.x];   // w = 1 when the halogen has a single-bond neighbour
+            const float4 sbh = sd.sb[hal_b ? b : e];   // w = 1 when the halogen has a single-bond neighbour
             r = halogen_weak(hal_b ? xb : xe, sbh, hal_b ? vb : ve, h_xyz, hal_b ? he0 : hb0,
                              hal_b ? he1 : hb1, comp);
         }
@@ -1507,7 +1479,10 @@ __device__ __forceinline__ uint32_t sift_geometry(const SiftRec& qb, const SiftR
 #define SIFT_TASKQ 128
 #endif
 #ifndef SIFT_RING
-#define SIFT_RING 256      // records a wave of the per-pair kernel holds in LDS (a power of two; a group stages at most 32 + 128)
+#define SIFT_RING 288      // records a wave of the per-pair kernel holds in LDS (a group stages at most 32 + 128)
+#endif
+#ifndef SIFT_COUNTED_WAIT
+#define SIFT_COUNTED_WAIT 1
 #endif
 #define SIFT_GT 8          // groups a wave has staged at a time
 struct SiftArgs {
@@ -1516,9 +1491,8 @@ struct SiftArgs {
     const int* gmap;
     const u64* npairs_ptr;  // per segment: pairs | groups << GROUP_SHIFT
     u64 cap, gcap;
-    const float4* s_xyzm;   // cell-sorted records: x, y, z, meta
-    const int4* s_q1;       //                      local id, own sorted position, h_off, bond_cnt | h_cnt << 8 | rad_idx << 16
-    const int4* s_b4;       // first bonded neighbours of the atom at each sorted position (k_prepare_static)
+    const float4* s_xyzm;   // cell-sorted records, two 16-byte columns: x, y, z, meta
+    const int4* s_qa;       //   local id, bonded neighbours in other residues
     SiftSide sd;
     const int* bond_idx;
     const double* h_xyz;
@@ -1541,22 +1515,40 @@ __device__ __forceinline__ void put_record(T v, T* p) {
     if (STREAM) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+// The five stores of a batch of records as ONE statement: exactly five vector-memory instructions, in this order, nothing
+// of the compiler's between them — the batch loop counts on it (s_waitcnt vmcnt(5), see sift_body).
+template <int STREAM>
+__device__ __forceinline__ void put_five(int* pi, int vi, int* pj, int vj, float* pd, float vd, uint8_t* pc, unsigned vc, uint16_t* psf, unsigned vs) {
+    if (STREAM)
+        asm volatile("global_store_dword %0, %1, off nt\n\tglobal_store_dword %2, %3, off nt\n\tglobal_store_dword %4, %5, off nt\n\t"
+                     "global_store_byte %6, %7, off nt\n\tglobal_store_short %8, %9, off nt"
+                     :: "v"(pi), "v"(vi), "v"(pj), "v"(vj), "v"(pd), "v"(vd), "v"(pc), "v"(vc), "v"(psf), "v"(vs) : "memory");
+    else
+        asm volatile("global_store_dword %0, %1, off\n\tglobal_store_dword %2, %3, off\n\tglobal_store_dword %4, %5, off\n\t"
+                     "global_store_byte %6, %7, off\n\tglobal_store_short %8, %9, off"
+                     :: "v"(pi), "v"(vi), "v"(pj), "v"(vj), "v"(pd), "v"(vd), "v"(pc), "v"(vc), "v"(psf), "v"(vs) : "memory");
+}
+typedef __attribute__((address_space(3))) void* lds_void_p;
 struct SiftShared {
-    uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
-    double2 tab[RAD_TABLE];      // the structure's distinct {vdw, cov} pairs
+    uint4 tq[4][SIFT_TASKQ];     // {output index, bgn local id, end local id, sift | need << 16}
     float4 thr[256];             // for the first 16 of them, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), reach of the second}
-    float4 rx[4][SIFT_RING];     // per wave: ring of staged records, x, y, z, meta
-    int4 rq[4][SIFT_RING];       //           ... local id, sorted position, h_off, counts | radius index
+    float4 rx[4][SIFT_RING];     // per wave: ring of staged records, two planes (s_xyzm, s_qa)
+    int4 ra[4][SIFT_RING];
     int4 gt[4][SIFT_GT];         // per wave: the staged groups {first descriptor, end, ring slot of home atom 0 | hcount << 16, records}
 };
+__device__ __forceinline__ int ring_wrap(int x) {       // x in [0, 2 RING)
+    if ((SIFT_RING & (SIFT_RING - 1)) == 0) return x & (SIFT_RING - 1);
+    return x >= SIFT_RING ? x - SIFT_RING : x;
+}
 // vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
 // vblock % 8 is still the XCD the dispatcher put the block on)
 template <int STREAM>
 __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgrid, SiftShared* sh) {
+    static_assert(SIFT_RING >= HOME_BLOCK + 128 && SIFT_RING < 32768, "a group (<= 32 home atoms + 128 candidates) must fit the ring");
     const u64* __restrict__ npairs_ptr = A.npairs_ptr;
     const u64 cap = A.cap;
     const float4* __restrict__ s_xyzm = A.s_xyzm;
-    const int4* __restrict__ s_q1 = A.s_q1;
+    const int4* __restrict__ s_qa = A.s_qa;
     const SiftSide sd = A.sd;
     const int* __restrict__ bond_idx = A.bond_idx;
     const double* __restrict__ h_xyz = A.h_xyz;
@@ -1569,7 +1561,6 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     uint8_t* __restrict__ out_ct = A.out_ct;
     int* __restrict__ err = A.err;
     uint4 (*tq)[SIFT_TASKQ] = sh->tq;
-    double2* s_tab = sh->tab;
     // Two stages per wavefront.  Stage A, one lane per pair: everything of I:715-936 that needs no hydrogen — distance
     // ladder, metal, type-pair flags, halogen bond — and the list of hydrogen-geometry branches the pair needs:
     //   0 is_hbond(bgn, end)   1 is_hbond(end, bgn)          (if / elif, I:804-819)
@@ -1580,10 +1571,20 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     // Where the records of a pair come from: the pair list is groups of 16-bit descriptors (PairList).  A wave takes an equal
     // run [f0, f1) of its segment's descriptors (a multiple of 64 each: the waves of a segment differ by one batch at most,
     // as with the flat (i, j) list before), finds the group of f0 through gmap and walks the groups from there: the home and
-    // candidate records of a group are loaded COALESCED (consecutive sorted positions in at most six runs) into the wave's
-    // ring of SIFT_RING records in LDS, and a batch of 64 descriptors — which may span several groups: lanes stay full —
-    // reads its two records from there.
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // candidate records of a group — consecutive sorted positions in at most six runs — are copied into the wave's ring of
+    // SIFT_RING records in LDS by global_load_lds (asynchronous, no registers: issued while the batch before is evaluated),
+    // and a batch of 64 descriptors — which may span several groups: lanes stay full — reads its two records from there.
+    // Stage A issues no global load of its own: the vector-memory operations of a batch are one load of the next descriptors, the
+    // copies for the next batch and, BEHIND them, the five stores of the batch's records (then whatever stage B does).  Memory
+    // operations retire in order on gfx9 (one vmcnt for loads and stores), so "at most five outstanding" at the top of the next
+    // batch means the copies have landed, while the stores may still be on their way: s_waitcnt vmcnt(5), not (0).
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef ARP_SIFT_TRACE
+    unsigned long long tr[8] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0, 0, 0};
+#define SIFT_T(k) tr[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define SIFT_T(k)
+#endif
     // The segment fill counts are read on the device: no host round trip between search and sift.
     // Block b works on the segment of the XCD it runs on — written by the search blocks that ran on the same XCD,
     // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
@@ -1596,7 +1597,6 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     const uint16_t* __restrict__ seg_desc = A.desc + (size_t)sgm * cap;
     const int4* __restrict__ seg_groups = A.groups + (size_t)sgm * A.gcap * GROUP_INT4;
     const int* __restrict__ seg_gmap = A.gmap + (size_t)sgm * (cap / 64 + 1);
-    s_tab[threadIdx.x] = sd.rad_tab[threadIdx.x];   // (blockDim.x == RAD_TABLE)
     {   // the three float32 thresholds of the ladder (I:717-718, 756-773: float64 sums, compared as float32) depend on the two
         // radius pairs only: for the common case — both atoms among the first 16 table entries — they are looked up, not computed
         const double2 ra = sd.rad_tab[threadIdx.x >> 4], rb_ = sd.rad_tab[threadIdx.x & 15];
@@ -1604,14 +1604,12 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), reach_float(rb_.x, comp, h_slack));
     }
     __syncthreads();
+    SIFT_T(1);
     int tn = 0;
     auto run_tasks = [&](int first_, int count) {   // stage B on tq[w][first_ .. first_ + count)
         if (lane < count) {
             const uint4 t = tq[w][first_ + lane];
-            SiftRec qb, qe;
-            qb.xyzm = s_xyzm[t.y]; qb.q1 = s_q1[t.y];
-            qe.xyzm = s_xyzm[t.z]; qe.q1 = s_q1[t.z];
-            const uint32_t add = sift_geometry(qb, qe, t.w >> 16, h_xyz, s_tab, sd, comp);
+            const uint32_t add = sift_geometry((int)t.y, (int)t.z, t.w >> 16, h_xyz, sd, comp);
             put_record<STREAM>((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
         }
     };
@@ -1628,95 +1626,121 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     if (f0 < nseg) {
         const unsigned f1 = min(f0 + quota, nseg);
         float4* const rx = sh->rx[w];
-        int4* const rq = sh->rq[w];
+        int4* const ra = sh->ra[w];
         int4* const gt = sh->gt[w];
-        constexpr int RM = SIFT_RING - 1;
         int g = __builtin_amdgcn_readfirstlane(seg_gmap[f0 >> 6]);          // the group that holds descriptor f0
         unsigned dsc_next = seg_desc[f0 + lane < nseg ? f0 + lane : f0];      // (travels beside the group headers)
         g = min(max(g, 0), max(ngrp - 1, 0));
-        int4 hq = seg_groups[(size_t)g * GROUP_INT4 + (lane & 3)];           // header of group g: word k in the lanes with lane % 4 == k
+        // group headers, sixteen at a time: word k of header g_h0 + j in lane 4 j + k
+        int g_h0 = g;
+        int4 hq = seg_groups[(size_t)min(g_h0 + (lane >> 2), max(ngrp - 1, 0)) * GROUP_INT4 + (lane & 3)];
         int head = 0, used = 0;          // ring: next free slot, records in use
         int gt_lo = 0, gt_n = 0;         // staged groups: oldest entry, how many
-        unsigned staged_end = f0;        // descriptors below this have their records in the ring
-        bool first_group = true;
-        for (unsigned b = f0; b < f1;) {
-            const unsigned need = min(b + 64u, f1);
-            // ---- stage groups until the batch is covered (or the ring / the table is full)
-            while (staged_end < need && g < ngrp && gt_n < SIFT_GT) {
-                const int js0 = __builtin_amdgcn_readlane(hq.x, 0), js1 = __builtin_amdgcn_readlane(hq.y, 0), js2 = __builtin_amdgcn_readlane(hq.z, 0),
-                          js3 = __builtin_amdgcn_readlane(hq.w, 0), js4 = __builtin_amdgcn_readlane(hq.x, 1);
-                const int o1 = __builtin_amdgcn_readlane(hq.y, 1), o2 = __builtin_amdgcn_readlane(hq.z, 1), o3 = __builtin_amdgcn_readlane(hq.w, 1),
-                          o4 = __builtin_amdgcn_readlane(hq.x, 2), total = __builtin_amdgcn_readlane(hq.y, 2);
-                const int hb = __builtin_amdgcn_readlane(hq.z, 2), kb = __builtin_amdgcn_readlane(hq.w, 2);
-                const unsigned gfirst = (unsigned)__builtin_amdgcn_readlane(hq.x, 3);
-                const int gcount = __builtin_amdgcn_readlane(hq.y, 3);
-                const int hcount = min(max(__builtin_amdgcn_readlane(hq.z, 3), 0), HOME_BLOCK);
+        unsigned staged_end = f0;        // descriptors below this have their records in the ring (or on their way)
+        // one run of <= 64 records: lane l < len copies the records at sorted position pos (its own) to ring slot (s0 + l) mod RING.
+        // global_load_lds writes lane l at M0 + 16 l: the part of the run beyond the ring's end is a second issue based RING slots lower.
+        auto copy_run = [&](int pos, int len, int s0) {
+            const int fit = min(len, SIFT_RING - s0);
+            if (lane < fit) {
+                __builtin_amdgcn_global_load_lds(s_xyzm + pos, (lds_void_p)(rx + s0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(s_qa + pos, (lds_void_p)(ra + s0), 16, 0, 0);
+            }
+            if (fit < len && lane >= fit && lane < len) {
+                __builtin_amdgcn_global_load_lds(s_xyzm + pos, (lds_void_p)(rx + (s0 - SIFT_RING)), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(s_qa + pos, (lds_void_p)(ra + (s0 - SIFT_RING)), 16, 0, 0);
+            }
+        };
+        // stage groups until descriptor `upto` is covered, or the ring / the table is full.  ASYNCHRONOUS: the copies are in
+        // flight when this returns (the batch loop waits before it reads the ring)
+        auto stage_until = [&](unsigned upto) {
+            while (staged_end < upto && g < ngrp && gt_n < SIFT_GT) {
+                if (g - g_h0 >= 16) {
+                    g_h0 = g;
+                    hq = seg_groups[(size_t)min(g_h0 + (lane >> 2), ngrp - 1) * GROUP_INT4 + (lane & 3)];
+                }
+                const int hl = __builtin_amdgcn_readfirstlane((g - g_h0) * 4);
+                const int js0 = __builtin_amdgcn_readlane(hq.x, hl), js1 = __builtin_amdgcn_readlane(hq.y, hl), js2 = __builtin_amdgcn_readlane(hq.z, hl),
+                          js3 = __builtin_amdgcn_readlane(hq.w, hl), js4 = __builtin_amdgcn_readlane(hq.x, hl + 1);
+                const int o1 = __builtin_amdgcn_readlane(hq.y, hl + 1), o2 = __builtin_amdgcn_readlane(hq.z, hl + 1), o3 = __builtin_amdgcn_readlane(hq.w, hl + 1),
+                          o4 = __builtin_amdgcn_readlane(hq.x, hl + 2), total = __builtin_amdgcn_readlane(hq.y, hl + 2);
+                const int hb = __builtin_amdgcn_readlane(hq.z, hl + 2), kb = __builtin_amdgcn_readlane(hq.w, hl + 2);
+                const unsigned gfirst = (unsigned)__builtin_amdgcn_readlane(hq.x, hl + 3);
+                const int gcount = __builtin_amdgcn_readlane(hq.y, hl + 3);
+                const int hcount = min(max(__builtin_amdgcn_readlane(hq.z, hl + 3), 0), HOME_BLOCK);
                 const int ncand = min(max(total - kb, 0), 128);
                 const int nrec = hcount + ncand;
                 if (used + nrec > SIFT_RING) break;                           // (a single group always fits: nrec <= 160)
-                if (first_group) { staged_end = max(staged_end, gfirst); first_group = false; }
                 // the records: home atoms [hb, hb + hcount), candidates kb + lane and kb + 64 + lane of the five ranges
-                {
-                    const int k0 = kb + lane, k1 = kb + 64 + lane;
-                    const bool vh = lane < hcount, v0 = lane < ncand, v1 = lane + 64 < ncand;
-                    const int ph = hb + (vh ? lane : 0);
-                    const int p0 = v0 ? cand_pos(k0, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4) : hb;
-                    const float4 xh = s_xyzm[ph];
-                    const int4 qh = s_q1[ph];
-                    const float4 x0 = s_xyzm[p0];
-                    const int4 q0 = s_q1[p0];
-                    if (vh) { rx[(head + lane) & RM] = xh; rq[(head + lane) & RM] = qh; }
-                    if (v0) { rx[(head + hcount + lane) & RM] = x0; rq[(head + hcount + lane) & RM] = q0; }
-                    if (ncand > 64) {
-                        const int p1 = v1 ? cand_pos(k1, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4) : hb;
-                        const float4 x1 = s_xyzm[p1];
-                        const int4 q1 = s_q1[p1];
-                        if (v1) { rx[(head + hcount + 64 + lane) & RM] = x1; rq[(head + hcount + 64 + lane) & RM] = q1; }
-                    }
-                }
+                copy_run(hb + lane, hcount, head);
+                copy_run(cand_pos(kb + lane, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4), min(ncand, 64), ring_wrap(head + hcount));
+                if (ncand > 64)
+                    copy_run(cand_pos(kb + 64 + lane, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4), ncand - 64, ring_wrap(head + hcount + 64));
                 if (lane == 0) gt[(gt_lo + gt_n) & (SIFT_GT - 1)] = make_int4((int)gfirst, (int)(gfirst + (unsigned)gcount), head | (hcount << 16), nrec);
                 ++gt_n;
-                head = (head + nrec) & RM;
+                head = ring_wrap(head + nrec);
                 used += nrec;
                 staged_end = gfirst + (unsigned)gcount;
                 ++g;
-                if (g < ngrp) hq = seg_groups[(size_t)g * GROUP_INT4 + (lane & 3)];
             }
+        };
+        stage_until(min(f0 + 64u, f1));
+        SIFT_T(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the first batch: everything asked for so far)
+        SIFT_T(3);
+        for (unsigned b = f0; b < f1;) {
+            const unsigned need = min(b + 64u, f1);
             __builtin_amdgcn_wave_barrier();
             if (staged_end <= b) break;          // (cannot happen in a pass whose lists did not overflow; such a pass is repeated)
             const unsigned nb = min(need, staged_end) - b;
             const unsigned ps = b + (unsigned)lane;
             const bool live = (unsigned)lane < nb;
             const unsigned dsc = dsc_next;
-            if (b + nb + (unsigned)lane < f1) dsc_next = seg_desc[b + nb + lane];     // the next batch's descriptors travel while this one is evaluated
-            bool queued = false;
-            uint4 task = make_uint4(0u, 0u, 0u, 0u);
             // the group of this lane's descriptor: the last staged one that begins at or before it
             int gslot = 0;
             for (int e = 0; e < gt_n; ++e) {
                 const int4 t = gt[(gt_lo + e) & (SIFT_GT - 1)];
                 gslot = (ps >= (unsigned)t.x) ? t.z : gslot;
             }
-            if (live) {
+            float4 vb, ve;
+            int4 nbr;      // .x = bgn's local id, .y .z .w = its bonded neighbours in other residues (I:748-757)
+            int e;
+            {
+                const int hslot = gslot & 0xFFFF, hcnt = gslot >> 16;
+                const int ih = ring_wrap(hslot + (int)(dsc & 31u)), ic_ = ring_wrap(hslot + hcnt + (int)((dsc >> 5) & 127u));
+                const bool h_first = (dsc & 0x1000u) != 0u;
+                const int ib_ = h_first ? ih : ic_, ie_ = h_first ? ic_ : ih;
+                vb = rx[ib_]; ve = rx[ie_];
+                nbr = ra[ib_];
+                e = ra[ie_].x;
+            }
+            // the records of this batch are in registers: groups that are used up leave the ring, and the records of the next
+            // batch are asked for (they travel while this one is evaluated)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            b += nb;
+            while (gt_n > 0) {
+                const int4 t = gt[gt_lo];
+                if ((unsigned)__builtin_amdgcn_readfirstlane(t.y) > b) break;
+                used -= __builtin_amdgcn_readfirstlane(t.w);
+                gt_lo = (gt_lo + 1) & (SIFT_GT - 1);
+                --gt_n;
+            }
+            if (b < f1) {
+                if (b + (unsigned)lane < f1) dsc_next = seg_desc[b + lane];
+                asm volatile("" ::: "memory");
+                stage_until(min(b + 64u, f1));
+            }
+            bool queued = false;
+            uint4 task = make_uint4(0u, 0u, 0u, 0u);
             const long long p = out_base + (long long)ps;
-            const int hslot = gslot & 0xFFFF, hcnt = gslot >> 16;
-            const int ih = (hslot + (int)(dsc & 31u)) & RM, ic_ = (hslot + hcnt + (int)((dsc >> 5) & 127u)) & RM;
-            const bool h_first = (dsc & 0x1000u) != 0u;
-            const int ib_ = h_first ? ih : ic_, ie_ = h_first ? ic_ : ih;
-            SiftRec qb, qe;
-            qb.xyzm = rx[ib_]; qb.q1 = rq[ib_];
-            qe.xyzm = rx[ie_]; qe.q1 = rq[ie_];
-            const int posb = qb.q1.y, pose = qe.q1.y;                  // sorted positions of the two atoms
-            const float4 vb = qb.xyzm, ve = qe.xyzm;
-            const int b_ = qb.q1.x, e = qe.q1.x;
+            int ct = 0;
+            const int b_ = nbr.x;
+            uint32_t s = 0;
+            float d = 0.0f;
+            if (live) {
+            const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
+            d = num::norm(num::sub(xb, xe));                    // interactions.py:745
             const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
             const uint32_t tb = mb & M_TMASK, te = me & M_TMASK;
-            const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
-            const float d = num::norm(num::sub(xb, xe));                    // interactions.py:745
-            // bgn's first bonded neighbours, for the covalent test (I:748-757): only pairs within the longest bond of the structure
-            // can be bonded, the others read one line all lanes share; asked for here, used at the end of the stage
-            const bool near_bond = d <= longest_bond;
-            const int4 nbr = A.s_b4[near_bond ? posb : 0];
             // Straight-line integer / mask code from here on: the reference's chains of `if` over the two type masks cost this
             // kernel an exec-mask branch each (~350 VALU + 220 SALU instructions per batch of 64 pairs, and VALU issue is what
             // the SIMDs run out of).  Only what is rare keeps a branch: radii outside the threshold table, a bonded-neighbour
@@ -1725,24 +1749,24 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             // interactions.py:643-691 (__get_contact_type): the six overriding assignments as a 16-entry table of 4-bit codes,
             // indexed by bgn selected | end selected << 1 | bgn water << 2 | end water << 3
             const uint32_t ct_idx = ((mb / M_SEL) & 1u) | (((me / M_SEL) & 1u) << 1) | (bw << 2) | (ew << 3);
-            const int ct = (int)((contact_type_table() >> (4u * ct_idx)) & 15ull);
+            ct = (int)((contact_type_table() >> (4u * ct_idx)) & 15ull);
             float f_sum_cov, f_sum_vdw, f_vdw_comp;                         // interactions.py:717-718 and the casts of 756-773
             float reach_e, reach_b;    // >= 1.2 + vdw + comp + the longest atom - hydrogen distance: beyond it no hydrogen of the partner reaches (U:86, 109, 145)
             {
-                const unsigned rib = (unsigned)qb.q1.w >> 16, rie = (unsigned)qe.q1.w >> 16;
-                if ((rib | rie) < 16u) {
+                const unsigned rib = (mb >> M_RAD4_SHIFT) & 15u, rie = (me >> M_RAD4_SHIFT) & 15u;
+                if (rib != M_RAD4_ESC && rie != M_RAD4_ESC) {
                     const float4 t = sh->thr[rib * 16u + rie];
                     f_sum_cov = t.x; f_sum_vdw = t.y; f_vdw_comp = t.z; reach_e = t.w;
                     reach_b = sh->thr[rie * 16u + rib].w;
                 } else {
-                    const double2 rb = rec_rad(qb.q1, s_tab, sd), re = rec_rad(qe.q1, s_tab, sd);   // {vdw, cov}
+                    const double2 rb = sd.rad[b_], re = sd.rad[e];   // {vdw, cov}
                     const double sum_vdw = rb.x + re.x;
                     f_sum_cov = (float)(rb.y + re.y); f_sum_vdw = (float)sum_vdw; f_vdw_comp = (float)(sum_vdw + comp);
                     reach_e = reach_float(re.x, comp, h_slack); reach_b = reach_float(rb.x, comp, h_slack);
                 }
             }
             // interactions.py:756-773: float32 distance against Python floats -> float32 compare; an exclusive ladder
-            uint32_t s = ARP_S_PROXIMAL;                                   // (selects from the bottom up: no branch per rung)
+            s = ARP_S_PROXIMAL;                                   // (selects from the bottom up: no branch per rung)
             s = (d <= f_vdw_comp) ? ARP_S_VDW : s;
             s = (d < f_sum_vdw) ? ARP_S_VDW_CLASH : s;
             s = (d < f_sum_cov) ? ARP_S_CLASH : s;
@@ -1777,7 +1801,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
                 // neighbour (U:139-141), or the partner is beyond the test's reach.  If EVERY applicable branch is such a one the
                 // pair gets no hbond / weak hbond bit — what the loops would find — and is not queued; if one is left the task
                 // runs with the full set (the last applicable weak branch decides, I:857-886).
-                const bool no_hb = (((unsigned)qb.q1.w >> 8) & 255u) == 0u, no_he = (((unsigned)qe.q1.w >> 8) & 255u) == 0u;
+                const bool no_hb = !(mb & M_HAS_H), no_he = !(me & M_HAS_H);
                 unsigned dead = 0;
                 dead |= (no_hb | (d > reach_e)) ? (1u | 8u | 32u) : 0u;               // hydrogens of bgn, target = end
                 dead |= (no_he | (d > reach_b)) ? (2u | 4u | 16u) : 0u;               // hydrogens of end, target = bgn
@@ -1787,11 +1811,11 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             }
             // interactions.py:748-757: end among the bonded neighbours of bgn (only pairs within the longest bond can be)
             // (one of the four equal <=> the smallest of the four XORs is zero; -1 / -2 never equal a local id)
-            const unsigned nx_ = min(min((unsigned)(nbr.x ^ e), (unsigned)(nbr.y ^ e)), min((unsigned)(nbr.z ^ e), (unsigned)(nbr.w ^ e)));
+            const bool near_bond = d <= longest_bond;
+            const unsigned nx_ = min(min((unsigned)(nbr.y ^ e), (unsigned)(nbr.z ^ e)), (unsigned)(nbr.w ^ e));
             bool cov = near_bond & (nx_ == 0u);
-            if (near_bond & !cov & (nbr.w == -2)) {                                   // more than four neighbours: the rest of the list
-                const int k0_ = sd.bond_off[b_];
-                for (int k = k0_ + 3, k1 = k0_ + rec_bond_cnt(qb.q1, sd); k < k1; ++k)
+            if (near_bond & !cov & (nbr.w == -2)) {                                   // more than three neighbours in other residues: the whole list
+                for (int k = sd.bond_off[b_], k1 = sd.bond_off[b_ + 1]; k < k1; ++k)
                     if (bond_idx[k] == e) { cov = true; break; }
             }
             s = cov ? ARP_S_COVALENT : s;
@@ -1799,23 +1823,20 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             // interactions.py:786: feature flags only for pairs that do not clash (covalent ones do get them) within 4.5 A
             const bool feat = !(s & ARP_S_CLASH) & (d <= (float)4.5);
             s |= feat ? f : 0u;
-            unsigned need = feat ? need_ : 0u;
+            const unsigned need = feat ? need_ : 0u;
             // interactions.py:889-895 (halogen bond: float32 angle at the donor), rare
             if (feat & in_vc & ((XY & 4u) != 0u)) {
                 if (X & 4u) { if (xbond(sd.sb[b_], xb, xe, err)) s |= ARP_S_XBOND; }
                 else if (xbond(sd.sb[e], xe, xb, err)) s |= ARP_S_XBOND;
             }
-            put_record<STREAM>(gid ? gid[b_] : b_, out_i + p);
-            put_record<STREAM>(gid ? gid[e] : e, out_j + p);
-            put_record<STREAM>(d, out_d + p);
-            put_record<STREAM>((uint8_t)ct, out_ct + p);
-            if (need) {
+            if (need) {       // (stage B stores the finished mask over the one stored below)
                 queued = true;
-                task = make_uint4((unsigned)p, (unsigned)posb, (unsigned)pose, s | (need << 16));
-            } else {
-                put_record<STREAM>((uint16_t)s, out_s + p);
+                task = make_uint4((unsigned)p, (unsigned)b_, (unsigned)e, s | (need << 16));
             }
             }
+            // the records of the batch: five vector-memory operations behind the copies (a queued pair's mask is stored again by
+            // stage B, later in program order)
+            if (live) put_five<STREAM>(out_i + p, gid ? gid[b_] : b_, out_j + p, gid ? gid[e] : e, out_d + p, d, out_ct + p, (unsigned)ct, out_s + p, s);
             // stage B bookkeeping (whole wave)
             const unsigned long long mq = __ballot(queued);
             if (mq) {
@@ -1826,19 +1847,26 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
                     run_tasks(tn, 64);
                 }
             }
-            b += nb;
-            // retire the groups that are used up
-            __builtin_amdgcn_wave_barrier();
-            while (gt_n > 0) {
-                const int4 t = gt[gt_lo];
-                if ((unsigned)__builtin_amdgcn_readfirstlane(t.y) > b) break;
-                used -= __builtin_amdgcn_readfirstlane(t.w);
-                gt_lo = (gt_lo + 1) & (SIFT_GT - 1);
-                --gt_n;
-            }
+#ifdef ARP_SIFT_TRACE
+            const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (SIFT_COUNTED_WAIT && !gid) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // the next batch's records have landed (its stores may be on their way)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ARP_SIFT_TRACE
+            tr[6] += __builtin_amdgcn_s_memrealtime() - tw0;
+            tr[7] += 1ull | ((unsigned long long)nb << 32);
+#endif
         }
+        SIFT_T(4);
     }
     if (tn > 0) run_tasks(0, tn);
+    SIFT_T(5);
+#ifdef ARP_SIFT_TRACE
+    if (g_search_trace && lane == 0) {
+        unsigned long long* t = g_search_trace + ((size_t)vblock * 4 + w) * 8;
+        for (int k = 0; k < 8; ++k) t[k] = tr[k];
+    }
+#endif
 }
 
 // Per-atom accumulators of the contact loop (interactions.py:821-852, 923-934; utils.py:182-221) from the
