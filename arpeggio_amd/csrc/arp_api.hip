@@ -291,12 +291,7 @@ struct arp_ctx {
     hipEvent_t ev_sel = nullptr, ev_planes = nullptr, ev_lists = nullptr;
     DevBuf<uint8_t> tmp_u8;
     // ---- pair list and outputs of the atom-contact pass
-    DevBuf<int2> pairs;           // arp_search_all: (i, j)
-    // the pair list of a contact pass (PairList, arp_pairs.h): PAIR_SEGS segments of descriptors / group headers / descriptor -> group
-    DevBuf<uint16_t> pl_desc;
-    DevBuf<int4> pl_groups;
-    DevBuf<int> pl_gmap;
-    size_t pl_gcap = 0;           // group headers per segment
+    DevBuf<int2> pairs;
     DevBuf<int> out_i, out_j;
     DevBuf<float> out_d;
     DevBuf<uint16_t> out_s;
@@ -888,6 +883,9 @@ int build_all_grid(arp_ctx* c, double radius, uint8_t* plus_init = nullptr, hipS
     return ARP_OK;
 }
 
+// Entries per segment of the contact pair list: an even number (the per-pair kernel fetches the pairs of a batch as 16-byte
+// quads), and 64 entries short of the allocation (it reads up to a batch beyond the end of a segment and ignores what it gets).
+inline size_t pair_segcap(size_t cap) { return cap > 64 ? ((cap - 64) / PAIR_SEGS) & ~(size_t)1 : 0; }
 // Blocks of the neighbour search: ~ARP_SEARCH_CPW cells per wave, a multiple of 8 (one per XCD).
 int search_blocks(const GridDesc& d, int cpw = 1) {
     int nb = (d.ncell + SEARCH_WAVES * cpw - 1) / (SEARCH_WAVES * cpw);
@@ -1073,7 +1071,7 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
                            c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
-                           0ull, PairList{}, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
+                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
@@ -1381,17 +1379,9 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         CHK(check_launch(c, "k_group_masks"));
     }
     c->contact_cells = c->atom_grid.d.ncell;
-    if (!c->pl_desc.p) HIPCHK(c, c->pl_desc.reserve((size_t)c->n * 16 + 8192));
-    const size_t segcap = (c->pl_desc.cap / PAIR_SEGS) & ~(size_t)63;   // the pair list is PAIR_SEGS segments of segcap descriptors
+    if (!c->pairs.p) HIPCHK(c, c->pairs.reserve((size_t)c->n * 16 + 8192));
+    const size_t segcap = pair_segcap(c->pairs.cap);   // the pair list is PAIR_SEGS segments of segcap entries
     const size_t cap = segcap * PAIR_SEGS;
-    // group headers: a group holds the hits of one home block among one chunk of candidates (~70 at protein density, one at
-    // least); sized for 8 per group and grown like the descriptors when a pass needs more
-    if (!c->pl_groups.p || c->pl_gcap == 0) {
-        c->pl_gcap = std::max<size_t>(c->pl_gcap, segcap / 8 + 1024);
-        HIPCHK(c, c->pl_groups.reserve(c->pl_gcap * PAIR_SEGS * GROUP_INT4));
-    }
-    HIPCHK(c, c->pl_gmap.reserve((segcap / 64 + 1) * PAIR_SEGS));
-    const PairList plist_{c->pl_desc.p, c->pl_groups.p, c->pl_gmap.p, (u64)segcap, (u64)c->pl_gcap};
     if (cap >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "contact list beyond 2^32 entries (k_sift's task queue holds 32-bit output indices)");
     HIPCHK(c, c->out_i.reserve(cap)); HIPCHK(c, c->out_j.reserve(cap)); HIPCHK(c, c->out_d.reserve(cap));
     HIPCHK(c, c->out_s.reserve(cap)); HIPCHK(c, c->out_ct.reserve(cap));
@@ -1434,13 +1424,13 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         if (tile_x == 2) {
             hipLaunchKernelGGL((k_search<MODE_CONTACTS, 2>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->has_home ? 1 : 0, (int2*)nullptr, (u64)segcap, plist_, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
                                c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
                                by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
         } else {
             hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
-                               include_seq_adj, c->has_home ? 1 : 0, (int2*)nullptr, (u64)segcap, plist_, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
+                               include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
                                c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
                                by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
         }
@@ -1459,7 +1449,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // (the blocks split their work statically: all of them must be resident from the start)
         static const int sift_bpc_env = env_int("ARP_SIFT_BPC", 0);
         const int sift_blocks_per_cu = sift_bpc_env > 0 ? sift_bpc_env : c->sift_per_cu;
-        const SiftArgs sa{c->pl_desc.p, c->pl_groups.p, c->pl_gmap.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, (u64)c->pl_gcap, c->s_xyzm.p, c->s_qa.p,
+        const SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_xyzm.p, c->s_qa.p,
                           SiftSide{c->rad_tab.p, c->rad.p, c->xyz.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + ctr_dev(C_ERR))};
@@ -1473,16 +1463,20 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         const int by_work = (int)std::min<int64_t>((expect + pairs_per_block - 1) / pairs_per_block + PAIR_SEGS, 1 << 20);
         const int slots = merged_ ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * sift_blocks_per_cu;
         const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
-        if (merged_ && stream_out)
-            hipLaunchKernelGGL(k_sift_planes<1>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
-                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
-        else if (merged_)
-            hipLaunchKernelGGL(k_sift_planes<0>, dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c),
-                               c->d_ctr + ctr_dev(C_PLIST), np, c->pub);
-        else if (stream_out)
-            hipLaunchKernelGGL(k_sift<1>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
-        else
-            hipLaunchKernelGGL(k_sift<0>, dim3(nsift), dim3(256), 0, c->stream, sa, c->pub);
+        // (four variants each: streaming stores or not, global ids or not — template parameters of the kernels, see sift_body)
+#define LAUNCH_SIFT_PLANES(S, G) hipLaunchKernelGGL((k_sift_planes<S, G>), dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c), \
+                                                    c->d_ctr + ctr_dev(C_PLIST), np, c->pub)
+#define LAUNCH_SIFT(S, G) hipLaunchKernelGGL((k_sift<S, G>), dim3(nsift), dim3(256), 0, c->stream, sa, c->pub)
+        const bool with_gid = sa.gid != nullptr;
+        if (merged_) {
+            if (stream_out) { if (with_gid) LAUNCH_SIFT_PLANES(1, 1); else LAUNCH_SIFT_PLANES(1, 0); }
+            else { if (with_gid) LAUNCH_SIFT_PLANES(0, 1); else LAUNCH_SIFT_PLANES(0, 0); }
+        } else {
+            if (stream_out) { if (with_gid) LAUNCH_SIFT(1, 1); else LAUNCH_SIFT(1, 0); }
+            else { if (with_gid) LAUNCH_SIFT(0, 1); else LAUNCH_SIFT(0, 0); }
+        }
+#undef LAUNCH_SIFT_PLANES
+#undef LAUNCH_SIFT
         return check_launch(c, "k_sift");
     };
     // A structure's FIRST pass (fork_lists): the list chain (~55 us at 100 k atoms) is longer than grid build + search (~43 us), and
@@ -1563,18 +1557,12 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
 
 // After read_counters(): publish contact results; returns true when the pair buffer overflowed.
 bool finish_contacts(arp_ctx* c) {
-    const u64 segcap = (c->pl_desc.cap / PAIR_SEGS) & ~(u64)63;
-    u64 np = 0, worst = 0, worst_g = 0;
-    for (int k = 0; k < PAIR_SEGS; ++k) {      // a segment's word: pairs | groups << GROUP_SHIFT
-        const u64 wd = c->h_ctr[C_SEG_PAIRS + k];
-        np += wd & PAIR_MASK;
-        worst = std::max(worst, wd & PAIR_MASK);
-        worst_g = std::max(worst_g, wd >> GROUP_SHIFT);
-    }
+    const u64 segcap = pair_segcap(c->pairs.cap);
+    u64 np = 0, worst = 0;
+    for (int k = 0; k < PAIR_SEGS; ++k) { np += c->h_ctr[C_SEG_PAIRS + k]; worst = std::max(worst, c->h_ctr[C_SEG_PAIRS + k]); }
     c->h_ctr[C_PAIRS] = np;
     c->h_ctr[C_SCRATCH0] = worst;
-    c->h_ctr[C_SCRATCH1] = worst_g;
-    if (worst > segcap || worst_g > (u64)c->pl_gcap) return true;
+    if (worst > segcap) return true;
     c->n_contacts = (int64_t)np;
     c->contacts_expected = (int64_t)np;
     c->contacts_valid = true;
@@ -1705,16 +1693,9 @@ bool finish_bag(arp_ctx* c, Bag& b, int slot) {
     return false;
 }
 int grow_pairs(arp_ctx* c) {
-    const size_t segcap = (c->pl_desc.cap / PAIR_SEGS) & ~(size_t)63;
-    if ((size_t)c->h_ctr[C_SCRATCH0] > segcap) {
-        const size_t need = (((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 127) & ~(size_t)63) * PAIR_SEGS;
-        c->pl_desc.release(); c->pl_gmap.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
-        HIPCHK(c, c->pl_desc.reserve(need));
-    }
-    if ((size_t)c->h_ctr[C_SCRATCH1] > c->pl_gcap) {
-        c->pl_gcap = (size_t)c->h_ctr[C_SCRATCH1] + (size_t)c->h_ctr[C_SCRATCH1] / 8 + 64;
-        c->pl_groups.release();
-    }
+    const size_t need = ((size_t)c->h_ctr[C_SCRATCH0] + (size_t)c->h_ctr[C_SCRATCH0] / 8 + 64) * PAIR_SEGS;
+    c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
+    HIPCHK(c, c->pairs.reserve(need));
     return ARP_OK;
 }
 int grow_bag(arp_ctx* c, Bag& b, int slot, bool d, bool f) {
@@ -1798,7 +1779,7 @@ int arp_create(int device, arp_ctx** out) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_search<MODE_CONTACTS>, 64 * SEARCH_WAVES, 0) == hipSuccess && per_cu > 0)
             c->search_resident = per_cu * c->num_cu;
         per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_sift_planes<0>, 256, 0) == hipSuccess && per_cu > 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_sift_planes<0, 0>, 256, 0) == hipSuccess && per_cu > 0)
             c->sift_per_cu = per_cu;
     }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
@@ -1840,8 +1821,7 @@ void arp_destroy(arp_ctx* c) {
     c->s_xyzm.release(); c->s_aux.release(); c->s_qa.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_qa.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
     c->sp_xyzm.release(); c->sp_aux.release(); c->sp_qa.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
-    c->pairs.release(); c->pl_desc.release(); c->pl_groups.release(); c->pl_gmap.release(); c->pl_gcap = 0;
-    c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
+    c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();
     c->bag_pack.release(); c->bag_perm.release();
     c->sort_key[0].release(); c->sort_key[1].release(); c->sort_val[0].release(); c->sort_val[1].release();
@@ -2849,7 +2829,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
-                           (u64)cap, PairList{}, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
+                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));

@@ -704,41 +704,12 @@ __global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc, PublishArgs
     pass_end(pub, 0);
 }
 
-// ---- the pair list of a pass: GROUPS + 16-bit descriptors ---------------------------------------------------------
-// k_search<MODE_CONTACTS> does not write (i, j) positions any more (8 bytes per pair, which the per-pair kernel answered with five
-// 16-byte gathers per lane).  It already holds the hits of a unit as 16-bit descriptors {candidate slot, home atom}; those are
-// what it writes, 2 bytes per pair, plus one 64-byte header per GROUP = the hits of one home block (<= 32 home atoms at sorted
-// positions [hb, hb + hcount)) among one 128-candidate chunk [kb, kb + 128) of the unit's candidate list (five contiguous ranges
-// of the cell-sorted arrays).  The per-pair kernel loads a group's home and candidate records COALESCED into LDS once and
-// evaluates its descriptors from there.  Groups and descriptors of a segment (one per XCD) are reserved together by ONE
-// returning atomic on a packed word {pairs: 36 bits, groups: 28 bits}, so the groups of a segment are in the order of their
-// descriptors and tile the descriptor index space without gaps; gmap[f / 64] = the group that holds descriptor f (every
-// multiple of 64), so that a wave of the per-pair kernel can start anywhere.
-//   header, four int4:  {js0, js1, js2, js3} {js4, o1, o2, o3} {o4, total, hb, kb} {first, count, hcount, own index}
-//                       (js = start of a range, o = candidates before it, total = candidates of the unit)
-//   descriptor:         home atom (5 bits) | candidate - kb (7 bits) << 5 | home atom is bgn (lower local id) << 12
-#define GROUP_SHIFT 36
-#define PAIR_MASK ((1ull << GROUP_SHIFT) - 1ull)
-#define GROUP_INT4 4          // int4 words per group header
-struct PairList {
-    uint16_t* desc;           // PAIR_SEGS segments of `cap` descriptors
-    int4* groups;             // PAIR_SEGS segments of `gcap` headers
-    int* gmap;                // PAIR_SEGS segments of `cap / 64 + 1` group indices
-    unsigned long long cap, gcap;
-};
-
 // ---- neighbour search ---------------------------------------------------------------
 #ifndef SEARCH_WAVES
 #define SEARCH_WAVES 8
 #endif
 #ifndef QCAP
-#define QCAP 512     // MODE_PAIRS: (i, j) pairs a wave queues before it flushes
-#endif
-#ifndef QD_CAP
-#define QD_CAP 1024  // MODE_CONTACTS: descriptors a wave queues ...
-#endif
-#ifndef QG_CAP
-#define QG_CAP 16    // ... in at most this many groups
+#define QCAP 512
 #endif
 #ifndef SEARCH_MIN_WAVES
 #define SEARCH_MIN_WAVES 6
@@ -801,7 +772,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                                                                const float4* __restrict__ s_xyzm,
                                                                const int4* __restrict__ s_aux, double r2,
                                                                int include_seq_adj, int count_owned, int2* __restrict__ pairs,
-                                                               unsigned long long cap, PairList pl, u64* __restrict__ ctr_pairs,
+                                                               unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
                                                                uint8_t* __restrict__ plus, GroupMasks gm, const int* __restrict__ cell_of_pos) {
     // ring / amide sets of _make_selection (I:1433-1437) from the residue tags the grid build of this pass left: every thread
@@ -811,10 +782,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     unsigned long long t_loops = 0;
 #endif
     group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-    __shared__ int2 q[MODE == MODE_PAIRS ? SEARCH_WAVES : 1][MODE == MODE_PAIRS ? QCAP : 1];   // raw search_all: (i, j) pairs
-    // contact search: descriptors and group headers of the wave (the expansion search queues nothing)
-    __shared__ uint16_t qd[MODE == MODE_CONTACTS ? SEARCH_WAVES : 1][MODE == MODE_CONTACTS ? QD_CAP : 1];
-    __shared__ int4 qg[MODE == MODE_CONTACTS ? SEARCH_WAVES : 1][MODE == MODE_CONTACTS ? QG_CAP * GROUP_INT4 : 1];
+    __shared__ int2 q[MODE == MODE_MARK ? 1 : SEARCH_WAVES][QCAP];   // (the expansion search queues nothing)
     __shared__ float4 s_hx[SEARCH_WAVES][HOME_BLOCK];   // home atoms of the moment: x, y, z, meta
     __shared__ int4 s_ha[SEARCH_WAVES][HOME_BLOCK];     //                         local id, residue, prev, next
     __shared__ uint16_t s_desc[MODE == MODE_MARK ? 1 : SEARCH_WAVES][DESC_CAP]; // hits of the chunk: candidate slot << 5 | home atom
@@ -865,43 +833,15 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     const int seg = (MODE == MODE_CONTACTS) ? xcc_id() : 0;
     u64* const seg_ctr = ctr_pairs + seg * CTR_LINE;
     int2* const seg_pairs = pairs + (size_t)seg * cap;
-    uint16_t* const seg_desc = pl.desc + (size_t)seg * pl.cap;
-    int4* const seg_groups = pl.groups + (size_t)seg * pl.gcap * GROUP_INT4;
-    int* const seg_gmap = pl.gmap + (size_t)seg * (pl.cap / 64 + 1);
-    int gn = 0;               // groups in the wave's queue (MODE_CONTACTS)
-    // the wave's queue leaves for [pbase, pbase + qn) of the segment's descriptors and [gbase, gbase + gn) of its groups
-    auto write_out = [&](unsigned long long pbase, unsigned long long gbase) {
-        if (MODE == MODE_CONTACTS) {
-            for (int k = lane; k < qn; k += 64)
-                if (pbase + k < pl.cap) seg_desc[pbase + k] = qd[w][k];
-            if (lane < gn) {
-                int4 h3 = qg[w][GROUP_INT4 * lane + 3];
-                const unsigned long long first = pbase + (unsigned)h3.x, end = first + (unsigned)h3.y;
-                h3.x = (int)(unsigned)first;
-                h3.w = (int)(unsigned)(gbase + lane);
-                if (gbase + lane < pl.gcap) {
-                    int4* const dst = seg_groups + (gbase + lane) * GROUP_INT4;
-                    dst[0] = qg[w][GROUP_INT4 * lane];
-                    dst[1] = qg[w][GROUP_INT4 * lane + 1];
-                    dst[2] = qg[w][GROUP_INT4 * lane + 2];
-                    dst[3] = h3;
-                }
-                for (unsigned long long m = (first + 63) >> 6; (m << 6) < end && (m << 6) < pl.cap; ++m) seg_gmap[m] = h3.w;
-            }
-        } else {
-            for (int k = lane; k < qn; k += 64)
-                if (pbase + k < cap) seg_pairs[pbase + k] = q[w][k];
-        }
-    };
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(seg_ctr, (unsigned long long)qn | ((unsigned long long)gn << GROUP_SHIFT));
+        if (lane == 0) base = atomicAdd(seg_ctr, (unsigned long long)qn);
         base = __shfl(base, 0);
-        write_out(base & PAIR_MASK, base >> GROUP_SHIFT);
+        for (int k = lane; k < qn; k += 64)
+            if (base + k < cap) seg_pairs[base + k] = q[w][k];
         __builtin_amdgcn_wave_barrier();
         qn = 0;
-        gn = 0;
     };
 
     // The waves of a block CLAIM its work one HOME BLOCK at a time (a cell's home atoms in blocks of 32: nearly always the
@@ -1203,9 +1143,6 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                 for (;;) {
                     const int c = __popc(l0) + __popc(l1);
                     if (!__any(c != 0)) break;
-                    // MODE_CONTACTS: the hits of a round (<= DESC_CAP) that pass the filters are one GROUP of the pair list
-                    if (MODE == MODE_CONTACTS && (qn + DESC_CAP > QD_CAP || gn == QG_CAP)) flush();
-                    const int gfirst = qn;
                     if (lane == 0) s_dn[w] = 0;
                     __builtin_amdgcn_wave_barrier();
                     int pos = DESC_CAP;
@@ -1238,8 +1175,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                         const uint32_t mj = (uint32_t)fetch((int)mj0, (int)mj1);
                         const int j = fetch(j0, j1);
                         const int h = hb + hh;
-                        bool pass = has, h_first = false;
-                        int pb = 0, pe = 0;
+                        bool pass = has;
+                        int pb, pe;
                         if (MODE == MODE_CONTACTS) {
                             const int4 aj = make_int4(fetch(a0.x, a1.x), fetch(a0.y, a1.y), fetch(a0.z, a1.z), fetch(a0.w, a1.w));
                             const int4 ah = s_ha[w][hh];
@@ -1248,9 +1185,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                             // residue's polypeptide flag is read (I:734 tests res_end twice), whose HOME bit decides
                             // ownership, and the order of the stored positions; the same-residue and sequence-neighbour
                             // tests are symmetric in the two atoms.
-                            h_first = ah.x < aj.x;
+                            const bool h_first = ah.x < aj.x;
                             const uint32_t m_bgn = h_first ? mh : mj;
                             const uint32_t m_end = h_first ? mj : mh;
+                            pb = h_first ? h : j;
+                            pe = h_first ? j : h;
                             // Straight-line filters: interactions.py:729 same residue; 733-741 sequence-adjacent residues — one
                             // of the four links equal <=> the smallest of the four XORs is zero —; ownership: the rank owning
                             // the bgn atom emits the pair
@@ -1265,26 +1204,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                         }
                         const unsigned long long mp = __ballot(pass);
                         if (mp) {
-                            if (MODE == MODE_CONTACTS) {
-                                // slot l < 64 is candidate kb + l, slot 64 + l candidate kb + 127 - l
-                                const unsigned kslot = second ? (unsigned)(191 - cidx) : (unsigned)cidx;
-                                if (pass) qd[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = (uint16_t)((unsigned)hh | (kslot << 5) | (h_first ? 0x1000u : 0u));
-                                qn += __popcll(mp);
-                            } else {
-                                if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
-                                qn += __popcll(mp);
-                                if (qn > QCAP - 64) flush();
-                            }
+                            if (pass) q[w][qn + __popcll(mp & ((1ull << lane) - 1ull))] = make_int2(pb, pe);
+                            qn += __popcll(mp);
+                            if (qn > QCAP - 64) flush();
                         }
-                    }
-                    if (MODE == MODE_CONTACTS && qn > gfirst) {      // close the group of this round
-                        if (lane == 0) {
-                            qg[w][GROUP_INT4 * gn] = make_int4(js0, js1, js2, js3);
-                            qg[w][GROUP_INT4 * gn + 1] = make_int4(js4, o1, o2, o3);
-                            qg[w][GROUP_INT4 * gn + 2] = make_int4(o4, total, hb, kb);
-                            qg[w][GROUP_INT4 * gn + 3] = make_int4(gfirst, qn - gfirst, hcount, 0);
-                        }
-                        ++gn;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1299,25 +1222,26 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
 #endif
     // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
     // run at ~90 per microsecond on this chip, so one per wave would dominate the kernel).
-    __shared__ int s_qn[SEARCH_WAVES], s_gn[SEARCH_WAVES];
+    __shared__ int s_qn[SEARCH_WAVES];
     __shared__ u64 s_base, s_cand[SEARCH_WAVES], s_acc[SEARCH_WAVES];
     const u64 w_cand = wave_sum_u32(n_cand), w_acc = wave_sum_u32(n_acc);
-    if (lane == 0) { s_qn[w] = qn; s_gn[w] = gn; s_cand[w] = w_cand; s_acc[w] = w_acc; }
+    if (lane == 0) { s_qn[w] = qn; s_cand[w] = w_cand; s_acc[w] = w_acc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int tot = 0, totg = 0;
+        int tot = 0;
         u64 tc = 0, ta = 0;
-        for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; totg += s_gn[k]; tc += s_cand[k]; ta += s_acc[k]; }
-        s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot | ((u64)totg << GROUP_SHIFT)) : 0;
+        for (int k = 0; k < SEARCH_WAVES; ++k) { tot += s_qn[k]; tc += s_cand[k]; ta += s_acc[k]; }
+        s_base = (MODE != MODE_MARK && tot > 0) ? atomicAdd(seg_ctr, (u64)tot) : 0;
         const int slot = blockIdx.x & (STAT_SLOTS - 1);
         atomicAdd(ctr_cand + slot * CTR_LINE, tc);
         atomicAdd(ctr_acc + slot * CTR_LINE, ta);
     }
     __syncthreads();
     if (MODE != MODE_MARK && qn > 0) {
-        u64 pbase = s_base & PAIR_MASK, gbase = s_base >> GROUP_SHIFT;
-        for (int k = 0; k < w; ++k) { pbase += (u64)s_qn[k]; gbase += (u64)s_gn[k]; }
-        write_out(pbase, gbase);
+        u64 base = s_base;
+        for (int k = 0; k < w; ++k) base += (u64)s_qn[k];
+        for (int k = lane; k < qn; k += 64)
+            if (base + k < cap) seg_pairs[base + k] = q[w][k];
     }
 #if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE)
     if (MODE == MODE_CONTACTS && g_search_trace && lane == 0) {
@@ -1478,19 +1402,13 @@ __device__ __forceinline__ uint32_t sift_geometry(int b, int e, unsigned need, c
 #ifndef SIFT_TASKQ
 #define SIFT_TASKQ 128
 #endif
-#ifndef SIFT_RING
-#define SIFT_RING 288      // records a wave of the per-pair kernel holds in LDS (a group stages at most 32 + 128)
-#endif
 #ifndef SIFT_COUNTED_WAIT
 #define SIFT_COUNTED_WAIT 1
 #endif
-#define SIFT_GT 8          // groups a wave has staged at a time
 struct SiftArgs {
-    const uint16_t* desc;   // the pair list of the pass (PairList): descriptors, group headers, descriptor -> group
-    const int4* groups;
-    const int* gmap;
-    const u64* npairs_ptr;  // per segment: pairs | groups << GROUP_SHIFT
-    u64 cap, gcap;
+    const int2* pairs;      // the pair list of the pass: sorted positions (bgn, end), PAIR_SEGS segments of `cap` entries
+    const u64* npairs_ptr;  // pairs per segment
+    u64 cap;
     const float4* s_xyzm;   // cell-sorted records, two 16-byte columns: x, y, z, meta
     const int4* s_qa;       //   local id, bonded neighbours in other residues
     SiftSide sd;
@@ -1531,20 +1449,19 @@ __device__ __forceinline__ void put_five(int* pi, int vi, int* pj, int vj, float
 typedef __attribute__((address_space(3))) void* lds_void_p;
 struct SiftShared {
     uint4 tq[4][SIFT_TASKQ];     // {output index, bgn local id, end local id, sift | need << 16}
-    float4 thr[256];             // for the first 16 of them, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), reach of the second}
-    float4 rx[4][SIFT_RING];     // per wave: ring of staged records, two planes (s_xyzm, s_qa)
-    int4 ra[4][SIFT_RING];
-    int4 gt[4][SIFT_GT];         // per wave: the staged groups {first descriptor, end, ring slot of home atom 0 | hcount << 16, records}
+    float4 thr[256];             // for the first 16 radius pairs, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), reach of the second}
+    // per wave: the records of ONE batch of 64 pairs, lane l's in slot l — gathered by global_load_lds while the batch before is evaluated
+    float4 xb[4][64], xe[4][64];
+    int4 qb[4][64], qe[4][64];
+    int2 pr[4][64];              // per wave: the pairs of the batch after that (one global_load_lds of 16 bytes by 32 lanes)
 };
-__device__ __forceinline__ int ring_wrap(int x) {       // x in [0, 2 RING)
-    if ((SIFT_RING & (SIFT_RING - 1)) == 0) return x & (SIFT_RING - 1);
-    return x >= SIFT_RING ? x - SIFT_RING : x;
-}
 // vblock / vgrid: this block's index among the sift blocks of the launch (a multiple of 8 blocks precedes them, so
 // vblock % 8 is still the XCD the dispatcher put the block on)
-template <int STREAM>
+// GID: the records carry global ids (a shard): a template parameter, because a run-time `gid ? gid[b] : b` leaves a full
+// s_waitcnt vmcnt(0) behind its branch — in front of the stores, i.e. a wait for the gather that was to travel meanwhile
+template <int STREAM, int GID>
 __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgrid, SiftShared* sh) {
-    static_assert(SIFT_RING >= HOME_BLOCK + 128 && SIFT_RING < 32768, "a group (<= 32 home atoms + 128 candidates) must fit the ring");
+    const int2* __restrict__ pairs = A.pairs;
     const u64* __restrict__ npairs_ptr = A.npairs_ptr;
     const u64 cap = A.cap;
     const float4* __restrict__ s_xyzm = A.s_xyzm;
@@ -1568,16 +1485,16 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     // Only ~15 % of the pairs need one, so those lanes are compacted (ballot) into a per-wave LDS task queue and
     // stage B runs the float64 hydrogen loops on 64 queued pairs at a time — full lanes instead of ~10 of 64.
     //
-    // Where the records of a pair come from: the pair list is groups of 16-bit descriptors (PairList).  A wave takes an equal
-    // run [f0, f1) of its segment's descriptors (a multiple of 64 each: the waves of a segment differ by one batch at most,
-    // as with the flat (i, j) list before), finds the group of f0 through gmap and walks the groups from there: the home and
-    // candidate records of a group — consecutive sorted positions in at most six runs — are copied into the wave's ring of
-    // SIFT_RING records in LDS by global_load_lds (asynchronous, no registers: issued while the batch before is evaluated),
-    // and a batch of 64 descriptors — which may span several groups: lanes stay full — reads its two records from there.
-    // Stage A issues no global load of its own: the vector-memory operations of a batch are one load of the next descriptors, the
-    // copies for the next batch and, BEHIND them, the five stores of the batch's records (then whatever stage B does).  Memory
-    // operations retire in order on gfx9 (one vmcnt for loads and stores), so "at most five outstanding" at the top of the next
-    // batch means the copies have landed, while the stores may still be on their way: s_waitcnt vmcnt(5), not (0).
+    // The two 32-byte records of a pair are a GATHER (four 16-byte loads per lane at unrelated addresses), and waiting for it in
+    // every batch was more than half of this kernel's wave cycles.  Now the gather of batch k + 1 is issued while batch k is
+    // evaluated, as global_load_lds: asynchronous, no registers — lane l's four quads land in slot l of four LDS planes of the
+    // wave, which the batch reads back as soon as its turn comes (consecutive slots: no bank conflicts).  One buffer is enough:
+    // a batch moves its records to registers first, and the next gather is issued behind that.
+    // Stage A issues no other global load: the vector-memory operations of an iteration are, in this order, the pairs of the
+    // batch after the next one (one load), the gather of the next batch (four copies), the five stores of this batch's records,
+    // then whatever stage B does.  Memory operations retire in order on gfx9 (one vmcnt for loads and stores), so "at most
+    // five outstanding" at the top of the next iteration means pairs and records have landed while the stores may still be on
+    // their way: s_waitcnt vmcnt(5), not (0) — the wave never waits for its own stores.
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifdef ARP_SIFT_TRACE
     unsigned long long tr[8] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0, 0, 0};
@@ -1586,7 +1503,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
 #define SIFT_T(k)
 #endif
     // The segment fill counts are read on the device: no host round trip between search and sift.
-    // Block b works on the segment of the XCD it runs on — written by the search blocks that ran on the same XCD,
+    // Block b works on the segment of the XCD it runs on — the pairs written by the search blocks that ran on the same XCD,
     // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
     const int sgm = xcc_id();      // (blocks b with the same b % 8 share an XCD, whichever it is: vblock / 8 still numbers the blocks of a segment)
     u64 heads[PAIR_SEGS];
@@ -1594,15 +1511,44 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_ * CTR_LINE];
     const float longest_bond = sd.longest_bond[0];
     const double h_slack = (double)sd.longest_bond[1] + 1e-4;   // |H - A| >= |D - A| - h_slack for every hydrogen H of D (margin: float32 distance, roundings)
-    const uint16_t* __restrict__ seg_desc = A.desc + (size_t)sgm * cap;
-    const int4* __restrict__ seg_groups = A.groups + (size_t)sgm * A.gcap * GROUP_INT4;
-    const int* __restrict__ seg_gmap = A.gmap + (size_t)sgm * (cap / 64 + 1);
+    const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
+    const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
+    const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
+    // (a pair beyond the end of the segment is read and ignored: the list is padded — see enqueue_contacts — and the count
+    // that says so is still on its way)
+    const int2 pr0 = (first + lane < (long long)cap) ? seg_pairs[first + lane] : make_int2(0, 0);
     {   // the three float32 thresholds of the ladder (I:717-718, 756-773: float64 sums, compared as float32) depend on the two
-        // radius pairs only: for the common case — both atoms among the first 16 table entries — they are looked up, not computed
+        // radius pairs only: for the common case — both atoms among the first 15 table entries — they are looked up, not computed
         const double2 ra = sd.rad_tab[threadIdx.x >> 4], rb_ = sd.rad_tab[threadIdx.x & 15];
         const double sv = ra.x + rb_.x;
         sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), reach_float(rb_.x, comp, h_slack));
     }
+    float4* const lxb = sh->xb[w];
+    float4* const lxe = sh->xe[w];
+    int4* const lqb = sh->qb[w];
+    int4* const lqe = sh->qe[w];
+    int2* const lpr = sh->pr[w];
+    // the gather of one batch: lane l's records -> slot l of the wave's four planes
+    auto gather = [&](int2 pr) {
+        __builtin_amdgcn_global_load_lds(s_xyzm + pr.x, (lds_void_p)lxb, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(s_qa + pr.x, (lds_void_p)lqb, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(s_xyzm + pr.y, (lds_void_p)lxe, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(s_qa + pr.y, (lds_void_p)lqe, 16, 0, 0);
+    };
+    // the 64 pairs that begin at `at` -> the wave's pair slots (lanes 0 .. 31 bring two pairs each).  The compiler must not see
+    // a load of its own here: it would wait for it with vmcnt(0) at the loop's edge — for this batch's stores, that is
+    auto fetch_pairs = [&](long long at) {
+        if (lane < 32) __builtin_amdgcn_global_load_lds(reinterpret_cast<const int4*>(seg_pairs + at) + lane, (lds_void_p)lpr, 16, 0, 0);
+    };
+    long long out_base = 0;
+#pragma unroll
+    for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
+        if (q_ < sgm) out_base += (long long)min(heads[q_], cap);
+    const long long nseg = (long long)min(heads[sgm], cap);
+    // (the first batch's records, before the barrier: they travel while the table is made.  Only pairs of THIS pass are followed:
+    // what lies beyond the end of the list are positions of another pass, of another structure perhaps)
+    if (first + lane < nseg) gather(pr0);
+    if (first + stride < nseg) fetch_pairs(first + stride);
     __syncthreads();
     SIFT_T(1);
     int tn = 0;
@@ -1612,131 +1558,35 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             const uint32_t add = sift_geometry((int)t.y, (int)t.z, t.w >> 16, h_xyz, sd, comp);
             put_record<STREAM>((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
         }
+        // (the compiler's own count of pending loads ends here: left open, it puts s_waitcnt vmcnt(0) at the edge of the batch
+        // loop — where the copies for the next batch and this batch's stores are in flight by design)
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     };
-    long long out_base = 0;
-#pragma unroll
-    for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
-        if (q_ < sgm) out_base += (long long)min(heads[q_] & PAIR_MASK, cap);
-    const unsigned nseg = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)min(heads[sgm] & PAIR_MASK, cap));
-    const int ngrp = __builtin_amdgcn_readfirstlane((int)min(heads[sgm] >> GROUP_SHIFT, A.gcap));
-    // equal runs of descriptors, a multiple of 64 each
-    const unsigned nwv = (unsigned)(vgrid / PAIR_SEGS) * 4u, wid = (unsigned)(vblock / PAIR_SEGS) * 4u + (unsigned)w;
-    const unsigned quota = (unsigned)__builtin_amdgcn_readfirstlane((int)((((nseg + nwv - 1u) / nwv) + 63u) & ~63u));
-    const unsigned f0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wid * quota));
-    if (f0 < nseg) {
-        const unsigned f1 = min(f0 + quota, nseg);
-        float4* const rx = sh->rx[w];
-        int4* const ra = sh->ra[w];
-        int4* const gt = sh->gt[w];
-        int g = __builtin_amdgcn_readfirstlane(seg_gmap[f0 >> 6]);          // the group that holds descriptor f0
-        unsigned dsc_next = seg_desc[f0 + lane < nseg ? f0 + lane : f0];      // (travels beside the group headers)
-        g = min(max(g, 0), max(ngrp - 1, 0));
-        // group headers, sixteen at a time: word k of header g_h0 + j in lane 4 j + k
-        int g_h0 = g;
-        int4 hq = seg_groups[(size_t)min(g_h0 + (lane >> 2), max(ngrp - 1, 0)) * GROUP_INT4 + (lane & 3)];
-        int head = 0, used = 0;          // ring: next free slot, records in use
-        int gt_lo = 0, gt_n = 0;         // staged groups: oldest entry, how many
-        unsigned staged_end = f0;        // descriptors below this have their records in the ring (or on their way)
-        // one run of <= 64 records: lane l < len copies the records at sorted position pos (its own) to ring slot (s0 + l) mod RING.
-        // global_load_lds writes lane l at M0 + 16 l: the part of the run beyond the ring's end is a second issue based RING slots lower.
-        auto copy_run = [&](int pos, int len, int s0) {
-            const int fit = min(len, SIFT_RING - s0);
-            if (lane < fit) {
-                __builtin_amdgcn_global_load_lds(s_xyzm + pos, (lds_void_p)(rx + s0), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(s_qa + pos, (lds_void_p)(ra + s0), 16, 0, 0);
-            }
-            if (fit < len && lane >= fit && lane < len) {
-                __builtin_amdgcn_global_load_lds(s_xyzm + pos, (lds_void_p)(rx + (s0 - SIFT_RING)), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(s_qa + pos, (lds_void_p)(ra + (s0 - SIFT_RING)), 16, 0, 0);
-            }
-        };
-        // stage groups until descriptor `upto` is covered, or the ring / the table is full.  ASYNCHRONOUS: the copies are in
-        // flight when this returns (the batch loop waits before it reads the ring)
-        auto stage_until = [&](unsigned upto) {
-            while (staged_end < upto && g < ngrp && gt_n < SIFT_GT) {
-                if (g - g_h0 >= 16) {
-                    g_h0 = g;
-                    hq = seg_groups[(size_t)min(g_h0 + (lane >> 2), ngrp - 1) * GROUP_INT4 + (lane & 3)];
-                }
-                const int hl = __builtin_amdgcn_readfirstlane((g - g_h0) * 4);
-                const int js0 = __builtin_amdgcn_readlane(hq.x, hl), js1 = __builtin_amdgcn_readlane(hq.y, hl), js2 = __builtin_amdgcn_readlane(hq.z, hl),
-                          js3 = __builtin_amdgcn_readlane(hq.w, hl), js4 = __builtin_amdgcn_readlane(hq.x, hl + 1);
-                const int o1 = __builtin_amdgcn_readlane(hq.y, hl + 1), o2 = __builtin_amdgcn_readlane(hq.z, hl + 1), o3 = __builtin_amdgcn_readlane(hq.w, hl + 1),
-                          o4 = __builtin_amdgcn_readlane(hq.x, hl + 2), total = __builtin_amdgcn_readlane(hq.y, hl + 2);
-                const int hb = __builtin_amdgcn_readlane(hq.z, hl + 2), kb = __builtin_amdgcn_readlane(hq.w, hl + 2);
-                const unsigned gfirst = (unsigned)__builtin_amdgcn_readlane(hq.x, hl + 3);
-                const int gcount = __builtin_amdgcn_readlane(hq.y, hl + 3);
-                const int hcount = min(max(__builtin_amdgcn_readlane(hq.z, hl + 3), 0), HOME_BLOCK);
-                const int ncand = min(max(total - kb, 0), 128);
-                const int nrec = hcount + ncand;
-                if (used + nrec > SIFT_RING) break;                           // (a single group always fits: nrec <= 160)
-                // the records: home atoms [hb, hb + hcount), candidates kb + lane and kb + 64 + lane of the five ranges
-                copy_run(hb + lane, hcount, head);
-                copy_run(cand_pos(kb + lane, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4), min(ncand, 64), ring_wrap(head + hcount));
-                if (ncand > 64)
-                    copy_run(cand_pos(kb + 64 + lane, o1, o2, o3, o4, js0, js1 - o1, js2 - o2, js3 - o3, js4 - o4), ncand - 64, ring_wrap(head + hcount + 64));
-                if (lane == 0) gt[(gt_lo + gt_n) & (SIFT_GT - 1)] = make_int4((int)gfirst, (int)(gfirst + (unsigned)gcount), head | (hcount << 16), nrec);
-                ++gt_n;
-                head = ring_wrap(head + nrec);
-                used += nrec;
-                staged_end = gfirst + (unsigned)gcount;
-                ++g;
-            }
-        };
-        stage_until(min(f0 + 64u, f1));
-        SIFT_T(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the first batch: everything asked for so far)
-        SIFT_T(3);
-        for (unsigned b = f0; b < f1;) {
-            const unsigned need = min(b + 64u, f1);
-            __builtin_amdgcn_wave_barrier();
-            if (staged_end <= b) break;          // (cannot happen in a pass whose lists did not overflow; such a pass is repeated)
-            const unsigned nb = min(need, staged_end) - b;
-            const unsigned ps = b + (unsigned)lane;
-            const bool live = (unsigned)lane < nb;
-            const unsigned dsc = dsc_next;
-            // the group of this lane's descriptor: the last staged one that begins at or before it
-            int gslot = 0;
-            for (int e = 0; e < gt_n; ++e) {
-                const int4 t = gt[(gt_lo + e) & (SIFT_GT - 1)];
-                gslot = (ps >= (unsigned)t.x) ? t.z : gslot;
-            }
-            float4 vb, ve;
-            int4 nbr;      // .x = bgn's local id, .y .z .w = its bonded neighbours in other residues (I:748-757)
-            int e;
-            {
-                const int hslot = gslot & 0xFFFF, hcnt = gslot >> 16;
-                const int ih = ring_wrap(hslot + (int)(dsc & 31u)), ic_ = ring_wrap(hslot + hcnt + (int)((dsc >> 5) & 127u));
-                const bool h_first = (dsc & 0x1000u) != 0u;
-                const int ib_ = h_first ? ih : ic_, ie_ = h_first ? ic_ : ih;
-                vb = rx[ib_]; ve = rx[ie_];
-                nbr = ra[ib_];
-                e = ra[ie_].x;
-            }
-            // the records of this batch are in registers: groups that are used up leave the ring, and the records of the next
-            // batch are asked for (they travel while this one is evaluated)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            b += nb;
-            while (gt_n > 0) {
-                const int4 t = gt[gt_lo];
-                if ((unsigned)__builtin_amdgcn_readfirstlane(t.y) > b) break;
-                used -= __builtin_amdgcn_readfirstlane(t.w);
-                gt_lo = (gt_lo + 1) & (SIFT_GT - 1);
-                --gt_n;
-            }
-            if (b < f1) {
-                if (b + (unsigned)lane < f1) dsc_next = seg_desc[b + lane];
-                asm volatile("" ::: "memory");
-                stage_until(min(b + 64u, f1));
-            }
-            bool queued = false;
-            uint4 task = make_uint4(0u, 0u, 0u, 0u);
-            const long long p = out_base + (long long)ps;
-            int ct = 0;
-            const int b_ = nbr.x;
-            uint32_t s = 0;
-            float d = 0.0f;
-            if (live) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the first batch: everything asked for so far)
+    SIFT_T(3);
+    for (long long base = first; base < nseg; base += stride) {
+        const long long ps = base + lane;   // (wave-uniform trip count: the queue below is a wave-wide affair)
+        const bool live = ps < nseg;
+        __builtin_amdgcn_wave_barrier();
+        // this batch's records: LDS -> registers
+        const float4 vb = lxb[lane], ve = lxe[lane];
+        const int4 nbr = lqb[lane];       // .x = bgn's local id, .y .z .w = its bonded neighbours in other residues (I:748-757)
+        const int e = lqe[lane].x;
+        const int2 pr = lpr[lane];        // the next batch's pairs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ... and the buffers are free: the pairs of the batch after the next one, the gather of the next batch
+        if (base + stride < nseg) {
+            if (base + 2 * stride < nseg) fetch_pairs(base + 2 * stride);      // (up to 63 entries beyond the segment's end are read and ignored: pair_segcap)
+            if (ps + stride < nseg) gather(pr);
+        }
+        bool queued = false;
+        uint4 task = make_uint4(0u, 0u, 0u, 0u);
+        const long long p = out_base + ps;
+        int ct = 0;
+        const int b_ = nbr.x;
+        uint32_t s = 0;
+        float d = 0.0f;
+        if (live) {
             const num::f3 xb = xyz_of(vb), xe = xyz_of(ve);
             d = num::norm(num::sub(xb, xe));                    // interactions.py:745
             const uint32_t mb = __float_as_uint(vb.w), me = __float_as_uint(ve.w);
@@ -1823,7 +1673,11 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             // interactions.py:786: feature flags only for pairs that do not clash (covalent ones do get them) within 4.5 A
             const bool feat = !(s & ARP_S_CLASH) & (d <= (float)4.5);
             s |= feat ? f : 0u;
+#ifdef EXP_NOTASKS      // (timing experiments only: no hydrogen geometry)
+            const unsigned need = 0u;
+#else
             const unsigned need = feat ? need_ : 0u;
+#endif
             // interactions.py:889-895 (halogen bond: float32 angle at the donor), rare
             if (feat & in_vc & ((XY & 4u) != 0u)) {
                 if (X & 4u) { if (xbond(sd.sb[b_], xb, xe, err)) s |= ARP_S_XBOND; }
@@ -1834,31 +1688,30 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
                 task = make_uint4((unsigned)p, (unsigned)b_, (unsigned)e, s | (need << 16));
             }
             }
-            // the records of the batch: five vector-memory operations behind the copies (a queued pair's mask is stored again by
-            // stage B, later in program order)
-            if (live) put_five<STREAM>(out_i + p, gid ? gid[b_] : b_, out_j + p, gid ? gid[e] : e, out_d + p, d, out_ct + p, (unsigned)ct, out_s + p, s);
-            // stage B bookkeeping (whole wave)
-            const unsigned long long mq = __ballot(queued);
-            if (mq) {
-                if (queued) tq[w][tn + __popcll(mq & ((1ull << lane) - 1ull))] = task;
-                tn += __popcll(mq);
-                if (tn >= 64) {
-                    tn -= 64;
-                    run_tasks(tn, 64);
-                }
+        // the records of the batch: five vector-memory operations behind the gather (a queued pair's mask is stored again by
+        // stage B, later in program order)
+        if (live) put_five<STREAM>(out_i + p, GID ? gid[b_] : b_, out_j + p, GID ? gid[e] : e, out_d + p, d, out_ct + p, (unsigned)ct, out_s + p, s);
+        // stage B bookkeeping (whole wave)
+        const unsigned long long mq = __ballot(queued);
+        if (mq) {
+            if (queued) tq[w][tn + __popcll(mq & ((1ull << lane) - 1ull))] = task;
+            tn += __popcll(mq);
+            if (tn >= 64) {
+                tn -= 64;
+                run_tasks(tn, 64);
             }
-#ifdef ARP_SIFT_TRACE
-            const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
-#endif
-            if (SIFT_COUNTED_WAIT && !gid) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // the next batch's records have landed (its stores may be on their way)
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef ARP_SIFT_TRACE
-            tr[6] += __builtin_amdgcn_s_memrealtime() - tw0;
-            tr[7] += 1ull | ((unsigned long long)nb << 32);
-#endif
         }
-        SIFT_T(4);
+#ifdef ARP_SIFT_TRACE
+        const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (SIFT_COUNTED_WAIT) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // the next batch's records have landed (this one's stores may be on their way)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ARP_SIFT_TRACE
+        tr[6] += __builtin_amdgcn_s_memrealtime() - tw0;
+        tr[7] += 1ull | ((unsigned long long)__popcll(__ballot(live)) << 32);
+#endif
     }
+    SIFT_T(4);
     if (tn > 0) run_tasks(0, tn);
     SIFT_T(5);
 #ifdef ARP_SIFT_TRACE

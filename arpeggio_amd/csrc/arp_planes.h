@@ -774,13 +774,13 @@ union SiftPlanesShared {
     PlaneShared planes;
     SiftShared sift;
 };
-template <int STREAM>
+template <int STREAM, int GID = 0>
 __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa, int nsift, AtomPlaneArgs ap, PlanePlaneArgs pp,
                                                                      GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
                                                                      u64* publish_counts, int np, PublishArgs pub) {
     __shared__ SiftPlanesShared s_sh;
     const int b = (int)blockIdx.x;
-    if (b >= np) sift_body<STREAM>(sa, b - np, nsift, &s_sh.sift);
+    if (b >= np) sift_body<STREAM, GID>(sa, b - np, nsift, &s_sh.sift);
     else planes_from_lists(ap, pp, gg, gp, L, publish_counts, b, np, &s_sh.planes);
     pass_end(pub, 0);
 }
@@ -791,9 +791,9 @@ __global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs
     planes_from_lists(ap, pp, gg, gp, L, publish_counts, (int)blockIdx.x, (int)gridDim.x, &s_sh);
     pass_end(pub, 1);
 }
-template <int STREAM>
+template <int STREAM, int GID = 0>
 __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift(SiftArgs sa, PublishArgs pub) {
     __shared__ SiftShared s_sh;
-    sift_body<STREAM>(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+    sift_body<STREAM, GID>(sa, (int)blockIdx.x, (int)gridDim.x, &s_sh);
     pass_end(pub, 0);
 }

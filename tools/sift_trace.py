@@ -33,7 +33,7 @@ print(f'{len(t)} waves, {int(work.sum())} with a run of descriptors')
 print('start', q(rel(0)), ' tables ready', q(rel(1)))
 w = t[work]
 r = lambda k: (w[:, k].astype(np.int64) - int(t0)) * TICK
-print('first copies issued (gmap + headers arrived)', q(r(2)), ' landed', q(r(3)))
+print('first batch landed', q(r(3)))
 print('loop ends', q(r(4)), ' wave ends', q(r(5)))
 iters = (w[:, 7] & 0xFFFFFFFF).astype(np.int64); lanes = (w[:, 7] >> 32).astype(np.int64)
 print('batches per wave', q(iters), ' lanes per batch', round(float(lanes.sum() / max(iters.sum(), 1)), 1), ' pairs', int(lanes.sum()))
