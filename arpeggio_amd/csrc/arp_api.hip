@@ -208,7 +208,8 @@ struct arp_ctx {
     std::string err;
     int num_cu = 256;
     int search_resident = 768;          // blocks of k_search<MODE_CONTACTS> the chip holds at once (occupancy x CUs)
-    int sift_per_cu = 3;                // blocks of the per-pair kernel a CU holds at once (its LDS ring bounds it)
+    int sift_per_cu = 4;                // blocks of the per-pair kernel a CU holds at once
+    uint64_t seg_last[PAIR_SEGS] = {0, 0, 0, 0, 0, 0, 0, 0};   // pairs per segment of the last contact pass (the next one's sift blocks are shared out by it)
 
     // ---- sizes
     int64_t n = 0, nres = 0, nring = 0, namide = 0;
@@ -251,6 +252,7 @@ struct arp_ctx {
     DevBuf<float4> s_xyzm;
     DevBuf<int4> s_aux;
     DevBuf<int4> s_qa;            // second quad of the sift records, cell-sorted (the first one is s_xyzm)
+    DevBuf<int> st_h, sp_h, s_h;  // index of every atom's first hydrogen: static, in the spatial order, cell-sorted
     DevBuf<int> tmp_i32;          // scratch for index uploads
     DevBuf<int4> st_qa;           // selection-independent record columns, composed once per structure (k_prepare_static)
     DevBuf<float> longest_bond;   // k_longest_bond, once per uploaded structure (ensure_static)
@@ -653,6 +655,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         c->lists_dirty = true;
         c->contacts_expected = 0;
         HIPCHK(c, c->st_qa.reserve((size_t)std::max(n, 1)));
+        HIPCHK(c, c->st_h.reserve((size_t)std::max(n, 1)));
         HIPCHK(c, c->st_aux.reserve((size_t)std::max(n, 1)));
         HIPCHK(c, c->st_xyzm.reserve((size_t)std::max(n, 1)));
     }
@@ -667,7 +670,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         // counting sort by cell.  The longest-bond words sit behind the histogram, so ONE fill clears both.
         GridDesc d;
         CHK(grid_desc_for(c, d, c->lo, c->hi, radius));
-        HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_qa.reserve((size_t)n));
+        HIPCHK(c, c->sp_xyzm.reserve((size_t)n)); HIPCHK(c, c->sp_aux.reserve((size_t)n)); HIPCHK(c, c->sp_qa.reserve((size_t)n)); HIPCHK(c, c->sp_h.reserve((size_t)n));
         HIPCHK(c, c->sp_cr.reserve((size_t)n)); HIPCHK(c, c->sp_cell.reserve((size_t)n));
         // layout of sp_cnt: [longest bond, longest atom - hydrogen distance, 2 words of padding | histogram of ncell + 1 cells]:
         // a fresh structure clears all of it with ONE fill, a new order for resident columns only the histogram
@@ -686,7 +689,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         c->longest_bond.borrow(c->sp_cnt.p, 2);
         if (columns) {
             if (!cleared) HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, want * sizeof(int), c->stream));
-            hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_qa.p,
+            hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_qa.p, c->st_h.p,
                                d, hist, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
         } else {
             if (regrow) HIPCHK(c, hipMemcpyAsync(c->sp_cnt.p, keep_longest, sizeof(keep_longest), hipMemcpyHostToDevice, c->stream));
@@ -705,7 +708,7 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
             hipLaunchKernelGGL(k_scan_fix, dim3((d.ncell + 4095) / 4096), dim3(1024), 0, c->stream, hist, d.ncell, c->sp_sums.p, ntiles, (unsigned long long*)nullptr);
         }
         hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, hist, c->st_xyzm.p,
-                           c->st_aux.p, c->st_qa.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_qa.p, c->sp_cell.p);
+                           c->st_aux.p, c->st_qa.p, c->st_h.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_qa.p, c->sp_h.p, c->sp_cell.p);
         CHK(check_launch(c, "k_static_permute"));
         c->sp_grid = d;
     }
@@ -725,6 +728,7 @@ StaticAtoms static_atoms(arp_ctx* c) {
     StaticAtoms r;
     r.xyzm = c->sp_xyzm.p;
     r.qa = c->sp_qa.p;
+    r.hoff = c->sp_h.p;
     r.aux = c->sp_aux.p;
     r.sel = c->sel_made ? c->sel.p : nullptr;
     r.plus = c->sel_made ? c->plus.p : nullptr;
@@ -756,7 +760,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
     HIPCHK(c, G.sums.reserve((size_t)(ncell + TILE_CELLS - 1) / TILE_CELLS + 2));
     HIPCHK(c, sx.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, sa.reserve((size_t)std::max(n, 1)));
-    if (srec) HIPCHK(c, srec->reserve((size_t)std::max(n, 1)));
+    if (srec) { HIPCHK(c, srec->reserve((size_t)std::max(n, 1))); HIPCHK(c, c->s_h.reserve((size_t)std::max(n, 1))); }
     CHK(ensure_static(c));
     const StaticAtoms r = static_atoms(c);
     int* const hist = G.cur ? G.cnt2.p : G.cnt.p;
@@ -777,7 +781,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
             Prof p(c, SLOT_SCATTER, st);
             const int steps = (ncell + 16 * 256 - 1) / (16 * 256);
 #define LAUNCH_SS(S) hipLaunchKernelGGL((k_scan_scatter_atoms<S>), dim3(nb), dim3(1024), (S) * 16384, st, r, n, ncell, G.cell_rank.p, hist, \
-                                        G.start.p, total_out, sx.p, sa.p, rec, gm)
+                                        G.start.p, total_out, sx.p, sa.p, rec, c->s_h.p, gm)
             switch (steps) {
                 case 1: LAUNCH_SS(1); break;
                 case 2: LAUNCH_SS(2); break;
@@ -813,7 +817,7 @@ int build_atom_grid(arp_ctx* c, Grid& G, DevBuf<float4>& sx, DevBuf<int4>& sa, D
                 CHK(check_launch(c, "k_scan"));
             }
             Prof p(c, SLOT_SCATTER, st);
-            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_rank.p, G.start.p, sx.p, sa.p, rec, gm);
+            hipLaunchKernelGGL(k_scatter_atoms, dim3(nblocks(n, 256)), dim3(256), 0, st, r, n, G.cell_rank.p, G.start.p, sx.p, sa.p, rec, c->s_h.p, gm);
             CHK(check_launch(c, "k_scatter_atoms"));
         }
         G.cur = 1 - G.cur;
@@ -843,6 +847,7 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
     HIPCHK(c, c->s_xyzm.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->s_aux.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->s_qa.reserve((size_t)std::max(n, 1)));
+    HIPCHK(c, c->s_h.reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c, radius));
     if (n > 0) {
         Prof p(c, SLOT_BIN);
@@ -859,7 +864,7 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
         CompactArgs A;
         A.r = static_atoms(c);
         A.sp_cell = c->sp_cell.p; A.n = n; A.ncell = ncell; A.req = req; A.forb = forb;
-        A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_qa = c->s_qa.p;
+        A.s_xyzm = c->s_xyzm.p; A.s_aux = c->s_aux.p; A.s_qa = c->s_qa.p; A.s_h = c->s_h.p;
         HIPCHK(c, c->s_cell.reserve((size_t)std::max(n, 1)));
         A.s_cell = c->s_cell.p;
         A.start = G.start.p; A.chain = c->compact_chain.p; A.epoch = c->compact_epoch; A.total_out = total_out;
@@ -1449,7 +1454,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // (the blocks split their work statically: all of them must be resident from the start)
         static const int sift_bpc_env = env_int("ARP_SIFT_BPC", 0);
         const int sift_blocks_per_cu = sift_bpc_env > 0 ? sift_bpc_env : c->sift_per_cu;
-        const SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_xyzm.p, c->s_qa.p,
+        SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_xyzm.p, c->s_qa.p, c->s_h.p, {0, 0, 0, 0, 0, 0, 0, 0},
                           SiftSide{c->rad_tab.p, c->rad.p, c->xyz.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
                           (int*)(c->d_ctr + ctr_dev(C_ERR))};
@@ -1464,6 +1469,26 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         const int slots = merged_ ? std::max(c->num_cu * sift_blocks_per_cu - np, 8 * PAIR_SEGS) : c->num_cu * sift_blocks_per_cu;
         const int nsift = std::max(std::min(slots, by_work), 8 * PAIR_SEGS) & ~(PAIR_SEGS - 1);
         // (four variants each: streaming stores or not, global ids or not — template parameters of the kernels, see sift_body)
+        {   // a segment's share of the sift blocks goes with its size in the pass before (k_sift: nblk)
+            static const int shares = env_int("ARP_SIFT_SHARES", 1);
+            const int B = nsift / PAIR_SEGS;
+            uint64_t tot = 0;
+            for (int k = 0; k < PAIR_SEGS; ++k) tot += c->seg_last[k];
+            int given = 0, big = 0;
+            for (int k = 0; k < PAIR_SEGS; ++k) {
+                sa.nblk[k] = (shares && tot > 0 && B > 1) ? std::max(1, (int)((double)nsift * (double)c->seg_last[k] / (double)tot + 0.5)) : B;
+                given += sa.nblk[k];
+                if (sa.nblk[k] > sa.nblk[big]) big = k;
+            }
+            // the shares add up to the launch (the largest one takes the rounding; never below one block)
+            while (given != nsift) {
+                const int step = given > nsift ? -1 : 1;
+                if (sa.nblk[big] + step < 1) { for (int k = 0; k < PAIR_SEGS; ++k) sa.nblk[k] = B; break; }
+                sa.nblk[big] += step; given += step;
+                big = 0;
+                for (int k = 1; k < PAIR_SEGS; ++k) if (sa.nblk[k] > sa.nblk[big]) big = k;
+            }
+        }
 #define LAUNCH_SIFT_PLANES(S, G) hipLaunchKernelGGL((k_sift_planes<S, G>), dim3(np + nsift), dim3(256), 0, c->stream, sa, nsift, ap, pp, gg, gp, plane_lists(c), \
                                                     c->d_ctr + ctr_dev(C_PLIST), np, c->pub)
 #define LAUNCH_SIFT(S, G) hipLaunchKernelGGL((k_sift<S, G>), dim3(nsift), dim3(256), 0, c->stream, sa, c->pub)
@@ -1562,6 +1587,7 @@ bool finish_contacts(arp_ctx* c) {
     for (int k = 0; k < PAIR_SEGS; ++k) { np += c->h_ctr[C_SEG_PAIRS + k]; worst = std::max(worst, c->h_ctr[C_SEG_PAIRS + k]); }
     c->h_ctr[C_PAIRS] = np;
     c->h_ctr[C_SCRATCH0] = worst;
+    for (int k = 0; k < PAIR_SEGS; ++k) c->seg_last[k] = c->h_ctr[C_SEG_PAIRS + k];
     if (worst > segcap) return true;
     c->n_contacts = (int64_t)np;
     c->contacts_expected = (int64_t)np;
@@ -1819,7 +1845,7 @@ void arp_destroy(arp_ctx* c) {
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
     c->s_xyzm.release(); c->s_aux.release(); c->s_qa.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_qa.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
-    c->sp_xyzm.release(); c->sp_aux.release(); c->sp_qa.release(); c->sp_cnt.release(); c->sp_cr.release();
+    c->sp_xyzm.release(); c->sp_aux.release(); c->sp_qa.release(); c->st_h.release(); c->sp_h.release(); c->s_h.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
     c->bag_ap.release(); c->bag_pp.release(); c->bag_gg.release(); c->bag_gp.release();

@@ -34,6 +34,9 @@
 #define M_RAD4_SHIFT 25
 #define M_RAD4_ESC 15u
 #define M_HAS_H (1u << 29)
+// ... and how many: bits 30-31 = hydrogens - 1 for one to three of them, 3 = four or more (then the CSR offsets say)
+#define M_HCNT_SHIFT 30
+#define M_HCNT_ESC 3u
 
 // Counters of a pass (one u64 each).  The enum is the LOGICAL layout — the order of the page-locked host mirror and of every
 // h_ctr[] index.  On the device a counter sits at word ctr_dev(logical) of a block of 128-byte lines, because returning
@@ -109,8 +112,10 @@ struct RawAtoms {
 //   s_qa   = local atom id, and the first three bonded neighbours (local ids) IN OTHER RESIDUES: -1 = none, .w = -2 = more than
 //            three (then the atom's whole CSR list is walked).  Bonded neighbours of the atom's own residue are left out because
 //            a pair of one residue never reaches the covalent test (I:729 comes before I:748).
-// Everything else — hydrogens, float64 radii, the halogen's neighbour — is read by local id from the uploaded arrays by the few
-// pairs that need it (stage B, rare branches of stage A).
+// and a third, 4-byte column for the pairs that need hydrogen geometry (stage B: a tenth of them, gathered by position again):
+//   s_h    = h_off, the index of the atom's first hydrogen
+// Everything else — float64 radii outside the table's first entries, the halogen's neighbour, a fifth hydrogen — is read by
+// local id from the uploaded arrays by the very few pairs that need it.
 #define RAD_TABLE 256
 #define RAD_NONE 0xFFFFu
 #define CNT_SAT 255
@@ -139,6 +144,7 @@ struct StaticAtoms {
     const float4* xyzm;         // x, y, z, static meta
     const int4* aux;            // local id, residue, previous residue, next residue
     const int4* qa;             // local id + bonded neighbours in other residues (see above)
+    const int* hoff;            // index of the first hydrogen
     const uint8_t* sel;         // null: nothing selected
     const uint8_t* plus;        // null: everything in selection_plus
     int all;                    // the selection is the whole structure (then selection_plus is, too): sel / plus not read
@@ -216,7 +222,7 @@ struct BlobCheck {
 // Once per uploaded structure, ONE launch: the static record columns, the 6 A cell of every atom for their spatial order
 // (histogram + rank in cell: what k_static_bin did as a launch of its own) and the longest bond / atom - hydrogen distance.
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
-                                                        int4* __restrict__ st_qa, GridDesc g6, int* __restrict__ cnt6,
+                                                        int4* __restrict__ st_qa, int* __restrict__ st_h, GridDesc g6, int* __restrict__ cnt6,
                                                         int2* __restrict__ cr6, const double* __restrict__ h_xyz, unsigned int* __restrict__ longest) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
     longest_bond_body(n, r.xyz, r.bond_off, r.bond_idx, r.h_off, h_xyz, longest);
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         const float4 sb = r.sb[i];
         if (sb.w != 0.0f) m |= M_HAS_SB;
         m |= min((uint32_t)r.rad_idx[i], M_RAD4_ESC) << M_RAD4_SHIFT;
-        if (r.h_off[i + 1] > r.h_off[i]) m |= M_HAS_H;
+        const int nh = r.h_off[i + 1] - r.h_off[i];
+        if (nh > 0) m |= M_HAS_H | (min((uint32_t)(nh - 1), M_HCNT_ESC) << M_HCNT_SHIFT);
         v.w = __uint_as_float(m);
         // the bonded neighbours in OTHER residues beside the record (-1: none; w = -2: more than three, walk the CSR list)
         int4 qa = make_int4(i, -1, -1, -1);
@@ -244,6 +251,7 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
         }
         st_xyzm[i] = v;
         st_qa[i] = qa;
+        st_h[i] = r.h_off[i];
         st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
         const int c6 = cell_index(g6, num::d3{(double)v.x, (double)v.y, (double)v.z}, g6.place ? g6.sid_atom[i] : 0);
         cr6[i] = make_int2(c6, atomicAdd(&cnt6[c6], 1));
@@ -275,15 +283,16 @@ __global__ __launch_bounds__(256) void k_static_bin(int n, const float4* __restr
 }
 __global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __restrict__ cr, const int* __restrict__ start,
                                                         const float4* __restrict__ st_xyzm, const int4* __restrict__ st_aux,
-                                                        const int4* __restrict__ st_qa,
+                                                        const int4* __restrict__ st_qa, const int* __restrict__ st_h,
                                                         float4* __restrict__ sp_xyzm, int4* __restrict__ sp_aux, int4* __restrict__ sp_qa,
-                                                        int* __restrict__ sp_cell) {
+                                                        int* __restrict__ sp_h, int* __restrict__ sp_cell) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 c = cr[i];
         const int pos = start[c.x] + c.y;
         sp_xyzm[pos] = st_xyzm[i];
         sp_aux[pos] = st_aux[i];
         sp_qa[pos] = st_qa[i];
+        sp_h[pos] = st_h[i];
         sp_cell[pos] = c.x;
     }
 }
@@ -378,23 +387,23 @@ __global__ __launch_bounds__(256) void k_bin_atoms(StaticAtoms r, int n, GridDes
 
 // one atom's cell-sorted records (search record 32 B; the contact grid adds the second quad of the sift record)
 __device__ __forceinline__ void scatter_one(const StaticAtoms& r, int i, int pos, float4* __restrict__ s_xyzm,
-                                            int4* __restrict__ s_aux, int4* __restrict__ s_qa) {
+                                            int4* __restrict__ s_aux, int4* __restrict__ s_qa, int* __restrict__ s_h) {
     const int4 aux = r.aux[i];
     const float4 xyzm = compose_xyzm(r, i, aux.x);
     s_xyzm[pos] = xyzm;
     s_aux[pos] = aux;
-    if (s_qa) s_qa[pos] = r.qa[i];
+    if (s_qa) { s_qa[pos] = r.qa[i]; s_h[pos] = r.hoff[i]; }
 }
 
 // counting-sort scatter fused with the record build, start table from a separate scan (large grids)
 __global__ __launch_bounds__(256) void k_scatter_atoms(StaticAtoms r, int n, const int2* __restrict__ cell_rank,
                                                        const int* __restrict__ start, float4* __restrict__ s_xyzm,
-                                                       int4* __restrict__ s_aux, int4* __restrict__ s_qa, GroupMasks gm) {
+                                                       int4* __restrict__ s_aux, int4* __restrict__ s_qa, int* __restrict__ s_h, GroupMasks gm) {
     group_masks(gm, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 cr = cell_rank[i];
         if (cr.x < 0) continue;
-        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_qa);
+        scatter_one(r, i, start[cr.x] + cr.y, s_xyzm, s_aux, s_qa, s_h);
     }
 }
 
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
                                                              const int* __restrict__ cell_cnt, int* __restrict__ start,
                                                              unsigned long long* __restrict__ total_out,
                                                              float4* __restrict__ s_xyzm, int4* __restrict__ s_aux,
-                                                             int4* __restrict__ s_qa, GroupMasks gm) {
+                                                             int4* __restrict__ s_qa, int* __restrict__ s_h, GroupMasks gm) {
     extern __shared__ __attribute__((aligned(16))) int s_start[];   // 16 * STEPS * 256 ints
     group_masks(gm, blockIdx.x * 1024 + threadIdx.x, gridDim.x * 1024);
     __shared__ int s_wtot[16], s_woff[17];
@@ -425,6 +434,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     const int4 my_aux = r.aux[ii];
     const float4 my_xyzm = compose_xyzm(r, ii, my_aux.x);
     const int4 my_qa = s_qa ? r.qa[ii] : make_int4(0, 0, 0, 0);
+    const int my_h = s_qa ? r.hoff[ii] : 0;
     int4 v[STEPS];
 #pragma unroll
     for (int k = 0; k < STEPS; ++k) {
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
         const int pos = s_start[cr.x] + s_woff[cr.x / CHUNK] + cr.y;
         s_xyzm[pos] = my_xyzm;
         s_aux[pos] = my_aux;
-        if (s_qa) s_qa[pos] = my_qa;
+        if (s_qa) { s_qa[pos] = my_qa; s_h[pos] = my_h; }
     }
 }
 
@@ -485,6 +495,7 @@ struct CompactArgs {
     float4* s_xyzm;
     int4* s_aux;
     int4* s_qa;                // second quad of the sift record
+    int* s_h;                  // first hydrogen
     int* start;                // out: ncell + 1
     int* s_cell;               // out: cell of every kept row (k_search splits its blocks by atoms, not by cells, when the grid is sparse)
     unsigned long long* chain; // one word per block
@@ -525,6 +536,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
     const bool keep = valid && ((m & A.req) == A.req) && !(m & A.forb);
     // the columns of a kept row travel while the counts meet
     const int4 qa = A.r.qa[ii];
+    const int hoff = A.r.hoff[ii];
     const int my_cell = A.sp_cell[ii];
     const int prev_cell = (i > 0 && valid) ? A.sp_cell[i - 1] : -1;
     const unsigned long long mk = __ballot(keep);
@@ -579,7 +591,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
     if (keep) {
         A.s_xyzm[kp] = xyzm;
         A.s_aux[kp] = aux;
-        if (A.s_qa) A.s_qa[kp] = qa;
+        if (A.s_qa) { A.s_qa[kp] = qa; A.s_h[kp] = hoff; }
         if (A.s_cell) A.s_cell[kp] = my_cell;
     }
     // The first row of a cell knows where the cell's kept rows begin; so do the empty cells before it (a protein in its
@@ -1364,12 +1376,31 @@ struct SiftSide {
     const float* longest_bond;   // k_longest_bond: [0] longest bond, [1] longest atom - hydrogen distance
 };
 
-// The hydrogen geometry of one pair (local ids b, e): the branches in `need` (bit k = branch k of the list in k_sift), run on a
+// One atom of a pair as stage B needs it, gathered by sorted position
+struct GeoAtom {
+    num::f3 x;
+    double vdw;
+    int lid, h0, h1;
+};
+__device__ __forceinline__ GeoAtom geo_atom(float4 xyzm, int lid, int hoff, const double* s_vdw16, const SiftSide& sd) {
+    const uint32_t m = __float_as_uint(xyzm.w);
+    const unsigned ri = (m >> M_RAD4_SHIFT) & 15u, hc = (m >> M_HCNT_SHIFT) & 3u;
+    GeoAtom a;
+    a.x = xyz_of(xyzm);
+    a.lid = lid;
+    a.vdw = s_vdw16[ri];
+    if (ri == M_RAD4_ESC) a.vdw = sd.rad[lid].x;
+    a.h0 = hoff;
+    a.h1 = (m & M_HAS_H) ? hoff + 1 + (int)hc : hoff;
+    if ((m & M_HAS_H) && hc == M_HCNT_ESC) a.h1 = sd.h_off[lid + 1];
+    return a;
+}
+// The hydrogen geometry of one pair: the branches in `need` (bit k = branch k of the list in k_sift), run on a
 // lane of the task stage.  Returns the SIFt bits they add.
-__device__ __forceinline__ uint32_t sift_geometry(int b, int e, unsigned need, const double* __restrict__ h_xyz, const SiftSide& sd, double comp) {
-    const num::f3 xb = xyz_of(sd.xyz[b]), xe = xyz_of(sd.xyz[e]);
-    const double vb = sd.rad[b].x, ve = sd.rad[e].x;
-    const int hb0 = sd.h_off[b], hb1 = sd.h_off[b + 1], he0 = sd.h_off[e], he1 = sd.h_off[e + 1];
+__device__ __forceinline__ uint32_t sift_geometry(const GeoAtom& B, const GeoAtom& E, unsigned need, const double* __restrict__ h_xyz, const SiftSide& sd, double comp) {
+    const num::f3 xb = B.x, xe = E.x;
+    const double vb = B.vdw, ve = E.vdw;
+    const int hb0 = B.h0, hb1 = B.h1, he0 = E.h0, he1 = E.h1;
     unsigned todo = need, res = 0;
     while (todo) {                     // almost always one branch per pair
         const int kind = __ffs(todo) - 1;
@@ -1383,7 +1414,7 @@ __device__ __forceinline__ uint32_t sift_geometry(int b, int e, unsigned need, c
                            donor_b ? ve : vb, comp, amin, cmin);
         } else {
             const bool hal_b = kind == 4;
-            const float4 sbh = sd.sb[hal_b ? b : e];   // w = 1 when the halogen has a single-bond neighbour
+            const float4 sbh = sd.sb[hal_b ? B.lid : E.lid];   // w = 1 when the halogen has a single-bond neighbour
             r = halogen_weak(hal_b ? xb : xe, sbh, hal_b ? vb : ve, h_xyz, hal_b ? he0 : hb0,
                              hal_b ? he1 : hb1, comp);
         }
@@ -1411,6 +1442,9 @@ struct SiftArgs {
     u64 cap;
     const float4* s_xyzm;   // cell-sorted records, two 16-byte columns: x, y, z, meta
     const int4* s_qa;       //   local id, bonded neighbours in other residues
+    const int* s_h;         // ... and, for stage B, the index of the atom's first hydrogen
+    int nblk[PAIR_SEGS];    // blocks per segment (sum = the sift blocks of the launch, each >= 1): a segment's share goes with its
+                            // size in the pass before (all equal when that is not known)
     SiftSide sd;
     const int* bond_idx;
     const double* h_xyz;
@@ -1448,7 +1482,8 @@ __device__ __forceinline__ void put_five(int* pi, int vi, int* pj, int vj, float
 }
 typedef __attribute__((address_space(3))) void* lds_void_p;
 struct SiftShared {
-    uint4 tq[4][SIFT_TASKQ];     // {output index, bgn local id, end local id, sift | need << 16}
+    uint4 tq[4][SIFT_TASKQ];     // {output index, bgn position, end position, sift | need << 16}
+    double vdw16[16];            // van der Waals radii of the first radius pairs (stage B)
     float4 thr[256];             // for the first 16 radius pairs, pair by pair: {(float)(cov + cov'), (float)(vdw + vdw'), (float)(vdw + vdw' + comp), reach of the second}
     // per wave: the records of ONE batch of 64 pairs, lane l's in slot l — gathered by global_load_lds while the batch before is evaluated
     float4 xb[4][64], xe[4][64];
@@ -1466,6 +1501,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     const u64 cap = A.cap;
     const float4* __restrict__ s_xyzm = A.s_xyzm;
     const int4* __restrict__ s_qa = A.s_qa;
+    const int* __restrict__ s_h = A.s_h;
     const SiftSide sd = A.sd;
     const int* __restrict__ bond_idx = A.bond_idx;
     const double* __restrict__ h_xyz = A.h_xyz;
@@ -1505,15 +1541,43 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     // The segment fill counts are read on the device: no host round trip between search and sift.
     // Block b works on the segment of the XCD it runs on — the pairs written by the search blocks that ran on the same XCD,
     // whose atom records are still in that XCD's L2 — and writes its results at the segment's offset.
-    const int sgm = xcc_id();      // (blocks b with the same b % 8 share an XCD, whichever it is: vblock / 8 still numbers the blocks of a segment)
+    // The segments differ in size by a fifth (the search blocks of an XCD cover different parts of the box), the blocks of an
+    // XCD are as many as every other's: a segment gets blocks in proportion to its size (nblk) — its own XCD's first, then
+    // the ones other XCDs can spare, in a fixed order every block works out for itself.
+    int sgm = xcc_id();      // (blocks b with the same b % 8 share an XCD, whichever it is: vblock / 8 numbers the blocks of an XCD)
+    int blk_in_seg = vblock / PAIR_SEGS, blks_of_seg = vgrid / PAIR_SEGS;
+    {
+        const int B = vgrid / PAIR_SEGS;
+        int spare_before = 0;       // spare blocks of the XCDs before this one
+#pragma unroll
+        for (int q_ = 0; q_ < PAIR_SEGS; ++q_)
+            if (q_ < sgm) spare_before += max(B - A.nblk[q_], 0);
+        const int mine = min(A.nblk[sgm], B);
+        if (blk_in_seg >= mine) {      // a spare block: the k-th spare one of the launch serves the k-th wanted one
+            int k = spare_before + (blk_in_seg - mine);
+            int found = sgm, idx = blk_in_seg;
+#pragma unroll
+            for (int q_ = PAIR_SEGS - 1; q_ >= 0; --q_) {
+                int want_before = 0;
+#pragma unroll
+                for (int r_ = 0; r_ < PAIR_SEGS; ++r_)
+                    if (r_ < q_) want_before += max(A.nblk[r_] - B, 0);
+                const int want = max(A.nblk[q_] - B, 0);
+                if (k >= want_before && k < want_before + want) { found = q_; idx = B + (k - want_before); }
+            }
+            sgm = found; blk_in_seg = idx;
+        }
+        blks_of_seg = max(A.nblk[sgm], 1);
+        if (blk_in_seg >= blks_of_seg) blk_in_seg = blks_of_seg - 1;      // (cannot happen when the shares add up to the launch: a harmless repeat otherwise)
+    }
     u64 heads[PAIR_SEGS];
 #pragma unroll
     for (int q_ = 0; q_ < PAIR_SEGS; ++q_) heads[q_] = npairs_ptr[q_ * CTR_LINE];
     const float longest_bond = sd.longest_bond[0];
     const double h_slack = (double)sd.longest_bond[1] + 1e-4;   // |H - A| >= |D - A| - h_slack for every hydrogen H of D (margin: float32 distance, roundings)
     const int2* __restrict__ seg_pairs = pairs + (size_t)sgm * cap;
-    const long long stride = (long long)(vgrid / PAIR_SEGS) * blockDim.x;
-    const long long first = (long long)(vblock / PAIR_SEGS) * blockDim.x + (threadIdx.x - lane);
+    const long long stride = (long long)blks_of_seg * blockDim.x;
+    const long long first = (long long)blk_in_seg * blockDim.x + (threadIdx.x - lane);
     // (a pair beyond the end of the segment is read and ignored: the list is padded — see enqueue_contacts — and the count
     // that says so is still on its way)
     const int2 pr0 = (first + lane < (long long)cap) ? seg_pairs[first + lane] : make_int2(0, 0);
@@ -1522,6 +1586,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
         const double2 ra = sd.rad_tab[threadIdx.x >> 4], rb_ = sd.rad_tab[threadIdx.x & 15];
         const double sv = ra.x + rb_.x;
         sh->thr[threadIdx.x] = make_float4((float)(ra.y + rb_.y), (float)sv, (float)(sv + comp), reach_float(rb_.x, comp, h_slack));
+        if (threadIdx.x < 16) sh->vdw16[threadIdx.x] = rb_.x;
     }
     float4* const lxb = sh->xb[w];
     float4* const lxe = sh->xe[w];
@@ -1547,6 +1612,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     const long long nseg = (long long)min(heads[sgm], cap);
     // (the first batch's records, before the barrier: they travel while the table is made.  Only pairs of THIS pass are followed:
     // what lies beyond the end of the list are positions of another pass, of another structure perhaps)
+    int2 pr_cur = pr0;        // the pairs of the batch at hand (stage B follows them again)
     if (first + lane < nseg) gather(pr0);
     if (first + stride < nseg) fetch_pairs(first + stride);
     __syncthreads();
@@ -1555,7 +1621,10 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     auto run_tasks = [&](int first_, int count) {   // stage B on tq[w][first_ .. first_ + count)
         if (lane < count) {
             const uint4 t = tq[w][first_ + lane];
-            const uint32_t add = sift_geometry((int)t.y, (int)t.z, t.w >> 16, h_xyz, sd, comp);
+            // (by sorted position, like the gather of stage A: the lines are close by in L1 / L2)
+            const float4 vb = s_xyzm[t.y], ve = s_xyzm[t.z];
+            const int lb = s_qa[t.y].x, le = s_qa[t.z].x, hb = s_h[t.y], he = s_h[t.z];
+            const uint32_t add = sift_geometry(geo_atom(vb, lb, hb, sh->vdw16, sd), geo_atom(ve, le, he, sh->vdw16, sd), t.w >> 16, h_xyz, sd, comp);
             put_record<STREAM>((uint16_t)((t.w & 0xFFFFu) | add), out_s + t.x);
         }
         // (the compiler's own count of pending loads ends here: left open, it puts s_waitcnt vmcnt(0) at the edge of the batch
@@ -1685,7 +1754,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
             }
             if (need) {       // (stage B stores the finished mask over the one stored below)
                 queued = true;
-                task = make_uint4((unsigned)p, (unsigned)b_, (unsigned)e, s | (need << 16));
+                task = make_uint4((unsigned)p, (unsigned)pr_cur.x, (unsigned)pr_cur.y, s | (need << 16));
             }
             }
         // the records of the batch: five vector-memory operations behind the gather (a queued pair's mask is stored again by
@@ -1701,6 +1770,7 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
                 run_tasks(tn, 64);
             }
         }
+        pr_cur = pr;
 #ifdef ARP_SIFT_TRACE
         const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
