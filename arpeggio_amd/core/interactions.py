@@ -163,7 +163,7 @@ class InteractionComplex:
                              f'their untyped atoms; also their rings and amide groups, if any)')
             hal = (pc.flags & config.F_HALOGEN) != 0
             if hal.any() and (hal[aa['i']] | hal[aa['j']]).any() and (pc.sb_nbr[hal] < 0).any():
-                needs.append('bonds inside residues (the single-bond neighbour of a halogen in contact, U:139-141, 173)')
+                needs.append('bonds inside non-standard residues (the single-bond neighbour of a halogen in contact, U:139-141, 173)')
         if needs:
             self._incomplete(needs)
 

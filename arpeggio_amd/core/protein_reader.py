@@ -369,6 +369,72 @@ RING_TEMPLATES = {
 SIDE_CHAIN_AMIDES = {'ASN': ('ND2', 'CG', 'OD1', 'CB'), 'GLN': ('NE2', 'CD', 'OE1', 'CG')}
 
 
+# Bonds between the heavy atoms of the standard residues (wwPDB chemical component definitions: atom-name pairs, bond order, and
+# whether OpenBabel flags the bond aromatic, i.e. both atoms in one of the RING_TEMPLATES rings), in place of OpenBabel's residue
+# perception / ConnectTheDots (P:124-131 hands the file to OpenBabel; I:748-757 and U:612-635 walk the result).  What arpeggio
+# reads off these bonds: the single-bond heavy neighbour of an atom (U:612-635: first bond of order 1 that is not aromatic) and
+# the parents of hydrogens.  The ORDER in which OpenBabel lists an atom's bonds is its own (recalled as: the order of creation,
+# residue perception first) — no halogen sits in a standard residue, so no result of the path depends on it.
+_BACKBONE = (('N', 'CA', 1), ('CA', 'C', 1), ('C', 'O', 2), ('C', 'OXT', 1))
+_SIDE = {
+    'ALA': (('CA', 'CB', 1),),
+    'ARG': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD', 1), ('CD', 'NE', 1), ('NE', 'CZ', 1), ('CZ', 'NH1', 1), ('CZ', 'NH2', 2)),
+    'ASN': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'OD1', 2), ('CG', 'ND2', 1)),
+    'ASP': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'OD1', 2), ('CG', 'OD2', 1)),
+    'CYS': (('CA', 'CB', 1), ('CB', 'SG', 1)),
+    'GLN': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD', 1), ('CD', 'OE1', 2), ('CD', 'NE2', 1)),
+    'GLU': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD', 1), ('CD', 'OE1', 2), ('CD', 'OE2', 1)),
+    'GLY': (),
+    'HIS': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'ND1', 1), ('CG', 'CD2', 2), ('ND1', 'CE1', 2), ('CD2', 'NE2', 1), ('CE1', 'NE2', 1)),
+    'ILE': (('CA', 'CB', 1), ('CB', 'CG1', 1), ('CB', 'CG2', 1), ('CG1', 'CD1', 1)),
+    'LEU': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD1', 1), ('CG', 'CD2', 1)),
+    'LYS': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD', 1), ('CD', 'CE', 1), ('CE', 'NZ', 1)),
+    'MET': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'SD', 1), ('SD', 'CE', 1)),
+    'MSE': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'SE', 1), ('SE', 'CE', 1)),
+    'PHE': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD1', 2), ('CG', 'CD2', 1), ('CD1', 'CE1', 1), ('CD2', 'CE2', 2), ('CE1', 'CZ', 2), ('CE2', 'CZ', 1)),
+    'PRO': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD', 1), ('CD', 'N', 1)),
+    'SER': (('CA', 'CB', 1), ('CB', 'OG', 1)),
+    'THR': (('CA', 'CB', 1), ('CB', 'OG1', 1), ('CB', 'CG2', 1)),
+    'TRP': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD1', 2), ('CG', 'CD2', 1), ('CD1', 'NE1', 1), ('NE1', 'CE2', 1), ('CD2', 'CE2', 2),
+            ('CD2', 'CE3', 1), ('CE2', 'CZ2', 1), ('CE3', 'CZ3', 2), ('CZ2', 'CH2', 2), ('CZ3', 'CH2', 1)),
+    'TYR': (('CA', 'CB', 1), ('CB', 'CG', 1), ('CG', 'CD1', 2), ('CG', 'CD2', 1), ('CD1', 'CE1', 1), ('CD2', 'CE2', 2), ('CE1', 'CZ', 2), ('CE2', 'CZ', 1),
+            ('CZ', 'OH', 1)),
+    'VAL': (('CA', 'CB', 1), ('CB', 'CG1', 1), ('CB', 'CG2', 1)),
+}
+RESIDUE_BONDS = {k: _BACKBONE + v for k, v in _SIDE.items()}
+
+
+def template_bonds(residues, atom_index):
+    """[(atom, atom, order, aromatic)] of the heavy atoms of the standard residues that are present, residue by residue in
+    template order (packed indices).  A bond is aromatic when both atoms lie in one aromatic ring of RING_TEMPLATES."""
+    out = []
+    for r in residues:
+        name = r.name.strip()
+        rings = [set(t) for t in RING_TEMPLATES.get(name, ())]
+        for a, b, order in RESIDUE_BONDS.get(name, ()):
+            pa, pb = r.by_name.get(a), r.by_name.get(b)
+            if pa is None or pb is None:
+                continue
+            arom = int(any(a in t and b in t for t in rings))
+            out.append((atom_index[id(pa)], atom_index[id(pb)], order, arom))
+    return out
+
+
+def hydrogen_parent_by_name(hname, residue):
+    """The heavy atom a hydrogen of a standard residue is named after (wwPDB nomenclature: H + the parent's name without its
+    element letter + a counter — HA on CA, HB2 on CB, HG21 on CG2, HD1 on CD1 or ND1, HH on OH, H / H1..H3 on N): the heavy
+    atom of the residue whose name, less its first letter, is the longest prefix of the hydrogen's name less its 'H'."""
+    rem = hname.strip()[1:]
+    best, best_len = None, -1
+    for a in residue.atoms:
+        if a.element in ('H', 'D'):
+            continue
+        suf = a.name.strip()[1:]
+        if rem.startswith(suf) and len(suf) > best_len and (suf or a.name.strip() == 'N'):
+            best, best_len = a, len(suf)
+    return best
+
+
 def template_rings(residues, atom_index):
     """Ring atom lists (packed indices, ring-path order) of the standard residues that have all atoms of a template, in the
     order of their first atom in the file."""
@@ -447,6 +513,14 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
     for k, a in enumerate(atoms):
         xyz64[k] = text_xyz[int(a.serial)]
     neighbours = {}
+    atom_index = {id(a): k for k, a in enumerate(atoms)}
+    # bonds inside the standard residues, from the residue templates (OpenBabel perceives them when it reads the file, before
+    # arpeggio adds the _struct_conn ones, P:124-131)
+    tbonds = template_bonds(residues, atom_index)
+    bond_kind = {}                                                    # (a, b) -> (order, aromatic); anything else: a single bond
+    for a_, b_, o_, ar_ in tbonds:
+        bond_kind[(a_, b_)] = bond_kind[(b_, a_)] = (o_, ar_)
+    add_bonds(neighbours, [(a_, b_) for a_, b_, _, _ in tbonds])
     try:
         sc = _category(text, '_struct_conn.')
         if sc.rows:
@@ -454,7 +528,6 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
             add_bonds(neighbours, pairs)
     except KeyError:
         pass
-    atom_index = {id(a): k for k, a in enumerate(atoms)}
     pep = []                                                          # peptide bonds: C of a residue - N of its successor in the polypeptide
     for k, r in enumerate(residues):
         if res_next[k] >= 0:
@@ -464,6 +537,12 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
     add_bonds(neighbours, pep)
     is_h = np.array([e in ('H', 'D') for e in element], bool) if n else np.zeros(0, bool)
     parent = attach_hydrogens(xyz64, is_h, res_id)
+    for h_ in np.nonzero(is_h & (parent < 0))[0] if n else ():        # a hydrogen of a standard residue too far from everything: by its name
+        r_ = atoms[h_].residue
+        if r_.name.strip() in RESIDUE_BONDS:
+            p_ = hydrogen_parent_by_name(atoms[h_].name, r_)
+            if p_ is not None:
+                parent[h_] = atom_index[id(p_)]
     add_bonds(neighbours, [(int(p_), int(h_)) for h_, p_ in enumerate(parent) if p_ >= 0])
     bond_off = np.zeros(n + 1, np.int32)
     for k in range(n):
@@ -478,7 +557,10 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
         h_off[k + 1] = h_off[k] + len(h_lists[k])
     h_xyz = np.array([xyz64[h_] for k in range(n) for h_ in h_lists[k]], np.float64).reshape(-1, 3)
     from .packed import single_bond_neighbours
-    sb_nbr = single_bond_neighbours(bond_off, bond_idx, np.ones(len(bond_idx), np.int32), np.zeros(len(bond_idx), np.int32), is_h)
+    kinds = [bond_kind.get((k, int(b)), (1, 0)) for k in range(n) for b in neighbours.get(k, ())]
+    bond_order = np.array([o_ for o_, _ in kinds], np.int32)
+    bond_aromatic = np.array([ar_ for _, ar_ in kinds], np.int32)
+    sb_nbr = single_bond_neighbours(bond_off, bond_idx, bond_order, bond_aromatic, is_h)
     ring_atoms = template_rings(residues, atom_index)
     amide_atoms = template_amides(residues, res_next, atom_index)
     pc = PackedComplex(
@@ -501,12 +583,14 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
     pc.res_het = [r.het for r in residues]
     pc.component_types = comp
     pc.type_mask = typing.apply_protein_typing(pc, use_ambiguities=use_ambiguities)
-    # what only OpenBabel can add: bonds INSIDE residues (residue templates / ConnectTheDots: they matter for the single-bond
+    # what only OpenBabel can add: bonds inside NON-STANDARD residues (ConnectTheDots: they matter for the single-bond
     # neighbour of halogens and for hydrogens further than 1.3 A from any atom — pairs inside a residue are never contacts,
     # I:729), hydrogens of a file that has none (AddHydrogens), SMARTS types of non-standard residues, rings, amides
     # ... and the element radii: OpenBabel's table restated from memory in core/typing.py, not verified against an OpenBabel build
-    pc.incomplete = ('bonds inside residues', 'added hydrogens', 'ligand atom types', 'rings of non-standard residues',
-                     'amides of non-standard residues', 'element radii unverified')
+    # (bonds inside the STANDARD residues come from the residue templates above)
+    pc.incomplete = ('bonds inside non-standard residues', 'added hydrogens', 'ligand atom types', 'rings of non-standard residues',
+                     'amides of non-standard residues', 'ring / amide ids not in OpenBabel\'s order', 'element radii unverified')
+    pc.bond_order, pc.bond_aromatic = bond_order, bond_aromatic
     pc.plane_geometry_pending = len(ring_atoms) + len(amide_atoms) > 0      # centres / normals not computed yet
     pc.hydrogen_parent = parent
     # atoms whose types only OpenBabel's SMARTS could give: heavy atoms of residues outside the typing dictionary that are not water

@@ -1629,6 +1629,7 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     for (int q = 0; q < 5; ++q) c->srt_off[q] = off[q];
     c->srt_bytes = bytes;
     if (k == 0) { c->contacts_sorted = true; return ARP_OK; }
+    if (k >= ((size_t)1 << 31)) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_sort: 2^31 records or more (the digit table's prefixes are 32-bit)");
     // significant bits of an atom index: packed ids of the resident structure, global ids on a shard
     const int64_t idmax = c->has_gid ? (c->gid_max >= 0 ? c->gid_max : ((int64_t)1 << 31) - 1) : std::max<int64_t>(c->n - 1, 1);
     int idbits = 1;
@@ -1942,6 +1943,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     CHK(upload_async(c, c->sb, sb0.data(), (size_t)n));
     CHK(upload_done(c));   // (the staging vectors above live until here)
     c->has_gid = c->has_home = false;
+    c->gid_max = -1;
     batch_reset(c);
     c->sel_made = false;
     c->sel_uploaded = false;   // a new structure starts with the default selection: everything (I:1395)
@@ -2330,6 +2332,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     c->static_dirty = true;
     c->lists_dirty = true;
     c->has_gid = c->has_home = c->has_group_owner = false;
+    c->gid_max = -1;
     c->shard_resident = false;
     batch_reset(c);
     c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
@@ -2716,6 +2719,7 @@ int arp_shard_assemble(arp_ctx* c, uint64_t dev_left, uint64_t bytes_left, uint6
     }
     CHK(validate_resident_blob(c, B, "arp_shard_assemble", d_err));     // waits; resets selection and ownership state
     c->has_gid = c->has_home = true;
+    c->gid_max = -1;      // (the merged ids live on the device only: the sort takes the 31-bit key width)
     c->has_group_owner = true;
     c->shard_resident = true;
     if (counts) { counts[0] = n; counts[1] = nring; counts[2] = namide; }
@@ -2746,12 +2750,13 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
     if (is_home) { CHK(upload(c, c->home, is_home, (size_t)c->n)); c->has_home = true; }
     else c->has_home = false;
     if (global_id) {
+        if (c->n > 0 && global_id[0] < 0) FAIL(c, ARP_E_ARG, "arp_set_ownership: global_id must not be negative");
         for (int64_t i = 1; i < c->n; ++i)
             if (global_id[i] <= global_id[i - 1]) FAIL(c, ARP_E_ARG, "arp_set_ownership: global_id must be strictly increasing");
         CHK(upload(c, c->gid, global_id, (size_t)c->n));
         c->has_gid = true;
         c->gid_max = c->n > 0 ? (int64_t)global_id[c->n - 1] : -1;
-    } else c->has_gid = false;
+    } else { c->has_gid = false; c->gid_max = -1; }
     c->atom_grid.valid = false;   // M_HOME is part of the sorted records
     c->all_grid_current = false;
     c->contacts_valid = false;

@@ -479,6 +479,15 @@ __global__ __launch_bounds__(1024) void k_scan_scatter_atoms(StaticAtoms r, int 
     }
 }
 
+#if defined(ARP_COMPACT_TRACE) && !defined(ARP_SEARCH_TRACE)
+#define ARP_SEARCH_TRACE      // (shares the search trace's buffer and entry points)
+#endif
+#if defined(ARP_SIFT_TRACE) && !defined(ARP_SEARCH_TRACE)
+#define ARP_SEARCH_TRACE
+#endif
+#ifdef ARP_SEARCH_TRACE
+__device__ unsigned long long* g_search_trace = nullptr;      // developer builds only (tools/*_trace.py)
+#endif
 // ---- the contact grid of a pass in ONE launch ---------------------------------------------------------------------
 // The static columns of a structure are kept in the order of the pass's own cells (ensure_spatial: counting sort by cell,
 // once per structure and cell edge).  The atoms a pass lets into its grid — selection_plus without hydrogens, I:707-712 —
@@ -518,6 +527,12 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
     __shared__ int s_base;
     constexpr int NW = COMPACT_THREADS / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef ARP_COMPACT_TRACE
+    unsigned long long tc[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0};
+#define COMPACT_T(k) tc[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define COMPACT_T(k)
+#endif
     const int i = blockIdx.x * COMPACT_THREADS + threadIdx.x;
     const bool valid = i < A.n;
     const int ii = valid ? i : A.n - 1;
@@ -542,6 +557,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
     const unsigned long long mk = __ballot(keep);
     const int rank_w = __popcll(mk & ((1ull << lane) - 1ull));
     if (lane == 0) s_wtot[wv] = __popcll(mk);
+    COMPACT_T(1);
     __syncthreads();
     if (wv == 0) {
         // block total, wave offsets; publish the aggregate; look back for the base
@@ -587,6 +603,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
         }
     }
     __syncthreads();
+    COMPACT_T(2);
     const int kp = s_base + s_woff[wv] + rank_w;        // kept rows before this one
     if (keep) {
         A.s_xyzm[kp] = xyzm;
@@ -609,6 +626,14 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
             for (int c = hi + 1 + lane; c <= A.ncell; c += 64) A.start[c] = tot;
         }
     }
+#ifdef ARP_COMPACT_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    COMPACT_T(3);
+    if (g_search_trace && lane == 0) {
+        unsigned long long* t = g_search_trace + ((size_t)blockIdx.x * NW + wv) * 4;
+        for (int k = 0; k < 4; ++k) t[k] = tc[k];
+    }
+#endif
 }
 
 // ---- end of a pass, without a launch of its own ------------------------------------------------------------
@@ -631,8 +656,8 @@ struct PublishArgs {
 // "s_waitcnt vmcnt(0)" of every wave + the workgroup barrier is what a release of the counter stores amounts to, without the
 // L2 write-back a release FENCE of that scope performs.  The asm statements carry a "memory" clobber: the compiler keeps
 // the relaxed flag store behind them.  tools/pub_stress.py is the check on hardware.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
-#error "pass_end relies on the gfx9 meaning of s_waitcnt vmcnt(0) for stores (this library is built for gfx950)"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "this library is built for gfx950 only: pass_end and the per-pair kernel rely on the gfx9 meaning of s_waitcnt vmcnt for stores, the sort kernels on 160 KB of LDS per CU, the per-pair kernel on global_load_lds_dwordx4"
 #endif
 __device__ __forceinline__ void pass_end(const PublishArgs& pa, int set) {
     if (!pa.expected) return;
@@ -768,14 +793,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // (tools/micro/xcc_queue.hip: block b of a 768-block launch ran on XCD (b + 7) % 8)
 __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
 
-#if defined(ARP_SIFT_TRACE) && !defined(ARP_SEARCH_TRACE)
-#define ARP_SEARCH_TRACE      // (the per-pair kernel's trace shares the search trace's buffer and entry points)
-#endif
-#ifdef ARP_SEARCH_TRACE
-// developer builds only (tools/search_trace.py): per block of k_search<MODE_CONTACTS> {start, end of the cell loops, end} in
-// s_memrealtime ticks (100 MHz), the XCD and the hardware id of the block's first wave
-__device__ unsigned long long* g_search_trace = nullptr;
-#endif
+// (developer builds, tools/search_trace.py: per block of k_search<MODE_CONTACTS> {start, end of the cell loops, end} in
+// s_memrealtime ticks (100 MHz), the XCD and the hardware id of the block's first wave — g_search_trace, declared above)
 
 // TX: x-adjacent home cells per tile (1 or 2; a template parameter: with one cell per tile the column rules below vanish at
 // compile time — as a run-time value they cost the small grids 3 us)
@@ -789,7 +808,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                                                                uint8_t* __restrict__ plus, GroupMasks gm, const int* __restrict__ cell_of_pos) {
     // ring / amide sets of _make_selection (I:1433-1437) from the residue tags the grid build of this pass left: every thread
     // of the launch takes at most a few (nothing to do when gm is empty)
-#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE)
+#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE) && !defined(ARP_COMPACT_TRACE)
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_loops = 0;
 #endif
@@ -1229,7 +1248,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
       __syncthreads();      // (before the cell bounds and the claim counter are written again)
      }
     }
-#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE)
+#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE) && !defined(ARP_COMPACT_TRACE)
     t_loops = __builtin_amdgcn_s_memrealtime();
 #endif
     // End of block: the per-wave queues of the block leave with ONE atomicAdd (single-address atomics
@@ -1255,7 +1274,7 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         for (int k = lane; k < qn; k += 64)
             if (base + k < cap) seg_pairs[base + k] = q[w][k];
     }
-#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE)
+#if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE) && !defined(ARP_COMPACT_TRACE)
     if (MODE == MODE_CONTACTS && g_search_trace && lane == 0) {
         unsigned long long* t = g_search_trace + ((size_t)blockIdx.x * SEARCH_WAVES + w) * 4;
         t[0] = t_begin; t[1] = t_loops; t[2] = __builtin_amdgcn_s_memrealtime();

@@ -37,6 +37,7 @@ import numpy as np
 
 REF = '/root/reference/arpeggio/core'
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('ARP_GOLDEN_OUT', HERE)      # (tests/test_fixture_freshness.py regenerates into a scratch directory)
 sys.path.insert(0, os.path.join(HERE, '..', '..'))
 
 
@@ -115,7 +116,7 @@ def main():
         ang_f32 = np.array([float(utils.get_angle(a[k], b[k], c[k])) for k in range(K)])            # U:174 usage
         ang_f64 = np.array([float(utils.get_angle(a[k], bh[k], c[k])) for k in range(K)])           # U:90 usage
         ang_mix = np.array([float(utils.get_angle(a[k], b[k], ch[k])) for k in range(K)])           # U:151 usage
-    np.savez_compressed(os.path.join(HERE, 'angles.npz'), a=a, b=b, c=c, bh=bh, ch=ch,
+    np.savez_compressed(os.path.join(OUT, 'angles.npz'), a=a, b=b, c=c, bh=bh, ch=ch,
                         ang_f32=ang_f32, ang_f64=ang_f64, ang_mix=ang_mix)
 
     # ------------------------------------------------------------- group angles
@@ -134,13 +135,13 @@ def main():
         gg_32 = np.array([abs(utils.group_group_angle({'normal': n32[k]}, {'normal': m32[k]}, True, True)) for k in range(K)])
         gg_3264 = np.array([float(abs(utils.group_group_angle({'normal': n32[k]}, {'normal': m64[k]}, True, True))) for k in range(K)])
     assert ga_32.dtype == np.float32 and gg_32.dtype == np.float32
-    np.savez_compressed(os.path.join(HERE, 'group_angles.npz'), n64=n64, m64=m64, p64=p64, n32=n32, m32=m32, p32=p32,
+    np.savez_compressed(os.path.join(OUT, 'group_angles.npz'), n64=n64, m64=m64, p64=p64, n32=n32, m32=m32, p32=p32,
                         ga_64=ga_64, ga_32=ga_32, ga_3264=ga_3264, gg_64=gg_64, gg_32=gg_32, gg_3264=gg_3264)
 
     # --------------------------------------------------------- float32 distance
     norm32 = np.array([np.linalg.norm(a[k] - c[k]) for k in range(K)])
     assert norm32.dtype == np.float32
-    np.savez_compressed(os.path.join(HERE, 'norm_f32.npz'), a=a, c=c, dist=norm32)
+    np.savez_compressed(os.path.join(OUT, 'norm_f32.npz'), a=a, c=c, dist=norm32)
 
     # ------------------------------------------------------- is_hbond / is_weak
     KH = 3000
@@ -158,7 +159,7 @@ def main():
         ac = types.SimpleNamespace(coord=acc[k], vdw_radius=float(acc_vdw[k]))
         res_h[k] = utils.is_hbond(d, ac, comp)
         res_w[k] = utils.is_weak_hbond(d, ac, comp)
-    np.savez_compressed(os.path.join(HERE, 'hbond.npz'), don=don, hoff=hoff, hxyz=hxyz, acc=acc, acc_vdw=acc_vdw,
+    np.savez_compressed(os.path.join(OUT, 'hbond.npz'), don=don, hoff=hoff, hxyz=hxyz, acc=acc, acc_vdw=acc_vdw,
                         comp=np.float64(comp), is_hbond=res_h, is_weak_hbond=res_w)
 
     # ------------------------------------------------------- __get_contact_type
@@ -189,7 +190,7 @@ def main():
                     if es: sel.add(B)
                     ct_rows.append({'bgn_sel': bs, 'end_sel': es, 'bgn_water': bw, 'end_water': ew,
                                     'contact_type': I['__get_contact_type'](None, A, B, sel)})
-    json.dump(ct_rows, open(os.path.join(HERE, 'contact_type.json'), 'w'), indent=1)
+    json.dump(ct_rows, open(os.path.join(OUT, 'contact_type.json'), 'w'), indent=1)
 
     # ------------------------------------------------------------- sift updates
     ctypes_all = ['INTRA_NON_SELECTION', 'INTRA_SELECTION', 'INTER', 'SELECTION_WATER', 'NON_SELECTION_WATER', 'WATER_WATER']
@@ -211,7 +212,7 @@ def main():
             utils.update_atom_fsift(at, add[5:], ct)
             steps.append({'addition': add, 'contact_type': ct})
         cases.append({'steps': steps, 'final': {k: [int(x) for x in v] for k, v in vars(at).items()}})
-    json.dump(cases, open(os.path.join(HERE, 'sift_updates.json'), 'w'))
+    json.dump(cases, open(os.path.join(OUT, 'sift_updates.json'), 'w'))
 
     # ------------------------------------------- plane / group loops (real code)
     from arpeggio_amd import synth
@@ -279,7 +280,7 @@ def main():
                  'bgn_res': int(x.bgn_res.idx), 'end_res': int(x.end_res.idx),
                  'bgn_res_atoms': list(x.bgn_res_atoms), 'end_res_atoms': list(x.end_res_atoms)} for x in lst]
 
-    np.savez_compressed(os.path.join(HERE, 'planes_input.npz'),
+    np.savez_compressed(os.path.join(OUT, 'planes_input.npz'),
                         ring_center=pc.ring_center, ring_normal=pc.ring_normal, ring_res=ring_res,
                         ring_sel=ring_sel.astype(np.uint8), ring_plus=ring_plus.astype(np.uint8),
                         amide_center=pc.amide_center, amide_normal=pc.amide_normal, amide_res=amide_res,
@@ -292,7 +293,7 @@ def main():
                'amide_amide_inter_integer_sift': {str(r.idx): r.amide_amide_inter_integer_sift for r in residues if any(r.amide_amide_inter_integer_sift)},
                'amide_ring_inter_integer_sift': {str(r.idx): r.amide_ring_inter_integer_sift for r in residues if any(r.amide_ring_inter_integer_sift)},
                'ring_amide_inter_integer_sift': {str(r.idx): r.ring_amide_inter_integer_sift for r in residues if any(r.ring_amide_inter_integer_sift)},
-               }, open(os.path.join(HERE, 'planes_expected.json'), 'w'))
+               }, open(os.path.join(OUT, 'planes_expected.json'), 'w'))
     print('planes:', len(self_.plane_plane_contacts), len(self_.group_group_contacts), len(self_.group_plane_contacts))
 
     # --------------------------------------------------------- selection_parser
@@ -346,7 +347,7 @@ def main():
             sel_out.append({'selectors': s, 'atoms': sorted(a_.idx for a_ in got)})
         except exceptions.SelectionError as e:
             sel_out.append({'selectors': s, 'error': 'SelectionError', 'args': [str(x) for x in e.args]})
-    json.dump({'atoms': rows, 'cases': sel_out}, open(os.path.join(HERE, 'selection_parser.json'), 'w'), indent=1)
+    json.dump({'atoms': rows, 'cases': sel_out}, open(os.path.join(OUT, 'selection_parser.json'), 'w'), indent=1)
     print('golden vectors written to', HERE)
 
 

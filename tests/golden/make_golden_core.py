@@ -565,6 +565,116 @@ def protein_bond_orders(pc):
     return order, arom
 
 
+def finish_geometry(rpc):
+    """read_mmcif leaves the centres / normals / residues of its template rings and amide groups to the GPU (initialize()).  A
+    fixture must not depend on a GPU: the amide groups go through the EXECUTED reference (_perceive_amide_groups, I:1531-1589, and
+    _assign_aromatic_rings_to_residues, I:1453-1492 — make_golden_prepare.run), the ring centres / normals through the restatement
+    of OpenBabel's OBRing::findCenterAndNormal (third-party, recalled: oracle/ref_py.ring_geometry)."""
+    if not getattr(rpc, 'plane_geometry_pending', False):
+        return
+    import copy
+    import make_golden_prepare as prep
+    from oracle import ref_py
+    rc, rn = ref_py.ring_geometry(rpc.xyz, rpc.ring_atoms)
+    geo = {}
+    prep.run(copy.deepcopy(rpc), [list(map(int, q)) for q in rpc.amide_atoms], rc, 'g', geo)
+    rpc.ring_center, rpc.ring_normal, rpc.ring_res = np.asarray(rc, np.float64).reshape(-1, 3), np.asarray(rn, np.float64).reshape(-1, 3), geo['g/ring_res']
+    rpc.amide_center, rpc.amide_normal, rpc.amide_res = geo['g/amide_center'], geo['g/amide_normal'], geo['g/amide_res']
+    rpc.plane_geometry_pending = False
+
+
+def reader_section(IC, config, add, arrays, utils):
+    # ---- D. a structure that came through the mmCIF reader (core/protein_reader.read_mmcif): alternative locations (the B
+    # child wins on occupancy), insertion codes 17A / 17B, a modified residue in the chain, a chain break, hetero groups, waters
+    # of two names, and a heavy water (element D: not a hydrogen at I:712, but its deuterons are hydrogens to OpenBabel, I:1524)
+    import tempfile
+    from make_golden_reader import peptide_atom_site, chem_comp, cif_text
+    from arpeggio_amd.core import protein_reader
+    cols = peptide_atom_site(np.random.default_rng(5), 0)
+    nrow = len(cols['id'])
+
+    def add_row(**kv):
+        for k in cols:
+            cols[k].append(kv.get(k, cols[k][nrow - 1]))
+    ox = np.array([float(cols['Cartn_x'][3]) + 2.9, float(cols['Cartn_y'][3]) + 0.4, float(cols['Cartn_z'][3]) + 0.3])
+    for nm, el, d in (('O', 'O', (0, 0, 0)), ('D1', 'D', (0.76, 0.59, 0.0)), ('D2', 'D', (-0.76, 0.59, 0.0))):
+        add_row(group_PDB='HETATM', id=str(len(cols['id']) + 1), type_symbol=el, label_atom_id=nm, label_alt_id=None, label_comp_id='DOD',
+                label_asym_id='A', label_seq_id=False, pdbx_PDB_ins_code=None, Cartn_x='%.3f' % (ox[0] + d[0]), Cartn_y='%.3f' % (ox[1] + d[1]),
+                Cartn_z='%.3f' % (ox[2] + d[2]), occupancy='1.00', pdbx_formal_charge=None, auth_seq_id='450', auth_asym_id='A', pdbx_PDB_model_num='1')
+    cc = chem_comp(0)
+    cc['id'].append('DOD'); cc['type'].append('NON-POLYMER'); cc['name'].append('DEUTERATED WATER')
+    for k in cc:
+        if len(cc[k]) < len(cc['id']):
+            cc[k].append(None)
+    text = cif_text('READER', [('_atom_site.', cols), ('_chem_comp.', cc)], singles=[('_entry.id', 'READER')])
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, 'reader_h.cif')
+        open(fn, 'w').write(text)
+        rpc = protein_reader.read_mmcif(fn)
+    rpc.id = 'reader'
+    finish_geometry(rpc)
+    assert (rpc.amide_res >= 0).all() and np.abs(rpc.amide_center).max() > 0 and rpc.n_amides > 0
+    arrays['reader/cif_text'] = np.array(text)
+    for tag, kw in (('whole', dict()), ('chain_b', dict(selectors=['/B//']))):
+        out, _ = run_case(IC, config, rpc, **kw)
+        add(f'reader:{tag}', rpc, out, pack='reader', selectors=kw.get('selectors'), sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode='canonical')
+    # ---- D2. a file with complete aromatic / amide side chains and explicit hydrogens (make_golden_reader.aromatic_atom_site): the
+    # ring and amide loops on a structure that came from a FILE — template rings / amides, template bonds, hydrogens by distance
+    from make_golden_reader import aromatic_atom_site
+    cols2 = aromatic_atom_site()
+    cc2 = {'id': sorted(set(cols2['label_comp_id'])), 'type': None, 'name': None}
+    cc2['type'] = ['peptide linking' if c == 'GLY' else 'L-peptide linking' for c in cc2['id']]
+    cc2['name'] = [c + ' RESIDUE' for c in cc2['id']]
+    text2 = cif_text('RINGS', [('_atom_site.', cols2), ('_chem_comp.', cc2)], singles=[('_entry.id', 'RINGS')])
+    with tempfile.TemporaryDirectory() as td:
+        fn = os.path.join(td, 'rings_h.cif')
+        open(fn, 'w').write(text2)
+        rpc2 = protein_reader.read_mmcif(fn)
+    rpc2.id = 'reader_rings'
+    finish_geometry(rpc2)
+    assert rpc2.n_rings >= 10 and rpc2.n_amides >= 18 and (rpc2.ring_res >= 0).all()
+    arrays['reader_rings/cif_text'] = np.array(text2)
+    # the bonds inside the standard residues come from read_mmcif's residue templates (protein_reader.RESIDUE_BONDS): holders
+    # carrying those bonds with their orders and aromatic flags, get_single_bond_neighbour (U:612-635) EXECUTED for every atom
+    arrays['reader_rings/bond_order'], arrays['reader_rings/bond_aromatic'] = rpc2.bond_order, rpc2.bond_aromatic
+    h2 = holders_from_pack(IC, rpc2, rpc2.bond_order, rpc2.bond_aromatic)
+    sb2 = np.full(rpc2.n_atoms, -1, np.int32)
+    for a_ in h2.s_atoms:
+        nb = utils.get_single_bond_neighbour(h2.ob_mol.GetAtomById(h2.bio_to_ob[a_]))
+        if nb is not None:
+            sb2[a_.idx] = h2.ob_to_bio[nb.GetId()].idx
+    arrays['reader_rings/sb_nbr_reference'] = sb2
+    assert np.array_equal(sb2, rpc2.sb_nbr), 'read_mmcif: single-bond neighbours differ from the executed get_single_bond_neighbour'
+    for tag, kw in (('whole', dict()), ('tyr', dict(selectors=['RESNAME:TYR'])), ('a25', dict(selectors=['/A/25/']))):
+        out, _ = run_case(IC, config, rpc2, bond_order=rpc2.bond_order, bond_aromatic=rpc2.bond_aromatic, **kw)
+        add(f'reader_rings:{tag}', rpc2, out, pack='reader_rings', selectors=kw.get('selectors'), sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode='canonical')
+        assert len(out['ap_atom']) and (tag != 'whole' or (len(out['pp_bgn']) and len(out['gg_bgn']) and len(out['gp_bgn']))), tag
+
+
+def check_reader():
+    """Re-runs section D alone and compares every array it makes with the committed core_cases.npz (the CPU suite calls this: a
+    fixture that no longer is what its generator makes must not go unnoticed again).  Returns the number of arrays compared."""
+    IC, utils, config, exceptions = reference_namespace()
+    arrays, seen = {}, []
+
+    def add(name, pc, out, **params):
+        if f'{params["pack"]}/xyz' not in arrays:
+            ex = extras_for(pc)
+            pc.lone_pair_electrons = (np.asarray(config.VALENCE)[ex['atomic_number']] - ex['bond_order'] - ex['formal_charge']).astype(np.int32)
+            arrays.update(pack_arrays(pc, params['pack'] + '/'))
+        for k, v in out.items():
+            arrays[f'{name}/{k}'] = v
+        seen.append(name)
+
+    reader_section(IC, config, add, arrays, utils)
+    z = np.load(os.path.join(HERE, 'core_cases.npz'), allow_pickle=False)
+    bad = [k for k, v in arrays.items() if k not in z.files or np.asarray(v).dtype != z[k].dtype or np.asarray(v).shape != z[k].shape
+           or np.asarray(v).tobytes() != z[k].tobytes()]
+    stale = [k for k in z.files if k.split('/')[0] in set(seen) | {'reader'} and k not in arrays]
+    assert not bad and not stale, (bad[:10], stale[:10])
+    return len(arrays)
+
+
 def main():
     IC, utils, config, exceptions = reference_namespace()
     from helpers import known_answer_packs, random_dense_pack
@@ -688,39 +798,7 @@ def main():
         add(f'proteinlike:{tag}', pc, out, pack='proteinlike', selectors=kw.get('selectors'), sel=None, cutoff=kw.get('cutoff', 5.0),
             comp=kw.get('comp', 0.1), seq_adj=kw.get('seq_adj', False), mode='canonical')
         print(f'   ({time.time() - t_run:.0f} s)')
-    # ---- D. a structure that came through the mmCIF reader (core/protein_reader.read_mmcif): alternative locations (the B
-    # child wins on occupancy), insertion codes 17A / 17B, a modified residue in the chain, a chain break, hetero groups, waters
-    # of two names, and a heavy water (element D: not a hydrogen at I:712, but its deuterons are hydrogens to OpenBabel, I:1524)
-    import tempfile
-    from make_golden_reader import peptide_atom_site, chem_comp, cif_text
-    from arpeggio_amd.core import protein_reader
-    cols = peptide_atom_site(np.random.default_rng(5), 0)
-    nrow = len(cols['id'])
-
-    def add_row(**kv):
-        for k in cols:
-            cols[k].append(kv.get(k, cols[k][nrow - 1]))
-    ox = np.array([float(cols['Cartn_x'][3]) + 2.9, float(cols['Cartn_y'][3]) + 0.4, float(cols['Cartn_z'][3]) + 0.3])
-    for nm, el, d in (('O', 'O', (0, 0, 0)), ('D1', 'D', (0.76, 0.59, 0.0)), ('D2', 'D', (-0.76, 0.59, 0.0))):
-        add_row(group_PDB='HETATM', id=str(len(cols['id']) + 1), type_symbol=el, label_atom_id=nm, label_alt_id=None, label_comp_id='DOD',
-                label_asym_id='A', label_seq_id=False, pdbx_PDB_ins_code=None, Cartn_x='%.3f' % (ox[0] + d[0]), Cartn_y='%.3f' % (ox[1] + d[1]),
-                Cartn_z='%.3f' % (ox[2] + d[2]), occupancy='1.00', pdbx_formal_charge=None, auth_seq_id='450', auth_asym_id='A', pdbx_PDB_model_num='1')
-    cc = chem_comp(0)
-    cc['id'].append('DOD'); cc['type'].append('NON-POLYMER'); cc['name'].append('DEUTERATED WATER')
-    for k in cc:
-        if len(cc[k]) < len(cc['id']):
-            cc[k].append(None)
-    text = cif_text('READER', [('_atom_site.', cols), ('_chem_comp.', cc)], singles=[('_entry.id', 'READER')])
-    with tempfile.TemporaryDirectory() as td:
-        fn = os.path.join(td, 'reader_h.cif')
-        open(fn, 'w').write(text)
-        rpc = protein_reader.read_mmcif(fn)
-    rpc.id = 'reader'
-    assert 'D' in rpc.element and np.diff(rpc.h_off).max() == 2           # the heavy water's oxygen carries both deuterons
-    arrays['reader/cif_text'] = np.array(text)
-    for tag, kw in (('whole', dict()), ('chain_b', dict(selectors=['/B//']))):
-        out, _ = run_case(IC, config, rpc, **kw)
-        add(f'reader:{tag}', rpc, out, pack='reader', selectors=kw.get('selectors'), sel=None, cutoff=5.0, comp=0.1, seq_adj=False, mode='canonical')
+    reader_section(IC, config, add, arrays, utils)
     small = synth.proteinlike(n_res=110, n_waters=70, id='proteinlike_small')
     o2, a2 = protein_bond_orders(small)
     out, exp = run_case(IC, config, small, bond_order=o2, bond_aromatic=a2, with_export=True)

@@ -21,6 +21,7 @@ import types
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('ARP_GOLDEN_OUT', HERE)      # (tests/test_fixture_freshness.py regenerates into a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
@@ -123,7 +124,7 @@ def main():
         name = f'soup{k}'
         run(pcs, np.array(good, np.int32), pcs.ring_center + rs.normal(scale=1.0, size=pcs.ring_center.shape), name, out); names.append(name)
     out['names'] = np.array(names)
-    np.savez_compressed(os.path.join(HERE, 'prepare_cases.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, 'prepare_cases.npz'), **out)
     print({n: (len(out[n + '/amide_atoms']), len(out[n + '/ring_res']), int((out[n + '/ring_res'] < 0).sum())) for n in names})
 
 

@@ -24,6 +24,7 @@ import types
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('ARP_GOLDEN_OUT', HERE)      # (tests/test_fixture_freshness.py regenerates into a scratch directory)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
@@ -121,6 +122,98 @@ def peptide_atom_site(rng, variant):
         del cols['B_iso_or_equiv']
         del cols['pdbx_formal_charge']
     return cols
+
+
+def aromatic_atom_site():
+    """A two-chain peptide with complete aromatic and amide side chains and explicit hydrogens: what the ring / amide loops of
+    run_arpeggio (I:938-1382) need from a FILE — PHE / TYR / TRP / HIS rings stacked at 3.6 A (parallel, tilted and on edge),
+    ASN / GLN side-chain amides, a methionine sulphur and a lysine nitrogen over rings.  Idealised, not energy-minimised:
+    consecutive residues are 3.6 A apart along the chain (C - N = 1.33 A), every ring a regular polygon of radius 1.39 A."""
+    rows = []
+    serial = [0]
+
+    def add(el, name, comp, chain, seq, xyz):
+        serial[0] += 1
+        rows.append(dict(group_PDB='ATOM', id=str(serial[0]), type_symbol=el, label_atom_id=name, label_alt_id=None, label_comp_id=comp,
+                         label_asym_id=chain, label_entity_id='1', label_seq_id=str(seq), pdbx_PDB_ins_code=None,
+                         Cartn_x='%.3f' % xyz[0], Cartn_y='%.3f' % xyz[1], Cartn_z='%.3f' % xyz[2], occupancy='1.00',
+                         B_iso_or_equiv='%.2f' % (10 + serial[0] % 7), pdbx_formal_charge=None, auth_seq_id=str(seq), auth_asym_id=chain,
+                         pdbx_PDB_model_num='1'))
+
+    def polygon(centre, normal, start, names, elements, comp, chain, seq, hydrogens=()):
+        n = np.asarray(normal, float) / np.linalg.norm(normal)
+        u = np.cross(n, [0.0, 0.0, 1.0])
+        if np.linalg.norm(u) < 1e-6:
+            u = np.cross(n, [0.0, 1.0, 0.0])
+        u /= np.linalg.norm(u)
+        v = np.cross(n, u)
+        k = len(names)
+        pts = {}
+        for j, (nm, el) in enumerate(zip(names, elements)):
+            t = start + 2 * np.pi * j / k
+            pts[nm] = np.asarray(centre) + 1.39 * (np.cos(t) * u + np.sin(t) * v)
+            add(el, nm, comp, chain, seq, pts[nm])
+        for hn, on in hydrogens:                      # a hydrogen 1.08 A outwards of its ring atom
+            d = pts[on] - np.asarray(centre)
+            add('H', hn, comp, chain, seq, pts[on] + 1.08 * d / np.linalg.norm(d))
+        return pts
+
+    def residue(comp, chain, seq, o, tilt=0.0):
+        o = np.asarray(o, float)
+        add('N', 'N', comp, chain, seq, o)
+        add('C', 'CA', comp, chain, seq, o + [1.46, 0, 0])
+        add('C', 'C', comp, chain, seq, o + [2.0, 1.4, 0])
+        add('O', 'O', comp, chain, seq, o + [1.4, 2.4, 0])
+        add('H', 'H', comp, chain, seq, o + [-0.5, -0.85, 0.0])
+        cb = o + [2.0, -1.2, 0.8]
+        if comp != 'GLY':
+            add('C', 'CB', comp, chain, seq, cb)
+        c = o + [1.8, -4.2, 1.2]                                           # centre of the side chain's ring, if it has one
+        nrm = [np.cos(tilt), np.sin(tilt), 0.0]                            # tilt = 0: normal along the chain
+        if comp in ('PHE', 'TYR'):
+            pts = polygon(c, nrm, 0.3, ['CG', 'CD1', 'CE1', 'CZ', 'CE2', 'CD2'], 'CCCCCC', comp, chain, seq,
+                          hydrogens=(('HD1', 'CD1'), ('HE1', 'CE1'), ('HE2', 'CE2'), ('HD2', 'CD2')) + ((('HZ', 'CZ'),) if comp == 'PHE' else ()))
+            if comp == 'TYR':
+                d = pts['CZ'] - c
+                oh = pts['CZ'] + 1.36 * d / np.linalg.norm(d)
+                add('O', 'OH', comp, chain, seq, oh)
+                add('H', 'HH', comp, chain, seq, oh + 0.96 * d / np.linalg.norm(d))
+        elif comp == 'HIS':
+            polygon(c, nrm, 0.1, ['CG', 'ND1', 'CE1', 'NE2', 'CD2'], 'CNCNC', comp, chain, seq, hydrogens=(('HD1', 'ND1'), ('HE1', 'CE1'), ('HD2', 'CD2')))
+        elif comp == 'TRP':
+            polygon(c, nrm, 0.2, ['CG', 'CD1', 'NE1', 'CE2', 'CD2'], 'CCNCC', comp, chain, seq, hydrogens=(('HD1', 'CD1'), ('HE1', 'NE1')))
+            n_ = np.asarray(nrm)
+            u = np.cross(n_, [0.0, 0.0, 1.0]); u /= np.linalg.norm(u)
+            polygon(c + 2.3 * u, nrm, 0.5, ['CZ2', 'CH2', 'CZ3', 'CE3'], 'CCCC', comp, chain, seq, hydrogens=(('HZ2', 'CZ2'), ('HH2', 'CH2')))
+        elif comp in ('ASN', 'GLN'):
+            names = {'ASN': ('CG', 'OD1', 'ND2'), 'GLN': ('CD', 'OE1', 'NE2')}[comp]
+            if comp == 'GLN':
+                add('C', 'CG', comp, chain, seq, o + [1.9, -2.6, 1.0])
+            add('C', names[0], comp, chain, seq, c + [0.0, 0.3, 0.0])
+            add('O', names[1], comp, chain, seq, c + [0.0, -0.4, 1.0])
+            add('N', names[2], comp, chain, seq, c + [0.0, -0.5, -1.1])
+            add('H', 'H' + names[2][1:] + '1', comp, chain, seq, c + [0.0, -1.5, -1.2])
+        elif comp == 'MET':
+            add('C', 'CG', comp, chain, seq, o + [1.9, -2.6, 1.0])
+            add('S', 'SD', comp, chain, seq, c)
+            add('C', 'CE', comp, chain, seq, c + [0.3, -1.7, 0.4])
+        elif comp == 'LYS':
+            add('C', 'CG', comp, chain, seq, o + [1.9, -2.6, 1.0])
+            add('C', 'CD', comp, chain, seq, o + [1.9, -3.4, 2.2])
+            add('C', 'CE', comp, chain, seq, c + [0.0, 1.0, 0.6])
+            add('N', 'NZ', comp, chain, seq, c)
+            for j in range(3):
+                add('H', f'HZ{j + 1}', comp, chain, seq, c + [0.95 * np.cos(2.1 * j), -0.3, 0.95 * np.sin(2.1 * j)])
+        return o + [3.3, 1.5, 0]
+
+    nxt = np.zeros(3)
+    for k, (comp, tilt) in enumerate((('PHE', 0.0), ('TYR', 0.0), ('TRP', 0.6), ('HIS', 1.3), ('ASN', 0.0), ('PHE', 0.3), ('GLN', 0.0), ('MET', 0.0),
+                                      ('PHE', 0.0), ('LYS', 0.0), ('TYR', 0.9), ('ALA', 0.0))):
+        nxt = residue(comp, 'A', 20 + k, nxt, tilt)
+    o = np.array([0.6, -8.6, 2.4])                                          # second chain: its side chains face the first one's
+    for k, (comp, tilt) in enumerate((('TYR', 0.2), ('ASN', 0.0), ('GLN', 0.0), ('TRP', 0.0), ('HIS', 0.5), ('GLY', 0.0))):
+        nxt_b = residue(comp, 'B', 5 + k, [o[0] + 3.3 * k, o[1] + 1.5 * k - 0.0, o[2]], tilt)
+    return {k: [r[k] for r in rows] for k in rows[0]}
 
 
 def chem_comp(variant):
@@ -245,7 +338,7 @@ def main():
                                    for r in residues],
                          polypeptide_residues=sorted(r.idx for r in obj.polypeptide_residues)))
     out = dict(cases=cases, missing_chem_comp=missing, hetero_flag=hetero, bookkeeping=book)
-    json.dump(out, open(os.path.join(HERE, 'reader.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(OUT, 'reader.json'), 'w'), indent=1)
     print('reader.json:', len(cases), 'cases,', sum(len(c['builder_calls']) for c in cases), 'builder calls')
 
 

@@ -18,6 +18,7 @@ import types
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('ARP_GOLDEN_OUT', HERE)      # (tests/test_fixture_freshness.py regenerates into a scratch directory)
 sys.path.insert(0, HERE)
 from make_golden_core import REF, compile_functions   # noqa: E402
 from make_golden_reader import cif_text                # noqa: E402
@@ -138,7 +139,7 @@ def main():
                     'new_bonds': [list(b) for b in mol.new_bonds],
                     'neighbours': {str(i): [n.oid for n in mol.atoms[i].nbrs] for i in ids if mol.atoms[i].nbrs}})
         assert len(mol.new_bonds) == 6, mol.new_bonds
-    json.dump(out, open(os.path.join(HERE, 'struct_conn.json'), 'w'), indent=0)
+    json.dump(out, open(os.path.join(OUT, 'struct_conn.json'), 'w'), indent=0)
     print([c['new_bonds'] for c in out])
 
 

@@ -18,6 +18,7 @@ import zlib
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('ARP_GOLDEN_OUT', HERE)      # (tests/test_fixture_freshness.py regenerates into a scratch directory)
 sys.path.insert(0, HERE)
 import make_golden_core as core   # noqa: E402  (holders + extraction helpers)
 
@@ -107,7 +108,7 @@ def main():
     holder.s_atoms = flagged
     holder._extend_atom_properties()          # interactions.py:1985-1991, executed
     out['element_flags'] = [{'element': a.element, 'is_metal': bool(a.is_metal), 'is_halogen': bool(a.is_halogen)} for a in flagged]
-    json.dump(out, open(os.path.join(HERE, 'typing.json'), 'w'), indent=0)
+    json.dump(out, open(os.path.join(OUT, 'typing.json'), 'w'), indent=0)
     print({k: len(v['atoms']) for k, v in out.items() if isinstance(v, dict)})
 
 

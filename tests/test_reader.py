@@ -135,7 +135,7 @@ def test_read_mmcif_end_to_end(golden, tmp_path):
     assert not pc.type_mask[lig].any()
     o = [i for i in range(pc.n_atoms) if pc.atom_name[i] == 'O' and pc.res_name[pc.res_id[i]] == 'GLY']
     assert o and all(pc.type_mask[i] & config.ATOM_TYPE_BIT['hbond acceptor'] for i in o)
-    assert {k: pc.component_types[k] for k in case['component_types']} == case['component_types'] and 'bonds inside residues' in pc.incomplete
+    assert {k: pc.component_types[k] for k in case['component_types']} == case['component_types'] and 'bonds inside non-standard residues' in pc.incomplete
     with pytest.raises(ValueError, match='_atom_site'):
         q = tmp_path / 'empty.cif'
         q.write_text('data_x\n_entry.id x\n')
@@ -220,8 +220,9 @@ def test_cif_path_through_the_constructor_equals_the_executed_reference(tmp_path
     """The structure of the executed-reference fixture that came through the mmCIF reader (`reader:*` cases of
     tests/golden/core_cases.npz: alternative locations, insertion codes, a modified residue, hetero groups, waters, a heavy
     water), this time from the FILE through InteractionComplex(path): structure_checks -> initialize -> run_arpeggio ->
-    get_contacts, as the reference's only caller does (CLI:159-182).  The atom-atom bag must be the reference's own records;
-    without allow_incomplete the run is refused, naming the hetero groups whose types only OpenBabel could give."""
+    get_contacts, as the reference's only caller does (CLI:159-182).  ALL FIVE bags and the selection's ring / amide id sets must
+    be the reference's own; without allow_incomplete the run is refused, naming the hetero groups whose types only OpenBabel
+    could give."""
     import json
     from arpeggio_amd.core import InteractionComplex, IncompleteStructureError
     z = np.load(os.path.join(golden_dir, 'core_cases.npz'), allow_pickle=False)
@@ -246,6 +247,17 @@ def test_cif_path_through_the_constructor_equals_the_executed_reference(tmp_path
         assert np.array_equal(got['dist'].view(np.uint32), z[case + '/aa_dist'][o].view(np.uint32)), case
         assert np.array_equal(got['sift'], z[case + '/aa_sift'][o]) and np.array_equal(got['ctype'], z[case + '/aa_ctype'][o]), case
         assert np.array_equal(np.sort(ic.selection_plus), np.sort(z[case + '/selection_plus'])), case
+        # ... and the rest of what the path from the FILE produces: rings and amide groups of the standard residues from residue
+        # templates, their centres / normals / residues computed on the GPU (initialize()), the four plane bags and the id sets —
+        # against the same structure run through the executed reference with the executed _perceive_amide_groups /
+        # _assign_aromatic_rings_to_residues behind it (tests/golden/make_golden_core.py, section D)
+        from test_golden_core import check_planes
+        b4 = ic._bags
+        check_planes(z, case, b4['atom_plane'], b4['plane_plane'], b4['group_group'], b4['group_plane'])
+        for attr in ('selection_ring_ids', 'selection_plus_ring_ids', 'selection_amide_ids', 'selection_plus_amide_ids'):
+            assert sorted(getattr(ic, attr)) == z[f'{case}/{attr}'].tolist(), (case, attr)
+        assert np.array_equal(ic.selection_plus_residues, z[case + '/selection_plus_residues']), case
+        assert len(z[case + '/gg_bgn']) + len(z[case + '/ap_ring']) > 0, case         # (the plane bags of this case are not empty)
         recs = ic.get_contacts()
         assert sum(r['type'] == 'atom-atom' for r in recs) == len(got['i']) > 0
         json.dumps(recs)
@@ -276,7 +288,7 @@ def test_struct_conn_bonds_equal_the_executed_reference(conn, tmp_path):
             if a in idx and b in idx:          # (the B child of an alternative location is not an atom of the pack)
                 ia, ib = idx[a], idx[b]
                 assert ib in pc.bond_idx[pc.bond_off[ia]:pc.bond_off[ia + 1]] and ia in pc.bond_idx[pc.bond_off[ib]:pc.bond_off[ib + 1]]
-        assert 'bonds inside residues' in pc.incomplete and 'bonds' not in pc.incomplete
+        assert 'bonds inside non-standard residues' in pc.incomplete and 'bonds' not in pc.incomplete
 
 
 def _cif_of(pc, decimals=3, split_chain=False):
