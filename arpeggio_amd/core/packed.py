@@ -208,7 +208,7 @@ class PackedComplex:
             self.lone_pair_electrons = _arr(self.lone_pair_electrons, np.int32)
         if self.type_mask_ambiguities is not None:
             self.type_mask_ambiguities = _arr(self.type_mask_ambiguities, np.uint16)
-        for rn in set(self.res_name):
+        for rn in sorted(set(self.res_name)):      # (sorted: the order of a set of strings changes from process to process)
             self.component_types.setdefault(rn, 'P')
         return self
 

@@ -63,6 +63,7 @@ def parse():
                     help='N > 1: run the general three-stage protocol (selection_plus bits over P2P + residue-set all-reduce '
                          'every step) although the whole-structure selection of the benchmark does not need it')
     ap.add_argument('--cpu-sample-atoms', type=int, default=100_000)
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the stand-in (configs[0], [1]) and rings (configs[4]) legs of the default N = 1 run')
     ap.add_argument('--dry-run', action='store_true',
                     help='everything a --gpus N launch does up to (not including) the first HIP call: environment, rank -> device mapping, '
                          'rendezvous of the ranks, broadcast of a 128-byte id, barrier, reduction; prints one JSON line on rank 0 (tests/test_sharding.py)')
@@ -94,6 +95,155 @@ def survey_8d_bytes(kernel, n_binned, ncell, n_pairs):
     if kernel == 'sift':         # hydrogen / bond side arrays + the output records
         return 16 * n_binned + 16 * n_pairs
     raise KeyError(kernel)
+
+
+def _timed_passes(step, min_s=0.25, min_n=50, warm=8):
+    for _ in range(warm):
+        out = step()
+    n, t0 = 0, time.perf_counter()
+    while n < min_n or time.perf_counter() - t0 < min_s:
+        out = step()
+        n += 1
+    return (time.perf_counter() - t0) / n * 1e3, n, out
+
+
+def _kernel_us(ctx, step, n=40):
+    ctx.set_profiling(True)
+    ctx.kernel_times(reset=True)
+    for _ in range(n):
+        step()
+    kt = ctx.kernel_times(reset=True)
+    ctx.set_profiling(False)
+    return {k: v['ms'] / max(v['launches'], 1) * 1e3 for k, v in kt.items() if v['launches']}
+
+
+def _dominant_roofline(kus, st, kernels=('bin', 'search', 'sift', 'mark_search')):
+    cands = {k: kus[k] for k in kernels if k in kus}
+    dom = max(cands, key=cands.get)
+    n_b = st['binned'] if dom != 'mark_search' else st.get('atoms', st['binned'])
+    b = survey_8d_bytes(dom, n_b, st['cells'], st['emitted'])
+    ach = b / (cands[dom] * 1e-6) / 1e9
+    return {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 6),
+            'traffic': None, 'algorithmic_bytes_per_launch': int(b), 'avg_launch_us': round(cands[dom], 2),
+            'note': 'SURVEY 8d bytes of the longest kernel of the pass over its HIP-event duration in this run'}
+
+
+def other_single_gpu_configs(args, device):
+    """The single-GPU configurations of BASELINE.json beside the headline (configs[2]), each measured the same way — a resident
+    pass that builds its grid, the SURVEY 8d roofline of its longest kernel, the C oracle on one host core beside it:
+      standin_whole   configs[1]: the 1tqn_h stand-in (the file is not available), whole structure
+      standin_ligand  configs[0]: the same structure, `-s /A/508/` (a ligand and its binding site)
+      rings           configs[4]: 10 000 aromatic rings + 10 000 amide groups: the centroid + normal plane kernels
+    World size 1 only; a few seconds of GPU time and a few seconds of CPU time in all."""
+    from arpeggio_amd import synth, _capi
+    out = {}
+    cx = _capi.Context(device)
+    try:
+        # ---- configs[1] / configs[0]: the stand-in
+        pc = synth.proteinlike()
+        cx.set_complex(pc)
+        cx.set_grid_reuse(False)
+        step = lambda: cx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+        ms, n, cnt = _timed_passes(step)
+        st = cx.stats()
+        kus = _kernel_us(cx, step)
+        whole = {'workload': f'1tqn_h stand-in (BASELINE configs[1]; the file is not available): {pc.n_atoms} atoms incl. explicit hydrogens, whole structure, 5 A cutoff',
+                 'ms_per_step': round(ms, 4), 'steps': n, 'value': round(st['candidates'] / (ms * 1e-3), 1), 'unit': 'candidate atom-pairs/s',
+                 'pairs': {'candidates': int(st['candidates']), 'accepted': int(st['accepted']), 'contacts_emitted': int(st['emitted'])},
+                 'bags': {k: int(v) for k, v in cnt.items()}, 'kernel_us': {k: round(v, 2) for k, v in kus.items()},
+                 'roofline': _dominant_roofline(kus, st)}
+        out['standin_whole'] = whole
+        lig = (np.asarray(pc.res_seq)[np.asarray(pc.res_id)] == 508).astype(np.uint8)
+        cx.set_selection(lig)
+        ms, n, cnt = _timed_passes(step)
+        st = cx.stats()
+        kus = _kernel_us(cx, step)
+        ligand = {'workload': 'the same stand-in, selection /A/508/ (BASELINE configs[0]): 6 A expansion of the ligand, selection_plus compacted into the grid of the pass, search, per-pair kernel, ring / amide loops',
+                  'selection': '/A/508/', 'selected_atoms': int(lig.sum()), 'ms_per_step': round(ms, 4), 'ms_per_pass': round(ms, 4), 'steps': n,
+                  'value': round(st['candidates'] / (ms * 1e-3), 1), 'unit': 'candidate atom-pairs/s (contact search; the 6 A expansion tests are counted beside)',
+                  'pairs': {'candidates': int(st['candidates']), 'expansion_candidates_6A': int(st['expand_candidates']), 'accepted': int(st['accepted']),
+                            'contacts_emitted': int(st['emitted'])},
+                  'candidate_pairs': int(st['candidates']), 'bags': {k: int(v) for k, v in cnt.items()}, 'kernel_us': {k: round(v, 2) for k, v in kus.items()},
+                  'roofline': _dominant_roofline(kus, dict(st, atoms=pc.n_atoms))}
+        out['standin_ligand'] = ligand
+        # ---- configs[4]: the plane kernels on 10 k rings + 10 k amides
+        pr = synth.config5()
+        cx.set_complex(pr)
+        cx.set_grid_reuse(False)
+        ms, n, cnt = _timed_passes(step, min_n=30)
+        rings = {'workload': f'BASELINE configs[4]: {pr.n_rings} aromatic rings + {pr.n_amides} amide groups ({pr.n_atoms} atoms) in a 100 A cube; whole pass and each plane loop alone',
+                 'ms_per_step': round(ms, 4), 'steps': n, 'bags': {k: int(v) for k, v in cnt.items()}, 'loops': {}}
+        cx.set_profiling(True)
+        R = int(pr.n_rings)
+        for name, units, unit_bytes in (('plane_plane', R, 56), ('atom_plane', R, 56), ('group_group', int(pr.n_amides), 32), ('group_plane', int(pr.n_amides), 32)):
+            for _ in range(5):
+                cx.launch_bag(name)
+            cx.kernel_times(reset=True)
+            for _ in range(40):
+                cx.launch_bag(name)
+            kt = cx.kernel_times(reset=True).get('planes')
+            us = kt['ms'] / max(kt['launches'], 1) * 1e3 if kt else None
+            emitted = int(cnt.get(name, 0))
+            b = unit_bytes * units + 32 * emitted          # SURVEY 8d: 56 B per ring (centre + normal f64 + ids; 32 B per amide: f32) + 32 B per emitted contact
+            rings['loops'][name] = {'kernel_us': None if us is None else round(us, 2), 'records': emitted, 'algorithmic_bytes': int(b),
+                                    'roofline': None if not us else {'bound': 'hbm', 'achieved': round(b / (us * 1e-6) / 1e9, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                                                     'frac': round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 7), 'traffic': None}}
+        cx.set_profiling(False)
+        pp = rings['loops']['plane_plane']
+        rings['roofline'] = dict(pp['roofline'] or {}, kernel='plane-plane loop (k_planes, one launch of its own here)', algorithmic_bytes_per_launch=pp['algorithmic_bytes'],
+                                 note='SURVEY 8d: 56 B per ring + 32 B per emitted contact; latency-bound list evaluation, the HBM fraction is tiny by construction')
+        rings['value'] = round(R * R / (pp['kernel_us'] * 1e-6), 1) if pp['kernel_us'] else None
+        rings['unit'] = "ordered ring pairs of the reference's loop per second (R^2 / plane-plane kernel time)"
+        out['rings'] = rings
+    finally:
+        cx.close()
+    return out
+
+
+def other_configs_cpu_baselines(args, cfg):
+    """cpu_baseline of the configurations of other_single_gpu_configs: the C oracle (oracle/ref_c.c) on ONE host core, a couple of
+    seconds each, on the same structures."""
+    import oracle
+    from arpeggio_amd import synth
+    pc = synth.proteinlike()
+    oc = oracle.OracleComplex(pc)
+    oc.make_selection(None)
+    n_known = len(oc.atom_contacts(args.cutoff, args.vdw_comp, False)['i'])
+    passes, cpu_s, cand_cpu = 0, 0.0, 0
+    while cpu_s < 2.0 and passes < 100:
+        t0 = time.perf_counter()
+        r = oc.atom_contacts(args.cutoff, args.vdw_comp, False, cap_hint=n_known)
+        oc.atom_plane(); oc.plane_plane(); oc.group_group(); oc.group_plane()
+        cpu_s += time.perf_counter() - t0
+        cand_cpu += int(r['stats'][0])
+        passes += 1
+    cfg['standin_whole']['cpu_baseline'] = {'value': round(cand_cpu / cpu_s, 1), 'unit': 'candidate atom-pairs/s', 'cores': 1, 'kind': 'port',
+                                            'ms_per_structure': round(cpu_s / passes * 1e3, 2),
+                                            'sample': f'{passes} whole passes of the C oracle (5 A search + per-pair SIFt + the four ring / amide loops) on the same structure, {cpu_s:.1f} s'}
+    lig = (np.asarray(pc.res_seq)[np.asarray(pc.res_id)] == 508).astype(np.uint8)
+    passes, cpu_s, cand_cpu = 0, 0.0, 0
+    while cpu_s < 1.0 and passes < 200:
+        t0 = time.perf_counter()
+        oc.make_selection(lig)
+        r = oc.atom_contacts(args.cutoff, args.vdw_comp, False)
+        oc.atom_plane(); oc.plane_plane(); oc.group_group(); oc.group_plane()
+        cpu_s += time.perf_counter() - t0
+        cand_cpu += int(r['stats'][0])
+        passes += 1
+    cfg['standin_ligand']['cpu_baseline'] = {'value': round(cand_cpu / cpu_s, 1), 'unit': 'candidate atom-pairs/s', 'cores': 1, 'kind': 'port',
+                                             'ms_per_structure': round(cpu_s / passes * 1e3, 2),
+                                             'sample': f'{passes} passes of the C oracle with the same selection (6 A expansion + 5 A search + per-pair SIFt + ring / amide loops), {cpu_s:.1f} s'}
+    pr = synth.config5()
+    ocr = oracle.OracleComplex(pr)
+    ocr.make_selection(None)
+    R = int(pr.n_rings)
+    t0 = time.perf_counter()
+    rec = ocr.plane_plane()
+    cpu_s = time.perf_counter() - t0
+    n_rec = len(next(iter(rec.values()))) if isinstance(rec, dict) and rec else None
+    cfg['rings']['cpu_baseline'] = {'value': round(R * R / cpu_s, 1), 'unit': 'ordered ring pairs/s', 'cores': 1, 'kind': 'port', 'ms_per_structure': round(cpu_s * 1e3, 1),
+                                    'sample': f'one pass of the plane-plane loop of the C oracle over the same {R} rings (O(R^2) ordered pairs like the reference, I:1064-1194)',
+                                    'records': n_rec}
 
 
 def per_gpu_workload(atoms):
@@ -613,6 +763,13 @@ def main():
                 step()
         except Exception as exc:   # never lose the main line over the extra measurement
             end_to_end = {'error': repr(exc)}
+    # the other single-GPU configurations of BASELINE.json (stand-in whole / ligand, rings): GPU parts here, CPU parts with the baselines below
+    other_configs = None
+    if world == 1 and args.workload == 'config3' and not args.no_other_configs:
+        try:
+            other_configs = other_single_gpu_configs(args, local_rank)
+        except Exception as exc:   # never lose the main line over the extra measurement
+            other_configs = {'error': repr(exc)}
     ctx.device_synchronize()
     t_gpu_legs_done = time.perf_counter()
 
@@ -641,6 +798,98 @@ def main():
         except Exception as exc:
             end_to_end['host_export_error'] = repr(exc)
     e2e_host = None
+
+    # ---- N > 1: what a scaling record should also say (never `value`) ----------------------------------------------------------
+    # (a) wall clock per DISTRIBUTED structure: shard set-up from this rank's home records — upload, faces cut on the device,
+    #     arp_shard_exchange_faces over RCCL, merge — + the first pass + the fetch of this rank's five bags; max over ranks
+    # (b) the general three-stage pass with a SELECTION (every 40th residue, by global id): arp_shard_exchange_plus and the
+    #     all-reduce of the residue sets are inside every timed step
+    # (c) at N = 8 with the default workload: BASELINE configs[3] itself, 250 000 atoms per GPU = 2 M atoms
+    multi = None
+    if world > 1:
+        multi = {}
+        try:
+            from arpeggio_amd import sharding
+
+            def build(atoms, whole, home_records=None):
+                if comm_device is None or args.host_halo:      # (debug transports: host buffers through the rendezvous)
+                    full_ = synth.slab_config(atoms, world, seed=4)
+                    sh_ = sharding.make_shard_distributed(full_, rank, world, transport)
+                    sharding.upload_shard(ctx, sh_, whole_structure=whole)
+                    return sh_
+                return sharding.make_shard_device(ctx, home_records if home_records is not None else synth.slab_home_records(atoms, world, rank, seed=4),
+                                                  rank, world, whole_structure=whole)
+
+            def red_max(x):
+                return float(rdzv.allreduce(np.array([x], np.float64), 'max')[0])
+
+            def red_sum(x):
+                return float(rdzv.allreduce(np.array([x], np.float64), 'sum')[0])
+
+            home_again = None if (comm_device is None or args.host_halo) else home
+            ts = []
+            for k in range(3):
+                sync_all()
+                tt = time.perf_counter()
+                sh_w = build(args.atoms, True, home_again)
+                cnt_w = sharding.run_shard_whole_structure(ctx, args.cutoff, args.vdw_comp, False)
+                bags_w, _ = ctx.fetch_packed()
+                ts.append(time.perf_counter() - tt)
+            multi['wall_clock_per_structure_ms'] = round(red_max(min(ts[1:])) * 1e3, 3)
+            multi['wall_clock_per_structure_definition'] = ('shard set-up from resident home records (upload + faces cut on the device + arp_shard_exchange_faces over RCCL + merge) + '
+                                                            'first pass + fetch of the rank\'s five bags (device sort, one copy); best of the last two of three, max over ranks')
+            multi['shard_setup_breakdown_ms_rank0'] = getattr(sh_w, 'timings_ms', None)
+            # (b) staged pass with a selection
+            sh_s = build(args.atoms, False, home_again)
+            gid = np.asarray(sh_s.global_id, np.int64)
+            sel = (((gid // 8) % 40) == 0).astype(np.uint8)
+            ctx.set_selection(sel)
+            sh_s.sel = sel
+            if comm_device is not None and not args.host_halo:
+                ex_s = sharding.DeviceExchange(ctx, sh_s)
+                step_s = lambda: sharding.run_shard_device(ctx, ex_s, args.cutoff, args.vdw_comp, False)
+            else:
+                step_s = lambda: sharding.run_shard(ctx, sh_s, transport, args.cutoff, args.vdw_comp, False)
+            for _ in range(5):
+                cnt_s = step_s()
+            sync_all()
+            n_s = max(20, min(args.steps, 200))
+            tt = time.perf_counter()
+            for _ in range(n_s):
+                cnt_s = step_s()
+            sync_all()
+            el_s = red_max(time.perf_counter() - tt)
+            st_s = ctx.stats()
+            multi['staged_selection_pass'] = {'ms_per_step': round(el_s / n_s * 1e3, 4), 'steps': n_s, 'selection': 'every 40th run of 8 atoms by global id (both atoms of a boundary pair agree on every rank)',
+                                              'selected_atoms_all_ranks': int(red_sum(float((sel * np.asarray(sh_s.is_home)).sum()))),
+                                              'candidates_all_ranks': red_sum(float(st_s['candidates'])), 'contacts_emitted_all_ranks': red_sum(float(st_s['emitted'])),
+                                              'per_step_exchange': 'arp_shard_exchange_plus (grouped ncclSend / ncclRecv of the halo atoms\' selection_plus bits) + arp_shard_reduce_residue_sets (ncclAllReduce MAX) between the three stages of every step'
+                                                                   if (comm_device is not None and not args.host_halo) else 'host buffers through the rendezvous (debug transport)'}
+            # (c) BASELINE configs[3]
+            if world == 8 and args.atoms == 100_000:
+                sync_all()
+                tt = time.perf_counter()
+                sh_4 = build(250_000, True)
+                setup4 = red_max(time.perf_counter() - tt)
+                step4 = lambda: sharding.run_shard_whole_structure(ctx, args.cutoff, args.vdw_comp, False)
+                for _ in range(5):
+                    step4()
+                sync_all()
+                n_4 = max(20, min(args.steps, 100))
+                tt = time.perf_counter()
+                for _ in range(n_4):
+                    step4()
+                sync_all()
+                el_4 = red_max(time.perf_counter() - tt)
+                st_4 = ctx.stats()
+                c4 = red_sum(float(st_4['candidates']))
+                multi['config4'] = {'workload': 'BASELINE configs[3]: 2 000 000 atoms, 8 x-slabs of 250 000 (+ one-cell halo over RCCL), whole structure',
+                                    'ms_per_step': round(el_4 / n_4 * 1e3, 4), 'steps': n_4, 'value': round(c4 * n_4 / el_4, 1), 'unit': 'candidate atom-pairs/s',
+                                    'contacts_emitted': red_sum(float(st_4['emitted'])), 'shard_setup_ms_incl_record_generation': round(setup4 * 1e3, 2),
+                                    'halo_exchange_ms_rank0': round(getattr(sh_4, 'halo_ms', 0.0), 3)}
+            # back to the headline's shard (nothing below reads device state, but a later leg might)
+        except Exception as exc:   # never lose the main line over the extra measurements
+            multi['error'] = repr(exc)      # (a rank that fails alone leaves the others in a collective: the rendezvous' time-out ends the run)
 
     # max over ranks of the elapsed time, sum over ranks of the work
     cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
@@ -829,6 +1078,13 @@ def main():
         except Exception as exc:
             cpu_py = {'error': repr(exc)}
 
+    if other_configs is not None and 'error' not in other_configs and not args.no_cpu_baseline:
+        try:
+            other_configs_cpu_baselines(args, other_configs)
+        except Exception as exc:
+            other_configs['cpu_baseline_error'] = repr(exc)
+    if ligand_pass is None and other_configs is not None:
+        ligand_pass = other_configs.get('standin_ligand')
     e2e_ms_sorted = (end_to_end or {}).get('ms_per_structure')
     line = {
         'metric': 'evaluated atom-pairs/s', 'value': round(value, 1), 'unit': 'candidate atom-pairs/s',
@@ -860,6 +1116,7 @@ def main():
         'launch_mode': 'three launches on one HIP stream per pass: k_compact_atoms (kernel_ms.bin: the contact grid of the pass), k_search, k_sift_planes (per-pair evaluation + ring/amide loops; kernel_ms: search / sift); the last launch publishes the counters; one host wait per step (pinned completion word, bounded spin); kernel_ms from a second pass of the same steps with HIP events (each bracket adds ~4 us to a small kernel; rocprofv3 averages are in profiles/)',
         'per_step_exchange': (None if world == 1 else ('selection_plus halo bits (P2P) + residue sets (all-reduce MAX) over RCCL' if args.staged_exchange else 'none: whole-structure selection, every rank knows selection_plus and the residue sets (DESIGN.md 6)')),
         'rccl_ranks_seen': rccl_ranks_seen,
+        'multi_gpu': multi,
         'halo_exchange_ms': round(halo_ms, 3), 'halo_exchange_bytes_sent_rank0': halo_bytes, 'shard_setup_ms': round(shard_setup_ms, 2), 'shard_setup_breakdown_ms': shard_timings,
         'halo_exchange': (halo_note if world > 1 else None),
         'scaling_note': (None if world == 1 else f'weak scaling: every GPU owns one config-3 cube of {args.atoms} atoms (+ a one-cell halo) — the workload of the N = 1 line with the same --atoms'),
@@ -871,8 +1128,11 @@ def main():
         'roofline_valu': roofline_valu,
         'roofline_pass': roofline_pass,
         'pass_with_grid_kept': grid_kept, 'ligand_selection_pass': ligand_pass,
+        'configs': other_configs,
         'roofline': roofline, 'cpu_baseline': cpu,
     }
+    if world > 1 and comm_device is not None and rccl_ranks_seen != world:
+        line['error'] = f'the RCCL communicator holds {rccl_ranks_seen} ranks, not {world}: this is not an {world}-GPU measurement'
     print(json.dumps(line), flush=True)
     if rdzv is not None:
         rdzv.barrier()

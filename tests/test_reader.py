@@ -257,10 +257,69 @@ def test_cif_path_through_the_constructor_equals_the_executed_reference(tmp_path
         for attr in ('selection_ring_ids', 'selection_plus_ring_ids', 'selection_amide_ids', 'selection_plus_amide_ids'):
             assert sorted(getattr(ic, attr)) == z[f'{case}/{attr}'].tolist(), (case, attr)
         assert np.array_equal(ic.selection_plus_residues, z[case + '/selection_plus_residues']), case
-        assert len(z[case + '/gg_bgn']) + len(z[case + '/ap_ring']) > 0, case         # (the plane bags of this case are not empty)
         recs = ic.get_contacts()
         assert sum(r['type'] == 'atom-atom' for r in recs) == len(got['i']) > 0
         json.dumps(recs)
+
+
+@pytest.mark.gpu
+def test_rings_and_amides_of_a_file_equal_the_executed_reference(tmp_path, golden_dir):
+    """A FILE with complete aromatic and amide side chains and explicit hydrogens (`reader_rings:*` of core_cases.npz,
+    tests/golden/make_golden_reader.aromatic_atom_site) through InteractionComplex(path): rings and amide groups from the residue
+    templates, bonds inside the residues from the residue templates, centres / normals / residues computed on the GPU in
+    initialize() — and then all five bags and the ring / amide id sets against the executed reference, which ran on the same
+    structure with the EXECUTED _perceive_amide_groups / _assign_aromatic_rings_to_residues behind it (no GPU in the fixture)."""
+    from arpeggio_amd.core import InteractionComplex
+    from test_golden_core import check_planes
+    z = np.load(os.path.join(golden_dir, 'core_cases.npz'), allow_pickle=False)
+    p = tmp_path / 'rings_h.cif'
+    p.write_text(str(z['reader_rings/cif_text']))
+    for case, selectors in (('reader_rings:whole', []), ('reader_rings:tyr', ['RESNAME:TYR']), ('reader_rings:a25', ['/A/25/'])):
+        ic = InteractionComplex(str(p), 0.1, 5.0, 7.4, allow_incomplete=True)
+        ic.structure_checks()
+        ic.initialize()
+        assert ic.params.has_hydrogens and ic.pc.n_rings == len(z['reader_rings/ring_res']) and ic.pc.n_amides == len(z['reader_rings/amide_res'])
+        # the geometry initialize() computed on the GPU against the fixture's (executed reference / restated OpenBabel)
+        assert np.array_equal(ic.pc.ring_res, z['reader_rings/ring_res']) and np.array_equal(ic.pc.amide_res, z['reader_rings/amide_res'])
+        assert np.array_equal(np.asarray(ic.pc.amide_center, np.float32), z['reader_rings/amide_center'])
+        assert np.abs(np.asarray(ic.pc.ring_center) - z['reader_rings/ring_center']).max() < 1e-12
+        ic.run_arpeggio(selectors, 5.0, 0.1, False)
+        got = ic._bags['atom_atom']
+        b, e = z[case + '/aa_bgn'], z[case + '/aa_end']
+        o = np.lexsort((e, b))
+        assert np.array_equal(got['i'], b[o]) and np.array_equal(got['j'], e[o]), case
+        assert np.array_equal(got['dist'].view(np.uint32), z[case + '/aa_dist'][o].view(np.uint32)), case
+        assert np.array_equal(got['sift'], z[case + '/aa_sift'][o]) and np.array_equal(got['ctype'], z[case + '/aa_ctype'][o]), case
+        b4 = ic._bags
+        check_planes(z, case, b4['atom_plane'], b4['plane_plane'], b4['group_group'], b4['group_plane'])
+        for attr in ('selection_ring_ids', 'selection_plus_ring_ids', 'selection_amide_ids', 'selection_plus_amide_ids'):
+            assert sorted(getattr(ic, attr)) == z[f'{case}/{attr}'].tolist(), (case, attr)
+        assert np.array_equal(np.sort(ic.selection_plus), np.sort(z[case + '/selection_plus'])), case
+        if case.endswith(':whole'):
+            assert min(len(z[case + '/ap_ring']), len(z[case + '/pp_bgn']), len(z[case + '/gg_bgn']), len(z[case + '/gp_bgn'])) > 0
+
+
+def test_template_bonds_give_the_single_bond_neighbours_of_the_executed_reference(tmp_path, golden_dir):
+    """read_mmcif on the aromatic-rich file: the bonds inside the standard residues come from the residue templates
+    (protein_reader.RESIDUE_BONDS) with their orders and aromatic flags; utils.get_single_bond_neighbour (U:612-635), EXECUTED on
+    holders carrying those bonds, gives the pack's sb_nbr (`reader_rings/sb_nbr_reference`).  And no hydrogen is left without a
+    heavy atom."""
+    z = np.load(os.path.join(golden_dir, 'core_cases.npz'), allow_pickle=False)
+    p = tmp_path / 'rings_h.cif'
+    p.write_text(str(z['reader_rings/cif_text']))
+    pc = protein_reader.read_mmcif(str(p))
+    assert np.array_equal(pc.sb_nbr, z['reader_rings/sb_nbr_reference']) and (pc.sb_nbr >= 0).sum() > 150
+    assert np.array_equal(pc.bond_order, z['reader_rings/bond_order']) and np.array_equal(pc.bond_aromatic, z['reader_rings/bond_aromatic'])
+    assert (pc.bond_order == 2).sum() > 40 and (pc.bond_aromatic == 1).sum() > 100
+    is_h = np.array([e in ('H', 'D') for e in pc.element])
+    assert is_h.sum() > 60 and (pc.hydrogen_parent[is_h] >= 0).all()
+    assert 'bonds inside non-standard residues' in pc.incomplete and 'bonds inside residues' not in pc.incomplete
+    # a ring carbon of PHE: its first single, non-aromatic heavy neighbour is CB (for CG) — and none for CD1 (both ring bonds aromatic)
+    names = np.array(pc.atom_name)
+    res = np.array(pc.res_name)[pc.res_id]
+    cg = np.nonzero((names == 'CG') & (res == 'PHE'))[0][0]
+    cd1 = np.nonzero((names == 'CD1') & (res == 'PHE'))[0][0]
+    assert names[pc.sb_nbr[cg]] == 'CB' and pc.sb_nbr[cd1] == -1
 
 
 # ---- _struct_conn, explicit hydrogens, gemmi's normalisation (round 3) ----------------------------------------------------

@@ -335,7 +335,7 @@ def test_bench_gpus_2_as_the_driver_launches_it_up_to_the_first_hip_call():
     ... --dry-run` on CPU: everything of the N > 1 launch before its first HIP call — RANK / LOCAL_RANK / WORLD_SIZE from the
     launcher, one rank per device (LOCAL_RANK -> device), the TCP rendezvous beside the launcher's own store on MASTER_PORT,
     the 128-byte communicator id from rank 0 to everybody, a reduction and the barriers; twice in a row on the SAME port (the
-    driver runs N = 1, 2, 4, 8 back to back), and once with four ranks.  The per-GPU workload of the line is the N = 1 one."""
+    driver runs N = 1, 2, 4, 8 back to back), once with four ranks and once with eight.  The per-GPU workload of the line is the N = 1 one."""
     import json
     import subprocess
     import sys
@@ -351,6 +351,9 @@ def test_bench_gpus_2_as_the_driver_launches_it_up_to_the_first_hip_call():
     assert first['ranks'][0]['uid_crc32'] != again['ranks'][0]['uid_crc32']                   # (a fresh id per launch)
     four = _dry_line(_launch_bench_dry(4, port + 1))
     assert sorted(r['device'] for r in four['ranks']) == [0, 1, 2, 3] and four['allreduce_sum'] == 10.0
+    eight = _dry_line(_launch_bench_dry(8, port + 2))         # the size of the driver's node
+    assert sorted(r['device'] for r in eight['ranks']) == list(range(8)) and eight['allreduce_sum'] == 36.0
+    assert len({r['uid_crc32'] for r in eight['ranks']}) == 1 and eight['config'] == four['config']
     # the same per-GPU workload at N = 1 (what SCALE divides by) as at N > 1
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry-run'], capture_output=True, text=True, timeout=120, cwd=root)
