@@ -69,7 +69,8 @@ for k, v in out.items():
         continue
     key = {'void k_search<0>': 'k_search', 'void k_search<0, 1>': 'k_search', 'void k_search<0, 2>': 'k_search_tiles', 'void k_search<2>': 'k_mark_search',
            'void k_search<2, 1>': 'k_mark_search', 'k_compact_atoms': 'k_bin', 'void k_compact_atoms<512>': 'k_bin', 'void k_compact_atoms<1024>': 'k_bin', 'k_sift_planes': 'k_sift',
-           'void k_sift_planes<0>': 'k_sift', 'void k_sift<0>': 'k_sift', 'void k_sift_planes<1>': 'k_sift_streaming', 'void k_sift<1>': 'k_sift_streaming'}.get(k, k)
+           'void k_sift_planes<0>': 'k_sift', 'void k_sift<0>': 'k_sift', 'void k_sift_planes<1>': 'k_sift_streaming', 'void k_sift<1>': 'k_sift_streaming',
+           'void k_sift_planes<0, 0>': 'k_sift', 'void k_sift_planes<1, 0>': 'k_sift_streaming', 'void k_sift_planes<0, 1>': 'k_sift_gid', 'void k_sift_planes<1, 1>': 'k_sift_streaming_gid'}.get(k, k)
     all_streams = int((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024)
     if key in ('k_sift', 'k_sift_streaming') and n_pairs is not None:
         hbm = int((v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 + 4 * n_pairs)

@@ -8,7 +8,7 @@ extra=${2:-}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --inflight 1 --min-seconds 0 $extra"
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-other-configs --inflight 1 --min-seconds 0 $extra"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o t -- $B > "$out/trace.log" 2>&1 < /dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -o f -- $B > "$out/fetch.log" 2>&1 < /dev/null
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -o w -- $B > "$out/write.log" 2>&1 < /dev/null
