@@ -792,10 +792,8 @@ class Context:
         for b, (name, cols) in enumerate(self._PACKED_BAGS):
             m = int(counts[1 + b])
             res = {key: view(offs[5 + 12 * b + q], dt, m) for key, q, dt in cols}
-            if sort_bags and m > BAG_SORT_MAX:       # (smaller bags were put into their canonical order on the device)
-                order = self._BAGS[name][2]
-                o = np.lexsort((res[order[1]], res[order[0]]))
-                res = {kk: v[o] for kk, v in res.items()}
+            # (every bag arrives in its canonical order, made on the device: one block's bitonic network for a bag of up to
+            # BAG_SORT_MAX records, the radix passes of the atom-atom bag beyond that)
             bags[name] = res
         return bags, buf
 

@@ -350,6 +350,12 @@ struct arp_ctx {
     bool init_plus_in_bin = false; // ... and writes selection_plus = selection (whole-structure selection)
     // ---- device-resident result bags of the ring / amide kernels
     Bag bag_ap, bag_pp, bag_gg, bag_gp;
+    DevBuf<uint32_t> bag_perm_big[4];   // ... of a bag beyond BAG_SORT_MAX records (bag_order_large)
+    DevBuf<unsigned long long> bagsort_key[2], bagsort_val[2];
+    DevBuf<int> bagsort_table, bagsort_i, bagsort_j;
+    DevBuf<long long> bagsort_total;
+    DevBuf<uint16_t> bagsort_s;
+    DevBuf<uint8_t> bagsort_ct;
     DevBuf<uint32_t> bag_perm;     // canonical order of the small ring / amide bags (k_bag_order), BAG_SORT_MAX indices per bag
     DevBuf<uint8_t> bag_pack;      // staging of small bags: device side ...
     uint8_t* bag_stage = nullptr;  // ... and its page-locked host copy
@@ -2956,6 +2962,57 @@ int arp_atom_contacts_sort(arp_ctx* c) {
     return sort_contacts(c);
 }
 
+// Canonical order of a ring / amide bag of MORE than BAG_SORT_MAX records (config 5: 42 k plane-plane records): the radix
+// passes of the atom-atom bag (arp_sort.h) on {first id, second id} with the record's index riding as the payload — its bits in
+// the float32 column — so that the sorted "distance" column IS the permutation k_pack_segments follows.
+__global__ __launch_bounds__(256) void k_iota_bits(long long n, float* __restrict__ out, uint16_t* __restrict__ zs, uint8_t* __restrict__ zc) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        out[i] = __uint_as_float((uint32_t)i);
+        zs[i] = 0;
+        zc[i] = 0;
+    }
+}
+int bag_order_large(arp_ctx* c, const int* first, const int* second, size_t k, int64_t idmax, DevBuf<uint32_t>& perm) {
+    HIPCHK(c, perm.reserve(2 * k));                       // [0, k): the permutation; [k, 2 k): the indices as the sort's input column
+    HIPCHK(c, c->bagsort_i.reserve(k)); HIPCHK(c, c->bagsort_j.reserve(k));
+    HIPCHK(c, c->bagsort_s.reserve(2 * k)); HIPCHK(c, c->bagsort_ct.reserve(2 * k));
+    int idbits = 1;
+    while (((int64_t)1 << idbits) <= std::max<int64_t>(idmax, 1)) ++idbits;
+    const int passes = (idbits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
+    for (int q = 0; q < 2; ++q) { HIPCHK(c, c->bagsort_key[q].reserve(k)); HIPCHK(c, c->bagsort_val[q].reserve(k)); }
+    const long long tiles = ((long long)k + SORT_TILE - 1) / SORT_TILE;
+    const int tstride = (int)((tiles + 3) & ~3ll);
+    HIPCHK(c, c->bagsort_table.reserve((size_t)SORT_BINS * (size_t)tstride));
+    HIPCHK(c, c->bagsort_total.reserve(SORT_BINS));
+    float* const idx_in = reinterpret_cast<float*>(perm.p + k);
+    hipLaunchKernelGGL(k_iota_bits, dim3(nblocks((int64_t)k, 256, 1024)), dim3(256), 0, c->stream, (long long)k, idx_in, c->bagsort_s.p + k, c->bagsort_ct.p + k);
+    SortArgs A{};
+    A.ci = first; A.cj = second;
+    A.d_in = idx_in; A.s_in = c->bagsort_s.p + k; A.ct_in = c->bagsort_ct.p + k;
+    A.i_out = c->bagsort_i.p; A.j_out = c->bagsort_j.p; A.d_out = reinterpret_cast<float*>(perm.p);
+    A.s_out = c->bagsort_s.p; A.ct_out = c->bagsort_ct.p;
+    A.n = (long long)k; A.T = (int)tiles; A.tstride = tstride; A.jbits = idbits;
+    A.table = c->bagsort_table.p; A.total = c->bagsort_total.p;
+    int shift = idbits;
+    for (int ps = 0; ps < passes; ++ps) {
+        A.first = ps == 0; A.last = 0;
+        A.shift = shift;
+        A.bits = idbits / passes + (ps < idbits % passes ? 1 : 0);
+        shift += A.bits;
+        A.key_in = ps > 0 ? c->bagsort_key[(ps - 1) & 1].p : nullptr;
+        A.val_in = ps > 0 ? c->bagsort_val[(ps - 1) & 1].p : nullptr;
+        A.key_out = c->bagsort_key[ps & 1].p;
+        A.val_out = c->bagsort_val[ps & 1].p;
+        hipLaunchKernelGGL(k_sort_hist, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1 << A.bits), dim3(SORT_THREADS), 0, c->stream, A);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(A.T), dim3(SORT_THREADS), 0, c->stream, A);
+    }
+    A.key_in = c->bagsort_key[(passes - 1) & 1].p;
+    A.val_in = c->bagsort_val[(passes - 1) & 1].p;
+    hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, A);
+    return check_launch(c, "bag_order_large");
+}
+
 // Every result of the last pass with ONE copy: the atom-atom bag in canonical order (sorted on the device if it is not yet)
 // and the used prefixes of the four ring / amide bags behind it, gathered in HBM (k_pack_segments) and copied in one piece.
 int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts[5], uint64_t offsets[ARP_PACKED_OFFSETS], uint64_t* bytes_used) {
@@ -2986,6 +3043,15 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
         bo.perm[b] = c->bag_perm.p + (size_t)b * BAG_SORT_MAX;
         any_order = any_order || small;
     }
+    const uint32_t* big_perm[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int b = 0; b < 4; ++b) {
+        Bag& g = *bags[b];
+        if (!(g.valid && g.count > BAG_SORT_MAX)) continue;
+        if ((uint64_t)g.count >= ((uint64_t)1 << 31)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: a ring / amide bag of 2^31 records or more");
+        const int64_t idmax = (c->has_gid || c->has_group_owner) ? (((int64_t)1 << 31) - 1) : std::max<int64_t>({c->n, c->nring, c->namide, 2}) - 1;      // (a shard's records carry global ids)
+        CHK(bag_order_large(c, bo.first[b], bo.second[b], (size_t)g.count, idmax, c->bag_perm_big[b]));
+        big_perm[b] = c->bag_perm_big[b].p;
+    }
     // (on the second stream, beside the radix passes of the atom-atom bag: one block per bag, 80 us for a bag of 4096)
     const bool order_aside = any_order && c->stream2 && !c->external_stream && !c->contacts_sorted;
     if (any_order) {
@@ -3005,7 +3071,7 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
             const size_t bytes = (size_t)g.count * es[q];
             if (t.n >= 48 || bytes >= ((size_t)1 << 32) || total >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: ring / amide bags too large for one piece (fetch them one by one)");
             offsets[5 + 12 * b + q] = total;
-            t.s[t.n++] = PackSeg{ptr[q], (uint32_t)total, (uint32_t)bytes, bo.n[b] > 0 ? bo.perm[b] : nullptr, (uint32_t)es[q]};
+            t.s[t.n++] = PackSeg{ptr[q], (uint32_t)total, (uint32_t)bytes, bo.n[b] > 0 ? bo.perm[b] : big_perm[b], (uint32_t)es[q]};
             total = (total + bytes + 15) & ~(size_t)15;
         }
     }

@@ -746,7 +746,7 @@ def main():
                 pipelined = round((time.perf_counter() - t2) / (per_thread * args.inflight) * 1e3, 4)
                 for cx in ctxs:
                     cx.close()
-            end_to_end = {'ms_per_structure': round(e2e_ms, 4), 'structures': n_e2e, 'canonical_order': 'atom-atom bag sorted by (i, j) on the device (arp_atom_contacts_sort: radix passes over i — one block for a bag of up to 32 768 records — + per-run rank by j), ring / amide bags of up to 8192 records by their two ids on the device as well (k_bag_order), larger ones on the host',
+            end_to_end = {'ms_per_structure': round(e2e_ms, 4), 'structures': n_e2e, 'canonical_order': 'atom-atom bag sorted by (i, j) on the device (arp_atom_contacts_sort: radix passes over i — one block for a bag of up to 32 768 records — + per-run rank by j), ring / amide bags by their two ids on the device as well (k_bag_order: one block up to 8192 records; the radix passes beyond)',
                           'ms_per_structure_%d_contexts_in_flight' % max(args.inflight, 1): pipelined,
                           'breakdown_ms': {k: round(v, 4) for k, v in br.items()},
                           'run_arpeggio_on_an_unseen_structure_ms': round(br['first_pass_ms'], 4),

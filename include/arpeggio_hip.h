@@ -281,10 +281,11 @@ int arp_atom_contacts_sort(arp_ctx* ctx);
  * atom-atom bag; offsets[5 + 12 * b + q] = array q of ring / amide bag b (b = 0..3 in the
  * order of counts[1..4]; q = 0, 1: the two int32 id columns, 2..5: float64 columns, 6..8:
  * float32 columns, 9..11: uint8 columns — the columns of the bag's *_fetch call in its
- * argument order within each type; 0 = the bag has no such array).  A ring / amide bag of up
- * to ARP_BAG_SORT_MAX records arrives in ITS canonical order as well — plane-plane, group-group
- * and group-plane by (first id, second id), atom-plane by (ring, atom): the order the
- * reference's loops create the records in (I:947-1382) —, a larger one in the device's order.
+ * argument order within each type; 0 = the bag has no such array).  Every ring / amide bag
+ * arrives in ITS canonical order as well — plane-plane, group-group and group-plane by (first
+ * id, second id), atom-plane by (ring, atom): the order the reference's loops create the
+ * records in (I:947-1382) — made on the device (up to ARP_BAG_SORT_MAX records by one block,
+ * beyond that by the radix passes of the atom-atom bag).
  * bytes_used = bytes written; ARP_E_CAPACITY with bytes_used set when host_bytes is too small. */
 #define ARP_BAG_SORT_MAX 8192
 #define ARP_PACKED_OFFSETS 53

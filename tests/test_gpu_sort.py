@@ -184,3 +184,25 @@ def test_ring_and_amide_bags_of_several_thousand_records_are_ordered_on_the_devi
             for k, v in raw.items():
                 assert np.array_equal(bags[name][k].view(np.uint8), v[o].view(np.uint8)), (name, k, m)
     assert any(4096 < m <= capi.BAG_SORT_MAX for m in seen) and any(64 < m <= 4096 for m in seen), seen
+
+
+def test_ring_and_amide_bags_beyond_one_block_are_ordered_on_the_device_too(ctx, capi):
+    """Bags of MORE than ARP_BAG_SORT_MAX records (BASELINE configs[4]: 42 k plane-plane records) go through the radix passes of the
+    atom-atom bag with the record index as the payload (bag_order_large): the packed fetch delivers them in the reference's creation
+    order with no host sort (round 4 left these to np.lexsort)."""
+    from arpeggio_amd import synth
+    seen = []
+    for nr, na, L in ((10_000, 10_000, 100.0), (6000, 9000, 70.0)):
+        ctx.set_complex(synth.config5(nr, na, L=L))
+        counts = ctx.run_launch(5.0, 0.1, False, 6.0)
+        bags, _ = ctx.fetch_packed()
+        for name, (_, _, order) in ctx._BAGS.items():
+            m = counts[name]
+            if m == 0:
+                continue
+            seen.append(m)
+            raw = {k: v.copy() for k, v in ctx.fetch_bag(name, sort=False).items()}
+            o = np.lexsort((raw[order[1]], raw[order[0]]))
+            for k, v in raw.items():
+                assert np.array_equal(bags[name][k].view(np.uint8), v[o].view(np.uint8)), (name, k, m)
+    assert sum(m > capi.BAG_SORT_MAX for m in seen) >= 3 and max(seen) > 40_000, seen
