@@ -271,6 +271,12 @@ struct arp_ctx {
     DevBuf<unsigned long long> compact_chain;   // k_compact_atoms: one word per block
     DevBuf<int> s_cell;                         // cell of every row of the contact grid (k_search: blocks split by atoms)
     bool s_cell_valid = false;                  // ... written by the build of the grid that is in place
+    DevBuf<int> sb_tile;                        // k_search's runs of tiles with equal numbers of atoms (k_balance_blocks): a hint from the pass before
+    bool sb_valid = false;
+    uint64_t sb_static_epoch = 0, sb_sel_epoch = 0;
+    double sb_radius = 0.0;
+    int sb_blocks = 0, sb_tx = 0;
+    bool sb_whole = false;
     unsigned int compact_epoch = 0;
     bool static_dirty = true;
     // The contact grid of a WHOLE-STRUCTURE pass (every atom selected: selection_plus = all atoms, I:1395 / 1407) depends on the
@@ -1082,7 +1088,7 @@ int enqueue_expansion(arp_ctx* c, double radius, hipStream_t st = nullptr) {
         Prof p(c, SLOT_MARK, st);
         hipLaunchKernelGGL((k_search<MODE_MARK>), dim3(search_blocks(c->all_grid.d)), dim3(64 * SEARCH_WAVES), 0, st,
                            c->all_grid.d, c->all_grid.start.p, c->a_xyzm.p, c->a_aux.p, radius * radius, 1, 0, (int2*)nullptr,
-                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr);
+                           0ull, c->d_ctr + ctr_dev(C_SCRATCH0), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), c->plus.p, GroupMasks{}, (const int*)nullptr, (const int*)nullptr);
         CHK(check_launch(c, "k_search<MARK>"));
     }
     // all_grid stays usable for the atom-plane kernel: it reads plus[] directly, M_SEL is current
@@ -1432,18 +1438,32 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             nbk = (nbk + 7) & ~7;
             nblocks_search = (R >= 8 && 2 * nbk >= R) ? std::min(std::max(1, (nbk + R / 2) / R) * R, 8192) & ~7 : nbk;
         }
+        static const int hint_mode = env_int("ARP_SEARCH_BALANCE_HINT", 1);
+        static const int cell_w16 = std::max(0, env_int("ARP_SEARCH_CELL_WEIGHT_X16", 64));      // weight of a cell in sixteenths of an atom
+        const bool hint_ok = hint_mode && !by_atoms && whole && c->sb_valid && c->sb_static_epoch == c->static_epoch && c->sb_sel_epoch == c->sel_epoch &&
+                             c->sb_radius == cutoff && c->sb_blocks == nblocks_search && c->sb_tx == tile_x && c->sb_tile.p;
+        const int* const balance_hint = hint_ok ? (const int*)c->sb_tile.p : (const int*)nullptr;
         if (tile_x == 2) {
             hipLaunchKernelGGL((k_search<MODE_CONTACTS, 2>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
                                include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
                                c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
-                               by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
+                               by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr, balance_hint);
         } else {
             hipLaunchKernelGGL((k_search<MODE_CONTACTS>), dim3(nblocks_search), dim3(64 * SEARCH_WAVES), 0,
                                c->stream, c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, cutoff * cutoff,
                                include_seq_adj, c->has_home ? 1 : 0, c->pairs.p, (u64)segcap, c->d_ctr + ctr_dev(C_SEG_PAIRS), c->d_ctr + ctr_dev(C_STAT_CAND),
                                c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
-                               by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr);
+                               by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr, balance_hint);
+        }
+        // the hint for the NEXT pass over this grid (same structure, selection, cutoff, launch shape): made behind the search, off
+        // every critical path; a first pass runs on equal runs of cells
+        if (hint_mode && !by_atoms && !hint_ok && whole && nblocks_search >= 16) {
+            HIPCHK(c, c->sb_tile.reserve((size_t)nblocks_search + 1));
+            hipLaunchKernelGGL(k_balance_blocks, dim3(nblocks(nblocks_search + 1, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
+                               nblocks_search, tile_x, cell_w16, c->sb_tile.p);
+            c->sb_valid = true; c->sb_static_epoch = c->static_epoch; c->sb_sel_epoch = c->sel_epoch; c->sb_radius = cutoff;
+            c->sb_blocks = nblocks_search; c->sb_tx = tile_x; c->sb_whole = whole;
         }
         return check_launch(c, "k_search<CONTACTS>");
     };
@@ -2866,7 +2886,7 @@ int arp_search_all(arp_ctx* c, double radius, const uint8_t* active, int64_t cap
     if (c->n > 0) {
         hipLaunchKernelGGL((k_search<MODE_PAIRS>), dim3(search_blocks(c->atom_grid.d)), dim3(64 * SEARCH_WAVES), 0, c->stream,
                            c->atom_grid.d, c->atom_grid.start.p, c->s_xyzm.p, c->s_aux.p, radius * radius, 1, 0, c->pairs.p,
-                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr);
+                           (u64)cap, c->d_ctr + ctr_dev(C_SEARCH_PAIRS), c->d_ctr + ctr_dev(C_STAT_MCAND), c->d_ctr + ctr_dev(C_STAT_MACC), (uint8_t*)nullptr, GroupMasks{}, (const int*)nullptr, (const int*)nullptr);
         CHK(check_launch(c, "k_search<PAIRS>"));
     }
     CHK(read_counters(c));

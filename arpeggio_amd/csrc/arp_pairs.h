@@ -576,6 +576,9 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_atoms(CompactArgs A
         if (lane == 0)
             __hip_atomic_store(A.chain + b, chain_word(A.epoch, b == 0 ? CHAIN_PFX : CHAIN_AGG, (unsigned)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int base = 0;
+        // (all four windows of a 100 k-atom launch asked for at once — lane l looking at blocks hi - l, hi - 64 - l, ... with four loads
+        // in flight — changed nothing: base known at 5.6 us against 5.5 in the per-wave trace; what the look-back waits for is the
+        // slowest predecessor's aggregate, not its own round trips)
         for (int hi = b - 1; hi >= 0; hi -= 64) {       // 64 predecessors at a time, nearest first: lane l looks at block hi - l
             const int k = hi - lane;
             unsigned long long wd = chain_word(A.epoch, CHAIN_PFX, 0);      // (lanes before block 0: a zero prefix)
@@ -796,6 +799,26 @@ __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg
 // (developer builds, tools/search_trace.py: per block of k_search<MODE_CONTACTS> {start, end of the cell loops, end} in
 // s_memrealtime ticks (100 MHz), the XCD and the hardware id of the block's first wave — g_search_trace, declared above)
 
+// Runs of tiles of equal WEIGHT for the nb blocks of k_search (see there).  A cell weighs its atoms + cell_w16 / 16 (its set-up:
+// range bounds, claim, the loads of its records — a block of a face of the box, where cells are a third emptier, must not get
+// that many more cells for its atoms): blk_tile[b] = the tile of the cell where the running weight passes b / nb of the total
+// (binary search in the start table), blk_tile[nb] = ntile.
+__global__ __launch_bounds__(256) void k_balance_blocks(GridDesc g, const int* __restrict__ start, int nb, int tx, int cell_w16, int* __restrict__ blk_tile) {
+    const int ntx = (g.nx + tx - 1) / tx, ntile = ntx * g.ny * g.nz;
+    const long long T = 16ll * start[g.ncell] + (long long)cell_w16 * g.ncell;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nb; b += gridDim.x * blockDim.x) {
+        if (b == nb || start[g.ncell] <= 0) { blk_tile[b] = (b == 0) ? 0 : ntile; continue; }
+        const long long p = (long long)b * T / nb;
+        int lo = 0, hi = g.ncell;                 // the last cell c whose running weight (before it) is <= p
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (16ll * start[mid] + (long long)cell_w16 * mid <= p) lo = mid; else hi = mid;
+        }
+        const int row = lo / g.nx;
+        blk_tile[b] = (b == 0) ? 0 : row * ntx + (lo - row * g.nx) / tx;
+    }
+}
+
 // TX: x-adjacent home cells per tile (1 or 2; a template parameter: with one cell per tile the column rules below vanish at
 // compile time — as a run-time value they cost the small grids 3 us)
 template <int MODE, int TX = 1>
@@ -805,7 +828,8 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
                                                                int include_seq_adj, int count_owned, int2* __restrict__ pairs,
                                                                unsigned long long cap, u64* __restrict__ ctr_pairs,
                                                                u64* __restrict__ ctr_cand, u64* __restrict__ ctr_acc,
-                                                               uint8_t* __restrict__ plus, GroupMasks gm, const int* __restrict__ cell_of_pos) {
+                                                               uint8_t* __restrict__ plus, GroupMasks gm, const int* __restrict__ cell_of_pos,
+                                                               const int* __restrict__ blk_tile) {
     // ring / amide sets of _make_selection (I:1433-1437) from the residue tags the grid build of this pass left: every thread
     // of the launch takes at most a few (nothing to do when gm is empty)
 #if defined(ARP_SEARCH_TRACE) && !defined(ARP_SIFT_TRACE) && !defined(ARP_COMPACT_TRACE)
@@ -836,6 +860,13 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
     int c_end = min((vb + 1) * tiles_per_block, ntile);
     auto tile_of_cell = [&](int c) -> int { const int row = c / g.nx; return row * ntx + (c - row * g.nx) / TX; };
     int h_lo = 0, h_hi = INT_MAX;      // positions of the cell-sorted array whose atoms this block takes as HOME atoms
+    if (!cell_of_pos && blk_tile) {
+        // Dense grids: equal runs of CELLS give the blocks of the box's faces half the work of the others (a 26^3 grid whose last
+        // layers are two thirds full: 10 k ... 41 k tests per CU).  blk_tile holds runs of tiles with equal numbers of ATOMS, worked
+        // out once per grid from its start table (k_balance_blocks) — a hint: any partition of the tiles is a correct one.
+        blk_begin = min(max(blk_tile[vb], 0), ntile);
+        c_end = min(max(blk_tile[vb + 1], blk_begin), ntile);
+    }
     if (cell_of_pos) {
         // Sparse or clumped grids — a protein in its bounding box, the selection_plus of a ligand inside a large structure, a
         // batch with its gaps, a chain folded onto itself — put their atoms into a fraction of the cells, and equal runs of
