@@ -658,7 +658,7 @@ struct PublishArgs {
 // stores as well as loads and returns only when the store has left the CU (on gfx10+ stores have a counter of their own), so
 // "s_waitcnt vmcnt(0)" of every wave + the workgroup barrier is what a release of the counter stores amounts to, without the
 // L2 write-back a release FENCE of that scope performs.  The asm statements carry a "memory" clobber: the compiler keeps
-// the relaxed flag store behind them.  tools/pub_stress.py is the check on hardware.
+// the relaxed flag store behind them.  tests/test_gpu_publication.py (and tools/pub_stress.py) are the check on hardware.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "this library is built for gfx950 only: pass_end and the per-pair kernel rely on the gfx9 meaning of s_waitcnt vmcnt for stores, the sort kernels on 160 KB of LDS per CU, the per-pair kernel on global_load_lds_dwordx4"
 #endif
