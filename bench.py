@@ -73,14 +73,14 @@ def parse():
 def algorithmic_bytes(kernel, n_binned, ncell, n_pairs, n_h=0):
     """HBM bytes one launch moves AS IMPLEMENTED, the 8 B / pair intermediate list included.  n_h = explicit
     hydrogens of the structure (24-byte float64 coordinates, read by the hydrogen-geometry tests of k_sift)."""
-    if kernel == 'bin':         # k_compact_atoms: 68 B of static columns + the row's cell read, 80 B of records + the cell written, the cell table
-        return 72 * n_binned + 84 * n_binned + 4 * (ncell + 1)
+    if kernel == 'bin':         # k_compact_atoms: 52 B of static columns + the row's cell (twice: its own, its neighbour's) read, 52 B of records + h_off + the cell written, the cell table
+        return 60 * n_binned + 60 * n_binned + 4 * (ncell + 1)
     if kernel == 'search':      # read each sorted record once (xyzm 16 B + aux 16 B), the cell table, write the pair list
         return 32 * n_binned + 4 * (ncell + 1) + 8 * n_pairs
     if kernel == 'mark_search':  # same reads, writes one byte per marked atom
         return 32 * n_binned + 4 * (ncell + 1) + n_binned
-    if kernel == 'sift':        # pair list + each atom's 32-byte record and 16-byte bonded-neighbour quad once + its hydrogens + 15-byte output record
-        return 8 * n_pairs + 48 * n_binned + 24 * n_h + 15 * n_pairs
+    if kernel == 'sift':        # pair list + each atom's two 16-byte quads and h_off once + its hydrogens + 15-byte output record
+        return 8 * n_pairs + 36 * n_binned + 24 * n_h + 15 * n_pairs
     raise KeyError(kernel)
 
 
