@@ -277,6 +277,12 @@ struct arp_ctx {
     double sb_radius = 0.0;
     int sb_blocks = 0, sb_tx = 0;
     bool sb_whole = false;
+    // (the grid key of the last pass that ran WITHOUT a hint: the hint is worked out by the second such pass over one grid — a
+    // structure that is evaluated once, the usual case, never pays for it)
+    bool sb_seen = false;
+    uint64_t sb_seen_static_epoch = 0, sb_seen_sel_epoch = 0;
+    double sb_seen_radius = 0.0;
+    int sb_seen_blocks = 0, sb_seen_tx = 0;
     unsigned int compact_epoch = 0;
     bool static_dirty = true;
     // The contact grid of a WHOLE-STRUCTURE pass (every atom selected: selection_plus = all atoms, I:1395 / 1407) depends on the
@@ -297,6 +303,11 @@ struct arp_ctx {
     bool all_grid_current = false;  // all_grid matches the current inputs and selection
     hipStream_t stream2 = nullptr;  // ring / amide kernels run here, concurrently with the contact pipeline
     hipEvent_t ev_sel = nullptr, ev_planes = nullptr, ev_lists = nullptr;
+    // arp_set_blob: the centre grids and candidate lists of the new structure are made on the second stream, behind ev_upload (the
+    // validation kernel on the main one) and in front of ev_uplists; the main stream joins them before anything reads or replaces
+    // what they read or write (join_upload_lists)
+    hipEvent_t ev_upload = nullptr, ev_uplists = nullptr;
+    bool uplists_pending = false;
     DevBuf<uint8_t> tmp_u8;
     // ---- pair list and outputs of the atom-contact pass
     DevBuf<int2> pairs;
@@ -335,6 +346,7 @@ struct arp_ctx {
     DevBuf<u64> plist_count;       // [4]
     bool plist_count_cleared = false;   // k_point_grids has just zeroed them (same stream, same pass)
     bool lists_dirty = true;
+    bool lists_from_upload = false;   // the lists in place were made with the upload of the resident structure (validate_resident_blob): composing its static columns does not stale them
     long long plist_known[4] = {-1, -1, -1, -1};   // entries the lists held at the end of the last pass (-1: not known yet)
     DevBuf<uint8_t> blob_dev;      // device copy of the last arp_set_blob upload (the input arrays are views into it)
     int64_t blob_nbond = 0, blob_nh = 0, blob_nrad = 0;
@@ -520,7 +532,7 @@ int batch_grid_desc(arp_ctx* c, GridDesc& d, double radius) {
     if (!slot) {   // every slot holds another radius: start over (grids built with the old tables are rebuilt)
         for (auto& g : c->batch_grid) g.valid = false;
         slot = &c->batch_grid[0];
-        c->static_dirty = true; c->lists_dirty = true;
+        c->static_dirty = true; c->lists_from_upload = false; c->lists_dirty = true;
         c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
     }
     const int64_t B = c->batch_n;
@@ -655,6 +667,14 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
     return ARP_OK;
 }
 
+// The main stream waits for the grids / lists the last arp_set_blob left to the second stream (no-op when nothing is pending)
+int join_upload_lists(arp_ctx* c) {
+    if (!c->uplists_pending) return ARP_OK;
+    c->uplists_pending = false;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_uplists, 0));
+    return ARP_OK;
+}
+
 // Selection-independent part of every atom record (rebuilt only when an input changed) and its SPATIAL ORDER: the rows sorted
 // by cell of the grid with cell edge `radius` (counting sort, x fastest), which a pass with that cell edge compacts into its
 // contact grid in one launch (k_compact_atoms).  radius = 0: any order will do (the one that exists, 6 A when there is none).
@@ -664,7 +684,8 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
     if (!columns && c->sp_radius == radius) return ARP_OK;
     const int n = (int)c->n;
     if (columns) {
-        c->lists_dirty = true;
+        if (!c->lists_from_upload) c->lists_dirty = true;      // (lists made with the upload read what these columns are composed from)
+        c->lists_from_upload = false;
         c->contacts_expected = 0;
         HIPCHK(c, c->st_qa.reserve((size_t)std::max(n, 1)));
         HIPCHK(c, c->st_h.reserve((size_t)std::max(n, 1)));
@@ -1011,11 +1032,13 @@ void host_bbox_d(const double* xyz, int64_t n, double lo[3], double hi[3]) {
 }
 
 int ensure_ring_grid(arp_ctx* c) {
+    CHK(join_upload_lists(c));
     if (c->ring_grid.valid) return ARP_OK;
     PtsD3 pts{c->ring_c.p};
     return build_grid<PtsD3>(c, c->ring_grid, pts, (int)c->nring, c->ring_lo, c->ring_hi, 6.0, c->sid_ring.p);
 }
 int ensure_amide_grid(arp_ctx* c) {
+    CHK(join_upload_lists(c));
     if (c->amide_grid.valid) return ARP_OK;
     PtsF3 pts{c->am_c.p};
     return build_grid<PtsF3>(c, c->amide_grid, pts, (int)c->namide, c->am_lo, c->am_hi, 6.0, c->sid_amide.p);
@@ -1023,6 +1046,7 @@ int ensure_amide_grid(arp_ctx* c) {
 
 // both centre grids in one launch when they are small (k_point_grids); otherwise each by the general path
 int ensure_center_grids(arp_ctx* c) {
+    CHK(join_upload_lists(c));      // (whoever asks for the grids on the main stream reads them there)
     static const int deterministic = env_int("ARP_DETERMINISTIC", 0);
     const bool want_r = c->nring > 0 && !c->ring_grid.valid, want_a = c->namide > 0 && !c->amide_grid.valid;
     const int small_points = 16384;
@@ -1307,28 +1331,39 @@ PlaneLists plane_lists(arp_ctx* c) {
     return L;
 }
 int ensure_plane_lists(arp_ctx* c) {
+    CHK(join_upload_lists(c));
     if (!c->lists_dirty && c->plist_count.p) return ARP_OK;
     const size_t want[4] = {(size_t)c->nring * 96 + 256, (size_t)c->nring * 16 + 256, (size_t)c->namide * 16 + 256, (size_t)c->namide * 8 + 256};
     for (int k = 0; k < 4; ++k) HIPCHK(c, c->plist[k].reserve(want[k]));
     HIPCHK(c, c->plist_count.reserve(4));
     if (!c->plist_count_cleared) HIPCHK(c, hipMemsetAsync(c->plist_count.p, 0, 4 * sizeof(u64), c->stream));   // (else: k_point_grids did, on this stream)
     c->plist_count_cleared = false;
-    AtomPlaneArgs ap{};
+    AtomRingListArgs ar{};
     PlanePlaneArgs pp{};
     GroupGroupArgs gg{};
     GroupPlaneArgs gp{};
     int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    CHK(prepare_atom_plane(c, ap, n0));      // all-atom 6 A grid (built here if need be), ring / amide grids
-    CHK(prepare_plane_plane(c, pp, n1));
-    CHK(prepare_group_group(c, gg, n2));
-    CHK(prepare_group_plane(c, gp, n3));
+    {   // (argument blocks and bag buffers only: the counters of the output bags are the evaluation's affair — a pass clears them
+        // itself, and at upload time each would be a fill launch in front of the lists)
+        const bool was_clean = c->ctr_clean;
+        c->ctr_clean = true;
+        int rc = prepare_plane_plane(c, pp, n1);      // (ring / amide grids: built here if need be)
+        if (rc == ARP_OK) rc = prepare_group_group(c, gg, n2);
+        if (rc == ARP_OK) rc = prepare_group_plane(c, gp, n3);
+        c->ctr_clean = was_clean;
+        CHK(rc);
+    }
+    // atom-plane candidates atom by atom against the ring grid (ar_enumerate): the atoms as uploaded, no atom grid
+    if (c->nring > 0 && c->n > 0) {
+        ar = AtomRingListArgs{c->ring_grid.d, c->ring_grid.start.p, c->ring_grid.perm.p, (int)c->n, c->xyz.p, c->tmask.p, c->flags.p, c->ring_c.p};
+        n0 = nblocks(c->n, 256, 4096);
+    }
     // one wavefront per ring / amide: a stencil walk is a chain of dependent loads, and this kernel runs alone
-    if (n0) n0 = nblocks(c->nring * 64, 256, 4096);
     if (n1) n1 = nblocks(c->nring * 64, 256, 4096);
     if (n2) n2 = nblocks(c->namide * 64, 256, 4096);
     if (n3) n3 = nblocks(c->namide * 64, 256, 4096);
     if (n0 + n1 + n2 + n3 > 0) {
-        hipLaunchKernelGGL(k_plane_lists, dim3(n0 + n1 + n2 + n3), dim3(256), 0, c->stream, ap, pp, gg, gp, plane_lists(c), n0, n0 + n1,
+        hipLaunchKernelGGL(k_plane_lists, dim3(n0 + n1 + n2 + n3), dim3(256), 0, c->stream, ar, pp, gg, gp, plane_lists(c), n0, n0 + n1,
                            n0 + n1 + n2, n0 + n1 + n2 + n3);
         CHK(check_launch(c, "k_plane_lists"));
     }
@@ -1370,9 +1405,10 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                         all_res ? 1 : 0, c->ring_sel.p, c->ring_plus.p, c->am_sel.p, c->am_plus.p};
         if (c->n == 0) masks_after_bin = true;   // no scatter launch to carry them
     }
-    // A structure's first pass also builds the static candidate lists of its ring / amide loops — two centre grids, the 6 A atom
-    // grid, k_plane_lists: 67 us of small launches in a row at 100 k atoms — and nothing before the last launch of the pass
-    // reads them: they go on the second stream, beside the grid build and the search of this pass, and are enqueued AFTER the
+    // The static candidate lists of a structure's ring / amide loops — two centre grids, k_plane_lists — are made with its upload
+    // when it comes as a blob (arp_set_blob: on the second stream, behind the validation kernel, joined below).  Structures set up
+    // by the classic setters or assembled from shards build them in their first pass: nothing before the last launch of the pass
+    // reads them, so they go on the second stream, beside the grid build and the search of this pass, and are enqueued AFTER the
     // search (the host needs ~5 us per launch: enqueued first they held the main stream's kernels back by as much).
     // (The other way round — search on the second stream, lists on the main one, so that the last launch follows the longer
     // chain in stream order — was no faster: the search then shares the chip with the 1024-thread scan blocks of the lists.)
@@ -1456,14 +1492,24 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
                                c->d_ctr + ctr_dev(C_STAT_ACC), (uint8_t*)nullptr, masks_after_bin ? GroupMasks{} : gm,
                                by_atoms ? (const int*)c->s_cell.p : (const int*)nullptr, balance_hint);
         }
-        // the hint for the NEXT pass over this grid (same structure, selection, cutoff, launch shape): made behind the search, off
-        // every critical path; a first pass runs on equal runs of cells
+        // the hint for the LATER passes over this grid (same structure, selection, cutoff, launch shape), made behind the search of
+        // the SECOND pass over it: the launch sits between the search and the per-pair kernel of that pass (6 us + a gap: a tenth
+        // of a structure's first pass when it was made there), and a structure that is evaluated once never needs it.  First and
+        // second pass run on equal runs of cells.
         if (hint_mode && !by_atoms && !hint_ok && whole && nblocks_search >= 16) {
-            HIPCHK(c, c->sb_tile.reserve((size_t)nblocks_search + 1));
-            hipLaunchKernelGGL(k_balance_blocks, dim3(nblocks(nblocks_search + 1, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
-                               nblocks_search, tile_x, cell_w16, c->sb_tile.p);
-            c->sb_valid = true; c->sb_static_epoch = c->static_epoch; c->sb_sel_epoch = c->sel_epoch; c->sb_radius = cutoff;
-            c->sb_blocks = nblocks_search; c->sb_tx = tile_x; c->sb_whole = whole;
+            const bool seen = c->sb_seen && c->sb_seen_static_epoch == c->static_epoch && c->sb_seen_sel_epoch == c->sel_epoch &&
+                              c->sb_seen_radius == cutoff && c->sb_seen_blocks == nblocks_search && c->sb_seen_tx == tile_x;
+            static const int hint_eager = env_int("ARP_SEARCH_BALANCE_HINT_EAGER", 0);
+            if (seen || hint_eager) {
+                HIPCHK(c, c->sb_tile.reserve((size_t)nblocks_search + 1));
+                hipLaunchKernelGGL(k_balance_blocks, dim3(nblocks(nblocks_search + 1, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
+                                   nblocks_search, tile_x, cell_w16, c->sb_tile.p);
+                c->sb_valid = true; c->sb_static_epoch = c->static_epoch; c->sb_sel_epoch = c->sel_epoch; c->sb_radius = cutoff;
+                c->sb_blocks = nblocks_search; c->sb_tx = tile_x; c->sb_whole = whole;
+            } else {
+                c->sb_seen = true; c->sb_seen_static_epoch = c->static_epoch; c->sb_seen_sel_epoch = c->sel_epoch; c->sb_seen_radius = cutoff;
+                c->sb_seen_blocks = nblocks_search; c->sb_seen_tx = tile_x;
+            }
         }
         return check_launch(c, "k_search<CONTACTS>");
     };
@@ -1541,6 +1587,9 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         CHK(launch_search());
         HIPCHK(c, hipEventRecord(c->ev_lists, c->stream));              // (the masks are in place)
         CHK(launch_sift(false));
+        // (enqueued behind the two big launches: a list kernel that starts beside the search takes CU slots the search counts on —
+        // its blocks are all meant to be resident at once — and doubles it: 27 -> 54 us at 100 k atoms)
+        CHK(join_upload_lists(c));                 // (on the MAIN stream, before the two change places)
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
         std::swap(c->stream, c->stream2);
         int rc = ensure_center_grids(c);
@@ -1845,6 +1894,8 @@ int arp_create(int device, arp_ctx** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_planes, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_lists, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_uplists, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_ctr, sizeof(u64) * C_DEV_WORDS);
     if (e == hipSuccess) e = hipMemset(c->d_ctr, 0, sizeof(u64) * C_DEV_WORDS);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_ctr_pinned, sizeof(u64) * (C_COUNT + 1), hipHostMallocDefault);
@@ -1891,6 +1942,8 @@ void arp_destroy(arp_ctx* c) {
     if (c->ev_sel) (void)hipEventDestroy(c->ev_sel);
     if (c->ev_planes) (void)hipEventDestroy(c->ev_planes);
     if (c->ev_lists) (void)hipEventDestroy(c->ev_lists);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
+    if (c->ev_uplists) (void)hipEventDestroy(c->ev_uplists);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1902,6 +1955,7 @@ const char* arp_last_error(arp_ctx* c) { return c ? c->err.c_str() : g_create_er
 int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, const double* cov, const uint16_t* type_mask,
                   const uint16_t* flags, const int32_t* res_id) {
     if (!c) return ARP_E_ARG;
+    CHK(join_upload_lists(c));
     if (n < 0 || n > 0x7FFFFFF0LL) FAIL(c, ARP_E_ARG, "arp_set_atoms: n out of range");
     if (n > 0 && (!xyz || !vdw || !cov || !type_mask || !flags || !res_id)) FAIL(c, ARP_E_ARG, "arp_set_atoms: null input");
     // the grids are sized from the bounding box: a NaN / inf coordinate has no cell
@@ -1918,7 +1972,7 @@ int arp_set_atoms(arp_ctx* c, int64_t n, const float* xyz, const double* vdw, co
     HIPCHK(c, hipSetDevice(c->device));
     // uploads below are enqueued together; whatever the exit path, they are complete before the staging vectors die
     struct SyncOnExit { arp_ctx* c; ~SyncOnExit() { (void)hipStreamSynchronize(c->stream); } } sync_on_exit{c};
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     c->n = n;
     c->h_xyz.assign(xyz, xyz + 3 * n);
     host_bbox(xyz, n, c->lo, c->hi);
@@ -1988,7 +2042,7 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
     if (nres < 0 || (nres > 0 && (!res_flags || !prev || !next))) FAIL(c, ARP_E_ARG, "arp_set_residues: bad input");
     if (nres <= c->max_res_id) FAIL(c, ARP_E_ARG, "arp_set_residues: an atom refers to a residue beyond the table");
     HIPCHK(c, hipSetDevice(c->device));
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     c->nres = nres;
     CHK(upload(c, c->res_flags, res_flags, (size_t)nres));
     CHK(upload(c, c->res_prev, prev, (size_t)nres));
@@ -2004,7 +2058,7 @@ int arp_set_residues(arp_ctx* c, int64_t nres, const uint8_t* res_flags, const i
 int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) {
     if (!c || !bond_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     if (!csr_ok(bond_off, c->n)) FAIL(c, ARP_E_ARG, "arp_set_bonds: offsets must start at 0 and never decrease");
     const int64_t m = bond_off[c->n];
     if (m < 0 || (m > 0 && !bond_idx)) FAIL(c, ARP_E_ARG, "arp_set_bonds: bad CSR");
@@ -2017,7 +2071,7 @@ int arp_set_bonds(arp_ctx* c, const int32_t* bond_off, const int32_t* bond_idx) 
 int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
     if (!c || !h_off) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     if (!csr_ok(h_off, c->n)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: offsets must start at 0 and never decrease");
     const int64_t m = h_off[c->n];
     if (m < 0 || (m > 0 && !h_xyz)) FAIL(c, ARP_E_ARG, "arp_set_hydrogens: bad CSR");
@@ -2030,7 +2084,7 @@ int arp_set_hydrogens(arp_ctx* c, const int32_t* h_off, const double* h_xyz) {
 int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
     if (!c || (c->n > 0 && !sb_nbr)) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     for (int64_t i = 0; i < c->n; ++i)
         if (sb_nbr[i] < -1 || sb_nbr[i] >= c->n) FAIL(c, ARP_E_ARG, "arp_set_single_bond_neighbours: index out of range");
     // the neighbour's coordinates are gathered on the device from the uploaded atoms (x, y, z, 1) / (0, 0, 0, 0)
@@ -2047,6 +2101,7 @@ int arp_set_single_bond_neighbours(arp_ctx* c, const int32_t* sb_nbr) {
 
 int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double* normal, const int32_t* ring_res) {
     if (!c) return ARP_E_ARG;
+    CHK(join_upload_lists(c));
     if (nring < 0 || (nring > 0 && (!center || !normal || !ring_res))) FAIL(c, ARP_E_ARG, "arp_set_rings: bad input");
     if (!all_finite(center, 3 * nring)) FAIL(c, ARP_E_ARG, "arp_set_rings: non-finite ring centre");   // (normals may be NaN: class '')
     c->max_ring_res = -1;
@@ -2056,7 +2111,7 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
     }
     HIPCHK(c, hipSetDevice(c->device));
     batch_reset(c);      // (the partition of a batch was declared for the arrays that were resident then: arp_set_batch again after this call)
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     c->nring = nring;
     host_bbox_d(center, nring, c->ring_lo, c->ring_hi);
     CHK(upload(c, c->ring_c, center, (size_t)nring * 3));
@@ -2072,6 +2127,7 @@ int arp_set_rings(arp_ctx* c, int64_t nring, const double* center, const double*
 
 int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float* normal, const int32_t* amide_res) {
     if (!c) return ARP_E_ARG;
+    CHK(join_upload_lists(c));
     if (namide < 0 || (namide > 0 && (!center || !normal || !amide_res))) FAIL(c, ARP_E_ARG, "arp_set_amides: bad input");
     if (!all_finite(center, 3 * namide)) FAIL(c, ARP_E_ARG, "arp_set_amides: non-finite amide centre");
     c->max_amide_res = -1;
@@ -2081,7 +2137,7 @@ int arp_set_amides(arp_ctx* c, int64_t namide, const float* center, const float*
     }
     HIPCHK(c, hipSetDevice(c->device));
     batch_reset(c);      // (the partition of a batch was declared for the arrays that were resident then: arp_set_batch again after this call)
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     c->namide = namide;
     host_bbox(center, namide, c->am_lo, c->am_hi);
     CHK(upload(c, c->am_c, center, (size_t)namide * 3));
@@ -2341,6 +2397,36 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     if (polled) { pub.expected = 1; pub.seq = ++c->publish_seq; }
     hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256, 2048)), dim3(256), 0, c->stream, bc, pub);
     CHK(check_launch(c, "k_validate_blob"));
+    // The 6 A grids of the ring and amide centres depend on the uploaded centres and their boxes only: they are built behind the
+    // validation kernel, while the host waits for its verdict and turns round (one launch for both; a structure that fails the
+    // validation has its grids thrown away below: centres outside their box are clamped into it, nothing is written out of bounds).
+    static const int grids_with_upload = env_int("ARP_GRIDS_WITH_UPLOAD", 1);
+    bool grids_made = false;
+    if (grids_with_upload && polled && h.n > 0 && h.nring + h.namide > 0) {
+        c->ring_grid.valid = false; c->amide_grid.valid = false;
+        c->lists_dirty = true;
+        batch_reset(c);
+        // ... on the SECOND stream (ARP_UPLOAD_ASIDE=0: behind the validation kernel on the main one, where the static order of the
+        // first pass then waits for them: 25 us of latency chains at 100 k atoms), joined by the first pass in front of its grid build
+        static const int aside = env_int("ARP_UPLOAD_ASIDE", 1);
+        const bool on_second = aside && c->stream2 && c->ev_upload && c->ev_uplists;
+        if (on_second) {
+            HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_upload, 0));
+            std::swap(c->stream, c->stream2);
+        }
+        int rc = ensure_center_grids(c);
+        static const int lists_with_upload = env_int("ARP_LISTS_WITH_UPLOAD", 1);
+        if (rc == ARP_OK && lists_with_upload) rc = ensure_plane_lists(c);      // (the four candidate lists need nothing else: see ar_enumerate)
+        if (on_second) {
+            std::swap(c->stream, c->stream2);
+            if (rc == ARP_OK) { HIPCHK(c, hipEventRecord(c->ev_uplists, c->stream2)); c->uplists_pending = true; }
+        }
+        CHK(rc);
+        grids_made = true;
+    }
+    const bool ring_grid_made = grids_made && c->ring_grid.valid, amide_grid_made = grids_made && c->amide_grid.valid;
+    const bool lists_made = grids_made && !c->lists_dirty;
     int h_err[2] = {0, 0};
     if (polled) {
         CHK(collect_counters(c));
@@ -2356,7 +2442,8 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     HIPCHK(c, c->ring_sel.reserve((size_t)std::max<int64_t>(h.nring, 1))); HIPCHK(c, c->ring_plus.reserve((size_t)std::max<int64_t>(h.nring, 1)));
     HIPCHK(c, c->am_sel.reserve((size_t)std::max<int64_t>(h.namide, 1))); HIPCHK(c, c->am_plus.reserve((size_t)std::max<int64_t>(h.namide, 1)));
     c->static_dirty = true;
-    c->lists_dirty = true;
+    c->lists_dirty = !lists_made;
+    c->lists_from_upload = lists_made;
     c->has_gid = c->has_home = c->has_group_owner = false;
     c->gid_max = -1;
     c->shard_resident = false;
@@ -2364,7 +2451,9 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
     c->sel_prefilled = true; c->sp_cnt_zeroed = zero_ints;      // (k_validate_blob's fills)
     c->contacts_valid = false;
-    c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
+    c->atom_grid.valid = false; c->all_grid_current = false;
+    const bool verdict_ok = h_err[0] == 0 && h_err[1] == 0;
+    c->ring_grid.valid = verdict_ok && ring_grid_made; c->amide_grid.valid = verdict_ok && amide_grid_made;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
     if (h_err[0] != 0 || h_err[1] != 0) {
         c->n = c->nres = c->nring = c->namide = 0;   // nothing usable is resident
@@ -2380,6 +2469,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
 
 int arp_set_blob(arp_ctx* c, const void* blob, uint64_t bytes) {
     if (!c || !blob || bytes < sizeof(arp_blob_header)) return ARP_E_ARG;
+    CHK(join_upload_lists(c));
     arp_blob_header h;
     memcpy(&h, blob, sizeof(h));
     CHK(check_blob_header(c, h, bytes));
@@ -2640,6 +2730,7 @@ int arp_shard_pack_face(arp_ctx* c, int slot, double x_lo, double x_hi, uint64_t
 int arp_shard_assemble(arp_ctx* c, uint64_t dev_left, uint64_t bytes_left, uint64_t dev_right, uint64_t bytes_right, int64_t nres_global,
                        int64_t counts[3]) {
     if (!c || nres_global < 0) return ARP_E_ARG;
+    CHK(join_upload_lists(c));
     if (!c->has_rec_home) FAIL(c, ARP_E_ARG, "arp_shard_assemble: call arp_shard_set_home first");
     HIPCHK(c, hipSetDevice(c->device));
     batch_reset(c);      // (a shard is one structure)
@@ -2772,7 +2863,7 @@ int arp_set_ownership(arp_ctx* c, const uint8_t* is_home, const int32_t* global_
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     batch_reset(c);      // (the partition of a batch was declared for the arrays that were resident then: arp_set_batch again after this call)
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     if (is_home) { CHK(upload(c, c->home, is_home, (size_t)c->n)); c->has_home = true; }
     else c->has_home = false;
     if (global_id) {
@@ -2794,7 +2885,7 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
     if (!c) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     batch_reset(c);      // (a shard is one structure)
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     if (!ring_home && !ring_gid && !amide_home && !amide_gid) { c->has_group_owner = false; return ARP_OK; }
     if ((c->nring > 0 && (!ring_home || !ring_gid)) || (c->namide > 0 && (!amide_home || !amide_gid)))
         FAIL(c, ARP_E_ARG, "arp_set_group_ownership: all four arrays are required");
@@ -2811,7 +2902,7 @@ int arp_set_group_ownership(arp_ctx* c, const uint8_t* ring_home, const int32_t*
 int arp_set_single_bond_neighbour_coords(arp_ctx* c, const float* sb_xyz, const uint8_t* sb_present) {
     if (!c || (c->n > 0 && (!sb_xyz || !sb_present))) return ARP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     std::vector<float4> sb((size_t)c->n);
     for (int64_t i = 0; i < c->n; ++i)
         sb[i] = sb_present[i] ? make_float4(sb_xyz[3 * i], sb_xyz[3 * i + 1], sb_xyz[3 * i + 2], 1.0f) : make_float4(0, 0, 0, 0);
@@ -2827,7 +2918,7 @@ int arp_set_selection_state(arp_ctx* c, const uint8_t* in_selection, const uint8
         (c->namide > 0 && (!amide_sel || !amide_plus)))
         FAIL(c, ARP_E_ARG, "arp_set_selection_state: null input");
     HIPCHK(c, hipSetDevice(c->device));
-    c->static_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false;
     CHK(upload(c, c->sel, in_selection, (size_t)c->n));
     CHK(upload(c, c->plus, in_plus, (size_t)c->n));
     c->sel_uploaded = true;
@@ -3704,9 +3795,10 @@ int arp_host_free(void* p) {
 int arp_set_batch(arp_ctx* c, int64_t nstruct, const int64_t* atom_off, const int64_t* ring_off, const int64_t* amide_off,
                   const double* boxes) {
     if (!c) return ARP_E_ARG;
+    CHK(join_upload_lists(c));
     if (nstruct == 0) {   // back to one structure
         batch_reset(c);
-        c->static_dirty = true; c->lists_dirty = true;
+        c->static_dirty = true; c->lists_from_upload = false; c->lists_dirty = true;
         c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
         return ARP_OK;
     }
@@ -3749,7 +3841,7 @@ int arp_set_batch(arp_ctx* c, int64_t nstruct, const int64_t* atom_off, const in
         CHK(check_launch(c, "k_fill_sid"));
     }
     c->batch_n = nstruct;
-    c->static_dirty = true; c->lists_dirty = true;
+    c->static_dirty = true; c->lists_from_upload = false; c->lists_dirty = true;
     c->contacts_valid = false;
     c->atom_grid.valid = false; c->all_grid_current = false; c->ring_grid.valid = false; c->amide_grid.valid = false;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;

@@ -156,33 +156,7 @@ struct StaticAtoms {
 // (positive floats order like their bit patterns).
 // out[1] = the longest distance between an atom and one of its hydrogens (same rounding up): a hydrogen of D is no nearer to A
 // than |D - A| minus this, which lets k_sift leave the hydrogen loops of far pairs alone.
-__device__ __forceinline__ void longest_bond_body(int n, const float4* __restrict__ xyz, const int* __restrict__ bond_off,
-                                                  const int* __restrict__ bond_idx, const int* __restrict__ h_off,
-                                                  const double* __restrict__ h_xyz, unsigned int* __restrict__ out) {
-    float m = 0.0f, mh = 0.0f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 a = xyz[i];
-        for (int k = bond_off[i], k1 = bond_off[i + 1]; k < k1; ++k) {
-            const float4 b = xyz[bond_idx[k]];
-            const double dx = (double)a.x - b.x, dy = (double)a.y - b.y, dz = (double)a.z - b.z;
-            m = fmaxf(m, (float)(sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-6)));
-        }
-        for (int k = h_off[i], k1 = h_off[i + 1]; k < k1; ++k) {
-            const double dx = (double)a.x - h_xyz[3 * (size_t)k], dy = (double)a.y - h_xyz[3 * (size_t)k + 1], dz = (double)a.z - h_xyz[3 * (size_t)k + 2];
-            mh = fmaxf(mh, (float)(sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-6)));
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); mh = fmaxf(mh, __shfl_xor(mh, o)); }
-    __shared__ float s_m[4], s_mh[4];   // one atomic per block: same-address atomics run at ~90 per microsecond
-    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_mh[threadIdx.x >> 6] = mh; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-        mh = fmaxf(fmaxf(s_mh[0], s_mh[1]), fmaxf(s_mh[2], s_mh[3]));
-        if (m > 0.0f) atomicMax(out, __float_as_uint(m));
-        if (mh > 0.0f) atomicMax(out + 1, __float_as_uint(mh));
-    }
-}
+// (computed by k_prepare_static, below, on its one walk over the bonds)
 
 // What the classic setters check on the host (arp_set_atoms ...), for structures that arrive as one blob: done on the
 // device (the arrays are already there), result in *err (0 / ARP_E_ARG) which arp_set_blob waits for.
@@ -225,36 +199,69 @@ __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float
                                                         int4* __restrict__ st_qa, int* __restrict__ st_h, GridDesc g6, int* __restrict__ cnt6,
                                                         int2* __restrict__ cr6, const double* __restrict__ h_xyz, unsigned int* __restrict__ longest) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
-    longest_bond_body(n, r.xyz, r.bond_off, r.bond_idx, r.h_off, h_xyz, longest);
+    // One walk over an atom's bonds serves both the longest bond (float32 distance, rounded up a little) and the neighbours in other
+    // residues, and it goes FOUR bonds at a time: index -> {coordinates, residue} is a chain of dependent loads per bond, and with
+    // 1.5 waves per SIMD at 100 k atoms nothing hides it (21 us when the two loops walked the list one bond after the other).
+    float lm = 0.0f, lmh = 0.0f;
     for (int i = gtid; i < n; i += gstride) {
         float4 v = r.xyz[i];
         const int res = r.res_id[i];
+        const int b0 = r.bond_off[i], b1 = r.bond_off[i + 1];
+        const int h0 = r.h_off[i], h1 = r.h_off[i + 1];
+        const float4 sb = r.sb[i];
         uint32_t m = (uint32_t)(r.tmask[i] & M_TMASK) | ((uint32_t)(r.flags[i] & 0x7F) << M_FLAG_SHIFT);
         if (!r.home || r.home[i]) m |= M_HOME;
         const uint8_t rf = r.res_flags ? r.res_flags[res] : 0;
         if (rf & ARP_R_POLYPEPTIDE) m |= M_RES_POLY;
         if (rf & ARP_R_HAS_SEQ) m |= M_RES_HASSEQ;
-        const float4 sb = r.sb[i];
         if (sb.w != 0.0f) m |= M_HAS_SB;
         m |= min((uint32_t)r.rad_idx[i], M_RAD4_ESC) << M_RAD4_SHIFT;
-        const int nh = r.h_off[i + 1] - r.h_off[i];
+        const int nh = h1 - h0;
         if (nh > 0) m |= M_HAS_H | (min((uint32_t)(nh - 1), M_HCNT_ESC) << M_HCNT_SHIFT);
-        v.w = __uint_as_float(m);
+        const int c6 = cell_index(g6, num::d3{(double)v.x, (double)v.y, (double)v.z}, g6.place ? g6.sid_atom[i] : 0);
+        const int rank = atomicAdd(&cnt6[c6], 1);      // (asked for early: the answer travels while the bonds are walked)
         // the bonded neighbours in OTHER residues beside the record (-1: none; w = -2: more than three, walk the CSR list)
         int4 qa = make_int4(i, -1, -1, -1);
         int k = 0;
-        for (int b = r.bond_off[i], b1 = r.bond_off[i + 1]; b < b1; ++b) {
-            const int nb = r.bond_idx[b];
-            if (r.res_id[nb] == res) continue;
-            if (k == 0) qa.y = nb; else if (k == 1) qa.z = nb; else if (k == 2) qa.w = nb; else qa.w = -2;
-            ++k;
+        for (int b = b0; b < b1; b += 4) {
+            int nb[4];
+            float4 w[4];
+            int rr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nb[q] = r.bond_idx[min(b + q, b1 - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { w[q] = r.xyz[nb[q]]; rr[q] = r.res_id[nb[q]]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (b + q >= b1) continue;
+                const double dx = (double)v.x - w[q].x, dy = (double)v.y - w[q].y, dz = (double)v.z - w[q].z;
+                lm = fmaxf(lm, (float)(sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-6)));
+                if (rr[q] == res) continue;
+                if (k == 0) qa.y = nb[q]; else if (k == 1) qa.z = nb[q]; else if (k == 2) qa.w = nb[q]; else qa.w = -2;
+                ++k;
+            }
         }
+        for (int h = h0; h < h1; ++h) {
+            const double dx = (double)v.x - h_xyz[3 * (size_t)h], dy = (double)v.y - h_xyz[3 * (size_t)h + 1], dz = (double)v.z - h_xyz[3 * (size_t)h + 2];
+            lmh = fmaxf(lmh, (float)(sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-6)));
+        }
+        v.w = __uint_as_float(m);
         st_xyzm[i] = v;
         st_qa[i] = qa;
-        st_h[i] = r.h_off[i];
+        st_h[i] = h0;
         st_aux[i] = make_int4(i, res, r.res_prev ? r.res_prev[res] : -1, r.res_next ? r.res_next[res] : -1);
-        const int c6 = cell_index(g6, num::d3{(double)v.x, (double)v.y, (double)v.z}, g6.place ? g6.sid_atom[i] : 0);
-        cr6[i] = make_int2(c6, atomicAdd(&cnt6[c6], 1));
+        cr6[i] = make_int2(c6, rank);
+    }
+    // longest bond / atom - hydrogen distance of the structure: one atomicMax per block
+    for (int o = 32; o > 0; o >>= 1) { lm = fmaxf(lm, __shfl_xor(lm, o)); lmh = fmaxf(lmh, __shfl_xor(lmh, o)); }
+    __shared__ float s_m[4], s_mh[4];
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = lm; s_mh[threadIdx.x >> 6] = lmh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lm = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        lmh = fmaxf(fmaxf(s_mh[0], s_mh[1]), fmaxf(s_mh[2], s_mh[3]));
+        if (lm > 0.0f) atomicMax(longest, __float_as_uint(lm));
+        if (lmh > 0.0f) atomicMax(longest + 1, __float_as_uint(lmh));
     }
 }
 

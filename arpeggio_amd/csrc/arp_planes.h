@@ -495,6 +495,60 @@ __device__ __forceinline__ void ap_enumerate_cg(const AtomPlaneArgs& A, int r, i
         }
     }
 }
+// The static candidate list of the atom-plane loop, ATOM by atom: every lane takes one atom of the structure — as uploaded, by
+// local id: no atom grid, no spatial order of the atoms is needed — and walks the 27-cell stencil of the 6 A grid of ring CENTRES
+// around it (I:960 is symmetric in the two points).  What it reads exists as soon as the structure and the centre grids do, so the
+// list is made with the upload, not by the first pass; a structure with few rings costs its atoms nine pairs of start-table words.
+// The wave walks its 64 stencils together: row by row, entry t of every lane's row at once (the sink is a wave-wide affair).
+struct AtomRingListArgs {
+    GridDesc g;                 // 6 A grid of the ring centres
+    const int* start;
+    const int* perm;
+    int n;                      // atoms
+    const float4* xyz;          // by local id, w unused
+    const uint16_t* tmask;
+    const uint16_t* flags;
+    const double* ring_c;
+};
+template <class Sink>
+__device__ __forceinline__ void ar_enumerate(const AtomRingListArgs& A, int i, int lane, Sink sink) {
+    const bool have = i < A.n;
+    const float4 v = have ? A.xyz[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t m = have ? ((uint32_t)(A.tmask[i] & M_TMASK) | ((uint32_t)(A.flags[i] & 0x7F) << M_FLAG_SHIFT)) : M_HYDROGEN;
+    const bool cand = have && !(m & (M_HYDROGEN | ARP_T_AROMATIC));       // I:964 hydrogens, I:975 aromatic atoms
+    if (!__any(cand)) return;
+    const GridDesc g = A.g;
+    const num::d3 p = {(double)v.x, (double)v.y, (double)v.z};
+    const CellBox cb = cand ? cell_box(g, p, g.place ? g.sid_atom[i] : 0) : CellBox{0, 0, 0};
+    const int xlo = max(cb.cx - 1, 0), xhi = min(cb.cx + 1, g.nx - 1);
+    // the bounds of the nine rows in ONE load round (eighteen loads in flight), then the rows one after the other
+    int js[9], len[9];
+#pragma unroll
+    for (int row = 0; row < 9; ++row) {
+        const int y2 = cb.cy + (row % 3) - 1, z2 = cb.cz + (row / 3) - 1;
+        const bool in = cand && y2 >= 0 && y2 < g.ny && z2 >= 0 && z2 < g.nz && xlo <= xhi;
+        const int rowbase = in ? (z2 * g.ny + y2) * g.nx : 0;
+        const int a = A.start[rowbase + (in ? xlo : 0)], b = A.start[rowbase + (in ? xhi + 1 : 0)];
+        js[row] = a;
+        len[row] = b - a;
+    }
+    int total = 0;
+#pragma unroll
+    for (int row = 0; row < 9; ++row) total += len[row];
+    if (!__any(total > 0)) return;
+#pragma unroll
+    for (int row = 0; row < 9; ++row) {
+        for (int t = 0; __any(t < len[row]); ++t) {
+            bool ok = false;
+            int r = 0;
+            if (t < len[row]) {
+                r = A.perm[js[row] + t];
+                ok = num::dist2_kd(ld3(A.ring_c, r), p) <= 36.0;      // I:960 tree membership (float64, inclusive)
+            }
+            sink(ok, r, i);
+        }
+    }
+}
 template <bool DYNAMIC, class Sink>
 __device__ __forceinline__ void pp_enumerate(const PlanePlaneArgs& A, int a, int lane, Sink sink) {
     if (DYNAMIC && (!A.ring_plus[a] || (A.ring_home && !A.ring_home[a]))) return;   // I:1081; multi-GPU: owner of the lower ring id emits
@@ -677,8 +731,8 @@ __device__ __forceinline__ void flush_list(const PlaneLists& L, int k, ListQueue
         if (g < L.cap[k]) L.pairs[k][g] = Q->q[i];
     }
 }
-// blocks [0, nb0) rings -> atom-plane list, [nb0, nb1) rings -> plane-plane, [nb1, nb2) amides -> group-group, rest -> group-plane
-__global__ __launch_bounds__(256) void k_plane_lists(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp,
+// blocks [0, nb0) atoms -> atom-plane list, [nb0, nb1) rings -> plane-plane, [nb1, nb2) amides -> group-group, rest -> group-plane
+__global__ __launch_bounds__(256) void k_plane_lists(AtomRingListArgs ar, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp,
                                                      PlaneLists L, int nb0, int nb1, int nb2, int nb3) {
     __shared__ ListQueue s_lq;
     if (threadIdx.x == 0) { s_lq.n = 0; s_lq.cut = LIST_QCAP; }
@@ -688,9 +742,7 @@ __global__ __launch_bounds__(256) void k_plane_lists(AtomPlaneArgs ap, PlanePlan
     if (b < nb0) {
         kind = 0;
         const int wave = (b * 256 + (int)threadIdx.x) >> 6, nwave = nb0 * 4;
-        // the list holds local atom ids: translate the sorted position
-        auto sink = [&](bool ok, int r, int j) { ListSink{L, 0, lane, &s_lq}(ok, r, ok ? ap.s_aux[j].x : 0); };
-        for (int r = wave; r < ap.nring; r += nwave) ap_enumerate<false>(ap, r, lane, sink);
+        for (int i0 = wave * 64; i0 < ar.n; i0 += nwave * 64) ar_enumerate(ar, i0 + lane, lane, ListSink{L, 0, lane, &s_lq});     // {ring, local atom id}
     } else if (b < nb1) {
         kind = 1;
         const int wave = ((b - nb0) * 256 + (int)threadIdx.x) >> 6, nwave = (nb1 - nb0) * 4;
