@@ -429,6 +429,69 @@ def test_blob_upload_equals_classic_upload_and_rejects_bad_input():
     a.close(); b.close()
 
 
+def _five_bags(ctx, counts):
+    out = {'atom_atom': ctx.atom_contacts_fetch(counts['atom_atom'])}
+    for bag in ('plane_plane', 'atom_plane', 'group_group', 'group_plane'):
+        out[bag] = ctx.fetch_bag(bag)
+    return out
+
+
+def _same_bags(x, y, what):
+    for bag in x:
+        for k in x[bag]:
+            assert np.array_equal(x[bag][k], y[bag][k], equal_nan=(x[bag][k].dtype.kind == 'f')), (what, bag, k)
+
+
+@pytest.mark.gpu
+def test_lists_made_with_the_upload_survive_whatever_follows_the_upload():
+    """arp_set_blob builds the centre grids and the ring / amide candidate lists of the new structure on the second stream while the
+    host waits for the validation (the atom-plane list atom by atom against the ring grid).  Whatever the caller does next — another
+    upload before any pass, classic setters on top of the blob, a batch declared over it, a partial selection — the five bags are
+    those of a context set up by the classic setters (whose lists are built inside its first pass)."""
+    import dataclasses
+    from arpeggio_amd import _capi, batch, synth
+    rich = synth.make_synthetic(6000, seed=21, box=(60.0, 60.0, 60.0), n_rings=1500, n_amides=1500, id='rich')     # rings every few angstroms
+    plain = synth.config3(20_000, seed=22)
+    prot = synth.proteinlike(n_res=80, n_waters=40, seed=23)
+    a, b = _capi.Context(0), _capi.Context(0)
+    # 1. one upload after the other, the first one never evaluated: its lists are abandoned half-way
+    for first, second in ((plain, rich), (rich, prot), (prot, plain)):
+        b.set_blob(_capi.pack_blob(first))
+        b.set_blob(_capi.pack_blob(second))
+        a.set_complex(second)
+        ca, cb = a.run_launch(5.0, 0.1, False, 6.0), b.run_launch(5.0, 0.1, False, 6.0)
+        assert ca == cb, (first.id, second.id)
+        _same_bags(_five_bags(a, ca), _five_bags(b, cb), second.id)
+    # 2. classic setters on top of a blob: new rings and amides (the same atoms) stale the lists of the upload
+    b.set_blob(_capi.pack_blob(rich))
+    moved = dataclasses.replace(rich, ring_center=rich.ring_center[::-1].copy(), ring_normal=rich.ring_normal[::-1].copy(), ring_res=rich.ring_res[::-1].copy(),
+                                amide_center=(rich.amide_center + np.float32(0.75)).astype(np.float32))
+    b._check(b._L.arp_set_rings(b._h, moved.n_rings, _capi._p(moved.ring_center), _capi._p(moved.ring_normal), _capi._p(moved.ring_res)), 'arp_set_rings')
+    b._check(b._L.arp_set_amides(b._h, moved.n_amides, _capi._p(moved.amide_center), _capi._p(moved.amide_normal), _capi._p(moved.amide_res)), 'arp_set_amides')
+    b._keep = (b._keep, moved)
+    a.set_complex(moved)
+    ca, cb = a.run_launch(5.0, 0.1, False, 6.0), b.run_launch(5.0, 0.1, False, 6.0)
+    assert ca == cb and ca['plane_plane'] > 0 and ca['atom_plane'] > 0 and ca['group_group'] > 0 and ca['group_plane'] > 0
+    _same_bags(_five_bags(a, ca), _five_bags(b, cb), 'classic rings on a blob')
+    # 3. a partial selection and other parameters over lists that came with the upload (they hold every candidate, the pass filters)
+    b.set_blob(_capi.pack_blob(rich)); a.set_complex(rich)
+    sel = (rich.res_id % 3 == 0).astype(np.uint8)
+    a.set_selection(sel); b.set_selection(sel)
+    for cutoff, comp in ((5.0, 0.1), (4.0, 0.3), (6.5, 0.0)):
+        ca, cb = a.run_launch(cutoff, comp, False, 6.0), b.run_launch(cutoff, comp, False, 6.0)
+        assert ca == cb, (cutoff, comp)
+        _same_bags(_five_bags(a, ca), _five_bags(b, cb), ('selection', cutoff))
+    # 4. a batch declared over an uploaded concatenation: the grids of the upload are thrown away, the structures keep apart
+    pcs = [synth.make_synthetic(1500, seed=30 + k, box=(40.0, 40.0, 40.0), n_rings=200, n_amides=200, id='b%d' % k) for k in range(3)]
+    big, off = batch.concat_complexes(pcs)
+    b.set_blob(_capi.pack_blob(big)); b.declare_batch(off)
+    a.set_batch(pcs)
+    ca, cb = a.run_launch(5.0, 0.1, False, 6.0), b.run_launch(5.0, 0.1, False, 6.0)
+    assert ca == cb and ca['plane_plane'] > 0
+    _same_bags(_five_bags(a, ca), _five_bags(b, cb), 'batch')
+    a.close(); b.close()
+
+
 def test_enqueue_and_wait_keep_several_contexts_busy_from_one_thread():
     """arp_run_enqueue / arp_run_wait: the pass of run_launch in two calls; three contexts driven round-robin by one thread give
     what three run_launch calls give, an enqueue without its wait (or a wait without an enqueue) is refused."""
