@@ -308,6 +308,7 @@ struct arp_ctx {
     // what they read or write (join_upload_lists)
     hipEvent_t ev_upload = nullptr, ev_uplists = nullptr;
     bool uplists_pending = false;
+    bool uplists_defer = false;       // inside enqueue_contacts: see join_upload_lists
     DevBuf<uint8_t> tmp_u8;
     // ---- pair list and outputs of the atom-contact pass
     DevBuf<int2> pairs;
@@ -668,8 +669,14 @@ int build_grid(arp_ctx* c, Grid& G, P pts, int n, const double lo[3], const doub
 }
 
 // The main stream waits for the grids / lists the last arp_set_blob left to the second stream (no-op when nothing is pending)
-int join_upload_lists(arp_ctx* c) {
+// (Inside a pass — uplists_defer — the callers that only prepare arguments ask without waiting: the one reader of the lists is the
+// last launch of the pass, enqueue_contacts joins in front of it, and by then the event has usually fired: no wait on the stream,
+// which would cost the main stream ~6 us between two of its kernels.)
+int join_upload_lists(arp_ctx* c, bool must = false) {
     if (!c->uplists_pending) return ARP_OK;
+    if (hipEventQuery(c->ev_uplists) == hipSuccess) { c->uplists_pending = false; return ARP_OK; }
+    (void)hipGetLastError();      // (hipErrorNotReady is not an error)
+    if (c->uplists_defer && !must) return ARP_OK;
     c->uplists_pending = false;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_uplists, 0));
     return ARP_OK;
@@ -1375,6 +1382,8 @@ int ensure_plane_lists(arp_ctx* c) {
 // per-pair kernel; with_planes: the four ring / amide loops (I:938-1382) ride in the last launch (k_sift_planes).
 // fuse_sets (arp_run_launch): the grid build also produces the residue / ring / amide sets of I:1413-1437.
 int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq_adj, bool with_planes) {
+    struct Defer { arp_ctx* c; ~Defer() { c->uplists_defer = false; } } defer{c};
+    c->uplists_defer = !c->external_stream;
     // the tree is built on selection_plus (I:1442); hydrogens are dropped at I:712
     if (!c->ctr_clean) CHK(zero_counter(c, C_BINNED, 1));
     CHK(zero_counter(c, C_ERR, 1));      // (before the grid build: its chained scan may raise the flag)
@@ -1522,6 +1531,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     bool sift_launched = false;
     auto launch_sift = [&](bool merged_) -> int {
         sift_launched = true;
+        CHK(join_upload_lists(c, /*must=*/true));      // (the list blocks of this launch read what the upload's second stream made)
         Prof p(c, SLOT_SIFT);
         // (the blocks split their work statically: all of them must be resident from the start)
         static const int sift_bpc_env = env_int("ARP_SIFT_BPC", 0);
@@ -1589,7 +1599,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         CHK(launch_sift(false));
         // (enqueued behind the two big launches: a list kernel that starts beside the search takes CU slots the search counts on —
         // its blocks are all meant to be resident at once — and doubles it: 27 -> 54 us at 100 k atoms)
-        CHK(join_upload_lists(c));                 // (on the MAIN stream, before the two change places)
+        CHK(join_upload_lists(c, true));           // (on the MAIN stream, before the two change places)
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sel, 0));
         std::swap(c->stream, c->stream2);
         int rc = ensure_center_grids(c);
@@ -2395,23 +2405,26 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     const int64_t work = std::max({h.n, h.nbond, 3 * h.nh, h.nring, h.namide, h.nres, (int64_t)1});
     PublishArgs pub{c->d_ctr, c->h_ctr_pinned, 0, 0};
     if (polled) { pub.expected = 1; pub.seq = ++c->publish_seq; }
+    // (what the second stream waits for below is the structure's copy, not its validation: the event goes in front of the kernel)
+    static const int grids_with_upload = env_int("ARP_GRIDS_WITH_UPLOAD", 1);
+    static const int upload_aside = env_int("ARP_UPLOAD_ASIDE", 1);
+    const bool with_upload = grids_with_upload && polled && h.n > 0 && h.nring + h.namide > 0;
+    const bool on_second = with_upload && upload_aside && c->stream2 && c->ev_upload && c->ev_uplists;
+    if (on_second) HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
     hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256, 2048)), dim3(256), 0, c->stream, bc, pub);
     CHK(check_launch(c, "k_validate_blob"));
-    // The 6 A grids of the ring and amide centres depend on the uploaded centres and their boxes only: they are built behind the
-    // validation kernel, while the host waits for its verdict and turns round (one launch for both; a structure that fails the
-    // validation has its grids thrown away below: centres outside their box are clamped into it, nothing is written out of bounds).
-    static const int grids_with_upload = env_int("ARP_GRIDS_WITH_UPLOAD", 1);
+    // The 6 A grids of the ring and amide centres and the candidate lists of the ring / amide loops depend on what was uploaded
+    // only (centres, their boxes, the atoms as they came): they are built beside the validation kernel, on the SECOND stream, as
+    // soon as the copy has landed, while the host waits for the verdict and turns round, and the first pass joins them in front of
+    // its grid build (ARP_UPLOAD_ASIDE=0: behind the validation kernel on the main stream, where the static order of the first pass
+    // then waits for them: 25 us of latency chains at 100 k atoms).  A structure that fails the validation has them thrown away
+    // below: centres outside their box are clamped into it, nothing is written out of bounds.
     bool grids_made = false;
-    if (grids_with_upload && polled && h.n > 0 && h.nring + h.namide > 0) {
+    if (with_upload) {
         c->ring_grid.valid = false; c->amide_grid.valid = false;
         c->lists_dirty = true;
         batch_reset(c);
-        // ... on the SECOND stream (ARP_UPLOAD_ASIDE=0: behind the validation kernel on the main one, where the static order of the
-        // first pass then waits for them: 25 us of latency chains at 100 k atoms), joined by the first pass in front of its grid build
-        static const int aside = env_int("ARP_UPLOAD_ASIDE", 1);
-        const bool on_second = aside && c->stream2 && c->ev_upload && c->ev_uplists;
         if (on_second) {
-            HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_upload, 0));
             std::swap(c->stream, c->stream2);
         }

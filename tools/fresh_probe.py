@@ -7,10 +7,17 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from arpeggio_amd import _capi, synth  # noqa: E402
 
-standin = len(sys.argv) > 1 and sys.argv[1] == 'standin'      # python tools/fresh_probe.py standin: the 5.9 k-atom 1tqn_h stand-in
+standin = 'standin' in sys.argv[1:]      # python tools/fresh_probe.py standin: the 5.9 k-atom 1tqn_h stand-in
+e2e = 'e2e' in sys.argv[1:]              # ... e2e: every structure also sorted and fetched (arp_fetch_packed)
 blobs = [_capi.pack_blob(synth.proteinlike(seed=2 + k) if standin else synth.config3(100_000, seed=3 + k)) for k in range(3)]
 ctx = _capi.Context(0)
+buf = None
 for rep in range(4):
     for b in blobs:
         ctx.set_blob(b)
-        ctx.run_launch(5.0, 0.1, False, 6.0)
+        cnt = ctx.run_launch(5.0, 0.1, False, 6.0)
+        if e2e:
+            if buf is None:
+                import numpy as np
+                buf = _capi.pinned_empty(int(cnt['atom_atom'] * 1.25) * 16 + (4 << 20), np.uint8)
+            ctx.fetch_packed(buf)
