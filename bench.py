@@ -753,8 +753,9 @@ def main():
                           'upload_bytes': nbytes_up, 'download_bytes': nbytes_down,
                           'candidate_pairs_per_s': round(st['candidates'] / (e2e_ms * 1e-3), 1),
                           'pack_blob_ms_host': round(pack_ms, 3),
-                          'note': 'fresh structure per step: arp_set_blob (one H2D copy from page-locked memory + device-side validation) + '
-                                  'static columns + ring / amide grids + pass + device sort of the atom-atom bag + all five result bags into one '
+                          'note': 'fresh structure per step: arp_set_blob (one H2D copy from page-locked memory + device-side validation; the ring / amide '
+                                  'centre grids and candidate lists are made beside it on a second stream) + static columns + contact grid + search + '
+                                  'per-pair kernel with the ring / amide loops (six launches, one stream) + device sort of the atom-atom bag + all five result bags into one '
                                   'page-locked host buffer with one copy; pack_blob_ms_host = NumPy packing of a PackedComplex into the blob (done '
                                   'by the producer of the structure, outside the figure)'}
             ctx.set_complex(pc)     # back to the resident benchmark structure
