@@ -191,7 +191,11 @@ int arp_blob_layout(void* blob, uint64_t bytes, int64_t n, int64_t nres, int64_t
 /* Replaces every input of the context with the blob's.  One asynchronous host-to-device copy on the context's stream,
  * then a device-side check of what the classic setters check on the host (finite coordinates inside the box, index
  * ranges, CSR offsets) that the call waits for: ARP_E_ARG if the blob fails it.  The blob may be reused or freed when
- * the call returns.  Selection and ownership are reset (whole structure, I:1395). */
+ * the call returns.  Selection and ownership are reset (whole structure, I:1395).
+ * With its own streams (no caller-owned one) the context also builds what depends on the uploaded arrays only — the 6 A grids of
+ * the ring / amide centres and the candidate lists of the ring / amide loops (I:938-1382) — on its second stream beside the
+ * check; they may still be running when the call returns, and every later call that reads or replaces what they read or
+ * write waits for them on the device (nothing for the caller to do). */
 int arp_set_blob(arp_ctx* ctx, const void* blob, uint64_t bytes);
 /* Host-only packer: fills every array of a blob whose header arp_blob_layout has written from the arrays the classic
  * setters take (same types and meanings; xyz is float[3 * n], hydrogen coordinates double[3 * nh], ...), builds the
