@@ -782,6 +782,12 @@ class Context:
         if rc == ARP_E_CAPACITY and int(used.value) > buf.nbytes:
             buf = pinned_empty(int(used.value) + int(used.value) // 4 + 4096, np.uint8)
             rc = self._L.arp_fetch_packed(self._h, _p(buf), buf.nbytes, counts, offs, C.byref(used))
+        if rc == ARP_E_CAPACITY and int(used.value) == 0:
+            # a result too large for one piece (an array or the whole beyond 4 GiB): bag by bag, as before arp_fetch_packed
+            bags = {'atom_atom': self.atom_contacts_fetch(int(self._counts[0]), sort=True)}
+            for name, _ in self._PACKED_BAGS:
+                bags[name] = self.fetch_bag(name, sort=sort_bags)
+            return bags, buf
         self._check(rc, 'arp_fetch_packed')
 
         def view(off, dtype, n):

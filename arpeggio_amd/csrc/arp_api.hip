@@ -3153,6 +3153,31 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     for (int q = 0; q < ARP_PACKED_OFFSETS; ++q) offsets[q] = 0;
     for (int q = 0; q < 5; ++q) offsets[q] = off[q];
     counts[0] = c->n_contacts;
+    // Sizes first: where every array of every bag goes in the one piece, and whether it fits — before anything is launched (a
+    // caller with too small a buffer, or a result beyond what one piece can address, leaves with bytes_used and no work done)
+    *bytes_used = 0;
+    int seg_of[4][12];
+    for (int b = 0; b < 4; ++b) {
+        Bag& g = *bags[b];
+        counts[1 + b] = g.valid ? g.count : 0;
+        for (int q = 0; q < 12; ++q) seg_of[b][q] = -1;
+        if (!g.valid || g.count == 0) continue;
+        if ((uint64_t)g.count >= ((uint64_t)1 << 31)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: a ring / amide bag of 2^31 records or more (fetch the bags one by one)");
+        const uint8_t* ptr[12] = {(const uint8_t*)g.a.p, (const uint8_t*)g.b.p, (const uint8_t*)g.d0.p, (const uint8_t*)g.d1.p,
+                                  (const uint8_t*)g.d2.p, (const uint8_t*)g.d3.p, (const uint8_t*)g.f0.p, (const uint8_t*)g.f1.p,
+                                  (const uint8_t*)g.f2.p, g.u0.p, g.u1.p, g.u2.p};
+        for (int q = 0; q < 12; ++q) {
+            if (!ptr[q]) continue;
+            const size_t bytes = (size_t)g.count * es[q];
+            if (t.n >= 48 || bytes >= ((size_t)1 << 32) || total >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: ring / amide bags too large for one piece (fetch them one by one)");
+            offsets[5 + 12 * b + q] = total;
+            seg_of[b][q] = t.n;
+            t.s[t.n++] = PackSeg{ptr[q], (uint32_t)total, (uint32_t)bytes, nullptr, (uint32_t)es[q]};
+            total = (total + bytes + 15) & ~(size_t)15;
+        }
+    }
+    *bytes_used = total;
+    if (!host || host_bytes < total) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: host buffer too small (bytes_used holds the size needed)");
     // canonical order of the small bags, made on the device: plane-plane, group-group, group-plane by (first id, second id),
     // atom-plane by (ring, atom) — the order the reference's loops create them in
     BagOrderArgs bo{};
@@ -3171,7 +3196,6 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     for (int b = 0; b < 4; ++b) {
         Bag& g = *bags[b];
         if (!(g.valid && g.count > BAG_SORT_MAX)) continue;
-        if ((uint64_t)g.count >= ((uint64_t)1 << 31)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: a ring / amide bag of 2^31 records or more");
         const int64_t idmax = (c->has_gid || c->has_group_owner) ? (((int64_t)1 << 31) - 1) : std::max<int64_t>({c->n, c->nring, c->namide, 2}) - 1;      // (a shard's records carry global ids)
         CHK(bag_order_large(c, bo.first[b], bo.second[b], (size_t)g.count, idmax, c->bag_perm_big[b]));
         big_perm[b] = c->bag_perm_big[b].p;
@@ -3183,24 +3207,9 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
         CHK(check_launch(c, "k_bag_order"));
         if (order_aside) HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
     }
-    for (int b = 0; b < 4; ++b) {
-        Bag& g = *bags[b];
-        counts[1 + b] = g.valid ? g.count : 0;
-        if (!g.valid || g.count == 0) continue;
-        const uint8_t* ptr[12] = {(const uint8_t*)g.a.p, (const uint8_t*)g.b.p, (const uint8_t*)g.d0.p, (const uint8_t*)g.d1.p,
-                                  (const uint8_t*)g.d2.p, (const uint8_t*)g.d3.p, (const uint8_t*)g.f0.p, (const uint8_t*)g.f1.p,
-                                  (const uint8_t*)g.f2.p, g.u0.p, g.u1.p, g.u2.p};
-        for (int q = 0; q < 12; ++q) {
-            if (!ptr[q]) continue;
-            const size_t bytes = (size_t)g.count * es[q];
-            if (t.n >= 48 || bytes >= ((size_t)1 << 32) || total >= ((size_t)1 << 32)) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: ring / amide bags too large for one piece (fetch them one by one)");
-            offsets[5 + 12 * b + q] = total;
-            t.s[t.n++] = PackSeg{ptr[q], (uint32_t)total, (uint32_t)bytes, bo.n[b] > 0 ? bo.perm[b] : big_perm[b], (uint32_t)es[q]};
-            total = (total + bytes + 15) & ~(size_t)15;
-        }
-    }
-    *bytes_used = total;
-    if (!host || host_bytes < total) FAIL(c, ARP_E_CAPACITY, "arp_fetch_packed: host buffer too small (bytes_used holds the size needed)");
+    for (int b = 0; b < 4; ++b)
+        for (int q = 0; q < 12; ++q)
+            if (seg_of[b][q] >= 0) t.s[seg_of[b][q]].perm = bo.n[b] > 0 ? bo.perm[b] : big_perm[b];
     c->contacts_sorted = c->contacts_sorted && c->sorted_slab.cap >= total;
     CHK(sort_contacts(c, total - cbytes));
     if (order_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));

@@ -175,7 +175,10 @@ int arp_set_amides(arp_ctx* ctx, int64_t namide, const float* center,
  *   9 bond_idx  int32[nbond]                                       20 rad_tab   double[2 * 256]  distinct {vdw, cov} pairs
  *  10 h_off     int32[n+1]  CSR (I:1513-1529)
  * lo/hi, ring_lo/hi, amide_lo/hi = bounding boxes of the atom coordinates / ring centres / amide centres (the grids are
- * sized from them; arp_set_blob verifies that every point lies inside).  n_rad = entries of rad_tab in use. */
+ * sized from them; arp_set_blob verifies that every point lies inside).  n_rad = entries of rad_tab in use.
+ * rad[i] MUST equal rad_tab[rad_idx[i]] bit for bit wherever rad_idx[i] != 0xFFFF (arp_blob_fill writes them so): from
+ * 32 768 atoms on, when every atom is in the table, arp_set_blob leaves array 1 on the host and the device writes the
+ * per-atom radii from the table — a blob that disagrees with itself would be evaluated with the table's values. */
 #define ARP_BLOB_MAGIC 0x31424F4C42505241ull   /* "ARPBLOB1" */
 #define ARP_BLOB_ARRAYS 21
 typedef struct arp_blob_header {
