@@ -3202,16 +3202,22 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     }
     // (on the second stream, beside the radix passes of the atom-atom bag: one block per bag, 80 us for a bag of 4096)
     const bool order_aside = any_order && c->stream2 && !c->external_stream && !c->contacts_sorted;
-    if (any_order) {
-        hipLaunchKernelGGL(k_bag_order, dim3(4), dim3(1024), 0, order_aside ? c->stream2 : c->stream, bo);
-        CHK(check_launch(c, "k_bag_order"));
-        if (order_aside) HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
-    }
     for (int b = 0; b < 4; ++b)
         for (int q = 0; q < 12; ++q)
             if (seg_of[b][q] >= 0) t.s[seg_of[b][q]].perm = bo.n[b] > 0 ? bo.perm[b] : big_perm[b];
     c->contacts_sorted = c->contacts_sorted && c->sorted_slab.cap >= total;
+    // (aside: the sort's launches go out first — they are the critical path, the host needs ~5 us per launch —, the one block per
+    // small bag on the second stream behind them)
+    if (any_order && !order_aside) {
+        hipLaunchKernelGGL(k_bag_order, dim3(4), dim3(1024), 0, c->stream, bo);
+        CHK(check_launch(c, "k_bag_order"));
+    }
     CHK(sort_contacts(c, total - cbytes));
+    if (any_order && order_aside) {
+        hipLaunchKernelGGL(k_bag_order, dim3(4), dim3(1024), 0, c->stream2, bo);
+        CHK(check_launch(c, "k_bag_order"));
+        HIPCHK(c, hipEventRecord(c->ev_planes, c->stream2));
+    }
     if (order_aside) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_planes, 0));
     if (t.n > 0) {
         hipLaunchKernelGGL(k_pack_segments, pack_grid(t), dim3(256), 0, c->stream, t, c->sorted_slab.p);

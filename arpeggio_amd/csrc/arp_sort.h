@@ -79,7 +79,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(SortArgs A) {
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const long long p = lo + r * SORT_THREADS + threadIdx.x;
-        if (p < hi) atomicAdd(&s_hist[(uint32_t)(sort_key_at(A, p) >> A.shift) & mask], 1);
+        // (the digits are bits of i: the first pass reads the i column alone, not the j column it would only shift away)
+        if (p < hi) atomicAdd(&s_hist[A.first ? (((uint32_t)A.ci[p] >> (A.shift - A.jbits)) & mask) : ((uint32_t)(A.key_in[p] >> A.shift) & mask)], 1);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < (1 << A.bits); d += SORT_THREADS) A.table[(size_t)d * A.tstride + blockIdx.x] = s_hist[d];

@@ -462,6 +462,12 @@ def test_lists_made_with_the_upload_survive_whatever_follows_the_upload():
         ca, cb = a.run_launch(5.0, 0.1, False, 6.0), b.run_launch(5.0, 0.1, False, 6.0)
         assert ca == cb, (first.id, second.id)
         _same_bags(_five_bags(a, ca), _five_bags(b, cb), second.id)
+    # ... and more centres than the one-launch centre grids take (16 384): the general grid build runs on the upload's stream
+    many = synth.make_synthetic(3000, seed=24, box=(90.0, 90.0, 90.0), n_rings=17_000, n_amides=300, id='many')
+    b.set_blob(_capi.pack_blob(many)); a.set_complex(many)
+    ca, cb = a.run_launch(5.0, 0.1, False, 6.0), b.run_launch(5.0, 0.1, False, 6.0)
+    assert ca == cb and ca['plane_plane'] > 1000
+    _same_bags(_five_bags(a, ca), _five_bags(b, cb), 'many rings')
     # 2. classic setters on top of a blob: new rings and amides (the same atoms) stale the lists of the upload
     b.set_blob(_capi.pack_blob(rich))
     moved = dataclasses.replace(rich, ring_center=rich.ring_center[::-1].copy(), ring_normal=rich.ring_normal[::-1].copy(), ring_res=rich.ring_res[::-1].copy(),
