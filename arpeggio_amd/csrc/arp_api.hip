@@ -677,6 +677,17 @@ int join_upload_lists(arp_ctx* c, bool must = false) {
     if (hipEventQuery(c->ev_uplists) == hipSuccess) { c->uplists_pending = false; return ARP_OK; }
     (void)hipGetLastError();      // (hipErrorNotReady is not an error)
     if (c->uplists_defer && !must) return ARP_OK;
+    if (c->uplists_defer) {
+        // In front of the last launch of a pass: the host is tens of microseconds ahead of the device there (grid build and search
+        // are queued), the lists a few short of done — asking again for a little while costs the device nothing, a wait on the
+        // stream costs it ~6 us between search and per-pair kernel.
+        static const int spin_us = env_int("ARP_JOIN_SPIN_US", 25);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < spin_us) {
+            if (hipEventQuery(c->ev_uplists) == hipSuccess) { c->uplists_pending = false; return ARP_OK; }
+            (void)hipGetLastError();
+        }
+    }
     c->uplists_pending = false;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_uplists, 0));
     return ARP_OK;
