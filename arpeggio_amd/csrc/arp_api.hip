@@ -308,6 +308,10 @@ struct arp_ctx {
     // what they read or write (join_upload_lists)
     hipEvent_t ev_upload = nullptr, ev_uplists = nullptr;
     bool uplists_pending = false;
+    DevBuf<int> upload_bad;           // number of the last upload whose device-side check failed (validate_resident_blob)
+    bool upload_bad_cleared = false;
+    int ahead_seq = 0;                // != 0: ensure_static is enqueued ahead of the verdict of upload number ahead_seq
+    double last_cutoff = 0.0;         // cell edge of the context's last pass
     bool uplists_defer = false;       // inside enqueue_contacts: see join_upload_lists
     DevBuf<uint8_t> tmp_u8;
     // ---- pair list and outputs of the atom-contact pass
@@ -741,7 +745,8 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
         if (columns) {
             if (!cleared) HIPCHK(c, hipMemsetAsync(c->sp_cnt.p, 0, want * sizeof(int), c->stream));
             hipLaunchKernelGGL(k_prepare_static, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, r, n, c->st_xyzm.p, c->st_aux.p, c->st_qa.p, c->st_h.p,
-                               d, hist, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p);
+                               d, hist, c->sp_cr.p, c->h_xyz_d.p, (unsigned int*)c->longest_bond.p,
+                               c->ahead_seq ? (const int*)c->upload_bad.p : (const int*)nullptr, c->ahead_seq);
         } else {
             if (regrow) HIPCHK(c, hipMemcpyAsync(c->sp_cnt.p, keep_longest, sizeof(keep_longest), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemsetAsync(hist, 0, ((size_t)d.ncell + 4) * sizeof(int), c->stream));
@@ -759,7 +764,8 @@ int ensure_static(arp_ctx* c, double radius = 0.0) {
             hipLaunchKernelGGL(k_scan_fix, dim3((d.ncell + 4095) / 4096), dim3(1024), 0, c->stream, hist, d.ncell, c->sp_sums.p, ntiles, (unsigned long long*)nullptr);
         }
         hipLaunchKernelGGL(k_static_permute, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, c->sp_cr.p, hist, c->st_xyzm.p,
-                           c->st_aux.p, c->st_qa.p, c->st_h.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_qa.p, c->sp_h.p, c->sp_cell.p);
+                           c->st_aux.p, c->st_qa.p, c->st_h.p, c->sp_xyzm.p, c->sp_aux.p, c->sp_qa.p, c->sp_h.p, c->sp_cell.p,
+                           c->ahead_seq ? (const int*)c->upload_bad.p : (const int*)nullptr, c->ahead_seq);
         CHK(check_launch(c, "k_static_permute"));
         c->sp_grid = d;
     }
@@ -1944,6 +1950,7 @@ void arp_destroy(arp_ctx* c) {
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
     c->s_xyzm.release(); c->s_aux.release(); c->s_qa.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_qa.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
+    c->upload_bad.release();
     c->sp_xyzm.release(); c->sp_aux.release(); c->sp_qa.release(); c->st_h.release(); c->sp_h.release(); c->s_h.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();
@@ -2421,6 +2428,29 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     static const int upload_aside = env_int("ARP_UPLOAD_ASIDE", 1);
     const bool with_upload = grids_with_upload && polled && h.n > 0 && h.nring + h.namide > 0;
     const bool on_second = with_upload && upload_aside && c->stream2 && c->ev_upload && c->ev_uplists;
+    // single-bond neighbour coordinates, ring / amide masks, bookkeeping: as the classic setters leave them (before the launches
+    // below, which read some of it: ownership flags, the batch, the static state)
+    const size_t n1 = (size_t)std::max<int64_t>(h.n, 1);
+    HIPCHK(c, c->sb.reserve(n1));
+    HIPCHK(c, c->ring_sel.reserve((size_t)std::max<int64_t>(h.nring, 1))); HIPCHK(c, c->ring_plus.reserve((size_t)std::max<int64_t>(h.nring, 1)));
+    HIPCHK(c, c->am_sel.reserve((size_t)std::max<int64_t>(h.namide, 1))); HIPCHK(c, c->am_plus.reserve((size_t)std::max<int64_t>(h.namide, 1)));
+    c->static_dirty = true;
+    c->lists_dirty = true;
+    c->lists_from_upload = false;
+    c->has_gid = c->has_home = c->has_group_owner = false;
+    c->gid_max = -1;
+    c->shard_resident = false;
+    batch_reset(c);
+    c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
+    c->sel_prefilled = true; c->sp_cnt_zeroed = zero_ints;      // (k_validate_blob's fills)
+    c->contacts_valid = false;
+    c->atom_grid.valid = false; c->all_grid_current = false;
+    // a failed check also leaves the number of this upload in a word of its own (the error word goes back to zero when the verdict
+    // is published): kernels enqueued ahead of the verdict look at it and leave (speculative static order, below)
+    HIPCHK(c, c->upload_bad.reserve(1));
+    if (!c->upload_bad_cleared) { HIPCHK(c, hipMemsetAsync(c->upload_bad.p, 0, sizeof(int), c->stream)); c->upload_bad_cleared = true; }
+    bc.bad_seq = polled ? c->upload_bad.p : nullptr;
+    bc.seq = (int)(pub.seq & 0x7FFFFFFF);
     if (on_second) HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
     hipLaunchKernelGGL(k_validate_blob, dim3(nblocks(work, 256, 2048)), dim3(256), 0, c->stream, bc, pub);
     CHK(check_launch(c, "k_validate_blob"));
@@ -2451,6 +2481,18 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     }
     const bool ring_grid_made = grids_made && c->ring_grid.valid, amide_grid_made = grids_made && c->amide_grid.valid;
     const bool lists_made = grids_made && !c->lists_dirty;
+    // The static columns of the structure and their spatial order — the first three launches of its first pass — go out NOW, for the
+    // cell edge of the context's last pass: they run while the host waits for the verdict and turns round (13 us between the end of
+    // the validation kernel and the first launch of the pass, at 100 k atoms), and leave at once when the check has failed
+    // (upload_bad: the arrays they would index are what the check is about).  A pass with another cell edge re-orders the columns
+    // as it does for any resident structure.
+    static const int static_ahead = env_int("ARP_STATIC_WITH_UPLOAD", 1);
+    if (static_ahead && polled && h.n > 0 && c->last_cutoff > 0) {
+        c->ahead_seq = bc.seq;
+        const int rc = ensure_static(c, c->last_cutoff);
+        c->ahead_seq = 0;
+        CHK(rc);
+    }
     int h_err[2] = {0, 0};
     if (polled) {
         CHK(collect_counters(c));
@@ -2460,23 +2502,10 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
         if (also) HIPCHK(c, hipMemcpyAsync(&h_err[1], also, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    // single-bond neighbour coordinates, ring / amide masks, bookkeeping: as the classic setters leave them
-    const size_t n1 = (size_t)std::max<int64_t>(h.n, 1);
-    HIPCHK(c, c->sb.reserve(n1));
-    HIPCHK(c, c->ring_sel.reserve((size_t)std::max<int64_t>(h.nring, 1))); HIPCHK(c, c->ring_plus.reserve((size_t)std::max<int64_t>(h.nring, 1)));
-    HIPCHK(c, c->am_sel.reserve((size_t)std::max<int64_t>(h.namide, 1))); HIPCHK(c, c->am_plus.reserve((size_t)std::max<int64_t>(h.namide, 1)));
-    c->static_dirty = true;
     c->lists_dirty = !lists_made;
     c->lists_from_upload = lists_made;
-    c->has_gid = c->has_home = c->has_group_owner = false;
-    c->gid_max = -1;
-    c->shard_resident = false;
-    batch_reset(c);
-    c->sel_made = false; c->sel_uploaded = false; c->nsel = -1; c->sel_all = false; c->whole_structure = false;
-    c->sel_prefilled = true; c->sp_cnt_zeroed = zero_ints;      // (k_validate_blob's fills)
-    c->contacts_valid = false;
-    c->atom_grid.valid = false; c->all_grid_current = false;
     const bool verdict_ok = h_err[0] == 0 && h_err[1] == 0;
+    if (!verdict_ok) { c->static_dirty = true; c->sp_radius = 0; }      // (whatever was composed ahead of the verdict is void)
     c->ring_grid.valid = verdict_ok && ring_grid_made; c->amide_grid.valid = verdict_ok && amide_grid_made;
     c->bag_ap.valid = c->bag_pp.valid = c->bag_gg.valid = c->bag_gp.valid = false;
     if (h_err[0] != 0 || h_err[1] != 0) {
@@ -3483,6 +3512,7 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         c->ctr_clean = true;
         struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; c->pub.expected = 0; c->fuse_sets = false; c->init_plus_in_bin = false; } } unclean{c};
         CHK(ensure_static(c, cutoff));       // (the spatial order of the columns is the one of this pass's cells)
+        c->last_cutoff = cutoff;
         // The pass ends inside its last kernel (k_sift_planes): the last block to finish publishes the counters.
         static const int inkernel_publish = env_int("ARP_INKERNEL_PUBLISH", 1);
         c->pub = PublishArgs{c->d_ctr, c->h_ctr_pinned, 0, 0};

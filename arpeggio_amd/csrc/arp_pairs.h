@@ -190,6 +190,9 @@ struct BlobCheck {
     // upload) and are written here from the table
     double2* rad_out;
     const double2* rad_tab;
+    // not null: a failed check also stores `seq` (the number of this upload) there, where it stays (see arp_set_blob)
+    int* bad_seq;
+    int seq;
 };
 // (k_validate_blob itself: behind pass_end, which it ends with)
 
@@ -197,7 +200,10 @@ struct BlobCheck {
 // (histogram + rank in cell: what k_static_bin did as a launch of its own) and the longest bond / atom - hydrogen distance.
 __global__ __launch_bounds__(256) void k_prepare_static(RawAtoms r, int n, float4* __restrict__ st_xyzm, int4* __restrict__ st_aux,
                                                         int4* __restrict__ st_qa, int* __restrict__ st_h, GridDesc g6, int* __restrict__ cnt6,
-                                                        int2* __restrict__ cr6, const double* __restrict__ h_xyz, unsigned int* __restrict__ longest) {
+                                                        int2* __restrict__ cr6, const double* __restrict__ h_xyz, unsigned int* __restrict__ longest,
+                                                        const int* __restrict__ bad_seq, int seq) {
+    // (enqueued ahead of the verdict of the upload's device-side check: a structure that failed it is not to be indexed)
+    if (bad_seq && __hip_atomic_load(bad_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) return;
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
     // One walk over an atom's bonds serves both the longest bond (float32 distance, rounded up a little) and the neighbours in other
     // residues, and it goes FOUR bonds at a time: index -> {coordinates, residue} is a chain of dependent loads per bond, and with
@@ -292,7 +298,9 @@ __global__ __launch_bounds__(256) void k_static_permute(int n, const int2* __res
                                                         const float4* __restrict__ st_xyzm, const int4* __restrict__ st_aux,
                                                         const int4* __restrict__ st_qa, const int* __restrict__ st_h,
                                                         float4* __restrict__ sp_xyzm, int4* __restrict__ sp_aux, int4* __restrict__ sp_qa,
-                                                        int* __restrict__ sp_h, int* __restrict__ sp_cell) {
+                                                        int* __restrict__ sp_h, int* __restrict__ sp_cell,
+                                                        const int* __restrict__ bad_seq, int seq) {
+    if (bad_seq && __hip_atomic_load(bad_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) return;      // (see k_prepare_static)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 c = cr[i];
         const int pos = start[c.x] + c.y;
@@ -747,7 +755,10 @@ __global__ __launch_bounds__(256) void k_validate_blob(BlobCheck bc, PublishArgs
     }
     for (int k = gtid; k < bc.fill_ones_n; k += gstride) bc.fill_ones[k] = 0x01010101u;
     for (int k = gtid; k < bc.fill_zero_n; k += gstride) bc.fill_zero[k] = make_int4(0, 0, 0, 0);
-    if (bad) atomicExch(bc.err, ARP_E_ARG);
+    if (bad) {
+        atomicExch(bc.err, ARP_E_ARG);
+        if (bc.bad_seq) atomicExch(bc.bad_seq, bc.seq);
+    }
     pass_end(pub, 0);
 }
 
