@@ -29,7 +29,7 @@ SYMBOLS = (
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
-    'arp_get_host_times', 'arp_set_whole_structure', 'arp_set_grid_reuse', 'arp_set_batch', 'arp_device_count', 'arp_device_synchronize', 'arp_comm_unique_id', 'arp_comm_init', 'arp_comm_destroy', 'arp_comm_info',
+    'arp_get_host_times', 'arp_set_whole_structure', 'arp_set_grid_reuse', 'arp_set_sort_after_pass', 'arp_set_batch', 'arp_device_count', 'arp_device_synchronize', 'arp_comm_unique_id', 'arp_comm_init', 'arp_comm_destroy', 'arp_comm_info',
     'arp_shard_exchange_faces', 'arp_shard_set_exchange_lists', 'arp_shard_exchange_plus', 'arp_shard_reduce_residue_sets', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
     'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob', 'arp_blob_fill',
     'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_records_fill', 'arp_shard_set_home', 'arp_shard_pack_face',
@@ -134,6 +134,7 @@ def load():
     L.arp_get_host_times.argtypes = [vp, vp, vp, i32]
     L.arp_set_whole_structure.argtypes = [vp, i32]
     L.arp_set_grid_reuse.argtypes = [vp, i32]
+    L.arp_set_sort_after_pass.argtypes = [vp, i32]
     L.arp_device_synchronize.argtypes = [vp]
     L.arp_set_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     L.arp_comm_unique_id.argtypes = [vp, C.c_uint64]
@@ -433,6 +434,11 @@ class Context:
     def set_grid_reuse(self, on=True):
         """Whole-structure passes keep their contact grid (default); ``False``: every pass builds it (measurements)."""
         self._check(self._L.arp_set_grid_reuse(self._h, int(bool(on))), 'arp_set_grid_reuse')
+
+    def set_sort_after_pass(self, on=True):
+        """``run_launch`` / ``run_wait`` enqueue the canonical sort of the atom-atom bag before they return (for callers that
+        fetch the sorted bag next: ``fetch_packed``)."""
+        self._check(self._L.arp_set_sort_after_pass(self._h, int(bool(on))), 'arp_set_sort_after_pass')
 
     def device_synchronize(self):
         """Everything enqueued on this context's GPU has completed (the bracket of a timed region)."""

@@ -130,6 +130,7 @@ class InteractionComplex:
             self._incomplete(['hydrogens (the file has none; the reference adds them with OpenBabel, I:99-105)'])
         if self._ctx is None:
             self._ctx = _capi.Context(self.device)
+            self._ctx.set_sort_after_pass(True)      # run_arpeggio always fetches the sorted bags next
         self._ctx.set_complex(self.pc)
         if getattr(self.pc, 'plane_geometry_pending', False):
             self.compute_plane_geometry()

@@ -291,6 +291,7 @@ struct arp_ctx {
     // selection launches no k_compact_atoms.  Any other selection compacts per pass, as the reference rebuilds
     // NeighborSearch(selection_plus) (I:1442).  arp_set_grid_reuse(ctx, 0) switches the reuse off (bench.py reports both).
     bool grid_reuse = true;
+    bool sort_after_pass = false;     // arp_set_sort_after_pass
     bool cg_valid = false, cg_fuse = false, cg_init_plus = false, cg_all_res = false, cg_pending = false, cg_reused = false;
     double cg_radius = 0.0;
     uint64_t static_epoch = 0, sel_epoch = 0, cg_static_epoch = 0, cg_sel_epoch = 0;
@@ -3241,7 +3242,7 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
         big_perm[b] = c->bag_perm_big[b].p;
     }
     // (on the second stream, beside the radix passes of the atom-atom bag: one block per bag, 80 us for a bag of 4096)
-    const bool order_aside = any_order && c->stream2 && !c->external_stream && !c->contacts_sorted;
+    const bool order_aside = any_order && c->stream2 && !c->external_stream;      // (beside the sort, which may be under way already: arp_set_sort_after_pass)
     for (int b = 0; b < 4; ++b)
         for (int q = 0; q < 12; ++q)
             if (seg_of[b][q] >= 0) t.s[seg_of[b][q]].perm = bo.n[b] > 0 ? bo.perm[b] : big_perm[b];
@@ -3589,7 +3590,14 @@ int run_pass_wait(arp_ctx* c, int64_t counts[5]) {
         counts[0] = c->n_contacts; counts[1] = c->bag_pp.count; counts[2] = c->bag_ap.count;
         counts[3] = c->bag_gg.count; counts[4] = c->bag_gp.count;
     }
-    return device_error(c);
+    const int rc_dev = device_error(c);
+    if (rc_dev == ARP_OK && c->sort_after_pass && c->contacts_valid && c->n_contacts > 0 && c->n_contacts < ((int64_t)1 << 31)) {
+        // (room for the ring / amide bags behind the sorted columns, as arp_fetch_packed lays them out: at most 52 bytes a record
+        // and twelve arrays a bag, each rounded up to 16 bytes)
+        const size_t extra = 52 * (size_t)(c->bag_pp.count + c->bag_ap.count + c->bag_gg.count + c->bag_gp.count) + 4 * 12 * 16;
+        CHK(sort_contacts(c, extra));
+    }
+    return rc_dev;
 }
 }  // namespace
 
@@ -4085,6 +4093,12 @@ int arp_debug_read(uint64_t device_ptr, void* host, uint64_t bytes) {
     return hipMemcpy(host, (const void*)(uintptr_t)device_ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess ? ARP_OK : ARP_E_HIP;
 }
 #endif
+
+int arp_set_sort_after_pass(arp_ctx* c, int enabled) {
+    if (!c) return ARP_E_ARG;
+    c->sort_after_pass = enabled != 0;
+    return ARP_OK;
+}
 
 int arp_set_grid_reuse(arp_ctx* c, int enabled) {
     if (!c) return ARP_E_ARG;

@@ -440,6 +440,11 @@ int arp_host_free(void* p);
  * selection_plus into a new grid every time, as the reference rebuilds NeighborSearch(selection_plus) (interactions.py:1442).
  * enabled = 0 makes every pass build its grid (measurements); default 1. */
 int  arp_set_grid_reuse(arp_ctx* ctx, int enabled);
+/* enabled = 1: arp_run_launch / arp_run_wait enqueue the canonical sort of the atom-atom bag (arp_atom_contacts_sort) as soon as
+ * the pass has reported its record count, before they return — for callers that fetch the sorted bag next (arp_fetch_packed,
+ * arp_atom_contacts_fetch after a sort; I:183-190 exports every record): the sort then starts a host round trip earlier and runs
+ * while the caller gets back to the library.  Default 0 (a caller that only wants counts pays for no sort). */
+int  arp_set_sort_after_pass(arp_ctx* ctx, int enabled);
 
 /* Sharded runs with NO selection (the reference's default, I:1395: every atom of the structure): the caller
  * asserts that the selection is the whole global structure.  Then selection_plus = selection on every rank and every

@@ -206,3 +206,28 @@ def test_ring_and_amide_bags_beyond_one_block_are_ordered_on_the_device_too(ctx,
             for k, v in raw.items():
                 assert np.array_equal(bags[name][k].view(np.uint8), v[o].view(np.uint8)), (name, k, m)
     assert sum(m > capi.BAG_SORT_MAX for m in seen) >= 3 and max(seen) > 40_000, seen
+
+
+def test_sort_enqueued_by_the_pass_itself_gives_the_same_bags(capi):
+    """arp_set_sort_after_pass: run_launch enqueues the canonical sort before it returns.  Every way of fetching afterwards —
+    one piece, the sorted columns alone, the unsorted bag — gives what a context without the switch gives; a pass that is not
+    fetched at all, a change of structure and a ring-heavy structure (bags that outgrow the room reserved behind the sorted
+    columns are sorted once more) included."""
+    from arpeggio_amd import synth
+    a, b = capi.Context(0), capi.Context(0)
+    b.set_sort_after_pass(True)
+    for pc in (synth.config3(30_000, seed=41), synth.proteinlike(n_res=90, n_waters=30, seed=42), synth.config5(3000, 3000, seed=43, L=60.0),
+               synth.config3(2_000, seed=44)):
+        a.set_complex(pc); b.set_blob(capi.pack_blob(pc))
+        for cutoff in (5.0, 4.0):
+            ca, cb = a.run_launch(cutoff, 0.1, False, 6.0), b.run_launch(cutoff, 0.1, False, 6.0)
+            assert ca == cb
+        b.run_launch(4.5, 0.1, False, 6.0); ca = a.run_launch(4.5, 0.1, False, 6.0)      # (the pass before was never fetched)
+        xa, _ = a.fetch_packed()
+        xb, _ = b.fetch_packed()
+        for bag in xa:
+            for k in xa[bag]:
+                assert np.array_equal(xa[bag][k], xb[bag][k], equal_nan=(xa[bag][k].dtype.kind == 'f')), (pc.id, bag, k)
+        _same_bag(xa['atom_atom'], b.atom_contacts_fetch(ca['atom_atom'], sort=True))
+        _same_bag(_host_sorted(a.atom_contacts_fetch(ca['atom_atom'], sort=False)), _host_sorted(b.atom_contacts_fetch(ca['atom_atom'], sort=False)))
+    a.close(); b.close()

@@ -29,6 +29,7 @@ out = {'tag': args.tag, 'atoms': int(fresh[0].n_atoms), 'first_pass_ms_median': 
        'upload_validate_ms_median': round(float(np.median(up)), 4), 'contacts': int(cnt['atom_atom']),
        'bags': {k: int(cnt[k]) for k in ('plane_plane', 'atom_plane', 'group_group', 'group_plane')}}
 if args.e2e:
+    ctx.set_sort_after_pass(os.environ.get('PROBE_SORT_AFTER_PASS', '1') != '0')
     buf = _capi.pinned_empty(int(cnt['atom_atom'] * 1.25) * 16 + (4 << 20), np.uint8)
     for k in range(6):
         ctx.set_blob(blobs[k % 4]); ctx.run_launch(5.0, 0.1, False, 6.0); ctx.fetch_packed(buf)

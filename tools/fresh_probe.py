@@ -11,6 +11,8 @@ standin = 'standin' in sys.argv[1:]      # python tools/fresh_probe.py standin: 
 e2e = 'e2e' in sys.argv[1:]              # ... e2e: every structure also sorted and fetched (arp_fetch_packed)
 blobs = [_capi.pack_blob(synth.proteinlike(seed=2 + k) if standin else synth.config3(100_000, seed=3 + k)) for k in range(3)]
 ctx = _capi.Context(0)
+if e2e:
+    ctx.set_sort_after_pass(True)
 buf = None
 for rep in range(4):
     for b in blobs:
