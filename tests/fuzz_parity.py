@@ -1,7 +1,10 @@
 """Long-running differential test (not collected by pytest): the body of test_random_parameters_and_selections and of
 test_random_shards_device_vs_host for as many fresh seeds as fit in the given time.
 
-    python tests/fuzz_parity.py [seconds] [first_seed]
+    python tests/fuzz_parity.py [seconds] [first_seed] [blob]
+
+`blob`: the parameters body uploads every structure as ONE blob (arp_set_blob: candidate lists, static columns and their
+spatial order made with the upload; the sort enqueued by the pass itself) instead of the classic setters.
 
 Prints one line per failing seed (with the assertion) and a summary; exit code 1 if any seed failed."""
 import os
@@ -20,7 +23,15 @@ def main():
     from arpeggio_amd import _capi
     import test_gpu_parity as tp
     import test_gpu_shard_device as ts
-    ctx = _capi.Context(0)
+    blob = 'blob' in sys.argv[3:]
+
+    def make_ctx():
+        c = _capi.Context(0)
+        if blob:
+            c.set_complex = lambda pc, c=c: c.set_blob(_capi.pack_blob(pc))
+            c.set_sort_after_pass(True)
+        return c
+    ctx = make_ctx()
     t0, done, failed = time.time(), 0, []
     while time.time() - t0 < budget:
         for name, fn, arg in (('parameters', tp.test_random_parameters_and_selections, ctx),
@@ -31,7 +42,7 @@ def main():
                 failed.append((name, seed))
                 print('FAIL', name, seed, repr(e)[:300], flush=True)
                 traceback.print_exc(limit=3)
-                ctx = _capi.Context(0)
+                ctx = make_ctx()
         done += 1
         seed += 1
     print('fuzz: %d seeds x 2 bodies in %.0f s, %d failures %s' % (done, time.time() - t0, len(failed), failed[:20]))
