@@ -5,8 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from arpeggio_amd import synth, _capi
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
-pc = synth.config3(n, seed=3)
+# python tools/search_trace.py [atoms | chain [residues]]: config 3 of that many atoms, or the chain model of tools/small_bench.py (clumps)
+if len(sys.argv) > 1 and sys.argv[1] == 'chain':
+    nr = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
+    pc = synth.proteinlike(n_res=nr, n_waters=nr // 2)
+else:
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+    pc = synth.config3(n, seed=3)
 ctx = _capi.Context(0)
 ctx.set_complex(pc)
 ctx.set_grid_reuse(False)
