@@ -277,6 +277,8 @@ struct arp_ctx {
     double sb_radius = 0.0;
     int sb_blocks = 0, sb_tx = 0;
     bool sb_whole = false;
+    bool sb_by_atoms = false, sb_seen_by_atoms = false;      // what the entries of sb_tile are: tiles, or atom positions (k_balance_atoms)
+    DevBuf<int> sb_cw, sb_cwp, sb_sums;                      // weight per cell, its running sum, tile totals of that scan
     // (the grid key of the last pass that ran WITHOUT a hint: the hint is worked out by the second such pass over one grid — a
     // structure that is evaluated once, the usual case, never pays for it)
     bool sb_seen = false;
@@ -1503,7 +1505,9 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         }
         static const int hint_mode = env_int("ARP_SEARCH_BALANCE_HINT", 1);
         static const int cell_w16 = std::max(0, env_int("ARP_SEARCH_CELL_WEIGHT_X16", 64));      // weight of a cell in sixteenths of an atom
-        const bool hint_ok = hint_mode && !by_atoms && whole && c->sb_valid && c->sb_static_epoch == c->static_epoch && c->sb_sel_epoch == c->sel_epoch &&
+        static const int hint_atoms = env_int("ARP_SEARCH_BALANCE_HINT_ATOMS", 1);      // ... also for blocks that take runs of atoms (k_balance_atoms)
+        const bool hint_wanted = hint_mode && whole && (!by_atoms || hint_atoms);
+        const bool hint_ok = hint_wanted && c->sb_valid && c->sb_by_atoms == by_atoms && c->sb_static_epoch == c->static_epoch && c->sb_sel_epoch == c->sel_epoch &&
                              c->sb_radius == cutoff && c->sb_blocks == nblocks_search && c->sb_tx == tile_x && c->sb_tile.p;
         const int* const balance_hint = hint_ok ? (const int*)c->sb_tile.p : (const int*)nullptr;
         if (tile_x == 2) {
@@ -1523,18 +1527,38 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // the SECOND pass over it: the launch sits between the search and the per-pair kernel of that pass (6 us + a gap: a tenth
         // of a structure's first pass when it was made there), and a structure that is evaluated once never needs it.  First and
         // second pass run on equal runs of cells.
-        if (hint_mode && !by_atoms && !hint_ok && whole && nblocks_search >= 16) {
-            const bool seen = c->sb_seen && c->sb_seen_static_epoch == c->static_epoch && c->sb_seen_sel_epoch == c->sel_epoch &&
+        if (hint_wanted && !hint_ok && nblocks_search >= 16) {
+            const bool seen = c->sb_seen && c->sb_seen_by_atoms == by_atoms && c->sb_seen_static_epoch == c->static_epoch && c->sb_seen_sel_epoch == c->sel_epoch &&
                               c->sb_seen_radius == cutoff && c->sb_seen_blocks == nblocks_search && c->sb_seen_tx == tile_x;
             static const int hint_eager = env_int("ARP_SEARCH_BALANCE_HINT_EAGER", 0);
             if (seen || hint_eager) {
                 HIPCHK(c, c->sb_tile.reserve((size_t)nblocks_search + 1));
-                hipLaunchKernelGGL(k_balance_blocks, dim3(nblocks(nblocks_search + 1, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
-                                   nblocks_search, tile_x, cell_w16, c->sb_tile.p);
-                c->sb_valid = true; c->sb_static_epoch = c->static_epoch; c->sb_sel_epoch = c->sel_epoch; c->sb_radius = cutoff;
+                if (!by_atoms) {
+                    hipLaunchKernelGGL(k_balance_blocks, dim3(nblocks(nblocks_search + 1, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
+                                       nblocks_search, tile_x, cell_w16, c->sb_tile.p);
+                } else {
+                    // runs of ATOMS of equal weight: weight per cell, its running sum (the scans of the grid builds), one binary search per block
+                    const int ncell = c->atom_grid.d.ncell;
+                    static const int w_unit = std::max(0, env_int("ARP_SEARCH_W_UNIT", 100)), w_chunk = std::max(0, env_int("ARP_SEARCH_W_CHUNK", 85)),
+                                     w_test8 = std::max(0, env_int("ARP_SEARCH_W_TEST_X8", 2));      // (k_cell_weights: wave instructions per unit, per chunk, per eight distance tests)
+                    HIPCHK(c, c->sb_cw.reserve(scan_padded(ncell))); HIPCHK(c, c->sb_cwp.reserve(scan_padded(ncell)));
+                    hipLaunchKernelGGL(k_cell_weights, dim3(nblocks(ncell, 256, 2048)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p, w_unit, w_chunk, w_test8, c->sb_cw.p);
+                    if (ncell <= 4096) hipLaunchKernelGGL((k_scan_small<4>), dim3(1), dim3(1024), 0, c->stream, c->sb_cw.p, ncell, c->sb_cwp.p, (u64*)nullptr);
+                    else if (ncell <= 16384) hipLaunchKernelGGL((k_scan_small<16>), dim3(1), dim3(1024), 0, c->stream, c->sb_cw.p, ncell, c->sb_cwp.p, (u64*)nullptr);
+                    else if (ncell <= 32768) hipLaunchKernelGGL((k_scan_small<32>), dim3(1), dim3(1024), 0, c->stream, c->sb_cw.p, ncell, c->sb_cwp.p, (u64*)nullptr);
+                    else {
+                        const int ntiles = (ncell + TILE_CELLS - 1) / TILE_CELLS;
+                        HIPCHK(c, c->sb_sums.reserve((size_t)ntiles + 2));
+                        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, c->stream, c->sb_cw.p, ncell, c->sb_cwp.p, c->sb_sums.p);
+                        hipLaunchKernelGGL(k_scan_fix, dim3((ncell + 4095) / 4096), dim3(1024), 0, c->stream, c->sb_cwp.p, ncell, c->sb_sums.p, ntiles, (unsigned long long*)nullptr);
+                    }
+                    hipLaunchKernelGGL(k_balance_atoms, dim3(nblocks(nblocks_search + 1, 256)), dim3(256), 0, c->stream, c->atom_grid.d, c->atom_grid.start.p,
+                                       (const int*)c->sb_cwp.p, nblocks_search, c->sb_tile.p);
+                }
+                c->sb_valid = true; c->sb_by_atoms = by_atoms; c->sb_static_epoch = c->static_epoch; c->sb_sel_epoch = c->sel_epoch; c->sb_radius = cutoff;
                 c->sb_blocks = nblocks_search; c->sb_tx = tile_x; c->sb_whole = whole;
             } else {
-                c->sb_seen = true; c->sb_seen_static_epoch = c->static_epoch; c->sb_seen_sel_epoch = c->sel_epoch; c->sb_seen_radius = cutoff;
+                c->sb_seen = true; c->sb_seen_by_atoms = by_atoms; c->sb_seen_static_epoch = c->static_epoch; c->sb_seen_sel_epoch = c->sel_epoch; c->sb_seen_radius = cutoff;
                 c->sb_seen_blocks = nblocks_search; c->sb_seen_tx = tile_x;
             }
         }
@@ -1951,7 +1975,7 @@ void arp_destroy(arp_ctx* c) {
     c->ring_c.release(); c->ring_n.release(); c->ring_res.release(); c->ring_sel.release(); c->ring_plus.release();
     c->am_c.release(); c->am_n.release(); c->am_res.release(); c->am_sel.release(); c->am_plus.release();
     c->s_xyzm.release(); c->s_aux.release(); c->s_qa.release(); c->tmp_i32.release(); c->sel_list.release(); c->st_qa.release(); c->rad_idx.release(); c->rad_tab.release(); c->st_aux.release(); c->st_xyzm.release();
-    c->upload_bad.release();
+    c->upload_bad.release(); c->sb_tile.release(); c->sb_cw.release(); c->sb_cwp.release(); c->sb_sums.release();
     c->sp_xyzm.release(); c->sp_aux.release(); c->sp_qa.release(); c->st_h.release(); c->sp_h.release(); c->s_h.release(); c->sp_cnt.release(); c->sp_cr.release();
     c->atom_grid.release(); c->all_grid.release(); c->a_xyzm.release(); c->a_aux.release(); c->ring_grid.release(); c->amide_grid.release(); c->tmp_u8.release();
     c->pairs.release(); c->out_i.release(); c->out_j.release(); c->out_d.release(); c->out_s.release(); c->out_ct.release();

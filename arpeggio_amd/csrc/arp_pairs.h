@@ -837,6 +837,57 @@ __global__ __launch_bounds__(256) void k_balance_blocks(GridDesc g, const int* _
     }
 }
 
+// ... and for blocks that take runs of cell-sorted ATOMS (sparse or clumped grids): equal runs of atoms are not equal work when the
+// density varies — a 96 k-atom chain folded onto itself gave its CUs 4 k ... 102 k distance tests each (median 49 k), and the
+// kernel lasts as long as the fullest one.  k_cell_weights prices every cell (its units, their chunks, its distance tests: the
+// candidates of a cell are the five ranges of the half stencil), a scan turns that into running weights, k_balance_atoms finds for every block the atom position where the running weight passes b / nb of the total
+// (binary search over the cells, then in proportion inside the cell).  A hint like the runs of tiles: any partition is correct.
+__global__ __launch_bounds__(256) void k_cell_weights(GridDesc g, const int* __restrict__ start, int w_unit, int w_chunk, int w_test8, int* __restrict__ cw) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.ncell; c += gridDim.x * blockDim.x) {
+        const int n = start[c + 1] - start[c];
+        int w = 0;
+        if (n > 0) {
+            const int row = c / g.nx, cx = c - row * g.nx;
+            const int cz = row / g.ny, cy = row - cz * g.ny;
+            long long cand = start[row * g.nx + min(cx + 2, g.nx)] - start[c];      // home pencil: own cell (later entries) and cx + 1
+#pragma unroll
+            for (int r = 1; r < 5; ++r) {
+                const int dy = (r == 1) ? 1 : (r - 3), dz = (r == 1) ? 0 : 1;
+                const int y2 = cy + dy, z2 = cz + dz;
+                if (y2 < 0 || y2 >= g.ny || z2 >= g.nz) continue;
+                const int rb = (z2 * g.ny + y2) * g.nx;
+                cand += start[rb + min(cx + 2, g.nx)] - start[rb + max(cx - 1, 0)];
+            }
+            // in wave instructions, as the ISA of k_search has them: a unit (a home block of 32 against a span of candidates) costs
+            // w_unit + w_chunk per chunk of 128 candidates, a distance test w_test8 / 8 (17 per home atom and chunk, the hits' share)
+            const long long nhb = (n + HOME_BLOCK - 1) / HOME_BLOCK, nch = (cand + 127) / 128;
+            // (a test in a crowded cell costs more than one in a sparse cell: more of them hit, and hits are what stage 2 walks —
+            // the test's price grows with the candidates of the cell, + 1 per 256 of them)
+            const long long tests = (long long)n * cand;
+            const long long v = (nhb * (w_unit + w_chunk * nch) + ((tests * w_test8 * (256 + cand)) >> 11) + 3) >> 2;
+            w = (int)min(v, (long long)(1 << 24));        // (the scan stays in 32 bits for 128 cells of that weight: clumps of thousands of atoms)
+        }
+        cw[c] = w;
+    }
+}
+__global__ __launch_bounds__(256) void k_balance_atoms(GridDesc g, const int* __restrict__ start, const int* __restrict__ cwp, int nb, int* __restrict__ blk_pos) {
+    const int T = start[g.ncell];
+    const long long W = cwp[g.ncell];
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b <= nb; b += gridDim.x * blockDim.x) {
+        if (b == 0 || b == nb || W <= 0) { blk_pos[b] = (b == 0) ? 0 : (W <= 0 ? (int)((long long)b * T / nb) : T); continue; }
+        const long long target = (long long)b * W / nb;
+        int lo = 0, hi = g.ncell;                 // the last cell whose running weight (before it) is <= target
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)cwp[mid] <= target) lo = mid; else hi = mid;
+        }
+        const int n = start[lo + 1] - start[lo];
+        const long long w = (long long)cwp[lo + 1] - cwp[lo];
+        const int inside = (w > 0) ? (int)min((long long)n, (target - cwp[lo]) * n / w) : 0;
+        blk_pos[b] = min(start[lo] + inside, T);
+    }
+}
+
 // TX: x-adjacent home cells per tile (1 or 2; a template parameter: with one cell per tile the column rules below vanish at
 // compile time — as a run-time value they cost the small grids 3 us)
 template <int MODE, int TX = 1>
@@ -894,7 +945,11 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         // against the cell's whole candidate set (the cell of an atom position is written by the grid build: two dependent
         // load rounds before the first cell).
         const long long T = start[g.ncell];
-        const int p0 = (int)((long long)vb * T / nb), p1 = (int)((long long)(vb + 1) * T / nb);
+        int p0 = (int)((long long)vb * T / nb), p1 = (int)((long long)(vb + 1) * T / nb);
+        if (blk_tile) {      // runs of atoms of equal WEIGHT (k_balance_atoms): a hint from an earlier pass over this grid
+            p0 = min(max(blk_tile[vb], 0), (int)T);
+            p1 = min(max(blk_tile[vb + 1], p0), (int)T);
+        }
         if (p1 > p0) {
             blk_begin = tile_of_cell(cell_of_pos[p0]);
             c_end = tile_of_cell(cell_of_pos[p1 - 1]) + 1;

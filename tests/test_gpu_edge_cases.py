@@ -498,6 +498,33 @@ def test_lists_made_with_the_upload_survive_whatever_follows_the_upload():
     a.close(); b.close()
 
 
+@pytest.mark.gpu
+def test_weighted_runs_of_atoms_change_no_result():
+    """Sparse and clumped grids give the blocks of k_search runs of ATOMS; from the third pass over a grid on, runs of equal WEIGHT
+    (k_cell_weights / k_balance_atoms, worked out by the second pass).  Any partition of the atoms is a correct one: every pass of
+    a sequence over one structure gives the same five bags, for a chain folded onto itself (clumps of dozens of atoms per cell), a
+    batch of proteins in one grid and a protein in its bounding box; a change of cutoff or structure in between starts over."""
+    from arpeggio_amd import _capi, synth
+    ctx = _capi.Context(0)
+    ctx.set_grid_reuse(False)
+    chain = synth.proteinlike(n_res=1200, n_waters=600, seed=31)
+    prot = synth.proteinlike(n_res=150, n_waters=60, seed=32)
+    for what, setup in (('chain', lambda: ctx.set_complex(chain)), ('protein', lambda: ctx.set_complex(prot)),
+                        ('batch', lambda: ctx.set_batch([synth.proteinlike(n_res=60 + 7 * k, n_waters=20, seed=40 + k) for k in range(6)]))):
+        setup()
+        ref = None
+        for k, cutoff in enumerate((5.0, 5.0, 5.0, 5.0, 4.0, 4.0, 4.0, 5.0)):
+            cnt = ctx.run_launch(cutoff, 0.1, False, 6.0)
+            bags = _five_bags(ctx, cnt)
+            if cutoff == 5.0:
+                if ref is None:
+                    ref = bags
+                else:
+                    _same_bags(ref, bags, (what, k))
+        assert len(ref['atom_atom']['i']) > 1000
+    ctx.close()
+
+
 def test_enqueue_and_wait_keep_several_contexts_busy_from_one_thread():
     """arp_run_enqueue / arp_run_wait: the pass of run_launch in two calls; three contexts driven round-robin by one thread give
     what three run_launch calls give, an enqueue without its wait (or a wait without an enqueue) is refused."""
