@@ -1790,7 +1790,8 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
         const int nbin = (int)idmax + 1;
         A.key_out = c->sort_key[0].p;
         A.val_out = c->sort_val[0].p;
-        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SORT_SMALL_THREADS), 0, c->stream, A, nbin);
+        static const int small_blocks = std::max(1, std::min(64, env_int("ARP_SORT_SMALL_BLOCKS", SORT_SMALL_BLOCKS)));
+        hipLaunchKernelGGL(k_sort_small, dim3(std::min(small_blocks, nbin)), dim3(SORT_SMALL_THREADS), 0, c->stream, A, nbin);
         A.key_in = c->sort_key[0].p;
         A.val_in = c->sort_val[0].p;
         hipLaunchKernelGGL(k_sort_runs, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, A);
