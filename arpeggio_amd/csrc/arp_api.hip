@@ -2412,6 +2412,7 @@ void borrow_blob_views(arp_ctx* c, const arp_blob_header& h) {
 // structure.  Waits for the stream.  `also` = further device error words OR-ed in (shard assembly), may be null.
 int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who, const int* also = nullptr, bool gather_sb = false, bool rad_from_table = false) {
     int* const d_err = (int*)(c->d_ctr + ctr_dev(C_ERR));
+    const bool after_batch = c->batch_n > 0;      // (before the bookkeeping below resets it)
     // The verdict reaches the host the way the counters of a pass do: the last block of the kernel stores the counter block in
     // the pinned mirror and the host polls the completion word (pass_end) — no copy launch behind the kernel, no
     // hipStreamSynchronize (~15 us per structure).  That needs the whole block zero at the start (its tickets live there) and
@@ -2452,7 +2453,10 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     // (what the second stream waits for below is the structure's copy, not its validation: the event goes in front of the kernel)
     static const int grids_with_upload = env_int("ARP_GRIDS_WITH_UPLOAD", 1);
     static const int upload_aside = env_int("ARP_UPLOAD_ASIDE", 1);
-    const bool with_upload = grids_with_upload && polled && h.n > 0 && h.nring + h.namide > 0;
+    // (not when the context's last structure was a batch: the next call is arp_set_batch again, which throws away whatever was made
+    // for the concatenation as ONE structure — whose overlaid coordinates make for enormous candidate lists on top: a batch of 64
+    // stand-ins took 3.2 instead of 1.4 ms end to end)
+    const bool with_upload = grids_with_upload && polled && h.n > 0 && h.nring + h.namide > 0 && !after_batch;
     const bool on_second = with_upload && upload_aside && c->stream2 && c->ev_upload && c->ev_uplists;
     // single-bond neighbour coordinates, ring / amide masks, bookkeeping: as the classic setters leave them (before the launches
     // below, which read some of it: ownership flags, the batch, the static state)
@@ -2513,7 +2517,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     // (upload_bad: the arrays they would index are what the check is about).  A pass with another cell edge re-orders the columns
     // as it does for any resident structure.
     static const int static_ahead = env_int("ARP_STATIC_WITH_UPLOAD", 1);
-    if (static_ahead && polled && h.n > 0 && c->last_cutoff > 0) {
+    if (static_ahead && polled && h.n > 0 && c->last_cutoff > 0 && !after_batch) {
         c->ahead_seq = bc.seq;
         const int rc = ensure_static(c, c->last_cutoff);
         c->ahead_seq = 0;
