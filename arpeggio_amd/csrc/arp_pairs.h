@@ -947,8 +947,10 @@ __global__ __launch_bounds__(64 * SEARCH_WAVES, SEARCH_MIN_WAVES) void k_search(
         const long long T = start[g.ncell];
         int p0 = (int)((long long)vb * T / nb), p1 = (int)((long long)(vb + 1) * T / nb);
         if (blk_tile) {      // runs of atoms of equal WEIGHT (k_balance_atoms): a hint from an earlier pass over this grid
-            p0 = min(max(blk_tile[vb], 0), (int)T);
-            p1 = min(max(blk_tile[vb + 1], p0), (int)T);
+            // (the table is non-decreasing by construction; the first run begins at 0 and the last one ends at T whatever it says, so
+            // that the runs tile [0, T) for any such table)
+            p0 = (vb == 0) ? 0 : min(max(blk_tile[vb], 0), (int)T);
+            p1 = (vb == nb - 1) ? (int)T : min(max(blk_tile[vb + 1], p0), (int)T);
         }
         if (p1 > p0) {
             blk_begin = tile_of_cell(cell_of_pos[p0]);
