@@ -108,6 +108,10 @@ struct Bag {  // outputs of one ring/amide kernel, resident in HBM until fetched
 // (perm: the segment's elements — es bytes each — leave in the order perm[0], perm[1], ...: the canonical order of a small bag)
 struct PackSeg { const uint8_t* src; uint32_t dst, bytes; const uint32_t* perm; uint32_t es; };
 struct PackTable { PackSeg s[48]; int n; };
+// n 16-byte quads from the device to a page-locked host buffer (small results: see arp_fetch_packed)
+__global__ __launch_bounds__(256) void k_copy_quads(const int4* __restrict__ src, int4* __restrict__ dst, unsigned n) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void k_pack_segments(PackTable t, uint8_t* __restrict__ out) {
     const PackSeg g = t.s[blockIdx.y];        // segment blockIdx.y, spread over the gridDim.x blocks of its row
     if (g.perm) {
@@ -3293,7 +3297,25 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
         hipLaunchKernelGGL(k_pack_segments, pack_grid(t), dim3(256), 0, c->stream, t, c->sorted_slab.p);
         CHK(check_launch(c, "k_pack_segments"));
     }
-    if (total) HIPCHK(c, hipMemcpyAsync(host, c->sorted_slab.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (total) {
+        // A small piece (a protein's bags: a few hundred kilobytes) into a page-locked, device-visible buffer is written by a kernel:
+        // the copy engine needs ~10 us to get going, which is as long as such a copy takes (stand-in end to end 0.155 -> see
+        // profiles/README.md).  Anything larger, or a pageable buffer: the copy engine.
+        static const size_t direct_max = (size_t)std::max(0, env_int("ARP_FETCH_DIRECT_MAX_KB", 1024)) << 10;
+        void* host_dev = nullptr;
+        if (total <= direct_max && host_bytes >= ((total + 15) & ~(uint64_t)15) && c->sorted_slab.cap >= ((total + 15) & ~(size_t)15)) {      // (whole quads on both sides)
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) host_dev = at.devicePointer;
+            else (void)hipGetLastError();
+        }
+        if (host_dev && ((uintptr_t)host_dev & 15) == 0) {
+            const unsigned nq = (unsigned)((total + 15) / 16);
+            hipLaunchKernelGGL(k_copy_quads, dim3(nblocks(nq, 256, 1024)), dim3(256), 0, c->stream, (const int4*)c->sorted_slab.p, (int4*)host_dev, nq);
+            CHK(check_launch(c, "k_copy_quads"));
+        } else {
+            HIPCHK(c, hipMemcpyAsync(host, c->sorted_slab.p, total, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ARP_OK;
 }
