@@ -459,7 +459,9 @@ class Context:
             raise AttributeError("'NoneType' object has no attribute 'GetId'")
         if rc == ARP_E_ARG:
             raise ValueError(f'{what}: {msg}')
-        raise NativeLibraryError(f'{what} failed ({rc}): {msg}')
+        err = NativeLibraryError(f'{what} failed ({rc}): {msg}')
+        err.code = rc
+        raise err
 
     # ---- inputs ----
     def set_complex(self, pc):
@@ -790,7 +792,17 @@ class Context:
             rc = self._L.arp_fetch_packed(self._h, _p(buf), buf.nbytes, counts, offs, C.byref(used))
         if rc == ARP_E_CAPACITY and int(used.value) == 0:
             # a result too large for one piece (an array or the whole beyond 4 GiB): bag by bag, as before arp_fetch_packed
-            bags = {'atom_atom': self.atom_contacts_fetch(int(self._counts[0]), sort=True)}
+            # (counts[0]: what arp_fetch_packed filled before it failed — self._counts is only fresh after run_launch / run_wait)
+            try:
+                aa = self.atom_contacts_fetch(int(counts[0]), sort=True)
+            except NativeLibraryError as e:
+                if getattr(e, 'code', None) != ARP_E_CAPACITY:
+                    raise
+                # 2^31 records or more: beyond the device sort's tables — unsorted fetch, canonical order on the host
+                aa = self.atom_contacts_fetch(int(counts[0]), sort=False)
+                order = np.lexsort((aa['j'], aa['i']))
+                aa = {k: v[order] for k, v in aa.items()}
+            bags = {'atom_atom': aa}
             for name, _ in self._PACKED_BAGS:
                 bags[name] = self.fetch_bag(name, sort=sort_bags)
             return bags, buf

@@ -420,19 +420,42 @@ def template_bonds(residues, atom_index):
     return out
 
 
-def hydrogen_parent_by_name(hname, residue):
+def hydrogen_parent_by_name(hname, residue, coord=None):
     """The heavy atom a hydrogen of a standard residue is named after (wwPDB nomenclature: H + the parent's name without its
-    element letter + a counter — HA on CA, HB2 on CB, HG21 on CG2, HD1 on CD1 or ND1, HH on OH, H / H1..H3 on N): the heavy
-    atom of the residue whose name, less its first letter, is the longest prefix of the hydrogen's name less its 'H'."""
-    rem = hname.strip()[1:]
-    best, best_len = None, -1
+    element letter + a counter — HA on CA, HB2 on CB, HG21 on CG2, HD1 on CD1 or ND1, HH on OH, H / H1..H3 / HN on N): the heavy
+    atom of the residue whose name, less its first letter, is the longest NON-EMPTY prefix of the hydrogen's name less its 'H'.
+    Ties (MSE: SE and CE both reduce to 'E'; HD1 of HIS: CD1 absent, ND1 present — no tie there) go to the candidate that has a
+    template bond to a carbon-like parent first (a hydrogen named after a selenium / sulphur that has no hydrogens in the
+    template is a methyl hydrogen of the carbon), then to the nearest in space when ``coord`` is given.  The backbone N only
+    takes the names H, H1, H2, H3, HN, D: anything else that matches nothing stays unattached (None)."""
+    name = hname.strip()
+    if name in ('H', 'H1', 'H2', 'H3', 'HN', 'D'):
+        for a in residue.atoms:
+            if a.name.strip() == 'N':
+                return a
+        return None
+    rem = name[1:]
+    cands, best_len = [], 0
     for a in residue.atoms:
         if a.element in ('H', 'D'):
             continue
         suf = a.name.strip()[1:]
-        if rem.startswith(suf) and len(suf) > best_len and (suf or a.name.strip() == 'N'):
-            best, best_len = a, len(suf)
-    return best
+        if not suf or not rem.startswith(suf):
+            continue
+        if len(suf) > best_len:
+            cands, best_len = [a], len(suf)
+        elif len(suf) == best_len:
+            cands.append(a)
+    if not cands:
+        return None
+    if len(cands) == 1:
+        return cands[0]
+    # heteroatoms that carry no hydrogen in any standard residue / MSE template lose a tie against a carbon or nitrogen
+    pref = [a for a in cands if a.element not in ('SE', 'S')] or cands
+    if len(pref) > 1 and coord is not None:
+        c0 = np.asarray(coord, np.float64)
+        pref.sort(key=lambda a: float(np.sum((np.asarray(a.coord, np.float64) - c0) ** 2)))
+    return pref[0]
 
 
 def template_rings(residues, atom_index):
@@ -540,7 +563,7 @@ def read_mmcif(path, use_ambiguities=False, normalise=True):
     for h_ in np.nonzero(is_h & (parent < 0))[0] if n else ():        # a hydrogen of a standard residue too far from everything: by its name
         r_ = atoms[h_].residue
         if r_.name.strip() in RESIDUE_BONDS:
-            p_ = hydrogen_parent_by_name(atoms[h_].name, r_)
+            p_ = hydrogen_parent_by_name(atoms[h_].name, r_, atoms[h_].coord)
             if p_ is not None:
                 parent[h_] = atom_index[id(p_)]
     add_bonds(neighbours, [(int(p_), int(h_)) for h_, p_ in enumerate(parent) if p_ >= 0])

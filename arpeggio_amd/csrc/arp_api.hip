@@ -213,6 +213,7 @@ struct arp_ctx {
     int num_cu = 256;
     int search_resident = 768;          // blocks of k_search<MODE_CONTACTS> the chip holds at once (occupancy x CUs)
     int sift_per_cu = 4;                // blocks of the per-pair kernel a CU holds at once
+    bool xcd_round_robin = true;   // consecutive blocks of a launch land on XCDs (x0 + b) % 8 (arp_create's probe)
     uint64_t seg_last[PAIR_SEGS] = {0, 0, 0, 0, 0, 0, 0, 0};   // pairs per segment of the last contact pass (the next one's sift blocks are shared out by it)
 
     // ---- sizes
@@ -1585,7 +1586,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         SiftArgs sa{c->pairs.p, c->d_ctr + ctr_dev(C_SEG_PAIRS), (u64)segcap, c->s_xyzm.p, c->s_qa.p, c->s_h.p, {0, 0, 0, 0, 0, 0, 0, 0},
                           SiftSide{c->rad_tab.p, c->rad.p, c->xyz.p, c->h_off.p, c->bond_off.p, c->sb.p, c->longest_bond.p}, c->bond_idx.p, c->h_xyz_d.p,
                           c->has_gid ? c->gid.p : nullptr, vdw_comp, c->out_i.p, c->out_j.p, c->out_d.p, c->out_s.p, c->out_ct.p,
-                          (int*)(c->d_ctr + ctr_dev(C_ERR))};
+                          (int*)(c->d_ctr + ctr_dev(C_ERR)), c->xcd_round_robin ? 0 : 1};
         // No more sift blocks than the pairs can feed (one batch of 64 per wave and block at least): what the previous pass over
         // this structure found, or ~13 per heavy atom for the first one.  A protein-sized structure then runs 70-odd blocks
         // instead of 1024, whose start-up and end-of-pass tickets were most of the kernel (stand-in: 25 -> 16 us).
@@ -1961,6 +1962,23 @@ int arp_create(int device, arp_ctx** out) {
         set_create_error(hipGetErrorString(e));
         delete c;
         return ARP_E_HIP;
+    }
+    {   // k_sift deals its blocks to the pair-list segments by (XCD, blockIdx / 8): exact only if consecutive blocks of a launch go
+        // round-robin over eight XCDs (up to a rotation).  Looked at once; otherwise the blocks are dealt out by index (seg_by_block).
+        int* probe = nullptr;
+        int h_probe[64];
+        bool rr = false;
+        if (hipMalloc((void**)&probe, sizeof(h_probe)) == hipSuccess) {
+            hipLaunchKernelGGL(k_xcc_probe, dim3(64), dim3(64), 0, c->stream, probe);
+            if (hipMemcpyAsync(h_probe, probe, sizeof(h_probe), hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) {
+                rr = true;
+                for (int b = 0; b < 64; ++b) rr = rr && ((h_probe[b] - h_probe[0] - b) & 7) == 0;
+            }
+            (void)hipFree(probe);
+        }
+        (void)hipGetLastError();
+        static const int force_by_block = env_int("ARP_SIFT_SEG_BY_BLOCK", 0);
+        c->xcd_round_robin = rr && !force_by_block;
     }
     *out = c;
     return ARP_OK;
@@ -2494,6 +2512,23 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
     // its grid build (ARP_UPLOAD_ASIDE=0: behind the validation kernel on the main stream, where the static order of the first pass
     // then waits for them: 25 us of latency chains at 100 k atoms).  A structure that fails the validation has them thrown away
     // below: centres outside their box are clamped into it, nothing is written out of bounds.
+    // A failure behind the validation kernel (an allocation, a launch): its verdict is still on its way and kernels of the second
+    // stream may be reading the blob — wait for both streams, consume what was published, leave no structure resident.
+    auto abandon = [&](int rc) -> int {
+        const std::string why = c->err;
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        if (polled) (void)collect_counters(c); else (void)hipStreamSynchronize(c->stream);
+        c->err = why;
+        c->uplists_pending = false;
+        c->n = c->nres = c->nring = c->namide = 0;
+        c->blob_bytes = 0;
+        c->static_dirty = true; c->sp_radius = 0;
+        c->lists_dirty = true; c->lists_from_upload = false;
+        c->ring_grid.valid = false; c->amide_grid.valid = false;
+        c->sel_prefilled = false; c->sp_cnt_zeroed = 0;
+        c->ctr_zero_ok = false;
+        return rc;
+    };
     bool grids_made = false;
     if (with_upload) {
         c->ring_grid.valid = false; c->amide_grid.valid = false;
@@ -2508,9 +2543,12 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
         if (rc == ARP_OK && lists_with_upload) rc = ensure_plane_lists(c);      // (the four candidate lists need nothing else: see ar_enumerate)
         if (on_second) {
             std::swap(c->stream, c->stream2);
-            if (rc == ARP_OK) { HIPCHK(c, hipEventRecord(c->ev_uplists, c->stream2)); c->uplists_pending = true; }
+            if (rc == ARP_OK) {
+                if (hipEventRecord(c->ev_uplists, c->stream2) != hipSuccess) { c->err = "hipEventRecord failed (upload lists)"; rc = ARP_E_HIP; }
+                else c->uplists_pending = true;
+            }
         }
-        CHK(rc);
+        if (rc != ARP_OK) return abandon(rc);
         grids_made = true;
     }
     const bool ring_grid_made = grids_made && c->ring_grid.valid, amide_grid_made = grids_made && c->amide_grid.valid;
@@ -2525,7 +2563,7 @@ int validate_resident_blob(arp_ctx* c, const arp_blob_header& h, const char* who
         c->ahead_seq = bc.seq;
         const int rc = ensure_static(c, c->last_cutoff);
         c->ahead_seq = 0;
-        CHK(rc);
+        if (rc != ARP_OK) return abandon(rc);
     }
     int h_err[2] = {0, 0};
     if (polled) {

@@ -814,6 +814,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // (tools/micro/xcc_queue.hip: block b of a 768-block launch ran on XCD (b + 7) % 8)
 __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
 
+__global__ void k_xcc_probe(int* __restrict__ out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
+
 // (developer builds, tools/search_trace.py: per block of k_search<MODE_CONTACTS> {start, end of the cell loops, end} in
 // s_memrealtime ticks (100 MHz), the XCD and the hardware id of the block's first wave — g_search_trace, declared above)
 
@@ -865,7 +867,11 @@ __global__ __launch_bounds__(256) void k_cell_weights(GridDesc g, const int* __r
             // the test's price grows with the candidates of the cell, + 1 per 256 of them)
             const long long tests = (long long)n * cand;
             const long long v = (nhb * (w_unit + w_chunk * nch) + ((tests * w_test8 * (256 + cand)) >> 11) + 3) >> 2;
-            w = (int)min(v, (long long)(1 << 24));        // (the scan stays in 32 bits for 128 cells of that weight: clumps of thousands of atoms)
+            // (the running sum of the weights is a 32-bit scan: a cell's weight is capped so that ncell of them cannot pass 2^31 - 1 —
+            // the table k_balance_atoms makes of it must be non-decreasing, or the blocks' runs of home atoms would overlap or leave
+            // gaps; typical cells weigh a few thousand, only clumps meet the cap, and a capped clump is still a heavy cell)
+            const long long wcap = min((long long)(1 << 24), (long long)INT_MAX / (long long)max(g.ncell, 1));
+            w = (int)min(v, max(wcap, 1ll));
         }
         cw[c] = w;
     }
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(256) void k_balance_atoms(GridDesc g, const int* __
         const int n = start[lo + 1] - start[lo];
         const long long w = (long long)cwp[lo + 1] - cwp[lo];
         const int inside = (w > 0) ? (int)min((long long)n, (target - cwp[lo]) * n / w) : 0;
-        blk_pos[b] = min(start[lo] + inside, T);
+        blk_pos[b] = max(min(start[lo] + max(inside, 0), T), 0);
     }
 }
 
@@ -1581,6 +1587,8 @@ struct SiftArgs {
     uint16_t* out_s;
     uint8_t* out_ct;
     int* err;
+    int seg_by_block;       // 1: the segment of a sift block is vblock % 8 instead of the XCD it runs on (a device whose dispatcher does
+                            // not deal consecutive blocks round-robin over eight XCDs — a partitioned mode, CU masking: arp_create looks)
 };
 // Contact records are not read again on the device in the pass that writes them.  When there are more of them than L2 and the
 // Infinity Cache keep (1 M atoms: 190 MB), streaming stores let them leave while the kernel runs instead of in the write-back at
@@ -1669,7 +1677,9 @@ __device__ __forceinline__ void sift_body(const SiftArgs& A, int vblock, int vgr
     // The segments differ in size by a fifth (the search blocks of an XCD cover different parts of the box), the blocks of an
     // XCD are as many as every other's: a segment gets blocks in proportion to its size (nblk) — its own XCD's first, then
     // the ones other XCDs can spare, in a fixed order every block works out for itself.
-    int sgm = xcc_id();      // (blocks b with the same b % 8 share an XCD, whichever it is: vblock / 8 numbers the blocks of an XCD)
+    // (blocks b with the same b % 8 share an XCD, whichever it is: vblock / 8 numbers the blocks of an XCD — checked once per
+    // context by arp_create (k_xcc_probe); where it does not hold the blocks are dealt out by their index alone)
+    int sgm = A.seg_by_block ? (vblock & (PAIR_SEGS - 1)) : xcc_id();
     int blk_in_seg = vblock / PAIR_SEGS, blks_of_seg = vgrid / PAIR_SEGS;
     {
         const int B = vgrid / PAIR_SEGS;
