@@ -963,22 +963,36 @@ def main():
         if ns:      # the same figure with rocprofv3's average duration of the committed profile (HIP-event brackets read 1 - 2 us long)
             committed = {'avg_launch_ms': round(ns * 1e-6, 5), 'achieved': round(b_alg / (ns * 1e-9) / 1e9, 2),
                          'frac': round(b_alg / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 6), 'source': pj.get('source')}
-    # The number that actually bounds these kernels: VALU issue.  SQ_INSTS_VALU of the committed PMC run (per launch) /
-    # (launch duration x 1024 SIMDs x 2.4 GHz / 4 cycles: a wave64 instruction occupies its 16-lane SIMD four cycles)
-    VALU_PEAK = 1024 * 2.4e9 / 4.0
+    # The number that actually bounds these kernels: VALU issue.  SQ_INSTS_VALU of the committed PMC run (per launch) / launch duration
+    # against the MEASURED issue rates of this chip (tools/micro/valu_issue.hip -> profiles/round6_valu_issue.json): a wave64
+    # instruction of the plain VOP2 / f32-FMA kind issues every ~2.4 cycles per SIMD (SIMD-32 x 2 passes: 1.0e9 /s/SIMD), but packed
+    # f32, f64, compares, carries, three-operand integer forms and v_readlane — what the distance loop of k_search and the float64
+    # geometry of k_sift are made of — every ~4.2 cycles (0.58e9 /s/SIMD).  `frac` is against the full rate (a lower bound of how busy
+    # the VALUs are), `frac_half_rate` against the half rate (an upper bound); through round 5 an assumed 1024 x 2.4 GHz / 4 stood here.
+    VALU_PEAK, VALU_PEAK_HALF, valu_src = 1024 * 2.4e9 / 2.0, 1024 * 2.4e9 / 4.0, 'assumed: no profiles/round6_valu_issue.json'
+    try:
+        vj = json.load(open(os.path.join(ROOT, 'profiles', 'round6_valu_issue.json')))
+        VALU_PEAK = float(vj['valu_issue_peak_per_s_chip'])
+        VALU_PEAK_HALF = float(vj['valu_issue_half_rate_per_s_per_simd']) * int(vj['simds'])
+        valu_src = 'measured: profiles/round6_valu_issue.json (tools/micro/valu_issue.hip, all 1024 SIMDs, 8 waves per SIMD)'
+    except (OSError, ValueError, KeyError):
+        pass
     roofline_valu = None
     if pj is not None:
-        roofline_valu = {'issue_peak_per_s': VALU_PEAK, 'source': f'instruction counts from the committed profile, NOT this run ({pj.get("source")}); durations of this run', 'kernels': {}}
+        roofline_valu = {'issue_peak_per_s': VALU_PEAK, 'issue_peak_half_rate_per_s': VALU_PEAK_HALF, 'peak_source': valu_src,
+                         'source': f'instruction counts from the committed profile, NOT this run ({pj.get("source")}); durations of this run', 'kernels': {}}
         total_insts = 0
         for k_, ms_ in candidates_for_dominant.items():
             pv = pj['kernels'].get(f'k_{k_}', {})
             if 'valu_insts_per_launch' in pv:
                 total_insts += pv['valu_insts_per_launch']
+                rate = pv['valu_insts_per_launch'] / (ms_ * 1e-3)
                 roofline_valu['kernels'][f'k_{k_}'] = {'valu_wave_instructions_per_launch': pv['valu_insts_per_launch'],
-                                                       'frac': round(pv['valu_insts_per_launch'] / (ms_ * 1e-3) / VALU_PEAK, 4)}
+                                                       'frac': round(rate / VALU_PEAK, 4), 'frac_half_rate': round(rate / VALU_PEAK_HALF, 4)}
         if total_insts:
             roofline_valu['pass'] = {'valu_wave_instructions_per_pass': total_insts, 'ms_per_step': round(ms_per_step, 4),
-                                     'frac': round(total_insts / (ms_per_step * 1e-3) / VALU_PEAK, 4)}
+                                     'frac': round(total_insts / (ms_per_step * 1e-3) / VALU_PEAK, 4),
+                                     'frac_half_rate': round(total_insts / (ms_per_step * 1e-3) / VALU_PEAK_HALF, 4)}
     roofline = {'kernel': f'k_{dom}', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 6), 'traffic': traffic,
                 'traffic_source': (None if traffic_src is None else f'committed profile, NOT this run: {traffic_src}'),

@@ -6,8 +6,9 @@
 // (100 MHz, min over the waves' starts .. max over their ends, so the launch is not in it) and from HIP events; the shader clock
 // from s_memtime / s_memrealtime inside the same kernel (s_memtime counts shader cycles on gfx9) and — printed beside it — from
 // `rocm-smi --showclocks` if that is on the PATH.  Output: wave-instructions per second per SIMD and per chip, and cycles per
-// instruction per SIMD, for v_fma_f32, v_pk_fma_f32, v_cmp + v_addc (the pair k_search's distance loop is made of), v_add_u32,
-// v_fma_f64 and v_mul_lo_u32.
+// instruction per SIMD, for v_fma_f32, v_pk_fma_f32, v_cmp + v_addc (the pair k_search's distance loop is made of, in its SGPR and
+// its VCC encodings), the plain f32 / u32 VOP2 / VOP3 forms, the packed f32 and the f64 forms, v_mul_lo_u32, v_readlane_b32;
+// 1, 2, 4, 8 waves per SIMD each.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,10 +22,16 @@ typedef unsigned long long u64;
 #define ITER 2048
 #define UNROLL 64      // instructions per iteration (8 chains x 8)
 
-enum { K_FMA32 = 0, K_PKFMA32 = 1, K_CMP_ADDC = 2, K_ADD_U32 = 3, K_FMA64 = 4, K_MUL_LO = 5, K_KINDS = 6 };
-static const char* kind_name[K_KINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_cmp_le_f32+v_addc_co_u32", "v_add_u32", "v_fma_f64", "v_mul_lo_u32"};
-// VALU instructions one "step" of the kind issues (the cmp + addc pair is two)
-static const int kind_insts[K_KINDS] = {1, 1, 2, 1, 1, 1};
+enum { K_FMA32 = 0, K_PKFMA32, K_CMP_ADDC, K_ADD_U32, K_FMA64, K_MUL_LO, K_CMP_VCC, K_CMP_SGPR, K_ADDC_VCC, K_CMP_ADDC_VCC, K_CNDMASK, K_SUB_F32,
+       K_MUL_F32, K_FMAC_F32, K_PK_ADD_F32, K_PK_MUL_F32, K_LSHL_OR, K_AND_OR, K_ADD_F64, K_MUL_F64, K_READLANE, K_ADD3, K_KINDS };
+static const char* kind_name[K_KINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_cmp_le_f32_e64(sgpr)+v_addc_co_u32_e64", "v_add_u32", "v_fma_f64", "v_mul_lo_u32",
+                                         "v_cmp_le_f32_e32(vcc)", "v_cmp_le_f32_e64(sgpr)", "v_addc_co_u32_e32(vcc)", "v_cmp_le_f32_e32+v_addc_co_u32_e32(vcc)",
+                                         "v_cndmask_b32_e32(vcc)", "v_sub_f32", "v_mul_f32", "v_fmac_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_lshl_or_b32",
+                                         "v_and_or_b32", "v_add_f64", "v_mul_f64", "v_readlane_b32", "v_add3_u32"};
+// VALU instructions one "step" of the kind issues (the cmp + addc pairs are two)
+static const int kind_insts[K_KINDS] = {1, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+// kinds that count towards the "plain full-rate" peak bench.py uses
+static const bool kind_plain[K_KINDS] = {true, false, false, true, false, false, false, false, false, false, true, true, true, true, false, false, true, true, false, false, false, true};
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -56,6 +63,22 @@ __global__ __launch_bounds__(512) void k_issue(u64* __restrict__ t_out, float* _
                 if (KIND == K_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[k]) : "v"(one));
                 if (KIND == K_FMA64) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[k]) : "v"(dm), "v"(dc));
                 if (KIND == K_MUL_LO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[k]) : "v"(2654435761u));
+                if (KIND == K_CMP_VCC) asm volatile("v_cmp_le_f32_e32 vcc, %0, %1" :: "v"(a[k]), "v"(m) : "vcc");
+                if (KIND == K_CMP_SGPR) { u64 msk; asm volatile("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(msk) : "v"(a[k]), "v"(m)); }
+                if (KIND == K_ADDC_VCC) asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(u[k]) :: "vcc");
+                if (KIND == K_CMP_ADDC_VCC) asm volatile("v_cmp_le_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(u[k]) : "v"(a[k]), "v"(m) : "vcc");
+                if (KIND == K_CNDMASK) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(u[k]) : "v"(one) : "vcc");
+                if (KIND == K_SUB_F32) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+                if (KIND == K_MUL_F32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(m));
+                if (KIND == K_FMAC_F32) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
+                if (KIND == K_PK_ADD_F32) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pc));
+                if (KIND == K_PK_MUL_F32) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pm));
+                if (KIND == K_LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(u[k]) : "v"(one));
+                if (KIND == K_AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(u[k]) : "v"(one));
+                if (KIND == K_ADD_F64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[k]) : "v"(dc));
+                if (KIND == K_MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[k]) : "v"(dm));
+                if (KIND == K_READLANE) { uint32_t sv; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sv) : "v"(u[k])); }
+                if (KIND == K_ADD3) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(u[k]) : "v"(one));
             }
         }
     }
@@ -77,7 +100,7 @@ template <int KIND>
 static int run_kind(int num_cu, u64* d_t, float* d_sink, std::vector<u64>& h_t, std::vector<Row>& rows) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int wps = 1; wps <= 8; ++wps) {
+    for (int wps = 1; wps <= 8; wps = (wps < 2 ? 2 : wps * 2)) {
         // one block per CU with 4 * wps waves: the dispatcher spreads a block's waves over the CU's four SIMDs
         const int threads = 64 * 4 * wps;
         const int blocks = num_cu;
@@ -125,12 +148,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_sink, 64));
     std::vector<u64> h_t(maxw * 4);
     std::vector<Row> rows;
-    if (run_kind<K_FMA32>(num_cu, d_t, d_sink, h_t, rows)) return 1;
-    if (run_kind<K_PKFMA32>(num_cu, d_t, d_sink, h_t, rows)) return 1;
-    if (run_kind<K_CMP_ADDC>(num_cu, d_t, d_sink, h_t, rows)) return 1;
-    if (run_kind<K_ADD_U32>(num_cu, d_t, d_sink, h_t, rows)) return 1;
-    if (run_kind<K_FMA64>(num_cu, d_t, d_sink, h_t, rows)) return 1;
-    if (run_kind<K_MUL_LO>(num_cu, d_t, d_sink, h_t, rows)) return 1;
+#define RUN(K) if (run_kind<K>(num_cu, d_t, d_sink, h_t, rows)) return 1
+    RUN(K_FMA32); RUN(K_PKFMA32); RUN(K_CMP_ADDC); RUN(K_ADD_U32); RUN(K_FMA64); RUN(K_MUL_LO); RUN(K_CMP_VCC); RUN(K_CMP_SGPR); RUN(K_ADDC_VCC);
+    RUN(K_CMP_ADDC_VCC); RUN(K_CNDMASK); RUN(K_SUB_F32); RUN(K_MUL_F32); RUN(K_FMAC_F32); RUN(K_PK_ADD_F32); RUN(K_PK_MUL_F32); RUN(K_LSHL_OR);
+    RUN(K_AND_OR); RUN(K_ADD_F64); RUN(K_MUL_F64); RUN(K_READLANE); RUN(K_ADD3);
     std::string smi;
     if (FILE* f = popen("rocm-smi --showclocks 2>/dev/null | grep -i sclk | head -2", "r")) {
         char buf[256];
@@ -144,11 +165,11 @@ int main(int argc, char** argv) {
         // the figure bench.py uses: the best sustained rate of the plain one-pass VALU kinds (f32 fma / u32 add / cmp + addc)
         double peak = 0, peak_mhz = 0;
         for (const Row& r : rows)
-            if ((r.kind == K_FMA32 || r.kind == K_ADD_U32 || r.kind == K_CMP_ADDC) && r.inst_per_s_simd > peak) { peak = r.inst_per_s_simd; peak_mhz = r.mhz; }
+            if (kind_plain[r.kind] && r.inst_per_s_simd > peak) { peak = r.inst_per_s_simd; peak_mhz = r.mhz; }
         fprintf(f, "{\"device\": \"%s\", \"num_cu\": %d, \"simds\": %d, \"iter\": %d, \"unroll\": %d,\n", prop.gcnArchName, num_cu, num_cu * 4, ITER, UNROLL);
         fprintf(f, " \"valu_issue_peak_per_s_per_simd\": %.6e, \"valu_issue_peak_per_s_chip\": %.6e, \"shader_clock_mhz_measured\": %.1f,\n", peak, peak * num_cu * 4, peak_mhz);
         fprintf(f, " \"cycles_per_wave64_instruction\": %.4f,\n", peak_mhz * 1e6 / peak);
-        for (size_t i = 0; i < smi.size(); ++i) if (smi[i] == '"' || smi[i] == '\n' || smi[i] == '\\') smi[i] = ' ';
+        for (size_t i = 0; i < smi.size(); ++i) if (smi[i] == '"' || smi[i] == '\\' || (unsigned char)smi[i] < 32) smi[i] = ' ';
         fprintf(f, " \"rocm_smi_sclk\": \"%s\",\n \"rows\": [\n", smi.c_str());
         for (size_t i = 0; i < rows.size(); ++i) {
             const Row& r = rows[i];
