@@ -328,19 +328,25 @@ def config5(n_rings: int = 10_000, n_amides: int = 10_000, seed: int = 5, L: flo
     return make_synthetic(0, seed=seed, box=(L, L, L), n_rings=n_rings, n_amides=n_amides, id='rings_10k')
 
 
-def slab_config(n_per_slab: int, n_slabs: int, seed: int = 4) -> PackedComplex:
+def slab_box(n_total: int, box_slabs: int):
+    """Box of the slab family: ``box_slabs`` cubes of n_total / box_slabs atoms (rho = 0.05 / A^3) side by side along x."""
+    L = ((n_total / box_slabs) / 0.05) ** (1.0 / 3.0)
+    return (L * box_slabs, L, L)
+
+
+def slab_config(n_per_slab: int, n_slabs: int, seed: int = 4, box_slabs: int = None) -> PackedComplex:
     """BASELINE.json configs[3] family: n_slabs * n_per_slab atoms, box elongated along x
-    so that each slab is the config-3 cube (weak scaling)."""
+    so that each slab is the config-3 cube (weak scaling).  ``box_slabs``: the box is that of ``box_slabs`` cubes whatever
+    ``n_slabs`` is — ONE structure (configs[3] itself: 2 M atoms, box_slabs = 8) cut into 1, 2, 4 or 8 slabs (strong scaling)."""
     n = n_per_slab * n_slabs
-    L = (n_per_slab / 0.05) ** (1.0 / 3.0)
     n_rings, n_amides = n // 100, n // 50
-    return make_synthetic(n - 6 * n_rings - 4 * n_amides, seed=seed, box=(L * n_slabs, L, L), n_rings=n_rings,
+    return make_synthetic(n - 6 * n_rings - 4 * n_amides, seed=seed, box=slab_box(n, box_slabs or n_slabs), n_rings=n_rings,
                           n_amides=n_amides, id=f'slab_{n_slabs}x{n_per_slab}')
 
 
 
 def slab_home_records(n_per_slab: int, n_slabs: int, rank: int, seed: int = 4, bond_radius: float = 1.7,
-                      water_frac: float = 0.05, atoms_per_residue: int = 8, residues_per_chain: int = 300):
+                      water_frac: float = 0.05, atoms_per_residue: int = 8, residues_per_chain: int = 300, box_slabs: int = None):
     """What rank ``rank`` of ``n_slabs`` owns of ``slab_config(n_per_slab, n_slabs, seed)`` — the records ``sharding.pack_records``
     would cut out of the whole structure, bit for bit — WITHOUT building the whole structure: every per-atom quantity of the
     synthetic model is a function of (seed, index), so a rank evaluates them for its slab (plus the 1.7 A of neighbours its
@@ -348,10 +354,9 @@ def slab_home_records(n_per_slab: int, n_slabs: int, rank: int, seed: int = 4, b
     behind the residue numbering, ring / amide positions).  Returns (records, book) for ``sharding.shard_records_to_device``."""
     from . import sharding
     n = n_per_slab * n_slabs
-    L = (n_per_slab / 0.05) ** (1.0 / 3.0)
     n_rings, n_amides = n // 100, n // 50
     n_uniform = n - 6 * n_rings - 4 * n_amides
-    box = np.asarray((L * n_slabs, L, L), np.float64)
+    box = np.asarray(slab_box(n, box_slabs or n_slabs), np.float64)      # (box_slabs: see slab_config)
     origin = np.zeros(3)
     n_ring_atoms = 6 * n_rings
     # ---- columns of ALL atoms the partition and the residue numbering need

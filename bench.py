@@ -64,6 +64,7 @@ def parse():
                          'every step) although the whole-structure selection of the benchmark does not need it')
     ap.add_argument('--cpu-sample-atoms', type=int, default=100_000)
     ap.add_argument('--no-other-configs', action='store_true', help='skip the stand-in (configs[0], [1]) and rings (configs[4]) legs of the default N = 1 run')
+    ap.add_argument('--no-config4', action='store_true', help='skip the strong-scaling leg (BASELINE configs[3]: ONE 2 M-atom structure cut into N slabs)')
     ap.add_argument('--dry-run', action='store_true',
                     help='everything a --gpus N launch does up to (not including) the first HIP call: environment, rank -> device mapping, '
                          'rendezvous of the ranks, broadcast of a 128-byte id, barrier, reduction; prints one JSON line on rank 0 (tests/test_sharding.py)')
@@ -200,6 +201,57 @@ def other_single_gpu_configs(args, device):
     return out
 
 
+CONFIG4_ATOMS, CONFIG4_BOX_SLABS = 2_000_000, 8      # BASELINE configs[3]: eight 250 k-atom cubes side by side along x
+
+
+def config4_workload(world):
+    return (f'BASELINE configs[3]: ONE synthetic structure of {CONFIG4_ATOMS} atoms (synth.slab_config(250000, 8): box of eight config-3-density cubes along x, '
+            f'rho = 0.05 / A^3, 5 A cutoff), whole structure, cut into {world} x-slab{"s" if world > 1 else ""} of {CONFIG4_ATOMS // world} atoms'
+            + (' (+ one-cell halo over RCCL)' if world > 1 else ' on one GPU'))
+
+
+def config4_single_gpu(args, device):
+    """multi_gpu.config4_strong at N = 1 (and configs.config4_2m_atoms): the 2 M-atom structure of BASELINE configs[3] on ONE GPU —
+    resident passes that build their grid, wall clock of a fresh upload + first pass + sorted fetch, SURVEY 8d roofline of the
+    longest kernel.  The same structure is cut into N x-slabs by `--gpus N` (strong scaling)."""
+    from arpeggio_amd import synth, _capi
+    t0 = time.perf_counter()
+    pc = synth.slab_config(CONFIG4_ATOMS // CONFIG4_BOX_SLABS, CONFIG4_BOX_SLABS, seed=4)
+    gen_s = time.perf_counter() - t0
+    cx = _capi.Context(device)
+    try:
+        cx.set_grid_reuse(False)
+        blob = _capi.pack_blob(pc)
+        walls, buf = [], None
+        for _ in range(3):
+            cx.device_synchronize()
+            tt = time.perf_counter()
+            cx.set_blob(blob)
+            cnt = cx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+            bags, buf = cx.fetch_packed(buf)
+            walls.append(time.perf_counter() - tt)
+        k_aa = bags['atom_atom']
+        assert len(k_aa['i']) == cnt['atom_atom']
+        step = lambda: cx.run_launch(args.cutoff, args.vdw_comp, False, 6.0)
+        ms, n, cnt = _timed_passes(step, min_s=1.0, min_n=20, warm=3)
+        st = cx.stats()
+        kus = _kernel_us(cx, step, n=10)
+        b_pass = 140 * st['binned'] + 16 * st['emitted']
+        return {'workload': config4_workload(1), 'n_gpus': 1, 'atoms_per_gpu': CONFIG4_ATOMS,
+                'ms_per_step': round(ms, 4), 'steps': n, 'value': round(st['candidates'] / (ms * 1e-3), 1), 'unit': 'candidate atom-pairs/s',
+                'step_definition': 'one whole run_arpeggio pass over the resident structure that builds its contact grid',
+                'pairs': {'candidates': int(st['candidates']), 'accepted': int(st['accepted']), 'contacts_emitted': int(st['emitted'])},
+                'bags': {k: int(v) for k, v in cnt.items()}, 'kernel_us': {k: round(v, 2) for k, v in kus.items()},
+                'wall_clock_per_structure_ms': round(min(walls[1:]) * 1e3, 3),
+                'wall_clock_per_structure_definition': 'arp_set_blob (one H2D copy + device-side validation) + first pass + device sort + one-copy fetch of all five bags; best of the last two of three',
+                'roofline': _dominant_roofline(kus, st),
+                'roofline_pass': {'bytes_per_pass': int(b_pass), 'bytes_model': 'SURVEY 8d: B_alg = 140 N + 16 P', 'achieved': round(b_pass / (ms * 1e-3) / 1e9, 2),
+                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(b_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                'structure_generation_s_host': round(gen_s, 1)}
+    finally:
+        cx.close()
+
+
 def other_configs_cpu_baselines(args, cfg):
     """cpu_baseline of the configurations of other_single_gpu_configs: the C oracle (oracle/ref_c.c) on ONE host core, a couple of
     seconds each, on the same structures."""
@@ -273,7 +325,10 @@ def dry_run(args, rank, local_rank, world, timeout):
     if rdzv is not None:
         rdzv.barrier()
     if rank == 0:
-        print(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks': everybody, 'allreduce_sum': total,
+        # the legs a real run of this launch adds to its line beside the weak-scaling headline (multi_gpu.*)
+        strong = (args.atoms == 100_000 and not args.no_config4 and CONFIG4_ATOMS % world == 0 and (world > 1 or not args.no_other_configs))
+        legs = {'config4_strong': {'workload': config4_workload(world), 'n_gpus': world, 'atoms_per_gpu': CONFIG4_ATOMS // world, 'scaling': 'strong'} if strong else None}
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks': everybody, 'allreduce_sum': total, 'legs': legs,
                           'config': {'workload': per_gpu_workload(args.atoms), 'atoms_per_gpu': args.atoms}}), flush=True)
     if rdzv is not None:
         rdzv.barrier()
@@ -894,9 +949,56 @@ def main():
                                     'ms_per_step': round(el_4 / n_4 * 1e3, 4), 'steps': n_4, 'value': round(c4 * n_4 / el_4, 1), 'unit': 'candidate atom-pairs/s',
                                     'contacts_emitted': red_sum(float(st_4['emitted'])), 'shard_setup_ms_incl_record_generation': round(setup4 * 1e3, 2),
                                     'halo_exchange_ms_rank0': round(getattr(sh_4, 'halo_ms', 0.0), 3)}
+            # (d) strong scaling: BASELINE configs[3] itself — ONE 2 M-atom structure — cut into `world` slabs, at every N
+            if args.atoms == 100_000 and not args.no_config4 and CONFIG4_ATOMS % world == 0:
+                per = CONFIG4_ATOMS // world
+                ts4, sh_4s = [], None
+                home4 = None if (comm_device is None or args.host_halo) else synth.slab_home_records(per, world, rank, seed=4, box_slabs=CONFIG4_BOX_SLABS)
+                full4 = synth.slab_config(per, world, seed=4, box_slabs=CONFIG4_BOX_SLABS) if home4 is None else None      # (debug transports only)
+                for k in range(2):
+                    sync_all()
+                    tt = time.perf_counter()
+                    if home4 is None:
+                        sh_4s = sharding.make_shard_distributed(full4, rank, world, transport)
+                        sharding.upload_shard(ctx, sh_4s, whole_structure=True)
+                    else:
+                        sh_4s = sharding.make_shard_device(ctx, home4, rank, world, whole_structure=True)
+                    sharding.run_shard_whole_structure(ctx, args.cutoff, args.vdw_comp, False)
+                    ctx.fetch_packed()
+                    ts4.append(time.perf_counter() - tt)
+                wall4 = red_max(ts4[-1])
+                step4s = lambda: sharding.run_shard_whole_structure(ctx, args.cutoff, args.vdw_comp, False)
+                for _ in range(3):
+                    step4s()
+                sync_all()
+                n_4s = max(10, min(args.steps, 50))
+                tt = time.perf_counter()
+                for _ in range(n_4s):
+                    step4s()
+                sync_all()
+                el_4s = red_max(time.perf_counter() - tt)
+                st_4s = ctx.stats()
+                c4s = red_sum(float(st_4s['candidates']))
+                multi['config4_strong'] = {'workload': config4_workload(world), 'n_gpus': world, 'atoms_per_gpu': per, 'scaling': 'strong',
+                                           'ms_per_step': round(el_4s / n_4s * 1e3, 4), 'steps': n_4s, 'value': round(c4s * n_4s / el_4s, 1), 'unit': 'candidate atom-pairs/s',
+                                           'step_definition': 'one whole-structure pass of every rank over its resident slab + halo that builds its contact grid; max over ranks',
+                                           'contacts_emitted': red_sum(float(st_4s['emitted'])),
+                                           'wall_clock_per_structure_ms': round(wall4 * 1e3, 3),
+                                           'wall_clock_per_structure_definition': 'shard set-up from resident home records (upload + faces cut on the device + arp_shard_exchange_faces over RCCL + merge) + first pass + fetch of the rank\'s five bags; second of two, max over ranks',
+                                           'halo_exchange_ms_rank0': round(getattr(sh_4s, 'halo_ms', 0.0), 3)}
             # back to the headline's shard (nothing below reads device state, but a later leg might)
         except Exception as exc:   # never lose the main line over the extra measurements
             multi['error'] = repr(exc)      # (a rank that fails alone leaves the others in a collective: the rendezvous' time-out ends the run)
+
+    if world == 1 and args.workload == 'config3' and args.atoms == 100_000 and not args.no_other_configs and not args.no_config4:
+        try:
+            c4 = config4_single_gpu(args, local_rank)
+            multi = {'config4_strong': dict(c4, scaling='strong')}
+            if other_configs is not None and 'error' not in other_configs:
+                other_configs['config4_2m_atoms'] = c4
+        except Exception as exc:   # never lose the main line over the extra measurement
+            multi = {'config4_strong': {'error': repr(exc)}}
+        t_gpu_legs_done = time.perf_counter()
 
     # max over ranks of the elapsed time, sum over ranks of the work
     cand, acc, emitted = st['candidates'], st['accepted'], st['emitted']
@@ -1117,6 +1219,15 @@ def main():
             other_configs_cpu_baselines(args, other_configs)
         except Exception as exc:
             other_configs['cpu_baseline_error'] = repr(exc)
+    if cpu is not None and multi and 'config4_strong' in multi and 'pairs' in multi['config4_strong'] and world == 1:
+        c4 = multi['config4_strong']
+        cb = {'value': cpu['value'], 'unit': 'candidate atom-pairs/s', 'cores': 1, 'kind': 'port',
+              'ms_per_structure_extrapolated': round(c4['pairs']['candidates'] / cpu['value'] * 1e3, 1),
+              'sample': 'SAMPLED: the C oracle on one host core over the headline\'s 100 000-atom structure of the same density and cutoff (cpu_baseline of this line: '
+                        f"{cpu['ms_per_structure']} ms per pass); a whole 2 M-atom pass at that rate would take the extrapolated figure — it was not run"}
+        c4['cpu_baseline'] = cb
+        if other_configs is not None and 'config4_2m_atoms' in other_configs:
+            other_configs['config4_2m_atoms']['cpu_baseline'] = cb
     if ligand_pass is None and other_configs is not None:
         ligand_pass = other_configs.get('standin_ligand')
     e2e_ms_sorted = (end_to_end or {}).get('ms_per_structure')

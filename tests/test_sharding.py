@@ -359,6 +359,10 @@ def test_bench_gpus_2_as_the_driver_launches_it_up_to_the_first_hip_call():
     one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry-run'], capture_output=True, text=True, timeout=120, cwd=root)
     one_line = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith('{')][-1])
     assert one_line['config'] == first['config'] == four['config'] and one_line['config']['atoms_per_gpu'] == 100_000
+    # the strong-scaling leg (BASELINE configs[3]: ONE 2 M-atom structure cut into N slabs) is part of the line at EVERY N, N = 1 included
+    for n, line in ((1, one_line), (2, first), (4, four), (8, eight)):
+        leg = line['legs']['config4_strong']
+        assert leg['n_gpus'] == n and leg['atoms_per_gpu'] * n == 2_000_000 and leg['scaling'] == 'strong' and '2000000 atoms' in leg['workload']
 
 
 def test_bench_rendezvous_times_out_when_a_rank_is_missing():
@@ -412,18 +416,21 @@ def test_rendezvous_ignores_strangers():
     assert [g[0] for g in got] == [0, 1] and all(g[1] == b'id-of-rank-0' for g in got)
 
 
-@pytest.mark.parametrize('n_per_slab,world', [(5000, 3), (3000, 2)])
-def test_a_rank_generates_its_own_slab(n_per_slab, world):
+@pytest.mark.parametrize('n_per_slab,world,box_slabs', [(5000, 3, None), (3000, 2, None), (3000, 2, 4), (6000, 1, 4)])
+def test_a_rank_generates_its_own_slab(n_per_slab, world, box_slabs):
     """synth.slab_home_records: what a rank owns of slab_config(...) WITHOUT the whole structure in its memory — every field of
     the records sharding.pack_records cuts out of the whole structure, same dtypes, same bytes; and the record buffer
     (the C ABI's packer on the records alone) equals the one the native packer makes from the whole structure."""
     from arpeggio_amd import _capi
-    full = synth.slab_config(n_per_slab, world, seed=4)
+    full = synth.slab_config(n_per_slab, world, seed=4, box_slabs=box_slabs)
+    if box_slabs:      # strong scaling (bench.py's config4_strong): ONE structure whatever the number of slabs it is cut into
+        same = synth.slab_config(n_per_slab * world // box_slabs, box_slabs, seed=4)
+        assert np.array_equal(same.xyz, full.xyz) and np.array_equal(same.bond_idx, full.bond_idx) and np.array_equal(same.h_xyz, full.h_xyz)
     edges, a_own, r_own, m_own = sharding._partition(full, world, sharding.halo_width())
     for rank in range(world):
         ids = [np.nonzero(o == rank)[0] for o in (a_own, r_own, m_own)]
         want = sharding.pack_records(full, *ids)
-        got, book = synth.slab_home_records(n_per_slab, world, rank, seed=4)
+        got, book = synth.slab_home_records(n_per_slab, world, rank, seed=4, box_slabs=box_slabs)
         assert np.array_equal(book['edges'], edges) and book['n_res_global'] == full.n_residues and book['n_atoms_global'] == full.n_atoms
         assert np.array_equal(book['home_x'], full.xyz[ids[0], 0].astype(np.float64))
         assert set(got) == set(want)
