@@ -46,6 +46,55 @@ def device_count():
     return int(load().arp_device_count())
 
 
+def _declare_host_entry_points(L):
+    """argtypes of the host-only entry points (mmCIF reader, JSON writer): the same in both libraries."""
+    vp, i64, dbl, i32 = C.c_void_p, C.c_int64, C.c_double, C.c_int
+    L.arp_cif_open.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_uint64]
+    L.arp_cif_close.argtypes = [vp]
+    L.arp_cif_close.restype = None
+    L.arp_cif_rows.argtypes = [vp]
+    L.arp_cif_rows.restype = C.c_int64
+    L.arp_cif_cols.argtypes = [vp]
+    L.arp_cif_blocks.argtypes = [vp]
+    L.arp_cif_tag.argtypes = [vp, i32]
+    L.arp_cif_tag.restype = C.c_char_p
+    L.arp_cif_text.argtypes = [vp]
+    L.arp_cif_text.restype = vp
+    L.arp_cif_column.argtypes = [vp, i32, vp, vp, vp]
+    L.arp_cif_column_f64.argtypes = [vp, i32, dbl, vp, C.POINTER(i64)]
+    L.arp_cif_column_i64.argtypes = [vp, i32, i64, vp, C.POINTER(i64)]
+    L.arp_write_contacts_json.argtypes = [C.c_char_p, i32, i32, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_char_p, i64]
+
+
+HOST_LIB_PATH = os.path.join(_HERE, 'csrc', 'libarpeggio_host.so')
+HOST_SYMBOLS = ('arp_cif_open', 'arp_cif_close', 'arp_cif_rows', 'arp_cif_cols', 'arp_cif_blocks', 'arp_cif_tag', 'arp_cif_text', 'arp_cif_column',
+                'arp_cif_column_f64', 'arp_cif_column_i64', 'arp_write_contacts_json')
+_host_lib = None
+
+
+def load_host():
+    """The library for the HOST-ONLY entry points (the mmCIF category reader, the JSON writer of the records): the HIP library
+    when it has been built — it holds them too —, otherwise ``libarpeggio_host.so``, the same sources (csrc/arp_cif.h,
+    arp_cif_api.h, arp_json.h) compiled with g++ (``arpeggio_amd.build.build_host``; built on first use).  No compute entry
+    point lives there: a machine without hipcc can read files and regenerate the golden fixtures, nothing more."""
+    global _host_lib
+    if _lib is not None:
+        return _lib
+    if _host_lib is not None:
+        return _host_lib
+    if os.path.exists(LIB_PATH):
+        return load()
+    from . import build as _build
+    path = _build.build_host()
+    try:
+        L = C.CDLL(path)
+    except OSError as e:
+        raise NativeLibraryError(f'cannot load {path}: {e}') from e
+    _declare_host_entry_points(L)
+    _host_lib = L
+    return L
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -101,21 +150,7 @@ def load():
     L.arp_shard_assemble.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, i64, vp]
     L.arp_shard_layout.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.arp_get_blob.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
-    L.arp_cif_open.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_uint64]
-    L.arp_cif_close.argtypes = [vp]
-    L.arp_cif_close.restype = None
-    L.arp_cif_rows.argtypes = [vp]
-    L.arp_cif_rows.restype = C.c_int64
-    L.arp_cif_cols.argtypes = [vp]
-    L.arp_cif_blocks.argtypes = [vp]
-    L.arp_cif_tag.argtypes = [vp, i32]
-    L.arp_cif_tag.restype = C.c_char_p
-    L.arp_cif_text.argtypes = [vp]
-    L.arp_cif_text.restype = vp
-    L.arp_cif_column.argtypes = [vp, i32, vp, vp, vp]
-    L.arp_cif_column_f64.argtypes = [vp, i32, dbl, vp, C.POINTER(i64)]
-    L.arp_cif_column_i64.argtypes = [vp, i32, i64, vp, C.POINTER(i64)]
-    L.arp_write_contacts_json.argtypes = [C.c_char_p, i32, i32, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_char_p, i64]
+    _declare_host_entry_points(L)
     L.arp_device_buffer.argtypes = [vp, i32, C.POINTER(C.c_uint64), C.POINTER(i64)]
     L.arp_run_stage.argtypes = [vp, i32, dbl, dbl, i32, dbl, vp]
     L.arp_set_group_ownership.argtypes = [vp, vp, vp, vp, vp]
@@ -352,7 +387,7 @@ class CifCategory:
     plus bulk numeric access for the big ``_atom_site`` table."""
 
     def __init__(self, text, category):
-        self._L = load()
+        self._L = load_host()
         raw = text.encode('utf-8') if isinstance(text, str) else bytes(text)
         h, err = C.c_void_p(), C.create_string_buffer(256)
         rc = self._L.arp_cif_open(raw, len(raw), category.encode(), C.byref(h), err, 256)

@@ -43,7 +43,25 @@ def build(force=False, verbose=False):
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
     build_pyexport(force)
+    build_host(force)
     return LIB
+
+
+HOST_LIB = os.path.join(CSRC, 'libarpeggio_host.so')
+HOST_DEPS = ['arp_host.cpp', 'arp_cif.h', 'arp_cif_api.h', 'arp_json.h']
+
+
+def build_host(force=False):
+    """libarpeggio_host.so: the host-only entry points (mmCIF reader, JSON writer) with g++ — no hipcc, no GPU.  What
+    tests/golden/make_golden*.py and the file reader need on a machine where the HIP library cannot be built."""
+    deps = [os.path.join(CSRC, f) for f in HOST_DEPS] + [os.path.join(HERE, '..', 'include', 'arpeggio_hip.h')]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    cxx = shutil.which('g++') or shutil.which('c++') or shutil.which('clang++')
+    if not cxx:
+        raise RuntimeError('no C++ compiler for libarpeggio_host.so')
+    subprocess.run([cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', os.path.join(CSRC, 'arp_host.cpp'), '-o', HOST_LIB, '-lpthread'], check=True)
+    return HOST_LIB
 
 
 PYEXPORT = os.path.join(HERE, '_pyexport.so')

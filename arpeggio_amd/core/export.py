@@ -207,7 +207,7 @@ def write_contacts_json(path, pc, bags, component_types, indent=4):
     import json
 
     from .. import _capi
-    L = _capi.load()
+    L = _capi.load_host()      # (host-only entry point: the HIP library, or the g++-built libarpeggio_host.so when that is absent)
     pc.ensure_labels()
     tail = contacts_json(pc, {k: v for k, v in bags.items() if k != 'atom_atom'}, component_types)
     pad = ' ' * indent

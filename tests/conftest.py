@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: minutes of CPU (the whole make_golden_core.py); runs only with ARP_RUN_SLOW=1')
 
 
 @pytest.fixture(scope='session')

@@ -806,13 +806,14 @@ def main():
         mode='canonical')
     exports['proteinlike_small:whole'] = exp
 
-    np.savez_compressed(os.path.join(HERE, 'core_cases.npz'), **arrays)
-    json.dump(meta, open(os.path.join(HERE, 'core_cases.json'), 'w'), indent=1)
+    OUT = os.environ.get('ARP_GOLDEN_OUT', HERE)      # (tests/test_fixture_freshness.py regenerates into a scratch directory)
+    np.savez_compressed(os.path.join(OUT, 'core_cases.npz'), **arrays)
+    json.dump(meta, open(os.path.join(OUT, 'core_cases.json'), 'w'), indent=1)
     # exports: JSON / CSV text, gzip (mtime 0: reproducible bytes)
     buf = io.BytesIO()
     with gzip.GzipFile(fileobj=buf, mode='wb', mtime=0) as gz:
         gz.write(json.dumps(exports, sort_keys=True).encode())
-    open(os.path.join(HERE, 'core_exports.json.gz'), 'wb').write(buf.getvalue())
+    open(os.path.join(OUT, 'core_exports.json.gz'), 'wb').write(buf.getvalue())
     print('sha256 of exports:', hashlib.sha256(buf.getvalue()).hexdigest()[:16], len(buf.getvalue()), 'bytes')
     print(len(meta), 'cases written')
 

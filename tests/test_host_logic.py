@@ -130,6 +130,25 @@ def test_product_fails_loudly_without_gpu():
         ic.run_arpeggio([], 5.0, 0.1, False)
 
 
+def test_host_only_library_has_the_reader_and_the_writer_and_nothing_that_computes(tmp_path):
+    """libarpeggio_host.so (g++, arpeggio_amd.build.build_host): the mmCIF reader and the JSON writer of include/arpeggio_hip.h —
+    what the fixture generators need on a machine without hipcc — and no compute entry point."""
+    import ctypes as C
+    import subprocess
+    from arpeggio_amd import _capi, build
+    path = build.build_host()
+    L = C.CDLL(path)
+    for sym in _capi.HOST_SYMBOLS:
+        assert hasattr(L, sym), sym
+    exported = {ln.split()[-1] for ln in subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout.splitlines() if ' T arp_' in ln}
+    assert exported == set(_capi.HOST_SYMBOLS) | {'arp_host_version'}, exported
+    _capi._declare_host_entry_points(L)
+    text = b"data_t\nloop_\n_atom_site.id\n_atom_site.Cartn_x\n1 1.5\n2 'a b'\n"
+    h, err = C.c_void_p(), C.create_string_buffer(64)
+    assert L.arp_cif_open(text, len(text), b'_atom_site.', C.byref(h), err, 64) == 0 and L.arp_cif_rows(h) == 2 and L.arp_cif_cols(h) == 2
+    L.arp_cif_close(h)
+
+
 def test_product_never_imports_the_oracle():
     """A product path routed through oracle/ would void every parity claim."""
     for base, _, files in os.walk(os.path.join(ROOT, 'arpeggio_amd')):
