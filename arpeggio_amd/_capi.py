@@ -29,7 +29,7 @@ SYMBOLS = (
     'arp_group_plane_launch', 'arp_atom_plane_fetch', 'arp_plane_plane_fetch', 'arp_group_group_fetch',
     'arp_group_plane_fetch', 'arp_get_selection', 'arp_set_group_ownership', 'arp_set_single_bond_neighbour_coords',
     'arp_set_selection_state', 'arp_atom_accumulators', 'arp_device_buffer', 'arp_run_stage', 'arp_use_stream',
-    'arp_get_host_times', 'arp_set_whole_structure', 'arp_set_grid_reuse', 'arp_set_sort_after_pass', 'arp_set_batch', 'arp_device_count', 'arp_device_synchronize', 'arp_comm_unique_id', 'arp_comm_init', 'arp_comm_destroy', 'arp_comm_info',
+    'arp_get_host_times', 'arp_set_whole_structure', 'arp_set_grid_reuse', 'arp_set_sort_after_pass', 'arp_set_packed_layout', 'arp_set_batch', 'arp_device_count', 'arp_device_synchronize', 'arp_comm_unique_id', 'arp_comm_init', 'arp_comm_destroy', 'arp_comm_info',
     'arp_shard_exchange_faces', 'arp_shard_set_exchange_lists', 'arp_shard_exchange_plus', 'arp_shard_reduce_residue_sets', 'arp_ring_geometry', 'arp_amide_geometry', 'arp_ring_residues',
     'arp_host_alloc', 'arp_host_free', 'arp_atom_integer_sifts', 'arp_blob_size', 'arp_blob_layout', 'arp_set_blob', 'arp_blob_fill',
     'arp_write_contacts_json', 'arp_records_size', 'arp_records_layout', 'arp_records_fill', 'arp_shard_set_home', 'arp_shard_pack_face',
@@ -170,6 +170,7 @@ def load():
     L.arp_set_whole_structure.argtypes = [vp, i32]
     L.arp_set_grid_reuse.argtypes = [vp, i32]
     L.arp_set_sort_after_pass.argtypes = [vp, i32]
+    L.arp_set_packed_layout.argtypes = [vp, i32]
     L.arp_device_synchronize.argtypes = [vp]
     L.arp_set_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     L.arp_comm_unique_id.argtypes = [vp, C.c_uint64]
@@ -381,6 +382,19 @@ def unpack_records_buffer(buf):
             'header': hdr}
 
 
+class RowsBag(dict):
+    """The atom-atom bag in ROWS layout (``Context.set_packed_layout(rows=True)``): ``row`` (N + 1 offsets) instead of ``i``;
+    ``bag['i']`` is made from it on first use."""
+
+    def __missing__(self, key):
+        if key != 'i':
+            raise KeyError(key)
+        row = self['row']
+        v = np.repeat(np.arange(len(row) - 1, dtype=np.int32), np.diff(row))
+        self['i'] = v
+        return v
+
+
 class CifCategory:
     """One category of an mmCIF text (``arp_cif_open``): what gemmi's ``cif_block.get_mmcif_category(name)`` gives the
     reference — ``columns()[item]`` is a list with ``None`` for '?', ``False`` for '.', the unquoted string otherwise —
@@ -474,6 +488,13 @@ class Context:
         """``run_launch`` / ``run_wait`` enqueue the canonical sort of the atom-atom bag before they return (for callers that
         fetch the sorted bag next: ``fetch_packed``)."""
         self._check(self._L.arp_set_sort_after_pass(self._h, int(bool(on))), 'arp_set_sort_after_pass')
+
+    def set_packed_layout(self, rows=False):
+        """Layout of the atom-atom bag in ``fetch_packed`` (arp_set_packed_layout): records (a bgn id per record) or ROWS — ``row``:
+        N + 1 offsets, the records of atom a are [row[a], row[a + 1]) — 4 bytes per record less over PCIe.  With rows the returned
+        bag is a ``RowsBag``: ``bag['i']`` expands the offsets on first use (np.repeat), everything else is as before."""
+        self._check(self._L.arp_set_packed_layout(self._h, 1 if rows else 0), 'arp_set_packed_layout')
+        self._packed_rows = bool(rows)
 
     def device_synchronize(self):
         """Everything enqueued on this context's GPU has completed (the bracket of a timed region)."""
@@ -846,8 +867,12 @@ class Context:
         def view(off, dtype, n):
             return np.frombuffer(buf, dtype, n, int(off)) if n else np.empty(0, dtype)
         k = int(counts[0])
-        bags = {'atom_atom': dict(i=view(offs[0], np.int32, k), j=view(offs[1], np.int32, k), dist=view(offs[2], np.float32, k),
-                                  sift=view(offs[3], np.uint16, k), ctype=view(offs[4], np.uint8, k))}
+        if getattr(self, '_packed_rows', False):
+            bags = {'atom_atom': RowsBag(row=np.frombuffer(buf, np.int32, self.n + 1, int(offs[0])), j=view(offs[1], np.int32, k),
+                                         dist=view(offs[2], np.float32, k), sift=view(offs[3], np.uint16, k), ctype=view(offs[4], np.uint8, k))}
+        else:
+            bags = {'atom_atom': dict(i=view(offs[0], np.int32, k), j=view(offs[1], np.int32, k), dist=view(offs[2], np.float32, k),
+                                      sift=view(offs[3], np.uint16, k), ctype=view(offs[4], np.uint8, k))}
         for b, (name, cols) in enumerate(self._PACKED_BAGS):
             m = int(counts[1 + b])
             res = {key: view(offs[5 + 12 * b + q], dt, m) for key, q, dt in cols}

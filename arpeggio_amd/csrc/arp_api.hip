@@ -338,6 +338,8 @@ struct arp_ctx {
     size_t srt_off[5] = {0, 0, 0, 0, 0};  // byte offsets of i, j, distance, SIFt, contact type in sorted_slab
     size_t srt_bytes = 0;               // bytes of the five columns
     bool contacts_sorted = false;       // sorted_slab holds the records of the last launch in (i, j) order
+    bool packed_csr = false;            // arp_set_packed_layout: the sorted bag's first column is N + 1 row offsets instead of k bgn ids
+    bool sorted_is_csr = false;         // ... and that is what sorted_slab holds now
     int64_t gid_max = -1;               // largest global atom id of a shard (-1: not known, 31-bit keys)
     bool pass_pending = false;      // arp_run_enqueue without its arp_run_wait yet
     double pending_cutoff = 5.0, pending_comp = 0.1, pending_expand = 6.0;
@@ -1739,9 +1741,9 @@ bool finish_contacts(arp_ctx* c) {
 // Layout of the sorted slab: the five columns one after the other, each on a 256-byte boundary; what follows them
 // (sorted_extra bytes) is the caller's (the packed ring / amide bags of arp_fetch_packed).
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-void sorted_layout(size_t k, size_t off[5], size_t* bytes) {
+void sorted_layout(size_t k, size_t off[5], size_t* bytes, size_t first_col_entries) {      // (first column: k bgn ids, or N + 1 row offsets)
     off[0] = 0;
-    off[1] = off[0] + al256(k * sizeof(int32_t));
+    off[1] = off[0] + al256(first_col_entries * sizeof(int32_t));
     off[2] = off[1] + al256(k * sizeof(int32_t));
     off[3] = off[2] + al256(k * sizeof(float));
     off[4] = off[3] + al256(k * sizeof(uint16_t));
@@ -1750,17 +1752,24 @@ void sorted_layout(size_t k, size_t off[5], size_t* bytes) {
 int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     if (!c->contacts_valid) FAIL(c, ARP_E_ARG, "arp_atom_contacts_sort: no atom-contact results (call a launch first)");
     const size_t k = (size_t)c->n_contacts;
+    const bool csr = c->packed_csr && !c->has_gid;      // (a shard's records carry global ids: no table of rows)
+    const size_t rows = (size_t)std::max<int64_t>(c->n, 0);
     size_t off[5], bytes;
-    sorted_layout(k, off, &bytes);
-    if (c->contacts_sorted && c->sorted_slab.cap >= bytes + extra_bytes) return ARP_OK;
+    sorted_layout(k, off, &bytes, csr ? rows + 1 : k);
+    if (c->contacts_sorted && c->sorted_is_csr == csr && c->sorted_slab.cap >= bytes + extra_bytes) return ARP_OK;
     {   // sized from the capacity of the unsorted columns, so that the slab is allocated once per structure size
         size_t off_cap[5], bytes_cap;
-        sorted_layout(std::max(k, c->out_i.cap), off_cap, &bytes_cap);
+        sorted_layout(std::max(k, c->out_i.cap), off_cap, &bytes_cap, std::max(std::max(k, c->out_i.cap), rows + 1));
         HIPCHK(c, c->sorted_slab.reserve(std::max(bytes_cap, bytes + extra_bytes)));
     }
     for (int q = 0; q < 5; ++q) c->srt_off[q] = off[q];
     c->srt_bytes = bytes;
-    if (k == 0) { c->contacts_sorted = true; return ARP_OK; }
+    c->sorted_is_csr = csr;
+    if (k == 0) {
+        if (csr) HIPCHK(c, hipMemsetAsync(c->sorted_slab.p + off[0], 0, (rows + 1) * sizeof(int32_t), c->stream));
+        c->contacts_sorted = true;
+        return ARP_OK;
+    }
     if (k >= ((size_t)1 << 31)) FAIL(c, ARP_E_CAPACITY, "arp_atom_contacts_sort: 2^31 records or more (the digit table's prefixes are 32-bit)");
     // significant bits of an atom index: packed ids of the resident structure, global ids on a shard
     const int64_t idmax = c->has_gid ? (c->gid_max >= 0 ? c->gid_max : ((int64_t)1 << 31) - 1) : std::max<int64_t>(c->n - 1, 1);
@@ -1788,6 +1797,8 @@ int sort_contacts(arp_ctx* c, size_t extra_bytes = 0) {
     A.jbits = idbits;
     A.table = c->sort_table.p;
     A.total = c->sort_total.p;
+    A.row_out = csr ? A.i_out : nullptr;
+    A.nrows = (int)rows;
     // a small bag: one block groups the records by bgn atom in one launch (k_sort_small)
     static const int small_mode = env_int("ARP_SORT_SMALL", 1);
     const bool small = small_mode && k <= (size_t)SORT_SMALL_MAX_RECORDS && idmax + 1 <= (int64_t)SORT_SMALL_MAX_BINS;
@@ -3179,6 +3190,13 @@ int arp_atom_contacts_fetch(arp_ctx* c, int64_t cap, int32_t* out_i, int32_t* ou
     const size_t k = (size_t)c->n_contacts;
     // five copies in flight, one synchronisation (into buffers from arp_host_alloc they run at PCIe speed); the records come
     // in the canonical (i, j) order once arp_atom_contacts_sort has run on them, in the order of the pair list before
+    if (c->contacts_sorted && c->sorted_is_csr && out_i) {      // (this call hands out bgn ids: the sorted columns once more, as records)
+        const bool was = c->packed_csr;
+        c->packed_csr = false;
+        const int rc = sort_contacts(c);
+        c->packed_csr = was;
+        CHK(rc);
+    }
     const uint8_t* sl = c->sorted_slab.p;
     const bool srt = c->contacts_sorted;
     if (k) {
@@ -3258,7 +3276,9 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     Bag* bags[4] = {&c->bag_pp, &c->bag_ap, &c->bag_gg, &c->bag_gp};      // (the order of get_contacts, I:183-210)
     static const size_t es[12] = {4, 4, 8, 8, 8, 8, 4, 4, 4, 1, 1, 1};
     size_t off[5], cbytes;
-    sorted_layout((size_t)c->n_contacts, off, &cbytes);
+    const bool csr = c->packed_csr && !c->has_gid;
+    if (c->packed_csr && c->has_gid) FAIL(c, ARP_E_ARG, "arp_fetch_packed: the row-offset layout needs packed atom ids (this context holds a shard with global ids)");
+    sorted_layout((size_t)c->n_contacts, off, &cbytes, csr ? (size_t)std::max<int64_t>(c->n, 0) + 1 : (size_t)c->n_contacts);
     size_t total = cbytes;
     PackTable t;
     t.n = 0;
@@ -3317,7 +3337,7 @@ int arp_fetch_packed(arp_ctx* c, void* host, uint64_t host_bytes, int64_t counts
     for (int b = 0; b < 4; ++b)
         for (int q = 0; q < 12; ++q)
             if (seg_of[b][q] >= 0) t.s[seg_of[b][q]].perm = bo.n[b] > 0 ? bo.perm[b] : big_perm[b];
-    c->contacts_sorted = c->contacts_sorted && c->sorted_slab.cap >= total;
+    c->contacts_sorted = c->contacts_sorted && c->sorted_slab.cap >= total && c->sorted_is_csr == csr;
     // (aside: the sort's launches go out first — they are the critical path, the host needs ~5 us per launch —, the one block per
     // small bag on the second stream behind them)
     if (any_order && !order_aside) {
@@ -4186,6 +4206,12 @@ int arp_debug_read(uint64_t device_ptr, void* host, uint64_t bytes) {
 int arp_set_sort_after_pass(arp_ctx* c, int enabled) {
     if (!c) return ARP_E_ARG;
     c->sort_after_pass = enabled != 0;
+    return ARP_OK;
+}
+
+int arp_set_packed_layout(arp_ctx* c, int layout) {
+    if (!c || (layout != ARP_LAYOUT_RECORDS && layout != ARP_LAYOUT_ROWS)) return ARP_E_ARG;
+    c->packed_csr = layout == ARP_LAYOUT_ROWS;
     return ARP_OK;
 }
 

@@ -57,6 +57,10 @@ struct SortArgs {
     int jbits;         // key = i << jbits | j
     int* table;        // [SORT_BINS][tstride]: records of tile t with digit d, then their exclusive prefix over the tiles
     long long* total;  // [SORT_BINS]: records with digit d
+    // CSR layout of the sorted bag (arp_set_packed_layout): not null -> k_sort_runs writes no i column but the row offsets —
+    // row_out[a] = first record of bgn atom a, row_out[nrows] = n; the records of atom a are [row_out[a], row_out[a + 1])
+    int* row_out;
+    int nrows;
 };
 
 __device__ __forceinline__ unsigned long long sort_key_at(const SortArgs& A, long long p) {
@@ -347,6 +351,16 @@ __global__ __launch_bounds__(256) void k_sort_runs(SortArgs A) {
         }
     const long long pos = a + rank;
     const unsigned long long v = A.val_in[p];
+    if (A.row_out) {
+        // the first record of a run knows where the rows of its atom — and of the record-less atoms since the run before it — begin
+        // (hydrogens present as atoms have no records: gaps of a few ids); the last record of the bag closes the table
+        if (p == a) {
+            const uint32_t ip = s_i[s - 1];                       // (0xFFFFFFFF in front of the first record)
+            for (long long id = (ip == 0xFFFFFFFFu) ? 0 : (long long)ip + 1; id <= (long long)i && id <= (long long)A.nrows; ++id) A.row_out[id] = (int)a;
+        }
+        if (p == A.n - 1)
+            for (long long id = (long long)i + 1; id <= (long long)A.nrows; ++id) A.row_out[id] = (int)A.n;
+    } else
     A.i_out[pos] = (int)i;
     A.j_out[pos] = (int)j;
     A.d_out[pos] = __uint_as_float((uint32_t)v);

@@ -231,3 +231,37 @@ def test_sort_enqueued_by_the_pass_itself_gives_the_same_bags(capi):
         _same_bag(xa['atom_atom'], b.atom_contacts_fetch(ca['atom_atom'], sort=True))
         _same_bag(_host_sorted(a.atom_contacts_fetch(ca['atom_atom'], sort=False)), _host_sorted(b.atom_contacts_fetch(ca['atom_atom'], sort=False)))
     a.close(); b.close()
+
+
+def test_rows_layout_of_the_packed_fetch_is_the_same_bag(capi):
+    """arp_set_packed_layout(ARP_LAYOUT_ROWS): N + 1 row offsets instead of the bgn column — with and without the sort enqueued by
+    the pass, for a structure with record-less atoms (explicit hydrogens), a structure without contacts at all, a large and a
+    small bag (one-launch sort); switching back and forth on one context; arp_atom_contacts_fetch still hands out records."""
+    from arpeggio_amd import synth
+    a, b = capi.Context(0), capi.Context(0)
+    b.set_packed_layout(rows=True)
+    lone = synth.config3(64, seed=45)
+    lone.xyz[:] = lone.xyz * 40.0            # nothing within 5 A of anything: an empty bag
+    for after in (False, True):
+        b.set_sort_after_pass(after)
+        for pc in (synth.config3(30_000, seed=41), synth.proteinlike(n_res=90, n_waters=30, seed=42), synth.config3(2_000, seed=44), lone):
+            a.set_complex(pc); b.set_complex(pc)
+            ca, cb = a.run_launch(5.0, 0.1, False, 6.0), b.run_launch(5.0, 0.1, False, 6.0)
+            assert ca == cb
+            xa, _ = a.fetch_packed()
+            xb, _ = b.fetch_packed()
+            row = xb['atom_atom']['row']
+            assert 'i' not in xb['atom_atom'] and len(row) == pc.n_atoms + 1 and row[0] == 0 and row[-1] == ca['atom_atom'] and np.all(np.diff(row) >= 0)
+            assert np.array_equal(row, np.searchsorted(xa['atom_atom']['i'], np.arange(pc.n_atoms + 1)))
+            for k in ('i', 'j', 'dist', 'sift', 'ctype'):
+                assert np.array_equal(xa['atom_atom'][k], xb['atom_atom'][k]), (pc.id, k)
+            for bag in ('plane_plane', 'atom_plane', 'group_group', 'group_plane'):
+                for k in xa[bag]:
+                    assert np.array_equal(xa[bag][k], xb[bag][k], equal_nan=(xa[bag][k].dtype.kind == 'f')), (pc.id, bag, k)
+            _same_bag(xa['atom_atom'], b.atom_contacts_fetch(ca['atom_atom'], sort=True))      # (records again: the slab is re-made)
+            xb2, _ = b.fetch_packed()                                                          # ... and rows again
+            assert np.array_equal(xb2['atom_atom']['row'], row) and np.array_equal(xb2['atom_atom']['j'], xa['atom_atom']['j'])
+    b.set_packed_layout(rows=False)
+    xb, _ = b.fetch_packed()
+    assert 'row' not in xb['atom_atom'] and np.array_equal(xb['atom_atom']['i'], xa['atom_atom']['i'])
+    a.close(); b.close()
