@@ -1699,7 +1699,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
             HIPCHK(c, hipStreamWaitEvent(st2, c->ev_lists, 0));
         }
         Prof p(c, SLOT_PLANES, st2);
-        hipLaunchKernelGGL(k_planes, dim3(std::max(np, 8)), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + ctr_dev(C_PLIST), c->pub);
+        hipLaunchKernelGGL(k_planes, dim3(std::max(np, 8)), dim3(256), 0, st2, ap, pp, gg, gp, plane_lists(c), c->d_ctr + ctr_dev(C_PLIST), c->pub, 15);
         CHK(check_launch(c, "k_planes"));
     }
     if (c->n > 0) {
@@ -1880,6 +1880,49 @@ int device_error(arp_ctx* c) {
     if ((int)(uint32_t)c->h_ctr[C_ERR] == ARP_E_HIP)
         FAIL(c, ARP_E_HIP, "the grid's prefix scan timed out waiting for another tile (device shared or partly masked?): results of this pass are invalid; "
                            "ARP_CHAINED_SCAN=0 selects the two-launch scan");
+    return ARP_OK;
+}
+
+// One ring / amide loop alone (arp_plane_plane_launch ...) from the static candidate lists of the structure, like the loops of a
+// whole pass: the entries of the list in chunks of 64 over the waves of ONE launch (k_planes with the other three kinds masked
+// out) — a launch of >= 1024 waves that each take a chunk or two, instead of one wave per ring / amide walking its 27-cell
+// stencil as a chain of dependent loads (the grid walks of arp_planes.h, which the lists are built by: 10 k rings took 22 - 37 us).
+// kind: 0 atom-plane, 1 plane-plane, 2 group-group, 3 group-plane.
+int enqueue_bag_from_lists(arp_ctx* c, int kind) {
+    AtomPlaneArgs ap{};
+    PlanePlaneArgs pp{};
+    GroupGroupArgs gg{};
+    GroupPlaneArgs gp{};
+    int nb = 0;
+    if (c->n > 0 && kind == 0) CHK(ensure_static(c, c->last_cutoff));      // (the atoms' records by local id: st_xyzm)
+    CHK(ensure_center_grids(c));
+    CHK(ensure_plane_lists(c));
+    if (kind == 0) CHK(prepare_atom_plane(c, ap, nb, /*contact_grid=*/true));
+    else if (kind == 1) CHK(prepare_plane_plane(c, pp, nb));
+    else if (kind == 2) CHK(prepare_group_group(c, gg, nb));
+    else CHK(prepare_group_plane(c, gp, nb));
+    if (!nb) return ARP_OK;
+    const long long entries = std::min<long long>((long long)c->plist[kind].cap, c->plist_known[kind] >= 0 ? c->plist_known[kind] + 64 : (long long)c->plist[kind].cap);
+    // one chunk of 64 entries per wave while the chip has room (8 waves per SIMD), more beyond
+    const int blocks = (int)std::min<long long>(std::max<long long>((entries + 255) / 256, 8), (long long)c->num_cu * 8);
+    Prof p(c, SLOT_PLANES, c->stream);
+    hipLaunchKernelGGL(k_planes, dim3(blocks), dim3(256), 0, c->stream, ap, pp, gg, gp, plane_lists(c), c->d_ctr + ctr_dev(C_PLIST), PublishArgs{nullptr, nullptr, 0, 0}, 1 << kind);
+    return check_launch(c, "k_planes (one list)");
+}
+int bag_launch_lists(arp_ctx* c, Bag& b, int slot, bool d, bool f, int kind, int64_t* count) {
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(ensure_default_selection(c));
+    for (int attempt = 0;; ++attempt) {
+        CHK(enqueue_bag_from_lists(c, kind));
+        CHK(read_counters(c));
+        collect_events(c);
+        const bool list_small = finish_plane_lists(c, /*grow=*/true) != 0;      // (a list that was too small is re-sized and rebuilt by the next attempt)
+        const bool bag_small = finish_bag(c, b, slot);
+        if (!list_small && !bag_small) break;
+        if (attempt == 3) FAIL(c, ARP_E_CAPACITY, "result bag could not be sized");
+        if (bag_small) CHK(grow_bag(c, b, slot, d, f));
+    }
+    if (count) *count = b.count;
     return ARP_OK;
 }
 
@@ -3454,20 +3497,30 @@ int arp_atom_integer_sifts(arp_ctx* c, uint8_t* out_isift) {
 }
 
 // ---- ring / amide contacts: launch (results stay in HBM) + fetch ----------------------------------
+// Which loops take the list path when called alone (measured on BASELINE configs[4], 10 k rings + 10 k amides, HIP events):
+// plane-plane 22.5 -> 18.6 us from the list; atom-plane 37 -> 63 us (its list has 60 candidates per ring: the walk, which tests the
+// atoms of a ring's cells as it meets them, does less); the two amide loops 19 - 20 us either way (a chain of five dependent round
+// trips whatever evaluates 1.5 k records).  ARP_BAG_LISTS: bit k = loop k from its list (default 2: plane-plane), 0 = every loop by
+// its grid walk as through round 5, 15 = all four from the lists (the way a whole pass evaluates them).
+static bool bag_walk(int kind = 1) { static const int v = env_int("ARP_BAG_LISTS", 2); return ((v >> kind) & 1) == 0; }
 int arp_atom_plane_launch(arp_ctx* c, int64_t* count) {
     if (!c) return ARP_E_ARG;
+    if (!bag_walk(0)) return bag_launch_lists(c, c->bag_ap, C_AP, true, false, 0, count);
     return bag_launch(c, c->bag_ap, C_AP, true, false, enqueue_atom_plane, count);
 }
 int arp_plane_plane_launch(arp_ctx* c, int64_t* count) {
     if (!c) return ARP_E_ARG;
+    if (!bag_walk(1)) return bag_launch_lists(c, c->bag_pp, C_PP, true, false, 1, count);
     return bag_launch(c, c->bag_pp, C_PP, true, false, enqueue_plane_plane, count);
 }
 int arp_group_group_launch(arp_ctx* c, int64_t* count) {
     if (!c) return ARP_E_ARG;
+    if (!bag_walk(2)) return bag_launch_lists(c, c->bag_gg, C_GG, false, true, 2, count);
     return bag_launch(c, c->bag_gg, C_GG, false, true, enqueue_group_group, count);
 }
 int arp_group_plane_launch(arp_ctx* c, int64_t* count) {
     if (!c) return ARP_E_ARG;
+    if (!bag_walk(3)) return bag_launch_lists(c, c->bag_gp, C_GP, true, false, 3, count);
     return bag_launch(c, c->bag_gp, C_GP, true, false, enqueue_group_plane, count);
 }
 

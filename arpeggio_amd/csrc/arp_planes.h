@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_plane_lists(AtomRingListArgs ar, PlaneP
 // lists), filter, evaluate.  vblock / vgrid: position among the blocks doing this work.
 __device__ __forceinline__ void planes_from_lists(const AtomPlaneArgs& ap, const PlanePlaneArgs& pp, const GroupGroupArgs& gg,
                                                   const GroupPlaneArgs& gp, const PlaneLists& L, u64* __restrict__ publish_counts,
-                                                  int vblock, int vgrid, PlaneShared* sh) {
+                                                  int vblock, int vgrid, PlaneShared* sh, int kinds = 15) {      // kinds: bit k = evaluate list k
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     long long cnt[4], chunks[5];
     chunks[0] = 0;
@@ -770,7 +770,7 @@ __device__ __forceinline__ void planes_from_lists(const AtomPlaneArgs& ap, const
     for (int k = 0; k < 4; ++k) {
         const u64 c = L.count[k];
         cnt[k] = (long long)(c < (u64)L.cap[k] ? c : (u64)L.cap[k]);
-        chunks[k + 1] = chunks[k] + (cnt[k] + 63) / 64;
+        chunks[k + 1] = chunks[k] + (((kinds >> k) & 1) ? (cnt[k] + 63) / 64 : 0);
         // the host checks them against the capacities at the end of the pass.  An ATOMIC, like every other write to the counter
         // block: the block that publishes the counters (pass_end) may run on another XCD — or, on a structure's first pass, in
         // the other kernel — and reads the memory-side values; a plain store would sit in this XCD's L2 until the kernel ends,
@@ -838,9 +838,9 @@ __global__ __launch_bounds__(256, SIFT_MIN_WAVES) void k_sift_planes(SiftArgs sa
 }
 // the two halves as separate kernels (sharded stage path with a caller-owned stream, structures without atoms / planes)
 __global__ __launch_bounds__(256) void k_planes(AtomPlaneArgs ap, PlanePlaneArgs pp, GroupGroupArgs gg, GroupPlaneArgs gp, PlaneLists L,
-                                                u64* publish_counts, PublishArgs pub) {
+                                                u64* publish_counts, PublishArgs pub, int kinds) {
     __shared__ PlaneShared s_sh;
-    planes_from_lists(ap, pp, gg, gp, L, publish_counts, (int)blockIdx.x, (int)gridDim.x, &s_sh);
+    planes_from_lists(ap, pp, gg, gp, L, publish_counts, (int)blockIdx.x, (int)gridDim.x, &s_sh, kinds);
     pass_end(pub, 1);
 }
 template <int STREAM, int GID = 0>

@@ -672,3 +672,32 @@ def test_bad_radii_are_rejected_whether_or_not_the_radius_column_travels(capi):
         assert c.run_launch() == n1
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_each_ring_amide_loop_alone_from_its_list_and_by_its_grid_walk():
+    """arp_*_launch alone: ARP_BAG_LISTS chooses, loop by loop, between the evaluation from the static candidate list (as a whole
+    pass does it) and the grid walk; both must deliver the same bags (two processes: the switch is read once)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, json, hashlib, numpy as np; sys.path.insert(0, %r)\n'
+            'from arpeggio_amd import synth, _capi\n'
+            'out = {}\n'
+            'for pc in (synth.config5(1500, 1500, seed=7, L=45.0), synth.proteinlike(n_res=120, n_waters=40, seed=9)):\n'
+            '    c = _capi.Context(0); c.set_complex(pc)\n'
+            '    for name in ("plane_plane", "atom_plane", "group_group", "group_plane"):\n'
+            '        n = c.launch_bag(name); b = c.fetch_bag(name, sort=True)\n'
+            '        h = hashlib.sha256()\n'
+            '        for k in sorted(b): h.update(np.ascontiguousarray(b[k]).tobytes())\n'
+            '        out[pc.id + ":" + name] = [int(n), h.hexdigest()]\n'
+            '    c.close()\n'
+            'print(json.dumps(out))\n') % root
+    res = {}
+    for mode in ('0', '15'):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, ARP_BAG_LISTS=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['0'] == res['15'] and sum(v[0] for v in res['0'].values()) > 1000, res
