@@ -701,3 +701,34 @@ def test_each_ring_amide_loop_alone_from_its_list_and_by_its_grid_walk():
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
     assert res['0'] == res['15'] and sum(v[0] for v in res['0'].values()) > 1000, res
+
+
+@pytest.mark.gpu
+def test_sift_blocks_dealt_by_index_give_the_same_contacts():
+    """ARP_SIFT_SEG_BY_BLOCK=1: the per-pair kernel takes a block's pair-list segment from its index instead of from the XCD it runs
+    on — what arp_create switches to on a device whose dispatcher is not round-robin over eight XCDs.  Same records, same counters."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, json, hashlib, numpy as np; sys.path.insert(0, %r)\n'
+            'from arpeggio_amd import synth, _capi\n'
+            'out = {}\n'
+            'for pc in (synth.config3(40_000, seed=11), synth.proteinlike(n_res=150, n_waters=60, seed=12)):\n'
+            '    c = _capi.Context(0); c.set_complex(pc)\n'
+            '    for k in range(3):\n'
+            '        cnt = c.run_launch(5.0, 0.1, False, 6.0)\n'
+            '    bags, _ = c.fetch_packed()\n'
+            '    h = hashlib.sha256()\n'
+            '    for name in sorted(bags):\n'
+            '        for k in sorted(bags[name]): h.update(np.ascontiguousarray(bags[name][k]).tobytes())\n'
+            '    out[pc.id] = [dict(cnt), h.hexdigest(), c.stats()["candidates"]]\n'
+            '    c.close()\n'
+            'print(json.dumps(out))\n') % root
+    res = {}
+    for mode in ('0', '1'):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, ARP_SIFT_SEG_BY_BLOCK=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['0'] == res['1'] and all(v[0]['atom_atom'] > 1000 for v in res['0'].values()), res
