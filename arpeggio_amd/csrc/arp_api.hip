@@ -26,7 +26,6 @@
 #include "arp_cif.h"
 #include "arp_comm.h"
 #include "arp_sort.h"
-#include "arp_tiny.h"
 
 namespace {
 
@@ -339,9 +338,6 @@ struct arp_ctx {
     size_t srt_off[5] = {0, 0, 0, 0, 0};  // byte offsets of i, j, distance, SIFt, contact type in sorted_slab
     size_t srt_bytes = 0;               // bytes of the five columns
     bool contacts_sorted = false;       // sorted_slab holds the records of the last launch in (i, j) order
-    bool tiny_front = false;            // this pass: expansion + contact grid + search in one block (k_tiny_front), set by run_pass_enqueue
-    bool tiny_blocked = false;          // the selection of the moment keeps more atoms than k_tiny_front takes: the three launches, until it changes
-    uint64_t tiny_blocked_sel = 0, tiny_blocked_static = 0;
     bool packed_csr = false;            // arp_set_packed_layout: the sorted bag's first column is N + 1 row offsets instead of k bgn ids
     bool sorted_is_csr = false;         // ... and that is what sorted_slab holds now
     int64_t gid_max = -1;               // largest global atom id of a shard (-1: not known, 31-bit keys)
@@ -907,7 +903,7 @@ int build_contact_grid(arp_ctx* c, double radius, uint32_t req, uint32_t forb, c
     return build_atom_grid(c, c->atom_grid, c->s_xyzm, c->s_aux, &c->s_qa, radius, req, forb, active, total_out, nullptr, nullptr, rm, gm);
 }
 // The contact grid of a pass as an ordered compaction of the static columns (k_compact_atoms): ONE launch.
-int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t forb, u64* total_out, uint8_t* plus_init, ResMarks rm, bool buffers_only = false) {
+int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t forb, u64* total_out, uint8_t* plus_init, ResMarks rm) {
     Grid& G = c->atom_grid;
     const int n = (int)c->n;
     CHK(grid_desc_for(c, G.d, c->lo, c->hi, radius));
@@ -920,13 +916,6 @@ int build_contact_grid_compact(arp_ctx* c, double radius, uint32_t req, uint32_t
     HIPCHK(c, c->s_qa.reserve((size_t)std::max(n, 1)));
     HIPCHK(c, c->s_h.reserve((size_t)std::max(n, 1)));
     CHK(ensure_static(c, radius));
-    if (buffers_only) {      // (k_tiny_front fills them: descriptor, columns and start table are in place, nothing is launched here)
-        HIPCHK(c, c->s_cell.reserve((size_t)std::max(n, 1)));
-        c->s_cell_valid = true;
-        G.valid = true;
-        G.n_binned = -1;
-        return ARP_OK;
-    }
     if (n > 0) {
         Prof p(c, SLOT_BIN);
         static const int compact_small_max = env_int("ARP_COMPACT_512_MAX_ROWS", 150000);
@@ -1468,8 +1457,7 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     }
     if (!reuse_grid) {
         c->cg_valid = false;
-        CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + ctr_dev(C_BINNED), c->init_plus_in_bin ? c->plus.p : nullptr, rm,
-                                       /*buffers_only=*/c->tiny_front));
+        CHK(build_contact_grid_compact(c, cutoff, M_PLUS, M_HYDROGEN, c->d_ctr + ctr_dev(C_BINNED), c->init_plus_in_bin ? c->plus.p : nullptr, rm));
         if (whole) {      // what this grid was built from; its atom count arrives with the counters of the pass (finish_contacts)
             c->cg_valid = true; c->cg_pending = true; c->cg_radius = cutoff; c->cg_static_epoch = c->static_epoch; c->cg_sel_epoch = c->sel_epoch;
             c->cg_fuse = c->fuse_sets; c->cg_init_plus = c->init_plus_in_bin; c->cg_all_res = all_res_now;
@@ -1492,21 +1480,6 @@ int enqueue_contacts(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     auto launch_search = [&]() -> int {
         if (search_launched || c->n == 0) return ARP_OK;
         search_launched = true;
-        if (c->tiny_front) {      // expansion + contact grid + search of a small selection in a small structure: one block (arp_tiny.h)
-            Prof p(c, SLOT_SEARCH);
-            TinyArgs T{};
-            T.n = (int)c->n; T.xyz = c->xyz.p; T.sel_list = c->sel_list.p; T.nsel = (int)c->nsel; T.sel = c->sel.p;
-            T.r2_expand = c->pending_expand * c->pending_expand; T.plus = c->plus.p; T.mark_stats = c->d_ctr + ctr_dev(C_STAT_MCAND);
-            T.sp_xyzm = c->sp_xyzm.p; T.sp_aux = c->sp_aux.p; T.sp_qa = c->sp_qa.p; T.sp_h = c->sp_h.p; T.sp_cell = c->sp_cell.p;
-            T.g = c->atom_grid.d; T.req = M_PLUS; T.forb = M_HYDROGEN;
-            T.s_xyzm = c->s_xyzm.p; T.s_aux = c->s_aux.p; T.s_qa = c->s_qa.p; T.s_h = c->s_h.p; T.s_cell = c->s_cell.p;
-            T.start = c->atom_grid.start.p; T.total_out = c->d_ctr + ctr_dev(C_BINNED); T.rm = rm; T.gm = masks_after_bin ? GroupMasks{} : gm;
-            T.r2 = cutoff * cutoff; T.include_seq_adj = include_seq_adj; T.pairs = c->pairs.p; T.cap = (u64)segcap;
-            T.ctr_pairs = c->d_ctr + ctr_dev(C_SEG_PAIRS); T.ctr_cand = c->d_ctr + ctr_dev(C_STAT_CAND); T.ctr_acc = c->d_ctr + ctr_dev(C_STAT_ACC);
-            T.overflow = c->d_ctr + ctr_dev(C_SCRATCH1);
-            hipLaunchKernelGGL(k_tiny_front, dim3(1), dim3(TINY_THREADS), 0, c->stream, T);
-            return check_launch(c, "k_tiny_front");
-        }
         Prof p(c, SLOT_SEARCH);
         // the contact search ends with a block-level flush of its pair queues, which amortises better over
         // ~3 cells per wave; the flush-free expansion search prefers 1 (sweeps in profiles/README.md)
@@ -3700,7 +3673,7 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
     };
     auto enqueue_all = [&]() -> int {
         c->ctr_clean = true;
-        struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; c->pub.expected = 0; c->fuse_sets = false; c->init_plus_in_bin = false; c->tiny_front = false; } } unclean{c};
+        struct Unclean { arp_ctx* c; ~Unclean() { c->ctr_clean = false; c->pub.expected = 0; c->fuse_sets = false; c->init_plus_in_bin = false; } } unclean{c};
         CHK(ensure_static(c, cutoff));       // (the spatial order of the columns is the one of this pass's cells)
         c->last_cutoff = cutoff;
         // The pass ends inside its last kernel (k_sift_planes): the last block to finish publishes the counters.
@@ -3718,13 +3691,6 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         // (not for several structures in one pass: their coordinates overlap, only the grid keeps them apart)
         const bool small_sel = !c->sel_all && c->nsel > 0 && c->nsel <= SMALL_SEL_MAX && c->n > 0 && !c->has_home &&
                                c->n * c->nsel <= (int64_t)1 << 24 && c->batch_n == 0;
-        // ... and when the structure is small as well, the direct test, the contact grid of the pass and its neighbour search are ONE launch of
-        // one block (k_tiny_front, arp_tiny.h) — the reference's own example, a ligand and its binding site, is four chains of dependent
-        // round trips otherwise.  More than TINY_KMAX atoms in selection_plus: the block says so, the pass is repeated the long way and
-        // the selection remembered (tiny_blocked, until it changes).
-        static const int tiny_mode = env_int("ARP_TINY_FRONT", 1);
-        c->tiny_front = tiny_mode && small_sel && c->n <= TINY_MAX_ROWS && !c->has_gid && c->stream2 != nullptr &&
-                        !(c->tiny_blocked && c->tiny_blocked_sel == c->sel_epoch && c->tiny_blocked_static == c->static_epoch);
         if (c->sel_all || small_sel) {
             c->sel_made = true;
             HIPCHK(c, c->plus.reserve((size_t)std::max<int64_t>(c->n, 1)));
@@ -3734,7 +3700,7 @@ int run_pass_enqueue(arp_ctx* c, double cutoff, double vdw_comp, int include_seq
         } else {
             CHK(enqueue_expansion(c, expand_radius));                                // I:342 (I:1384-1424)
         }
-        if (small_sel && !c->tiny_front) {
+        if (small_sel) {
             Prof p(c, SLOT_MARK);
             hipLaunchKernelGGL(k_expand_small, dim3(nblocks(c->n, 256, 1 << 22)), dim3(256), 0, c->stream, (int)c->n, c->xyz.p, c->sel_list.p,
                                (int)c->nsel, c->sel.p, expand_radius * expand_radius, c->plus.p, c->d_ctr + ctr_dev(C_STAT_MCAND));
@@ -3774,9 +3740,8 @@ int run_pass_wait(arp_ctx* c, int64_t counts[5]) {
         c->host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         ++c->host_passes;
         collect_events(c);
-        int again = any_overflow(true);
+        const int again = any_overflow(true);
         if (again < 0) return again;
-        if (c->h_ctr[C_SCRATCH1] != 0) { c->tiny_blocked = true; c->tiny_blocked_sel = c->sel_epoch; c->tiny_blocked_static = c->static_epoch; again = 1; }      // (k_tiny_front left without searching: too many atoms kept)
         if (!again) break;
         if (attempt == 2) FAIL(c, ARP_E_CAPACITY, "arp_run_launch: result buffers could not be sized");
         CHK(run_pass_enqueue(c, c->pending_cutoff, c->pending_comp, c->pending_seq_adj, c->pending_expand));   // a buffer was too small: once more

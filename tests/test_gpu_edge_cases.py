@@ -732,48 +732,3 @@ def test_sift_blocks_dealt_by_index_give_the_same_contacts():
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
     assert res['0'] == res['1'] and all(v[0]['atom_atom'] > 1000 for v in res['0'].values()), res
-
-
-@pytest.mark.gpu
-def test_small_selection_front_in_one_block_equals_the_three_launches():
-    """k_tiny_front (expansion + contact grid + neighbour search of a small selection in a small structure by ONE block) against the
-    three launches it replaces (ARP_TINY_FRONT=0): every bag, every id set and every counter — ligand, single residues, a selection whose
-    selection_plus is too large for the block (it must say so and the pass be repeated the long way), changing selections and
-    parameters on one context, the first pass after an upload."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ('import sys, json, hashlib, numpy as np; sys.path.insert(0, %r)\n'
-            'from arpeggio_amd import synth, _capi\n'
-            'out = {}\n'
-            'for pc in (synth.proteinlike(seed=1), synth.proteinlike(n_res=150, n_waters=60, seed=12), synth.config3(6000, seed=13)):\n'
-            '    c = _capi.Context(0); c.set_complex(pc)\n'
-            '    rid = np.asarray(pc.res_id)\n'
-            '    sels = {"res3": rid == 3, "res10_11": (rid == 10) | (rid == 11), "first40": np.arange(pc.n_atoms) < 40, "wide": rid %% 9 == 0, "res3again": rid == 3}\n'
-            '    if hasattr(pc, "res_seq"): sels["lig508"] = np.asarray(pc.res_seq)[rid] == 508\n'
-            '    for name, mask in sels.items():\n'
-            '        if not mask.any(): continue\n'
-            '        c.set_selection(mask.astype(np.uint8))\n'
-            '        for cutoff, comp, adj in ((5.0, 0.1, False), (4.0, 0.3, True)):\n'
-            '            cnt = c.run_launch(cutoff, comp, adj, 6.0)\n'
-            '            bags, _ = c.fetch_packed()\n'
-            '            h = hashlib.sha256()\n'
-            '            for bag in sorted(bags):\n'
-            '                for k in sorted(bags[bag]): h.update(np.ascontiguousarray(bags[bag][k]).tobytes())\n'
-            '            sets = c.make_selection_masks()\n'
-            '            for k in sorted(sets): h.update(np.ascontiguousarray(sets[k]).tobytes())\n'
-            '            st = c.stats()\n'
-            '            out["%%s:%%s:%%s" %% (pc.id, name, cutoff)] = [dict(cnt), h.hexdigest(), {k: int(v) for k, v in st.items()}]\n'
-            '    c.close()\n'
-            'print(json.dumps(out))\n') % root
-    res = {}
-    for mode in ('0', '1'):
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, ARP_TINY_FRONT=mode), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
-        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert set(res['0']) == set(res['1']) and len(res['0']) >= 20
-    for k in res['0']:
-        assert res['0'][k] == res['1'][k], (k, res['0'][k], res['1'][k])
-    assert any(v[2]['binned'] > 512 for v in res['0'].values()) and any(0 < v[2]['binned'] <= 512 for v in res['0'].values())
